@@ -1,0 +1,597 @@
+"""CPU oracle for the vi-hds hot path.  TEST INFRASTRUCTURE ONLY.
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import this
+file.  The product path (``vi-hds_amd/``) never does, and fails loudly when the HIP library is missing.
+
+What this is
+------------
+An op-by-op, eager-PyTorch (CPU, fp32) restatement of the reference's batched ODE-integration + ELBO
+path: one ``[B,S]`` tensor per quantity, a python time loop, autograd for the backward -- the same tensor
+program the reference executes, written as plain functions.  Every function cites the reference
+``file:line`` (relative to /root/reference) whose arithmetic (and operation *order*, which fixes fp32
+rounding) it follows.  It doubles as the timed ``cpu_baseline`` ("port") in bench.py.
+
+Pinning status (see tests/test_oracle_golden.py, tests/golden/*.npz, tests/golden/make_fixtures.py)
+--------------------------------------------------------------------------------------------------
+* PINNED against outputs of the reference itself run in the build container (fixtures committed with the
+  generating script): integrators ``modeuler`` / ``modeulerwhile``; models dr_constant, dr_constant_v2,
+  dr_constant_precisions, auto_constant, auto_constant_precisions, dr_blackbox, prpr_constant; observe;
+  constant and neural precisions; Gaussian observation log-prob; Normal/LogNormal/Constant sample, clip and
+  log-prob; IWAE loss; gradients w.r.t. theta, q(mu, log_prec) and decoder MLP weights.
+* PARITY UNPINNED: ``euler`` / ``midpoint`` / ``rk4``.  They live in the third-party dependency
+  ``torchdiffeq==0.1`` (requirements.txt:6; call site vihds/ode.py:79-81) which is neither vendored in
+  /root/reference nor installed here (no network).  Their tableaux below restate torchdiffeq 0.1's
+  fixed-grid solvers as published (grid = the supplied ``t``; ``midpoint``: y_mid = y + f(t,y)*dt/2,
+  dy = dt*f(t+dt/2, y_mid); ``rk4`` = the 3/8-rule "rk4_alt_step_func").  The only reference-anchored
+  check is the reference's own criterion (tests/test_ode_solvers.py:83-89): final state within 5 % CV of
+  the pinned ``modeuler`` result.
+* PARITY UNPINNED: relay_constant(_precisions), degrader_constant(_precisions).  The reference raises at
+  construction (relay_constant.py:17,201; degrader_constant.py:17), so no reference output can exist; the
+  functions here restate the reference's equations (relay_constant.py:28-134,220-251;
+  degrader_constant.py:28-143).
+"""
+import math
+from collections import OrderedDict
+
+import torch
+
+LOG2PI = math.log(2.0 * math.pi)
+
+# --------------------------------------------------------------------------------------------------
+# distributions (vihds/distributions.py)
+# --------------------------------------------------------------------------------------------------
+NORMAL, LOGNORMAL, CONSTANT = 0, 1, 2
+
+
+def dist_sample(kind, mu, prec, u):
+    """distributions.py:327-330 (Normal), :369-371 (LogNormal), :241-242 (Constant).
+    sigma = 1/sqrt(prec) is formed first (distributions.py:315), then mu + sigma*u."""
+    if kind == CONSTANT:
+        return torch.zeros_like(u) + mu
+    sigma = 1.0 / prec.sqrt()
+    x = mu + sigma * u
+    return x.exp() if kind == LOGNORMAL else x
+
+
+def dist_clip(kind, p_mu, p_prec, x, stddevs):
+    """distributions.py:332-336 / :377-381; bounds are plain numbers (``.data[0]``) => no grad through them.
+    The prior's sigma comes from TfNormal.__init__: sigma given -> prec = 1/sigma^2 (:292), else
+    sigma = 1/sqrt(prec) (:286)."""
+    if kind == CONSTANT:
+        return x
+    sigma = 1.0 / p_prec.sqrt()
+    lower = p_mu - stddevs * sigma
+    upper = p_mu + stddevs * sigma
+    if kind == LOGNORMAL:
+        lower, upper = lower.exp(), upper.exp()
+    return x.clamp(float(lower), float(upper))
+
+
+def normal_log_prob(mu, prec, x):
+    """distributions.py:338-345.  NB: the constant is -log(2*pi), not -0.5*log(2*pi)."""
+    return -LOG2PI + 0.5 * (prec + 1e-12).log() - 0.5 * prec * (mu - x).pow(2)
+
+
+def dist_log_prob(kind, mu, prec, x):
+    """distributions.py:338-345, :373-375, :245-246."""
+    if kind == CONSTANT:
+        return torch.zeros_like(x)
+    if kind == LOGNORMAL:
+        log_x = (x + 1e-12).log()
+        return normal_log_prob(mu, prec, log_x) - log_x
+    return normal_log_prob(mu, prec, x)
+
+
+def chained_log_prob(kinds, mus, precs, thetas):
+    """distributions.py:64-74: stack the per-parameter log-probs on a new last axis and sum it."""
+    lps = [dist_log_prob(k, m, p, x) for k, m, p, x in zip(kinds, mus, precs, thetas)]
+    return torch.stack(lps, -1).sum(-1)
+
+
+# --------------------------------------------------------------------------------------------------
+# integrators
+# --------------------------------------------------------------------------------------------------
+def modified_euler_integrate(func, x0, times):
+    """vihds/solvers.py:9-17: Heun with h FIXED to times[1]-times[0] but the true (t1,t2) passed to f."""
+    xs = [x0]
+    h = times[1] - times[0]
+    for k in range(len(times) - 1):
+        t1, t2 = times[k], times[k + 1]
+        f1 = func(t1, xs[-1])
+        f2 = func(t2, xs[-1] + h * f1)
+        xs.append(xs[-1] + 0.5 * h * (f1 + f2))
+    return torch.stack(xs)
+
+
+def modified_euler_while(func, x0, times):
+    """vihds/solvers.py:20-41: the same scheme with h = t2 - t1 per step."""
+    xs = [x0]
+    x = x0
+    for k in range(1, len(times)):
+        t1, t2 = times[k - 1], times[k]
+        h = t2 - t1
+        f1 = func(t1, x)
+        f2 = func(t2, x + h * f1)
+        x = x + 0.5 * h * (f1 + f2)
+        xs.append(x)
+    return torch.stack(xs)
+
+
+def _fixed_grid(step, func, x0, times):
+    """torchdiffeq==0.1 FixedGridODESolver.integrate with step_size=None: grid == times, y1 = y0 + dy,
+    outputs at the grid points.  [recalled; parity unpinned]"""
+    xs = [x0]
+    y = x0
+    for k in range(len(times) - 1):
+        t0, t1 = times[k], times[k + 1]
+        y = y + step(func, t0, t1 - t0, y)
+        xs.append(y)
+    return torch.stack(xs)
+
+
+def _euler_step(func, t, dt, y):
+    return dt * func(t, y)
+
+
+def _midpoint_step(func, t, dt, y):
+    y_mid = y + func(t, y) * dt / 2
+    return dt * func(t + dt / 2, y_mid)
+
+
+def _rk4_38_step(func, t, dt, y):
+    """torchdiffeq 0.1 rk_common.rk4_alt_step_func (3/8 rule)."""
+    k1 = func(t, y)
+    k2 = func(t + dt / 3, y + dt * k1 / 3)
+    k3 = func(t + dt * 2 / 3, y + dt * (k1 / -3 + k2))
+    k4 = func(t + dt, y + dt * (k1 - k2 + k3))
+    return (k1 + 3 * k2 + 3 * k3 + k4) * (dt / 8)
+
+
+SOLVERS = {
+    "modeuler": modified_euler_integrate,
+    "modeulerwhile": modified_euler_while,
+    "euler": lambda f, x0, t: _fixed_grid(_euler_step, f, x0, t),
+    "midpoint": lambda f, x0, t: _fixed_grid(_midpoint_step, f, x0, t),
+    "rk4": lambda f, x0, t: _fixed_grid(_rk4_38_step, f, x0, t),
+}
+
+
+def simulate(rhs, x0, times, solver):
+    """vihds/ode.py:66-82: integrate, then [T,B,S,N] -> [B,S,N,T]."""
+    sol = SOLVERS[solver](rhs, x0, times)
+    return sol.permute(1, 2, 3, 0)
+
+
+# --------------------------------------------------------------------------------------------------
+# neural pieces
+# --------------------------------------------------------------------------------------------------
+def neural_precisions_rhs(w, t, state, constants, n_out=4, act="tanh"):
+    """vihds/precisions.py:76-87 with the constructor's wiring (:55-74).
+
+    ``w`` holds 'prod_w','prod_b','degr_w','degr_b' and, when a hidden layer exists, 'hid_w','hid_b'.
+    n_hidden < 1: sigmoid(W act(x) + b) -- the activation is applied to the INPUT (:60-61).
+    n_hidden >= 1: sigmoid(W act(W_h x + b_h) + b), hidden layer shared by prod and degr (:73-74)."""
+    actf = torch.tanh if act == "tanh" else torch.relu
+    B, S = state.shape[0], state.shape[1]
+    xs = state[:, :, :-n_out]
+    var = state[:, :, -n_out:]
+    t_exp = t.repeat([B, S, 1])
+    feats = [t_exp, xs] + ([constants] if constants is not None else [])
+    x = torch.cat(feats, dim=2)
+    if "hid_w" in w:
+        h = actf(torch.nn.functional.linear(x, w["hid_w"], w["hid_b"]))
+    else:
+        h = actf(x)
+    xa = torch.sigmoid(torch.nn.functional.linear(h, w["prod_w"], w["prod_b"]))
+    xd = torch.sigmoid(torch.nn.functional.linear(h, w["degr_w"], w["degr_b"]))
+    return xa - xd * var
+
+
+def neural_states_rhs(w, x, constants):
+    """vihds/ode.py:134-138."""
+    aug = torch.cat([x, constants], dim=2)
+    hidden = torch.relu(torch.nn.functional.linear(aug, w["hid_w"], w["hid_b"]))
+    prod = torch.sigmoid(torch.nn.functional.linear(hidden, w["prod_w"], w["prod_b"]))
+    degr = torch.sigmoid(torch.nn.functional.linear(hidden, w["degr_w"], w["degr_b"]))
+    return prod - degr * x
+
+
+def device_conditioner(weight, ones, relevance, dev_1hot, is_default):
+    """vihds/ode.py:43-58 + DeviceConditioner :99-116 (Linear(D,1,no bias) -> ReLU).
+    ``weight`` [1,D] is supplied by the caller (the reference re-draws it N(2,1.5) on every call)."""
+    B, S = ones.shape
+    flat = ones.reshape(B * S, 1)
+    dev_rel = dev_1hot * relevance
+    cond = torch.relu(torch.nn.functional.linear(dev_rel, weight)).repeat([S, 1])
+    out = flat * (1.0 + cond) if is_default else flat * cond
+    return out.reshape(B, S)
+
+
+# --------------------------------------------------------------------------------------------------
+# model right-hand sides.  Each ``make_<model>`` returns (rhs(t, state), x0[B,S,N]).
+# theta: dict name -> [B,S] tensor.  cond: [B,C] (= log(1+c), datasets.py:87).
+# --------------------------------------------------------------------------------------------------
+def _tile(c, S):
+    # dr_constant.py:27-29: c.repeat([S,1]).transpose(0,1) -> [B,S]
+    return torch.transpose(c.repeat([S, 1]), 0, 1)
+
+
+def _treatments(cond, S):
+    tt = torch.clamp(torch.exp(cond) - 1.0, 1e-12, 1e6)
+    return [_tile(c, S) for c in torch.unbind(tt, dim=1)]
+
+
+def _hill_fracs(th, c6, c12):
+    """dr_constant.py:58-68 (identical in relay_constant.py:78-87, degrader_constant.py:90-99)."""
+    nR = torch.clamp(th["nR"], 0.5, 3.0)
+    nS = torch.clamp(th["nS"], 0.5, 3.0)
+    KR6 = torch.clamp(th["KR6"], 1e-12, 1e0)
+    KR12 = torch.clamp(th["KR12"], 1e-12, 1e0)
+    KS6 = torch.clamp(th["KS6"], 1e-12, 1e0)
+    KS12 = torch.clamp(th["KS12"], 1e-12, 1e0)
+    fR = ((KR6 * c6).pow(nR) + (KR12 * c12).pow(nR)) / (1.0 + KR6 * c6 + KR12 * c12).pow(nR)
+    fS = ((KS6 * c6).pow(nS) + (KS12 * c12).pow(nS)) / (1.0 + KS6 * c6 + KS12 * c12).pow(nS)
+    return fR, fS
+
+
+def _growth(th):
+    return torch.clamp(th["r"], 0.0, 4.0), torch.clamp(th["K"], 0.0, 4.0)
+
+
+def _promoters(th, luxR, lasR, fR, fS):
+    """dr_constant.py:86-95."""
+    bR = luxR * luxR * fR
+    bS = lasR * lasR * fS
+    P76 = (th["e76"] + th["KGR_76"] * bR + th["KGS_76"] * bS) / (1.0 + th["KGR_76"] * bR + th["KGS_76"] * bS)
+    P81 = (th["e81"] + th["KGR_81"] * bR + th["KGS_81"] * bS) / (1.0 + th["KGR_81"] * bR + th["KGS_81"] * bS)
+    return P76, P81
+
+
+def _with_precisions(core_rhs, n_core, prec_w, act="tanh"):
+    if prec_w is None:
+        return core_rhs
+
+    def rhs(t, state):
+        dX = core_rhs(t, state)
+        dV = neural_precisions_rhs(prec_w, t, state, None, act=act)
+        return torch.cat([dX, dV], dim=2)
+
+    return rhs
+
+
+def make_dr_constant(th, cond, version=1, prec_w=None):
+    """models/dr_constant.py:14-112 (RHS), :133-150 / :176-196 (x0)."""
+    B, S = th["r"].shape
+    c6, c12 = _treatments(cond, S)
+    r, K = _growth(th)
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    dyfp = torch.clamp(th["dyfp"], 1e-12, 2.0)
+    dcfp = torch.clamp(th["dcfp"], 1e-12, 2.0)
+    dR = torch.clamp(th["dR"], 1e-12, 5.0)
+    dS = torch.clamp(th["dS"], 1e-12, 5.0)
+    if version == 1:
+        fR, fS = _hill_fracs(th, c6, c12)
+    else:  # dr_constant.py:69-73
+        nR = torch.clamp(th["nR"], 0.5, 3.0)
+        nS = torch.clamp(th["nS"], 0.5, 3.0)
+        eS6 = torch.clamp(th["eS6"], 1e-12, 1e0)
+        eR12 = torch.clamp(th["eR12"], 1e-12, 1e0)
+        fR = c6.pow(nR) + (eR12 * c12).pow(nR)
+        fS = (eS6 * c6).pow(nS) + c12.pow(nS)
+    rc, tlag = th["rc"], th["tlag"]
+
+    def core(t, state):
+        x, rfp, yfp, cfp, f530, f480, luxR, lasR = torch.unbind(state[:, :, :8], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        P76, P81 = _promoters(th, luxR, lasR, fR, fS)
+        d = [
+            gamma * x,
+            rc - (gamma + drfp) * rfp,
+            rc * th["aYFP"] * P81 - (gamma + dyfp) * yfp,
+            rc * th["aCFP"] * P76 - (gamma + dcfp) * cfp,
+            rc * th["a530"] - gamma * f530,
+            rc * th["a480"] - gamma * f480,
+            rc * th["aR"] - (gamma + dR) * luxR,
+            rc * th["aS"] - (gamma + dS) * lasR,
+        ]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [th["init_x"], th["init_rfp"], th["init_yfp"], th["init_cfp"], zero, zero, th["init_luxR"], th["init_lasR"]]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 8, prec_w), torch.stack(init, dim=2)
+
+
+def make_auto_constant(th, cond, prec_w=None):
+    """models/auto_constant.py:12-63 (RHS), :73-78 / :110-126 (x0)."""
+    B, S = th["r"].shape
+    r, K = _growth(th)
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    rc, tlag = th["rc"], th["tlag"]
+
+    def core(t, state):
+        x, rfp, f530, f480 = torch.unbind(state[:, :, :4], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        d = [gamma * x, rc - (gamma + drfp) * rfp, rc * th["a530"] - gamma * f530, rc * th["a480"] - gamma * f480]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [th["init_x"], th["init_rfp"], zero, zero]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 4, prec_w), torch.stack(init, dim=2)
+
+
+def make_prpr_constant(th, cond, prec_w=None):
+    """models/prpr_constant.py:13-69 (RHS), x0 :79-85."""
+    B, S = th["r"].shape
+    r, K = _growth(th)
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    dyfp = torch.clamp(th["dyfp"], 1e-12, 2.0)
+    dcfp = torch.clamp(th["dcfp"], 1e-12, 2.0)
+    rc, tlag = th["rc"], th["tlag"]
+
+    def core(t, state):
+        x, rfp, yfp, cfp, f530, f480 = torch.unbind(state[:, :, :6], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        d = [
+            gamma * x,
+            rc - (gamma + drfp) * rfp,
+            rc * th["aYFP_PR"] - (gamma + dyfp) * yfp,
+            rc * th["aCFP_PR"] - (gamma + dcfp) * cfp,
+            rc * th["a530"] - gamma * f530,
+            rc * th["a480"] - gamma * f480,
+        ]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [th["init_x"], th["init_rfp"], th["init_yfp"], th["init_cfp"], zero, zero]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 6, prec_w), torch.stack(init, dim=2)
+
+
+def make_relay_constant(th, cond, prec_w=None):
+    """models/relay_constant.py:28-134 (RHS), :151-180 / :220-251 (x0).  PARITY UNPINNED (reference raises)."""
+    B, S = th["r"].shape
+    c6, c12 = _treatments(cond, S)
+    r, K = _growth(th)
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    dyfp = torch.clamp(th["dyfp"], 1e-12, 2.0)
+    dcfp = torch.clamp(th["dcfp"], 1e-12, 2.0)
+    dR = torch.clamp(th["dR"], 1e-12, 5.0)
+    dS = torch.clamp(th["dS"], 1e-12, 5.0)
+    dlasI = torch.clamp(th["dlasI"], 1e-12, 5.0)
+    dluxI = torch.clamp(th["dluxI"], 1e-12, 5.0)
+    fR, fS = _hill_fracs(th, c6, c12)
+    rc, tlag = th["rc"], th["tlag"]
+
+    def core(t, state):
+        x, rfp, yfp, cfp, f530, f480, luxR, lasR, luxI, lasI = torch.unbind(state[:, :, :10], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        P76, P81 = _promoters(th, luxR, lasR, fR, fS)
+        d = [
+            gamma * x,
+            rc - (gamma + drfp) * rfp,
+            rc * th["aYFP"] * P81 - (gamma + dyfp) * yfp,
+            rc * th["aCFP"] * P76 - (gamma + dcfp) * cfp,
+            rc * th["a530"] - gamma * f530,
+            rc * th["a480"] - gamma * f480,
+            rc * th["aR"] - (gamma + dR) * luxR,
+            rc * th["aS"] - (gamma + dS) * lasR,
+            rc * P81 - (gamma + dluxI) * luxI,
+            rc * P76 - (gamma + dlasI) * lasI,
+            (th["KC6"] * rc * x * luxI) / (1.0 + luxI / th["Klux"]),
+            (th["KC12"] * rc * x * lasI) / (1.0 + lasI / th["Klas"]),
+        ]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [
+        th["init_x"], th["init_rfp"], th["init_yfp"], th["init_cfp"], zero, zero, th["init_luxR"], th["init_lasR"],
+        th["init_luxI"], th["init_lasI"], c6, c12,
+    ]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 12, prec_w), torch.stack(init, dim=2)
+
+
+def make_degrader_constant(th, cond, prec_w=None):
+    """models/degrader_constant.py:28-143 (RHS), :167-190 (x0).  PARITY UNPINNED (reference raises)."""
+    B, S = th["r"].shape
+    c6, c12, ara = _treatments(cond, S)
+    r, K = _growth(th)
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    dyfp = torch.clamp(th["dyfp"], 1e-12, 2.0)
+    dcfp = torch.clamp(th["dcfp"], 1e-12, 2.0)
+    dR = torch.clamp(th["dR"], 1e-12, 5.0)
+    dS = torch.clamp(th["dS"], 1e-12, 5.0)
+    nA = torch.clamp(th["nA"], 0.5, 3.0)
+    PBAD = (ara.pow(nA) + (th["eA"] * th["KAra"].pow(nA))) / (ara.pow(nA) + th["KAra"].pow(nA))
+    rC6 = th["dA6"] * c6
+    rC12 = th["dA12"] * c12
+    fR, fS = _hill_fracs(th, c6, c12)
+    rc, tlag = th["rc"], th["tlag"]
+
+    def core(t, state):
+        x, rfp, yfp, cfp, f530, f480, luxR, lasR, aiiA = torch.unbind(state[:, :, :9], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        P76, P81 = _promoters(th, luxR, lasR, fR, fS)
+        d = [
+            gamma * x,
+            rc - (gamma + drfp) * rfp,
+            rc * th["aYFP"] * P81 - (gamma + dyfp) * yfp,
+            rc * th["aCFP"] * P76 - (gamma + dcfp) * cfp,
+            rc * th["a530"] - gamma * f530,
+            rc * th["a480"] - gamma * f480,
+            rc * th["aR"] - (gamma + dR) * luxR,
+            rc * th["aS"] - (gamma + dS) * lasR,
+            rc * th["aI"] * PBAD - (th["daiiA"] + (gamma * aiiA)),
+            x * rC6 * aiiA,
+            x * rC12 * aiiA,
+        ]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [
+        th["init_x"], th["init_rfp"], th["init_yfp"], th["init_cfp"], zero, zero, th["init_luxR"], th["init_lasR"],
+        th["init_aiiA"], c6, c12,
+    ]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 11, prec_w), torch.stack(init, dim=2)
+
+
+def make_dr_blackbox(th, cond, dev_1hot, states_w, prec_w, n_x, n_y, n_z, n_latent_species,
+                     init_latent_species=0.001, init_prec=0.00001):
+    """models/dr_blackbox.py:16-58 (RHS), :98-103 (x0).  ``th`` already holds the device-offset y's
+    (condition_theta, :86-96)."""
+    B, S = th["init_x"].shape
+    devices = dev_1hot.unsqueeze(1).repeat([1, S, 1])
+    treatments_rep = cond.unsqueeze(1).repeat([1, S, 1])
+    lat = [th["z%d" % (i + 1)] for i in range(n_z)] + [th["x%d" % (i + 1)] for i in range(n_x)]
+    latents = torch.stack(lat, dim=-1)
+    if n_y > 0:
+        Y = torch.stack([th["y%d" % (i + 1)] for i in range(n_y)], dim=-1)
+        constants = torch.cat([latents, Y, treatments_rep, devices], dim=2)
+    else:
+        constants = torch.cat([latents, treatments_rep, devices], dim=2)
+
+    def rhs(t, state):
+        dx = neural_states_rhs(states_w, state[:, :, :-4], constants)
+        dv = neural_precisions_rhs(prec_w, t, state, constants, act="relu")
+        return torch.cat([dx, dv], dim=2)
+
+    x0 = torch.stack([th["init_x"], th["init_rfp"], th["init_yfp"], th["init_cfp"]], dim=2)
+    h0 = torch.full([B, S, n_latent_species], init_latent_species)
+    p0 = torch.full([B, S, 4], init_prec)
+    return rhs, torch.cat([x0, h0, p0], dim=2)
+
+
+# --------------------------------------------------------------------------------------------------
+# observation model and ELBO
+# --------------------------------------------------------------------------------------------------
+def observe_default(xs):
+    """vihds/ode.py:84-93: [OD, OD*RFP, OD*(YFP+F530), OD*(CFP+F480)] -> [B,S,4,T]."""
+    xp = [xs[:, :, 0, :], xs[:, :, 0, :] * xs[:, :, 1, :], xs[:, :, 0, :] * (xs[:, :, 2, :] + xs[:, :, 4, :]),
+          xs[:, :, 0, :] * (xs[:, :, 3, :] + xs[:, :, 5, :])]
+    return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
+
+
+def observe_direct(xs):
+    """models/dr_blackbox.py:112-121, models/auto_constant.py:89-97: [OD, OD*s1, OD*s2, OD*s3]."""
+    xp = [xs[:, :, 0, :], xs[:, :, 0, :] * xs[:, :, 1, :], xs[:, :, 0, :] * xs[:, :, 2, :],
+          xs[:, :, 0, :] * xs[:, :, 3, :]]
+    return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
+
+
+def expand_constant_precisions(th, n_times, names=("prec_x", "prec_rfp", "prec_yfp", "prec_cfp")):
+    """vihds/precisions.py:31-35."""
+    p = torch.stack([th[v] for v in names], dim=-1)
+    return torch.unsqueeze(p, 3).repeat([1, 1, 1, n_times])
+
+
+def split_neural_precisions(sol, n_out=4):
+    """vihds/precisions.py:89-94 (inverse=False)."""
+    return sol[:, :, :-n_out, :], sol[:, :, -n_out:, :]
+
+
+def log_prob_observations(x_predict, x_obs, precisions):
+    """vihds/training.py:24-33 + :41-44; sum over time -> [B,S,4]."""
+    x_obs_ = torch.unsqueeze(x_obs, 1)
+    lp = -0.5 * (math.log(2.0 * math.pi) - precisions.log() + precisions * (x_predict - x_obs_).pow(2))
+    return torch.sum(lp, 3)
+
+
+def iwae_loss(log_p_by_species, log_p_theta, log_q_theta):
+    """vihds/training.py:135-149: returns the value the reference stores under 'elbo' (= -ELBO)."""
+    log_p_obs = log_p_by_species.sum(dim=2)
+    n_iwae = log_p_obs.shape[1]
+    log_w = log_p_obs + log_p_theta - log_q_theta
+    lse = log_w.logsumexp(dim=1, keepdim=True)
+    return -(lse - math.log(n_iwae)).mean(), log_w
+
+
+def importance_weighted_summaries(log_w, x_predict, x_states, precisions):
+    """vihds/utils.py:79-99 (Results.init), in torch instead of host numpy."""
+    w = (log_w - log_w.logsumexp(dim=1, keepdim=True)).exp()[:, :, None, None]
+    mu = (w * x_predict).sum(1)
+    std = ((w * (x_predict ** 2 + 1.0 / precisions)).sum(1) - mu ** 2).sqrt()
+    states = (w * x_states).sum(1)
+    var = (w / precisions).sum(1)
+    return mu, std, states, var
+
+
+# --------------------------------------------------------------------------------------------------
+# drivers used by tests / smoke / bench cpu_baseline
+# --------------------------------------------------------------------------------------------------
+MODEL_TABLE = {
+    # model key (models/__init__.py:19-35) -> (maker, observe, neural_precisions?)
+    "dr_constant": (lambda th, c, **k: make_dr_constant(th, c, 1, **k), observe_default, False),
+    "dr_constant_v2": (lambda th, c, **k: make_dr_constant(th, c, 2, **k), observe_default, False),
+    "dr_constant_precisions": (lambda th, c, **k: make_dr_constant(th, c, 1, **k), observe_default, True),
+    "dr_constant_precisions_v2": (lambda th, c, **k: make_dr_constant(th, c, 2, **k), observe_default, True),
+    "auto_constant": (make_auto_constant, observe_direct, False),
+    "auto_constant_precisions": (make_auto_constant, observe_direct, True),
+    "prpr_constant": (make_prpr_constant, observe_default, False),
+    "prpr_constant_precisions": (make_prpr_constant, observe_default, True),
+    "relay_constant": (make_relay_constant, observe_default, False),
+    "relay_constant_precisions": (make_relay_constant, observe_default, True),
+    "degrader_constant": (make_degrader_constant, observe_default, False),
+    "degrader_constant_precisions": (make_degrader_constant, observe_default, True),
+}
+
+
+def decode(model, th, cond, times, solver, prec_w=None, blackbox=None):
+    """Decoder.forward (vihds/decoders.py:28-45) after condition_theta: simulate -> expand_precisions ->
+    observe.  Returns (x_states, x_predict, precisions)."""
+    if model == "dr_blackbox":
+        rhs, x0 = make_dr_blackbox(th, cond, **blackbox)
+        sol = simulate(rhs, x0, times, solver)
+        xs, prec = split_neural_precisions(sol)
+        return xs, observe_direct(xs), prec
+    maker, observe, neural = MODEL_TABLE[model]
+    if neural:
+        rhs, x0 = maker(th, cond, prec_w=prec_w)
+        sol = simulate(rhs, x0, times, solver)
+        xs, prec = split_neural_precisions(sol)
+    else:
+        rhs, x0 = maker(th, cond)
+        sol = simulate(rhs, x0, times, solver)
+        xs, prec = sol, expand_constant_precisions(th, len(times))
+    return xs, observe(xs), prec
+
+
+def sample_clip_theta(names, kinds, q_mu, q_prec, p_mu, p_prec, u, stddevs=4):
+    """ChainedDistribution.sample (distributions.py:119-142) then p.clip (vae.py:34; distributions.py:76-85).
+    q_mu/q_prec: per-parameter tensors broadcastable against u[:,:,i] ([B,1] or [1])."""
+    th = OrderedDict()
+    for i, n in enumerate(names):
+        x = dist_sample(kinds[i], q_mu[i], q_prec[i], u[:, :, i])
+        th[n] = dist_clip(kinds[i], p_mu[i], p_prec[i], x, stddevs)
+    return th
+
+
+def elbo_from_theta(model, names, kinds, th, q_mu, q_prec, p_mu, p_prec, cond, times, obs, solver,
+                    prec_w=None, blackbox=None):
+    """BaseVAE.forward tail + Training.cost (vae.py:35; training.py:127-149) for a given clipped theta.
+    Only the parameters named in ``names`` enter log q / log p (distributions.py:64-74): aR/aS do not."""
+    xs, xp, prec = decode(model, th, cond, times, solver, prec_w=prec_w, blackbox=blackbox)
+    lpo = log_prob_observations(xp, obs, prec)
+    vals = [th[n] for n in names]
+    log_q = chained_log_prob(kinds, q_mu, q_prec, vals)
+    log_p = chained_log_prob(kinds, p_mu, p_prec, vals)
+    loss, log_w = iwae_loss(lpo, log_p, log_q)
+    return dict(loss=loss, log_w=log_w, log_q=log_q, log_p=log_p, log_p_by_species=lpo, x_states=xs, x_predict=xp,
+                precisions=prec)

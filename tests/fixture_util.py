@@ -1,0 +1,108 @@
+"""Shared helpers for tests: load a golden fixture (tests/golden/*.npz, produced by the reference via
+tests/golden/make_fixtures.py) into the argument shapes the oracle and the HIP path take."""
+import json
+import os
+from collections import OrderedDict
+
+import numpy as np
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+ALL_FIXTURES = [
+    "dr_constant_one_modeuler",
+    "dr_constant_one_s5_modeulerwhile",
+    "dr_constant_icml_tiny_modeuler",
+    "dr_constant_icml_tiny_modeulerwhile",
+    "dr_constant_icml_full_modeuler",
+    "dr_constant_v2_tiny_modeuler",
+    "auto_constant_tiny_modeuler",
+    "dr_constant_precisions_tiny_modeuler",
+    "auto_constant_precisions_tiny_modeuler",
+    "dr_blackbox_icml_tiny_modeuler",
+    "prpr_constant_tiny_modeuler",
+]
+
+
+class Fixture:
+    def __init__(self, name):
+        self.name = name
+        self.z = np.load(os.path.join(GOLDEN, name + ".npz"))
+        self.cfg = json.loads(str(self.z["config_json"]))
+        self.model = self.cfg["model"]
+        self.solver = self.cfg["solver"]
+        self.names = [str(n) for n in self.z["theta_names"]]
+        self.extra_names = [str(n) for n in self.z["extra_names"]]
+        self.kinds = [int(k) for k in self.z["kind"]]
+
+    def t(self, key, device="cpu", dtype=torch.float32):
+        return torch.tensor(np.asarray(self.z[key]), dtype=dtype, device=device)
+
+    @property
+    def B(self):
+        return self.z["theta"].shape[1]
+
+    @property
+    def S(self):
+        return self.z["theta"].shape[2]
+
+    def theta_dict(self, requires_grad=False, device="cpu"):
+        """Clipped theta as the decoder saw it (+ aR/aS from condition_theta), as leaf tensors."""
+        th = OrderedDict()
+        arr = self.t("theta", device)
+        for i, n in enumerate(self.names):
+            th[n] = arr[i].clone().requires_grad_(requires_grad)
+        if self.extra_names:
+            ex = self.t("extra_theta", device)
+            for i, n in enumerate(self.extra_names):
+                th[n] = ex[i].clone()
+        return th
+
+    def q_params(self, device="cpu"):
+        """Per-parameter (mu, prec) of q as [B,1] tensors (globals were broadcast over B by the fixture)."""
+        qm = self.t("q_mu", device)
+        qp = self.t("q_prec", device)
+        return [qm[i][:, None] for i in range(len(self.names))], [qp[i][:, None] for i in range(len(self.names))]
+
+    def p_params(self, device="cpu"):
+        pm = self.t("p_mu", device)
+        pp = self.t("p_prec", device)
+        return [pm[i] for i in range(len(self.names))], [pp[i] for i in range(len(self.names))]
+
+    def decoder_weights(self, device="cpu"):
+        """Neural-precision / neural-state weights in the oracle's naming."""
+        d = {k[len("decoder_param/"):]: self.t(k, device) for k in self.z.files if k.startswith("decoder_param/")}
+        prec_w = None
+        if "ode_model.precisions.prec_production.weight" in d:
+            prec_w = {
+                "prod_w": d["ode_model.precisions.prec_production.weight"],
+                "prod_b": d["ode_model.precisions.prec_production.bias"],
+                "degr_w": d["ode_model.precisions.prec_degradation.weight"],
+                "degr_b": d["ode_model.precisions.prec_degradation.bias"],
+            }
+            if "ode_model.precisions.prec_hidden.weight" in d:
+                prec_w["hid_w"] = d["ode_model.precisions.prec_hidden.weight"]
+                prec_w["hid_b"] = d["ode_model.precisions.prec_hidden.bias"]
+        states_w = None
+        if "ode_model.neural_states.states_hidden.weight" in d:
+            states_w = {
+                "hid_w": d["ode_model.neural_states.states_hidden.weight"],
+                "hid_b": d["ode_model.neural_states.states_hidden.bias"],
+                "prod_w": d["ode_model.neural_states.states_production.weight"],
+                "prod_b": d["ode_model.neural_states.states_production.bias"],
+                "degr_w": d["ode_model.neural_states.states_degradation.weight"],
+                "degr_b": d["ode_model.neural_states.states_degradation.bias"],
+            }
+        offset = None
+        if "ode_model.offset_layer.weight" in d:
+            offset = (d["ode_model.offset_layer.weight"], d["ode_model.offset_layer.bias"])
+        return prec_w, states_w, offset
+
+    def decoder_weight_grads(self):
+        return {k[len("decoder_grad/"):]: self.t(k) for k in self.z.files if k.startswith("decoder_grad/")}
+
+
+def rel_err(a, b):
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
