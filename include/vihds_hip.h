@@ -1,0 +1,150 @@
+/*
+ * vihds_hip.h -- C ABI of the MI355X (gfx950) implementation of vi-hds's batched ODE-integration + ELBO path.
+ *
+ * This is the drop-in boundary.  The reference is pure Python/PyTorch, so the binding
+ * a maintainer adds is a ctypes stub; every entry point takes plain pointers and sizes, is
+ * asynchronous on the given HIP stream, allocates nothing, keeps no global state besides a thread-local
+ * error string, and returns 0 on success or a negative code (VIHDS_E_*).
+ *
+ * Memory layout (all fp32, all buffers caller-owned device memory):
+ *   n_traj = B*S trajectories, flat index i = b*S + s (IWAE sample fastest).
+ *   theta   [n_rows][B][S]   structure-of-arrays: one row per named parameter; `slot_row` maps the kernel's
+ *                            fixed per-model slot order (vihds_model_slot_name) to rows of this buffer.
+ *   cond    [B][C]           log(1+c) treatments (vihds/datasets.py:87)
+ *   dev1hot [B][D]           device one-hot blocks (only dr_blackbox reads it)
+ *   times   [T]              observation time grid
+ *   obs     [B][4][T]        observations, the reference's own layout (vihds/training.py:47-52)
+ *   traj    [T][N][B][S]     ODE solution.  The reference returns sol.permute(1,2,3,0) -- a non-contiguous
+ *                            [B,S,N,T] view of a [T,B,S,N] stack (vihds/ode.py:82); the host wraps this buffer
+ *                            in the equivalent strided view.
+ *   xpred   [T][4][B][S]     observed signals (vihds/ode.py:84-93)
+ *   logp    [4][B][S]        sum over time of the Gaussian observation log-density (vihds/training.py:24-44)
+ */
+#ifndef VIHDS_HIP_H
+#define VIHDS_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VIHDS_ABI_VERSION 1
+
+/* error codes */
+#define VIHDS_OK 0
+#define VIHDS_E_BADARG (-1)   /* null pointer / bad size / unknown enum */
+#define VIHDS_E_UNSUPPORTED (-2)
+#define VIHDS_E_HIP (-3)      /* a HIP runtime call failed; see vihds_last_error() */
+
+/* models: keys of models.LOOKUP (reference models/__init__.py:19-35) */
+enum vihds_model {
+  VIHDS_MODEL_DR_CONSTANT = 0,                /* models/dr_constant.py:115  (version 1) */
+  VIHDS_MODEL_DR_CONSTANT_V2 = 1,             /* models/dr_constant.py:163  */
+  VIHDS_MODEL_AUTO_CONSTANT = 2,              /* models/auto_constant.py:66 */
+  VIHDS_MODEL_PRPR_CONSTANT = 3,              /* models/prpr_constant.py:72 */
+  VIHDS_MODEL_RELAY_CONSTANT = 4,             /* models/relay_constant.py:137 */
+  VIHDS_MODEL_DEGRADER_CONSTANT = 5,          /* models/degrader_constant.py:146 */
+  VIHDS_MODEL_DR_CONSTANT_PRECISIONS = 6,     /* models/dr_constant.py:169 */
+  VIHDS_MODEL_DR_CONSTANT_PRECISIONS_V2 = 7,  /* models/dr_constant.py:212 */
+  VIHDS_MODEL_AUTO_CONSTANT_PRECISIONS = 8,   /* models/auto_constant.py:100 */
+  VIHDS_MODEL_PRPR_CONSTANT_PRECISIONS = 9,   /* models/prpr_constant.py:101 */
+  VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS = 10, /* models/relay_constant.py:199 */
+  VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS = 11, /* models/degrader_constant.py:195 */
+  VIHDS_MODEL_DR_BLACKBOX = 12,               /* models/dr_blackbox.py:61 */
+  VIHDS_MODEL_COUNT = 13
+};
+
+/* solvers: values of params.solver (reference vihds/ode.py:75-81, vihds/config.py:59) */
+enum vihds_solver {
+  VIHDS_SOLVER_MODEULER = 0,      /* vihds/solvers.py:9-17   h = times[1]-times[0] for every step */
+  VIHDS_SOLVER_MODEULERWHILE = 1, /* vihds/solvers.py:20-41  h = t2-t1 */
+  VIHDS_SOLVER_EULER = 2,         /* torchdiffeq==0.1 fixed-grid 'euler'    (restated; parity unpinned) */
+  VIHDS_SOLVER_MIDPOINT = 3,      /* torchdiffeq==0.1 fixed-grid 'midpoint' (restated; parity unpinned) */
+  VIHDS_SOLVER_RK4 = 4,           /* torchdiffeq==0.1 fixed-grid 'rk4' = 3/8 rule (restated; parity unpinned) */
+  VIHDS_SOLVER_COUNT = 5
+};
+
+#define VIHDS_MAX_SLOTS 64
+
+/* One decoder problem: replaces the argument bundle of OdeModel.simulate + expand_precisions + observe +
+ * log_prob_observations (vihds/decoders.py:28-45, vihds/training.py:24-33). */
+typedef struct vihds_ode_problem {
+  int model;    /* enum vihds_model */
+  int solver;   /* enum vihds_solver */
+  int B, S, T;  /* data rows, IWAE samples per row, time points */
+  int C, D;     /* #conditions (cond row length), device_depth (dev1hot row length) */
+  int n_rows;   /* rows of the theta / g_theta buffers */
+  int slot_row[VIHDS_MAX_SLOTS]; /* kernel slot -> theta row; must be set for every slot of the model */
+  /* sizes of the neural blocks (0 when the model has none); weights buffer layout in DESIGN.md */
+  int n_hidden_prec;   /* params.n_hidden_decoder_precisions (vihds/precisions.py:55) */
+  int n_hidden_states; /* params.n_hidden_decoder (dr_blackbox only) */
+  int n_latent_states; /* params.n_latent_species (dr_blackbox only) */
+  int n_const;         /* dr_blackbox: length of the time-invariant feature vector (n_z+n_x+n_y+C+D) */
+  float init_latent;   /* dr_blackbox.py:101 */
+  float init_prec;     /* dr_blackbox.py:102 */
+} vihds_ode_problem;
+
+int vihds_abi_version(void);
+const char* vihds_last_error(void);
+
+/* Introspection so the host maps YAML parameter names to kernel slots without duplicating tables. */
+int vihds_model_n_states(int model);      /* ODE state size N (incl. 4 precision states for *_precisions) */
+int vihds_model_n_species(int model);     /* states handed to observe(): N minus neural precision states */
+int vihds_model_n_slots(int model);       /* number of theta slots the kernel reads */
+const char* vihds_model_slot_name(int model, int slot); /* reference parameter name of a slot */
+int vihds_model_n_weights(const vihds_ode_problem* p);  /* floats in the `weights` buffer (0 if none) */
+
+/* Forward: integrate, observe, and reduce the observation log-likelihood over time.
+ * traj / xpred / logp may each be NULL to skip that output.  `weights` is NULL for white-box models. */
+int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                  const float* times, const float* obs, const float* weights, float* traj, float* xpred,
+                  float* logp, void* stream);
+
+/* Backward (discrete adjoint of the chosen scheme = what autograd computes in the reference).
+ * Upstream gradients g_traj [T][N][B][S], g_xpred [T][4][B][S], g_logp [4][B][S] may each be NULL (= zero).
+ * Writes g_theta [n_rows][B][S] for every slot row (other rows untouched: pre-zero the buffer) and ADDS into
+ * g_weights (pre-zero it). */
+int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                  const float* times, const float* obs, const float* weights, const float* traj,
+                  const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
+                  float* g_weights, void* stream);
+
+/* theta side: ChainedDistribution.sample + p.clip + q.log_prob + p.log_prob
+ * (vihds/distributions.py:64-85,119-142,327-381; vihds/vae.py:31-34) over all P parameters at once.
+ *   kind   [P]      0 Normal, 1 LogNormal, 2 Constant
+ *   q_mu   [P][B], q_prec [P][B]   (global / constant parameters broadcast over B by the caller)
+ *   p_mu   [P],    p_prec [P]
+ *   clip_lo[P],    clip_hi[P]      p.clip bounds: mu -/+ stddevs*sigma, exp'd for LogNormal
+ *                                  (distributions.py:332-336,377-381); ignored for Constant
+ *   u      [B][S][P]               reference layout (vihds/vae.py:22-24)
+ *   theta  [n_rows>=P][B][S] rows 0..P-1 written;  log_q, log_p [B][S] */
+int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
+                    const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
+                    const float* u, float* theta, float* log_q, float* log_p, void* stream);
+/* g_theta [P..][B][S], g_log_q, g_log_p [B][S] (each may be NULL) -> g_q_mu, g_q_prec [P][B] (overwritten) */
+int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
+                    const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
+                    const float* u, const float* g_theta, const float* g_log_q, const float* g_log_p,
+                    float* g_q_mu, float* g_q_prec, void* stream);
+
+/* IWAE reduction (vihds/training.py:135-149):  log_w = sum_j logp[j] + log_p - log_q;  per row b:
+ * row_max[b] = max_s log_w, row_sumexp[b] = sum_s exp(log_w - row_max[b]).  The host finishes
+ * lse = row_max + log(row_sumexp) (after the cross-rank combine when S is sharded) and the mean over B. */
+int vihds_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
+                   float* row_max, float* row_sumexp, void* stream);
+/* g_lse [B], lse [B] -> g_logw [B][S] = g_lse[b] * exp(log_w - lse[b]) */
+int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const float* g_lse, float* g_logw,
+                   void* stream);
+
+/* Evaluation summaries (vihds/utils.py:79-99, Results.init) on device: importance-weighted mean / std of the
+ * predictions, mean of the states, mean of 1/precision.  w = exp(log_w - lse).
+ *   prec_theta_rows: for constant precisions the 4 theta rows holding prec_*; prec_traj: neural precisions
+ *   taken from traj states [n_species..n_species+3]. */
+int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
+                       const float* traj, const float* xpred, const float* theta, const int* prec_rows,
+                       float* iw_predict_mu /*[B][4][T]*/, float* iw_predict_std /*[B][4][T]*/,
+                       float* iw_states /*[B][n_species][T]*/, float* iw_variance /*[B][4][T]*/, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VIHDS_HIP_H */

@@ -103,6 +103,6 @@ class Fixture:
 
 
 def rel_err(a, b):
-    a = torch.as_tensor(a, dtype=torch.float64).cpu()
-    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    a = torch.as_tensor(a).detach().to(torch.float64).cpu()
+    b = torch.as_tensor(b).detach().to(torch.float64).cpu()
     return float((a - b).abs().max() / (b.abs().max() + 1e-30))

@@ -1,0 +1,37 @@
+"""Ad-hoc kernel timing probe (not a test): HIP-event timing of the ODE fwd/bwd kernels at BASELINE shapes."""
+import sys, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vi-hds_amd"), os.path.join(ROOT, "tests")]
+import torch
+from vihds import ops, hip
+from test_hip_parity import _full_problem
+
+def timeit(fn, n=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3  # us
+
+for model in ["dr_constant"]:
+  for (B, S) in [(36, 200), (36, 1000), (234, 1000)]:
+    for solver in ["modeuler", "midpoint", "rk4"]:
+        T = 86
+        slots, theta, cond, times, obs = _full_problem(B, S, T)
+        row_of = {n: i for i, n in enumerate(slots)}
+        spec = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2)
+        th = theta.clone().requires_grad_(True)
+        out = {}
+        def fwd():
+            out["o"] = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, None)
+        fwd()
+        g = torch.ones_like(out["o"][2])
+        def bwd():
+            th.grad = None
+            out["o"][2].backward(g, retain_graph=True)
+        tf = timeit(fwd); tb = timeit(bwd)
+        N = 8; P = 35
+        fbytes = 4 * (P * B * S + B * S * N * T + B * S * 4 * T); bbytes = 4 * (B * S * N * T + P * B * S)
+        print("%s B=%d S=%d %-9s fwd %8.1f us (%.0f GB/s)  bwd %8.1f us (%.0f GB/s)" % (model, B, S, solver, tf, fbytes / tf / 1e3, tb, bbytes / tb / 1e3))

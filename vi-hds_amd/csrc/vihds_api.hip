@@ -1,0 +1,215 @@
+// C ABI (include/vihds_hip.h): argument checking, model registry and dispatch to the kernel launchers.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+
+#include "../../include/vihds_hip.h"
+#include "vihds_ode_kernels.hpp"
+
+namespace vihds {
+// per-model translation units (ode_<model>.hip)
+#define VIHDS_DECL(name)                                                        \
+  int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
+  int n_slots_##name();                                                         \
+  int n_states_##name();                                                        \
+  const char* slot_name_##name(int s);
+VIHDS_DECL(dr_constant_v1)
+VIHDS_DECL(dr_constant_v2)
+VIHDS_DECL(auto_constant)
+VIHDS_DECL(prpr_constant)
+VIHDS_DECL(relay_constant)
+VIHDS_DECL(degrader_constant)
+#undef VIHDS_DECL
+
+// vihds_elbo.hip
+void launch_theta_fwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
+                      const float*, const float*, float*, float*, float*, hipStream_t);
+void launch_theta_bwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
+                      const float*, const float*, const float*, const float*, const float*, float*, float*,
+                      hipStream_t);
+void launch_iwae_fwd(int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
+void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
+                         const int*, float*, float*, float*, float*, hipStream_t);
+
+struct ModelEntry {
+  int (*launch)(bool, int, const OdeArgs&, hipStream_t);
+  int (*n_slots)();
+  int (*n_states)();
+  const char* (*slot_name)(int);
+  bool neural_prec;
+};
+#define VIHDS_ENTRY(name, np) \
+  { launch_##name, n_slots_##name, n_states_##name, slot_name_##name, np }
+static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
+    VIHDS_ENTRY(dr_constant_v1, false),     // VIHDS_MODEL_DR_CONSTANT
+    VIHDS_ENTRY(dr_constant_v2, false),     // VIHDS_MODEL_DR_CONSTANT_V2
+    VIHDS_ENTRY(auto_constant, false),      // VIHDS_MODEL_AUTO_CONSTANT
+    VIHDS_ENTRY(prpr_constant, false),      // VIHDS_MODEL_PRPR_CONSTANT
+    VIHDS_ENTRY(relay_constant, false),     // VIHDS_MODEL_RELAY_CONSTANT
+    VIHDS_ENTRY(degrader_constant, false),  // VIHDS_MODEL_DEGRADER_CONSTANT
+    {nullptr, nullptr, nullptr, nullptr, true},  // *_PRECISIONS and DR_BLACKBOX: see vihds_model_supported()
+    {nullptr, nullptr, nullptr, nullptr, true},
+    {nullptr, nullptr, nullptr, nullptr, true},
+    {nullptr, nullptr, nullptr, nullptr, true},
+    {nullptr, nullptr, nullptr, nullptr, true},
+    {nullptr, nullptr, nullptr, nullptr, true},
+    {nullptr, nullptr, nullptr, nullptr, true},
+};
+
+static thread_local char g_err[256] = "";
+static int fail(int code, const char* msg) {
+  std::snprintf(g_err, sizeof(g_err), "%s", msg);
+  return code;
+}
+static int check_hip(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    std::snprintf(g_err, sizeof(g_err), "%s: %s", what, hipGetErrorString(e));
+    return VIHDS_E_HIP;
+  }
+  return VIHDS_OK;
+}
+static const char* kPrecNames[4] = {"prec_x", "prec_rfp", "prec_yfp", "prec_cfp"};
+
+static const ModelEntry* entry(int model) {
+  if (model < 0 || model >= VIHDS_MODEL_COUNT) return nullptr;
+  return kModels[model].launch ? &kModels[model] : nullptr;
+}
+
+static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& a) {
+  if (p->B <= 0 || p->S <= 0 || p->T < 2) return fail(VIHDS_E_BADARG, "B, S must be > 0 and T >= 2");
+  if ((long long)p->B * p->S > 0x7fffffffLL) return fail(VIHDS_E_BADARG, "B*S exceeds int range");
+  const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
+  std::memset(&a, 0, sizeof(a));
+  a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
+  for (int q = 0; q < ns; ++q) {
+    if (p->slot_row[q] < 0 || p->slot_row[q] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
+    a.slot_row[q] = p->slot_row[q];
+  }
+  return VIHDS_OK;
+}
+}  // namespace vihds
+
+using namespace vihds;
+
+extern "C" {
+
+int vihds_abi_version(void) { return VIHDS_ABI_VERSION; }
+const char* vihds_last_error(void) { return g_err; }
+
+int vihds_model_n_states(int model) {
+  const ModelEntry* e = entry(model);
+  return e ? e->n_states() : VIHDS_E_UNSUPPORTED;
+}
+int vihds_model_n_species(int model) {
+  const ModelEntry* e = entry(model);
+  return e ? e->n_states() - (e->neural_prec ? 4 : 0) : VIHDS_E_UNSUPPORTED;
+}
+int vihds_model_n_slots(int model) {
+  const ModelEntry* e = entry(model);
+  return e ? e->n_slots() + (e->neural_prec ? 0 : 4) : VIHDS_E_UNSUPPORTED;
+}
+const char* vihds_model_slot_name(int model, int slot) {
+  const ModelEntry* e = entry(model);
+  if (!e || slot < 0) return nullptr;
+  const int ns = e->n_slots();
+  if (slot < ns) return e->slot_name(slot);
+  if (!e->neural_prec && slot < ns + 4) return kPrecNames[slot - ns];
+  return nullptr;
+}
+int vihds_model_n_weights(const vihds_ode_problem* p) {
+  (void)p;
+  return 0;
+}
+
+int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                  const float* times, const float* obs, const float* weights, float* traj, float* xpred, float* logp,
+                  void* stream) {
+  (void)dev1hot; (void)weights;
+  if (!p || !theta || !times) return fail(VIHDS_E_BADARG, "null problem/theta/times");
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  if (logp && !obs) return fail(VIHDS_E_BADARG, "logp requested without obs");
+  OdeArgs a;
+  int rc = build_args(p, e, a);
+  if (rc) return rc;
+  if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
+  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs;
+  a.traj = traj; a.xpred = xpred; a.logp = logp;
+  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+  if (rc) return fail(rc, "unknown solver");
+  return check_hip("vihds_ode_fwd launch");
+}
+
+int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                  const float* times, const float* obs, const float* weights, const float* traj, const float* g_traj,
+                  const float* g_xpred, const float* g_logp, float* g_theta, float* g_weights, void* stream) {
+  (void)dev1hot; (void)weights; (void)g_weights;
+  if (!p || !theta || !times || !traj || !g_theta) return fail(VIHDS_E_BADARG, "null problem/theta/times/traj/g_theta");
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  if (!obs) return fail(VIHDS_E_BADARG, "null obs");
+  OdeArgs a;
+  int rc = build_args(p, e, a);
+  if (rc) return rc;
+  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs;
+  a.traj_in = traj; a.g_traj = g_traj; a.g_xpred = g_xpred; a.g_logp = g_logp; a.g_theta = g_theta;
+  rc = e->launch(true, p->solver, a, (hipStream_t)stream);
+  if (rc) return fail(rc, "unknown solver");
+  return check_hip("vihds_ode_bwd launch");
+}
+
+int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
+                    const float* p_prec, const float* clip_lo, const float* clip_hi, const float* u, float* theta,
+                    float* log_q, float* log_p, void* stream) {
+  if (P <= 0 || B <= 0 || S <= 0) return fail(VIHDS_E_BADARG, "P, B, S must be > 0");
+  if (!kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !theta)
+    return fail(VIHDS_E_BADARG, "null argument");
+  launch_theta_fwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, theta, log_q, log_p,
+                   (hipStream_t)stream);
+  return check_hip("vihds_theta_fwd launch");
+}
+
+int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
+                    const float* p_prec, const float* clip_lo, const float* clip_hi, const float* u,
+                    const float* g_theta, const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec,
+                    void* stream) {
+  if (P <= 0 || B <= 0 || S <= 0) return fail(VIHDS_E_BADARG, "P, B, S must be > 0");
+  if (!kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !g_q_mu || !g_q_prec)
+    return fail(VIHDS_E_BADARG, "null argument");
+  launch_theta_bwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, g_theta, g_log_q, g_log_p, g_q_mu,
+                   g_q_prec, (hipStream_t)stream);
+  return check_hip("vihds_theta_bwd launch");
+}
+
+int vihds_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
+                   float* row_max, float* row_sumexp, void* stream) {
+  if (B <= 0 || S <= 0 || !logp || !log_w || !row_max || !row_sumexp) return fail(VIHDS_E_BADARG, "bad argument");
+  launch_iwae_fwd(B, S, logp, log_p, log_q, log_w, row_max, row_sumexp, (hipStream_t)stream);
+  return check_hip("vihds_iwae_fwd launch");
+}
+
+int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const float* g_lse, float* g_logw,
+                   void* stream) {
+  if (B <= 0 || S <= 0 || !log_w || !lse || !g_lse || !g_logw) return fail(VIHDS_E_BADARG, "bad argument");
+  launch_iwae_bwd(B, S, log_w, lse, g_lse, g_logw, (hipStream_t)stream);
+  return check_hip("vihds_iwae_bwd launch");
+}
+
+int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
+                       const float* traj, const float* xpred, const float* theta, const int* prec_rows,
+                       float* iw_predict_mu, float* iw_predict_std, float* iw_states, float* iw_variance,
+                       void* stream) {
+  if (B <= 0 || S <= 0 || T <= 0 || !log_w || !lse || !traj || !xpred || !iw_predict_mu || !iw_predict_std ||
+      !iw_states || !iw_variance)
+    return fail(VIHDS_E_BADARG, "bad argument");
+  if (theta && !prec_rows) return fail(VIHDS_E_BADARG, "theta given without prec_rows");
+  if (!theta && N_total < n_species + 4) return fail(VIHDS_E_BADARG, "neural precisions need N_total >= n_species+4");
+  launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, theta, prec_rows, iw_predict_mu,
+                      iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
+  return check_hip("vihds_iw_summaries launch");
+}
+
+}  // extern "C"

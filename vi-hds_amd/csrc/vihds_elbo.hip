@@ -1,0 +1,260 @@
+// theta-side and ELBO-side kernels:
+//   theta_fwd/bwd : ChainedDistribution.sample + p.clip + q.log_prob + p.log_prob for all P parameters at once
+//                   (reference vihds/distributions.py:64-85,119-142,327-381 and vihds/vae.py:31-34)
+//   iwae_fwd/bwd  : importance-weight row reductions of Training.cost (vihds/training.py:135-149)
+//   iw_summaries  : Results.init importance-weighted summaries (vihds/utils.py:79-99) without host copies
+#include <hip/hip_runtime.h>
+
+#include "../../include/vihds_hip.h"
+
+namespace vihds {
+
+constexpr float LOG2PI_F = 1.8378770664093453f;
+enum { KIND_NORMAL = 0, KIND_LOGNORMAL = 1, KIND_CONSTANT = 2 };
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o, 64));
+  return v;
+}
+// result valid in every thread
+template <int BLOCK>
+__device__ __forceinline__ float block_sum(float v, float* sm) {
+  v = wave_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  float r = 0.f;
+#pragma unroll
+  for (int w = 0; w < BLOCK / 64; ++w) r += sm[w];
+  __syncthreads();
+  return r;
+}
+template <int BLOCK>
+__device__ __forceinline__ float block_max(float v, float* sm) {
+  v = wave_max(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (lane == 0) sm[wid] = v;
+  __syncthreads();
+  float r = sm[0];
+#pragma unroll
+  for (int w = 1; w < BLOCK / 64; ++w) r = fmaxf(r, sm[w]);
+  __syncthreads();
+  return r;
+}
+
+// Normal log-density as the reference writes it (distributions.py:338-345): note -log(2*pi), not -0.5*log(2*pi)
+__device__ __forceinline__ float normal_lp(float mu, float prec, float x) {
+  const float d = mu - x;
+  return -LOG2PI_F + 0.5f * logf(prec + 1e-12f) - 0.5f * prec * d * d;
+}
+
+// one thread per (b, s); loops over the P parameters so u[b][s][:] is read as one contiguous run and every
+// theta row store is coalesced; log q / log p accumulate in registers (no cross-thread reduction).
+__global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
+                                 const float* __restrict__ q_prec, const float* __restrict__ p_mu,
+                                 const float* __restrict__ p_prec, const float* __restrict__ clip_lo,
+                                 const float* __restrict__ clip_hi, const float* __restrict__ u,
+                                 float* __restrict__ theta, float* __restrict__ log_q, float* __restrict__ log_p) {
+  const int n = B * S;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = i / S;
+  float lq = 0.f, lp = 0.f;
+  for (int p = 0; p < P; ++p) {
+    const int kd = kind[p];
+    const float uu = u[(size_t)i * P + p];
+    const float mu = q_mu[p * B + b];
+    float x;
+    if (kd == KIND_CONSTANT) {
+      x = 0.f * uu + mu;  // zeros_like(u) + value (distributions.py:241-242)
+    } else {
+      const float prec = q_prec[p * B + b];
+      const float sigma = 1.f / sqrtf(prec);
+      float z = mu + sigma * uu;
+      x = (kd == KIND_LOGNORMAL) ? expf(z) : z;
+      const float lo = clip_lo[p], hi = clip_hi[p];
+      x = x < lo ? lo : (x > hi ? hi : x);
+      const float v = (kd == KIND_LOGNORMAL) ? logf(x + 1e-12f) : x;
+      const float jac = (kd == KIND_LOGNORMAL) ? v : 0.f;
+      lq += normal_lp(mu, prec, v) - jac;
+      lp += normal_lp(p_mu[p], p_prec[p], v) - jac;
+    }
+    theta[(size_t)p * n + i] = x;
+  }
+  if (log_q) log_q[i] = lq;
+  if (log_p) log_p[i] = lp;
+}
+
+// one block per data row b; for each parameter the S per-sample contributions are reduced in a fixed order
+// (wave shuffle tree, then waves in order) so gradients are run-to-run deterministic.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
+                 const float* __restrict__ q_prec, const float* __restrict__ p_mu, const float* __restrict__ p_prec,
+                 const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, const float* __restrict__ u,
+                 const float* __restrict__ g_theta, const float* __restrict__ g_log_q,
+                 const float* __restrict__ g_log_p, float* __restrict__ g_q_mu, float* __restrict__ g_q_prec) {
+  __shared__ float sm[BLOCK / 64];
+  const int n = B * S;
+  const int b = blockIdx.x;
+  for (int p = 0; p < P; ++p) {
+    const int kd = kind[p];
+    float am = 0.f, ap = 0.f;
+    if (kd == KIND_CONSTANT) {
+      // constants carry no trainable distribution parameters in the reference (encoders.py:242-253)
+      if (threadIdx.x == 0) { g_q_mu[p * B + b] = 0.f; g_q_prec[p * B + b] = 0.f; }
+      continue;
+    }
+    const float mu = q_mu[p * B + b], prec = q_prec[p * B + b];
+    const float sigma = 1.f / sqrtf(prec);
+    const float pm = p_mu[p], pp = p_prec[p], lo = clip_lo[p], hi = clip_hi[p];
+    for (int s = threadIdx.x; s < S; s += BLOCK) {
+      const int i = b * S + s;
+      const float uu = u[(size_t)i * P + p];
+      const float z = mu + sigma * uu;
+      const float xr = (kd == KIND_LOGNORMAL) ? expf(z) : z;
+      const float x = xr < lo ? lo : (xr > hi ? hi : xr);
+      const float pass = (xr >= lo && xr <= hi) ? 1.f : 0.f;
+      const float glq = g_log_q ? g_log_q[i] : 0.f;
+      const float glp = g_log_p ? g_log_p[i] : 0.f;
+      float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
+      float v, dv_dx;
+      if (kd == KIND_LOGNORMAL) { v = logf(x + 1e-12f); dv_dx = 1.f / (x + 1e-12f); }
+      else { v = x; dv_dx = 1.f; }
+      const float jac = (kd == KIND_LOGNORMAL) ? 1.f : 0.f;
+      // d lq/dv = prec*(mu - v) - jac ; d lp/dv = pp*(pm - v) - jac
+      const float gv = glq * (prec * (mu - v) - jac) + glp * (pp * (pm - v) - jac);
+      gx += gv * dv_dx;
+      // back through clip and (for LogNormal) exp
+      float gz = gx * pass;
+      if (kd == KIND_LOGNORMAL) gz *= xr;
+      // z = mu + u / sqrt(prec)
+      am += gz;
+      ap += gz * uu * (-0.5f) * sigma / prec;
+      // explicit dependence of log q on (mu, prec)
+      const float d = mu - v;
+      am += glq * (-prec * d);
+      ap += glq * (0.5f / (prec + 1e-12f) - 0.5f * d * d);
+    }
+    am = block_sum<BLOCK>(am, sm);
+    ap = block_sum<BLOCK>(ap, sm);
+    if (threadIdx.x == 0) { g_q_mu[p * B + b] = am; g_q_prec[p * B + b] = ap; }
+  }
+}
+
+// log_w = sum_j logp[j] + log_p - log_q ; per-row max and sum-exp.  One block per row.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+iwae_fwd_kernel(int B, int S, const float* __restrict__ logp, const float* __restrict__ log_p,
+                const float* __restrict__ log_q, float* __restrict__ log_w, float* __restrict__ row_max,
+                float* __restrict__ row_sumexp) {
+  __shared__ float sm[BLOCK / 64];
+  const int n = B * S, b = blockIdx.x;
+  float m = -INFINITY;
+  for (int s = threadIdx.x; s < S; s += BLOCK) {
+    const int i = b * S + s;
+    float lw = ((logp[i] + logp[n + i]) + logp[2 * n + i]) + logp[3 * n + i];
+    lw = lw + (log_p ? log_p[i] : 0.f) - (log_q ? log_q[i] : 0.f);
+    log_w[i] = lw;
+    m = fmaxf(m, lw);
+  }
+  m = block_max<BLOCK>(m, sm);
+  float se = 0.f;
+  for (int s = threadIdx.x; s < S; s += BLOCK) se += expf(log_w[b * S + s] - m);
+  se = block_sum<BLOCK>(se, sm);
+  if (threadIdx.x == 0) { row_max[b] = m; row_sumexp[b] = se; }
+}
+
+__global__ void iwae_bwd_kernel(int B, int S, const float* __restrict__ log_w, const float* __restrict__ lse,
+                                const float* __restrict__ g_lse, float* __restrict__ g_logw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S) return;
+  const int b = i / S;
+  g_logw[i] = g_lse[b] * expf(log_w[i] - lse[b]);
+}
+
+// Results.init (vihds/utils.py:79-99): one block per (b, t); rows of the [T][*][B][S] buffers are contiguous in s.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
+                    const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
+                    const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3, float* __restrict__ mu_out,
+                    float* __restrict__ std_out, float* __restrict__ states_out, float* __restrict__ var_out) {
+  __shared__ float sm[BLOCK / 64];
+  const int b = blockIdx.x, t = blockIdx.y;
+  const size_t n = (size_t)B * S;
+  const float l = lse[b];
+  const int prow[4] = {pr0, pr1, pr2, pr3};
+  for (int j = 0; j < 4; ++j) {
+    float a_mu = 0.f, a_sq = 0.f, a_var = 0.f;
+    for (int s = threadIdx.x; s < S; s += BLOCK) {
+      const size_t i = (size_t)b * S + s;
+      const float w = expf(log_w[i] - l);
+      const float xp = xpred[((size_t)t * 4 + j) * n + i];
+      const float prec = theta ? theta[(size_t)prow[j] * n + i] : traj[((size_t)t * N_total + n_species + j) * n + i];
+      const float iv = 1.f / prec;
+      a_mu += w * xp;
+      a_sq += w * (xp * xp + iv);
+      a_var += w * iv;
+    }
+    a_mu = block_sum<BLOCK>(a_mu, sm);
+    a_sq = block_sum<BLOCK>(a_sq, sm);
+    a_var = block_sum<BLOCK>(a_var, sm);
+    if (threadIdx.x == 0) {
+      const size_t o = ((size_t)b * 4 + j) * T + t;
+      mu_out[o] = a_mu;
+      std_out[o] = sqrtf(a_sq - a_mu * a_mu);
+      var_out[o] = a_var;
+    }
+  }
+  for (int j = 0; j < n_species; ++j) {
+    float a = 0.f;
+    for (int s = threadIdx.x; s < S; s += BLOCK) {
+      const size_t i = (size_t)b * S + s;
+      a += expf(log_w[i] - l) * traj[((size_t)t * N_total + j) * n + i];
+    }
+    a = block_sum<BLOCK>(a, sm);
+    if (threadIdx.x == 0) states_out[((size_t)b * n_species + j) * T + t] = a;
+  }
+}
+
+// ---- launchers (called from vihds_api.hip) ---------------------------------------------------------
+void launch_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
+                      const float* p_prec, const float* lo, const float* hi, const float* u, float* theta,
+                      float* log_q, float* log_p, hipStream_t st) {
+  const int n = B * S, blk = 64;
+  hipLaunchKernelGGL(theta_fwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec, p_mu,
+                     p_prec, lo, hi, u, theta, log_q, log_p);
+}
+void launch_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
+                      const float* p_prec, const float* lo, const float* hi, const float* u, const float* g_theta,
+                      const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec, hipStream_t st) {
+  hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B), dim3(256), 0, st, P, B, S, kind, q_mu, q_prec, p_mu, p_prec, lo,
+                     hi, u, g_theta, g_log_q, g_log_p, g_q_mu, g_q_prec);
+}
+void launch_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
+                     float* row_max, float* row_sumexp, hipStream_t st) {
+  hipLaunchKernelGGL((iwae_fwd_kernel<256>), dim3(B), dim3(256), 0, st, B, S, logp, log_p, log_q, log_w, row_max,
+                     row_sumexp);
+}
+void launch_iwae_bwd(int B, int S, const float* log_w, const float* lse, const float* g_lse, float* g_logw,
+                     hipStream_t st) {
+  const int n = B * S, blk = 256;
+  hipLaunchKernelGGL(iwae_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_lse, g_logw);
+}
+void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
+                         const float* traj, const float* xpred, const float* theta, const int* prec_rows, float* mu,
+                         float* sd, float* states, float* var, hipStream_t st) {
+  int r[4] = {0, 0, 0, 0};
+  if (theta && prec_rows) for (int j = 0; j < 4; ++j) r[j] = prec_rows[j];
+  hipLaunchKernelGGL((iw_summaries_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species, log_w, lse,
+                     traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+}
+
+}  // namespace vihds

@@ -1,0 +1,303 @@
+// Fused ODE-integration kernels: one thread per (row b, IWAE sample s) trajectory, the whole time loop inside
+// the kernel, state and effective parameters in VGPRs, trajectory written [T][N][B][S] so that each store
+// instruction of a wave covers 64 consecutive floats.
+//
+// Forward  = reference OdeModel.simulate (vihds/ode.py:66-82) + observe (:84-93) + expand_precisions
+//            (vihds/precisions.py:31-35) + log_prob_observations (vihds/training.py:24-44), fused.
+// Backward = discrete adjoint of the chosen scheme, i.e. exactly the gradient autograd produces for the
+//            reference's python time loop: for each step (last to first) reload y_k from the stored
+//            trajectory, recompute the stage states, and pull the adjoint back through the stages.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/vihds_hip.h"
+#include "vihds_models.hpp"
+
+namespace vihds {
+
+constexpr float LOG2PI_F = 1.8378770664093453f;  // math.log(2*math.pi), vihds/training.py:43
+
+struct OdeArgs {
+  int B, S, T, C, n;  // n = B*S
+  int slot_row[VIHDS_MAX_SLOTS];
+  const float* theta;
+  const float* cond;
+  const float* times;
+  const float* obs;
+  float* traj;
+  float* xpred;
+  float* logp;
+  const float* traj_in;  // backward: stored trajectory
+  const float* g_traj;
+  const float* g_xpred;
+  const float* g_logp;
+  float* g_theta;
+};
+
+template <int OBS>
+__device__ __forceinline__ void observe(const float* y, float* xp) {
+  xp[0] = y[0];
+  xp[1] = y[0] * y[1];
+  if (OBS == OBS_DEFAULT) {  // vihds/ode.py:84-93
+    xp[2] = y[0] * (y[2] + y[4]);
+    xp[3] = y[0] * (y[3] + y[5]);
+  } else {  // models/auto_constant.py:89-97, models/dr_blackbox.py:112-121
+    xp[2] = y[0] * y[2];
+    xp[3] = y[0] * y[3];
+  }
+}
+template <int OBS>
+__device__ __forceinline__ void observe_vjp(const float* y, const float* xpb, float* yb) {
+  if (OBS == OBS_DEFAULT) {
+    yb[0] += xpb[0] + xpb[1] * y[1] + xpb[2] * (y[2] + y[4]) + xpb[3] * (y[3] + y[5]);
+    yb[1] += xpb[1] * y[0];
+    yb[2] += xpb[2] * y[0];
+    yb[4] += xpb[2] * y[0];
+    yb[3] += xpb[3] * y[0];
+    yb[5] += xpb[3] * y[0];
+  } else {
+    yb[0] += xpb[0] + xpb[1] * y[1] + xpb[2] * y[2] + xpb[3] * y[3];
+    yb[1] += xpb[1] * y[0];
+    yb[2] += xpb[2] * y[0];
+    yb[3] += xpb[3] * y[0];
+  }
+}
+
+// ---- one step of each scheme ---------------------------------------------------------------------
+template <class M, int SOLVER>
+__device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y, const float* p) {
+  constexpr int N = M::N;
+  float k1[N], k2[N], ya[N];
+  if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
+    // vihds/solvers.py:12-16 / :21-25
+    const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + h * k1[j];
+    M::rhs(t1, ya, p, k2);
+    const float hh = 0.5f * h;
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + hh * (k1[j] + k2[j]);
+  } else if (SOLVER == VIHDS_SOLVER_EULER) {
+    const float dt = t1 - t0;
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + dt * k1[j];
+  } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
+    // torchdiffeq 0.1 Midpoint.step_func: y_mid = y + f(t,y)*dt/2 ; dy = dt*f(t+dt/2, y_mid)
+    const float dt = t1 - t0;
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + k1[j] * dt * 0.5f;
+    M::rhs(t0 + dt * 0.5f, ya, p, k2);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + dt * k2[j];
+  } else {
+    // torchdiffeq 0.1 rk4_alt_step_func (3/8 rule)
+    const float dt = t1 - t0;
+    float k3[N], k4[N];
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * k1[j] / 3.f;
+    M::rhs(t0 + dt / 3.f, ya, p, k2);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] / -3.f + k2[j]);
+    M::rhs(t0 + dt * 2.f / 3.f, ya, p, k3);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);
+    M::rhs(t0 + dt, ya, p, k4);
+    const float d8 = dt / 8.f;
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + (k1[j] + 3.f * k2[j] + 3.f * k3[j] + k4[j]) * d8;
+  }
+}
+
+// reverse of one step: lam (adjoint of y_{k+1}) -> adjoint of y_k ; pb += parameter adjoint
+template <class M, int SOLVER>
+__device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const float* y, const float* p, float* lam,
+                                             float* pb) {
+  constexpr int N = M::N;
+  float k1[N], ya[N], v[N], w[N];
+  if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
+    const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
+    const float hh = 0.5f * h;
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + h * k1[j];
+    // y' = y + hh*(f1 + f2)
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = hh * lam[j]; w[j] = 0.f; }
+    M::rhs_vjp(t1, ya, p, v, w, pb);  // w = ya_bar
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] += h * w[j]; }
+    M::rhs_vjp(t0, y, p, v, lam, pb);
+  } else if (SOLVER == VIHDS_SOLVER_EULER) {
+    const float dt = t1 - t0;
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) v[j] = dt * lam[j];
+    M::rhs_vjp(t0, y, p, v, lam, pb);
+  } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
+    const float dt = t1 - t0;
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + k1[j] * dt * 0.5f;
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = dt * lam[j]; w[j] = 0.f; }
+    M::rhs_vjp(t0 + dt * 0.5f, ya, p, v, w, pb);  // w = ymid_bar
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] = 0.5f * dt * w[j]; }
+    M::rhs_vjp(t0, y, p, v, lam, pb);
+  } else {
+    const float dt = t1 - t0;
+    const float d3 = dt / 3.f;
+    float k2[N], k3[N], y2[N], y3[N];
+    M::rhs(t0, y, p, k1);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y2[j] = y[j] + dt * k1[j] / 3.f;
+    M::rhs(t0 + dt / 3.f, y2, p, k2);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y3[j] = y[j] + dt * (k1[j] / -3.f + k2[j]);
+    M::rhs(t0 + dt * 2.f / 3.f, y3, p, k3);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);  // y4
+    const float d8 = dt / 8.f;
+    float k1b[N], k2b[N], k3b[N];
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+      v[j] = d8 * lam[j];  // k4_bar
+      k1b[j] = v[j];
+      k2b[j] = 3.f * v[j];
+      k3b[j] = 3.f * v[j];
+      w[j] = 0.f;
+    }
+    M::rhs_vjp(t0 + dt, ya, p, v, w, pb);  // w = y4_bar
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+      lam[j] += w[j];
+      k1b[j] += dt * w[j];
+      k2b[j] -= dt * w[j];
+      k3b[j] += dt * w[j];
+      w[j] = 0.f;
+    }
+    M::rhs_vjp(t0 + dt * 2.f / 3.f, y3, p, k3b, w, pb);  // w = y3_bar
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+      lam[j] += w[j];
+      k1b[j] -= d3 * w[j];
+      k2b[j] += dt * w[j];
+      w[j] = 0.f;
+    }
+    M::rhs_vjp(t0 + dt / 3.f, y2, p, k2b, w, pb);  // w = y2_bar
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+      lam[j] += w[j];
+      k1b[j] += d3 * w[j];
+    }
+    M::rhs_vjp(t0, y, p, k1b, lam, pb);
+  }
+}
+
+template <class M>
+__device__ __forceinline__ void load_theta(const OdeArgs& a, int i, int b, float* th, float* prec, float* c) {
+  VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) prec[j] = a.theta[(size_t)a.slot_row[M::NSLOT + j] * a.n + i];
+  VIHDS_UNROLL for (int q = 0; q < M::NC; ++q) c[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+}
+
+// ---- forward -------------------------------------------------------------------------------------
+template <class M, int SOLVER>
+__global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
+  constexpr int N = M::N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int b = i / a.S;
+  float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP], y[N];
+  load_theta<M>(a, i, b, th, prec, c);
+  M::prepare(th, c, p);
+  M::init(th, c, y);
+
+  float lc[4], lp[4];
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) { lc[j] = LOG2PI_F - logf(prec[j]); lp[j] = 0.f; }
+  const float* ob = a.obs + (size_t)b * 4 * a.T;
+  const float h0 = a.times[1] - a.times[0];
+  const size_t n = a.n;
+
+  for (int k = 0; k < a.T; ++k) {
+    if (k > 0) ode_step<M, SOLVER>(a.times[k - 1], a.times[k], h0, y, p);
+    if (a.traj) {
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) a.traj[((size_t)k * N + j) * n + i] = y[j];
+    }
+    float xp[4];
+    observe<M::OBS>(y, xp);
+    if (a.xpred) {
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.xpred[((size_t)k * 4 + j) * n + i] = xp[j];
+    }
+    if (a.logp) {
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+        const float e = xp[j] - ob[j * a.T + k];
+        lp[j] += -0.5f * (lc[j] + prec[j] * e * e);
+      }
+    }
+  }
+  if (a.logp) {
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.logp[(size_t)j * n + i] = lp[j];
+  }
+}
+
+// ---- backward ------------------------------------------------------------------------------------
+template <class M, int SOLVER>
+__global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
+  constexpr int N = M::N;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n) return;
+  const int b = i / a.S;
+  float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP];
+  load_theta<M>(a, i, b, th, prec, c);
+  M::prepare(th, c, p);
+
+  float lam[N], pb[M::NP], precb[4], glp[4];
+  VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] = 0.f;
+  VIHDS_UNROLL for (int j = 0; j < M::NP; ++j) pb[j] = 0.f;
+  const size_t n = a.n;
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+    precb[j] = 0.f;
+    glp[j] = a.g_logp ? a.g_logp[(size_t)j * n + i] : 0.f;
+  }
+  const float* ob = a.obs + (size_t)b * 4 * a.T;
+  const float h0 = a.times[1] - a.times[0];
+
+  for (int k = a.T - 1; k >= 0; --k) {
+    float y[N];
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = a.traj_in[((size_t)k * N + j) * n + i];
+    if (k < a.T - 1) ode_step_vjp<M, SOLVER>(a.times[k], a.times[k + 1], h0, y, p, lam, pb);
+    // gradient injected at time k: log-likelihood term, x_predict and trajectory upstream grads
+    float xp[4], xpb[4];
+    observe<M::OBS>(y, xp);
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+      const float e = xp[j] - ob[j * a.T + k];
+      xpb[j] = -glp[j] * prec[j] * e;
+      precb[j] += glp[j] * (0.5f / prec[j] - 0.5f * e * e);
+      if (a.g_xpred) xpb[j] += a.g_xpred[((size_t)k * 4 + j) * n + i];
+    }
+    observe_vjp<M::OBS>(y, xpb, lam);
+    if (a.g_traj) {
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] += a.g_traj[((size_t)k * N + j) * n + i];
+    }
+  }
+  float thb[M::NSLOT];
+  VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
+  M::prepare_vjp(th, c, p, pb, thb);
+  M::init_vjp(lam, thb);
+  VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.g_theta[(size_t)a.slot_row[M::NSLOT + j] * n + i] = precb[j];
+}
+
+inline int pick_block(int n) { return n >= (1 << 18) ? 256 : 64; }
+
+template <class M, int SOLVER>
+inline void launch_fwd_s(const OdeArgs& a, hipStream_t st) {
+  const int blk = pick_block(a.n);
+  hipLaunchKernelGGL((ode_fwd_kernel<M, SOLVER>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
+}
+template <class M, int SOLVER>
+inline void launch_bwd_s(const OdeArgs& a, hipStream_t st) {
+  const int blk = pick_block(a.n);
+  hipLaunchKernelGGL((ode_bwd_kernel<M, SOLVER>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
+}
+
+template <class M>
+inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+#define VIHDS_CASE(SV)                                           \
+  case SV:                                                       \
+    if (backward) launch_bwd_s<M, SV>(a, st);                    \
+    else launch_fwd_s<M, SV>(a, st);                             \
+    return VIHDS_OK;
+  switch (solver) {
+    VIHDS_CASE(VIHDS_SOLVER_MODEULER)
+    VIHDS_CASE(VIHDS_SOLVER_MODEULERWHILE)
+    VIHDS_CASE(VIHDS_SOLVER_EULER)
+    VIHDS_CASE(VIHDS_SOLVER_MIDPOINT)
+    VIHDS_CASE(VIHDS_SOLVER_RK4)
+  }
+#undef VIHDS_CASE
+  return VIHDS_E_BADARG;
+}
+
+}  // namespace vihds

@@ -1,0 +1,133 @@
+"""ctypes binding of libvihds_hip.so (C ABI: include/vihds_hip.h).
+
+This is the stub a vi-hds maintainer would add: the reference is pure Python/PyTorch, so the
+foreign-function boundary is ctypes; torch is only used by callers for device memory and streams.  There is no
+CPU fallback: if the library is missing or a call fails, a RuntimeError is raised.
+"""
+import ctypes
+import os
+
+VIHDS_MAX_SLOTS = 64
+
+MODELS = {
+    # models.LOOKUP key (reference models/__init__.py:19-35) -> enum vihds_model
+    "dr_constant": 0,
+    "dr_constant_v2": 1,
+    "auto_constant": 2,
+    "prpr_constant": 3,
+    "relay_constant": 4,
+    "degrader_constant": 5,
+    "dr_constant_precisions": 6,
+    "dr_constant_precisions_v2": 7,
+    "auto_constant_precisions": 8,
+    "prpr_constant_precisions": 9,
+    "relay_constant_precisions": 10,
+    "degrader_constant_precisions": 11,
+    "dr_blackbox": 12,
+}
+SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}
+
+_c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
+
+
+class OdeProblem(ctypes.Structure):
+    """struct vihds_ode_problem"""
+
+    _fields_ = [
+        ("model", ctypes.c_int),
+        ("solver", ctypes.c_int),
+        ("B", ctypes.c_int),
+        ("S", ctypes.c_int),
+        ("T", ctypes.c_int),
+        ("C", ctypes.c_int),
+        ("D", ctypes.c_int),
+        ("n_rows", ctypes.c_int),
+        ("slot_row", ctypes.c_int * VIHDS_MAX_SLOTS),
+        ("n_hidden_prec", ctypes.c_int),
+        ("n_hidden_states", ctypes.c_int),
+        ("n_latent_states", ctypes.c_int),
+        ("n_const", ctypes.c_int),
+        ("init_latent", ctypes.c_float),
+        ("init_prec", ctypes.c_float),
+    ]
+
+
+_LIB = None
+_P = ctypes.c_void_p
+_I = ctypes.c_int
+
+_PROTOTYPES = {
+    "vihds_abi_version": (_I, []),
+    "vihds_last_error": (ctypes.c_char_p, []),
+    "vihds_model_n_states": (_I, [_I]),
+    "vihds_model_n_species": (_I, [_I]),
+    "vihds_model_n_slots": (_I, [_I]),
+    "vihds_model_slot_name": (ctypes.c_char_p, [_I, _I]),
+    "vihds_model_n_weights": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
+    "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 13),
+    "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 12),
+    "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 14),
+    "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
+    "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
+    "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
+}
+
+
+def library_path():
+    here = os.path.dirname(os.path.abspath(__file__))
+    return os.environ.get("VIHDS_HIP_LIB", os.path.join(os.path.dirname(here), "lib", "libvihds_hip.so"))
+
+
+def lib():
+    """Load (once) and return the shared library; raise loudly if it is not there."""
+    global _LIB
+    if _LIB is None:
+        import torch  # noqa: F401  -- make sure torch's HIP runtime is the one already mapped in this process
+
+        path = library_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                "libvihds_hip.so not found at %s -- build it with `make -C vi-hds_amd/csrc` "
+                "(or __graft_entry__.build()); there is no CPU fallback" % path
+            )
+        handle = ctypes.CDLL(path)
+        for name, (res, args) in _PROTOTYPES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
+            fn.restype = res
+            fn.argtypes = args
+        if handle.vihds_abi_version() != 1:
+            raise RuntimeError("libvihds_hip.so ABI version mismatch")
+        _LIB = handle
+    return _LIB
+
+
+def exported_symbols():
+    return sorted(_PROTOTYPES)
+
+
+def check(rc, what):
+    if rc != 0:
+        msg = lib().vihds_last_error().decode()
+        raise RuntimeError("%s failed (code %d): %s" % (what, rc, msg))
+
+
+def model_slots(model_key):
+    """Reference parameter names in the kernel's slot order for a model."""
+    L = lib()
+    m = MODELS[model_key]
+    n = L.vihds_model_n_slots(m)
+    if n < 0:
+        raise RuntimeError("model '%s' is not supported by this build of libvihds_hip.so" % model_key)
+    return [L.vihds_model_slot_name(m, s).decode() for s in range(n)]
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream():
+    import torch
+
+    return torch.cuda.current_stream().cuda_stream

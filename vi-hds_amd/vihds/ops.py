@@ -1,0 +1,244 @@
+"""torch.autograd.Function wrappers around the HIP kernels (C ABI in include/vihds_hip.h).
+
+PyTorch is plumbing here: it owns the device buffers and the stream the kernels are enqueued on, and its
+autograd graph calls the hand-written backward kernels.  Nothing in this module computes on the CPU and there
+is no fallback: tensors must live on a HIP device.
+"""
+import ctypes
+import math
+
+import torch
+
+from vihds import hip
+
+
+def _require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("vihds HIP ops need tensors on the GPU (got a %s tensor); there is no CPU fallback"
+                               % t.device)
+
+
+def _c(t):
+    return None if t is None else t.contiguous()
+
+
+class OdeProblemSpec:
+    """Host-side description of one decoder problem (struct vihds_ode_problem) for a fixed model/solver."""
+
+    def __init__(self, model, solver, row_of, n_rows, C, D=0, n_hidden_prec=0, n_hidden_states=0,
+                 n_latent_states=0, n_const=0, init_latent=0.001, init_prec=1e-5):
+        if model not in hip.MODELS:
+            raise KeyError("unknown model '%s'" % model)
+        if solver not in hip.SOLVERS:
+            raise NotImplementedError(
+                "solver '%s' is not implemented by the HIP path (available: %s); adaptive torchdiffeq solvers "
+                "are out of scope" % (solver, ", ".join(sorted(hip.SOLVERS))))
+        self.model, self.solver = model, solver
+        self.slots = hip.model_slots(model)
+        self.n_states = hip.lib().vihds_model_n_states(hip.MODELS[model])
+        self.n_species = hip.lib().vihds_model_n_species(hip.MODELS[model])
+        missing = [s for s in self.slots if s not in row_of]
+        if missing:
+            raise KeyError("model '%s' needs parameters %s which the spec does not define" % (model, missing))
+        self.n_rows = n_rows
+        self.proto = hip.OdeProblem()
+        self.proto.model = hip.MODELS[model]
+        self.proto.solver = hip.SOLVERS[solver]
+        self.proto.C, self.proto.D, self.proto.n_rows = C, D, n_rows
+        for q, s in enumerate(self.slots):
+            self.proto.slot_row[q] = row_of[s]
+        self.proto.n_hidden_prec = n_hidden_prec
+        self.proto.n_hidden_states = n_hidden_states
+        self.proto.n_latent_states = n_latent_states
+        self.proto.n_const = n_const
+        self.proto.init_latent = init_latent
+        self.proto.init_prec = init_prec
+
+    def bind(self, B, S, T):
+        p = hip.OdeProblem()
+        ctypes.pointer(p)[0] = self.proto
+        p.B, p.S, p.T = B, S, T
+        return p
+
+
+class OdeSolveObserve(torch.autograd.Function):
+    """simulate + observe + Gaussian log-likelihood in one kernel; adjoint in one kernel.
+
+    forward(theta[R,B,S], cond[B,C], times[T], obs[B,4,T]) ->
+        traj  [T,N,B,S]  (the host hands out .permute(2,3,1,0) = the reference's [B,S,N,T] view, ode.py:82)
+        xpred [T,4,B,S]
+        logp  [4,B,S]
+    Any subset of the three outputs may be used downstream; unused ones cost nothing in backward.
+    """
+
+    @staticmethod
+    def forward(ctx, spec, theta, cond, times, obs, dev1hot, weights):
+        _require_cuda(theta, cond, times, obs)
+        theta, cond, times, obs = _c(theta), _c(cond), _c(times), _c(obs)
+        R, B, S = theta.shape
+        T = times.shape[0]
+        if R != spec.n_rows:
+            raise RuntimeError("theta has %d rows, problem expects %d" % (R, spec.n_rows))
+        prob = spec.bind(B, S, T)
+        N = spec.n_states
+        traj = torch.empty((T, N, B, S), device=theta.device, dtype=torch.float32)
+        xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32)
+        logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
+        rc = hip.lib().vihds_ode_fwd(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
+                                     hip.ptr(times), hip.ptr(obs), hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred),
+                                     hip.ptr(logp), hip.current_stream())
+        hip.check(rc, "vihds_ode_fwd")
+        ctx.spec, ctx.prob = spec, prob
+        ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
+        ctx.set_materialize_grads(False)
+        return traj, xpred, logp
+
+    @staticmethod
+    def backward(ctx, g_traj, g_xpred, g_logp):
+        theta, cond, times, obs, traj, dev1hot, weights = ctx.saved_tensors
+        g_theta = torch.zeros_like(theta)
+        g_w = torch.zeros_like(weights) if weights is not None else None
+        g_traj, g_xpred, g_logp = _c(g_traj), _c(g_xpred), _c(g_logp)
+        rc = hip.lib().vihds_ode_bwd(ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
+                                     hip.ptr(times), hip.ptr(obs), hip.ptr(weights), hip.ptr(traj), hip.ptr(g_traj),
+                                     hip.ptr(g_xpred), hip.ptr(g_logp), hip.ptr(g_theta), hip.ptr(g_w),
+                                     hip.current_stream())
+        hip.check(rc, "vihds_ode_bwd")
+        return None, g_theta, None, None, None, None, g_w
+
+
+class ThetaSampleLogProb(torch.autograd.Function):
+    """q.sample(u) -> p.clip -> (theta, log q(theta), log p(theta)) for all P parameters in one kernel.
+
+    q_mu, q_prec: [P,B];  p_mu, p_prec, clip_lo, clip_hi: [P];  kind: int32 [P];  u: [B,S,P]
+    returns theta [n_rows,B,S] (rows P.. are zero, for the caller to fill), log_q [B,S], log_p [B,S]
+    """
+
+    @staticmethod
+    def forward(ctx, q_mu, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows):
+        _require_cuda(q_mu, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u)
+        q_mu, q_prec, u = _c(q_mu), _c(q_prec), _c(u)
+        P, B = q_mu.shape
+        S = u.shape[1]
+        if u.shape[0] != B or u.shape[2] != P:
+            raise RuntimeError("u must be [B,S,P]")
+        if n_rows > P:
+            theta = torch.zeros((n_rows, B, S), device=u.device, dtype=torch.float32)
+        else:
+            theta = torch.empty((P, B, S), device=u.device, dtype=torch.float32)
+        log_q = torch.empty((B, S), device=u.device, dtype=torch.float32)
+        log_p = torch.empty((B, S), device=u.device, dtype=torch.float32)
+        rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_mu), hip.ptr(q_prec), hip.ptr(p_mu),
+                                       hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
+                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), hip.current_stream())
+        hip.check(rc, "vihds_theta_fwd")
+        ctx.save_for_backward(q_mu, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u)
+        ctx.set_materialize_grads(False)
+        return theta, log_q, log_p
+
+    @staticmethod
+    def backward(ctx, g_theta, g_log_q, g_log_p):
+        q_mu, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u = ctx.saved_tensors
+        P, B = q_mu.shape
+        S = u.shape[1]
+        g_theta, g_log_q, g_log_p = _c(g_theta), _c(g_log_q), _c(g_log_p)
+        g_mu = torch.empty_like(q_mu)
+        g_prec = torch.empty_like(q_prec)
+        rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_mu), hip.ptr(q_prec), hip.ptr(p_mu),
+                                       hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
+                                       hip.ptr(g_theta), hip.ptr(g_log_q), hip.ptr(g_log_p), hip.ptr(g_mu),
+                                       hip.ptr(g_prec), hip.current_stream())
+        hip.check(rc, "vihds_theta_bwd")
+        return g_mu, g_prec, None, None, None, None, None, None, None
+
+
+class IwaeRows(torch.autograd.Function):
+    """log_w = sum_j logp[j] + log_p - log_q and its per-row (max, sum-exp).  Returns (log_w, row_max,
+    row_sumexp); gradients flow back through `lse` via :func:`iwae_lse`."""
+
+    @staticmethod
+    def forward(ctx, logp, log_p, log_q):
+        _require_cuda(logp, log_p, log_q)
+        logp, log_p, log_q = _c(logp), _c(log_p), _c(log_q)
+        _, B, S = logp.shape
+        log_w = torch.empty((B, S), device=logp.device, dtype=torch.float32)
+        row_max = torch.empty((B,), device=logp.device, dtype=torch.float32)
+        row_se = torch.empty((B,), device=logp.device, dtype=torch.float32)
+        rc = hip.lib().vihds_iwae_fwd(B, S, hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q), hip.ptr(log_w),
+                                      hip.ptr(row_max), hip.ptr(row_se), hip.current_stream())
+        hip.check(rc, "vihds_iwae_fwd")
+        ctx.has = (log_p is not None, log_q is not None)
+        ctx.mark_non_differentiable(row_max, row_se)
+        return log_w, row_max, row_se
+
+    @staticmethod
+    def backward(ctx, g_logw, _gm, _gs):
+        if g_logw is None:
+            return None, None, None
+        g4 = g_logw.unsqueeze(0).expand(4, -1, -1)
+        return g4, (g_logw if ctx.has[0] else None), (-g_logw if ctx.has[1] else None)
+
+
+class _LseFromLogw(torch.autograd.Function):
+    """lse[b] given log_w and the (possibly cross-rank combined) lse; backward = softmax weights kernel."""
+
+    @staticmethod
+    def forward(ctx, log_w, lse):
+        ctx.save_for_backward(log_w, lse)
+        return lse.clone()
+
+    @staticmethod
+    def backward(ctx, g_lse):
+        log_w, lse = ctx.saved_tensors
+        B, S = log_w.shape
+        g_lse = _c(g_lse)
+        g_logw = torch.empty_like(log_w)
+        rc = hip.lib().vihds_iwae_bwd(B, S, hip.ptr(log_w), hip.ptr(lse), hip.ptr(g_lse), hip.ptr(g_logw),
+                                      hip.current_stream())
+        hip.check(rc, "vihds_iwae_bwd")
+        return g_logw, None
+
+
+def iwae_lse(logp, log_p, log_q, group=None):
+    """Row-wise logsumexp of the importance weights (vihds/training.py:141-144).
+
+    With ``group`` (a torch.distributed process group over which the S axis is sharded) the per-row
+    (max, sum-exp) pairs are combined with two tiny all-reduces; the backward needs no communication because
+    the local softmax weights only need the global lse."""
+    log_w, row_max, row_se = IwaeRows.apply(logp, log_p, log_q)
+    if group is not None:
+        import torch.distributed as dist
+
+        gmax = row_max.clone()
+        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+        se = row_se * torch.exp(row_max - gmax)
+        dist.all_reduce(se, op=dist.ReduceOp.SUM, group=group)
+        lse = gmax + torch.log(se)
+    else:
+        lse = row_max + torch.log(row_se)
+    return _LseFromLogw.apply(log_w, lse), log_w
+
+
+def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None):
+    """-ELBO exactly as Training.cost forms it (vihds/training.py:144-149)."""
+    lse, log_w = iwae_lse(logp, log_p, log_q, group)
+    S = n_iwae_total if n_iwae_total is not None else log_w.shape[1]
+    return -(lse - math.log(S)).mean(), log_w, lse
+
+
+def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None):
+    """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99)."""
+    _require_cuda(log_w, lse, traj, xpred)
+    T, N, B, S = traj.shape
+    dev = traj.device
+    mu = torch.empty((B, 4, T), device=dev)
+    sd = torch.empty((B, 4, T), device=dev)
+    st = torch.empty((B, n_species, T), device=dev)
+    var = torch.empty((B, 4, T), device=dev)
+    rows = (ctypes.c_int * 4)(*prec_rows) if prec_rows is not None else None
+    rc = hip.lib().vihds_iw_summaries(B, S, T, N, n_species, hip.ptr(_c(log_w)), hip.ptr(_c(lse)), hip.ptr(traj),
+                                      hip.ptr(xpred), hip.ptr(theta), rows, hip.ptr(mu), hip.ptr(sd), hip.ptr(st),
+                                      hip.ptr(var), hip.current_stream())
+    hip.check(rc, "vihds_iw_summaries")
+    return mu, sd, st, var
