@@ -1,0 +1,190 @@
+#!/usr/bin/env python3
+"""Headline benchmark: ELBO training steps/sec on dr_constant_icml (B=36 rows, n_iwae=200, T=86, RK4), fp32.
+
+  python bench.py --gpus N --steps K --warmup W
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = Training._run_batch semantics (reference vihds/training.py:324-340): draw u -> encoder -> sample/clip
+theta + log q/log p (theta kernel) -> integrate + observe + log-likelihood (ODE kernel) -> IWAE loss -> backward
+through all three hand-written adjoints and the encoder -> Adam.  Inputs (the 36-row batch) are resident in HBM;
+u is drawn on the device inside the step.  N > 1: the IWAE-sample axis is sharded, every rank integrates 200
+samples per row (weak scaling: global n_iwae = 200*N), two [36]-float all-reduces combine the row logsumexp and
+one flat all-reduce sums the parameter gradients; `value` counts N step-equivalents per iteration.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
+(ODE adjoint) and `cpu_baseline` (the oracle's op-by-op CPU restatement of the same step, timed here)."""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for _p in (ROOT, os.path.join(ROOT, "vi-hds_amd")):
+    if _p not in sys.path:
+        sys.path.insert(0, _p)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+B_ROWS, N_IWAE, N_TIMES, N_STATES, N_PARAMS = 36, 200, 86, 8, 35
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def algorithmic_bytes(B, S, T=N_TIMES, N=N_STATES, P=N_PARAMS):
+    """fwd = read theta + write trajectory + write x_predict; bwd = read trajectory + write d theta."""
+    fwd = 4 * (P * B * S + B * S * N * T + B * S * 4 * T)
+    bwd = 4 * (B * S * N * T + P * B * S)
+    return fwd, bwd
+
+
+def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=6):
+    """The oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd, Adam) timed on this
+    box's host cores on the same workload.  Checker code used as a *reported baseline* only."""
+    from oracle import vihds_oracle as O
+    from vihds import synthetic
+
+    threads = torch.get_num_threads()
+    args, settings, data, parameters, model, training = synthetic.build(
+        "dr_constant_icml", B_ROWS, N_IWAE, solver=solver, device="cpu", seed=0, observations=observations)
+    enc = model.encoder
+    opt = torch.optim.Adam(enc.parameters(), lr=0.01)
+    batch = training.train_data
+    names = enc.names
+    kinds = [d.kind for d in enc.descs]
+    _, pm, pp = enc.p.image("cpu", 1)
+    p_mu, p_prec = [pm[i, 0] for i in range(len(names))], [pp[i, 0] for i in range(len(names))]
+    rel = {k: torch.tensor(v) for k, v in settings.data.relevance_vectors.items()}
+    times_s = []
+    steps = 0
+    t_all = time.perf_counter()
+    while steps < max_steps and (time.perf_counter() - t_all) < seconds_budget:
+        t0 = time.perf_counter()
+        u = torch.tensor(np.random.randn(B_ROWS, N_IWAE, len(names)).astype(np.float32))
+        q = enc(batch)
+        _, q_mu, q_prec = q.image("cpu", B_ROWS)
+        qm = [q_mu[i][:, None] for i in range(len(names))]
+        qp = [q_prec[i][:, None] for i in range(len(names))]
+        th = O.sample_clip_theta(names, kinds, qm, qp, p_mu, p_prec, u)
+        ones = torch.ones(B_ROWS, N_IWAE)
+        for k in ("aR", "aS"):
+            w = 2.0 + 1.5 * torch.randn(1, batch.dev_1hot.shape[1])
+            th[k] = O.device_conditioner(w, ones, rel[k], batch.dev_1hot, True)
+        out = O.elbo_from_theta("dr_constant", names, kinds, th, qm, qp, p_mu, p_prec, batch.inputs, batch.times,
+                                batch.observations, solver)
+        out["loss"].backward()
+        opt.step()
+        opt.zero_grad()
+        times_s.append(time.perf_counter() - t0)
+        steps += 1
+    med = float(np.median(times_s[1:] if len(times_s) > 1 else times_s))
+    return {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median of all but "
+                      "the first; eager PyTorch CPU restatement of the reference path (oracle/), %d threads"
+                      % (steps, B_ROWS, N_IWAE, N_TIMES, solver, threads),
+            "ms_per_step": 1e3 * med}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--solver", default="rk4")
+    ap.add_argument("--eager", action="store_true", help="launch every kernel from python instead of replaying a hipGraph")
+    ap.add_argument("--host-rng", action="store_true", help="draw u with host numpy as the reference does (vae.py:22-24)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--roofline-steps", type=int, default=20)
+    a = ap.parse_args()
+
+    from vihds import ops, parallel, synthetic
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
+                         % (a.gpus, world))
+    shard = parallel.init_from_env()
+    rank = shard.rank if shard is not None else 0
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    use_graph = not a.eager and not a.host_rng
+    # every rank: same seed => same encoder init, same DeviceConditioner draws, same full u (sliced per rank)
+    args, settings, data, parameters, model, training = synthetic.build(
+        "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=0, shard=shard,
+        u_rng="numpy" if a.host_rng else "device", conditioner_rng="cpu" if a.host_rng else "device",
+        hip_graph=use_graph, nan_check_every=0)
+    model.train()
+    batch = training.train_data
+    step = training.graph_step if use_graph else training.step
+
+    def barrier():
+        torch.cuda.synchronize()
+        if shard is not None:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        loss = step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if shard is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t)
+    final_loss = float(loss)
+    if not np.isfinite(final_loss):
+        raise SystemExit("non-finite loss %r after the timed steps" % final_loss)
+
+    # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
+    ops.TIMER = ops.KernelTimer()
+    for _ in range(a.roofline_steps):
+        training.step(batch)
+    kt = ops.TIMER.summary()
+    ops.TIMER = None
+    fwd_b, bwd_b = algorithmic_bytes(B_ROWS, N_IWAE)
+    dom = "ode_bwd" if kt["ode_bwd"]["mean_us"] >= kt["ode_fwd"]["mean_us"] else "ode_fwd"
+    dom_bytes = bwd_b if dom == "ode_bwd" else fwd_b
+
+    def gbs(nbytes, us):
+        return nbytes / (us * 1e-6) / 1e9
+
+    roofline = {
+        "bound": "hbm", "kernel": "%s_kernel<DrConstant<1>,%s>" % (dom, a.solver),
+        "achieved": gbs(dom_bytes, kt[dom]["mean_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": gbs(dom_bytes, kt[dom]["mean_us"]) / HBM_PEAK_GBS, "traffic": None,
+        "algorithmic_bytes_per_launch": dom_bytes, "mean_us": kt[dom]["mean_us"], "launches_timed": kt[dom]["launches"],
+        "other_kernel": {"kernel": "ode_fwd" if dom == "ode_bwd" else "ode_bwd",
+                         "mean_us": kt["ode_fwd" if dom == "ode_bwd" else "ode_bwd"]["mean_us"],
+                         "achieved": gbs(fwd_b if dom == "ode_bwd" else bwd_b,
+                                         kt["ode_fwd" if dom == "ode_bwd" else "ode_bwd"]["mean_us"])},
+        "step_algorithmic_bytes": fwd_b + bwd_b,
+    }
+    if rank != 0:
+        return
+    out = {
+        "metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)",
+        "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
+                               "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
+                   "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
+                   "launch": "hipGraph replay" if use_graph else "eager", "u_rng": "host numpy" if a.host_rng else "device philox",
+                   "parallelism": "iwae-sample shard x%d" % world},
+        "final_loss": final_loss, "roofline": roofline,
+    }
+    if world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(a.solver, batch.observations.detach().cpu())
+        out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

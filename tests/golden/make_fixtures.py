@@ -272,7 +272,80 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
         },
     }
     fx["config_json"] = np.array(json.dumps(cfg))
+    # the experiment definition this case ran with (parsed YAML: data + model + params blocks), so the GPU
+    # end-to-end test can build the same model without /root/reference
+    import yaml
+
+    with open("specs/%s.yaml" % spec) as fh:
+        fx["spec_json"] = np.array(json.dumps(yaml.safe_load(fh)))
+    fx["devices"] = np.asarray(batch.devices)
     return fx
+
+
+def run_training_trace(spec, solver, n_iwae, epochs, seed):
+    """Run the reference's own Training.run() (run_xval.run_on_split) for a few epochs and record the loss of
+    every training step plus the evaluation ELBOs, together with the processed dataset it ran on, so the GPU
+    build can be driven through the identical sequence (same seeds => same shuffles, u draws and conditioner
+    weights) on a box that has neither the reference nor its CSV files."""
+    import torch
+    from vihds.config import Config
+    from vihds.datasets import build_datasets
+    from vihds.parameters import Parameters
+    from vihds.run_xval import create_parser
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    parser = create_parser(True)
+    args = parser.parse_args(["--train_samples=%d" % n_iwae, "--test_samples=%d" % n_iwae, "--seed=%d" % seed,
+                              "--epochs=%d" % epochs, "--test_epoch=%d" % epochs, "--plot_epoch=0",
+                              "specs/%s.yaml" % spec])
+    args.heldout = None
+    settings = Config(args)
+    settings.params.solver = solver
+    data = build_datasets(args, settings)
+    parameters = Parameters(settings.params)
+    model = build_model(args, settings, data, parameters)
+    training = Training(args, settings, data, parameters, model)
+    losses = []
+    orig_cost = training.cost
+
+    def recording_cost(*a, **k):
+        out = orig_cost(*a, **k)
+        if not k.get("full_output", False):
+            losses.append(float(out.elbo))
+        return out
+
+    training.cost = recording_cost
+    evals = []
+    orig_eval = training._evaluate_elbo_and_plot
+
+    def recording_eval(*a, **k):
+        out = orig_eval(*a, **k)
+        evals.append(float(out.elbo))
+        return out
+
+    training._evaluate_elbo_and_plot = recording_eval
+    os.makedirs(".vihds_cache_fixture", exist_ok=True)
+    cwd = os.getcwd()
+    os.chdir(tempfile.mkdtemp())  # Results.dump writes .vihds_cache relative to cwd
+    try:
+        training.run()
+    finally:
+        os.chdir(cwd)
+    ds = data.train.dataset
+    import yaml
+
+    with open("specs/%s.yaml" % spec) as fh:
+        spec_dict = yaml.safe_load(fh)
+    return {
+        "step_losses": np.array(losses, np.float64), "valid_elbo": np.array(evals, np.float64),
+        "times": to_np(ds.times), "devices": np.asarray(ds.devices), "dev_1hot": to_np(ds.dev_1hot),
+        "inputs": to_np(ds.inputs), "observations": to_np(ds.observations),
+        "train_ids": np.asarray(data.train.indices), "valid_ids": np.asarray(data.test.indices),
+        "spec_json": np.array(json.dumps(spec_dict)),
+        "config_json": np.array(json.dumps({"spec": spec, "model": settings.model, "solver": solver, "n_iwae": n_iwae,
+                                            "epochs": epochs, "seed": seed, "folds": 4, "split": 1})),
+    }
 
 
 PROVENANCE = (
@@ -311,6 +384,16 @@ def main():
     patch_merge_observations()
     import torch
 
+    if not a.only or "trace" in a.only:
+        for name, spec, solver, S, epochs in [("trace_dr_constant_icml_modeuler", "dr_constant_icml", "modeuler", 20, 4),
+                                              ("trace_auto_constant_modeuler", "auto_constant", "modeuler", 20, 6)]:
+            fx = run_training_trace(spec, solver, S, epochs, 0)
+            fx["provenance"] = np.array(PROVENANCE + " [training trace: run_on_split semantics, losses per step] torch %s numpy %s"
+                                        % (torch.__version__, np.__version__))
+            out = os.path.join(HERE, name + ".npz")
+            np.savez_compressed(out, **fx)
+            print("wrote %s  steps=%d first=%.4f last=%.4f valid=%s" % (out, len(fx["step_losses"]), fx["step_losses"][0],
+                                                                        fx["step_losses"][-1], fx["valid_elbo"]))
     for name, spec, solver, S, rows, stride in CASES:
         if a.only and a.only not in name:
             continue

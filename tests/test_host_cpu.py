@@ -1,0 +1,139 @@
+"""CPU-only tests of the host side: the C ABI library loads and exports every symbol include/vihds_hip.h
+declares, the YAML -> parameter tables match what the reference built, the batched encoder initialises to the
+reference's weights under the same seed, and the product path refuses to run without a GPU."""
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from fixture_util import ALL_FIXTURES, Fixture, rel_err
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    from vihds import hip
+
+    header = open(os.path.join(ROOT, "include", "vihds_hip.h")).read()
+    declared = sorted(set(re.findall(r"\b(vihds_[a-z_0-9]+)\s*\(", header)))
+    assert declared, "no declarations parsed"
+    lib = hip.lib()
+    for name in declared:
+        assert hasattr(lib, name), "libvihds_hip.so does not export %s" % name
+    assert sorted(hip.exported_symbols()) == declared
+    assert lib.vihds_abi_version() == 1
+
+
+def test_model_slot_tables():
+    from vihds import hip
+
+    dr = hip.model_slots("dr_constant")
+    assert len(dr) == 37 and dr[:4] == ["r", "K", "tlag", "rc"] and dr[-4:] == ["prec_x", "prec_rfp", "prec_yfp", "prec_cfp"]
+    assert "eS6" in hip.model_slots("dr_constant_v2") and "KR6" not in hip.model_slots("dr_constant_v2")
+    assert hip.lib().vihds_model_n_states(hip.MODELS["relay_constant"]) == 12
+    assert hip.lib().vihds_model_n_states(hip.MODELS["degrader_constant"]) == 11
+    assert hip.lib().vihds_model_n_states(99) < 0
+
+
+@pytest.mark.parametrize("name", ALL_FIXTURES)
+def test_parameter_tables_match_reference(name):
+    """names / order / kinds / prior (mu, prec) / clip bounds as the reference derived them from the same YAML."""
+    import e2e_util as E
+    from vihds.encoders import Encoder
+
+    fx = Fixture(name)
+    args, settings, data, parameters = E.build_from_fixture(fx)
+    assert [d.name for d in parameters.ordered()] == fx.names
+    assert [d.kind for d in parameters.ordered()] == fx.kinds
+    enc = Encoder(parameters, data, False, device="cpu")
+    _, pm, pp = enc.p.image("cpu", 1)
+    live = torch.tensor([k != 2 for k in fx.kinds])
+    assert torch.equal(pm[:, 0][live], fx.t("p_mu")[live])
+    assert torch.allclose(pp[:, 0][live], fx.t("p_prec")[live], rtol=1e-7)
+    # clip at 4 sigma reproduces the reference's clipped samples exactly where clipping was active
+    lo, hi = enc.p.clip_image(4.0, "cpu")
+    un, cl = fx.t("theta_unclipped"), fx.t("theta")
+    assert torch.allclose(torch.minimum(torch.maximum(un, lo[:, None, None]), hi[:, None, None]), cl, rtol=1e-6)
+
+
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
+                                  "dr_constant_one_modeuler", "dr_constant_precisions_tiny_modeuler"])
+def test_encoder_initialises_to_reference_weights_and_q(name):
+    """Same torch seed => the batched heads hold exactly the weights of the reference's per-parameter Linear(n,1)
+    heads, and q(mu, prec) for the fixture batch equals the reference's."""
+    import e2e_util as E
+    from vihds.vae import build_model
+
+    fx = Fixture(name)
+    args, settings, data, parameters = E.build_from_fixture(fx)
+    model = build_model(args, settings, data, parameters)
+    enc = model.encoder
+    ref = {k[len("encoder_param/"):]: fx.t(k) for k in fx.z.files if k.startswith("encoder_param/")}
+    assert torch.equal(enc.conditional.conv.weight, ref["conditional.conv.weight"])
+    assert torch.equal(enc.conditional.lin.weight, ref["conditional.lin.weight"])
+    for i, d in enumerate(enc.local):
+        assert torch.equal(enc.local_heads.weight[2 * i], ref["q_local_defs.%s.layers.mu.weight" % d.name][0])
+        assert torch.equal(enc.local_heads.weight[2 * i + 1], ref["q_local_defs.%s.layers.log_prec.weight" % d.name][0])
+        assert torch.equal(enc.local_heads.bias[2 * i], ref["q_local_defs.%s.layers.mu.bias" % d.name][0])
+    for i, d in enumerate(enc.gcond):
+        assert torch.equal(enc.gcond_heads.weight[2 * i], ref["q_global_cond_defs.%s.layers.mu.weight" % d.name][0])
+    for i, d in enumerate(enc.glob):
+        assert float(enc.global_free[i, 0]) == float(ref["q_global_defs.%s.free_params.mu" % d.name])
+        assert float(enc.global_free[i, 1]) == float(ref["q_global_defs.%s.free_params.log_prec" % d.name])
+    # decoder-side neural weights follow in the same RNG stream
+    dref = {k[len("decoder_param/"):]: fx.t(k) for k in fx.z.files if k.startswith("decoder_param/")}
+    for k, v in dict(model.decoder.named_parameters()).items():
+        assert torch.equal(v.detach(), dref[k]), k
+    q = enc(E.batch_from_fixture(fx, "cpu"))
+    _, q_mu, q_prec = q.image("cpu", fx.B)
+    live = torch.tensor([k != 2 for k in fx.kinds])
+    assert rel_err(q_mu[live], fx.t("q_mu")[live]) < 1e-5
+    assert rel_err(q_prec[live], fx.t("q_prec")[live]) < 1e-5
+    assert q.get_tensor_names()[:2] == ["%s.mu" % fx.names[0], "%s.prec" % fx.names[0]]
+
+
+def test_product_path_refuses_cpu_tensors():
+    """No CPU fallback: the ops raise instead of silently computing elsewhere."""
+    from vihds import ops
+
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.IwaeRows.apply(torch.zeros(4, 2, 3), None, None)
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    import hip_util as H
+
+    th, row_of = H.pack_theta(fx, "cpu")
+    spec = H.spec_for(fx, row_of, th.shape[0])
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.OdeSolveObserve.apply(spec, th, fx.t("inputs"), fx.t("times"), fx.t("observations"), None, None)
+
+
+def test_lookup_has_reference_keys():
+    import models
+
+    keys = {"debug_constant", "auto_constant", "auto_constant_precisions", "degrader_constant_precisions",
+            "dr_constant", "dr_constant_v2", "dr_constant_precisions", "dr_constant_precisions_v2", "dr_blackbox",
+            "inducer_constant", "inducer_constant_precisions", "prpr_constant", "prpr_constant_precisions",
+            "relay_constant", "relay_constant_precisions"}  # reference models/__init__.py:19-35
+    assert keys <= set(models.LOOKUP)
+    with pytest.raises(NotImplementedError):
+        models.LOOKUP["inducer_constant"](None)
+
+
+def test_device_conditioner_reproduces_reference_values():
+    """aR/aS of the full fixture = 1 + relu(w . (dev_1hot * relevance)) with the reference's tiling quirk."""
+    import e2e_util as E
+    from vihds.vae import build_model
+
+    fx = Fixture("dr_constant_icml_full_modeuler")
+    args, settings, data, parameters = E.build_from_fixture(fx)
+    model = build_model(args, settings, data, parameters)
+    np.random.seed(fx.cfg["seed"] + 1)
+    torch.manual_seed(fx.cfg["seed"] + 1)
+    ode = model.decoder.ode_model
+    ones = torch.ones(fx.B, fx.S)
+    aR = ode.device_conditioner(ones, "aR", fx.t("dev_1hot"))
+    aS = ode.device_conditioner(ones, "aS", fx.t("dev_1hot"))
+    assert rel_err(aR, fx.t("extra_theta")[0]) < 1e-6
+    assert rel_err(aS, fx.t("extra_theta")[1]) < 1e-6

@@ -1,0 +1,79 @@
+"""Black-box double-receiver model (plugin class of the reference's models/dr_blackbox.py:61-125): the RHS is
+two small MLPs (NeuralStates, NeuralPrecisions) whose weights live here; the arithmetic runs in the kernel."""
+import torch
+import torch.nn as nn
+
+from vihds.ode import OdeModel
+from vihds.precisions import NeuralPrecisions
+from vihds.utils import default_get_value, variable_summaries
+
+
+class NeuralStates(nn.Module):
+    """Weights of dx = sigmoid(W_p h) - sigmoid(W_d h) * x, h = relu(W_h [x, const]) (reference ode.py:119-146)."""
+
+    def __init__(self, n_inputs, n_hidden, n_states, n_latents):
+        super(NeuralStates, self).__init__()
+        self.n_latents, self.n_states = n_latents, n_states
+        self.states_hidden = nn.Linear(n_inputs, n_hidden)
+        nn.init.xavier_uniform_(self.states_hidden.weight)
+        self.states_production = nn.Linear(n_hidden, n_states)
+        nn.init.xavier_uniform_(self.states_production.weight)
+        self.states_degradation = nn.Linear(n_hidden, n_states)
+        nn.init.xavier_uniform_(self.states_degradation.weight)
+
+    def flat_weights(self):
+        mods = [self.states_hidden, self.states_production, self.states_degradation]
+        return torch.cat([t.reshape(-1) for m in mods for t in (m.weight, m.bias)])
+
+    def summaries(self, writer, epoch):
+        if writer is not None:
+            for name in ["states_hidden", "states_production", "states_degradation"]:
+                module = getattr(self, name)
+                variable_summaries(writer, epoch, module.weight, name + "_weights", False)
+                variable_summaries(writer, epoch, module.bias, name + "_bias", False)
+
+
+class DR_Blackbox(OdeModel):
+    model_key = "dr_blackbox"
+    observe_kind = "direct"
+
+    def __init__(self, config):
+        super(DR_Blackbox, self).__init__(config)
+        p = config.params
+        self.n_x, self.n_y, self.n_z = p.n_x, p.n_y, p.n_z
+        n_latents = self.n_x + self.n_y + self.n_z
+        self.n_species = 4
+        self.n_latent_species = p.n_latent_species
+        self.n_hidden_precisions = p.n_hidden_decoder_precisions
+        self.n_states = self.n_species + self.n_latent_species
+        n_inputs = self.n_states + n_latents + self.n_treatments + self.device_depth
+        self.precisions = NeuralPrecisions(n_inputs, self.n_hidden_precisions, 4, hidden_activation=nn.ReLU)
+        self.species = ["OD", "RFP", "YFP", "CFP"]
+        self.n_hidden = p.n_hidden_decoder
+        self.init_latent_species = default_get_value(p, "init_latent_species", 0.001)
+        self.init_prec = default_get_value(p, "init_prec", 0.00001)
+        self.offset_layer = nn.Linear(self.device_depth, self.n_y)
+        self.neural_states = NeuralStates(n_inputs, p.n_hidden_decoder, self.n_states, n_latents)
+
+    def condition_theta(self, theta, dev_1hot, writer, epoch):
+        """y_i += offset_layer(dev_1hot)_i (reference dr_blackbox.py:86-96); re-binds the attribute only."""
+        offset = self.offset_layer(dev_1hot)  # [B, n_y]
+        for i in range(self.n_y):
+            pname = "y%d" % (i + 1)
+            setattr(theta, pname, getattr(theta, pname) + offset[:, i: i + 1])
+        return theta
+
+    def neural_weights(self):
+        return torch.cat([self.neural_states.flat_weights(), self.precisions.flat_weights()])
+
+    def problem_kwargs(self, config):
+        return {
+            "n_hidden_prec": int(self.n_hidden_precisions), "n_hidden_states": int(self.n_hidden),
+            "n_latent_states": int(self.n_latent_species),
+            "n_const": self.n_x + self.n_y + self.n_z + self.n_treatments + self.device_depth,
+            "init_latent": float(self.init_latent_species), "init_prec": float(self.init_prec),
+        }
+
+    def summaries(self, writer, epoch):
+        self.neural_states.summaries(writer, epoch)
+        self.precisions.summaries(writer, epoch)

@@ -1,0 +1,146 @@
+"""YAML + argparse -> Config, with the reference's attribute names and defaults (vihds/config.py).
+
+Host-side plumbing only: nothing here is on the hot path."""
+import datetime
+import os
+import re
+import shutil
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import yaml
+
+from vihds.utils import AttrDict, attrify
+
+PARAM_DEFAULTS = {
+    # reference vihds/config.py:56-88
+    "solver": "midpoint", "adjoint_solver": False, "use_laplace": False, "n_filters": 10, "filter_size": 10,
+    "pool_size": 5, "lambda_l2": 0.001, "lambda_l2_hidden": 0.001, "n_hidden": 50, "n_hidden_decoder": 50,
+    "n_batch": 36, "data_format": "channels_last", "precision_type": "constant", "precision_alpha": 1000.0,
+    "precision_beta": 1.0, "init_prec": 0.00001, "init_latent_species": 0.001, "transfer_func": "tanh",
+    "n_hidden_decoder_precisions": 20, "n_growth_layers": 4, "tb_gradients": False, "plot_histograms": False,
+    "learning_boundaries": [250, 500], "learning_rate": 0.01, "learning_gamma": 0.2,
+    # additions of this implementation (documented in DESIGN.md); every one defaults to reference behaviour
+    "u_rng": "numpy",          # "numpy": host RNG as vae.py:22-24 | "device": torch Philox on the GPU
+    "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48)
+    "hip_graph": False,        # capture the whole training step in a hipGraph
+    "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
+}
+
+
+def _tidy_args(args):
+    """reference vihds/config.py:18-37: clamp test/plot epochs, seed numpy and torch."""
+    print("Processing command-line arguments")
+    print("-", args)
+    if args.test_epoch > args.epochs:
+        print("- Setting test_epoch to %d" % args.epochs)
+        args.test_epoch = args.epochs
+    if args.plot_epoch > args.epochs:
+        print("- Setting plot_epoch to %d" % args.epochs)
+        args.plot_epoch = args.epochs
+    if args.seed is not None:
+        print("- Setting: np.random.seed({})".format(args.seed))
+        np.random.seed(args.seed)
+        print("- Setting: torch.manual_seed({})".format(args.seed))
+        torch.manual_seed(args.seed)
+    return args
+
+
+def apply_defaults_params(config):
+    out = attrify(dict(PARAM_DEFAULTS))
+    for k in config:
+        out[k] = config[k]
+    return out
+
+
+def depth(group_values):
+    return len(set(g for g in group_values if g is not None))
+
+
+def proc_data(ds):
+    """Device/group bookkeeping (reference vihds/config.py:95-121)."""
+    groups = list(ds.groups.items())
+    ds.component_maps = OrderedDict((k, OrderedDict(zip(ds.devices, g))) for k, g in groups)
+    ds.device_depth = sum(depth(cm.values()) for cm in ds.component_maps.values())
+    ds.relevance_vectors = OrderedDict()
+    k1 = 0
+    for k, g in groups:
+        k2 = k1 + depth(g)
+        rv = np.zeros(ds.device_depth)
+        rv[k1:k2] = 1.0
+        if k in ds.default_devices:
+            rv[k1 + ds.default_devices[k]] = 0.0
+        ds.relevance_vectors[k] = rv.astype(np.float32)
+        k1 = k2
+    ds.device_map = dict(zip(ds.devices, (float(v) for v in range(len(ds.devices)))))
+    ds.device_idx_to_device_name = dict(enumerate(ds.devices))
+    ds.device_lookup = {v: k for k, v in ds.device_map.items()}
+    return ds
+
+
+def get_data_directory():
+    return os.getenv("INFERENCE_DATA_DIR") or "data"
+
+
+def get_results_directory():
+    return os.getenv("INFERENCE_RESULTS_DIR") or "results"
+
+
+def apply_defaults_data(config):
+    out = attrify({
+        "groups": {"default": [0] * len(config.devices)}, "default_devices": dict(), "normalize": None,
+        "merge": True, "subtract_background": True, "separate_conditions": False, "dtype": "float32",
+    })
+    for k in config:
+        out[k] = config[k]
+    out.data_dir = get_data_directory()
+    return proc_data(out)
+
+
+class Config(object):
+    """settings.{data, params, model, seed, device, trainer} (reference vihds/config.py:143-179)."""
+
+    def __init__(self, args=None, spec=None):
+        if args is not None:
+            args = _tidy_args(args)
+            if args.yaml is None:
+                return
+            with open(args.yaml, "r") as stream:
+                spec = yaml.safe_load(stream)
+        spec = attrify(spec)
+        self.data = apply_defaults_data(spec.data)
+        self.params = apply_defaults_params(spec.params)
+        if args is not None and getattr(args, "precision_hidden_layers", None) is not None:
+            self.params.n_hidden_decoder_precisions = args.precision_hidden_layers
+        self.model = spec.model
+        self.seed = getattr(args, "seed", None)
+        gpu = getattr(args, "gpu", None)
+        if self.data.dtype != "float32":
+            raise NotImplementedError("the HIP path computes in float32 (dtype=%s requested)" % self.data.dtype)
+        if gpu is not None and torch.cuda.is_available():
+            print("- GPU mode computation")
+            self.device = torch.device("cuda:" + str(gpu))
+            torch.cuda.set_device(self.device)
+        else:
+            print("- CPU mode computation")
+            self.device = torch.device("cpu")
+        self.trainer = None
+
+
+class Trainer(object):
+    """Results directory + copy of the YAML (reference vihds/config.py:203-227)."""
+
+    def __init__(self, args, log_dir=None, add_timestamp=False):
+        self.results_dir = get_results_directory()
+        self.experiment = args.experiment
+        self.yaml_file_name = args.yaml
+        if log_dir is None:
+            name = self.experiment
+            if add_timestamp:
+                name += "_" + re.sub("[^A-Za-z0-9]+", "", datetime.datetime.now().isoformat())
+            self.tb_log_dir = os.path.join(self.results_dir, name)
+            os.makedirs(self.tb_log_dir, exist_ok=True)
+            shutil.copyfile(self.yaml_file_name, os.path.join(self.tb_log_dir, os.path.basename(self.yaml_file_name)))
+        else:
+            self.tb_log_dir = log_dir

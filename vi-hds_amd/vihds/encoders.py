@@ -1,0 +1,167 @@
+"""Encoder: data -> q(theta | x, d), plus the prior p (counterpart of the reference's vihds/encoders.py).
+
+Stays PyTorch-ROCm (conv / linear trunk: SURVEY.md 2 row 15, out of scope as kernels).  Two things differ from
+a literal transcription, both value-preserving:
+  * the per-parameter `nn.Linear(n, 1)` heads (reference encoders.py:137-141, :183-185) are evaluated as ONE
+    matmul per level; they are *initialised* one head at a time in the reference's construction order, so the same
+    torch seed yields the same weights;
+  * the heads write straight into the packed [P,B] (mu, log_prec) tables the theta kernel reads.
+"""
+from collections import OrderedDict
+
+import torch
+from torch import nn
+
+from vihds.distributions import CLASS_OF_KIND, CONSTANT, ChainedDistribution, TfConstant
+
+
+class ConditionalEncoder(nn.Module):
+    """Conv1d -> AvgPool1d(stride 1) -> flatten -> Linear -> tanh (reference encoders.py:16-55)."""
+
+    def __init__(self, n_channels, n_obs, params):
+        super(ConditionalEncoder, self).__init__()
+        self.n_outputs = params.n_hidden
+        n_conv = n_obs - (params.filter_size - 1)
+        n_pool = n_conv - (params.pool_size - 1)
+        self.conv = nn.Conv1d(n_channels, params.n_filters, params.filter_size)
+        nn.init.orthogonal_(self.conv.weight)
+        self.pool = nn.AvgPool1d(params.pool_size, stride=1)
+        self.lin = nn.Linear(n_pool * params.n_filters, self.n_outputs)
+        nn.init.orthogonal_(self.lin.weight)
+        if params.transfer_func != "tanh":
+            raise Exception("Unknown activation layer %s" % params["transfer_func"])
+        self.act = nn.Tanh()
+
+    def forward(self, x):
+        x = self.pool(self.conv(x))
+        return self.act(self.lin(x.view(x.size(0), -1)))
+
+
+class LocalAndGlobal:
+    """Tuple of local, global-conditional, global and constant items (reference encoders.py:58-92)."""
+
+    def __init__(self, loc, glob_cond, glob, const):
+        self.loc, self.glob_cond, self.glob, self.const = loc, glob_cond, glob, const
+
+    @classmethod
+    def from_list(cls, seq):
+        return cls(seq[0], seq[1], seq[2], seq[3])
+
+    def to_list(self):
+        return [self.loc, self.glob_cond, self.glob, self.const]
+
+    def sum(self):
+        return self.loc + self.glob_cond + self.glob + self.const
+
+
+class _Heads(nn.Module):
+    """All (mu, log_prec) heads of one conditioning level as a single Linear."""
+
+    def __init__(self, descs, n_inputs, use_bias):
+        super(_Heads, self).__init__()
+        ws, bs = [], []
+        for _d in descs:
+            for _free in ("mu", "log_prec"):  # reference construction order, one default-initialised head each
+                layer = nn.Linear(n_inputs, 1, use_bias)
+                ws.append(layer.weight.data)
+                if use_bias:
+                    bs.append(layer.bias.data)
+        self.weight = nn.Parameter(torch.cat(ws, 0))
+        self.bias = nn.Parameter(torch.cat(bs, 0)) if use_bias else None
+
+    def forward(self, x):
+        out = torch.nn.functional.linear(x, self.weight, self.bias)  # [B, 2*n]
+        return out[:, 0::2].t(), out[:, 1::2].t()  # mu [n,B], log_prec [n,B]
+
+
+class Encoder(nn.Module):
+    """reference encoders.py:348-418.  forward(data) -> q (a ChainedDistribution); `.p` is the prior."""
+
+    def __init__(self, parameters, data, verbose=False, device=None):
+        super(Encoder, self).__init__()
+        print("Initialising encoder")
+        self.verbose = verbose
+        self.parameter_specs = parameters  # (the reference shadows nn.Module.parameters here, encoders.py:359)
+        self.n_species = data.train.dataset.n_species
+        self.n_times = data.train.dataset.n_times
+        self.device = torch.device(device) if device is not None else torch.device("cpu")
+        pd = parameters.params_dict
+        self.conditional = ConditionalEncoder(self.n_species, self.n_times - 1, pd)
+        lvl = lambda name: parameters.level(name).descriptions() if parameters.level(name) else []  # noqa: E731
+        self.local, self.gcond, self.glob, self.const = lvl("local"), lvl("global_cond"), lvl("global"), lvl("constant")
+        self.descs = self.local + self.gcond + self.glob + self.const
+        self.names = [d.name for d in self.descs]
+
+        def n_in(descs, with_data):
+            if not descs:
+                return 0, False, False
+            cond = descs[0].conditioning or {}
+            tr, dv = bool(cond.get("treatments", False)), bool(cond.get("devices", False))
+            return (self.conditional.n_outputs if with_data else 0) + (data.n_conditions if tr else 0) + (data.depth if dv else 0), tr, dv
+
+        n_l, self.l_tr, self.l_dv = n_in(self.local, True)
+        n_g, self.g_tr, self.g_dv = n_in(self.gcond, False)
+        self.local_heads = _Heads(self.local, n_l, True) if self.local else None
+        self.gcond_heads = _Heads(self.gcond, n_g, False) if self.gcond else None
+        if self.glob:
+            self.global_free = nn.Parameter(torch.tensor([d.init_free_params for d in self.glob], dtype=torch.float32))
+        else:
+            self.global_free = None
+        self.register_buffer("const_values", torch.tensor([d.value for d in self.const], dtype=torch.float32))
+        self.register_buffer("kind", torch.tensor([d.kind for d in self.descs], dtype=torch.int32))
+        self.to(self.device)
+        self.set_up_p()
+
+    def set_up_p(self):
+        """Prior chain in theta order (reference encoders.py:406-414, :285-345)."""
+        p = ChainedDistribution(name="p")
+        dev = self.device
+        for d in self.descs:
+            if d.kind == CONSTANT:
+                p.add_distribution(d.name, TfConstant(value=torch.tensor([d.value], device=dev)))
+            else:
+                kw = {k: (None if v is None else torch.tensor([v], dtype=torch.float32, device=dev))
+                      for k, v in d.defaults.items()}
+                p.add_distribution(d.name, CLASS_OF_KIND[d.kind](**kw))
+        self.p = p
+
+    def evaluate_q(self, data):
+        B = data.observations.shape[0]
+        obs = data.observations
+        delta_obs = obs[:, :, 1: self.n_times] - obs[:, :, : self.n_times - 1]
+        encoded = self.conditional(delta_obs)
+        mus, lps = [], []
+        if self.local:
+            x = [encoded] + ([data.inputs] if self.l_tr else []) + ([data.dev_1hot] if self.l_dv else [])
+            m, l = self.local_heads(torch.cat(x, 1))
+            mus.append(m), lps.append(l)
+        if self.gcond:
+            x = ([data.inputs] if self.g_tr else []) + ([data.dev_1hot] if self.g_dv else [])
+            m, l = self.gcond_heads(torch.cat(x, 1) if len(x) > 1 else x[0])
+            mus.append(m), lps.append(l)
+        if self.glob:
+            mus.append(self.global_free[:, 0:1].expand(-1, B))
+            lps.append(self.global_free[:, 1:2].expand(-1, B))
+        if self.const:
+            mus.append(self.const_values[:, None].expand(-1, B))
+            lps.append(torch.zeros((len(self.const), B), device=obs.device))
+        q_mu = torch.cat(mus, 0)
+        q_lp = torch.cat(lps, 0)
+        q_prec = q_lp.exp()
+        q = ChainedDistribution(name="q")
+        n_lg = len(self.local) + len(self.gcond)
+        for i, d in enumerate(self.descs):
+            if d.kind == CONSTANT:
+                dist = TfConstant(value=self.const_values[i - n_lg - len(self.glob)].reshape(1))
+            else:
+                dist = CLASS_OF_KIND[d.kind](wait_for_assigned=True, variable=i < n_lg)
+                if i < n_lg:  # one value per data row: [B,1] like the reference's Linear(n,1) output
+                    dist.assign_free_and_constrained(q_mu[i][:, None], q_lp[i][:, None], q_prec[i][:, None])
+                else:  # a single global value: shape [1]
+                    dist.assign_free_and_constrained(q_mu[i][:1], q_lp[i][:1], q_prec[i][:1])
+            q.add_distribution(d.name, dist)
+        q.attach_image(self.kind, q_mu, q_prec)
+        return q
+
+    def forward(self, data):
+        return self.evaluate_q(data)

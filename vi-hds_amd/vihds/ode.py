@@ -1,0 +1,157 @@
+"""OdeModel: the plugin base class of models.LOOKUP (counterpart of the reference's vihds/ode.py).
+
+`simulate` keeps the reference signature and return value ([B,S,N,T], a strided view) but runs the whole time
+loop -- and, fused in the same kernel, observe + the Gaussian log-likelihood -- as ONE HIP kernel
+(vihds_ode_fwd) with a hand-written discrete adjoint (vihds_ode_bwd).  There is no torchdiffeq and no CPU path.
+"""
+import torch
+import torch.nn as nn
+
+from vihds import ops
+from vihds.utils import default_get_value
+
+
+class DecodedSolution(object):
+    """What one fused kernel launch produced for a batch: views in the reference's layouts."""
+
+    def __init__(self, traj, xpred, logp):
+        self.traj_buffer, self.xpred_buffer, self.logp_buffer = traj, xpred, logp  # [T,N,B,S], [T,4,B,S], [4,B,S]
+        self.sol = traj.permute(2, 3, 1, 0)          # [B,S,N,T]  (reference ode.py:82)
+        self.x_predict = xpred.permute(2, 3, 1, 0)   # [B,S,4,T]  (reference ode.py:84-93)
+        self.log_p_by_species = logp.permute(1, 2, 0)  # [B,S,4] (reference training.py:24-33)
+
+
+class DeviceConditioner(nn.Module):
+    """Linear(D,1) -> ReLU with weights ~ N(2, 1.5) (reference ode.py:99-116)."""
+
+    def __init__(self, n_inputs, use_bias=False, activation="relu"):
+        super(DeviceConditioner, self).__init__()
+        self.cond = nn.Linear(n_inputs, 1, use_bias)
+        nn.init.xavier_uniform_(self.cond.weight)
+        nn.init.normal_(self.cond.weight, mean=2.0, std=1.5)
+        self.act = nn.ReLU()
+
+    def forward(self, x):
+        return self.act(self.cond(x))
+
+
+class OdeModel(nn.Module):
+    """Plugin interface (reference ode.py:28-96): subclasses set `species`, `n_species`, `precisions`,
+    `model_key` (the models.LOOKUP key = the kernel to run) and may override condition_theta / observe."""
+
+    model_key = None
+    observe_kind = "default"
+
+    def __init__(self, config):
+        super(OdeModel, self).__init__()
+        self.device_depth = config.data.device_depth
+        self.n_treatments = len(config.data.conditions)
+        self.use_laplace = default_get_value(config.params, "use_laplace", False, verbose=True)
+        if self.use_laplace:
+            raise NotImplementedError("use_laplace: the reference's Laplace log-prob (training.py:36-38) cannot "
+                                      "run (torch.log of a float); only the Gaussian likelihood is implemented")
+        self.precisions = None
+        self.species = None
+        self.n_species = None
+        self.relevance = config.data.relevance_vectors
+        self.default_devices = config.data.default_devices
+        self.device = config.device
+        self.conditioner_rng = default_get_value(config.params, "conditioner_rng", "cpu")
+        self._spec_cache = {}
+        self._tile_index = {}
+        self._relevance_dev = {}
+        self._last = None
+
+    # ---- device conditioning (reference ode.py:43-58) ----------------------------------------------
+    def device_conditioner(self, param, param_name, dev_1hot, use_bias=False, activation="relu"):
+        """NB reference behaviour kept: a NEW DeviceConditioner with fresh N(2,1.5) weights on every call
+         -- the weights are not trained."""
+        n_batch, n_iwae = param.shape[0], param.shape[1]
+        n_inputs = dev_1hot.shape[1]
+        if self.conditioner_rng == "device" and dev_1hot.is_cuda:
+            weight = 2.0 + 1.5 * torch.randn((1, n_inputs), device=dev_1hot.device)
+        else:
+            weight = DeviceConditioner(n_inputs, use_bias=use_bias, activation=activation).cond.weight.detach()
+            weight = weight.to(dev_1hot.device)
+        rkey = (param_name, str(dev_1hot.device))
+        if rkey not in self._relevance_dev:  # uploaded once: no host->device copy inside a captured step
+            self._relevance_dev[rkey] = torch.as_tensor(self.relevance[param_name], device=dev_1hot.device)
+        rel = self._relevance_dev[rkey]
+        cond = torch.relu(torch.nn.functional.linear(dev_1hot * rel, weight)).reshape(-1)  # [B]
+        # Reference quirk kept on purpose (ode.py:46,52-57): `param` is flattened row-major (k = b*S+s) but the
+        # conditioner output is tiled with .repeat([S,1]) (k -> cond[k mod B]), so entry (b,s) is scaled by the
+        # value of row (b*S+s) mod B, not row b.
+        key = (n_batch, n_iwae, str(dev_1hot.device))
+        if key not in self._tile_index:
+            k = torch.arange(n_batch * n_iwae, device=dev_1hot.device)
+            self._tile_index[key] = (k % n_batch).reshape(n_batch, n_iwae)
+        param_cond = cond[self._tile_index[key]]
+        if param_name in self.default_devices:
+            return param * (1.0 + param_cond)
+        return param * param_cond
+
+    def condition_theta(self, theta, dev_1hot, writer, epoch):
+        raise NotImplementedError("TODO: write your condition_theta")
+
+    # ---- kernel problem description -----------------------------------------------------------------
+    def neural_weights(self):
+        """Flat weight buffer for models with neural blocks (None for white-box models)."""
+        return None
+
+    def problem_kwargs(self, config):
+        return {}
+
+    def _spec(self, config, row_of, n_rows):
+        key = (config.params.solver, n_rows, tuple(sorted(row_of.items())))
+        if key not in self._spec_cache:
+            if default_get_value(config.params, "adjoint_solver", False):
+                raise NotImplementedError("adjoint_solver: the HIP path always uses the discrete adjoint")
+            self._spec_cache[key] = ops.OdeProblemSpec(self.model_key, config.params.solver, row_of, n_rows,
+                                                       C=self.n_treatments, D=self.device_depth,
+                                                       **self.problem_kwargs(config))
+        return self._spec_cache[key]
+
+    def solve(self, config, times, theta, conditions, dev_1hot, observations=None):
+        """One fused launch: trajectory, observed signals and (if observations are given) the per-species
+        log-likelihood.  Returns a DecodedSolution."""
+        import vihds.hip as hip
+
+        slots = hip.model_slots(self.model_key)
+        packed, row_of = theta.pack(slots)
+        spec = self._spec(config, row_of, packed.shape[0])
+        dev = packed.device
+        times = times.to(dev)
+        obs = observations
+        if obs is None:  # likelihood not requested: feed zeros (logp output is then meaningless and unused)
+            obs = torch.zeros((packed.shape[1], 4, times.shape[0]), device=dev)
+        traj, xpred, logp = ops.OdeSolveObserve.apply(spec, packed, conditions.to(dev), times, obs.to(dev),
+                                                      dev_1hot.to(dev) if dev_1hot is not None else None,
+                                                      self.neural_weights())
+        self._last = DecodedSolution(traj, xpred, logp)
+        self._last.has_logp = observations is not None
+        return self._last
+
+    # ---- reference entry points ---------------------------------------------------------------------
+    def simulate(self, config, times, theta, conditions, dev_1hot, condition_on_device=True, observations=None):
+        """reference ode.py:66-82 -> [B,S,N,T]."""
+        return self.solve(config, times, theta, conditions, dev_1hot, observations).sol
+
+    def expand_precisions(self, theta, times, x_states):
+        return self.precisions.expand(theta, len(times), x_states)
+
+    def observe(self, x_sample, _theta):
+        """reference ode.py:84-93.  When x_sample is (a view of) the solution just simulated, the fused
+        kernel's x_predict is returned; otherwise the observation map is evaluated with torch ops."""
+        last = self._last
+        if last is not None and x_sample.data_ptr() == last.sol.data_ptr() and x_sample.shape[3] == last.sol.shape[3]:
+            return last.x_predict
+        x0 = x_sample[:, :, 0, :]
+        if self.observe_kind == "default":
+            xp = [x0, x0 * x_sample[:, :, 1, :], x0 * (x_sample[:, :, 2, :] + x_sample[:, :, 4, :]),
+                  x0 * (x_sample[:, :, 3, :] + x_sample[:, :, 5, :])]
+        else:
+            xp = [x0, x0 * x_sample[:, :, 1, :], x0 * x_sample[:, :, 2, :], x0 * x_sample[:, :, 3, :]]
+        return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
+
+    def summaries(self, writer, epoch):
+        pass

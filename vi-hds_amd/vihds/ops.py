@@ -12,6 +12,38 @@ import torch
 from vihds import hip
 
 
+class KernelTimer(object):
+    """HIP-event timing of individual kernel launches on the stream they are enqueued on (torch's current
+    stream = the stream handed to the C ABI).  Enabled by bench.py for its roofline leg only."""
+
+    def __init__(self):
+        self.spans = {}
+
+    def launch(self, name, fn):
+        e0 = torch.cuda.Event(enable_timing=True)
+        e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        rc = fn()
+        e1.record()
+        self.spans.setdefault(name, []).append((e0, e1))
+        return rc
+
+    def summary(self):
+        torch.cuda.synchronize()
+        out = {}
+        for name, evs in self.spans.items():
+            ms = [a.elapsed_time(b) for a, b in evs]
+            out[name] = {"launches": len(ms), "mean_us": 1e3 * sum(ms) / len(ms), "min_us": 1e3 * min(ms)}
+        return out
+
+
+TIMER = None  # set to a KernelTimer to time every ODE kernel launch
+
+
+def _launch(name, fn):
+    return TIMER.launch(name, fn) if TIMER is not None else fn()
+
+
 def _require_cuda(*tensors):
     for t in tensors:
         if t is not None and not t.is_cuda:
@@ -85,9 +117,9 @@ class OdeSolveObserve(torch.autograd.Function):
         traj = torch.empty((T, N, B, S), device=theta.device, dtype=torch.float32)
         xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32)
         logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
-        rc = hip.lib().vihds_ode_fwd(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
-                                     hip.ptr(times), hip.ptr(obs), hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred),
-                                     hip.ptr(logp), hip.current_stream())
+        rc = _launch("ode_fwd", lambda: hip.lib().vihds_ode_fwd(
+            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+            hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred), hip.ptr(logp), hip.current_stream()))
         hip.check(rc, "vihds_ode_fwd")
         ctx.spec, ctx.prob = spec, prob
         ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
@@ -100,10 +132,10 @@ class OdeSolveObserve(torch.autograd.Function):
         g_theta = torch.zeros_like(theta)
         g_w = torch.zeros_like(weights) if weights is not None else None
         g_traj, g_xpred, g_logp = _c(g_traj), _c(g_xpred), _c(g_logp)
-        rc = hip.lib().vihds_ode_bwd(ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
-                                     hip.ptr(times), hip.ptr(obs), hip.ptr(weights), hip.ptr(traj), hip.ptr(g_traj),
-                                     hip.ptr(g_xpred), hip.ptr(g_logp), hip.ptr(g_theta), hip.ptr(g_w),
-                                     hip.current_stream())
+        rc = _launch("ode_bwd", lambda: hip.lib().vihds_ode_bwd(
+            ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+            hip.ptr(weights), hip.ptr(traj), hip.ptr(g_traj), hip.ptr(g_xpred), hip.ptr(g_logp), hip.ptr(g_theta),
+            hip.ptr(g_w), hip.current_stream()))
         hip.check(rc, "vihds_ode_bwd")
         return None, g_theta, None, None, None, None, g_w
 

@@ -1,0 +1,280 @@
+"""Training loop and the IWAE cost (counterpart of the reference's vihds/training.py).
+
+`Training.cost` keeps the reference signature.  Its three reductions -- Gaussian observation log-likelihood over
+time (fused into the ODE kernel), log p(theta) - log q(theta) (fused into the theta kernel) and the
+importance-weight logsumexp (vihds_iwae_fwd) -- all run in HIP kernels.
+"""
+import functools
+import math
+import os
+import time
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader
+
+from vihds import ops, parallel
+from vihds.encoders import LocalAndGlobal
+from vihds.utils import Results, TrainingLogData, attrify, default_get_value, variable_summaries
+
+
+def log_prob_gaussian(x_obs, x_predict, precisions):
+    """reference training.py:41-44 (generic torch fallback for callers that bring their own tensors; still GPU)."""
+    return -0.5 * (math.log(2.0 * math.pi) - precisions.log() + precisions * (x_predict - x_obs).pow(2))
+
+
+def log_prob_observations(model, x_predict, x_obs, precisions, use_laplace=False):
+    """reference training.py:24-33 -> [B,S,4]."""
+    if use_laplace:
+        raise NotImplementedError("Laplace likelihood is dead code in the reference (training.py:36-38)")
+    return torch.sum(log_prob_gaussian(torch.unsqueeze(x_obs, 1), x_predict, precisions), 3)
+
+
+def batch_to_device(times, device, d):
+    """reference training.py:47-52"""
+    d["times"] = times.to(device)
+    d["dev_1hot"] = d["dev_1hot"].to(device)
+    d["inputs"] = d["inputs"].to(device)
+    d["observations"] = d["observations"].to(device)
+    return attrify(d)
+
+
+def collate_merged(times, device, batch):
+    """reference training.py:55-68"""
+    dd = {
+        "devices": torch.stack([torch.tensor(b["devices"]) for b in batch]),
+        "dev_1hot": torch.stack([torch.as_tensor(b["dev_1hot"], dtype=torch.float32) for b in batch]),
+        "inputs": torch.stack([torch.as_tensor(b["inputs"], dtype=torch.float32) for b in batch]),
+        "observations": torch.stack([torch.as_tensor(b["observations"], dtype=torch.float32) for b in batch]),
+    }
+    return batch_to_device(times, device, dd)
+
+
+class Training:
+    """Orchestrates IWAE training of the VAE (reference training.py:71-383)."""
+
+    def __init__(self, args, settings, data, parameters, model):
+        self.args = args
+        self.settings = settings
+        self.dataset_pair = data
+        self.model = model
+        self.shard = getattr(model, "shard", None)
+        p = settings.params
+        on_gpu = settings.device.type == "cuda"
+        self.use_graph = bool(default_get_value(p, "hip_graph", False)) and on_gpu
+        self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))
+        # capturable Adam keeps step counts on the device => the whole step can live in one hipGraph
+        self.lr = torch.tensor(float(p.learning_rate), device=settings.device) if self.use_graph else p.learning_rate
+        self.optimizer = torch.optim.Adam(model.parameters(recurse=True), lr=self.lr, capturable=self.use_graph,
+                                          foreach=True if on_gpu else None)
+        self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, p.learning_boundaries,
+                                                              gamma=p.learning_gamma)
+        n_vals = LocalAndGlobal.from_list(parameters.get_parameter_counts())
+        self.model.n_theta = n_vals.sum()
+        self.n_batch = min(p.n_batch, data.n_train)
+        self.train_data = batch_to_device(data.train.dataset.times, settings.device,
+                                          data.train.dataset[data.train.indices])
+        self.valid_data = batch_to_device(data.test.dataset.times, settings.device,
+                                          data.test.dataset[data.test.indices])
+        self.train_loader = DataLoader(
+            dataset=data.train, batch_size=self.n_batch, shuffle=True,
+            collate_fn=functools.partial(collate_merged, data.train.dataset.times, settings.device),
+        )
+        if settings.trainer is not None:
+            held_out_name = args.heldout or "%d_of_%d" % (args.split, args.folds)
+            self.train_path = os.path.join(settings.trainer.tb_log_dir, "train_%s" % held_out_name)
+            self.valid_path = os.path.join(settings.trainer.tb_log_dir, "valid_%s" % held_out_name)
+            os.makedirs(self.train_path, exist_ok=True)
+            os.makedirs(self.valid_path, exist_ok=True)
+        else:
+            self.train_path = self.valid_path = None
+        self.empty_cache = True
+        self._graphs = {}
+        self._grad_buffer = None
+        self._steps = 0
+
+    # ------------------------------------------------------------------------------------------------
+    def cost(self, batch_data, batch_results, theta, q, p, full_output=False, writer=None, epoch=None):
+        """reference training.py:127-174.  Returns {"elbo": -ELBO} (sic) or a Results object."""
+        x_states, x_predict, precisions = batch_results
+        fused = getattr(batch_results, "log_p_by_species", None)
+        if fused is not None:
+            logp = batch_results.solution.logp_buffer  # [4,B,S] straight from the ODE kernel
+            log_p_by_species = fused
+        else:
+            log_p_by_species = log_prob_observations(self.model, x_predict, batch_data.observations, precisions,
+                                                     self.settings.params.use_laplace)
+            logp = log_p_by_species.permute(2, 0, 1).contiguous()
+        log_q_theta = q.log_prob(theta)
+        log_p_theta = p.log_prob(theta)
+        n_local = logp.shape[2]
+        n_iwae = n_local * (self.shard.world if self.shard is not None else 1)
+        group = self.shard.group if self.shard is not None else None
+        iwae_cost, log_unnormalized_iws, lse = ops.iwae_loss(logp, log_p_theta, log_q_theta, n_iwae_total=n_iwae,
+                                                             group=group if self.shard is not None else None)
+        elbo = -iwae_cost
+        if not full_output:
+            return attrify({"elbo": iwae_cost})
+        if writer is not None:
+            normalized_iws = (log_unnormalized_iws - lse[:, None]).exp()
+            self._update_summaries(writer, epoch, q, log_unnormalized_iws, normalized_iws, logp.sum(0),
+                                   log_p_by_species, elbo, log_p_theta, log_q_theta)
+        sol = getattr(batch_results, "solution", None)
+        output = Results()
+        ode_model = self.model.decoder.ode_model
+        if sol is not None:
+            if ode_model.precisions.dynamic:
+                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
+                                        sol.xpred_buffer.detach(), ode_model.n_species)
+            else:
+                packed, row_of = theta.pack(ode_model.precisions.precision_vars)
+                rows = [row_of[v] for v in ode_model.precisions.precision_vars]
+                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
+                                        sol.xpred_buffer.detach(), ode_model.n_species, theta=packed.detach(),
+                                        prec_rows=rows)
+        else:
+            w = (log_unnormalized_iws - lse[:, None]).exp()[:, :, None, None]
+            mu = (w * x_predict).sum(1)
+            summ = (mu, ((w * (x_predict ** 2 + 1.0 / precisions)).sum(1) - mu ** 2).sqrt(), (w * x_states).sum(1),
+                    (w / precisions).sum(1))
+        output.init_from_device(self.model.decoder.state_names, q, theta, elbo, summ)
+        return output
+
+    def _update_summaries(self, writer, epoch, q, log_unnormalized_iws, normalized_iws, log_p_observations,
+                          log_p_by_species, elbo, log_p_theta, log_q_theta):
+        """TensorBoard scalars (reference training.py:176-210)."""
+        plot_histograms = self.settings.params.plot_histograms
+        q.attach_summaries(writer, epoch, plot_histograms)
+        row = min(1, log_unnormalized_iws.shape[0] - 1)
+        variable_summaries(writer, epoch, log_unnormalized_iws[row, :], "IWS_unn_log", plot_histograms)
+        variable_summaries(writer, epoch, normalized_iws[row, :], "IWS_normed", plot_histograms)
+        writer.add_scalar("ELBO/elbo", elbo, epoch)
+        writer.add_scalar("ELBO/log_p", log_p_observations.logsumexp(axis=1).mean(), epoch)
+        for i, plot in enumerate(self.settings.data.signals):
+            writer.add_scalar("ELBO/log_p_" + plot, log_p_by_species[:, :, i].logsumexp(axis=1).mean(), epoch)
+        writer.add_scalar("ELBO/log_prior", log_p_theta.logsumexp(axis=1).mean(), epoch)
+        writer.add_scalar("ELBO/loq_q", log_q_theta.logsumexp(axis=1).mean(), epoch)
+
+    # ------------------------------------------------------------------------------------------------
+    def _evaluate_elbo_and_plot(self, epoch, log_data, train_writer, valid_writer):
+        """reference training.py:267-322 (stdout format is parsed by the reference's tests/test_run_xval.py:55-60;
+        figure plotting is out of scope)."""
+        print("epoch %4d" % epoch, end="", flush=True)
+        log_data.n_test += 1
+        test_start = time.time()
+        with torch.no_grad():
+            train_results, theta, q, p = self.model(self.train_data, self.args.train_samples, writer=train_writer,
+                                                    epoch=epoch)
+            train_output = self.cost(self.train_data, train_results, theta, q, p, full_output=True,
+                                     writer=train_writer, epoch=epoch)
+        print(" | train (iwae-elbo = %0.4f, time = %0.2f, total = %0.2f)"
+              % (train_output.elbo, log_data.total_train_time / epoch, log_data.total_train_time), end="", flush=True)
+        with torch.no_grad():
+            valid_results, theta, q, p = self.model(self.valid_data, self.args.test_samples, writer=valid_writer,
+                                                    epoch=epoch)
+            valid_output = self.cost(self.valid_data, valid_results, theta, q, p, full_output=True,
+                                     writer=valid_writer, epoch=epoch)
+        for w in (train_writer, valid_writer):
+            if w is not None:
+                w.flush()
+        log_data.total_test_time += time.time() - test_start
+        print(" | val (iwae-elbo = %0.4f, time = %0.2f, total = %0.2f)"
+              % (valid_output.elbo, log_data.total_test_time / log_data.n_test, log_data.total_test_time))
+        if valid_output.elbo > log_data.max_val_elbo:
+            log_data.max_val_elbo = valid_output.elbo
+            valid_output.dump()
+            self.empty_cache = False
+        log_data.training_elbo_list.append(train_output.elbo)
+        log_data.validation_elbo_list.append(valid_output.elbo)
+        return valid_output
+
+    # ------------------------------------------------------------------------------------------------
+    def step(self, batch):
+        """One ELBO training step on a device batch: forward, cost, backward, (gradient all-reduce), Adam.
+        Returns the loss tensor (-ELBO) without synchronising."""
+        batch_results, theta, q, p = self.model(batch, self.args.train_samples)
+        elbo = self.cost(batch, batch_results, theta, q, p).elbo
+        elbo.backward()
+        if self.shard is not None:
+            self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.shard.group,
+                                                             self._grad_buffer)
+        self.optimizer.step()
+        self.optimizer.zero_grad(set_to_none=not self.use_graph)
+        return elbo
+
+    def graph_step(self, batch):
+        """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
+        graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and fixed batch shape."""
+        key = tuple(batch.observations.shape)
+        if key not in self._graphs:
+            static = attrify({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+            self.optimizer.zero_grad(set_to_none=False)
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):  # warm-up on a side stream (allocator, lazy inits, Adam state)
+                    loss = self.step(static)
+            torch.cuda.current_stream().wait_stream(s)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self.step(static)
+            self._graphs[key] = (g, static, loss)
+        g, static, loss = self._graphs[key]
+        for k in ("dev_1hot", "inputs", "observations", "times"):
+            static[k].copy_(batch[k], non_blocking=True)
+        g.replay()
+        return loss
+
+    def _run_batch(self, epoch_start, batch, log_data):
+        """reference training.py:324-340"""
+        log_data.batch_feed_time += time.time() - epoch_start
+        train_start = time.time()
+        elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
+        self._steps += 1
+        if self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
+            print("Cannot proceed with ELBO = nan. Exiting.")
+            return False
+        log_data.batch_train_time += time.time() - train_start
+        return True
+
+    def run(self):
+        """reference training.py:342-383"""
+        train_writer = valid_writer = None
+        if self.settings.trainer is not None:
+            try:
+                from torch.utils.tensorboard import SummaryWriter
+
+                train_writer, valid_writer = SummaryWriter(self.train_path), SummaryWriter(self.valid_path)
+            except ImportError:
+                print("- tensorboard is not installed: summaries disabled")
+        log_data = TrainingLogData()
+        print("---------------------------")
+        if self.args.heldout:
+            split_name = "heldout device = %s" % self.args.heldout
+        else:
+            split_name = "split %d of %d" % (self.args.split, self.args.folds)
+        print("Training: %s" % split_name)
+        iterating = True
+        epoch = 1
+        valid_output = None
+        while iterating is True and (epoch < self.args.epochs + 1):
+            self.model.train()
+            epoch_start = time.time()
+            for batch in self.train_loader:
+                if iterating:
+                    iterating = self._run_batch(epoch_start, batch, log_data)
+            log_data.total_train_time += time.time() - epoch_start
+            if iterating and (np.mod(epoch, self.args.test_epoch) == 0):
+                self.model.eval()
+                valid_output = self._evaluate_elbo_and_plot(epoch, log_data, train_writer, valid_writer)
+            self.scheduler.step()
+            epoch += 1
+        for w in (train_writer, valid_writer):
+            if w is not None:
+                w.close()
+        if self.empty_cache or valid_output is None:
+            print("Exiting with no results in cache")
+            return None
+        valid_output.load()
+        valid_output.elbo_list = log_data.validation_elbo_list
+        return valid_output

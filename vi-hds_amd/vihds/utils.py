@@ -1,0 +1,111 @@
+"""Small host-side helpers shared by the vihds package (counterpart of the reference's vihds/utils.py)."""
+import os
+
+import numpy as np
+
+
+class AttrDict(dict):
+    """dict with attribute access -- what the reference gets from the third-party `munch` package
+    (vihds/config.py:9); written here so the path has no dependency the image lacks."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError:
+            raise AttributeError(k)
+
+    def __setattr__(self, k, v):
+        self[k] = v
+
+
+def attrify(x):
+    """Recursive dict -> AttrDict (the reference's munchify)."""
+    if isinstance(x, dict):
+        return AttrDict((k, attrify(v)) for k, v in x.items())
+    if isinstance(x, (list, tuple)):
+        return type(x)(attrify(v) for v in x)
+    return x
+
+
+munchify = attrify  # name used by callers of the reference API
+
+
+def default_get_value(dct, key, default_value, verbose=False):
+    """reference vihds/utils.py:42-47"""
+    if key in dct:
+        return dct[key]
+    if verbose:
+        print("%s using default %s" % (key, str(default_value)))
+    return default_value
+
+
+def variable_summaries(writer, epoch, var, name, plot_histograms=False):
+    """TensorBoard scalar summaries of a tensor (reference vihds/utils.py:30-39)."""
+    if writer is None:
+        return
+    mean = var.mean()
+    writer.add_scalar(name + "/mean", mean, epoch)
+    writer.add_scalar(name + "/stddev", (var - mean).pow(2).mean().sqrt(), epoch)
+    writer.add_scalar(name + "/max", var.max(), epoch)
+    writer.add_scalar(name + "/min", var.min(), epoch)
+    if plot_histograms:
+        writer.add_histogram(name + "/histogram", var, epoch)
+
+
+class TrainingLogData:
+    """Timers and ELBO history collected during training (reference vihds/utils.py:50-62)."""
+
+    def __init__(self):
+        self.training_elbo_list = []
+        self.validation_elbo_list = []
+        self.batch_feed_time = 0.0
+        self.batch_train_time = 0.0
+        self.total_train_time = 0.0
+        self.total_test_time = 0.0
+        self.n_test = 0
+        self.max_val_elbo = -float("inf")
+
+
+class Results:
+    """Evaluation results with the reference's attribute names and on-disk format (vihds/utils.py:65-156).
+
+    The importance-weighted summaries are computed on the GPU by vihds_iw_summaries (no [B,S,.,T] host
+    copies); only the [B,.,T] results travel to the host."""
+
+    _ARRAYS = ["q_values", "theta", "elbo", "iw_predict_mu", "iw_predict_std", "iw_states", "iw_variance"]
+
+    def __init__(self):
+        self.species_names = None
+        self.q_names = None
+        self.q_values = None
+        self.theta = None
+        self.elbo = None
+        self.iw_predict_mu = None
+        self.iw_predict_std = None
+        self.iw_states = None
+        self.iw_variance = None
+
+    def init_from_device(self, species_names, q, theta, elbo, summaries):
+        self.species_names = species_names
+        self.q_names = q.get_tensor_names()
+        self.q_values = np.array([x.detach().cpu().numpy() for x in q.get_tensors()], dtype=object)
+        self.theta = np.array([x.detach().cpu().numpy() for x in theta.get_tensors()])
+        self.elbo = elbo.detach().cpu().numpy()
+        mu, sd, st, var = summaries
+        self.iw_predict_mu = mu.detach().cpu().numpy()
+        self.iw_predict_std = sd.detach().cpu().numpy()
+        self.iw_states = st.detach().cpu().numpy()
+        self.iw_variance = var.detach().cpu().numpy()
+
+    def dump(self, location=".vihds_cache"):
+        os.makedirs(location, exist_ok=True)
+        for base, data in (("species_names", self.species_names), ("q_names", self.q_names)):
+            np.savetxt(os.path.join(location, base + ".csv"), np.array(data, dtype=str), delimiter=",", fmt="%s")
+        for base in self._ARRAYS:
+            np.save(os.path.join(location, base + ".npy"), getattr(self, base))
+
+    def load(self, location=".vihds_cache"):
+        self.species_names = np.loadtxt(os.path.join(location, "species_names.csv"), dtype=str, delimiter=",")
+        self.q_names = np.loadtxt(os.path.join(location, "q_names.csv"), dtype=str, delimiter=",")
+        for base in self._ARRAYS:
+            setattr(self, base, np.load(os.path.join(location, base + ".npy"), allow_pickle=True))

@@ -1,0 +1,52 @@
+"""BaseVAE glue (counterpart of the reference's vihds/vae.py): sample u -> encoder -> q.sample -> p.clip ->
+decoder.  The sample/clip/log-prob chain is one kernel; the decoder is one kernel."""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from vihds.decoders import Decoder
+from vihds.encoders import Encoder
+from vihds.utils import default_get_value
+
+
+class BaseVAE(nn.Module):
+    def __init__(self, encoder, decoder, device, u_rng="numpy", shard=None):
+        super(BaseVAE, self).__init__()
+        self.encoder = encoder
+        self.decoder = decoder
+        self.device = device
+        self.n_theta = None
+        self.u_rng = u_rng
+        self.shard = shard  # vihds.parallel.SampleShard or None
+
+    def sample_u(self, n_batch, n_samples, device=None):
+        """Standard-normal draws u [B,S,P].  "numpy" = the reference's host RNG stream (vae.py:22-24);
+        "device" = torch's Philox generator on the GPU (graph-capturable, no host->device copy)."""
+        if self.u_rng == "device":
+            return torch.randn((n_batch, n_samples, self.n_theta), device=self.device)
+        u = torch.tensor(np.random.randn(n_batch, n_samples, self.n_theta).astype(np.float32))
+        return u.to(self.device, non_blocking=True)
+
+    def forward(self, data, samples, writer=None, epoch=None):
+        u = self.sample_u(len(data.inputs), samples)
+        if self.shard is not None:
+            u = self.shard.take(u)  # every rank drew the same full u; keep this rank's slice of S
+        q = self.encoder(data)
+        p = self.encoder.p
+        clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4)
+        result, conditioned_theta = self.decoder(clipped_theta, data, writer, epoch)
+        return result, conditioned_theta, q, p
+
+
+def build_model(args, settings, dataset, parameters, shard=None):
+    """reference vae.py:39-51.  Construction order (encoder, then decoder) matches the reference so that the
+    same torch seed gives the same initial weights."""
+    encoder = Encoder(parameters, dataset, getattr(args, "verbose", False), device=settings.device)
+    if settings.data.device_depth > 1:
+        decoder_condition_on_device = True
+    else:
+        print("- Only a single device being considered, so disabling device-conditioning in the decoder")
+        decoder_condition_on_device = False
+    decoder = Decoder(settings, decoder_condition_on_device).to(settings.device)
+    return BaseVAE(encoder, decoder, settings.device, u_rng=default_get_value(settings.params, "u_rng", "numpy"),
+                   shard=shard)
