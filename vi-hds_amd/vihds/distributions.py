@@ -142,14 +142,21 @@ class TfNormal(TfCrnDistribution):
                     sigma = 1.0 / prec.sqrt()
             else:
                 prec = 1.0 / (sigma * sigma)
-        self.sigma, self.prec = sigma, prec
+        self._sigma, self.prec = sigma, prec
         self.nbr_params = 2
         self.param_names = ["mu", "prec"]
 
+    @property
+    def sigma(self):
+        # derived lazily: the hot path never needs the per-distribution sigma tensors (the theta kernel forms
+        # 1/sqrt(prec) itself), so q's ~30 distributions cost no launches per step
+        if self._sigma is None and self.prec is not None:
+            self._sigma = 1.0 / self.prec.sqrt()
+        return self._sigma
+
     def assign_free_and_constrained(self, mu, log_prec, prec):
         self.mu, self.log_prec, self.prec = mu, log_prec, prec
-        if prec is not None:
-            self.sigma = 1.0 / prec.sqrt()
+        self._sigma = None
 
     def _transform(self, z):
         return z

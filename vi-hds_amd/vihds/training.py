@@ -189,7 +189,7 @@ class Training:
         return valid_output
 
     # ------------------------------------------------------------------------------------------------
-    def step(self, batch):
+    def step(self, batch, zero_grad=True):
         """One ELBO training step on a device batch: forward, cost, backward, (gradient all-reduce), Adam.
         Returns the loss tensor (-ELBO) without synchronising."""
         batch_results, theta, q, p = self.model(batch, self.args.train_samples)
@@ -199,29 +199,34 @@ class Training:
             self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.shard.group,
                                                              self._grad_buffer)
         self.optimizer.step()
-        self.optimizer.zero_grad(set_to_none=not self.use_graph)
-        return elbo
+        if zero_grad:
+            self.optimizer.zero_grad(set_to_none=True)
+        return elbo.detach()
 
     def graph_step(self, batch):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
-        graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and fixed batch shape."""
+        graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and a fixed batch shape.
+        Capture follows PyTorch's whole-network recipe: warm up on a side stream, drop the .grad tensors, then
+        capture forward + backward + optimizer.step() so the gradients live in the graph's private pool and are
+        rewritten (not accumulated) by every replay."""
         key = tuple(batch.observations.shape)
         if key not in self._graphs:
             static = attrify({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
-            self.optimizer.zero_grad(set_to_none=False)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
-                for _ in range(3):  # warm-up on a side stream (allocator, lazy inits, Adam state)
-                    loss = self.step(static)
+                for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
+                    self.step(static)
             torch.cuda.current_stream().wait_stream(s)
+            self.optimizer.zero_grad(set_to_none=True)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                loss = self.step(static)
+                loss = self.step(static, zero_grad=False)
             self._graphs[key] = (g, static, loss)
         g, static, loss = self._graphs[key]
         for k in ("dev_1hot", "inputs", "observations", "times"):
-            static[k].copy_(batch[k], non_blocking=True)
+            if static[k].data_ptr() != batch[k].data_ptr():
+                static[k].copy_(batch[k], non_blocking=True)
         g.replay()
         return loss
 
