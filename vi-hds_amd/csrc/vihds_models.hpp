@@ -30,7 +30,20 @@ __device__ __forceinline__ float clamp_pass(float x, float lo, float hi) {
   // torch.clamp backward: gradient flows where lo <= x <= hi (bounds included)
   return (x >= lo && x <= hi) ? 1.f : 0.f;
 }
-__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+// Division and exp on the time-loop path.  v_rcp_f32 / v_exp_f32 are accurate to ~1 ulp, far inside the 1e-4
+// parity budget, and replace the ~10-instruction IEEE division sequence and the range-reduced expf: the RHS is
+// a long dependent chain on a handful of wavefronts, so instruction count is time.  (prepare/prepare_vjp run
+// once per trajectory and keep the accurate powf/logf.)  Build with -DVIHDS_PRECISE_MATH to switch back.
+#ifdef VIHDS_PRECISE_MATH
+__device__ __forceinline__ float frcp(float x) { return 1.f / x; }
+__device__ __forceinline__ float fdiv(float a, float b) { return a / b; }
+__device__ __forceinline__ float fexp(float x) { return expf(x); }
+#else
+__device__ __forceinline__ float frcp(float x) { return __builtin_amdgcn_rcpf(x); }
+__device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_amdgcn_rcpf(b); }
+__device__ __forceinline__ float fexp(float x) { return __expf(x); }
+#endif
+__device__ __forceinline__ float sigmoid_f(float x) { return frcp(1.f + fexp(-x)); }
 
 // d/da a^n and d/dn a^n, matching autograd of torch.pow(tensor, tensor)
 __device__ __forceinline__ void pow_vjp(float a, float n, float an, float g, float& ab, float& nb) {
@@ -49,7 +62,7 @@ __device__ __forceinline__ Growth growth(float t, float x, float r, float K, flo
   Growth o;
   o.sig = sigmoid_f(4.f * (t - tlag));
   o.gr = r * o.sig;
-  o.g = 1.f - x / K;
+  o.g = 1.f - fdiv(x, K);
   o.gamma = o.gr * o.g;
   return o;
 }
@@ -58,7 +71,7 @@ __device__ __forceinline__ void growth_vjp(const Growth& G, float x, float r, fl
                                            float& rb, float& Kb, float& tlagb) {
   float grb = gammab * G.g;
   float gb = gammab * G.gr;
-  float invK = 1.f / K;
+  float invK = frcp(K);
   xb -= gb * invK;
   Kb += gb * x * invK * invK;
   rb += grb * G.sig;
@@ -70,11 +83,11 @@ __device__ __forceinline__ void growth_vjp(const Growth& G, float x, float r, fl
 __device__ __forceinline__ float promoter(float e, float KGR, float KGS, float bR, float bS, float& den) {
   float num = e + KGR * bR + KGS * bS;
   den = 1.f + KGR * bR + KGS * bS;
-  return num / den;
+  return fdiv(num, den);
 }
 __device__ __forceinline__ void promoter_vjp(float P, float den, float KGR, float KGS, float bR, float bS, float Pb,
                                              float& eb, float& KGRb, float& KGSb, float& bRb, float& bSb) {
-  float nb = Pb / den;
+  float nb = fdiv(Pb, den);
   float db = -nb * P;
   float s = nb + db;
   eb += nb;
@@ -482,8 +495,8 @@ struct RelayConstant {
     dy[7] = rc * p[P_aS] - (gm + p[P_dS]) * y[7];
     dy[8] = rc * P81 - (gm + p[P_dluxI]) * y[8];
     dy[9] = rc * P76 - (gm + p[P_dlasI]) * y[9];
-    dy[10] = (p[P_KC6] * rc * y[0] * y[8]) / (1.f + y[8] / p[P_Klux]);
-    dy[11] = (p[P_KC12] * rc * y[0] * y[9]) / (1.f + y[9] / p[P_Klas]);
+    dy[10] = fdiv(p[P_KC6] * rc * y[0] * y[8], 1.f + fdiv(y[8], p[P_Klux]));
+    dy[11] = fdiv(p[P_KC12] * rc * y[0] * y[9], 1.f + fdiv(y[9], p[P_Klas]));
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
@@ -505,17 +518,18 @@ struct RelayConstant {
     yb[8] -= v[8] * (gm + p[P_dluxI]);
     yb[9] -= v[9] * (gm + p[P_dlasI]);
     // d_c6 = (KC6*rc*x*luxI)/(1 + luxI/Klux)
-    float den6 = 1.f + y[8] / p[P_Klux], den12 = 1.f + y[9] / p[P_Klas];
+    float iKlux = frcp(p[P_Klux]), iKlas = frcp(p[P_Klas]);
+    float den6 = 1.f + y[8] * iKlux, den12 = 1.f + y[9] * iKlas;
     float num6 = p[P_KC6] * rc * y[0] * y[8], num12 = p[P_KC12] * rc * y[0] * y[9];
-    float n6b = v[10] / den6, n12b = v[11] / den12;
-    float d6b = -n6b * (num6 / den6), d12b = -n12b * (num12 / den12);
+    float n6b = fdiv(v[10], den6), n12b = fdiv(v[11], den12);
+    float d6b = -n6b * fdiv(num6, den6), d12b = -n12b * fdiv(num12, den12);
     pb[P_KC6] += n6b * rc * y[0] * y[8];
     pb[P_KC12] += n12b * rc * y[0] * y[9];
     yb[0] += n6b * p[P_KC6] * rc * y[8] + n12b * p[P_KC12] * rc * y[9];
-    yb[8] += n6b * p[P_KC6] * rc * y[0] + d6b / p[P_Klux];
-    yb[9] += n12b * p[P_KC12] * rc * y[0] + d12b / p[P_Klas];
-    pb[P_Klux] -= d6b * y[8] / (p[P_Klux] * p[P_Klux]);
-    pb[P_Klas] -= d12b * y[9] / (p[P_Klas] * p[P_Klas]);
+    yb[8] += n6b * p[P_KC6] * rc * y[0] + d6b * iKlux;
+    yb[9] += n12b * p[P_KC12] * rc * y[0] + d12b * iKlas;
+    pb[P_Klux] -= d6b * y[8] * iKlux * iKlux;
+    pb[P_Klas] -= d12b * y[9] * iKlas * iKlas;
     pb[P_rc] += v[1] + v[2] * p[P_aYFP] * P81 + v[3] * p[P_aCFP] * P76 + v[4] * p[P_a530] + v[5] * p[P_a480] +
                 v[6] * p[P_aR] + v[7] * p[P_aS] + v[8] * P81 + v[9] * P76 + n6b * p[P_KC6] * y[0] * y[8] +
                 n12b * p[P_KC12] * y[0] * y[9];

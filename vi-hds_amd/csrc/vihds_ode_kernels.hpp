@@ -90,11 +90,12 @@ __device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y,
   } else {
     // torchdiffeq 0.1 rk4_alt_step_func (3/8 rule)
     const float dt = t1 - t0;
+    const float d3 = dt / 3.f;  // one division per step; the per-element k/3 become multiplies (1-ulp difference)
     float k3[N], k4[N];
     M::rhs(t0, y, p, k1);
-    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * k1[j] / 3.f;
-    M::rhs(t0 + dt / 3.f, ya, p, k2);
-    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] / -3.f + k2[j]);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + d3 * k1[j];
+    M::rhs(t0 + d3, ya, p, k2);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
     M::rhs(t0 + dt * 2.f / 3.f, ya, p, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);
     M::rhs(t0 + dt, ya, p, k4);
@@ -136,9 +137,9 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
     const float d3 = dt / 3.f;
     float k2[N], k3[N], y2[N], y3[N];
     M::rhs(t0, y, p, k1);
-    VIHDS_UNROLL for (int j = 0; j < N; ++j) y2[j] = y[j] + dt * k1[j] / 3.f;
-    M::rhs(t0 + dt / 3.f, y2, p, k2);
-    VIHDS_UNROLL for (int j = 0; j < N; ++j) y3[j] = y[j] + dt * (k1[j] / -3.f + k2[j]);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y2[j] = y[j] + d3 * k1[j];
+    M::rhs(t0 + d3, y2, p, k2);
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y3[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
     M::rhs(t0 + dt * 2.f / 3.f, y3, p, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);  // y4
     const float d8 = dt / 8.f;
@@ -165,7 +166,7 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k2b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + dt / 3.f, y2, p, k2b, w, pb);  // w = y2_bar
+    M::rhs_vjp(t0 + d3, y2, p, k2b, w, pb);  // w = y2_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] += d3 * w[j];

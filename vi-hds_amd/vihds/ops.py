@@ -240,13 +240,9 @@ def iwae_lse(logp, log_p, log_q, group=None):
     the local softmax weights only need the global lse."""
     log_w, row_max, row_se = IwaeRows.apply(logp, log_p, log_q)
     if group is not None:
-        import torch.distributed as dist
+        from vihds.parallel import combine_row_lse
 
-        gmax = row_max.clone()
-        dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
-        se = row_se * torch.exp(row_max - gmax)
-        dist.all_reduce(se, op=dist.ReduceOp.SUM, group=group)
-        lse = gmax + torch.log(se)
+        lse = combine_row_lse(row_max, row_se, group)
     else:
         lse = row_max + torch.log(row_se)
     return _LseFromLogw.apply(log_w, lse), log_w

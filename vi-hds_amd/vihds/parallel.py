@@ -31,6 +31,16 @@ class SampleShard(object):
         return u[:, lo:hi].contiguous()
 
 
+def combine_row_lse(row_max, row_sumexp, group):
+    """Global row-wise logsumexp from per-rank (max, sum exp(. - max)) pairs: all-reduce(MAX) of the maxima, rescale
+    the local sums to the global maximum, all-reduce(SUM).  2 x B floats on the wire (144 B at B=36)."""
+    gmax = row_max.clone()
+    dist.all_reduce(gmax, op=dist.ReduceOp.MAX, group=group)
+    se = row_sumexp * torch.exp(row_max - gmax)
+    dist.all_reduce(se, op=dist.ReduceOp.SUM, group=group)
+    return gmax + torch.log(se)
+
+
 def init_from_env(backend=None):
     """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))

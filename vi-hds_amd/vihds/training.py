@@ -109,9 +109,9 @@ class Training:
         log_p_theta = p.log_prob(theta)
         n_local = logp.shape[2]
         n_iwae = n_local * (self.shard.world if self.shard is not None else 1)
-        group = self.shard.group if self.shard is not None else None
+        group = (self.shard.group or torch.distributed.group.WORLD) if self.shard is not None else None
         iwae_cost, log_unnormalized_iws, lse = ops.iwae_loss(logp, log_p_theta, log_q_theta, n_iwae_total=n_iwae,
-                                                             group=group if self.shard is not None else None)
+                                                             group=group)
         elbo = -iwae_cost
         if not full_output:
             return attrify({"elbo": iwae_cost})
