@@ -12,7 +12,8 @@ pytestmark = pytest.mark.gpu
 
 CASES = ["dr_constant_one_modeuler", "dr_constant_one_s5_modeulerwhile", "dr_constant_icml_tiny_modeuler",
          "dr_constant_icml_tiny_modeulerwhile", "dr_constant_icml_full_modeuler", "dr_constant_v2_tiny_modeuler",
-         "auto_constant_tiny_modeuler", "prpr_constant_tiny_modeuler"]
+         "auto_constant_tiny_modeuler", "prpr_constant_tiny_modeuler", "dr_constant_precisions_tiny_modeuler",
+         "auto_constant_precisions_tiny_modeuler"]
 
 
 def _ref_encoder_grads(fx, enc):
@@ -68,6 +69,9 @@ def test_training_step_matches_reference(name):
     got = dict(model.encoder.named_parameters())
     for k, g in ref.items():
         assert rel_err(got[k].grad, g) < 1e-3, k
+    dref = {k[len("decoder_grad/"):]: fx.t(k) for k in fx.z.files if k.startswith("decoder_grad/")}
+    for k, v in model.decoder.named_parameters():  # neural-precision weights
+        assert rel_err(v.grad, dref[k]) < 1e-3, k
 
 
 def test_reference_api_compat_paths():

@@ -31,7 +31,19 @@ CONST_PREC_FIXTURES = [
 ]
 
 
-def _hip_forward(fx, solver=None, theta=None):
+NEURAL_PREC_FIXTURES = ["dr_constant_precisions_tiny_modeuler", "auto_constant_precisions_tiny_modeuler"]
+
+
+def _flat_prec_weights(fx, requires_grad=False):
+    """NeuralPrecisions weights in the kernel's buffer order: prod_w, prod_b, degr_w, degr_b."""
+    prec_w, _, _ = fx.decoder_weights(DEV)
+    if prec_w is None:
+        return None
+    w = torch.cat([prec_w[k].reshape(-1) for k in ("prod_w", "prod_b", "degr_w", "degr_b")])
+    return w.requires_grad_(requires_grad)
+
+
+def _hip_forward(fx, solver=None, theta=None, weights=None):
     from vihds import ops
     import hip_util as H
 
@@ -39,32 +51,42 @@ def _hip_forward(fx, solver=None, theta=None):
     if theta is not None:
         th = theta
     spec = H.spec_for(fx, row_of, th.shape[0], solver)
+    if weights is None:
+        weights = _flat_prec_weights(fx)
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, fx.t("inputs", DEV), fx.t("times", DEV),
-                                                  fx.t("observations", DEV), None, None)
+                                                  fx.t("observations", DEV), None, weights)
     return th, row_of, traj, xpred, logp
 
 
-@pytest.mark.parametrize("name", CONST_PREC_FIXTURES)
+@pytest.mark.parametrize("name", CONST_PREC_FIXTURES + NEURAL_PREC_FIXTURES)
 def test_ode_forward_matches_reference(name):
     import hip_util as H
 
     fx = Fixture(name)
     th, row_of, traj, xpred, logp = _hip_forward(fx)
     st = int(fx.z["sample_stride"])
+    if name in NEURAL_PREC_FIXTURES:  # the last four states are the precisions (reference precisions.py:89-94)
+        full = H.view_bsnt(traj)
+        assert rel_err(full[:, :, :-4], fx.t("x_states")) < TOL
+        assert rel_err(full[:, :, -4:], fx.t("precisions")) < TOL
+        assert rel_err(H.view_bsnt(xpred), fx.t("x_predict")) < TOL
+        assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+        return
     assert rel_err(H.view_bsnt(traj)[:, ::st], fx.t("x_states")) < TOL
     assert rel_err(H.view_bsnt(xpred)[:, ::st], fx.t("x_predict")) < TOL
     assert rel_err(H.view_bsnt(traj).double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64)) < TOL
     assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
 
 
-@pytest.mark.parametrize("name", CONST_PREC_FIXTURES)
+@pytest.mark.parametrize("name", CONST_PREC_FIXTURES + NEURAL_PREC_FIXTURES)
 def test_elbo_and_theta_gradient_match_reference(name):
     from vihds import ops
 
     fx = Fixture(name)
     th, row_of = __import__("hip_util").pack_theta(fx, DEV)
     th.requires_grad_(True)
-    _, _, traj, xpred, logp = _hip_forward(fx, theta=th)
+    wts = _flat_prec_weights(fx, requires_grad=True)
+    _, _, traj, xpred, logp = _hip_forward(fx, theta=th, weights=wts)
     loss, log_w, lse = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
     assert rel_err(loss, fx.t("loss")) < TOL
     loss.backward()
@@ -81,6 +103,12 @@ def test_elbo_and_theta_gradient_match_reference(name):
     extra = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
     got = th.grad[: len(fx.names)].cpu() + extra
     assert rel_err(got[live], fx.t("theta_grad")[live]) < GTOL
+    if wts is not None:  # shared neural-precision weights: gradient reduced over all trajectories in-kernel
+        ref = fx.decoder_weight_grads()
+        gref = torch.cat([ref["ode_model.precisions." + k].reshape(-1) for k in
+                          ("prec_production.weight", "prec_production.bias", "prec_degradation.weight",
+                           "prec_degradation.bias")])
+        assert rel_err(wts.grad, gref) < GTOL
 
 
 @pytest.mark.parametrize("name", CONST_PREC_FIXTURES + ["dr_blackbox_icml_tiny_modeuler"])

@@ -20,6 +20,12 @@ VIHDS_DECL(auto_constant)
 VIHDS_DECL(prpr_constant)
 VIHDS_DECL(relay_constant)
 VIHDS_DECL(degrader_constant)
+VIHDS_DECL(dr_constant_prec_v1)
+VIHDS_DECL(dr_constant_prec_v2)
+VIHDS_DECL(auto_constant_prec)
+VIHDS_DECL(prpr_constant_prec)
+VIHDS_DECL(relay_constant_prec)
+VIHDS_DECL(degrader_constant_prec)
 #undef VIHDS_DECL
 
 // vihds_elbo.hip
@@ -49,13 +55,13 @@ static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
     VIHDS_ENTRY(prpr_constant, false),      // VIHDS_MODEL_PRPR_CONSTANT
     VIHDS_ENTRY(relay_constant, false),     // VIHDS_MODEL_RELAY_CONSTANT
     VIHDS_ENTRY(degrader_constant, false),  // VIHDS_MODEL_DEGRADER_CONSTANT
-    {nullptr, nullptr, nullptr, nullptr, true},  // *_PRECISIONS and DR_BLACKBOX: see vihds_model_supported()
-    {nullptr, nullptr, nullptr, nullptr, true},
-    {nullptr, nullptr, nullptr, nullptr, true},
-    {nullptr, nullptr, nullptr, nullptr, true},
-    {nullptr, nullptr, nullptr, nullptr, true},
-    {nullptr, nullptr, nullptr, nullptr, true},
-    {nullptr, nullptr, nullptr, nullptr, true},
+    VIHDS_ENTRY(dr_constant_prec_v1, true),     // VIHDS_MODEL_DR_CONSTANT_PRECISIONS
+    VIHDS_ENTRY(dr_constant_prec_v2, true),     // VIHDS_MODEL_DR_CONSTANT_PRECISIONS_V2
+    VIHDS_ENTRY(auto_constant_prec, true),      // VIHDS_MODEL_AUTO_CONSTANT_PRECISIONS
+    VIHDS_ENTRY(prpr_constant_prec, true),      // VIHDS_MODEL_PRPR_CONSTANT_PRECISIONS
+    VIHDS_ENTRY(relay_constant_prec, true),     // VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS
+    VIHDS_ENTRY(degrader_constant_prec, true),  // VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS
+    {nullptr, nullptr, nullptr, nullptr, true},  // VIHDS_MODEL_DR_BLACKBOX: not built yet
 };
 
 static thread_local char g_err[256] = "";
@@ -120,23 +126,33 @@ const char* vihds_model_slot_name(int model, int slot) {
   return nullptr;
 }
 int vihds_model_n_weights(const vihds_ode_problem* p) {
-  (void)p;
-  return 0;
+  if (!p) return VIHDS_E_BADARG;
+  const ModelEntry* e = entry(p->model);
+  if (!e) return VIHDS_E_UNSUPPORTED;
+  if (!e->neural_prec) return 0;
+  if (p->n_hidden_prec > 0) return VIHDS_E_UNSUPPORTED;  // white-box + hidden-layer precisions: no spec uses it
+  const int n_in = e->n_states() - 4 + 1;
+  return 2 * (4 * n_in + 4);
 }
 
 int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, float* traj, float* xpred, float* logp,
                   void* stream) {
-  (void)dev1hot; (void)weights;
+  (void)dev1hot;
   if (!p || !theta || !times) return fail(VIHDS_E_BADARG, "null problem/theta/times");
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (logp && !obs) return fail(VIHDS_E_BADARG, "logp requested without obs");
+  if (e->neural_prec) {
+    if (p->n_hidden_prec > 0)
+      return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural precisions: weights must not be NULL");
+  }
   OdeArgs a;
   int rc = build_args(p, e, a);
   if (rc) return rc;
   if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
-  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs;
+  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs; a.weights = weights;
   a.traj = traj; a.xpred = xpred; a.logp = logp;
   rc = e->launch(false, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
@@ -146,15 +162,20 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj, const float* g_traj,
                   const float* g_xpred, const float* g_logp, float* g_theta, float* g_weights, void* stream) {
-  (void)dev1hot; (void)weights; (void)g_weights;
+  (void)dev1hot;
   if (!p || !theta || !times || !traj || !g_theta) return fail(VIHDS_E_BADARG, "null problem/theta/times/traj/g_theta");
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (!obs) return fail(VIHDS_E_BADARG, "null obs");
+  if (e->neural_prec) {
+    if (p->n_hidden_prec > 0)
+      return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural precisions: weights must not be NULL");
+  }
   OdeArgs a;
   int rc = build_args(p, e, a);
   if (rc) return rc;
-  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs;
+  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs; a.weights = weights; a.g_weights = g_weights;
   a.traj_in = traj; a.g_traj = g_traj; a.g_xpred = g_xpred; a.g_logp = g_logp; a.g_theta = g_theta;
   rc = e->launch(true, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");

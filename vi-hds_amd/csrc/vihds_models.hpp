@@ -133,6 +133,9 @@ __device__ __forceinline__ void hill_frac_vjp(float n_raw, float K6_raw, float K
 template <int VERSION>
 struct DrConstant {
   static constexpr int N = 8;
+  static constexpr int NS = 8;  // species handed to observe()
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;   // shared neural weights
   static constexpr int NC = 2;
   static constexpr int OBS = OBS_DEFAULT;
   enum Slot {
@@ -217,7 +220,7 @@ struct DrConstant {
     thb[SI + 0] = yb[0]; thb[SI + 1] = yb[1]; thb[SI + 2] = yb[2]; thb[SI + 3] = yb[3];
     thb[SI + 4] = yb[6]; thb[SI + 5] = yb[7];
   }
-  __device__ static void rhs(float t, const float* y, const float* p, float* dy) {
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -233,7 +236,8 @@ struct DrConstant {
     dy[6] = rc * p[P_aR] - (gm + p[P_dR]) * y[6];
     dy[7] = rc * p[P_aS] - (gm + p[P_dS]) * y[7];
   }
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb, float*) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -280,6 +284,9 @@ struct DrConstant {
 // ---------------------------------------------------------------------------------------------
 struct AutoConstant {
   static constexpr int N = 4;
+  static constexpr int NS = 4;  // species handed to observe()
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;   // shared neural weights
   static constexpr int NC = 0;
   static constexpr int OBS = OBS_DIRECT;
   enum Slot { S_r, S_K, S_tlag, S_rc, S_drfp, S_a530, S_a480, S_init_x, S_init_rfp, NSLOT };
@@ -312,7 +319,7 @@ struct AutoConstant {
   __device__ static void init_vjp(const float* yb, float* thb) {
     thb[S_init_x] = yb[0]; thb[S_init_rfp] = yb[1];
   }
-  __device__ static void rhs(float t, const float* y, const float* p, float* dy) {
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     dy[0] = gm * y[0];
@@ -320,7 +327,8 @@ struct AutoConstant {
     dy[2] = rc * p[P_a530] - gm * y[2];
     dy[3] = rc * p[P_a480] - gm * y[3];
   }
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb, float*) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     float gammab = v[0] * y[0] - v[1] * y[1] - v[2] * y[2] - v[3] * y[3];
@@ -341,6 +349,9 @@ struct AutoConstant {
 // ---------------------------------------------------------------------------------------------
 struct PrprConstant {
   static constexpr int N = 6;
+  static constexpr int NS = 6;  // species handed to observe()
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;   // shared neural weights
   static constexpr int NC = 0;
   static constexpr int OBS = OBS_DEFAULT;
   enum Slot { S_r, S_K, S_tlag, S_rc, S_drfp, S_dyfp, S_dcfp, S_aYFP, S_aCFP, S_a530, S_a480,
@@ -377,7 +388,7 @@ struct PrprConstant {
   __device__ static void init_vjp(const float* yb, float* thb) {
     thb[S_init_x] = yb[0]; thb[S_init_rfp] = yb[1]; thb[S_init_yfp] = yb[2]; thb[S_init_cfp] = yb[3];
   }
-  __device__ static void rhs(float t, const float* y, const float* p, float* dy) {
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     dy[0] = gm * y[0];
@@ -387,7 +398,8 @@ struct PrprConstant {
     dy[4] = rc * p[P_a530] - gm * y[4];
     dy[5] = rc * p[P_a480] - gm * y[5];
   }
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb, float*) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     float gammab = v[0] * y[0] - v[1] * y[1] - v[2] * y[2] - v[3] * y[3] - v[4] * y[4] - v[5] * y[5];
@@ -415,6 +427,9 @@ struct PrprConstant {
 // ---------------------------------------------------------------------------------------------
 struct RelayConstant {
   static constexpr int N = 12;
+  static constexpr int NS = 12;  // species handed to observe()
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;   // shared neural weights
   static constexpr int NC = 2;
   static constexpr int OBS = OBS_DEFAULT;
   enum Slot {
@@ -478,7 +493,7 @@ struct RelayConstant {
     thb[S_init_x] = yb[0]; thb[S_init_rfp] = yb[1]; thb[S_init_yfp] = yb[2]; thb[S_init_cfp] = yb[3];
     thb[S_init_luxR] = yb[6]; thb[S_init_lasR] = yb[7]; thb[S_init_luxI] = yb[8]; thb[S_init_lasI] = yb[9];
   }
-  __device__ static void rhs(float t, const float* y, const float* p, float* dy) {
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -498,7 +513,8 @@ struct RelayConstant {
     dy[10] = fdiv(p[P_KC6] * rc * y[0] * y[8], 1.f + fdiv(y[8], p[P_Klux]));
     dy[11] = fdiv(p[P_KC12] * rc * y[0] * y[9], 1.f + fdiv(y[9], p[P_Klas]));
   }
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb, float*) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -564,6 +580,9 @@ struct RelayConstant {
 // ---------------------------------------------------------------------------------------------
 struct DegraderConstant {
   static constexpr int N = 11;
+  static constexpr int NS = 11;  // species handed to observe()
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;   // shared neural weights
   static constexpr int NC = 3;
   static constexpr int OBS = OBS_DEFAULT;
   enum Slot {
@@ -639,7 +658,7 @@ struct DegraderConstant {
     thb[S_init_x] = yb[0]; thb[S_init_rfp] = yb[1]; thb[S_init_yfp] = yb[2]; thb[S_init_cfp] = yb[3];
     thb[S_init_luxR] = yb[6]; thb[S_init_lasR] = yb[7]; thb[S_init_aiiA] = yb[8];
   }
-  __device__ static void rhs(float t, const float* y, const float* p, float* dy) {
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -658,7 +677,8 @@ struct DegraderConstant {
     dy[9] = y[0] * p[P_rC6] * y[8];
     dy[10] = y[0] * p[P_rC12] * y[8];
   }
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* v, float* yb, float* pb) {
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb, float*) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -703,6 +723,87 @@ struct DegraderConstant {
     pb[P_fR] += bRb * y[6] * y[6];
     pb[P_fS] += bSb * y[7] * y[7];
     growth_vjp(G, y[0], p[P_r], p[P_K], gammab, yb[0], pb[P_r], pb[P_K], pb[P_tlag]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// <white-box model> + neural precisions with no hidden layer     reference: vihds/precisions.py:55-61,76-87
+//   state = [core species (NS), 4 precisions];  input x = [t, species];  h = tanh(x) (activation on the INPUT)
+//   d prec_j/dt = sigmoid(Wp[j].h + bp[j]) - sigmoid(Wd[j].h + bd[j]) * prec_j
+// weights buffer (NeuralPrecisions.flat_weights): Wp [4][NIN], bp [4], Wd [4][NIN], bd [4]   (NIN = NS + 1)
+// (every reference spec that pairs a white-box model with neural precisions sets n_hidden_decoder_precisions: 0)
+// ---------------------------------------------------------------------------------------------
+template <class Core>
+struct WithPrec {
+  static constexpr int NS = Core::N;
+  static constexpr int N = Core::N + 4;
+  static constexpr int NC = Core::NC;
+  static constexpr int OBS = Core::OBS;
+  static constexpr int NSLOT = Core::NSLOT + 4;
+  static constexpr int NP = Core::NP;
+  static constexpr int NIN = Core::N + 1;
+  static constexpr int NW = 2 * (4 * NIN + 4);
+  static constexpr bool NEURAL_PREC = true;
+  static constexpr int O_WP = 0, O_BP = 4 * NIN, O_WD = 4 * NIN + 4, O_BD = 8 * NIN + 4;
+  __host__ static const char* slot_name(int s) {
+    static const char* n[] = {"init_prec_x", "init_prec_rfp", "init_prec_yfp", "init_prec_cfp"};
+    return s < Core::NSLOT ? Core::slot_name(s) : n[s - Core::NSLOT];
+  }
+  __device__ static void prepare(const float* th, const float* c, float* p) { Core::prepare(th, c, p); }
+  __device__ static void prepare_vjp(const float* th, const float* c, const float* p, const float* pb, float* thb) {
+    Core::prepare_vjp(th, c, p, pb, thb);
+  }
+  __device__ static void init(const float* th, const float* c, float* y) {
+    Core::init(th, c, y);
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) y[NS + j] = th[Core::NSLOT + j];
+  }
+  __device__ static void init_vjp(const float* yb, float* thb) {
+    Core::init_vjp(yb, thb);
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) thb[Core::NSLOT + j] = yb[NS + j];
+  }
+  __device__ static void hidden(float t, const float* y, float* h) {
+    h[0] = tanhf(t);
+    VIHDS_UNROLL for (int i = 0; i < NS; ++i) h[i + 1] = tanhf(y[i]);
+  }
+  __device__ static void rhs(float t, const float* y, const float* p, const float* w, float* dy) {
+    Core::rhs(t, y, p, w, dy);
+    float h[NIN];
+    hidden(t, y, h);
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+      float za = w[O_BP + j], zd = w[O_BD + j];
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) {
+        za += w[O_WP + j * NIN + i] * h[i];
+        zd += w[O_WD + j * NIN + i] * h[i];
+      }
+      dy[NS + j] = sigmoid_f(za) - sigmoid_f(zd) * y[NS + j];
+    }
+  }
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* w, const float* v, float* yb,
+                                 float* pb, float* wb) {
+    Core::rhs_vjp(t, y, p, w, v, yb, pb, wb);
+    float h[NIN], hb[NIN];
+    hidden(t, y, h);
+    VIHDS_UNROLL for (int i = 0; i < NIN; ++i) hb[i] = 0.f;
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+      float za = w[O_BP + j], zd = w[O_BD + j];
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) {
+        za += w[O_WP + j * NIN + i] * h[i];
+        zd += w[O_WD + j * NIN + i] * h[i];
+      }
+      const float a = sigmoid_f(za), d = sigmoid_f(zd);
+      const float vj = v[NS + j];
+      yb[NS + j] -= vj * d;
+      const float zab = vj * a * (1.f - a);
+      const float zdb = -vj * y[NS + j] * d * (1.f - d);
+      wb[O_BP + j] += zab;
+      wb[O_BD + j] += zdb;
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) {
+        wb[O_WP + j * NIN + i] += zab * h[i];
+        wb[O_WD + j * NIN + i] += zdb * h[i];
+        hb[i] += w[O_WP + j * NIN + i] * zab + w[O_WD + j * NIN + i] * zdb;
+      }
+    }
+    VIHDS_UNROLL for (int i = 0; i < NS; ++i) yb[i] += hb[i + 1] * (1.f - h[i + 1] * h[i + 1]);
   }
 };
 

@@ -24,6 +24,8 @@ struct OdeArgs {
   const float* cond;
   const float* times;
   const float* obs;
+  const float* weights;  // shared neural weights (NULL for white-box models)
+  float* g_weights;      // backward: += gradient of the shared weights
   float* traj;
   float* xpred;
   float* logp;
@@ -65,40 +67,40 @@ __device__ __forceinline__ void observe_vjp(const float* y, const float* xpb, fl
 
 // ---- one step of each scheme ---------------------------------------------------------------------
 template <class M, int SOLVER>
-__device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y, const float* p) {
+__device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y, const float* p, const float* wts) {
   constexpr int N = M::N;
   float k1[N], k2[N], ya[N];
   if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
     // vihds/solvers.py:12-16 / :21-25
     const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + h * k1[j];
-    M::rhs(t1, ya, p, k2);
+    M::rhs(t1, ya, p, wts, k2);
     const float hh = 0.5f * h;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + hh * (k1[j] + k2[j]);
   } else if (SOLVER == VIHDS_SOLVER_EULER) {
     const float dt = t1 - t0;
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + dt * k1[j];
   } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
     // torchdiffeq 0.1 Midpoint.step_func: y_mid = y + f(t,y)*dt/2 ; dy = dt*f(t+dt/2, y_mid)
     const float dt = t1 - t0;
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + k1[j] * dt * 0.5f;
-    M::rhs(t0 + dt * 0.5f, ya, p, k2);
+    M::rhs(t0 + dt * 0.5f, ya, p, wts, k2);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + dt * k2[j];
   } else {
     // torchdiffeq 0.1 rk4_alt_step_func (3/8 rule)
     const float dt = t1 - t0;
     const float d3 = dt / 3.f;  // one division per step; the per-element k/3 become multiplies (1-ulp difference)
     float k3[N], k4[N];
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + d3 * k1[j];
-    M::rhs(t0 + d3, ya, p, k2);
+    M::rhs(t0 + d3, ya, p, wts, k2);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
-    M::rhs(t0 + dt * 2.f / 3.f, ya, p, k3);
+    M::rhs(t0 + dt * 2.f / 3.f, ya, p, wts, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);
-    M::rhs(t0 + dt, ya, p, k4);
+    M::rhs(t0 + dt, ya, p, wts, k4);
     const float d8 = dt / 8.f;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + (k1[j] + 3.f * k2[j] + 3.f * k3[j] + k4[j]) * d8;
   }
@@ -106,41 +108,41 @@ __device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y,
 
 // reverse of one step: lam (adjoint of y_{k+1}) -> adjoint of y_k ; pb += parameter adjoint
 template <class M, int SOLVER>
-__device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const float* y, const float* p, float* lam,
-                                             float* pb) {
+__device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const float* y, const float* p,
+                                             const float* wts, float* lam, float* pb, float* wtsb) {
   constexpr int N = M::N;
   float k1[N], ya[N], v[N], w[N];
   if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
     const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
     const float hh = 0.5f * h;
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + h * k1[j];
     // y' = y + hh*(f1 + f2)
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = hh * lam[j]; w[j] = 0.f; }
-    M::rhs_vjp(t1, ya, p, v, w, pb);  // w = ya_bar
+    M::rhs_vjp(t1, ya, p, wts, v, w, pb, wtsb);  // w = ya_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] += h * w[j]; }
-    M::rhs_vjp(t0, y, p, v, lam, pb);
+    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
   } else if (SOLVER == VIHDS_SOLVER_EULER) {
     const float dt = t1 - t0;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) v[j] = dt * lam[j];
-    M::rhs_vjp(t0, y, p, v, lam, pb);
+    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
   } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
     const float dt = t1 - t0;
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + k1[j] * dt * 0.5f;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = dt * lam[j]; w[j] = 0.f; }
-    M::rhs_vjp(t0 + dt * 0.5f, ya, p, v, w, pb);  // w = ymid_bar
+    M::rhs_vjp(t0 + dt * 0.5f, ya, p, wts, v, w, pb, wtsb);  // w = ymid_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] = 0.5f * dt * w[j]; }
-    M::rhs_vjp(t0, y, p, v, lam, pb);
+    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
   } else {
     const float dt = t1 - t0;
     const float d3 = dt / 3.f;
     float k2[N], k3[N], y2[N], y3[N];
-    M::rhs(t0, y, p, k1);
+    M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y2[j] = y[j] + d3 * k1[j];
-    M::rhs(t0 + d3, y2, p, k2);
+    M::rhs(t0 + d3, y2, p, wts, k2);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y3[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
-    M::rhs(t0 + dt * 2.f / 3.f, y3, p, k3);
+    M::rhs(t0 + dt * 2.f / 3.f, y3, p, wts, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);  // y4
     const float d8 = dt / 8.f;
     float k1b[N], k2b[N], k3b[N];
@@ -151,7 +153,7 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k3b[j] = 3.f * v[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + dt, ya, p, v, w, pb);  // w = y4_bar
+    M::rhs_vjp(t0 + dt, ya, p, wts, v, w, pb, wtsb);  // w = y4_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] += dt * w[j];
@@ -159,33 +161,46 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k3b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + dt * 2.f / 3.f, y3, p, k3b, w, pb);  // w = y3_bar
+    M::rhs_vjp(t0 + dt * 2.f / 3.f, y3, p, wts, k3b, w, pb, wtsb);  // w = y3_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] -= d3 * w[j];
       k2b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + d3, y2, p, k2b, w, pb);  // w = y2_bar
+    M::rhs_vjp(t0 + d3, y2, p, wts, k2b, w, pb, wtsb);  // w = y2_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] += d3 * w[j];
     }
-    M::rhs_vjp(t0, y, p, k1b, lam, pb);
+    M::rhs_vjp(t0, y, p, wts, k1b, lam, pb, wtsb);
   }
 }
 
 template <class M>
 __device__ __forceinline__ void load_theta(const OdeArgs& a, int i, int b, float* th, float* prec, float* c) {
   VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) prec[j] = a.theta[(size_t)a.slot_row[M::NSLOT + j] * a.n + i];
+  if (!M::NEURAL_PREC) {  // constant precisions: four more theta rows (reference precisions.py:31-35)
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) prec[j] = a.theta[(size_t)a.slot_row[M::NSLOT + j] * a.n + i];
+  }
   VIHDS_UNROLL for (int q = 0; q < M::NC; ++q) c[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+}
+
+// Shared neural weights are staged in LDS once per block; every lane reads the same address (broadcast).
+template <class M>
+__device__ __forceinline__ const float* stage_weights(const OdeArgs& a, float* lds) {
+  if (M::NW == 0) return nullptr;
+  for (int q = threadIdx.x; q < M::NW; q += blockDim.x) lds[q] = a.weights[q];
+  __syncthreads();
+  return lds;
 }
 
 // ---- forward -------------------------------------------------------------------------------------
 template <class M, int SOLVER>
 __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   constexpr int N = M::N;
+  __shared__ float wlds[M::NW > 0 ? M::NW : 1];
+  const float* wts = stage_weights<M>(a, wlds);
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const int b = i / a.S;
@@ -195,13 +210,16 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   M::init(th, c, y);
 
   float lc[4], lp[4];
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) { lc[j] = LOG2PI_F - logf(prec[j]); lp[j] = 0.f; }
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+    lc[j] = M::NEURAL_PREC ? 0.f : LOG2PI_F - logf(prec[j]);
+    lp[j] = 0.f;
+  }
   const float* ob = a.obs + (size_t)b * 4 * a.T;
   const float h0 = a.times[1] - a.times[0];
   const size_t n = a.n;
 
   for (int k = 0; k < a.T; ++k) {
-    if (k > 0) ode_step<M, SOLVER>(a.times[k - 1], a.times[k], h0, y, p);
+    if (k > 0) ode_step<M, SOLVER>(a.times[k - 1], a.times[k], h0, y, p, wts);
     if (a.traj) {
       VIHDS_UNROLL for (int j = 0; j < N; ++j) a.traj[((size_t)k * N + j) * n + i] = y[j];
     }
@@ -213,7 +231,12 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
     if (a.logp) {
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
         const float e = xp[j] - ob[j * a.T + k];
-        lp[j] += -0.5f * (lc[j] + prec[j] * e * e);
+        if (M::NEURAL_PREC) {  // precisions are ODE states (reference precisions.py:89-94)
+          const float pr = y[M::NS + j];
+          lp[j] += -0.5f * (LOG2PI_F - logf(pr) + pr * e * e);
+        } else {
+          lp[j] += -0.5f * (lc[j] + prec[j] * e * e);
+        }
       }
     }
   }
@@ -226,16 +249,21 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
 template <class M, int SOLVER>
 __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   constexpr int N = M::N;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= a.n) return;
+  constexpr int NWB = M::NW > 0 ? M::NW : 1;
+  __shared__ float wlds[NWB];
+  const float* wts = stage_weights<M>(a, wlds);
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i0 < a.n;
+  const int i = live ? i0 : a.n - 1;  // tail lanes shadow the last trajectory (they take part in the reductions)
   const int b = i / a.S;
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP];
   load_theta<M>(a, i, b, th, prec, c);
   M::prepare(th, c, p);
 
-  float lam[N], pb[M::NP], precb[4], glp[4];
+  float lam[N], pb[M::NP], precb[4], glp[4], wtsb[NWB];
   VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] = 0.f;
   VIHDS_UNROLL for (int j = 0; j < M::NP; ++j) pb[j] = 0.f;
+  VIHDS_UNROLL for (int j = 0; j < NWB; ++j) wtsb[j] = 0.f;
   const size_t n = a.n;
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
     precb[j] = 0.f;
@@ -247,14 +275,17 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   for (int k = a.T - 1; k >= 0; --k) {
     float y[N];
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = a.traj_in[((size_t)k * N + j) * n + i];
-    if (k < a.T - 1) ode_step_vjp<M, SOLVER>(a.times[k], a.times[k + 1], h0, y, p, lam, pb);
+    if (k < a.T - 1) ode_step_vjp<M, SOLVER>(a.times[k], a.times[k + 1], h0, y, p, wts, lam, pb, wtsb);
     // gradient injected at time k: log-likelihood term, x_predict and trajectory upstream grads
     float xp[4], xpb[4];
     observe<M::OBS>(y, xp);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       const float e = xp[j] - ob[j * a.T + k];
-      xpb[j] = -glp[j] * prec[j] * e;
-      precb[j] += glp[j] * (0.5f / prec[j] - 0.5f * e * e);
+      const float pr = M::NEURAL_PREC ? y[M::NS + j] : prec[j];
+      xpb[j] = -glp[j] * pr * e;
+      const float prb = glp[j] * (0.5f / pr - 0.5f * e * e);
+      if (M::NEURAL_PREC) lam[M::NS + j] += prb;
+      else precb[j] += prb;
       if (a.g_xpred) xpb[j] += a.g_xpred[((size_t)k * 4 + j) * n + i];
     }
     observe_vjp<M::OBS>(y, xpb, lam);
@@ -266,8 +297,20 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
   M::prepare_vjp(th, c, p, pb, thb);
   M::init_vjp(lam, thb);
-  VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.g_theta[(size_t)a.slot_row[M::NSLOT + j] * n + i] = precb[j];
+  if (live) {
+    VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
+    if (!M::NEURAL_PREC) {
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.g_theta[(size_t)a.slot_row[M::NSLOT + j] * n + i] = precb[j];
+    }
+  }
+  if (M::NW > 0 && a.g_weights) {
+    // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
+    VIHDS_UNROLL for (int q = 0; q < NWB; ++q) {
+      float v = live ? wtsb[q] : 0.f;
+      VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+    }
+  }
 }
 
 inline int pick_block(int n) { return n >= (1 << 18) ? 256 : 64; }
