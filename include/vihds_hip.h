@@ -101,12 +101,19 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
 
 /* Backward (discrete adjoint of the chosen scheme = what autograd computes in the reference).
  * Upstream gradients g_traj [T][N][B][S], g_xpred [T][4][B][S], g_logp [4][B][S] may each be NULL (= zero).
- * Writes g_theta [n_rows][B][S] for every slot row (other rows untouched: pre-zero the buffer) and ADDS into
- * g_weights (pre-zero it). */
+ * Writes g_theta [n_rows][B][S] for every slot row (other rows untouched: pre-zero the buffer).
+ * Shared-weight gradients:
+ *   - white-box models with neural precisions: ADDED into g_weights (pre-zero it);
+ *   - dr_blackbox: the contraction over (trajectory x RHS evaluation) is left to the caller as batched GEMMs:
+ *     the kernel fills `aux` (vihds_ode_bwd_aux_floats floats) with, per evaluation e, the field block
+ *     [E][F = vihds_blackbox_dump_fields()][B*S] (layer inputs and pre-activation gradients; field order in
+ *     DESIGN.md 4.4) followed by Delta [HS+HP][B*S]; g_weights is not touched.  aux may be NULL otherwise. */
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj,
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
-                  float* g_weights, void* stream);
+                  float* g_weights, float* aux, void* stream);
+long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
+int vihds_blackbox_dump_fields(void);
 
 /* theta side: ChainedDistribution.sample + p.clip + q.log_prob + p.log_prob
  * (vihds/distributions.py:64-85,119-142,327-381; vihds/vae.py:31-34) over all P parameters at once.

@@ -192,6 +192,74 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
     assert rel_err(got[live], ref[live]) < GTOL
 
 
+def test_blackbox_forward_and_gradients_match_reference():
+    """dr_blackbox (MLP right-hand side): trajectories, precisions, log-likelihood, d loss/d theta and the gradients
+    of all 1 760 shared MLP weights (adjoint kernel dump + batched GEMMs) against the reference's autograd."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture("dr_blackbox_icml_tiny_modeuler")
+    prec_w, states_w, offset = fx.decoder_weights(DEV)
+    order = ("hid_w", "hid_b", "prod_w", "prod_b", "degr_w", "degr_b")
+    wts = torch.cat([states_w[k].reshape(-1) for k in order] + [prec_w[k].reshape(-1) for k in order])
+    wts.requires_grad_(True)
+    P = len(fx.names)
+    th = fx.t("theta", DEV)
+    dev = fx.t("dev_1hot", DEV)
+    off = torch.nn.functional.linear(dev, offset[0], offset[1])  # [B, n_y]; condition_theta (dr_blackbox.py:86-96)
+    ycond = torch.stack([th[fx.names.index("y%d" % (i + 1))] + off[:, i: i + 1] for i in range(2)])
+    theta = torch.cat([th, ycond], 0).requires_grad_(True)
+    row_of = {n: i for i, n in enumerate(fx.names)}
+    row_of["y1"], row_of["y2"] = P, P + 1  # the simulator sees the offset y's; log q / log p the sampled ones
+    p = fx.cfg["params"]
+    spec = ops.OdeProblemSpec("dr_blackbox", fx.solver, row_of, P + 2, C=2, D=dev.shape[1],
+                               n_hidden_prec=p["n_hidden_decoder_precisions"], n_hidden_states=p["n_hidden_decoder"],
+                               n_latent_states=p["n_latent_species"], n_const=p["n_z"] + p["n_x"] + p["n_y"] + 2 + dev.shape[1],
+                               init_latent=p["init_latent_species"], init_prec=p["init_prec"])
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
+                                                  fx.t("observations", DEV), dev, wts)
+    full = H.view_bsnt(traj)
+    assert rel_err(full[:, :, :-4], fx.t("x_states")) < TOL
+    assert rel_err(full[:, :, -4:], fx.t("precisions")) < TOL
+    assert rel_err(H.view_bsnt(xpred), fx.t("x_predict")) < TOL
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+    loss, log_w, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
+    assert rel_err(loss, fx.t("loss")) < TOL
+    loss.backward()
+    ref = fx.decoder_weight_grads()
+    skey = {"hid_w": "states_hidden.weight", "hid_b": "states_hidden.bias", "prod_w": "states_production.weight",
+            "prod_b": "states_production.bias", "degr_w": "states_degradation.weight", "degr_b": "states_degradation.bias"}
+    pkey = {"hid_w": "prec_hidden.weight", "hid_b": "prec_hidden.bias", "prod_w": "prec_production.weight",
+            "prod_b": "prec_production.bias", "degr_w": "prec_degradation.weight", "degr_b": "prec_degradation.bias"}
+    gref = torch.cat([ref["ode_model.neural_states." + skey[k]].reshape(-1) for k in order] +
+                     [ref["ode_model.precisions." + pkey[k]].reshape(-1) for k in order])
+    got = wts.grad.cpu()
+    o = 0
+    for name, blk in [("states." + k, ref["ode_model.neural_states." + skey[k]]) for k in order] + \
+                     [("prec." + k, ref["ode_model.precisions." + pkey[k]]) for k in order]:
+        k = blk.numel()
+        assert rel_err(got[o: o + k], blk.reshape(-1)) < 2e-3, name
+        o += k
+    assert rel_err(got, gref) < GTOL
+    # theta gradient: the offset y rows carry d loss/d y_cond; the reference's grad on the sampled y adds log p - log q
+    thc = fx.theta_dict(requires_grad=True)
+    qm, qp = fx.q_params()
+    pm, pp = fx.p_params()
+    vals = [thc[n] for n in fx.names]
+    extra = O.chained_log_prob(fx.kinds, pm, pp, vals) - O.chained_log_prob(fx.kinds, qm, qp, vals)
+    w = torch.softmax(log_w.detach().cpu(), dim=1) * (-1.0 / fx.B)
+    (extra * w).sum().backward()
+    g = theta.grad.cpu()
+    got_th = g[:P].clone()
+    got_th[fx.names.index("y1")] += g[P]
+    got_th[fx.names.index("y2")] += g[P + 1]
+    got_th = got_th + torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    assert rel_err(got_th[live], fx.t("theta_grad")[live]) < GTOL
+    # offset layer gradient follows from the y_cond rows by the chain rule (torch ops in the host model)
+    assert rel_err((g[P:].sum(2) @ dev.cpu()), ref["ode_model.offset_layer.weight"]) < GTOL
+
+
 def test_generic_upstream_gradients_traj_and_xpred():
     """The adjoint kernel must also serve callers that consume x_states / x_predict directly (plugin surface):
     compare d/dtheta of an arbitrary functional of (traj, xpred) with the oracle's autograd."""

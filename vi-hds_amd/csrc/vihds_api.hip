@@ -26,7 +26,12 @@ VIHDS_DECL(auto_constant_prec)
 VIHDS_DECL(prpr_constant_prec)
 VIHDS_DECL(relay_constant_prec)
 VIHDS_DECL(degrader_constant_prec)
+VIHDS_DECL(dr_blackbox)
 #undef VIHDS_DECL
+int bb_n_weights(int n_const);
+long long bb_aux_floats(int n, int T, int solver);
+int bb_check(int L, int HS, int HP, int n_const, int C, int D);
+int bb_dump_fields();
 
 // vihds_elbo.hip
 void launch_theta_fwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
@@ -61,7 +66,7 @@ static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
     VIHDS_ENTRY(prpr_constant_prec, true),      // VIHDS_MODEL_PRPR_CONSTANT_PRECISIONS
     VIHDS_ENTRY(relay_constant_prec, true),     // VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS
     VIHDS_ENTRY(degrader_constant_prec, true),  // VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS
-    {nullptr, nullptr, nullptr, nullptr, true},  // VIHDS_MODEL_DR_BLACKBOX: not built yet
+    VIHDS_ENTRY(dr_blackbox, true),             // VIHDS_MODEL_DR_BLACKBOX
 };
 
 static thread_local char g_err[256] = "";
@@ -90,6 +95,7 @@ static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& 
   const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
+  a.solver = p->solver; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
   for (int q = 0; q < ns; ++q) {
     if (p->slot_row[q] < 0 || p->slot_row[q] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
     a.slot_row[q] = p->slot_row[q];
@@ -130,29 +136,46 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+    if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
+      return VIHDS_E_UNSUPPORTED;
+    return bb_n_weights(p->n_const);
+  }
   if (p->n_hidden_prec > 0) return VIHDS_E_UNSUPPORTED;  // white-box + hidden-layer precisions: no spec uses it
   const int n_in = e->n_states() - 4 + 1;
   return 2 * (4 * n_in + 4);
 }
 
+long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
+  if (!p) return VIHDS_E_BADARG;
+  if (p->model != VIHDS_MODEL_DR_BLACKBOX) return 0;
+  return bb_aux_floats(p->B * p->S, p->T, p->solver);
+}
+int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
+
 int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, float* traj, float* xpred, float* logp,
                   void* stream) {
-  (void)dev1hot;
   if (!p || !theta || !times) return fail(VIHDS_E_BADARG, "null problem/theta/times");
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (logp && !obs) return fail(VIHDS_E_BADARG, "logp requested without obs");
   if (e->neural_prec) {
-    if (p->n_hidden_prec > 0)
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+    if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
+        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
+                                         "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
+      if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
+    } else if (p->n_hidden_prec > 0) {
       return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
-    if (!weights) return fail(VIHDS_E_BADARG, "model has neural precisions: weights must not be NULL");
+    }
   }
   OdeArgs a;
   int rc = build_args(p, e, a);
   if (rc) return rc;
   if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
-  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs; a.weights = weights;
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
   a.traj = traj; a.xpred = xpred; a.logp = logp;
   rc = e->launch(false, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
@@ -161,21 +184,29 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
 
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj, const float* g_traj,
-                  const float* g_xpred, const float* g_logp, float* g_theta, float* g_weights, void* stream) {
-  (void)dev1hot;
+                  const float* g_xpred, const float* g_logp, float* g_theta, float* g_weights, float* aux,
+                  void* stream) {
   if (!p || !theta || !times || !traj || !g_theta) return fail(VIHDS_E_BADARG, "null problem/theta/times/traj/g_theta");
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (!obs) return fail(VIHDS_E_BADARG, "null obs");
   if (e->neural_prec) {
-    if (p->n_hidden_prec > 0)
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+    if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
+        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
+                                         "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
+      if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
+    } else if (p->n_hidden_prec > 0) {
       return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
-    if (!weights) return fail(VIHDS_E_BADARG, "model has neural precisions: weights must not be NULL");
+    }
   }
   OdeArgs a;
   int rc = build_args(p, e, a);
   if (rc) return rc;
-  a.theta = theta; a.cond = cond; a.times = times; a.obs = obs; a.weights = weights; a.g_weights = g_weights;
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
+  a.g_weights = g_weights; a.aux = aux;
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && !aux) return fail(VIHDS_E_BADARG, "dr_blackbox backward needs the aux buffer");
   a.traj_in = traj; a.g_traj = g_traj; a.g_xpred = g_xpred; a.g_logp = g_logp; a.g_theta = g_theta;
   rc = e->launch(true, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");

@@ -1,0 +1,31 @@
+// Kernel argument block shared by every ODE kernel (passed by value).
+#pragma once
+#include "../../include/vihds_hip.h"
+
+namespace vihds {
+
+struct OdeArgs {
+  int B, S, T, C, n;  // n = B*S
+  int solver;
+  int slot_row[VIHDS_MAX_SLOTS];
+  const float* theta;
+  const float* cond;
+  const float* dev1hot;  // [B][D] (dr_blackbox only)
+  int D, n_const;        // device_depth; blackbox: #time-invariant MLP inputs
+  const float* times;
+  const float* obs;
+  const float* weights;  // shared neural weights (NULL for white-box models)
+  float* g_weights;      // backward: += gradient of the shared weights
+  float* traj;
+  float* xpred;
+  float* logp;
+  const float* traj_in;  // backward: stored trajectory
+  const float* g_traj;
+  const float* g_xpred;
+  const float* g_logp;
+  float* g_theta;
+  float* aux;            // backward scratch (dr_blackbox: per-evaluation dump for the weight-gradient GEMMs)
+  float init_latent, init_prec;
+};
+
+}  // namespace vihds

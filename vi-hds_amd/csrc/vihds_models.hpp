@@ -237,7 +237,7 @@ struct DrConstant {
     dy[7] = rc * p[P_aS] - (gm + p[P_dS]) * y[7];
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
-                                 float* pb, float*) {
+                                 float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -328,7 +328,7 @@ struct AutoConstant {
     dy[3] = rc * p[P_a480] - gm * y[3];
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
-                                 float* pb, float*) {
+                                 float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     float gammab = v[0] * y[0] - v[1] * y[1] - v[2] * y[2] - v[3] * y[3];
@@ -399,7 +399,7 @@ struct PrprConstant {
     dy[5] = rc * p[P_a480] - gm * y[5];
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
-                                 float* pb, float*) {
+                                 float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float rc = p[P_rc], gm = G.gamma;
     float gammab = v[0] * y[0] - v[1] * y[1] - v[2] * y[2] - v[3] * y[3] - v[4] * y[4] - v[5] * y[5];
@@ -514,7 +514,7 @@ struct RelayConstant {
     dy[11] = fdiv(p[P_KC12] * rc * y[0] * y[9], 1.f + fdiv(y[9], p[P_Klas]));
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
-                                 float* pb, float*) {
+                                 float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -678,7 +678,7 @@ struct DegraderConstant {
     dy[10] = y[0] * p[P_rC12] * y[8];
   }
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
-                                 float* pb, float*) {
+                                 float* pb) {
     Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
     float bR = y[6] * y[6] * p[P_fR], bS = y[7] * y[7] * p[P_fS];
     float d76, d81;
@@ -767,6 +767,7 @@ struct WithPrec {
   }
   __device__ static void rhs(float t, const float* y, const float* p, const float* w, float* dy) {
     Core::rhs(t, y, p, w, dy);
+    __asm__ volatile("" ::: "memory");  // keep the LDS weight loads inside the time loop (no hoist-and-spill)
     float h[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
@@ -778,9 +779,12 @@ struct WithPrec {
       dy[NS + j] = sigmoid_f(za) - sigmoid_f(zd) * y[NS + j];
     }
   }
+  template <class Ctx>
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* w, const float* v, float* yb,
-                                 float* pb, float* wb) {
-    Core::rhs_vjp(t, y, p, w, v, yb, pb, wb);
+                                 float* pb, Ctx& ctx) {
+    float* wb = ctx.wb;
+    Core::rhs_vjp(t, y, p, w, v, yb, pb);
+    __asm__ volatile("" ::: "memory");
     float h[NIN], hb[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int i = 0; i < NIN; ++i) hb[i] = 0.f;

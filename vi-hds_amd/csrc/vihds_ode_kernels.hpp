@@ -10,31 +10,17 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "../../include/vihds_hip.h"
+#include "vihds_args.hpp"
 #include "vihds_models.hpp"
+#include "vihds_blackbox.hpp"
 
 namespace vihds {
 
 constexpr float LOG2PI_F = 1.8378770664093453f;  // math.log(2*math.pi), vihds/training.py:43
 
-struct OdeArgs {
-  int B, S, T, C, n;  // n = B*S
-  int slot_row[VIHDS_MAX_SLOTS];
-  const float* theta;
-  const float* cond;
-  const float* times;
-  const float* obs;
-  const float* weights;  // shared neural weights (NULL for white-box models)
-  float* g_weights;      // backward: += gradient of the shared weights
-  float* traj;
-  float* xpred;
-  float* logp;
-  const float* traj_in;  // backward: stored trajectory
-  const float* g_traj;
-  const float* g_xpred;
-  const float* g_logp;
-  float* g_theta;
-};
 
 template <int OBS>
 __device__ __forceinline__ void observe(const float* y, float* xp) {
@@ -64,6 +50,34 @@ __device__ __forceinline__ void observe_vjp(const float* y, const float* xpb, fl
     yb[3] += xpb[3] * y[0];
   }
 }
+
+// backward context per model kind
+struct NoCtx {};
+template <int NW>
+struct WeightGradCtx {
+  float wb[NW];
+};
+template <class M, bool BB = is_blackbox<M>::value, bool HAS_W = (M::NW > 0)>
+struct bwd_ctx {  // white-box
+  using type = NoCtx;
+  __device__ static void init(type&, const OdeArgs&, int) {}
+};
+template <class M>
+struct bwd_ctx<M, false, true> {  // white-box + neural precisions
+  using type = WeightGradCtx<M::NW>;
+  __device__ static void init(type& c, const OdeArgs&, int) {
+    VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) c.wb[q] = 0.f;
+  }
+};
+template <class M>
+struct bwd_ctx<M, true, true> {  // dr_blackbox
+  using type = BlackboxCtx;
+  __device__ static void init(type& c, const OdeArgs& a, int i) {
+    c.dump = a.aux + i;
+    c.n = (size_t)a.n;
+    c.e = 0;
+  }
+};
 
 // ---- one step of each scheme ---------------------------------------------------------------------
 template <class M, int SOLVER>
@@ -106,10 +120,17 @@ __device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y,
   }
 }
 
+template <class M, class Ctx>
+__device__ __forceinline__ void call_vjp(float t, const float* y, const float* p, const float* w, const float* v,
+                                         float* yb, float* pb, Ctx& ctx) {
+  if constexpr (std::is_same<Ctx, NoCtx>::value) M::rhs_vjp(t, y, p, w, v, yb, pb);
+  else M::rhs_vjp(t, y, p, w, v, yb, pb, ctx);
+}
+
 // reverse of one step: lam (adjoint of y_{k+1}) -> adjoint of y_k ; pb += parameter adjoint
-template <class M, int SOLVER>
+template <class M, int SOLVER, class Ctx>
 __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const float* y, const float* p,
-                                             const float* wts, float* lam, float* pb, float* wtsb) {
+                                             const float* wts, float* lam, float* pb, Ctx& wtsb) {
   constexpr int N = M::N;
   float k1[N], ya[N], v[N], w[N];
   if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
@@ -119,21 +140,21 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + h * k1[j];
     // y' = y + hh*(f1 + f2)
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = hh * lam[j]; w[j] = 0.f; }
-    M::rhs_vjp(t1, ya, p, wts, v, w, pb, wtsb);  // w = ya_bar
+    call_vjp<M>(t1, ya, p, wts, v, w, pb, wtsb);  // w = ya_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] += h * w[j]; }
-    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
+    call_vjp<M>(t0, y, p, wts, v, lam, pb, wtsb);
   } else if (SOLVER == VIHDS_SOLVER_EULER) {
     const float dt = t1 - t0;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) v[j] = dt * lam[j];
-    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
+    call_vjp<M>(t0, y, p, wts, v, lam, pb, wtsb);
   } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
     const float dt = t1 - t0;
     M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + k1[j] * dt * 0.5f;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { v[j] = dt * lam[j]; w[j] = 0.f; }
-    M::rhs_vjp(t0 + dt * 0.5f, ya, p, wts, v, w, pb, wtsb);  // w = ymid_bar
+    call_vjp<M>(t0 + dt * 0.5f, ya, p, wts, v, w, pb, wtsb);  // w = ymid_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) { lam[j] += w[j]; v[j] = 0.5f * dt * w[j]; }
-    M::rhs_vjp(t0, y, p, wts, v, lam, pb, wtsb);
+    call_vjp<M>(t0, y, p, wts, v, lam, pb, wtsb);
   } else {
     const float dt = t1 - t0;
     const float d3 = dt / 3.f;
@@ -153,7 +174,7 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k3b[j] = 3.f * v[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + dt, ya, p, wts, v, w, pb, wtsb);  // w = y4_bar
+    call_vjp<M>(t0 + dt, ya, p, wts, v, w, pb, wtsb);  // w = y4_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] += dt * w[j];
@@ -161,19 +182,19 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k3b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + dt * 2.f / 3.f, y3, p, wts, k3b, w, pb, wtsb);  // w = y3_bar
+    call_vjp<M>(t0 + dt * 2.f / 3.f, y3, p, wts, k3b, w, pb, wtsb);  // w = y3_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] -= d3 * w[j];
       k2b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    M::rhs_vjp(t0 + d3, y2, p, wts, k2b, w, pb, wtsb);  // w = y2_bar
+    call_vjp<M>(t0 + d3, y2, p, wts, k2b, w, pb, wtsb);  // w = y2_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] += d3 * w[j];
     }
-    M::rhs_vjp(t0, y, p, wts, k1b, lam, pb, wtsb);
+    call_vjp<M>(t0, y, p, wts, k1b, lam, pb, wtsb);
   }
 }
 
@@ -189,10 +210,14 @@ __device__ __forceinline__ void load_theta(const OdeArgs& a, int i, int b, float
 // Shared neural weights are staged in LDS once per block; every lane reads the same address (broadcast).
 template <class M>
 __device__ __forceinline__ const float* stage_weights(const OdeArgs& a, float* lds) {
-  if (M::NW == 0) return nullptr;
-  for (int q = threadIdx.x; q < M::NW; q += blockDim.x) lds[q] = a.weights[q];
-  __syncthreads();
-  return lds;
+  if constexpr (M::NW == 0) {
+    return nullptr;
+  } else {
+    if constexpr (is_blackbox<M>::value) M::stage(a, lds);
+    else for (int q = threadIdx.x; q < M::NW; q += blockDim.x) lds[q] = a.weights[q];
+    __syncthreads();
+    return lds;
+  }
 }
 
 // ---- forward -------------------------------------------------------------------------------------
@@ -206,8 +231,13 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP], y[N];
   load_theta<M>(a, i, b, th, prec, c);
-  M::prepare(th, c, p);
-  M::init(th, c, y);
+  if constexpr (is_blackbox<M>::value) {
+    M::prepare_bb(th, a, b, p);
+    M::init_bb(th, a, y);
+  } else {
+    M::prepare(th, c, p);
+    M::init(th, c, y);
+  }
 
   float lc[4], lp[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
@@ -232,7 +262,7 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
         const float e = xp[j] - ob[j * a.T + k];
         if (M::NEURAL_PREC) {  // precisions are ODE states (reference precisions.py:89-94)
-          const float pr = y[M::NS + j];
+          const float pr = y[(M::N - 4) + j];
           lp[j] += -0.5f * (LOG2PI_F - logf(pr) + pr * e * e);
         } else {
           lp[j] += -0.5f * (lc[j] + prec[j] * e * e);
@@ -249,8 +279,7 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
 template <class M, int SOLVER>
 __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   constexpr int N = M::N;
-  constexpr int NWB = M::NW > 0 ? M::NW : 1;
-  __shared__ float wlds[NWB];
+  __shared__ float wlds[M::NW > 0 ? M::NW : 1];
   const float* wts = stage_weights<M>(a, wlds);
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i0 < a.n;
@@ -258,12 +287,16 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP];
   load_theta<M>(a, i, b, th, prec, c);
-  M::prepare(th, c, p);
+  if constexpr (is_blackbox<M>::value) M::prepare_bb(th, a, b, p);
+  else M::prepare(th, c, p);
 
-  float lam[N], pb[M::NP], precb[4], glp[4], wtsb[NWB];
+  float lam[N], pb[M::NP], precb[4], glp[4];
   VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] = 0.f;
   VIHDS_UNROLL for (int j = 0; j < M::NP; ++j) pb[j] = 0.f;
-  VIHDS_UNROLL for (int j = 0; j < NWB; ++j) wtsb[j] = 0.f;
+  // backward context: per-thread shared-weight gradient accumulators (white-box + neural precisions), or the
+  // evaluation dump cursor (dr_blackbox)
+  typename bwd_ctx<M>::type wtsb;
+  bwd_ctx<M>::init(wtsb, a, i);
   const size_t n = a.n;
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
     precb[j] = 0.f;
@@ -281,10 +314,10 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
     observe<M::OBS>(y, xp);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       const float e = xp[j] - ob[j * a.T + k];
-      const float pr = M::NEURAL_PREC ? y[M::NS + j] : prec[j];
+      const float pr = M::NEURAL_PREC ? y[(M::N - 4) + j] : prec[j];
       xpb[j] = -glp[j] * pr * e;
       const float prb = glp[j] * (0.5f / pr - 0.5f * e * e);
-      if (M::NEURAL_PREC) lam[M::NS + j] += prb;
+      if (M::NEURAL_PREC) lam[(M::N - 4) + j] += prb;
       else precb[j] += prb;
       if (a.g_xpred) xpb[j] += a.g_xpred[((size_t)k * 4 + j) * n + i];
     }
@@ -295,7 +328,12 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   }
   float thb[M::NSLOT];
   VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
-  M::prepare_vjp(th, c, p, pb, thb);
+  if constexpr (is_blackbox<M>::value) {
+    M::prepare_vjp_bb(th, a, b, pb, thb);
+    if (live) M::store_delta(a, i, pb);
+  } else {
+    M::prepare_vjp(th, c, p, pb, thb);
+  }
   M::init_vjp(lam, thb);
   if (live) {
     VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
@@ -303,12 +341,14 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.g_theta[(size_t)a.slot_row[M::NSLOT + j] * n + i] = precb[j];
     }
   }
-  if (M::NW > 0 && a.g_weights) {
-    // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
-    VIHDS_UNROLL for (int q = 0; q < NWB; ++q) {
-      float v = live ? wtsb[q] : 0.f;
-      VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-      if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+  if constexpr (!is_blackbox<M>::value && M::NW > 0) {
+    if (a.g_weights) {
+      // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
+      VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) {
+        float v = live ? wtsb.wb[q] : 0.f;
+        VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+      }
     }
   }
 }

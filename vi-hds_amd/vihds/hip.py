@@ -65,7 +65,9 @@ _PROTOTYPES = {
     "vihds_model_slot_name": (ctypes.c_char_p, [_I, _I]),
     "vihds_model_n_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
-    "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 13),
+    "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
+    "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
+    "vihds_blackbox_dump_fields": (_I, []),
     "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 12),
     "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 14),
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),

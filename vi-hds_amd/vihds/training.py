@@ -125,12 +125,12 @@ class Training:
         if sol is not None:
             if ode_model.precisions.dynamic:
                 summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
-                                        sol.xpred_buffer.detach(), ode_model.n_species)
+                                        sol.xpred_buffer.detach(), x_states.shape[2])
             else:
                 packed, row_of = theta.pack(ode_model.precisions.precision_vars)
                 rows = [row_of[v] for v in ode_model.precisions.precision_vars]
                 summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
-                                        sol.xpred_buffer.detach(), ode_model.n_species, theta=packed.detach(),
+                                        sol.xpred_buffer.detach(), x_states.shape[2], theta=packed.detach(),
                                         prec_rows=rows)
         else:
             w = (log_unnormalized_iws - lse[:, None]).exp()[:, :, None, None]
