@@ -81,6 +81,8 @@ typedef struct vihds_ode_problem {
   int n_const;         /* dr_blackbox: length of the time-invariant feature vector (n_z+n_x+n_y+C+D) */
   float init_latent;   /* dr_blackbox.py:101 */
   float init_prec;     /* dr_blackbox.py:102 */
+  int logp_grad_broadcast; /* backward only: 1 = g_logp is ONE [B][S] array applied to all four species
+                              (what the IWAE reduction hands back); 0 = [4][B][S] */
 } vihds_ode_problem;
 
 int vihds_abi_version(void);
@@ -141,6 +143,22 @@ int vihds_iwae_fwd(int B, int S, const float* logp, const float* log_p, const fl
 /* g_lse [B], lse [B] -> g_logw [B][S] = g_lse[b] * exp(log_w - lse[b]) */
 int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const float* g_lse, float* g_logw,
                    void* stream);
+
+/* Single-process convenience: the two calls above plus the finish, i.e. all of vihds/training.py:135-149:
+ * lse[b] = row_max + log(row_sumexp), loss[0] = -mean_b(lse[b] - log(n_iwae_total)).
+ * Backward: g_logw[b][s] = -(g_loss[0]/B) * exp(log_w - lse[b]). */
+int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
+                        float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream);
+int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
+                        void* stream);
+
+/* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
+ * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *
+ * relevance[e][d]) with r = (b*S+s) mod B (the reference's .repeat tiling, kept).  z [E][D] are standard normals
+ * (w_mean=2, w_std=1.5 reproduce DeviceConditioner's init) or final weights (w_mean=0, w_std=1). */
+int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+                           const float* dev1hot, const float* relevance, const int* is_default, float* out,
+                           void* stream);
 
 /* Evaluation summaries (vihds/utils.py:79-99, Results.init) on device: importance-weighted mean / std of the
  * predictions, mean of the states, mean of 1/precision.  w = exp(log_w - lse).

@@ -23,14 +23,14 @@ def _ref_encoder_grads(fx, enc):
            "conditional.lin.weight": ref["conditional.lin.weight"], "conditional.lin.bias": ref["conditional.lin.bias"]}
     if enc.local:
         w, b = [], []
-        for d in enc.local:
-            for free in ("mu", "log_prec"):
+        for free in ("mu", "log_prec"):  # heads are stored [all mu ; all log_prec]
+            for d in enc.local:
                 w.append(ref["q_local_defs.%s.layers.%s.weight" % (d.name, free)])
                 b.append(ref["q_local_defs.%s.layers.%s.bias" % (d.name, free)])
         out["local_heads.weight"], out["local_heads.bias"] = torch.cat(w, 0), torch.cat(b, 0)
     if enc.gcond:
         out["gcond_heads.weight"] = torch.cat([ref["q_global_cond_defs.%s.layers.%s.weight" % (d.name, f)]
-                                               for d in enc.gcond for f in ("mu", "log_prec")], 0)
+                                               for f in ("mu", "log_prec") for d in enc.gcond], 0)
     if enc.glob:
         out["global_free"] = torch.stack([torch.cat([ref["q_global_defs.%s.free_params.mu" % d.name],
                                                      ref["q_global_defs.%s.free_params.log_prec" % d.name]])

@@ -73,12 +73,15 @@ def test_encoder_initialises_to_reference_weights_and_q(name):
     ref = {k[len("encoder_param/"):]: fx.t(k) for k in fx.z.files if k.startswith("encoder_param/")}
     assert torch.equal(enc.conditional.conv.weight, ref["conditional.conv.weight"])
     assert torch.equal(enc.conditional.lin.weight, ref["conditional.lin.weight"])
+    nl, ng = len(enc.local), len(enc.gcond)  # heads are stored [all mu ; all log_prec]
     for i, d in enumerate(enc.local):
-        assert torch.equal(enc.local_heads.weight[2 * i], ref["q_local_defs.%s.layers.mu.weight" % d.name][0])
-        assert torch.equal(enc.local_heads.weight[2 * i + 1], ref["q_local_defs.%s.layers.log_prec.weight" % d.name][0])
-        assert torch.equal(enc.local_heads.bias[2 * i], ref["q_local_defs.%s.layers.mu.bias" % d.name][0])
+        assert torch.equal(enc.local_heads.weight[i], ref["q_local_defs.%s.layers.mu.weight" % d.name][0])
+        assert torch.equal(enc.local_heads.weight[nl + i], ref["q_local_defs.%s.layers.log_prec.weight" % d.name][0])
+        assert torch.equal(enc.local_heads.bias[i], ref["q_local_defs.%s.layers.mu.bias" % d.name][0])
+        assert torch.equal(enc.local_heads.bias[nl + i], ref["q_local_defs.%s.layers.log_prec.bias" % d.name][0])
     for i, d in enumerate(enc.gcond):
-        assert torch.equal(enc.gcond_heads.weight[2 * i], ref["q_global_cond_defs.%s.layers.mu.weight" % d.name][0])
+        assert torch.equal(enc.gcond_heads.weight[i], ref["q_global_cond_defs.%s.layers.mu.weight" % d.name][0])
+        assert torch.equal(enc.gcond_heads.weight[ng + i], ref["q_global_cond_defs.%s.layers.log_prec.weight" % d.name][0])
     for i, d in enumerate(enc.glob):
         assert float(enc.global_free[i, 0]) == float(ref["q_global_defs.%s.free_params.mu" % d.name])
         assert float(enc.global_free[i, 1]) == float(ref["q_global_defs.%s.free_params.log_prec" % d.name])

@@ -1,6 +1,7 @@
 // C ABI (include/vihds_hip.h): argument checking, model registry and dispatch to the kernel launchers.
 #include <hip/hip_runtime.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstring>
 
@@ -41,6 +42,10 @@ void launch_theta_bwd(int, int, int, const int*, const float*, const float*, con
                       hipStream_t);
 void launch_iwae_fwd(int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_iwae_finish(int, float, const float*, const float*, float*, float*, hipStream_t);
+void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_device_condition(int, int, int, int, float, float, const float*, const float*, const float*, const int*,
+                             float*, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
                          const int*, float*, float*, float*, float*, hipStream_t);
 
@@ -95,7 +100,7 @@ static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& 
   const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
-  a.solver = p->solver; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
+  a.solver = p->solver; a.logp_grad_broadcast = p->logp_grad_broadcast; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
   for (int q = 0; q < ns; ++q) {
     if (p->slot_row[q] < 0 || p->slot_row[q] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
     a.slot_row[q] = p->slot_row[q];
@@ -248,6 +253,31 @@ int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const flo
   if (B <= 0 || S <= 0 || !log_w || !lse || !g_lse || !g_logw) return fail(VIHDS_E_BADARG, "bad argument");
   launch_iwae_bwd(B, S, log_w, lse, g_lse, g_logw, (hipStream_t)stream);
   return check_hip("vihds_iwae_bwd launch");
+}
+
+int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
+                        float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream) {
+  if (B <= 0 || S <= 0 || n_iwae_total <= 0 || !logp || !log_w || !row_max || !row_sumexp || !lse || !loss)
+    return fail(VIHDS_E_BADARG, "bad argument");
+  launch_iwae_fwd(B, S, logp, log_p, log_q, log_w, row_max, row_sumexp, (hipStream_t)stream);
+  launch_iwae_finish(B, logf((float)n_iwae_total), row_max, row_sumexp, lse, loss, (hipStream_t)stream);
+  return check_hip("vihds_iwae_loss_fwd launch");
+}
+
+int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
+                        void* stream) {
+  if (B <= 0 || S <= 0 || !log_w || !lse || !g_loss || !g_logw) return fail(VIHDS_E_BADARG, "bad argument");
+  launch_iwae_loss_bwd(B, S, log_w, lse, g_loss, g_logw, (hipStream_t)stream);
+  return check_hip("vihds_iwae_loss_bwd launch");
+}
+
+int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+                           const float* dev1hot, const float* relevance, const int* is_default, float* out,
+                           void* stream) {
+  if (E <= 0 || B <= 0 || S <= 0 || D <= 0 || !z || !dev1hot || !relevance || !is_default || !out)
+    return fail(VIHDS_E_BADARG, "bad argument");
+  launch_device_condition(E, B, S, D, w_mean, w_std, z, dev1hot, relevance, is_default, out, (hipStream_t)stream);
+  return check_hip("vihds_device_condition launch");
 }
 
 int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,

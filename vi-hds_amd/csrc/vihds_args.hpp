@@ -7,6 +7,7 @@ namespace vihds {
 struct OdeArgs {
   int B, S, T, C, n;  // n = B*S
   int solver;
+  int logp_grad_broadcast;  // backward: g_logp is one [B][S] array applied to all four species
   int slot_row[VIHDS_MAX_SLOTS];
   const float* theta;
   const float* cond;

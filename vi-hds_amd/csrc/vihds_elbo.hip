@@ -179,6 +179,50 @@ __global__ void iwae_bwd_kernel(int B, int S, const float* __restrict__ log_w, c
   g_logw[i] = g_lse[b] * expf(log_w[i] - lse[b]);
 }
 
+// lse[b] = max + log(sumexp); loss = -mean_b(lse - log n_iwae)  (vihds/training.py:144-149); one block, fixed order
+__global__ void __launch_bounds__(256)
+iwae_finish_kernel(int B, float log_n, const float* __restrict__ row_max, const float* __restrict__ row_sumexp,
+                   float* __restrict__ lse, float* __restrict__ loss) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float l = row_max[b] + logf(row_sumexp[b]);
+    lse[b] = l;
+    acc += l - log_n;
+  }
+  acc = block_sum<256>(acc, sm);
+  if (threadIdx.x == 0) loss[0] = -acc / (float)B;
+}
+
+// d loss / d log_w = -(g_loss / B) * softmax_s(log_w)
+__global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log_w, const float* __restrict__ lse,
+                                     const float* __restrict__ g_loss, float* __restrict__ g_logw) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= B * S) return;
+  const int b = i / S;
+  g_logw[i] = -(g_loss[0] / (float)B) * expf(log_w[i] - lse[b]);
+}
+
+// OdeModel.device_conditioner applied to ones (reference vihds/ode.py:43-58, models/dr_constant.py:124-131):
+//   out[e][b][s] = (default_e ? 1 : 0) + relu( sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] * rel[e][d] ),
+//   r = (b*S + s) mod B   -- the reference tiles the [B,1] conditioner output with .repeat([S,1]) against a
+//   row-major flattening of [B,S] (ode.py:46,52-57); kept as is.
+__global__ void device_condition_kernel(int E, int B, int S, int D, float w_mean, float w_std,
+                                        const float* __restrict__ z, const float* __restrict__ dev1hot,
+                                        const float* __restrict__ rel, const int* __restrict__ is_default,
+                                        float* __restrict__ out) {
+  const int n = B * S;
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int r = i % B;
+  for (int e = 0; e < E; ++e) {
+    float c = 0.f;
+    for (int d = 0; d < D; ++d) c += (w_mean + w_std * z[e * D + d]) * (dev1hot[r * D + d] * rel[e * D + d]);
+    c = fmaxf(c, 0.f);
+    out[(size_t)e * n + i] = (is_default[e] ? 1.f : 0.f) + c;
+  }
+}
+
 // Results.init (vihds/utils.py:79-99): one block per (b, t); rows of the [T][*][B][S] buffers are contiguous in s.
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
@@ -247,6 +291,23 @@ void launch_iwae_bwd(int B, int S, const float* log_w, const float* lse, const f
                      hipStream_t st) {
   const int n = B * S, blk = 256;
   hipLaunchKernelGGL(iwae_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_lse, g_logw);
+}
+void launch_iwae_finish(int B, float log_n, const float* row_max, const float* row_sumexp, float* lse, float* loss,
+                        hipStream_t st) {
+  hipLaunchKernelGGL(iwae_finish_kernel, dim3(1), dim3(256), 0, st, B, log_n, row_max, row_sumexp, lse, loss);
+}
+void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
+                          hipStream_t st) {
+  const int n = B * S, blk = 256;
+  hipLaunchKernelGGL(iwae_loss_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_loss,
+                     g_logw);
+}
+void launch_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+                             const float* dev1hot, const float* rel, const int* is_default, float* out,
+                             hipStream_t st) {
+  const int n = B * S, blk = 256;
+  hipLaunchKernelGGL(device_condition_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, E, B, S, D, w_mean, w_std,
+                     z, dev1hot, rel, is_default, out);
 }
 void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
                          const float* traj, const float* xpred, const float* theta, const int* prec_rows, float* mu,

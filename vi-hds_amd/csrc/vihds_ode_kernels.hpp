@@ -300,7 +300,7 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   const size_t n = a.n;
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
     precb[j] = 0.f;
-    glp[j] = a.g_logp ? a.g_logp[(size_t)j * n + i] : 0.f;
+    glp[j] = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
   }
   const float* ob = a.obs + (size_t)b * 4 * a.T;
   const float h0 = a.times[1] - a.times[0];

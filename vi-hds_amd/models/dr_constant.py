@@ -12,6 +12,7 @@ PREC = ["prec_x", "prec_rfp", "prec_yfp", "prec_cfp"]
 
 class DR_Constant(OdeModel):
     model_key = "dr_constant"
+    extra_theta_names = ("aR", "aS")
 
     def __init__(self, config):
         super(DR_Constant, self).__init__(config)
@@ -23,10 +24,7 @@ class DR_Constant(OdeModel):
 
     def condition_theta(self, theta, dev_1hot, writer, epoch):
         """aR, aS = device_conditioner(ones) (reference dr_constant.py:124-131)."""
-        ones = torch.ones((theta.get_n_batch(), theta.get_n_samples()), device=dev_1hot.device)
-        theta.aR = self.device_conditioner(ones, "aR", dev_1hot)
-        theta.aS = self.device_conditioner(ones, "aS", dev_1hot)
-        return theta
+        return self.condition_ones(theta, ["aR", "aS"], dev_1hot)
 
     def simulate(self, config, times, theta, conditions, dev_1hot, condition_on_device=True, observations=None):
         self.aR, self.aS = theta.aR, theta.aS

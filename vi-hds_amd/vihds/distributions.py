@@ -66,6 +66,16 @@ class DotOperatorSamples(object):
     def get_tensors(self):
         return self.values
 
+    def bind_reserved_row(self, name, row):
+        """Expose a reserved row of the packed buffer (filled in place by a kernel, e.g. the device conditioner)
+        as an attribute -- what `theta.aR = ...` does in the reference -- without a copy."""
+        object.__setattr__(self, name, self._packed[row])
+        self._row_of[name] = row
+        self._rebound.pop(name, None)
+
+    def n_reserved_rows(self):
+        return 0 if self._packed is None else self._packed.shape[0] - len(self.samples)
+
     def pack(self, slot_names):
         """([R,B,S] buffer, name -> row) holding at least `slot_names`, as the simulator sees them (i.e. with
         re-bound attributes).  Zero-copy when nothing was re-bound."""

@@ -66,12 +66,15 @@ class _Heads(nn.Module):
                 ws.append(layer.weight.data)
                 if use_bias:
                     bs.append(layer.bias.data)
-        self.weight = nn.Parameter(torch.cat(ws, 0))
-        self.bias = nn.Parameter(torch.cat(bs, 0)) if use_bias else None
+        # stored as [all mu heads ; all log_prec heads] so both outputs are contiguous row blocks
+        order = list(range(0, len(ws), 2)) + list(range(1, len(ws), 2))
+        self.weight = nn.Parameter(torch.cat([ws[i] for i in order], 0))
+        self.bias = nn.Parameter(torch.cat([bs[i] for i in order], 0)) if use_bias else None
+        self.n = len(descs)
 
     def forward(self, x):
-        out = torch.nn.functional.linear(x, self.weight, self.bias)  # [B, 2*n]
-        return out[:, 0::2].t(), out[:, 1::2].t()  # mu [n,B], log_prec [n,B]
+        out = torch.nn.functional.linear(x, self.weight, self.bias).t()  # [2*n, B]
+        return out[: self.n], out[self.n:]  # mu [n,B], log_prec [n,B]
 
 
 class Encoder(nn.Module):
@@ -108,6 +111,7 @@ class Encoder(nn.Module):
         else:
             self.global_free = None
         self.register_buffer("const_values", torch.tensor([d.value for d in self.const], dtype=torch.float32))
+        self.register_buffer("const_zeros", torch.zeros(len(self.const), dtype=torch.float32))
         self.register_buffer("kind", torch.tensor([d.kind for d in self.descs], dtype=torch.int32))
         self.to(self.device)
         self.set_up_p()
@@ -144,9 +148,10 @@ class Encoder(nn.Module):
             lps.append(self.global_free[:, 1:2].expand(-1, B))
         if self.const:
             mus.append(self.const_values[:, None].expand(-1, B))
-            lps.append(torch.zeros((len(self.const), B), device=obs.device))
-        q_mu = torch.cat(mus, 0)
-        q_lp = torch.cat(lps, 0)
+            lps.append(self.const_zeros[:, None].expand(-1, B))
+        P = len(self.descs)
+        q_all = torch.cat(mus + lps, 0)  # ONE launch builds both packed tables: [2P, B]
+        q_mu, q_lp = q_all[:P], q_all[P:]
         q_prec = q_lp.exp()
         q = ChainedDistribution(name="q")
         n_lg = len(self.local) + len(self.gcond)

@@ -49,6 +49,7 @@ class OdeProblem(ctypes.Structure):
         ("n_const", ctypes.c_int),
         ("init_latent", ctypes.c_float),
         ("init_prec", ctypes.c_float),
+        ("logp_grad_broadcast", ctypes.c_int),
     ]
 
 
@@ -72,6 +73,9 @@ _PROTOTYPES = {
     "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 14),
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
+    "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
+    "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 5),
+    "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 6),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }
 

@@ -4,6 +4,7 @@
 loop -- and, fused in the same kernel, observe + the Gaussian log-likelihood -- as ONE HIP kernel
 (vihds_ode_fwd) with a hand-written discrete adjoint (vihds_ode_bwd).  There is no torchdiffeq and no CPU path.
 """
+import numpy as np
 import torch
 import torch.nn as nn
 
@@ -89,6 +90,39 @@ class OdeModel(nn.Module):
         if param_name in self.default_devices:
             return param * (1.0 + param_cond)
         return param * param_cond
+
+    # names of attributes condition_theta adds to theta (rows reserved behind the sampled parameters)
+    extra_theta_names = ()
+
+    def condition_ones(self, theta, names, dev_1hot):
+        """theta.<name> = device_conditioner(ones, name, dev_1hot) for several names in ONE kernel launch, written
+        straight into rows reserved in theta's packed buffer (falls back to the op-by-op path when theta has no
+        reserved rows, e.g. when it was built by hand)."""
+        n_batch, n_iwae = theta.get_n_batch(), theta.get_n_samples()
+        base = len(theta.samples)
+        if theta.n_reserved_rows() < len(names) or not dev_1hot.is_cuda:
+            ones = torch.ones((n_batch, n_iwae), device=dev_1hot.device)
+            for n in names:
+                setattr(theta, n, self.device_conditioner(ones, n, dev_1hot))
+            return theta
+        dev = dev_1hot.device
+        key = (tuple(names), str(dev))
+        if key not in self._relevance_dev:
+            rel = torch.tensor(np.stack([self.relevance[n] for n in names]), dtype=torch.float32, device=dev)
+            dflt = torch.tensor([1 if n in self.default_devices else 0 for n in names], dtype=torch.int32, device=dev)
+            self._relevance_dev[key] = (rel, dflt)
+        rel, dflt = self._relevance_dev[key]
+        D = dev_1hot.shape[1]
+        if self.conditioner_rng == "device":
+            z, mean, std = torch.randn((len(names), D), device=dev), 2.0, 1.5
+        else:  # the reference's stream: a fresh DeviceConditioner per name, drawn on the host
+            z = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in names], 0).to(dev)
+            mean, std = 0.0, 1.0
+        with torch.no_grad():
+            ops.device_condition(z, dev_1hot, rel, dflt, theta._packed[base: base + len(names)], mean, std)
+        for j, n in enumerate(names):
+            theta.bind_reserved_row(n, base + j)
+        return theta
 
     def condition_theta(self, theta, dev_1hot, writer, epoch):
         raise NotImplementedError("TODO: write your condition_theta")

@@ -86,6 +86,7 @@ class OdeProblemSpec:
         self.proto.n_const = n_const
         self.proto.init_latent = init_latent
         self.proto.init_prec = init_prec
+        self.covers_all_rows = len({row_of[s] for s in self.slots}) == n_rows
 
     def bind(self, B, S, T):
         p = hip.OdeProblem()
@@ -129,9 +130,17 @@ class OdeSolveObserve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_traj, g_xpred, g_logp):
         theta, cond, times, obs, traj, dev1hot, weights = ctx.saved_tensors
-        g_theta = torch.zeros_like(theta)
+        # the kernel writes every slot row; rows that are not slots (if any) must read as zero
+        g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
         g_w = torch.zeros_like(weights) if weights is not None else None
-        g_traj, g_xpred, g_logp = _c(g_traj), _c(g_xpred), _c(g_logp)
+        prob = ctx.prob
+        if g_logp is not None and g_logp.dim() == 3 and g_logp.stride(0) == 0 and g_logp[0].is_contiguous():
+            prob.logp_grad_broadcast = 1  # IwaeLoss hands back one [B,S] gradient for all four species: no copy
+            g_logp = g_logp[0]
+        else:
+            prob.logp_grad_broadcast = 0
+            g_logp = _c(g_logp)
+        g_traj, g_xpred = _c(g_traj), _c(g_xpred)
         n_aux = hip.lib().vihds_ode_bwd_aux_floats(ctypes.byref(ctx.prob))
         aux = torch.empty(n_aux, device=theta.device, dtype=torch.float32) if n_aux > 0 else None
         rc = _launch("ode_bwd", lambda: hip.lib().vihds_ode_bwd(
@@ -296,8 +305,57 @@ def iwae_lse(logp, log_p, log_q, group=None):
     return _LseFromLogw.apply(log_w, lse), log_w
 
 
+class IwaeLoss(torch.autograd.Function):
+    """Single-process -ELBO in two launches (rows kernel + finish) and one backward launch; the gradient w.r.t.
+    logp is returned as a stride-0 view over the four species (consumed without a copy by the ODE adjoint)."""
+
+    @staticmethod
+    def forward(ctx, logp, log_p, log_q, n_total):
+        _require_cuda(logp, log_p, log_q)
+        logp, log_p, log_q = _c(logp), _c(log_p), _c(log_q)
+        _, B, S = logp.shape
+        dev = logp.device
+        log_w = torch.empty((B, S), device=dev, dtype=torch.float32)
+        rows = torch.empty((3, B), device=dev, dtype=torch.float32)  # row_max, row_sumexp, lse
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        rc = hip.lib().vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q),
+                                           hip.ptr(log_w), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
+                                           hip.ptr(loss), hip.current_stream())
+        hip.check(rc, "vihds_iwae_loss_fwd")
+        lse = rows[2]
+        ctx.save_for_backward(log_w, lse)
+        ctx.has = (log_p is not None, log_q is not None)
+        ctx.mark_non_differentiable(log_w, lse)
+        return loss, log_w, lse
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):
+        log_w, lse = ctx.saved_tensors
+        B, S = log_w.shape
+        g_logw = torch.empty_like(log_w)
+        rc = hip.lib().vihds_iwae_loss_bwd(B, S, hip.ptr(log_w), hip.ptr(lse), hip.ptr(_c(g_loss)), hip.ptr(g_logw),
+                                           hip.current_stream())
+        hip.check(rc, "vihds_iwae_loss_bwd")
+        return (g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None,
+                -g_logw if ctx.has[1] else None, None)
+
+
+def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std):
+    """OdeModel.device_conditioner applied to ones for E parameters in one launch, written into `out` [E,B,S]."""
+    _require_cuda(z, dev_1hot, relevance, is_default, out)
+    E, B, S = out.shape
+    rc = hip.lib().vihds_device_condition(E, B, S, dev_1hot.shape[1], float(w_mean), float(w_std), hip.ptr(_c(z)),
+                                          hip.ptr(_c(dev_1hot)), hip.ptr(relevance), hip.ptr(is_default),
+                                          hip.ptr(out), hip.current_stream())
+    hip.check(rc, "vihds_device_condition")
+    return out
+
+
 def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None):
     """-ELBO exactly as Training.cost forms it (vihds/training.py:144-149)."""
+    if group is None:
+        S = n_iwae_total if n_iwae_total is not None else logp.shape[2]
+        return IwaeLoss.apply(logp, log_p, log_q, S)
     lse, log_w = iwae_lse(logp, log_p, log_q, group)
     S = n_iwae_total if n_iwae_total is not None else log_w.shape[1]
     return -(lse - math.log(S)).mean(), log_w, lse

@@ -14,8 +14,15 @@ class ConstantPrecisions(nn.Module):
         self.precision_vars = precision_vars
 
     def expand(self, theta, n_times, x_states):
-        # [B,S,4,T]; a stride-0 view over T instead of the reference's materialising .repeat (same values)
-        p = torch.stack([getattr(theta, v) for v in self.precision_vars], dim=-1)
+        # [B,S,4,T]; a stride-0 view over T instead of the reference's materialising .repeat (same values), and
+        # when the four precisions are consecutive rows of theta's packed buffer, a pure view of those rows
+        rows = [getattr(theta, "_row_of", {}).get(v) for v in self.precision_vars]
+        packed = getattr(theta, "_packed", None)
+        if packed is not None and None not in rows and rows == list(range(rows[0], rows[0] + len(rows))) \
+                and not any(v in theta._rebound for v in self.precision_vars):
+            p = packed[rows[0]: rows[0] + len(rows)].permute(1, 2, 0)
+        else:
+            p = torch.stack([getattr(theta, v) for v in self.precision_vars], dim=-1)
         return x_states, p.unsqueeze(3).expand(-1, -1, -1, n_times)
 
     def summaries(self, _writer, _epoch):

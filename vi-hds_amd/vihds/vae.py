@@ -33,7 +33,9 @@ class BaseVAE(nn.Module):
             u = self.shard.take(u)  # every rank drew the same full u; keep this rank's slice of S
         q = self.encoder(data)
         p = self.encoder.p
-        clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4)
+        ode_model = self.decoder.ode_model
+        n_extra = len(ode_model.extra_theta_names) if self.decoder.condition_on_device else 0
+        clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4, n_extra_rows=n_extra)
         result, conditioned_theta = self.decoder(clipped_theta, data, writer, epoch)
         return result, conditioned_theta, q, p
 
