@@ -146,11 +146,12 @@ int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const flo
 
 /* Single-process convenience: the two calls above plus the finish, i.e. all of vihds/training.py:135-149:
  * lse[b] = row_max + log(row_sumexp), loss[0] = -mean_b(lse[b] - log(n_iwae_total)).
- * Backward: g_logw[b][s] = -(g_loss[0]/B) * exp(log_w - lse[b]). */
+ * Backward: g_logw[b][s] = -(g_loss[0]/B) * exp(log_w - lse[b]); g_neg_logw (optional) receives its negation, the
+ * gradient w.r.t. log_q. */
 int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream);
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
-                        void* stream);
+                        float* g_neg_logw, void* stream);
 
 /* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
  * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *

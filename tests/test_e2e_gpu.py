@@ -34,7 +34,7 @@ def _ref_encoder_grads(fx, enc):
     if enc.glob:
         out["global_free"] = torch.stack([torch.cat([ref["q_global_defs.%s.free_params.mu" % d.name],
                                                      ref["q_global_defs.%s.free_params.log_prec" % d.name]])
-                                          for d in enc.glob])
+                                          for d in enc.glob]).t()
     return out
 
 

@@ -143,10 +143,8 @@ def test_full_chain_q_gradients_match_reference(name):
     theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_lp.exp(), kind, p_mu, p_prec, lo, hi, fx.t("u", DEV),
                                                        n_rows)
     row_of = {n: i for i, n in enumerate(fx.names + fx.extra_names)}
-    if fx.extra_names:
-        extra = torch.zeros_like(theta)
-        extra[P:] = fx.t("extra_theta", DEV)
-        theta = theta + extra
+    if fx.extra_names:  # rows P.. are reserved (uninitialised) for the conditioner's output
+        theta = torch.cat([theta[:P], fx.t("extra_theta", DEV)], 0)
     spec = H.spec_for(fx, row_of, n_rows)
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
                                                   fx.t("observations", DEV), None, None)

@@ -83,8 +83,8 @@ def test_encoder_initialises_to_reference_weights_and_q(name):
         assert torch.equal(enc.gcond_heads.weight[i], ref["q_global_cond_defs.%s.layers.mu.weight" % d.name][0])
         assert torch.equal(enc.gcond_heads.weight[ng + i], ref["q_global_cond_defs.%s.layers.log_prec.weight" % d.name][0])
     for i, d in enumerate(enc.glob):
-        assert float(enc.global_free[i, 0]) == float(ref["q_global_defs.%s.free_params.mu" % d.name])
-        assert float(enc.global_free[i, 1]) == float(ref["q_global_defs.%s.free_params.log_prec" % d.name])
+        assert float(enc.global_free[0, i]) == float(ref["q_global_defs.%s.free_params.mu" % d.name])
+        assert float(enc.global_free[1, i]) == float(ref["q_global_defs.%s.free_params.log_prec" % d.name])
     # decoder-side neural weights follow in the same RNG stream
     dref = {k[len("decoder_param/"):]: fx.t(k) for k in fx.z.files if k.startswith("decoder_param/")}
     for k, v in dict(model.decoder.named_parameters()).items():

@@ -43,7 +43,7 @@ void launch_theta_bwd(int, int, int, const int*, const float*, const float*, con
 void launch_iwae_fwd(int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_iwae_finish(int, float, const float*, const float*, float*, float*, hipStream_t);
-void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, float, float, const float*, const float*, const float*, const int*,
                              float*, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
@@ -265,9 +265,9 @@ int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const
 }
 
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
-                        void* stream) {
+                        float* g_neg_logw, void* stream) {
   if (B <= 0 || S <= 0 || !log_w || !lse || !g_loss || !g_logw) return fail(VIHDS_E_BADARG, "bad argument");
-  launch_iwae_loss_bwd(B, S, log_w, lse, g_loss, g_logw, (hipStream_t)stream);
+  launch_iwae_loss_bwd(B, S, log_w, lse, g_loss, g_logw, g_neg_logw, (hipStream_t)stream);
   return check_hip("vihds_iwae_loss_bwd launch");
 }
 

@@ -196,11 +196,14 @@ iwae_finish_kernel(int B, float log_n, const float* __restrict__ row_max, const 
 
 // d loss / d log_w = -(g_loss / B) * softmax_s(log_w)
 __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log_w, const float* __restrict__ lse,
-                                     const float* __restrict__ g_loss, float* __restrict__ g_logw) {
+                                     const float* __restrict__ g_loss, float* __restrict__ g_logw,
+                                     float* __restrict__ g_neg_logw) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= B * S) return;
   const int b = i / S;
-  g_logw[i] = -(g_loss[0] / (float)B) * expf(log_w[i] - lse[b]);
+  const float g = -(g_loss[0] / (float)B) * expf(log_w[i] - lse[b]);
+  g_logw[i] = g;
+  if (g_neg_logw) g_neg_logw[i] = -g;  // d loss / d log_q
 }
 
 // OdeModel.device_conditioner applied to ones (reference vihds/ode.py:43-58, models/dr_constant.py:124-131):
@@ -297,10 +300,10 @@ void launch_iwae_finish(int B, float log_n, const float* row_max, const float* r
   hipLaunchKernelGGL(iwae_finish_kernel, dim3(1), dim3(256), 0, st, B, log_n, row_max, row_sumexp, lse, loss);
 }
 void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
-                          hipStream_t st) {
+                          float* g_neg_logw, hipStream_t st) {
   const int n = B * S, blk = 256;
   hipLaunchKernelGGL(iwae_loss_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_loss,
-                     g_logw);
+                     g_logw, g_neg_logw);
 }
 void launch_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
                              const float* dev1hot, const float* rel, const int* is_default, float* out,

@@ -232,21 +232,37 @@ class ChainedDistribution(object):
 
     def __init__(self, name="unknown"):
         self.name = name
-        self.distributions = OrderedDict()
+        self._distributions = OrderedDict()
         self.slot_dependencies = OrderedDict()
-        self._image = None  # (kind_dev, mu_PB, prec_PB) supplied by the Encoder
+        self._image = None      # (kind_dev, mu_PB, prec_PB)
+        self._packed_q = None   # (kind_dev, q_all [2P,B] = [mu ; log_prec], names) supplied by the Encoder
+        self._builder = None    # fills _distributions on first use (the hot path never needs the member objects)
         self._clip_cache = {}
+
+    @property
+    def distributions(self):
+        if self._builder is not None:
+            builder, self._builder = self._builder, None
+            builder(self)
+        return self._distributions
 
     # ---- construction --------------------------------------------------------------------------
     def add_distribution(self, key, value, slots=None):
-        assert key not in self.distributions, "ChainedDistribution (%s) already has %s" % (self.name, key)
-        self.distributions[key] = value
+        assert key not in self._distributions, "ChainedDistribution (%s) already has %s" % (self.name, key)
+        self._distributions[key] = value
         setattr(self, key, value)
         self.slot_dependencies[key] = slots or {}
         self._image = None
 
     def attach_image(self, kind_dev, mu, prec):
         self._image = (kind_dev, mu, prec)
+
+    def attach_packed(self, kind_dev, q_all, names, builder):
+        self._packed_q = (kind_dev, q_all, list(names))
+        self._builder = builder
+
+    def names(self):
+        return self._packed_q[2] if self._packed_q is not None else list(self.distributions.keys())
 
     def order_distributions(self):
         return OrderedDict((n, i) for i, n in enumerate(self.distributions))
@@ -259,6 +275,10 @@ class ChainedDistribution(object):
 
     def image(self, device, n_batch=1):
         """Packed (kind, mu [P,Bq], prec [P,Bq]); built from the member tensors when the Encoder did not attach one."""
+        if self._image is None and self._packed_q is not None:
+            kind, q_all, names = self._packed_q
+            P = len(names)
+            self._image = (kind, q_all[:P], q_all[P:].exp())
         if self._image is None:
             mus, precs = [], []
             for d in self.distributions.values():
@@ -269,7 +289,7 @@ class ChainedDistribution(object):
                     mus.append(d.mu.reshape(-1).to(device).expand(n_batch))
                     precs.append(d.prec.reshape(-1).to(device).expand(n_batch))
             kind = torch.tensor(self.kinds(), dtype=torch.int32, device=device)
-            self._image = (kind, torch.stack(mus), torch.stack(precs))
+            self._image = (kind, torch.stack(mus).contiguous(), torch.stack(precs).contiguous())
         return self._image
 
     def clip_image(self, stddevs, device):
@@ -294,25 +314,31 @@ class ChainedDistribution(object):
         """q.sample(u) -> p.clip(., stddevs) -> (theta, log q(theta), log p(theta)) in ONE kernel
         (reference vae.py:31-34 + training.py:136-137).  log q / log p are cached on the returned theta so
         that the later q.log_prob(theta) / p.log_prob(theta) calls (Training.cost) are free."""
-        assert list_of_u.shape[-1] == len(self.distributions), (
+        names = self.names()
+        P = len(names)
+        assert list_of_u.shape[-1] == P, (
             "ChainedDistribution (%s #= %d):: must give a list of u's, one for each distribution."
             % (self.name, list_of_u.shape[-1]))
         dev = list_of_u.device
         n_batch = list_of_u.shape[0]
-        kind, q_mu, q_prec = self.image(dev, n_batch)
         if p is None:
-            p_mu = p_prec = torch.zeros(len(self.distributions), device=dev) + 1.0
-            inf = torch.full((len(self.distributions),), float("inf"), device=dev)
+            p_mu = p_prec = torch.ones(P, device=dev)
+            inf = torch.full((P,), float("inf"), device=dev)
             lo, hi = -inf, inf
         else:
-            assert list(p.distributions.keys()) == list(self.distributions.keys()), "q and p must chain the same names"
+            assert p.names() == names, "q and p must chain the same names"
             _, pm, pp = p.image(dev, 1)
-            p_mu, p_prec = pm[:, 0].contiguous(), pp[:, 0].contiguous()
+            p_mu, p_prec = pm[:, 0], pp[:, 0]
             lo, hi = p.clip_image(stddevs, dev)
-        P = len(self.distributions)
-        theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_prec, kind, p_mu, p_prec, lo, hi, list_of_u,
-                                                           P + n_extra_rows)
-        samples = DotOperatorSamples.from_packed(list(self.distributions.keys()), theta)
+        if self._packed_q is not None:
+            kind, q_all, _ = self._packed_q
+            theta, log_q, log_p = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, list_of_u,
+                                                                     P + n_extra_rows)
+        else:
+            kind, q_mu, q_prec = self.image(dev, n_batch)
+            theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_prec, kind, p_mu, p_prec, lo, hi, list_of_u,
+                                                               P + n_extra_rows)
+        samples = DotOperatorSamples.from_packed(names, theta)
         samples._log_prob_cache[id(self)] = log_q
         if p is not None:
             samples._log_prob_cache[id(p)] = log_p
@@ -325,12 +351,12 @@ class ChainedDistribution(object):
         u = u.to(device)
         if stop_grad:
             kind, mu, prec = self.image(u.device, u.shape[0])
-            saved = self._image
-            self._image = (kind, mu.detach(), prec.detach())
+            saved = (self._image, self._packed_q)
+            self._image, self._packed_q = (kind, mu.detach(), prec.detach()), None
             try:
                 return self.sample_clip_log_prob(u, None, 0.0)
             finally:
-                self._image = saved
+                self._image, self._packed_q = saved
         return self.sample_clip_log_prob(u, None, 0.0)
 
     def clip(self, theta, stddevs=3, skip=None):

@@ -73,8 +73,43 @@ class _Heads(nn.Module):
         self.n = len(descs)
 
     def forward(self, x):
-        out = torch.nn.functional.linear(x, self.weight, self.bias).t()  # [2*n, B]
-        return out[: self.n], out[self.n:]  # mu [n,B], log_prec [n,B]
+        return torch.nn.functional.linear(x, self.weight, self.bias).t()  # [2*n, B]: mu rows then log_prec rows
+
+
+class _PackQTables(torch.autograd.Function):
+    """[mu ; log_prec] tables of all P parameters, [2P, B], from the per-level pieces in ONE concatenation; the
+    backward hands each level its rows with one cat (heads) / one reduction over B (globals) instead of autograd's
+    per-slice zero-fill + copy + add chains."""
+
+    @staticmethod
+    def forward(ctx, local_t, gcond_t, global_free, const_values, B):
+        dev = (local_t if local_t is not None else global_free if global_free is not None else const_values).device
+        nl = 0 if local_t is None else local_t.shape[0] // 2
+        ng = 0 if gcond_t is None else gcond_t.shape[0] // 2
+        ngl = 0 if global_free is None else global_free.shape[1]
+        nc = const_values.shape[0]
+        ctx.sizes = (nl, ng, ngl, nc, B)
+        mus, lps = [], []
+        if nl:
+            mus.append(local_t[:nl]), lps.append(local_t[nl:])
+        if ng:
+            mus.append(gcond_t[:ng]), lps.append(gcond_t[ng:])
+        if ngl:
+            mus.append(global_free[0][:, None].expand(-1, B)), lps.append(global_free[1][:, None].expand(-1, B))
+        if nc:
+            mus.append(const_values[:, None].expand(-1, B))
+            lps.append(torch.zeros((), device=dev).expand(nc, B))
+        return torch.cat(mus + lps, 0)
+
+    @staticmethod
+    def backward(ctx, g):
+        nl, ng, ngl, nc, B = ctx.sizes
+        P = nl + ng + ngl + nc
+        g2 = g.view(2, P, B)
+        g_local = g2[:, :nl].reshape(2 * nl, B) if nl else None
+        g_gcond = g2[:, nl: nl + ng].reshape(2 * ng, B) if ng else None
+        g_glob = g2[:, nl + ng: nl + ng + ngl].sum(2) if ngl else None
+        return g_local, g_gcond, g_glob, None, None
 
 
 class Encoder(nn.Module):
@@ -106,8 +141,9 @@ class Encoder(nn.Module):
         n_g, self.g_tr, self.g_dv = n_in(self.gcond, False)
         self.local_heads = _Heads(self.local, n_l, True) if self.local else None
         self.gcond_heads = _Heads(self.gcond, n_g, False) if self.gcond else None
-        if self.glob:
-            self.global_free = nn.Parameter(torch.tensor([d.init_free_params for d in self.glob], dtype=torch.float32))
+        if self.glob:  # [2, n_global]: row 0 = mu, row 1 = log_prec
+            self.global_free = nn.Parameter(torch.tensor([d.init_free_params for d in self.glob],
+                                                         dtype=torch.float32).t().contiguous())
         else:
             self.global_free = None
         self.register_buffer("const_values", torch.tensor([d.value for d in self.const], dtype=torch.float32))
@@ -134,26 +170,25 @@ class Encoder(nn.Module):
         obs = data.observations
         delta_obs = obs[:, :, 1: self.n_times] - obs[:, :, : self.n_times - 1]
         encoded = self.conditional(delta_obs)
-        mus, lps = [], []
+        local_t = gcond_t = None
         if self.local:
             x = [encoded] + ([data.inputs] if self.l_tr else []) + ([data.dev_1hot] if self.l_dv else [])
-            m, l = self.local_heads(torch.cat(x, 1))
-            mus.append(m), lps.append(l)
+            local_t = self.local_heads(torch.cat(x, 1))
         if self.gcond:
             x = ([data.inputs] if self.g_tr else []) + ([data.dev_1hot] if self.g_dv else [])
-            m, l = self.gcond_heads(torch.cat(x, 1) if len(x) > 1 else x[0])
-            mus.append(m), lps.append(l)
-        if self.glob:
-            mus.append(self.global_free[:, 0:1].expand(-1, B))
-            lps.append(self.global_free[:, 1:2].expand(-1, B))
-        if self.const:
-            mus.append(self.const_values[:, None].expand(-1, B))
-            lps.append(self.const_zeros[:, None].expand(-1, B))
+            gcond_t = self.gcond_heads(torch.cat(x, 1) if len(x) > 1 else x[0])
         P = len(self.descs)
-        q_all = torch.cat(mus + lps, 0)  # ONE launch builds both packed tables: [2P, B]
+        q_all = _PackQTables.apply(local_t, gcond_t, self.global_free, self.const_values, B)  # [2P, B]
+        q = ChainedDistribution(name="q")
+        q.attach_packed(self.kind, q_all, self.names, lambda chain: self._build_members(chain, q_all))
+        return q
+
+    def _build_members(self, q, q_all):
+        """The per-parameter TfNormal / TfLogNormal / TfConstant views (reference encoders.py:143-169, 187-253); built
+        on first use only (evaluation, summaries, the reference-style call sequence)."""
+        P = len(self.descs)
         q_mu, q_lp = q_all[:P], q_all[P:]
         q_prec = q_lp.exp()
-        q = ChainedDistribution(name="q")
         n_lg = len(self.local) + len(self.gcond)
         for i, d in enumerate(self.descs):
             if d.kind == CONSTANT:
@@ -165,8 +200,7 @@ class Encoder(nn.Module):
                 else:  # a single global value: shape [1]
                     dist.assign_free_and_constrained(q_mu[i][:1], q_lp[i][:1], q_prec[i][:1])
             q.add_distribution(d.name, dist)
-        q.attach_image(self.kind, q_mu, q_prec)
-        return q
+        q._image = (self.kind, q_mu, q_prec)
 
     def forward(self, data):
         return self.evaluate_q(data)

@@ -74,7 +74,7 @@ _PROTOTYPES = {
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
-    "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 5),
+    "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
     "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 6),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

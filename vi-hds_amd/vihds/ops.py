@@ -212,10 +212,8 @@ class ThetaSampleLogProb(torch.autograd.Function):
         S = u.shape[1]
         if u.shape[0] != B or u.shape[2] != P:
             raise RuntimeError("u must be [B,S,P]")
-        if n_rows > P:
-            theta = torch.zeros((n_rows, B, S), device=u.device, dtype=torch.float32)
-        else:
-            theta = torch.empty((P, B, S), device=u.device, dtype=torch.float32)
+        # rows P.. are reserved for the caller (filled in place, e.g. by the device-conditioner kernel)
+        theta = torch.empty((max(n_rows, P), B, S), device=u.device, dtype=torch.float32)
         log_q = torch.empty((B, S), device=u.device, dtype=torch.float32)
         log_p = torch.empty((B, S), device=u.device, dtype=torch.float32)
         rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_mu), hip.ptr(q_prec), hip.ptr(p_mu),
@@ -240,6 +238,47 @@ class ThetaSampleLogProb(torch.autograd.Function):
                                        hip.ptr(g_prec), hip.current_stream())
         hip.check(rc, "vihds_theta_bwd")
         return g_mu, g_prec, None, None, None, None, None, None, None
+
+
+class ThetaSampleLogProbPacked(torch.autograd.Function):
+    """Same kernel as ThetaSampleLogProb, fed by the encoder's single [2P,B] table ([mu rows ; log_prec rows]):
+    prec = exp(log_prec) is formed here and the backward returns ONE [2P,B] gradient (d/d mu ; d/d log_prec), so
+    autograd needs no slice / exp nodes between the encoder heads and the kernel."""
+
+    @staticmethod
+    def forward(ctx, q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows):
+        _require_cuda(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u)
+        q_all, u = _c(q_all), _c(u)
+        P = q_all.shape[0] // 2
+        B = q_all.shape[1]
+        S = u.shape[1]
+        if u.shape[0] != B or u.shape[2] != P:
+            raise RuntimeError("u must be [B,S,P]")
+        q_prec = q_all[P:].exp()
+        theta = torch.empty((max(n_rows, P), B, S), device=u.device, dtype=torch.float32)
+        log_q = torch.empty((B, S), device=u.device, dtype=torch.float32)
+        log_p = torch.empty((B, S), device=u.device, dtype=torch.float32)
+        rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_prec), hip.ptr(p_mu),
+                                       hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
+                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), hip.current_stream())
+        hip.check(rc, "vihds_theta_fwd")
+        ctx.save_for_backward(q_all, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u)
+        ctx.set_materialize_grads(False)
+        return theta, log_q, log_p
+
+    @staticmethod
+    def backward(ctx, g_theta, g_log_q, g_log_p):
+        q_all, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u = ctx.saved_tensors
+        P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
+        g_theta, g_log_q, g_log_p = _c(g_theta), _c(g_log_q), _c(g_log_p)
+        g_all = torch.empty_like(q_all)
+        rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_prec), hip.ptr(p_mu),
+                                       hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
+                                       hip.ptr(g_theta), hip.ptr(g_log_q), hip.ptr(g_log_p), hip.ptr(g_all),
+                                       hip.ptr(g_all[P:]), hip.current_stream())
+        hip.check(rc, "vihds_theta_bwd")
+        g_all[P:].mul_(q_prec)  # d/d log_prec = prec * d/d prec
+        return g_all, None, None, None, None, None, None, None
 
 
 class IwaeRows(torch.autograd.Function):
@@ -326,18 +365,21 @@ class IwaeLoss(torch.autograd.Function):
         ctx.save_for_backward(log_w, lse)
         ctx.has = (log_p is not None, log_q is not None)
         ctx.mark_non_differentiable(log_w, lse)
+        ctx.set_materialize_grads(False)
         return loss, log_w, lse
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
+        if g_loss is None:
+            return None, None, None, None
         log_w, lse = ctx.saved_tensors
         B, S = log_w.shape
         g_logw = torch.empty_like(log_w)
+        g_neg = torch.empty_like(log_w) if ctx.has[1] else None
         rc = hip.lib().vihds_iwae_loss_bwd(B, S, hip.ptr(log_w), hip.ptr(lse), hip.ptr(_c(g_loss)), hip.ptr(g_logw),
-                                           hip.current_stream())
+                                           hip.ptr(g_neg), hip.current_stream())
         hip.check(rc, "vihds_iwae_loss_bwd")
-        return (g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None,
-                -g_logw if ctx.has[1] else None, None)
+        return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None
 
 
 def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std):
