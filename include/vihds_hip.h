@@ -83,6 +83,8 @@ typedef struct vihds_ode_problem {
   float init_prec;     /* dr_blackbox.py:102 */
   int logp_grad_broadcast; /* backward only: 1 = g_logp is ONE [B][S] array applied to all four species
                               (what the IWAE reduction hands back); 0 = [4][B][S] */
+  int kernel_variant;      /* 0 = auto; 1 = one thread per trajectory; 2 = lane-split (8 lanes per trajectory,
+                              dr_constant family only; auto picks it below 16 384 trajectories) */
 } vihds_ode_problem;
 
 int vihds_abi_version(void);

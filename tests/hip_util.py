@@ -18,9 +18,9 @@ def pack_theta(fx, device):
     return theta, {n: i for i, n in enumerate(names)}
 
 
-def spec_for(fx, row_of, n_rows, solver=None):
+def spec_for(fx, row_of, n_rows, solver=None, kernel_variant=0):
     return ops.OdeProblemSpec(fx.model, solver or fx.solver, row_of, n_rows, C=fx.z["inputs"].shape[1],
-                              D=fx.z["dev_1hot"].shape[1])
+                              D=fx.z["dev_1hot"].shape[1], kernel_variant=kernel_variant)
 
 
 def view_bsnt(buf):

@@ -43,14 +43,14 @@ def _flat_prec_weights(fx, requires_grad=False):
     return w.requires_grad_(requires_grad)
 
 
-def _hip_forward(fx, solver=None, theta=None, weights=None):
+def _hip_forward(fx, solver=None, theta=None, weights=None, kernel_variant=0):
     from vihds import ops
     import hip_util as H
 
     th, row_of = H.pack_theta(fx, DEV)
     if theta is not None:
         th = theta
-    spec = H.spec_for(fx, row_of, th.shape[0], solver)
+    spec = H.spec_for(fx, row_of, th.shape[0], solver, kernel_variant)
     if weights is None:
         weights = _flat_prec_weights(fx)
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, fx.t("inputs", DEV), fx.t("times", DEV),
@@ -158,6 +158,62 @@ def test_full_chain_q_gradients_match_reference(name):
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
     assert rel_err(gm[live], fx.t("q_mu_grad")[live]) < GTOL
     assert rel_err(gl[live], fx.t("q_logprec_grad")[live]) < GTOL
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("name", ["dr_constant_one_modeuler", "dr_constant_one_s5_modeulerwhile",
+                                  "dr_constant_icml_tiny_modeuler", "dr_constant_icml_full_modeuler",
+                                  "dr_constant_v2_tiny_modeuler"])
+def test_both_kernel_variants_match_reference(name, variant):
+    """dr_constant has two kernel families (one thread per trajectory; 8 lanes per trajectory).  Both must match the
+    reference fixture, forward and gradient, whatever the automatic size-based choice would be."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture(name)
+    th, row_of = H.pack_theta(fx, DEV)
+    th.requires_grad_(True)
+    _, _, traj, xpred, logp = _hip_forward(fx, theta=th, kernel_variant=variant)
+    st = int(fx.z["sample_stride"])
+    assert rel_err(H.view_bsnt(traj)[:, ::st], fx.t("x_states")) < TOL
+    assert rel_err(H.view_bsnt(xpred)[:, ::st], fx.t("x_predict")) < TOL
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+    loss, log_w, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
+    assert rel_err(loss, fx.t("loss")) < TOL
+    loss.backward()
+    thc = fx.theta_dict(requires_grad=True)
+    qm, qp = fx.q_params()
+    pm, pp = fx.p_params()
+    vals = [thc[n] for n in fx.names]
+    lw_extra = O.chained_log_prob(fx.kinds, pm, pp, vals) - O.chained_log_prob(fx.kinds, qm, qp, vals)
+    (lw_extra * (torch.softmax(log_w.detach().cpu(), dim=1) * (-1.0 / fx.B))).sum().backward()
+    extra = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    assert rel_err((th.grad[: len(fx.names)].cpu() + extra)[live], fx.t("theta_grad")[live]) < GTOL
+
+
+@pytest.mark.parametrize("variant", [1, 2])
+@pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4"])
+def test_lane_split_solvers_and_generic_gradients(solver, variant):
+    """euler / midpoint / rk4 and the generic upstream gradients (g_traj, g_xpred) under both kernel families, vs the
+    CPU restatement."""
+    import hip_util as H
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    g = torch.Generator().manual_seed(7)
+    thc = fx.theta_dict(requires_grad=True)
+    xs, xp, prec = O.decode(fx.model, thc, fx.t("inputs"), fx.t("times"), solver)
+    lpo = O.log_prob_observations(xp, fx.t("observations"), prec)
+    wa, wb, wc = torch.randn(xs.shape, generator=g), torch.randn(xp.shape, generator=g), torch.randn(lpo.shape, generator=g)
+    ((xs * wa).sum() + (xp * wb).sum() + (lpo * wc).sum() * 1e-4).backward()
+    th, row_of = H.pack_theta(fx, DEV)
+    th.requires_grad_(True)
+    _, _, traj, xpred, logp = _hip_forward(fx, solver=solver, theta=th, kernel_variant=variant)
+    assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+    ((H.view_bsnt(traj) * wa.to(DEV)).sum() + (H.view_bsnt(xpred) * wb.to(DEV)).sum() +
+     (H.view_bs4(logp) * wc.to(DEV)).sum() * 1e-4).backward()
+    ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
+    assert rel_err(th.grad[: len(fx.names)].cpu(), ref) < GTOL
 
 
 @pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4", "modeuler", "modeulerwhile"])

@@ -1,9 +1,21 @@
-// Instantiates the fused forward / adjoint ODE kernels for one model (one translation unit per model so the
-// library builds in parallel).  Model definition: vihds_models.hpp.
+// dr_constant (version 1): thread-per-trajectory kernels for large batches, lane-split kernels (8 lanes per
+// trajectory, vihds_dr_lanes.hpp) below VIHDS_LANE_SPLIT_MAX_N trajectories.
+#include <cstdlib>
+
 #include "vihds_ode_kernels.hpp"
+#include "vihds_dr_lanes.hpp"
 
 namespace vihds {
+static int lane_split_max_n_v1() {
+  static const int v = [] {
+    const char* e = std::getenv("VIHDS_LANE_SPLIT_MAX_N");
+    return e ? std::atoi(e) : 16384;
+  }();
+  return v;
+}
 int launch_dr_constant_v1(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v1());
+  if (lanes) return launch_dr_lanes<1>(backward, solver, a, st);
   return launch_ode<DrConstant<1>>(backward, solver, a, st);
 }
 int n_slots_dr_constant_v1() { return DrConstant<1>::NSLOT; }

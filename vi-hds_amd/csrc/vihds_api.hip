@@ -100,7 +100,7 @@ static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& 
   const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
-  a.solver = p->solver; a.logp_grad_broadcast = p->logp_grad_broadcast; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
+  a.solver = p->solver; a.kernel_variant = p->kernel_variant; a.logp_grad_broadcast = p->logp_grad_broadcast; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
   for (int q = 0; q < ns; ++q) {
     if (p->slot_row[q] < 0 || p->slot_row[q] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
     a.slot_row[q] = p->slot_row[q];

@@ -7,6 +7,7 @@ namespace vihds {
 struct OdeArgs {
   int B, S, T, C, n;  // n = B*S
   int solver;
+  int kernel_variant;  // 0 auto, 1 thread-per-trajectory, 2 lane-split
   int logp_grad_broadcast;  // backward: g_logp is one [B][S] array applied to all four species
   int slot_row[VIHDS_MAX_SLOTS];
   const float* theta;

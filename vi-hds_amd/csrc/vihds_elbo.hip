@@ -54,19 +54,27 @@ __device__ __forceinline__ float normal_lp(float mu, float prec, float x) {
   return -LOG2PI_F + 0.5f * logf(prec + 1e-12f) - 0.5f * prec * d * d;
 }
 
-// one thread per (b, s); loops over the P parameters so u[b][s][:] is read as one contiguous run and every
-// theta row store is coalesced; log q / log p accumulate in registers (no cross-thread reduction).
+// four lanes per (b, s): lane q of the quad handles parameters p = q, q+4, ...; the quad reads 16 contiguous bytes of
+// u[b][s][:] per iteration, every theta row store covers runs of 16 consecutive trajectories, and log q / log p are
+// quad-reduced with two DPP adds (no LDS, no atomics).
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xf, 0xf, false));
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
+  return v;
+}
 __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
                                  const float* __restrict__ q_prec, const float* __restrict__ p_mu,
                                  const float* __restrict__ p_prec, const float* __restrict__ clip_lo,
                                  const float* __restrict__ clip_hi, const float* __restrict__ u,
                                  float* __restrict__ theta, float* __restrict__ log_q, float* __restrict__ log_p) {
   const int n = B * S;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = t >> 2, q = t & 3;
+  const bool live = i0 < n;
+  const int i = live ? i0 : n - 1;
   const int b = i / S;
   float lq = 0.f, lp = 0.f;
-  for (int p = 0; p < P; ++p) {
+  for (int p = q; p < P; p += 4) {
     const int kd = kind[p];
     const float uu = u[(size_t)i * P + p];
     const float mu = q_mu[p * B + b];
@@ -85,14 +93,19 @@ __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ ki
       lq += normal_lp(mu, prec, v) - jac;
       lp += normal_lp(p_mu[p], p_prec[p], v) - jac;
     }
-    theta[(size_t)p * n + i] = x;
+    if (live) theta[(size_t)p * n + i] = x;
   }
-  if (log_q) log_q[i] = lq;
-  if (log_p) log_p[i] = lp;
+  lq = quad_sum(lq);
+  lp = quad_sum(lp);
+  if (live && q == 0) {
+    if (log_q) log_q[i] = lq;
+    if (log_p) log_p[i] = lp;
+  }
 }
 
-// one block per data row b; for each parameter the S per-sample contributions are reduced in a fixed order
-// (wave shuffle tree, then waves in order) so gradients are run-to-run deterministic.
+// one block per (data row b, chunk of THETA_BWD_PCHUNK parameters); for each parameter the S per-sample
+// contributions are reduced in a fixed order (wave shuffle tree, then waves in order): deterministic gradients.
+constexpr int THETA_BWD_PCHUNK = 4;
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
@@ -103,7 +116,8 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
   __shared__ float sm[BLOCK / 64];
   const int n = B * S;
   const int b = blockIdx.x;
-  for (int p = 0; p < P; ++p) {
+  const int p_end = min(P, (int)(blockIdx.y + 1) * THETA_BWD_PCHUNK);
+  for (int p = blockIdx.y * THETA_BWD_PCHUNK; p < p_end; ++p) {
     const int kd = kind[p];
     float am = 0.f, ap = 0.f;
     if (kd == KIND_CONSTANT) {
@@ -276,14 +290,14 @@ void launch_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, c
                       const float* p_prec, const float* lo, const float* hi, const float* u, float* theta,
                       float* log_q, float* log_p, hipStream_t st) {
   const int n = B * S, blk = 64;
-  hipLaunchKernelGGL(theta_fwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec, p_mu,
-                     p_prec, lo, hi, u, theta, log_q, log_p);
+  hipLaunchKernelGGL(theta_fwd_kernel, dim3((4 * n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec,
+                     p_mu, p_prec, lo, hi, u, theta, log_q, log_p);
 }
 void launch_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
                       const float* p_prec, const float* lo, const float* hi, const float* u, const float* g_theta,
                       const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec, hipStream_t st) {
-  hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B), dim3(256), 0, st, P, B, S, kind, q_mu, q_prec, p_mu, p_prec, lo,
-                     hi, u, g_theta, g_log_q, g_log_p, g_q_mu, g_q_prec);
+  hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B, (P + THETA_BWD_PCHUNK - 1) / THETA_BWD_PCHUNK), dim3(256), 0, st,
+                     P, B, S, kind, q_mu, q_prec, p_mu, p_prec, lo, hi, u, g_theta, g_log_q, g_log_p, g_q_mu, g_q_prec);
 }
 void launch_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
                      float* row_max, float* row_sumexp, hipStream_t st) {

@@ -106,16 +106,16 @@ __device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y,
   } else {
     // torchdiffeq 0.1 rk4_alt_step_func (3/8 rule)
     const float dt = t1 - t0;
-    const float d3 = dt / 3.f;  // one division per step; the per-element k/3 become multiplies (1-ulp difference)
+    const float d3 = dt * (1.f / 3.f);  // the per-element k/3 of torchdiffeq become multiplies (1-ulp difference)
     float k3[N], k4[N];
     M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + d3 * k1[j];
     M::rhs(t0 + d3, ya, p, wts, k2);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
-    M::rhs(t0 + dt * 2.f / 3.f, ya, p, wts, k3);
+    M::rhs(t0 + 2.f * d3, ya, p, wts, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);
     M::rhs(t0 + dt, ya, p, wts, k4);
-    const float d8 = dt / 8.f;
+    const float d8 = dt * 0.125f;
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = y[j] + (k1[j] + 3.f * k2[j] + 3.f * k3[j] + k4[j]) * d8;
   }
 }
@@ -157,15 +157,15 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
     call_vjp<M>(t0, y, p, wts, v, lam, pb, wtsb);
   } else {
     const float dt = t1 - t0;
-    const float d3 = dt / 3.f;
+    const float d3 = dt * (1.f / 3.f);
     float k2[N], k3[N], y2[N], y3[N];
     M::rhs(t0, y, p, wts, k1);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y2[j] = y[j] + d3 * k1[j];
     M::rhs(t0 + d3, y2, p, wts, k2);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) y3[j] = y[j] + (dt * k2[j] - d3 * k1[j]);
-    M::rhs(t0 + dt * 2.f / 3.f, y3, p, wts, k3);
+    M::rhs(t0 + 2.f * d3, y3, p, wts, k3);
     VIHDS_UNROLL for (int j = 0; j < N; ++j) ya[j] = y[j] + dt * (k1[j] - k2[j] + k3[j]);  // y4
-    const float d8 = dt / 8.f;
+    const float d8 = dt * 0.125f;
     float k1b[N], k2b[N], k3b[N];
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       v[j] = d8 * lam[j];  // k4_bar
@@ -182,7 +182,7 @@ __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const
       k3b[j] += dt * w[j];
       w[j] = 0.f;
     }
-    call_vjp<M>(t0 + dt * 2.f / 3.f, y3, p, wts, k3b, w, pb, wtsb);  // w = y3_bar
+    call_vjp<M>(t0 + 2.f * d3, y3, p, wts, k3b, w, pb, wtsb);  // w = y3_bar
     VIHDS_UNROLL for (int j = 0; j < N; ++j) {
       lam[j] += w[j];
       k1b[j] -= d3 * w[j];
@@ -248,8 +248,20 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   const float h0 = a.times[1] - a.times[0];
   const size_t n = a.n;
 
+  // times / observations are prefetched one step ahead so their load latency is off the dependent chain
+  float tA = a.times[0], tB = a.times[1];
+  float obc[4], obn[4];
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) { obc[j] = a.logp ? ob[j * a.T] : 0.f; obn[j] = 0.f; }
   for (int k = 0; k < a.T; ++k) {
-    if (k > 0) ode_step<M, SOLVER>(a.times[k - 1], a.times[k], h0, y, p, wts);
+    const float tC = (k + 1 < a.T) ? a.times[k + 1] : tB;
+    if (a.logp && k + 1 < a.T) {
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) obn[j] = ob[j * a.T + k + 1];
+    }
+    if (k > 0) {
+      ode_step<M, SOLVER>(tA, tB, h0, y, p, wts);
+      tA = tB;
+    }
+    tB = tC;
     if (a.traj) {
       VIHDS_UNROLL for (int j = 0; j < N; ++j) a.traj[((size_t)k * N + j) * n + i] = y[j];
     }
@@ -260,13 +272,14 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
     }
     if (a.logp) {
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-        const float e = xp[j] - ob[j * a.T + k];
+        const float e = xp[j] - obc[j];
         if (M::NEURAL_PREC) {  // precisions are ODE states (reference precisions.py:89-94)
           const float pr = y[(M::N - 4) + j];
           lp[j] += -0.5f * (LOG2PI_F - logf(pr) + pr * e * e);
         } else {
           lp[j] += -0.5f * (lc[j] + prec[j] * e * e);
         }
+        obc[j] = obn[j];
       }
     }
   }
@@ -305,15 +318,28 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   const float* ob = a.obs + (size_t)b * 4 * a.T;
   const float h0 = a.times[1] - a.times[0];
 
+  // software pipeline: the stored state, observations and times of step k-1 are requested while step k computes
+  float yn[N], obn[4];
+  VIHDS_UNROLL for (int j = 0; j < N; ++j) yn[j] = a.traj_in[((size_t)(a.T - 1) * N + j) * n + i];
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) obn[j] = ob[j * a.T + a.T - 1];
+  float tHi = a.times[a.T - 1], tLo = tHi;
   for (int k = a.T - 1; k >= 0; --k) {
-    float y[N];
-    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = a.traj_in[((size_t)k * N + j) * n + i];
-    if (k < a.T - 1) ode_step_vjp<M, SOLVER>(a.times[k], a.times[k + 1], h0, y, p, wts, lam, pb, wtsb);
+    float y[N], obk[4];
+    VIHDS_UNROLL for (int j = 0; j < N; ++j) y[j] = yn[j];
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) obk[j] = obn[j];
+    const float tK = tLo;
+    if (k > 0) {
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) yn[j] = a.traj_in[((size_t)(k - 1) * N + j) * n + i];
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) obn[j] = ob[j * a.T + k - 1];
+      tLo = a.times[k - 1];
+    }
+    if (k < a.T - 1) ode_step_vjp<M, SOLVER>(tK, tHi, h0, y, p, wts, lam, pb, wtsb);
+    tHi = tK;
     // gradient injected at time k: log-likelihood term, x_predict and trajectory upstream grads
     float xp[4], xpb[4];
     observe<M::OBS>(y, xp);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-      const float e = xp[j] - ob[j * a.T + k];
+      const float e = xp[j] - obk[j];
       const float pr = M::NEURAL_PREC ? y[(M::N - 4) + j] : prec[j];
       xpb[j] = -glp[j] * pr * e;
       const float prb = glp[j] * (0.5f / pr - 0.5f * e * e);

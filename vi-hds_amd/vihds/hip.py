@@ -50,6 +50,7 @@ class OdeProblem(ctypes.Structure):
         ("init_latent", ctypes.c_float),
         ("init_prec", ctypes.c_float),
         ("logp_grad_broadcast", ctypes.c_int),
+        ("kernel_variant", ctypes.c_int),
     ]
 
 

@@ -59,7 +59,7 @@ class OdeProblemSpec:
     """Host-side description of one decoder problem (struct vihds_ode_problem) for a fixed model/solver."""
 
     def __init__(self, model, solver, row_of, n_rows, C, D=0, n_hidden_prec=0, n_hidden_states=0,
-                 n_latent_states=0, n_const=0, init_latent=0.001, init_prec=1e-5):
+                 n_latent_states=0, n_const=0, init_latent=0.001, init_prec=1e-5, kernel_variant=0):
         if model not in hip.MODELS:
             raise KeyError("unknown model '%s'" % model)
         if solver not in hip.SOLVERS:
@@ -86,6 +86,7 @@ class OdeProblemSpec:
         self.proto.n_const = n_const
         self.proto.init_latent = init_latent
         self.proto.init_prec = init_prec
+        self.proto.kernel_variant = kernel_variant
         self.covers_all_rows = len({row_of[s] for s in self.slots}) == n_rows
 
     def bind(self, B, S, T):
