@@ -122,10 +122,12 @@ def main():
                          % (a.gpus, world))
     shard = parallel.init_from_env()
     rank = shard.rank if shard is not None else 0
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     use_graph = not a.eager and not a.host_rng
+    if shard is not None and (torch.distributed.get_backend() != "nccl" or os.environ.get("VIHDS_BENCH_MULTI_EAGER")):
+        use_graph = False  # only RCCL collectives can be captured in a hipGraph
     # every rank: same seed => same encoder init, same DeviceConditioner draws, same full u (sliced per rank)
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,
@@ -134,7 +136,7 @@ def main():
     model.train()
     batch = training.train_data
     step = training.graph_step if use_graph else training.step
-
+    launch_mode = "hipGraph replay" if use_graph else "eager"
     def barrier():
         torch.cuda.synchronize()
         if shard is not None:
@@ -161,24 +163,39 @@ def main():
     ops.TIMER = ops.KernelTimer()
     for _ in range(a.roofline_steps):
         training.step(batch)
+        ops.TIMER.launch("null", lambda: 0)  # an empty event pair: the events' own cost on this stream
     kt = ops.TIMER.summary()
     ops.TIMER = None
+    null_us = kt["null"]["min_us"]
+    for k in ("ode_fwd", "ode_bwd"):
+        kt[k]["mean_us"] = max(kt[k]["mean_us"] - null_us, 1e-3)
     fwd_b, bwd_b = algorithmic_bytes(B_ROWS, N_IWAE)
     dom = "ode_bwd" if kt["ode_bwd"]["mean_us"] >= kt["ode_fwd"]["mean_us"] else "ode_fwd"
-    dom_bytes = bwd_b if dom == "ode_bwd" else fwd_b
+    oth = "ode_fwd" if dom == "ode_bwd" else "ode_bwd"
+    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b}
+    solver_id = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}[a.solver]
+    lanes = B_ROWS * N_IWAE <= 16384  # the library's automatic choice (vihds_dr_lanes.hpp)
+    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d>(vihds::OdeArgs)" % (k[4:], solver_id)) if lanes else
+                ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
+             for k in ("ode_fwd", "ode_bwd")}
 
-    def gbs(nbytes, us):
-        return nbytes / (us * 1e-6) / 1e9
+    def gbs(nb, us):
+        return nb / (us * 1e-6) / 1e9
 
+    traffic, traffic_src = None, None
+    pmc_file = os.path.join(ROOT, "profiles", "r01_g_pmc_hbm_traffic.json")
+    if os.path.exists(pmc_file) and a.solver == "rk4":
+        pmc = json.load(open(pmc_file))["kernels"].get(kname[dom])
+        if pmc:
+            traffic, traffic_src = pmc["hbm_bytes_corrected"], "profiles/r01_g_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
     roofline = {
-        "bound": "hbm", "kernel": "%s_kernel<DrConstant<1>,%s>" % (dom, a.solver),
-        "achieved": gbs(dom_bytes, kt[dom]["mean_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": gbs(dom_bytes, kt[dom]["mean_us"]) / HBM_PEAK_GBS, "traffic": None,
-        "algorithmic_bytes_per_launch": dom_bytes, "mean_us": kt[dom]["mean_us"], "launches_timed": kt[dom]["launches"],
-        "other_kernel": {"kernel": "ode_fwd" if dom == "ode_bwd" else "ode_bwd",
-                         "mean_us": kt["ode_fwd" if dom == "ode_bwd" else "ode_bwd"]["mean_us"],
-                         "achieved": gbs(fwd_b if dom == "ode_bwd" else bwd_b,
-                                         kt["ode_fwd" if dom == "ode_bwd" else "ode_bwd"]["mean_us"])},
+        "bound": "hbm", "kernel": kname[dom],
+        "achieved": gbs(nbytes[dom], kt[dom]["mean_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": gbs(nbytes[dom], kt[dom]["mean_us"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": nbytes[dom], "mean_us": kt[dom]["mean_us"],
+        "launches_timed": kt[dom]["launches"], "event_pair_overhead_us_subtracted": null_us,
+        "other_kernel": {"kernel": kname[oth], "mean_us": kt[oth]["mean_us"],
+                         "achieved": gbs(nbytes[oth], kt[oth]["mean_us"]), "algorithmic_bytes_per_launch": nbytes[oth]},
         "step_algorithmic_bytes": fwd_b + bwd_b,
     }
     if rank != 0:
@@ -191,7 +208,7 @@ def main():
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
-                   "launch": "hipGraph replay" if use_graph else "eager", "u_rng": "host numpy" if a.host_rng else "device philox",
+                   "launch": launch_mode, "u_rng": "host numpy" if a.host_rng else "device philox",
                    "parallelism": "iwae-sample shard x%d" % world},
         "final_loss": final_loss, "roofline": roofline,
     }

@@ -47,8 +47,8 @@ def init_from_env(backend=None):
     if world == 1:
         return None
     if not dist.is_initialized():
-        if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend is None:  # VIHDS_DIST_BACKEND=gloo lets the plumbing be exercised with several ranks on one GPU
+            backend = os.environ.get("VIHDS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
         dist.init_process_group(backend=backend)
