@@ -15,6 +15,16 @@ def timeit(fn, n=20, warm=3):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / n * 1e3  # us
 
+from test_hip_parity import _blackbox_problem
+B, S, T = 36, 200, 86
+spec, theta, wts, cond, dev, times, obs = _blackbox_problem(B, S, T)
+th = theta.clone().requires_grad_(True); w = wts.clone().requires_grad_(True); out = {}
+def bfwd(): out["o"] = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, dev, w)
+bfwd(); gl = torch.ones_like(out["o"][2])
+def bbwd():
+    th.grad = None; w.grad = None
+    out["o"][2].backward(gl, retain_graph=True)
+print("dr_blackbox midpoint B=36 S=200: fwd %.1f us, bwd (adjoint + dump + weight-grad GEMMs) %.1f us; 4.15 GFLOP fwd declared -> %.2f TFLOP/s" % (timeit(bfwd), timeit(bbwd), 4.15e9 / timeit(bfwd) / 1e6))
 for model in ["dr_constant"]:
   for (B, S) in [(36, 200), (36, 1000), (234, 1000)]:
     for solver in ["modeuler", "midpoint", "rk4"]:

@@ -505,3 +505,79 @@ def test_bad_arguments_fail_loudly():
         ops.OdeProblemSpec("dr_constant", "rk4", {"r": 0}, 1, C=2)
     with pytest.raises(RuntimeError):
         ops.IwaeRows.apply(torch.zeros(4, 2, 3), None, None)  # CPU tensor: no fallback
+
+
+# ---------------------------------------------------------------------------------------------------
+# BASELINE configs 4 and 5 at full size (dr_blackbox 36x200, T=86; relay_constant_precisions 36x200, N=16, T=99):
+# size-independent properties -- shard consistency (bit-exact) and a directional finite-difference derivative
+# ---------------------------------------------------------------------------------------------------
+def _blackbox_problem(B, S, T, seed=0):
+    from vihds import hip, ops
+
+    g = torch.Generator().manual_seed(seed)
+    slots = hip.model_slots("dr_blackbox")
+    th = {n: (torch.full((B, S), 0.002 if n == "init_x" else 0.0) if n.startswith("init_")
+              else torch.randn(B, S, generator=g)) for n in slots}
+    theta = torch.stack([th[n] for n in slots]).to(DEV)
+    C, D = 2, 7
+    n_const = 12 + C + D
+    spec = ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
+                               n_hidden_prec=20, n_hidden_states=25, n_latent_states=2, n_const=n_const,
+                               init_latent=0.001, init_prec=1e-5)
+    n_w = hip.lib().vihds_model_n_weights(__import__("ctypes").byref(spec.bind(B, S, T)))
+    assert n_w == 1760
+    wts = (torch.randn(n_w, generator=g) * 0.3).to(DEV)
+    cond = torch.log1p(torch.rand(B, C, generator=g) * 1000.0).to(DEV)
+    dev = torch.nn.functional.one_hot(torch.arange(B) % D, D).float().to(DEV)
+    times = (torch.arange(T, dtype=torch.float32) * 0.1933).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+    return spec, theta, wts, cond, dev, times, obs
+
+
+def test_config4_blackbox_full_size_properties():
+    from vihds import ops
+
+    B, S, T = 36, 200, 86
+    spec, theta, wts, cond, dev, times, obs = _blackbox_problem(B, S, T)
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, cond, times, obs, dev, wts)
+    assert traj.shape == (T, 10, B, S) and torch.isfinite(traj).all() and torch.isfinite(logp).all()
+    h = S // 2
+    t2, _, l2 = ops.OdeSolveObserve.apply(spec, theta[:, :, :h].contiguous(), cond, times, obs, dev, wts)
+    assert torch.equal(t2, traj[:, :, :, :h]) and torch.equal(l2, logp[:, :, :h])
+    # directional derivative w.r.t. the shared MLP weights (adjoint dump + batched GEMMs) vs central differences
+    def f(w):
+        return ops.OdeSolveObserve.apply(spec, theta, cond, times, obs, dev, w)[2].double().sum() * 1e-3
+
+    w = wts.clone().requires_grad_(True)
+    f(w).backward()
+    d = torch.randn(wts.shape, device=DEV, generator=torch.Generator(device=DEV).manual_seed(2)) * 0.3
+    eps = 1e-3
+    fd = (f(wts + eps * d) - f(wts - eps * d)) / (2 * eps)
+    an = (w.grad.double() * d.double()).sum()
+    assert abs(float(fd - an)) / (abs(float(an)) + 1e-12) < 2e-2
+
+
+def test_config5_relay_precisions_full_size_properties():
+    from vihds import hip, ops
+
+    B, S, T = 36, 200, 99
+    slots = hip.model_slots("relay_constant_precisions")
+    th = _synthetic_theta(slots, B, S, 3)
+    for n in slots:
+        if n.startswith("init_prec"):
+            th[n] = torch.exp(3.0 + 0.3 * torch.randn(B, S, generator=torch.Generator().manual_seed(9)))
+    theta = torch.stack([th[n] for n in slots]).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    cond = torch.log1p(torch.rand(B, 2, generator=g) * 1000.0).to(DEV)
+    times = (torch.arange(T, dtype=torch.float32) * 0.17).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+    spec = ops.OdeProblemSpec("relay_constant_precisions", "midpoint", {n: i for i, n in enumerate(slots)}, len(slots), C=2)
+    wts = (torch.randn(2 * (4 * 13 + 4), generator=g) * 0.2).to(DEV).requires_grad_(True)
+    thg = theta.clone().requires_grad_(True)
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, thg, cond, times, obs, None, wts)
+    assert traj.shape == (T, 16, B, S) and torch.isfinite(traj).all() and torch.isfinite(logp).all()
+    (logp.double().sum() * 1e-3).backward()
+    assert torch.isfinite(thg.grad).all() and torch.isfinite(wts.grad).all()
+    h = S // 2
+    t2, _, l2 = ops.OdeSolveObserve.apply(spec, theta[:, :, h:].contiguous(), cond, times, obs, None, wts.detach())
+    assert torch.equal(t2, traj[:, :, :, h:]) and torch.equal(l2, logp[:, :, h:])
