@@ -109,9 +109,10 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
  * Shared-weight gradients:
  *   - white-box models with neural precisions: ADDED into g_weights (pre-zero it);
  *   - dr_blackbox: the contraction over (trajectory x RHS evaluation) is left to the caller as batched GEMMs:
- *     the kernel fills `aux` (vihds_ode_bwd_aux_floats floats) with, per evaluation e, the field block
- *     [E][F = vihds_blackbox_dump_fields()][B*S] (layer inputs and pre-activation gradients; field order in
- *     DESIGN.md 4.4) followed by Delta [HS+HP][B*S]; g_weights is not touched.  aux may be NULL otherwise. */
+ *     the kernel fills `aux` (vihds_ode_bwd_aux_floats floats) with the field-major dump
+ *     [F = vihds_blackbox_dump_fields()][E evaluations][B*S] (layer inputs and pre-activation gradients; field
+ *     order in DESIGN.md 4.4) followed by Delta [HS+HP][B*S] and the output-bias adjoint sums [2*NX+8][B*S];
+ *     g_weights is not touched.  aux may be NULL otherwise. */
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj,
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,

@@ -246,7 +246,8 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
     assert rel_err(got[live], ref[live]) < GTOL
 
 
-def test_blackbox_forward_and_gradients_match_reference():
+@pytest.mark.parametrize("variant", [0, 1])  # 0 = auto (MFMA formulation), 1 = VALU, one thread per trajectory
+def test_blackbox_forward_and_gradients_match_reference(variant):
     """dr_blackbox (MLP right-hand side): trajectories, precisions, log-likelihood, d loss/d theta and the gradients
     of all 1 760 shared MLP weights (adjoint kernel dump + batched GEMMs) against the reference's autograd."""
     from vihds import ops
@@ -269,7 +270,7 @@ def test_blackbox_forward_and_gradients_match_reference():
     spec = ops.OdeProblemSpec("dr_blackbox", fx.solver, row_of, P + 2, C=2, D=dev.shape[1],
                                n_hidden_prec=p["n_hidden_decoder_precisions"], n_hidden_states=p["n_hidden_decoder"],
                                n_latent_states=p["n_latent_species"], n_const=p["n_z"] + p["n_x"] + p["n_y"] + 2 + dev.shape[1],
-                               init_latent=p["init_latent_species"], init_prec=p["init_prec"])
+                               init_latent=p["init_latent_species"], init_prec=p["init_prec"], kernel_variant=variant)
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
                                                   fx.t("observations", DEV), dev, wts)
     full = H.view_bsnt(traj)

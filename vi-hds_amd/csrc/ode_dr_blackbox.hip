@@ -1,18 +1,21 @@
 // dr_blackbox kernels for the configuration of the reference's specs/dr_blackbox_icml.yaml:17-31
 // (n_latent_species 2, n_hidden_decoder 25, n_hidden_decoder_precisions 20, n_z 5, n_x 5, n_y 2).
 #include "vihds_ode_kernels.hpp"
+#include "vihds_blackbox_mfma.hpp"
 
 namespace vihds {
 using BB = Blackbox<2, 25, 20, 5, 5, 2>;
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
-  return launch_ode<BB>(backward, solver, a, st);
+  // kernel_variant 1 = VALU, one thread per trajectory (vihds_blackbox.hpp); otherwise the MFMA formulation
+  if (a.kernel_variant == 1) return launch_ode<BB>(backward, solver, a, st);
+  return launch_bb_mfma(backward, solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }
 int n_states_dr_blackbox() { return BB::N; }
 const char* slot_name_dr_blackbox(int s) { return BB::slot_name(s); }
 int bb_n_weights(int n_const) { return BB::n_weights(n_const); }
 long long bb_aux_floats(int n, int T, int solver) {
-  return (long long)(T - 1) * BB::stages(solver) * BB::NF * n + (long long)BB::NP * n;
+  return (long long)(T - 1) * BB::stages(solver) * BB::NF * n + (long long)BB::NTAIL * n;
 }
 int bb_check(int L, int HS, int HP, int n_const, int C, int D) {
   return L == 2 && HS == 25 && HP == 20 && n_const == BB::NLAT + C + D;

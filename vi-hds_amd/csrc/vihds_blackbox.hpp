@@ -28,9 +28,11 @@ template <class M>
 struct is_blackbox : std::false_type {};
 
 struct BlackboxCtx {
-  float* dump;  // &aux[i]
-  size_t n;     // trajectories (stride between fields)
-  int e;        // evaluation counter
+  float* dump;    // &aux[i]
+  size_t n;       // trajectories
+  size_t fstride; // floats between consecutive fields = E * n  (dump layout [F][E][n])
+  int e;          // evaluation counter
+  float bsum[20]; // running sums of the second-layer pre-activation adjoints (-> output-bias gradients)
 };
 
 __device__ __forceinline__ float bb_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -53,8 +55,8 @@ struct Blackbox {
                        L_CD = L_VD + 4 * HP, NW = L_CD + 4;
   // dump fields per evaluation
   static constexpr int F_ZA = 0, F_ZD = F_ZA + NX, F_HS = F_ZD + NX, F_GS = F_HS + HS, F_Y = F_GS + HS,
-                       F_ZAP = F_Y + NX, F_ZDP = F_ZAP + 4, F_HP = F_ZDP + 4, F_GP = F_HP + HP, F_T = F_GP + HP,
-                       NF = F_T + 1;
+                       F_T = F_Y + NX, F_ZAP = F_T + 1, F_ZDP = F_ZAP + 4, F_HP = F_ZDP + 4, F_GP = F_HP + HP,
+                       NF = F_GP + HP;
 
   __host__ static const char* slot_name(int s) {
     static char names[NSLOT][16];
@@ -152,10 +154,13 @@ struct Blackbox {
     }
   }
   // Delta [NP][n] after the evaluation dump
-  __device__ static void store_delta(const OdeArgs& a, int i, const float* pb) {
+  static constexpr int NTAIL = NP + 2 * NX + 8;  // Delta, then the output-bias adjoint sums
+  __device__ static void store_delta(const OdeArgs& a, int i, const float* pb, const BlackboxCtx& ctx) {
     float* d = a.aux + (size_t)dump_evals(a) * NF * a.n;
 #pragma unroll
     for (int k = 0; k < NP; ++k) d[(size_t)k * a.n + i] = pb[k];
+#pragma unroll
+    for (int k = 0; k < 2 * NX + 8; ++k) d[(size_t)(NP + k) * a.n + i] = ctx.bsum[k];
   }
   __host__ __device__ static int stages(int solver) {
     return solver == VIHDS_SOLVER_EULER ? 1 : (solver == VIHDS_SOLVER_RK4 ? 4 : 2);
@@ -212,8 +217,8 @@ struct Blackbox {
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* w, const float* v, float* yb,
                                  float* pb, BlackboxCtx& ctx) {
     __asm__ volatile("" ::: "memory");
-    float* D = ctx.dump + (size_t)ctx.e * NF * ctx.n;
-    const size_t n = ctx.n;
+    float* D = ctx.dump + (size_t)ctx.e * ctx.n;
+    const size_t n = ctx.fstride;  // distance between fields
     ctx.e += 1;
     // ---- states net: recompute, then transpose
     float hs[HS], za[NX], zd[NX];
@@ -240,6 +245,8 @@ struct Blackbox {
       D[(size_t)(F_ZA + j) * n] = zab[j];
       D[(size_t)(F_ZD + j) * n] = zdb[j];
       D[(size_t)(F_Y + j) * n] = y[j];
+      ctx.bsum[j] += zab[j];
+      ctx.bsum[NX + j] += zdb[j];
     }
 #pragma unroll
     for (int k = 0; k < HS; ++k) {
@@ -277,6 +284,8 @@ struct Blackbox {
       pdb[j] = -vj * y[NX + j] * d * (1.f - d);
       D[(size_t)(F_ZAP + j) * n] = pab[j];
       D[(size_t)(F_ZDP + j) * n] = pdb[j];
+      ctx.bsum[2 * NX + j] += pab[j];
+      ctx.bsum[2 * NX + 4 + j] += pdb[j];
     }
 #pragma unroll
     for (int k = 0; k < HP; ++k) {

@@ -27,25 +27,30 @@ __device__ __forceinline__ float dpp_mov(float old, float src) {
                                                                CTRL, ROW_MASK, BANK_MASK, false));
 }
 // value of lane J (0..7) of this lane's 8-lane group, in all 8 lanes
+// full-mask DPP move: every lane is written, so there is no 'old' value to preserve (saves a v_mov per use)
+template <int CTRL>
+__device__ __forceinline__ float dpp_all(float src) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, src), CTRL, 0xf, 0xf, true));
+}
 template <int J>
 __device__ __forceinline__ float bcast8(float v) {
   constexpr int q = J & 3;
-  float t = dpp_mov<q | (q << 2) | (q << 4) | (q << 6)>(v, v);  // quad_perm: lane q of each quad
+  float t = dpp_all<q | (q << 2) | (q << 4) | (q << 6)>(v);  // quad_perm: lane q of each quad
   if (J < 4) t = dpp_mov<0x114, 0xf, 0xA>(t, t);                  // row_shr:4 into banks 1,3 (lanes 4-7, 12-15)
   else t = dpp_mov<0x104, 0xf, 0x5>(t, t);                        // row_shl:4 into banks 0,2
   return t;
 }
 // sum over the 8-lane group, result in all 8 lanes
 __device__ __forceinline__ float sum8(float v) {
-  v += dpp_mov<0xB1>(0.f, v);   // quad_perm [1,0,3,2]
-  v += dpp_mov<0x4E>(0.f, v);   // quad_perm [2,3,0,1]
-  v += dpp_mov<0x141>(0.f, v);  // row_half_mirror: lane l <- lane 7-l of the same half row
+  v += dpp_all<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_all<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_all<0x141>(v);  // row_half_mirror: lane l <- lane 7-l of the same half row
   return v;
 }
 // sum over the quad, result in all 4 lanes
 __device__ __forceinline__ float sum4(float v) {
-  v += dpp_mov<0xB1>(0.f, v);
-  v += dpp_mov<0x4E>(0.f, v);
+  v += dpp_all<0xB1>(v);
+  v += dpp_all<0x4E>(v);
   return v;
 }
 
@@ -149,6 +154,10 @@ struct DrLanes {
   __device__ __forceinline__ static float rhs_vjp(float t, float y, const DrLane& L, float v, Adj& A) {
     Eval E;
     rhs(t, y, L, E);
+    return rhs_vjp(y, L, v, A, E);
+  }
+  // the same with the stage's intermediates already at hand (from the forward recomputation)
+  __device__ __forceinline__ static float rhs_vjp(float y, const DrLane& L, float v, Adj& A, const Eval& E) {
     float yb = v * (L.sgn * E.gam - L.deg);
     A.cb += v * E.P;
     A.degb -= v * y;
@@ -200,39 +209,42 @@ struct DrLanes {
     if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
       const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
       const float hh = 0.5f * h;
-      const float k1 = rhs(t0, y, L);
+      Eval E1;
+      const float k1 = rhs(t0, y, L, E1);
       const float ya = y + h * k1;
       float v = hh * lam;
       const float w = rhs_vjp(t1, ya, L, v, A);
       lam += w;
       v += h * w;
-      return lam + rhs_vjp(t0, y, L, v, A);
+      return lam + rhs_vjp(y, L, v, A, E1);
     } else if (SOLVER == VIHDS_SOLVER_EULER) {
       return lam + rhs_vjp(t0, y, L, (t1 - t0) * lam, A);
     } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
       const float dt = t1 - t0;
-      const float k1 = rhs(t0, y, L);
+      Eval E1;
+      const float k1 = rhs(t0, y, L, E1);
       const float ym = y + k1 * dt * 0.5f;
       const float w = rhs_vjp(t0 + dt * 0.5f, ym, L, dt * lam, A);
       lam += w;
-      return lam + rhs_vjp(t0, y, L, 0.5f * dt * w, A);
+      return lam + rhs_vjp(y, L, 0.5f * dt * w, A, E1);
     } else {
       const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
-      const float k1 = rhs(t0, y, L);
+      Eval E1, E2, E3;  // stage intermediates of the forward recomputation, reused by the transposed stages
+      const float k1 = rhs(t0, y, L, E1);
       const float y2 = y + d3 * k1;
-      const float k2 = rhs(t0 + d3, y2, L);
+      const float k2 = rhs(t0 + d3, y2, L, E2);
       const float y3 = y + (dt * k2 - d3 * k1);
-      const float k3 = rhs(t0 + 2.f * d3, y3, L);
+      const float k3 = rhs(t0 + 2.f * d3, y3, L, E3);
       const float y4 = y + dt * (k1 - k2 + k3);
       const float k4b = d8 * lam;
       float k1b = k4b, k2b = 3.f * k4b, k3b = 3.f * k4b;
       float w = rhs_vjp(t0 + dt, y4, L, k4b, A);
       lam += w; k1b += dt * w; k2b -= dt * w; k3b += dt * w;
-      w = rhs_vjp(t0 + 2.f * d3, y3, L, k3b, A);
+      w = rhs_vjp(y3, L, k3b, A, E3);
       lam += w; k1b -= d3 * w; k2b += dt * w;
-      w = rhs_vjp(t0 + d3, y2, L, k2b, A);
+      w = rhs_vjp(y2, L, k2b, A, E2);
       lam += w; k1b += d3 * w;
-      return lam + rhs_vjp(t0, y, L, k1b, A);
+      return lam + rhs_vjp(y, L, k1b, A, E1);
     }
   }
 

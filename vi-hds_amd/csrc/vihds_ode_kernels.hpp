@@ -75,7 +75,9 @@ struct bwd_ctx<M, true, true> {  // dr_blackbox
   __device__ static void init(type& c, const OdeArgs& a, int i) {
     c.dump = a.aux + i;
     c.n = (size_t)a.n;
+    c.fstride = (size_t)(a.T - 1) * M::stages(a.solver) * a.n;
     c.e = 0;
+    VIHDS_UNROLL for (int k = 0; k < 20; ++k) c.bsum[k] = 0.f;
   }
 };
 
@@ -356,7 +358,7 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   VIHDS_UNROLL for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
   if constexpr (is_blackbox<M>::value) {
     M::prepare_vjp_bb(th, a, b, pb, thb);
-    if (live) M::store_delta(a, i, pb);
+    if (live) M::store_delta(a, i, pb, wtsb);
   } else {
     M::prepare_vjp(th, c, p, pb, thb);
   }

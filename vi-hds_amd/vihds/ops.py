@@ -164,25 +164,28 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     HS, HP, L = prob.n_hidden_states, prob.n_hidden_prec, prob.n_latent_states
     NX = 4 + L
     NP = HS + HP
-    E = (aux.numel() - NP * n) // (F * n)
-    D = aux[: E * F * n].view(E, F, n)
-    delta = aux[E * F * n:].view(NP, n)
+    n_tail = NP + 2 * NX + 8
+    E = (aux.numel() - n_tail * n) // (F * n)
+    # field-major dump; viewed [E, rows, n] so the contraction is a strided batched GEMM over the E evaluations
+    # (split-K over evaluations: a single GEMM with K = E*n ~ 10^6 runs on one workgroup in hipBLASLt)
+    D = aux[: F * E * n].view(F, E, n).permute(1, 0, 2)
+    tail = aux[F * E * n:].view(n_tail, n)
+    delta, bias_sums = tail[:NP], tail[NP:].sum(1)
     o = 0
     za_zd = D[:, o: o + 2 * NX]; o += 2 * NX
     hs = D[:, o: o + HS]; o += HS
     gs = D[:, o: o + HS]; o += HS
-    y = D[:, o: o + NX]; o += NX
+    y = D[:, o: o + NX]
+    y_t = D[:, o: o + NX + 1]; o += NX + 1   # states followed by the evaluation time
     zap_zdp = D[:, o: o + 8]; o += 8
     hp = D[:, o: o + HP]; o += HP
     gp = D[:, o: o + HP]; o += HP
-    tt = D[:, o: o + 1]
-    g_out_s = torch.bmm(za_zd, hs.transpose(1, 2)).sum(0)    # [2NX, HS]: d Wp ; d Wd
-    g_in_s = torch.bmm(gs, y.transpose(1, 2)).sum(0)          # [HS, NX]: d Wh[:, :NX]
+    g_out_s = torch.bmm(za_zd, hs.transpose(1, 2)).sum(0)     # [2NX, HS]: d Wp ; d Wd
+    g_in_s = torch.bmm(gs, y.transpose(1, 2)).sum(0)          # [HS, NX]:  d Wh[:, :NX]
     g_out_p = torch.bmm(zap_zdp, hp.transpose(1, 2)).sum(0)   # [8, HP]
-    g_in_p = torch.bmm(gp, y.transpose(1, 2)).sum(0)          # [HP, NX]
-    g_t = (gp * tt).sum((0, 2))                               # [HP]: d Vh[:, 0]
-    b_out_s = za_zd.sum((0, 2))
-    b_out_p = zap_zdp.sum((0, 2))
+    g_yt = torch.bmm(gp, y_t.transpose(1, 2)).sum(0)          # [HP, NX+1]
+    g_in_p = torch.cat([g_yt[:, NX:], g_yt[:, :NX]], 1)       # d Vh[:, :1+NX]: time column first, then the states
+    b_out_s, b_out_p = bias_sums[: 2 * NX], bias_sums[2 * NX:]
     # time-invariant inputs as the kernel saw them: latent theta rows (slot order), treatments, device one-hot
     n_lat = prob.n_const - prob.C - prob.D
     rows = torch.tensor([prob.slot_row[q] for q in range(n_lat)], device=theta.device)
@@ -193,7 +196,7 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     b_hid = delta.sum(1)
     parts = [torch.cat([g_in_s, g_const[:HS]], 1).reshape(-1), b_hid[:HS], g_out_s[:NX].reshape(-1), b_out_s[:NX],
              g_out_s[NX:].reshape(-1), b_out_s[NX:],
-             torch.cat([g_t[:, None], g_in_p, g_const[HS:]], 1).reshape(-1), b_hid[HS:], g_out_p[:4].reshape(-1),
+             torch.cat([g_in_p, g_const[HS:]], 1).reshape(-1), b_hid[HS:], g_out_p[:4].reshape(-1),
              b_out_p[:4], g_out_p[4:].reshape(-1), b_out_p[4:]]
     return torch.cat(parts)
 
