@@ -173,6 +173,24 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
                        float* iw_predict_mu /*[B][4][T]*/, float* iw_predict_std /*[B][4][T]*/,
                        float* iw_states /*[B][n_species][T]*/, float* iw_variance /*[B][4][T]*/, void* stream);
 
+/* Adam update of the encoder / decoder-network parameters (reference training.py:82,338: torch.optim.Adam, default
+ * betas/eps, no weight decay, no amsgrad) as one launch over up to VIHDS_ADAM_MAX_TENSORS parameter tensors:
+ *   m += (g - m)(1-beta1);  v = beta2 v + (1-beta2) g^2;  t = step+1
+ *   p -= lr / (1-beta1^t) * m / (sqrt(v) / sqrt(1-beta2^t) + eps)
+ * m / v are flat buffers holding the tensors back to back in table order.  `state` is two device floats
+ * {step count, block ticket}: the kernel reads the count, and the last block to finish increments it, so the whole
+ * update is graph-capturable with no host-side step.  lr_dev (optional) overrides lr with a device scalar (learning
+ * rate schedules under a captured graph). */
+#define VIHDS_ADAM_MAX_TENSORS 32
+typedef struct vihds_adam_tensors {
+  int n;
+  int size[VIHDS_ADAM_MAX_TENSORS];
+  float* param[VIHDS_ADAM_MAX_TENSORS];
+  const float* grad[VIHDS_ADAM_MAX_TENSORS]; /* NULL: tensor received no gradient this step, skipped */
+} vihds_adam_tensors;
+int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
+                    float beta1, float beta2, float eps, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -582,3 +582,40 @@ def test_config5_relay_precisions_full_size_properties():
     h = S // 2
     t2, _, l2 = ops.OdeSolveObserve.apply(spec, theta[:, :, h:].contiguous(), cond, times, obs, None, wts.detach())
     assert torch.equal(t2, traj[:, :, :, h:]) and torch.equal(l2, logp[:, :, h:])
+
+
+@pytest.mark.parametrize("n_tensors,lr_on_device", [(5, False), (40, True)])
+def test_adam_step_matches_torch_adam(n_tensors, lr_on_device):
+    """vihds_adam_step (one launch, device-side step counter) vs torch.optim.Adam on the CPU over several steps,
+    including a tensor that receives no gradient, more tensors than one launch table holds, and a device lr that
+    changes between steps (reference training.py:82,338,372: Adam + MultiStepLR)."""
+    from vihds.optim import HipAdam
+
+    g = torch.Generator().manual_seed(5)
+    shapes = [(720, 50), (50,), (10, 4, 10), (3,), (1,)] + [(7, 3)] * (n_tensors - 5)
+    ref = [torch.randn(s, generator=g).requires_grad_(True) for s in shapes]
+    dev = [r.detach().clone().to(DEV).requires_grad_(True) for r in ref]
+    lr = torch.tensor(0.01, device=DEV) if lr_on_device else 0.01
+    opt_ref = torch.optim.Adam(ref, lr=0.01)
+    opt = HipAdam(dev, lr=lr)
+    for it in range(6):
+        for k, (r, d) in enumerate(zip(ref, dev)):
+            if k == 3 and it < 2:  # no gradient yet: both optimisers must leave it alone
+                r.grad = d.grad = None
+                continue
+            gr = torch.randn(r.shape, generator=g) * (1.0 + it)
+            r.grad, d.grad = gr.clone(), gr.to(DEV)
+        if it == 3:
+            for grp in opt_ref.param_groups:
+                grp["lr"] = 0.002
+            if lr_on_device:
+                lr.fill_(0.002)
+            else:
+                opt.param_groups[0]["lr"] = 0.002
+        opt_ref.step()
+        opt.step()
+    assert opt.step_count() == 6
+    for k, (r, d) in enumerate(zip(ref, dev)):
+        if k == 3:
+            continue  # torch starts that tensor's own step count late; the flat device counter does not
+        assert rel_err(d.detach().cpu(), r.detach()) < 2e-6, k

@@ -46,6 +46,7 @@ void launch_iwae_finish(int, float, const float*, const float*, float*, float*, 
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, float, float, const float*, const float*, const float*, const int*,
                              float*, hipStream_t);
+void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
                          const int*, float*, float*, float*, float*, hipStream_t);
 
@@ -292,6 +293,16 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
   launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, theta, prec_rows, iw_predict_mu,
                       iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
   return check_hip("vihds_iw_summaries launch");
+}
+
+int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
+                    float beta1, float beta2, float eps, void* stream) {
+  if (!t || !m || !v || !state) return fail(VIHDS_E_BADARG, "null argument");
+  if (t->n < 0 || t->n > VIHDS_ADAM_MAX_TENSORS) return fail(VIHDS_E_BADARG, "tensor count out of range");
+  for (int k = 0; k < t->n; ++k)
+    if (t->size[k] < 0 || !t->param[k]) return fail(VIHDS_E_BADARG, "bad tensor table entry");
+  launch_adam(*t, m, v, state, lr_dev, lr, beta1, beta2, eps, (hipStream_t)stream);
+  return check_hip("vihds_adam_step launch");
 }
 
 }  // extern "C"

@@ -285,6 +285,10 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
       tA = tB;
     }
     tB = tC;
+    // land the prefetched values here, before this step's stores are issued: the vmcnt wait the compiler needs for
+    // them then covers the previous step's stores (a full step old) instead of stalling on the ones just issued
+    float ob_nx = ob_next;
+    asm volatile("" : "+v"(tB), "+v"(ob_nx));
     if (a.traj && live) a.traj[((size_t)k * 8 + j) * n + i] = y;
     float inner;
     const float xp = D::observe(y, bcast8<0>(y), L, inner);
@@ -293,7 +297,7 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
       const float e = xp - ob_cur;
       lp += -0.5f * (lc + L.prec * e * e);
     }
-    ob_cur = ob_next;
+    ob_cur = ob_nx;
   }
   if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
 }

@@ -58,6 +58,16 @@ _LIB = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 
+ADAM_MAX_TENSORS = 32
+
+
+class AdamTensors(ctypes.Structure):
+    """struct vihds_adam_tensors (include/vihds_hip.h)"""
+
+    _fields_ = [("n", ctypes.c_int), ("size", ctypes.c_int * ADAM_MAX_TENSORS),
+                ("param", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grad", ctypes.c_void_p * ADAM_MAX_TENSORS)]
+
+
 _PROTOTYPES = {
     "vihds_abi_version": (_I, []),
     "vihds_last_error": (ctypes.c_char_p, []),
@@ -77,6 +87,7 @@ _PROTOTYPES = {
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
     "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 6),
+    "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 4 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }
 

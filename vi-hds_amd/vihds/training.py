@@ -65,9 +65,13 @@ class Training:
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))
         # capturable Adam keeps step counts on the device => the whole step can live in one hipGraph
         self.lr = torch.tensor(float(p.learning_rate), device=settings.device) if self.use_graph else p.learning_rate
-        # fused Adam: one multi-tensor kernel for the whole update instead of ~10 foreach launches
-        self.optimizer = torch.optim.Adam(model.parameters(recurse=True), lr=self.lr, capturable=self.use_graph,
-                                          fused=True if on_gpu else None)
+        # one launch for the whole update, step counter on the device (vihds/optim.py)
+        if on_gpu:
+            from vihds.optim import HipAdam
+
+            self.optimizer = HipAdam(model.parameters(recurse=True), lr=self.lr)
+        else:  # host-side construction only (CPU unit tests of the control flow); the decoder itself has no CPU path
+            self.optimizer = torch.optim.Adam(model.parameters(recurse=True), lr=self.lr)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, p.learning_boundaries,
                                                               gamma=p.learning_gamma)
         n_vals = LocalAndGlobal.from_list(parameters.get_parameter_counts())
