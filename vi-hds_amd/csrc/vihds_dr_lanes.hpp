@@ -59,8 +59,16 @@ struct DrLane {
   float r, invK, K, tlag, rc, fR, fS;
   // this lane's species
   float sgn, deg, a, c, e, KGR, KGS, prec;
+  // promoter in the lane's own operand order: lanes 2 / 3 see (v1, v2) = (LuxR, LasR) / (LasR, LuxR) after one
+  // row_shl:4 and one swap, so  KGR*bR + KGS*bS = c1*v1^2 + c2*v2^2  with c1, c2 folded per lane (0 elsewhere)
+  float c1, c2, c1x2, c2x2, ce, cm;  // ce = c*e, cm = c*(1-e):  c*P = ce + cm * kb/(1+kb)
   float m0, m6, m7, mo1, mo2;  // lane masks (1.0 / 0.0): species 0, 6, 7; observe: own state, state j+2
+  float m0invK;
+  float tm1, tm2;              // this lane's stage-time multipliers (lane j&3 evaluates the sigmoid of stage j&3)
+  int js;                      // j & 3
 };
+
+constexpr int QP_SWAP23 = 0 | (1 << 2) | (3 << 4) | (2 << 6);  // quad_perm [0,1,3,2]
 
 template <int VERSION>
 struct DrLanes {
@@ -99,6 +107,7 @@ struct DrLanes {
     }
   }
 
+  template <int SOLVER>
   __device__ static void prepare(const OdeArgs& a, int i, int b, int j, DrLane& L, float* c, float& y0) {
     c[0] = clampf(expf(a.cond[b * a.C + 0]) - 1.f, 1e-12f, 1e6f);
     c[1] = clampf(expf(a.cond[b * a.C + 1]) - 1.f, 1e-12f, 1e6f);
@@ -117,88 +126,144 @@ struct DrLanes {
     if (j == 2) { L.e = th(a, M::S_e81, i); L.KGR = th(a, M::S_KGR81, i); L.KGS = th(a, M::S_KGS81, i); }
     else if (j == 3) { L.e = th(a, M::S_e76, i); L.KGR = th(a, M::S_KGR76, i); L.KGS = th(a, M::S_KGS76, i); }
     else { L.e = 1.f; L.KGR = 0.f; L.KGS = 0.f; }
+    // lane 2: (v1, v2) = (LuxR, LasR); lane 3: (LasR, LuxR)
+    L.c1 = j == 3 ? L.KGS * L.fS : L.KGR * L.fR;
+    L.c2 = j == 3 ? L.KGR * L.fR : L.KGS * L.fS;
+    if (j != 2 && j != 3) { L.c1 = 0.f; L.c2 = 0.f; }
+    L.c1x2 = 2.f * L.c1; L.c2x2 = 2.f * L.c2;
+    L.ce = L.c * L.e;
+    L.cm = (j == 2 || j == 3) ? L.c * (1.f - L.e) : 0.f;
     L.prec = j < 4 ? th(a, M::NSLOT + j, i) : 1.f;
     L.m0 = j == 0 ? 1.f : 0.f; L.m6 = j == 6 ? 1.f : 0.f; L.m7 = j == 7 ? 1.f : 0.f;
     L.mo1 = (j >= 1 && j <= 3) ? 1.f : 0.f; L.mo2 = (j == 2 || j == 3) ? 1.f : 0.f;
+    L.m0invK = L.m0 * L.invK;
+    L.js = j & 3;
+    // stage times (torchdiffeq fixed-grid tableaux; solvers.py:9-41 for the Heun variants)
+    L.tm1 = 0.f; L.tm2 = 0.f;
+    if (SOLVER == VIHDS_SOLVER_RK4) {         // t0, t0 + dt/3, t0 + 2 dt/3, t0 + dt
+      L.tm1 = L.js == 1 ? 1.f : (L.js == 2 ? 2.f : 0.f);
+      L.tm2 = L.js == 3 ? 1.f : 0.f;
+    } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {  // t0, t0 + dt/2
+      L.tm1 = L.js == 1 ? 0.5f : 0.f;
+    }
     const int is = init_slot(j);
     y0 = is < 0 ? 0.f : th(a, is, i);
   }
 
-  struct Eval {
-    float x, lR, lS, sig, gr, g, gam, bR, bS, den, P;
+  // ---- growth-rate sigmoid, one stage per lane ------------------------------------------------------------
+  // gr(t) = r * sigmoid(4 (t - tlag)) does not depend on the state, so the (up to) four stage times of a step are
+  // evaluated side by side in the four lanes of each quad and handed to the stages by a quad_perm broadcast:
+  // one exp + one rcp per step instead of one per stage.
+  struct Sig {
+    float sig, gr;
   };
-  __device__ __forceinline__ static float rhs(float t, float y, const DrLane& L, Eval& E) {
-    E.x = bcast8<0>(y);
-    E.lR = bcast8<6>(y);
-    E.lS = bcast8<7>(y);
-    E.sig = sigmoid_f(4.f * (t - L.tlag));
-    E.gr = L.r * E.sig;
-    E.g = 1.f - E.x * L.invK;
-    E.gam = E.gr * E.g;
-    E.bR = E.lR * E.lR * L.fR;
-    E.bS = E.lS * E.lS * L.fS;
-    const float num = L.e + L.KGR * E.bR + L.KGS * E.bS;
-    E.den = 1.f + L.KGR * E.bR + L.KGS * E.bS;
-    E.P = fdiv(num, E.den);
-    return L.c * E.P + (L.sgn * E.gam - L.deg) * y;
+  template <int SOLVER>
+  __device__ __forceinline__ static Sig stage_sigmoid(float t0, float t1, const DrLane& L) {
+    float tj;
+    if (SOLVER == VIHDS_SOLVER_RK4) {
+      const float dt = t1 - t0, d3 = dt * (1.f / 3.f);
+      tj = fmaf(L.tm2, dt, fmaf(L.tm1, d3, t0));
+    } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
+      tj = fmaf(L.tm1, t1 - t0, t0);
+    } else if (SOLVER == VIHDS_SOLVER_EULER) {
+      tj = t0;
+    } else {  // Heun: f(t0, .), f(t1, .)
+      tj = L.js == 1 ? t1 : t0;
+    }
+    Sig s;
+    s.sig = sigmoid_f(4.f * (tj - L.tlag));
+    s.gr = L.r * s.sig;
+    return s;
   }
-  __device__ __forceinline__ static float rhs(float t, float y, const DrLane& L) {
-    Eval E;
-    return rhs(t, y, L, E);
+  template <int STAGE>
+  __device__ __forceinline__ static float stage_gr(const Sig& s) {
+    return dpp_all<STAGE | (STAGE << 2) | (STAGE << 4) | (STAGE << 6)>(s.gr);
   }
 
-  struct Adj {  // parameter adjoints: per-lane (cb, degb, eb, KGRb, KGSb) and shared (identical in all 8 lanes)
-    float cb, degb, eb, KGRb, KGSb, rb, Kb, tlagb, fRb, fSb;
+  struct Eval {
+    float x, v1, v2, b1, b2, rd, t, g, gr, coef;
   };
-  // returns (d rhs/d y)^T v for this lane's state; accumulates parameter adjoints
-  __device__ __forceinline__ static float rhs_vjp(float t, float y, const DrLane& L, float v, Adj& A) {
-    Eval E;
-    rhs(t, y, L, E);
-    return rhs_vjp(y, L, v, A, E);
+  // dy_j = c_j P_j + (s_j gamma - deg_j) y_j  with  c P = ce + cm * kb / (1 + kb),  kb = KGR bR + KGS bS
+  // (the same promoter as dr_constant.py:88-95 with the numerator split off: (e + kb)/(1 + kb) = e + (1-e) kb/(1+kb))
+  __device__ __forceinline__ static float rhs(float gr, float y, const DrLane& L, Eval& E) {
+    E.x = bcast8<0>(y);
+    E.v1 = dpp_mov<0x104, 0xf, 0x5>(0.f, y);  // row_shl:4 into lanes 0-3 of the group: lane 2 <- LuxR, lane 3 <- LasR
+    E.v2 = dpp_all<QP_SWAP23>(E.v1);           // lane 2 <- LasR, lane 3 <- LuxR
+    E.gr = gr;
+    E.b1 = E.v1 * E.v1;
+    E.b2 = E.v2 * E.v2;
+    const float kb = fmaf(L.c2, E.b2, L.c1 * E.b1);
+    E.rd = frcp(1.f + kb);
+    E.t = kb * E.rd;
+    E.g = fmaf(-L.invK, E.x, 1.f);
+    E.coef = fmaf(L.sgn, gr * E.g, -L.deg);
+    return fmaf(E.coef, y, fmaf(L.cm, E.t, L.ce));
   }
-  // the same with the stage's intermediates already at hand (from the forward recomputation)
-  __device__ __forceinline__ static float rhs_vjp(float y, const DrLane& L, float v, Adj& A, const Eval& E) {
-    float yb = v * (L.sgn * E.gam - L.deg);
-    A.cb += v * E.P;
-    A.degb -= v * y;
-    const float nb = fdiv(v * L.c, E.den);
-    const float s = nb - nb * E.P;
-    A.eb += nb;
-    A.KGRb += s * E.bR;
-    A.KGSb += s * E.bS;
-    const float bRb = sum8(s * L.KGR);
-    const float bSb = sum8(s * L.KGS);
-    const float gamb = sum8(v * L.sgn * y);
-    yb += L.m6 * (bRb * 2.f * E.lR * L.fR) + L.m7 * (bSb * 2.f * E.lS * L.fS);
-    A.fRb += bRb * E.lR * E.lR;
-    A.fSb += bSb * E.lS * E.lS;
-    const float grb = gamb * E.g, gb = gamb * E.gr;
-    yb -= L.m0 * (gb * L.invK);
-    A.Kb += gb * E.x * L.invK * L.invK;
-    A.rb += grb * E.sig;
-    A.tlagb -= 4.f * grb * L.r * E.sig * (1.f - E.sig);
+  __device__ __forceinline__ static float rhs(float gr, float y, const DrLane& L) {
+    Eval E;
+    return rhs(gr, y, L, E);
+  }
+
+  // Adjoint accumulators.  Everything that is linear in the stage adjoints is only summed here and mapped to the
+  // parameters once, after the time loop (bwd kernel tail).
+  struct Adj {
+    float sv, svt;    // sum v, sum v*t          -> c, e
+    float degb;       // -sum v*y                -> deg
+    float c1b, c2b;   // sum kb_bar * v1^2, v2^2 -> KGR, KGS, fR, fS
+    float gbx;        // sum gamma_bar*gr*x      -> K
+    float rb, tl;     // per stage lane: sum gr_bar*sig, sum gr_bar*r*sig*(1-sig) -> r, tlag
+  };
+  // returns (d rhs/d y)^T v for this lane's state; accumulates parameter adjoints; grb = adjoint of this stage's gr
+  __device__ __forceinline__ static float rhs_vjp(float y, const DrLane& L, float v, Adj& A, const Eval& E, float& grb) {
+    float yb = v * E.coef;
+    A.sv += v;
+    A.svt = fmaf(v, E.t, A.svt);
+    const float vy = v * y;
+    A.degb -= vy;
+    const float gamb = sum8(L.sgn * vy);
+    // promoter (non-zero in lanes 2, 3 only): t = kb rd, d t / d kb = rd (1 - t)
+    const float kbb = (v * L.cm) * fmaf(-E.t, E.rd, E.rd);
+    A.c1b = fmaf(kbb, E.b1, A.c1b);
+    A.c2b = fmaf(kbb, E.b2, A.c2b);
+    const float v1b = (kbb * L.c1x2) * E.v1;
+    const float v2b = (kbb * L.c2x2) * E.v2;
+    const float tot = v1b + dpp_all<QP_SWAP23>(v2b);  // lane 2: -> LuxR, lane 3: -> LasR
+    yb += dpp_mov<0x114, 0xf, 0xA>(0.f, tot);          // row_shr:4: lanes 6, 7 receive from lanes 2, 3
+    const float gb = gamb * E.gr;
+    yb = fmaf(-L.m0invK, gb, yb);
+    A.gbx = fmaf(gb, E.x, A.gbx);
+    grb = gamb * E.g;
     return yb;
   }
+  // per-stage gr adjoints -> this lane's stage accumulators
+  __device__ __forceinline__ static void stage_sigmoid_vjp(const Sig& s, const DrLane& L, float g1, float g2, float g3,
+                                                           float g4, Adj& A) {
+    const float gsel = L.js == 0 ? g1 : (L.js == 1 ? g2 : (L.js == 2 ? g3 : g4));
+    A.rb = fmaf(gsel, s.sig, A.rb);
+    A.tl = fmaf(gsel, s.gr * (1.f - s.sig), A.tl);
+  }
 
+  // number of RHS evaluations per step
   template <int SOLVER>
   __device__ __forceinline__ static float step(float t0, float t1, float h0, float y, const DrLane& L) {
+    const Sig s = stage_sigmoid<SOLVER>(t0, t1, L);
     if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
       const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
-      const float k1 = rhs(t0, y, L);
-      const float k2 = rhs(t1, y + h * k1, L);
+      const float k1 = rhs(stage_gr<0>(s), y, L);
+      const float k2 = rhs(stage_gr<1>(s), y + h * k1, L);
       return y + (0.5f * h) * (k1 + k2);
     } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      return y + (t1 - t0) * rhs(t0, y, L);
+      return y + (t1 - t0) * rhs(stage_gr<0>(s), y, L);
     } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
       const float dt = t1 - t0;
-      const float k1 = rhs(t0, y, L);
-      return y + dt * rhs(t0 + dt * 0.5f, y + k1 * dt * 0.5f, L);
+      const float k1 = rhs(stage_gr<0>(s), y, L);
+      return y + dt * rhs(stage_gr<1>(s), y + k1 * dt * 0.5f, L);
     } else {
       const float dt = t1 - t0, d3 = dt * (1.f / 3.f);
-      const float k1 = rhs(t0, y, L);
-      const float k2 = rhs(t0 + d3, y + d3 * k1, L);
-      const float k3 = rhs(t0 + 2.f * d3, y + (dt * k2 - d3 * k1), L);
-      const float k4 = rhs(t0 + dt, y + dt * (k1 - k2 + k3), L);
+      const float k1 = rhs(stage_gr<0>(s), y, L);
+      const float k2 = rhs(stage_gr<1>(s), y + d3 * k1, L);
+      const float k3 = rhs(stage_gr<2>(s), y + (dt * k2 - d3 * k1), L);
+      const float k4 = rhs(stage_gr<3>(s), y + dt * (k1 - k2 + k3), L);
       return y + (k1 + 3.f * k2 + 3.f * k3 + k4) * (dt * 0.125f);
     }
   }
@@ -206,46 +271,54 @@ struct DrLanes {
   template <int SOLVER>
   __device__ __forceinline__ static float step_vjp(float t0, float t1, float h0, float y, const DrLane& L, float lam,
                                                    Adj& A) {
+    const Sig s = stage_sigmoid<SOLVER>(t0, t1, L);
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f, g4 = 0.f;
     if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
       const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
-      const float hh = 0.5f * h;
-      Eval E1;
-      const float k1 = rhs(t0, y, L, E1);
+      Eval E1, E2;
+      const float k1 = rhs(stage_gr<0>(s), y, L, E1);
       const float ya = y + h * k1;
-      float v = hh * lam;
-      const float w = rhs_vjp(t1, ya, L, v, A);
+      rhs(stage_gr<1>(s), ya, L, E2);
+      float v = 0.5f * h * lam;
+      const float w = rhs_vjp(ya, L, v, A, E2, g2);
       lam += w;
       v += h * w;
-      return lam + rhs_vjp(y, L, v, A, E1);
+      lam += rhs_vjp(y, L, v, A, E1, g1);
     } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      return lam + rhs_vjp(t0, y, L, (t1 - t0) * lam, A);
+      Eval E1;
+      rhs(stage_gr<0>(s), y, L, E1);
+      lam += rhs_vjp(y, L, (t1 - t0) * lam, A, E1, g1);
     } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
       const float dt = t1 - t0;
-      Eval E1;
-      const float k1 = rhs(t0, y, L, E1);
+      Eval E1, E2;
+      const float k1 = rhs(stage_gr<0>(s), y, L, E1);
       const float ym = y + k1 * dt * 0.5f;
-      const float w = rhs_vjp(t0 + dt * 0.5f, ym, L, dt * lam, A);
+      rhs(stage_gr<1>(s), ym, L, E2);
+      const float w = rhs_vjp(ym, L, dt * lam, A, E2, g2);
       lam += w;
-      return lam + rhs_vjp(y, L, 0.5f * dt * w, A, E1);
+      lam += rhs_vjp(y, L, 0.5f * dt * w, A, E1, g1);
     } else {
       const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
-      Eval E1, E2, E3;  // stage intermediates of the forward recomputation, reused by the transposed stages
-      const float k1 = rhs(t0, y, L, E1);
+      Eval E1, E2, E3, E4;  // stage intermediates of the forward recomputation, reused by the transposed stages
+      const float k1 = rhs(stage_gr<0>(s), y, L, E1);
       const float y2 = y + d3 * k1;
-      const float k2 = rhs(t0 + d3, y2, L, E2);
+      const float k2 = rhs(stage_gr<1>(s), y2, L, E2);
       const float y3 = y + (dt * k2 - d3 * k1);
-      const float k3 = rhs(t0 + 2.f * d3, y3, L, E3);
+      const float k3 = rhs(stage_gr<2>(s), y3, L, E3);
       const float y4 = y + dt * (k1 - k2 + k3);
+      rhs(stage_gr<3>(s), y4, L, E4);
       const float k4b = d8 * lam;
       float k1b = k4b, k2b = 3.f * k4b, k3b = 3.f * k4b;
-      float w = rhs_vjp(t0 + dt, y4, L, k4b, A);
+      float w = rhs_vjp(y4, L, k4b, A, E4, g4);
       lam += w; k1b += dt * w; k2b -= dt * w; k3b += dt * w;
-      w = rhs_vjp(y3, L, k3b, A, E3);
+      w = rhs_vjp(y3, L, k3b, A, E3, g3);
       lam += w; k1b -= d3 * w; k2b += dt * w;
-      w = rhs_vjp(y2, L, k2b, A, E2);
+      w = rhs_vjp(y2, L, k2b, A, E2, g2);
       lam += w; k1b += d3 * w;
-      return lam + rhs_vjp(y, L, k1b, A, E1);
+      lam += rhs_vjp(y, L, k1b, A, E1, g1);
     }
+    stage_sigmoid_vjp(s, L, g1, g2, g3, g4, A);
+    return lam;
   }
 
   // observed signal of lanes 0..3 (reference vihds/ode.py:84-93): OD, OD*RFP, OD*(YFP+F530), OD*(CFP+F480)
@@ -256,39 +329,51 @@ struct DrLanes {
   }
 };
 
-template <int VERSION, int SOLVER>
+// LDS_IN: the block's time grid and observation rows are staged in LDS once ([T] + [nb][4][T] floats, nb = batch
+// rows the block's 32 trajectories span).  The time loop then holds no vector-memory loads at all, so its stores
+// are never waited for: with a global load in the loop every s_waitcnt vmcnt(0) for the load also waits for the
+// step's trajectory / x_predict stores (measured ~80 ns of a ~410 ns rk4 step at B=36, S=200).
+template <int VERSION, int SOLVER, bool LDS_IN>
 __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
   using D = DrLanes<VERSION>;
+  extern __shared__ float lds[];
   const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int i0 = blockIdx.x * D::TPB + tl;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
+  int ob_off = 0;
+  if (LDS_IN) {
+    const int first = blockIdx.x * D::TPB, last = min(first + D::TPB, a.n) - 1;
+    const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+    for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
+    const float* src = a.obs + (size_t)b0 * 4 * a.T;
+    for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
+    __syncthreads();
+    ob_off = a.T + ((b - b0) * 4 + (j & 3)) * a.T;
+  }
+  const float* ob = a.obs + ((size_t)b * 4 + (j & 3)) * a.T;
+  auto time_at = [&](int k) { return LDS_IN ? lds[k] : a.times[k]; };
+  auto obs_at = [&](int k) { return LDS_IN ? lds[ob_off + k] : ob[k]; };
   DrLane L;
   float c[2], y;
-  D::prepare(a, i, b, j, L, c, y);
+  D::template prepare<SOLVER>(a, i, b, j, L, c, y);
   const float lc = LOG2PI_F - logf(L.prec);
   float lp = 0.f;
-  const float* ob = a.obs + ((size_t)b * 4 + (j & 3)) * a.T;
   const float h0 = a.times[1] - a.times[0];
   const size_t n = a.n;
-  // times and observations are prefetched one step ahead: a load issued inside the step it is needed in would sit
-  // on the dependent chain behind an s_waitcnt vmcnt(0) (measured: ~half of the loop time)
+  // times and observations are fetched one step ahead so that their latency is off the dependent chain
   const bool want_lp = a.logp && j < 4;
-  float tA = a.times[0], tB = a.times[1];
-  float ob_cur = want_lp ? ob[0] : 0.f;
+  float tA = time_at(0), tB = time_at(1);
+  float ob_cur = want_lp ? obs_at(0) : 0.f;
   for (int k = 0; k < a.T; ++k) {
-    const float tC = (k + 1 < a.T) ? a.times[k + 1] : tB;
-    const float ob_next = (want_lp && k + 1 < a.T) ? ob[k + 1] : 0.f;
+    const float tC = (k + 1 < a.T) ? time_at(k + 1) : tB;
+    const float ob_next = (want_lp && k + 1 < a.T) ? obs_at(k + 1) : 0.f;
     if (k > 0) {
       y = D::template step<SOLVER>(tA, tB, h0, y, L);
       tA = tB;
     }
     tB = tC;
-    // land the prefetched values here, before this step's stores are issued: the vmcnt wait the compiler needs for
-    // them then covers the previous step's stores (a full step old) instead of stalling on the ones just issued
-    float ob_nx = ob_next;
-    asm volatile("" : "+v"(tB), "+v"(ob_nx));
     if (a.traj && live) a.traj[((size_t)k * 8 + j) * n + i] = y;
     float inner;
     const float xp = D::observe(y, bcast8<0>(y), L, inner);
@@ -297,7 +382,7 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
       const float e = xp - ob_cur;
       lp += -0.5f * (lc + L.prec * e * e);
     }
-    ob_cur = ob_nx;
+    ob_cur = ob_next;
   }
   if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
 }
@@ -313,8 +398,8 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   DrLane L;
   float c[2], y0;
-  D::prepare(a, i, b, j, L, c, y0);
-  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  D::template prepare<SOLVER>(a, i, b, j, L, c, y0);
+  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const size_t n = a.n;
   const float glp = (a.g_logp && j < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
@@ -355,7 +440,18 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
     lam += L.m0 * xsum + gtk;
   }
   // ---- parameter adjoints -> theta rows (each slot row written by exactly one lane)
-  const float rcb = sum8(A.cb * L.a);
+  // c enters as ce = c e and cm = c (1 - e):  c_bar = sv e + svt (1 - e),  e_bar = c (sv - svt)
+  const bool prom = j == 2 || j == 3;
+  const float cb = prom ? A.sv * L.e + A.svt * (1.f - L.e) : A.sv;
+  const float eb = L.c * (A.sv - A.svt);
+  // c1 = K1 f1, c2 = K2 f2 with (K1, f1, K2, f2) = (KGR, fR, KGS, fS) in lane 2 and (KGS, fS, KGR, fR) in lane 3
+  const float KGRb = j == 3 ? A.c2b * L.fR : A.c1b * L.fR;
+  const float KGSb = j == 3 ? A.c1b * L.fS : A.c2b * L.fS;
+  const float fRb = sum8(prom ? (j == 3 ? A.c2b : A.c1b) * L.KGR : 0.f);
+  const float fSb = sum8(prom ? (j == 3 ? A.c1b : A.c2b) * L.KGS : 0.f);
+  const float rcb = sum8(cb * L.a);
+  const float rb = sum4(A.rb), tlagb = -4.f * sum4(A.tl);
+  const float Kb = A.gbx * L.invK * L.invK;
   if (!live) return;
   auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
   auto raw = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
@@ -365,30 +461,30 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   const int ds = D::deg_slot(j);
   if (ds >= 0) put(ds, A.degb * clamp_pass(raw(ds), 1e-12f, (j == 6 || j == 7) ? 5.f : 2.f));
   const int as = D::a_slot(j);
-  if (as >= 0) put(as, A.cb * L.rc);
-  if (j == 2) { put(M::S_e81, A.eb); put(M::S_KGR81, A.KGRb); put(M::S_KGS81, A.KGSb); }
-  if (j == 3) { put(M::S_e76, A.eb); put(M::S_KGR76, A.KGRb); put(M::S_KGS76, A.KGSb); }
+  if (as >= 0) put(as, cb * L.rc);
+  if (j == 2) { put(M::S_e81, eb); put(M::S_KGR81, KGRb); put(M::S_KGS81, KGSb); }
+  if (j == 3) { put(M::S_e76, eb); put(M::S_KGR76, KGRb); put(M::S_KGS76, KGSb); }
   if (j == 0) {
-    put(M::S_r, A.rb * clamp_pass(raw(M::S_r), 0.f, 4.f));
-    put(M::S_K, A.Kb * clamp_pass(raw(M::S_K), 0.f, 4.f));
-    put(M::S_tlag, A.tlagb);
+    put(M::S_r, rb * clamp_pass(raw(M::S_r), 0.f, 4.f));
+    put(M::S_K, Kb * clamp_pass(raw(M::S_K), 0.f, 4.f));
+    put(M::S_tlag, tlagb);
     put(M::S_rc, rcb);
     float thh[M::NSLOT], thb[M::NSLOT];
     thh[M::S_nR] = raw(M::S_nR); thh[M::S_nS] = raw(M::S_nS); thh[M::S_H0] = raw(M::S_H0); thh[M::S_H1] = raw(M::S_H1);
     if (VERSION == 1) {
       thh[M::S_H2] = raw(M::S_H2); thh[M::S_H3] = raw(M::S_H3);
-      hill_frac_vjp(thh[M::S_nR], thh[M::S_H0], thh[M::S_H1], c[0], c[1], A.fRb, thb[M::S_nR], thb[M::S_H0], thb[M::S_H1]);
-      hill_frac_vjp(thh[M::S_nS], thh[M::S_H2], thh[M::S_H3], c[0], c[1], A.fSb, thb[M::S_nS], thb[M::S_H2], thb[M::S_H3]);
+      hill_frac_vjp(thh[M::S_nR], thh[M::S_H0], thh[M::S_H1], c[0], c[1], fRb, thb[M::S_nR], thb[M::S_H0], thb[M::S_H1]);
+      hill_frac_vjp(thh[M::S_nS], thh[M::S_H2], thh[M::S_H3], c[0], c[1], fSb, thb[M::S_nS], thb[M::S_H2], thb[M::S_H3]);
       put(M::S_H2, thb[M::S_H2]); put(M::S_H3, thb[M::S_H3]);
     } else {
       const float nR = clampf(thh[M::S_nR], 0.5f, 3.f), nS = clampf(thh[M::S_nS], 0.5f, 3.f);
       const float eS6 = clampf(thh[M::S_H0], 1e-12f, 1.f), eR12 = clampf(thh[M::S_H1], 1e-12f, 1.f);
       float nRb = 0.f, nSb = 0.f, dummy = 0.f, a12b = 0.f, a6b = 0.f;
       const float a12 = eR12 * c[1], a6 = eS6 * c[0];
-      pow_vjp(c[0], nR, powf(c[0], nR), A.fRb, dummy, nRb);
-      pow_vjp(a12, nR, powf(a12, nR), A.fRb, a12b, nRb);
-      pow_vjp(a6, nS, powf(a6, nS), A.fSb, a6b, nSb);
-      pow_vjp(c[1], nS, powf(c[1], nS), A.fSb, dummy, nSb);
+      pow_vjp(c[0], nR, powf(c[0], nR), fRb, dummy, nRb);
+      pow_vjp(a12, nR, powf(a12, nR), fRb, a12b, nRb);
+      pow_vjp(a6, nS, powf(a6, nS), fSb, a6b, nSb);
+      pow_vjp(c[1], nS, powf(c[1], nS), fSb, dummy, nSb);
       thb[M::S_nR] = nRb * clamp_pass(thh[M::S_nR], 0.5f, 3.f);
       thb[M::S_nS] = nSb * clamp_pass(thh[M::S_nS], 0.5f, 3.f);
       thb[M::S_H0] = a6b * c[0] * clamp_pass(thh[M::S_H0], 1e-12f, 1.f);
@@ -398,13 +494,22 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   }
 }
 
+// LDS floats the forward kernel stages per block: the time grid + the observation rows of the batch rows one block spans
+inline size_t dr_lane_fwd_lds_bytes(const OdeArgs& a, int tpb) {
+  const int nb = min(a.B, (tpb - 1) / a.S + 2);
+  return ((size_t)a.T + (size_t)nb * 4 * a.T) * sizeof(float);
+}
+
 template <int VERSION>
 inline int launch_dr_lanes(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const dim3 grid((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB), block(256);
-#define VIHDS_LCASE(SV)                                                                          \
-  case SV:                                                                                       \
-    if (backward) hipLaunchKernelGGL((dr_lane_bwd_kernel<VERSION, SV>), grid, block, 0, st, a);  \
-    else hipLaunchKernelGGL((dr_lane_fwd_kernel<VERSION, SV>), grid, block, 0, st, a);           \
+  const size_t lds = dr_lane_fwd_lds_bytes(a, DrLanes<VERSION>::TPB);
+  const bool lds_in = lds <= 48 * 1024;  // long grids / many rows per block fall back to global loads in the loop
+#define VIHDS_LCASE(SV)                                                                                   \
+  case SV:                                                                                                \
+    if (backward) hipLaunchKernelGGL((dr_lane_bwd_kernel<VERSION, SV>), grid, block, 0, st, a);           \
+    else if (lds_in) hipLaunchKernelGGL((dr_lane_fwd_kernel<VERSION, SV, true>), grid, block, lds, st, a); \
+    else hipLaunchKernelGGL((dr_lane_fwd_kernel<VERSION, SV, false>), grid, block, 0, st, a);             \
     return VIHDS_OK;
   switch (solver) {
     VIHDS_LCASE(VIHDS_SOLVER_MODEULER)
