@@ -91,24 +91,78 @@ struct DrLanes {
     return t[j];
   }
 
-  __device__ static void hill(const OdeArgs& a, int i, const float* c, float& fR, float& fS) {
-    float thh[M::NSLOT];
-    thh[M::S_nR] = th(a, M::S_nR, i); thh[M::S_nS] = th(a, M::S_nS, i);
-    thh[M::S_H0] = th(a, M::S_H0, i); thh[M::S_H1] = th(a, M::S_H1, i);
+  // Hill fractions (dr_constant.py:58-73), one power term per lane.  v1: f = (a^n + b^n) / (1 + a + b)^n with
+  // a = K6 c6, b = K12 c12 -> lanes 0-2 hold the LuxR terms (a, b, 1+a+b; exponent nR), lanes 3-5 the LasR terms.
+  // v2: fR = c6^nR + (eR12 c12)^nR, fS = (eS6 c6)^nS + c12^nS -> lanes 0-3.  The accurate powf is ~150 instructions;
+  // evaluated serially in every lane it was most of the kernel prologue (and, with its adjoint, of the epilogue).
+  struct HillTerm {
+    float base, n, pw;
+  };
+  __device__ static void hill(const OdeArgs& a, int i, int j, const float* c, HillTerm& H, float& fR, float& fS) {
+    const float nR = clampf(th(a, M::S_nR, i), 0.5f, 3.f), nS = clampf(th(a, M::S_nS, i), 0.5f, 3.f);
     if (VERSION == 1) {
-      thh[M::S_H2] = th(a, M::S_H2, i); thh[M::S_H3] = th(a, M::S_H3, i);
-      fR = hill_frac(thh[M::S_nR], thh[M::S_H0], thh[M::S_H1], c[0], c[1]);
-      fS = hill_frac(thh[M::S_nS], thh[M::S_H2], thh[M::S_H3], c[0], c[1]);
+      const bool isR = j < 3;
+      const float K6 = clampf(th(a, isR ? M::S_H0 : M::S_H2, i), 1e-12f, 1.f);
+      const float K12 = clampf(th(a, isR ? M::S_H1 : M::S_H3, i), 1e-12f, 1.f);
+      const float ta = K6 * c[0], tb = K12 * c[1];
+      const int k = isR ? j : j - 3;
+      H.base = j >= 6 ? 1.f : (k == 0 ? ta : (k == 1 ? tb : 1.f + ta + tb));
+      H.n = j >= 6 ? 1.f : (isR ? nR : nS);
+      H.pw = powf(H.base, H.n);
+      fR = (bcast8<0>(H.pw) + bcast8<1>(H.pw)) / bcast8<2>(H.pw);
+      fS = (bcast8<3>(H.pw) + bcast8<4>(H.pw)) / bcast8<5>(H.pw);
     } else {
-      const float nR = clampf(thh[M::S_nR], 0.5f, 3.f), nS = clampf(thh[M::S_nS], 0.5f, 3.f);
-      const float eS6 = clampf(thh[M::S_H0], 1e-12f, 1.f), eR12 = clampf(thh[M::S_H1], 1e-12f, 1.f);
-      fR = powf(c[0], nR) + powf(eR12 * c[1], nR);
-      fS = powf(eS6 * c[0], nS) + powf(c[1], nS);
+      const float eS6 = clampf(th(a, M::S_H0, i), 1e-12f, 1.f), eR12 = clampf(th(a, M::S_H1, i), 1e-12f, 1.f);
+      H.base = j == 0 ? c[0] : (j == 1 ? eR12 * c[1] : (j == 2 ? eS6 * c[0] : (j == 3 ? c[1] : 1.f)));
+      H.n = j < 2 ? nR : (j < 4 ? nS : 1.f);
+      H.pw = powf(H.base, H.n);
+      fR = bcast8<0>(H.pw) + bcast8<1>(H.pw);
+      fS = bcast8<2>(H.pw) + bcast8<3>(H.pw);
     }
+  }
+  // adjoint: every lane differentiates its own term (same formulas as pow_vjp), then the per-parameter sums are
+  // gathered inside the 8-lane group.  Outputs are the raw-parameter adjoints (clamp pass-through applied).
+  struct HillAdj {
+    float nR, nS, H0, H1, H2, H3;
+  };
+  __device__ static HillAdj hill_vjp(const OdeArgs& a, int i, int j, const float* c, const HillTerm& H, float fRb,
+                                     float fSb) {
+    float g;
+    if (VERSION == 1) {
+      const float p0 = bcast8<0>(H.pw), p1 = bcast8<1>(H.pw), p2 = bcast8<2>(H.pw);
+      const float p3 = bcast8<3>(H.pw), p4 = bcast8<4>(H.pw), p5 = bcast8<5>(H.pw);
+      const float numbR = fRb / p2, dnbR = -fRb * (p0 + p1) / (p2 * p2);
+      const float numbS = fSb / p5, dnbS = -fSb * (p3 + p4) / (p5 * p5);
+      g = j < 2 ? numbR : (j == 2 ? dnbR : (j < 5 ? numbS : (j == 5 ? dnbS : 0.f)));
+    } else {
+      g = j < 2 ? fRb : (j < 4 ? fSb : 0.f);
+    }
+    float ab = 0.f, nb = 0.f;
+    pow_vjp(H.base, H.n, H.pw, g, ab, nb);
+    HillAdj o;
+    const float nr_raw = th(a, M::S_nR, i), ns_raw = th(a, M::S_nS, i);
+    if (VERSION == 1) {
+      o.nR = sum8(j < 3 ? nb : 0.f) * clamp_pass(nr_raw, 0.5f, 3.f);
+      o.nS = sum8((j >= 3 && j < 6) ? nb : 0.f) * clamp_pass(ns_raw, 0.5f, 3.f);
+      const float a0 = bcast8<0>(ab), a1 = bcast8<1>(ab), a2 = bcast8<2>(ab);
+      const float a3 = bcast8<3>(ab), a4 = bcast8<4>(ab), a5 = bcast8<5>(ab);
+      o.H0 = (a0 + a2) * c[0] * clamp_pass(th(a, M::S_H0, i), 1e-12f, 1.f);
+      o.H1 = (a1 + a2) * c[1] * clamp_pass(th(a, M::S_H1, i), 1e-12f, 1.f);
+      o.H2 = (a3 + a5) * c[0] * clamp_pass(th(a, M::S_H2, i), 1e-12f, 1.f);
+      o.H3 = (a4 + a5) * c[1] * clamp_pass(th(a, M::S_H3, i), 1e-12f, 1.f);
+    } else {
+      o.nR = sum8(j < 2 ? nb : 0.f) * clamp_pass(nr_raw, 0.5f, 3.f);
+      o.nS = sum8((j >= 2 && j < 4) ? nb : 0.f) * clamp_pass(ns_raw, 0.5f, 3.f);
+      o.H0 = bcast8<2>(ab) * c[0] * clamp_pass(th(a, M::S_H0, i), 1e-12f, 1.f);  // eS6
+      o.H1 = bcast8<1>(ab) * c[1] * clamp_pass(th(a, M::S_H1, i), 1e-12f, 1.f);  // eR12
+      o.H2 = 0.f; o.H3 = 0.f;
+    }
+    return o;
   }
 
   template <int SOLVER>
-  __device__ static void prepare(const OdeArgs& a, int i, int b, int j, DrLane& L, float* c, float& y0) {
+  __device__ static void prepare(const OdeArgs& a, int i, int b, int j, DrLane& L, float* c, float& y0,
+                                 HillTerm& H) {
     c[0] = clampf(expf(a.cond[b * a.C + 0]) - 1.f, 1e-12f, 1e6f);
     c[1] = clampf(expf(a.cond[b * a.C + 1]) - 1.f, 1e-12f, 1e6f);
     L.r = clampf(th(a, M::S_r, i), 0.f, 4.f);
@@ -116,7 +170,7 @@ struct DrLanes {
     L.invK = frcp(L.K);
     L.tlag = th(a, M::S_tlag, i);
     L.rc = th(a, M::S_rc, i);
-    hill(a, i, c, L.fR, L.fS);
+    hill(a, i, j, c, H, L.fR, L.fS);
     L.sgn = j == 0 ? 1.f : -1.f;
     const int ds = deg_slot(j);
     L.deg = ds < 0 ? 0.f : clampf(th(a, ds, i), 1e-12f, (j == 6 || j == 7) ? 5.f : 2.f);
@@ -357,7 +411,8 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
   auto obs_at = [&](int k) { return LDS_IN ? lds[ob_off + k] : ob[k]; };
   DrLane L;
   float c[2], y;
-  D::template prepare<SOLVER>(a, i, b, j, L, c, y);
+  typename D::HillTerm H;
+  D::template prepare<SOLVER>(a, i, b, j, L, c, y, H);
   const float lc = LOG2PI_F - logf(L.prec);
   float lp = 0.f;
   const float h0 = a.times[1] - a.times[0];
@@ -398,7 +453,8 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   DrLane L;
   float c[2], y0;
-  D::template prepare<SOLVER>(a, i, b, j, L, c, y0);
+  typename D::HillTerm H;
+  D::template prepare<SOLVER>(a, i, b, j, L, c, y0, H);
   typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const size_t n = a.n;
@@ -452,6 +508,7 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   const float rcb = sum8(cb * L.a);
   const float rb = sum4(A.rb), tlagb = -4.f * sum4(A.tl);
   const float Kb = A.gbx * L.invK * L.invK;
+  const typename D::HillAdj HA = D::hill_vjp(a, i, j, c, H, fRb, fSb);
   if (!live) return;
   auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
   auto raw = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
@@ -469,28 +526,8 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
     put(M::S_K, Kb * clamp_pass(raw(M::S_K), 0.f, 4.f));
     put(M::S_tlag, tlagb);
     put(M::S_rc, rcb);
-    float thh[M::NSLOT], thb[M::NSLOT];
-    thh[M::S_nR] = raw(M::S_nR); thh[M::S_nS] = raw(M::S_nS); thh[M::S_H0] = raw(M::S_H0); thh[M::S_H1] = raw(M::S_H1);
-    if (VERSION == 1) {
-      thh[M::S_H2] = raw(M::S_H2); thh[M::S_H3] = raw(M::S_H3);
-      hill_frac_vjp(thh[M::S_nR], thh[M::S_H0], thh[M::S_H1], c[0], c[1], fRb, thb[M::S_nR], thb[M::S_H0], thb[M::S_H1]);
-      hill_frac_vjp(thh[M::S_nS], thh[M::S_H2], thh[M::S_H3], c[0], c[1], fSb, thb[M::S_nS], thb[M::S_H2], thb[M::S_H3]);
-      put(M::S_H2, thb[M::S_H2]); put(M::S_H3, thb[M::S_H3]);
-    } else {
-      const float nR = clampf(thh[M::S_nR], 0.5f, 3.f), nS = clampf(thh[M::S_nS], 0.5f, 3.f);
-      const float eS6 = clampf(thh[M::S_H0], 1e-12f, 1.f), eR12 = clampf(thh[M::S_H1], 1e-12f, 1.f);
-      float nRb = 0.f, nSb = 0.f, dummy = 0.f, a12b = 0.f, a6b = 0.f;
-      const float a12 = eR12 * c[1], a6 = eS6 * c[0];
-      pow_vjp(c[0], nR, powf(c[0], nR), fRb, dummy, nRb);
-      pow_vjp(a12, nR, powf(a12, nR), fRb, a12b, nRb);
-      pow_vjp(a6, nS, powf(a6, nS), fSb, a6b, nSb);
-      pow_vjp(c[1], nS, powf(c[1], nS), fSb, dummy, nSb);
-      thb[M::S_nR] = nRb * clamp_pass(thh[M::S_nR], 0.5f, 3.f);
-      thb[M::S_nS] = nSb * clamp_pass(thh[M::S_nS], 0.5f, 3.f);
-      thb[M::S_H0] = a6b * c[0] * clamp_pass(thh[M::S_H0], 1e-12f, 1.f);
-      thb[M::S_H1] = a12b * c[1] * clamp_pass(thh[M::S_H1], 1e-12f, 1.f);
-    }
-    put(M::S_nR, thb[M::S_nR]); put(M::S_nS, thb[M::S_nS]); put(M::S_H0, thb[M::S_H0]); put(M::S_H1, thb[M::S_H1]);
+    put(M::S_nR, HA.nR); put(M::S_nS, HA.nS); put(M::S_H0, HA.H0); put(M::S_H1, HA.H1);
+    if (VERSION == 1) { put(M::S_H2, HA.H2); put(M::S_H3, HA.H3); }
   }
 }
 
