@@ -107,6 +107,9 @@ def main():
     ap.add_argument("--solver", default="rk4")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from python instead of replaying a hipGraph")
     ap.add_argument("--host-rng", action="store_true", help="draw u with host numpy as the reference does (vae.py:22-24)")
+    ap.add_argument("--device-rng", choices=["kernel", "device"], default="kernel",
+                    help="kernel: u and the conditioner weights are drawn inside the HIP kernels (counter-based "
+                         "Philox); device: torch.randn on the GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
@@ -131,7 +134,7 @@ def main():
     # every rank: same seed => same encoder init, same DeviceConditioner draws, same full u (sliced per rank)
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,
-        u_rng="numpy" if a.host_rng else "device", conditioner_rng="cpu" if a.host_rng else "device",
+        u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
         hip_graph=use_graph, nan_check_every=0)
     model.train()
     batch = training.train_data
@@ -208,7 +211,7 @@ def main():
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
-                   "launch": launch_mode, "u_rng": "host numpy" if a.host_rng else "device philox",
+                   "launch": launch_mode, "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": "iwae-sample shard x%d" % world},
         "final_loss": final_loss, "roofline": roofline,
     }

@@ -129,14 +129,32 @@ int vihds_blackbox_dump_fields(void);
  *                                  (distributions.py:332-336,377-381); ignored for Constant
  *   u      [B][S][P]               reference layout (vihds/vae.py:22-24)
  *   theta  [n_rows>=P][B][S] rows 0..P-1 written;  log_q, log_p [B][S] */
+typedef struct vihds_theta_opts {
+  /* Where q's parameters live.  NULL: parameter p is row p of q_mu and row p of q_prec.  Else [2P]: entries 0..P-1
+   * are the rows of q_mu holding mu_p, entries P..2P-1 the rows of q_prec holding prec_p (the encoder's level-blocked
+   * table [local mu; local log-prec; global-conditioned mu; ...] is then consumed, and its gradient produced, in
+   * place; g_q_mu / g_q_prec are indexed the same way). */
+  const int* q_rows;
+  /* q_prec holds log-precisions (what the encoder heads emit, encoders.py:150-165): the kernel exponentiates and the
+   * adjoint returns d/d log_prec. */
+  int q_prec_is_log;
+  /* NULL: u is an input (the reference's host draw, vae.py:22-24).  Else 4 device words {seed lo, seed hi, step,
+   * ticket}: the forward draws u ~ N(0,1) itself (Philox4x32-10 + Box-Muller, see csrc/vihds_elbo.hip), WRITES it
+   * to u, and the last block advances `step` - fresh draws on every replay of a captured graph. */
+  unsigned int* rng;
+  /* rng: this call covers samples s_offset .. s_offset+S-1 of S_total per data row (S sharded over ranks: every rank
+   * gets the slice of the same global draw). */
+  int S_total, s_offset;
+} vihds_theta_opts;
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
                     const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
-                    const float* u, float* theta, float* log_q, float* log_p, void* stream);
+                    float* u, float* theta, float* log_q, float* log_p, const vihds_theta_opts* opts /* or NULL */,
+                    void* stream);
 /* g_theta [P..][B][S], g_log_q, g_log_p [B][S] (each may be NULL) -> g_q_mu, g_q_prec [P][B] (overwritten) */
 int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
                     const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
                     const float* u, const float* g_theta, const float* g_log_q, const float* g_log_p,
-                    float* g_q_mu, float* g_q_prec, void* stream);
+                    float* g_q_mu, float* g_q_prec, const vihds_theta_opts* opts /* or NULL */, void* stream);
 
 /* IWAE reduction (vihds/training.py:135-149):  log_w = sum_j logp[j] + log_p - log_q;  per row b:
  * row_max[b] = max_s log_w, row_sumexp[b] = sum_s exp(log_w - row_max[b]).  The host finishes
@@ -159,8 +177,11 @@ int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, cons
 /* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
  * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *
  * relevance[e][d]) with r = (b*S+s) mod B (the reference's .repeat tiling, kept).  z [E][D] are standard normals
- * (w_mean=2, w_std=1.5 reproduce DeviceConditioner's init) or final weights (w_mean=0, w_std=1). */
-int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+ * (w_mean=2, w_std=1.5 reproduce DeviceConditioner's init) or final weights (w_mean=0, w_std=1).
+ * rng (optional; 4 device words as vihds_theta_opts.rng, a state of its own): the kernel draws z itself and advances
+ * the step - the reference re-randomises the conditioner on every call (ode.py:48), this keeps that inside a
+ * captured graph without a launch for the draw.  z may then be NULL. */
+int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
                            const float* dev1hot, const float* relevance, const int* is_default, float* out,
                            void* stream);
 

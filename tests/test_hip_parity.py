@@ -6,6 +6,7 @@ Tolerance: 1e-4 relative (max-abs difference over max-abs reference) for traject
 log-likelihoods and the ELBO -- the bound BASELINE.json's north_star states; gradients 5e-4.
 """
 import math
+import numpy as np
 
 import pytest
 import torch
@@ -619,3 +620,92 @@ def test_adam_step_matches_torch_adam(n_tensors, lr_on_device):
         if k == 3:
             continue  # torch starts that tensor's own step count late; the flat device counter does not
         assert rel_err(d.detach().cpu(), r.detach()) < 2e-6, k
+
+
+def test_theta_kernel_draws_its_own_normals():
+    """u_rng: kernel -- the theta kernel draws u ~ N(0,1) (Philox4x32-10 + Box-Muller), writes it out, advances the
+    device-side step; the draws match the numpy restatement, are independent of S-sharding, and theta / log q / log p
+    are the same as when that u is fed back in as an input."""
+    from vihds import ops
+    import hip_util as H
+    from philox_ref import expected_kernel_normals as _expected_kernel_normals
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    kind, q_mu, q_prec, p_mu, p_prec, lo, hi = H.theta_inputs(fx, DEV)
+    P, B = q_mu.shape
+    S = 24
+    q_all = torch.cat([q_mu, q_prec.log()], 0).contiguous()
+    rows = torch.arange(2 * P, dtype=torch.int32, device=DEV)
+    seed = 0x1234567890ABCDEF
+    state = ops.KernelNormal.new_state(seed, DEV)
+    rng = ops.KernelNormal((B, S, P), state)
+    th1, lq1, lp1, u1 = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, rng, P, rows)
+    th2, _, _, u2 = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, rng, P, rows)
+    assert state.cpu().tolist()[2:] == [2, 0]  # two launches: step advanced twice, ticket back at zero
+    for step, u in ((0, u1), (1, u2)):
+        want = torch.tensor(_expected_kernel_normals(B, S, P, seed, step))
+        assert (u.cpu() - want).abs().max() < 2e-5
+    assert not torch.equal(u1, u2)
+    # feeding the drawn u back in as an input gives the same samples and log-probs
+    th3, lq3, lp3, _ = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, u1, P, rows)
+    assert torch.equal(th1, th3) and torch.equal(lq1, lq3) and torch.equal(lp1, lp3)
+    # S sharded over two ranks: each draws its slice of the same global stream
+    state2 = ops.KernelNormal.new_state(seed, DEV)
+    full = ops.KernelNormal((B, S, P), state2)
+    halves = []
+    for lo_s, hi_s in ((0, S // 2), (S // 2, S)):
+        st = ops.KernelNormal.new_state(seed, DEV)
+        part = ops.KernelNormal((B, S, P), st).take(lo_s, hi_s)
+        halves.append(ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, part, P, rows)[3])
+    assert torch.equal(torch.cat(halves, 1), u1)
+    # and they look like standard normals
+    big = ops.KernelNormal((B, 4096, P), ops.KernelNormal.new_state(7, DEV))
+    ub = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, big, P, rows)[3]
+    assert abs(float(ub.mean())) < 5e-3 and abs(float(ub.std()) - 1.0) < 5e-3
+    assert abs(float((ub ** 4).mean()) - 3.0) < 5e-2
+    del full
+
+
+def test_device_condition_kernel_matches_reference_formula_and_draws_its_own_weights():
+    """vihds_device_condition: (a) with given z equals the op-by-op reference formula incl. its .repeat tiling quirk
+    (ode.py:43-58); (b) with a device RNG state the kernel draws z itself: same result as feeding the numpy
+    restatement of those draws, and a fresh draw on the next call."""
+    from vihds import ops
+    from philox_ref import philox4x32_10
+
+    E, B, S, D = 2, 5, 7, 6
+    g = torch.Generator().manual_seed(3)
+    dev1hot = torch.zeros(B, D)
+    dev1hot[torch.arange(B), torch.randint(0, 3, (B,), generator=g)] = 1.0
+    dev1hot[torch.arange(B), 3 + torch.randint(0, 3, (B,), generator=g)] = 1.0
+    rel = torch.tensor([[1, 1, 1, 0, 0, 0], [0, 0, 0, 1, 1, 1]], dtype=torch.float32)
+    dflt = torch.tensor([1, 0], dtype=torch.int32)
+
+    def reference(z):
+        out = torch.empty(E, B, S)
+        k = torch.arange(B * S).reshape(B, S) % B
+        for e in range(E):
+            cond = torch.relu(((dev1hot * rel[e]) @ (2.0 + 1.5 * z[e])))
+            out[e] = (1.0 if dflt[e] else 0.0) + cond[k]
+        return out
+
+    z = torch.randn(E, D, generator=g)
+    out = torch.empty(E, B, S, device=DEV)
+    ops.device_condition(z.to(DEV), dev1hot.to(DEV), rel.to(DEV), dflt.to(DEV), out, 2.0, 1.5)
+    assert rel_err(out.cpu(), reference(z)) < 1e-6
+    seed = 0xFEDCBA9876543210 & (2 ** 62 - 1)
+    state = ops.KernelNormal.new_state(seed, DEV)
+    outs = []
+    for step in range(2):
+        ops.device_condition(None, dev1hot.to(DEV), rel.to(DEV), dflt.to(DEV), out, 2.0, 1.5, rng_state=state)
+        idx = np.arange(E * D, dtype=np.uint64)
+        r = philox4x32_10(idx, np.full_like(idx, 0xC04D), np.full_like(idx, step), np.zeros_like(idx),
+                          np.uint64(seed & 0xFFFFFFFF), np.uint64(seed >> 32))
+        u1 = np.minimum((r[0].astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -32), np.float32(0.99999994))
+        u2 = (r[1].astype(np.float32) + np.float32(0.5)) * np.float32(2.0 ** -32)
+        zk = np.sqrt(-2.0 * np.log(u1.astype(np.float64))) * np.cos(2.0 * np.pi * u2.astype(np.float64))
+        want = reference(torch.tensor(zk.reshape(E, D), dtype=torch.float32))
+        assert rel_err(out.cpu(), want) < 1e-5
+        outs.append(out.clone())
+    assert not torch.equal(outs[0], outs[1])
+    assert state.cpu().tolist()[2:] == [2, 0]

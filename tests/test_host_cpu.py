@@ -140,3 +140,16 @@ def test_device_conditioner_reproduces_reference_values():
     aS = ode.device_conditioner(ones, "aS", fx.t("dev_1hot"))
     assert rel_err(aR, fx.t("extra_theta")[0]) < 1e-6
     assert rel_err(aS, fx.t("extra_theta")[1]) < 1e-6
+
+
+def test_philox_known_answers():
+    """Random123 known-answer vectors for philox4x32-10 pin the numpy restatement the kernel RNG is checked against."""
+    from philox_ref import philox4x32_10
+
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8)),
+           ((0xFFFFFFFF,) * 4, (0xFFFFFFFF,) * 2, (0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD)),
+           ((0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344), (0xA4093822, 0x299F31D0),
+            (0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1))]
+    for ctr, key, want in kat:
+        got = philox4x32_10(*ctr, *key)
+        assert tuple(int(g) for g in got) == want

@@ -36,15 +36,17 @@ int bb_dump_fields();
 
 // vihds_elbo.hip
 void launch_theta_fwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
-                      const float*, const float*, float*, float*, float*, hipStream_t);
+                      const float*, float*, float*, float*, float*, const vihds_theta_opts&, hipStream_t);
 void launch_theta_bwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
                       const float*, const float*, const float*, const float*, const float*, float*, float*,
-                      hipStream_t);
+                      const vihds_theta_opts&, hipStream_t);
 void launch_iwae_fwd(int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_iwae_finish(int, float, const float*, const float*, float*, float*, hipStream_t);
+void launch_iwae_loss_small(int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
+                            float*, hipStream_t);
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
-void launch_device_condition(int, int, int, int, float, float, const float*, const float*, const float*, const int*,
+void launch_device_condition(int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
 void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
@@ -219,13 +221,21 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   return check_hip("vihds_ode_bwd launch");
 }
 
+static vihds_theta_opts theta_opts(const vihds_theta_opts* o) {
+  vihds_theta_opts d = {nullptr, 0, nullptr, 0, 0};
+  return o ? *o : d;
+}
+
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
-                    const float* p_prec, const float* clip_lo, const float* clip_hi, const float* u, float* theta,
-                    float* log_q, float* log_p, void* stream) {
+                    const float* p_prec, const float* clip_lo, const float* clip_hi, float* u, float* theta,
+                    float* log_q, float* log_p, const vihds_theta_opts* opts, void* stream) {
   if (P <= 0 || B <= 0 || S <= 0) return fail(VIHDS_E_BADARG, "P, B, S must be > 0");
   if (!kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !theta)
     return fail(VIHDS_E_BADARG, "null argument");
-  launch_theta_fwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, theta, log_q, log_p,
+  const vihds_theta_opts o = theta_opts(opts);
+  if (o.rng && (o.S_total < S || o.s_offset < 0 || o.s_offset + S > o.S_total))
+    return fail(VIHDS_E_BADARG, "rng: need 0 <= s_offset and s_offset + S <= S_total");
+  launch_theta_fwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, theta, log_q, log_p, o,
                    (hipStream_t)stream);
   return check_hip("vihds_theta_fwd launch");
 }
@@ -233,12 +243,12 @@ int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, con
 int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
                     const float* p_prec, const float* clip_lo, const float* clip_hi, const float* u,
                     const float* g_theta, const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec,
-                    void* stream) {
+                    const vihds_theta_opts* opts, void* stream) {
   if (P <= 0 || B <= 0 || S <= 0) return fail(VIHDS_E_BADARG, "P, B, S must be > 0");
   if (!kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !g_q_mu || !g_q_prec)
     return fail(VIHDS_E_BADARG, "null argument");
   launch_theta_bwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, g_theta, g_log_q, g_log_p, g_q_mu,
-                   g_q_prec, (hipStream_t)stream);
+                   g_q_prec, theta_opts(opts), (hipStream_t)stream);
   return check_hip("vihds_theta_bwd launch");
 }
 
@@ -260,6 +270,11 @@ int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream) {
   if (B <= 0 || S <= 0 || n_iwae_total <= 0 || !logp || !log_w || !row_max || !row_sumexp || !lse || !loss)
     return fail(VIHDS_E_BADARG, "bad argument");
+  if ((long long)B * S <= 16384) {  // one launch; above this one block per row + a finish kernel is faster
+    launch_iwae_loss_small(B, S, logf((float)n_iwae_total), logp, log_p, log_q, log_w, row_max, row_sumexp, lse, loss,
+                           (hipStream_t)stream);
+    return check_hip("vihds_iwae_loss_fwd launch");
+  }
   launch_iwae_fwd(B, S, logp, log_p, log_q, log_w, row_max, row_sumexp, (hipStream_t)stream);
   launch_iwae_finish(B, logf((float)n_iwae_total), row_max, row_sumexp, lse, loss, (hipStream_t)stream);
   return check_hip("vihds_iwae_loss_fwd launch");
@@ -272,12 +287,12 @@ int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, cons
   return check_hip("vihds_iwae_loss_bwd launch");
 }
 
-int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
                            const float* dev1hot, const float* relevance, const int* is_default, float* out,
                            void* stream) {
-  if (E <= 0 || B <= 0 || S <= 0 || D <= 0 || !z || !dev1hot || !relevance || !is_default || !out)
+  if (E <= 0 || B <= 0 || S <= 0 || D <= 0 || (!z && !rng) || !dev1hot || !relevance || !is_default || !out)
     return fail(VIHDS_E_BADARG, "bad argument");
-  launch_device_condition(E, B, S, D, w_mean, w_std, z, dev1hot, relevance, is_default, out, (hipStream_t)stream);
+  launch_device_condition(E, B, S, D, w_mean, w_std, z, rng, dev1hot, relevance, is_default, out, (hipStream_t)stream);
   return check_hip("vihds_device_condition launch");
 }
 

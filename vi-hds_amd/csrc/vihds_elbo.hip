@@ -62,10 +62,42 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
   return v;
 }
+// Counter-based standard normals for u (the reference draws u ~ N(0,1)[B,S,P] on the host, vae.py:22-24; this is the
+// graph-capturable device alternative): Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit seed, counter =
+// (global sample index b*S_total + s, parameter block p/4, step lo, step hi); the four 32-bit outputs give the four
+// normals of parameters 4k..4k+3 through two Box-Muller pairs, u1 = (x + 0.5) 2^-32, u2 = (y + 0.5) 2^-32,
+// z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = sqrt(-2 ln u1) sin(2 pi u2).  Independent of the launch geometry and of how
+// S is sharded over ranks.  tests/test_hip_parity.py re-implements it in numpy (with the Random123 known answer).
+__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
+                                              unsigned int k0, unsigned int k1, unsigned int* out) {
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+    const unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
+    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+  }
+  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+__device__ __forceinline__ float philox_normal(unsigned int idx, unsigned int pblock, unsigned int step_lo,
+                                               unsigned int step_hi, unsigned int k0, unsigned int k1, int q) {
+  unsigned int r[4];
+  philox4x32_10(idx, pblock, step_lo, step_hi, k0, k1, r);
+  const unsigned int x = (q & 2) ? r[2] : r[0], y = (q & 2) ? r[3] : r[1];
+  const float u1 = ((float)x + 0.5f) * 2.3283064365386963e-10f;  // exact products; (x + .5) rounds to <= 2^32
+  const float u2 = ((float)y + 0.5f) * 2.3283064365386963e-10f;
+  const float rad = sqrtf(-2.f * logf(fminf(u1, 0.99999994f)));
+  return rad * ((q & 1) ? sinf(6.283185307179586f * u2) : cosf(6.283185307179586f * u2));
+}
+
+// rng: {seed lo, seed hi, step, ticket} or NULL.  With rng the kernel draws u itself and writes it to `u` (the adjoint
+// and the host read it from there); the last block to finish advances the step, so replays of a captured graph get
+// fresh draws without any host-side bookkeeping.
 __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
-                                 const float* __restrict__ q_prec, const float* __restrict__ p_mu,
-                                 const float* __restrict__ p_prec, const float* __restrict__ clip_lo,
-                                 const float* __restrict__ clip_hi, const float* __restrict__ u,
+                                 const float* __restrict__ q_prec, const int* __restrict__ q_rows, int prec_is_log,
+                                 const float* __restrict__ p_mu, const float* __restrict__ p_prec,
+                                 const float* __restrict__ clip_lo, const float* __restrict__ clip_hi,
+                                 float* __restrict__ u, unsigned int* rng, int S_total, int s_off,
                                  float* __restrict__ theta, float* __restrict__ log_q, float* __restrict__ log_p) {
   const int n = B * S;
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -73,16 +105,29 @@ __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ ki
   const bool live = i0 < n;
   const int i = live ? i0 : n - 1;
   const int b = i / S;
+  unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
+  if (rng) {
+    k0 = rng[0]; k1 = rng[1]; step = rng[2];
+    gidx = (unsigned int)(b * S_total + s_off + (i - b * S));
+  }
   float lq = 0.f, lp = 0.f;
   for (int p = q; p < P; p += 4) {
     const int kd = kind[p];
-    const float uu = u[(size_t)i * P + p];
-    const float mu = q_mu[p * B + b];
+    float uu;
+    if (rng) {
+      uu = philox_normal(gidx, (unsigned int)(p >> 2), step, 0u, k0, k1, q);
+      if (live) u[(size_t)i * P + p] = uu;
+    } else {
+      uu = u[(size_t)i * P + p];
+    }
+    const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
+    const float mu = q_mu[rm * B + b];
     float x;
     if (kd == KIND_CONSTANT) {
       x = 0.f * uu + mu;  // zeros_like(u) + value (distributions.py:241-242)
     } else {
-      const float prec = q_prec[p * B + b];
+      const float pr = q_prec[rp * B + b];
+      const float prec = prec_is_log ? expf(pr) : pr;
       const float sigma = 1.f / sqrtf(prec);
       float z = mu + sigma * uu;
       x = (kd == KIND_LOGNORMAL) ? expf(z) : z;
@@ -101,15 +146,27 @@ __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ ki
     if (log_q) log_q[i] = lq;
     if (log_p) log_p[i] = lp;
   }
+  if (rng) {  // every block has read rng[2] by the time the last one gets here
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int ticket = atomicAdd(&rng[3], 1u);
+      if (ticket == gridDim.x - 1) {
+        rng[2] = step + 1u;
+        rng[3] = 0u;
+      }
+    }
+  }
 }
 
 // one block per (data row b, chunk of THETA_BWD_PCHUNK parameters); for each parameter the S per-sample
 // contributions are reduced in a fixed order (wave shuffle tree, then waves in order): deterministic gradients.
+// prec_is_log: the q precision table holds log-precisions and g_q_prec receives d/d log_prec = prec * d/d prec.
 constexpr int THETA_BWD_PCHUNK = 4;
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float* __restrict__ q_mu,
-                 const float* __restrict__ q_prec, const float* __restrict__ p_mu, const float* __restrict__ p_prec,
+                 const float* __restrict__ q_prec, const int* __restrict__ q_rows, int prec_is_log,
+                 const float* __restrict__ p_mu, const float* __restrict__ p_prec,
                  const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, const float* __restrict__ u,
                  const float* __restrict__ g_theta, const float* __restrict__ g_log_q,
                  const float* __restrict__ g_log_p, float* __restrict__ g_q_mu, float* __restrict__ g_q_prec) {
@@ -119,13 +176,15 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
   const int p_end = min(P, (int)(blockIdx.y + 1) * THETA_BWD_PCHUNK);
   for (int p = blockIdx.y * THETA_BWD_PCHUNK; p < p_end; ++p) {
     const int kd = kind[p];
+    const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
     float am = 0.f, ap = 0.f;
     if (kd == KIND_CONSTANT) {
       // constants carry no trainable distribution parameters in the reference (encoders.py:242-253)
-      if (threadIdx.x == 0) { g_q_mu[p * B + b] = 0.f; g_q_prec[p * B + b] = 0.f; }
+      if (threadIdx.x == 0) { g_q_mu[rm * B + b] = 0.f; g_q_prec[rp * B + b] = 0.f; }
       continue;
     }
-    const float mu = q_mu[p * B + b], prec = q_prec[p * B + b];
+    const float mu = q_mu[rm * B + b];
+    const float prec = prec_is_log ? expf(q_prec[rp * B + b]) : q_prec[rp * B + b];
     const float sigma = 1.f / sqrtf(prec);
     const float pm = p_mu[p], pp = p_prec[p], lo = clip_lo[p], hi = clip_hi[p];
     for (int s = threadIdx.x; s < S; s += BLOCK) {
@@ -158,7 +217,7 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
     }
     am = block_sum<BLOCK>(am, sm);
     ap = block_sum<BLOCK>(ap, sm);
-    if (threadIdx.x == 0) { g_q_mu[p * B + b] = am; g_q_prec[p * B + b] = ap; }
+    if (threadIdx.x == 0) { g_q_mu[rm * B + b] = am; g_q_prec[rp * B + b] = prec_is_log ? ap * prec : ap; }
   }
 }
 
@@ -208,6 +267,47 @@ iwae_finish_kernel(int B, float log_n, const float* __restrict__ row_max, const 
   if (threadIdx.x == 0) loss[0] = -acc / (float)B;
 }
 
+
+// The whole single-process IWAE loss in ONE launch for small batches (headline shape: 36 rows x 200 samples): one
+// 1024-thread block, one wave per row (rows w, w+16, ...), wave-level max / sum-exp, then the mean over rows in a
+// fixed order.  Replaces iwae_fwd_kernel + iwae_finish_kernel (each launch costs ~3-4 us in the step's graph).
+__global__ void __launch_bounds__(1024)
+iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp, const float* __restrict__ log_p,
+                       const float* __restrict__ log_q, float* __restrict__ log_w, float* __restrict__ row_max,
+                       float* __restrict__ row_sumexp, float* __restrict__ lse, float* __restrict__ loss) {
+  __shared__ float sm[16];
+  const int n = B * S, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wid; b < B; b += 16) {
+    float m = -INFINITY;
+    for (int s = lane; s < S; s += 64) {
+      const int i = b * S + s;
+      float lw = ((logp[i] + logp[n + i]) + logp[2 * n + i]) + logp[3 * n + i];
+      lw = lw + (log_p ? log_p[i] : 0.f) - (log_q ? log_q[i] : 0.f);
+      log_w[i] = lw;
+      m = fmaxf(m, lw);
+    }
+    m = __shfl(wave_max(m), 0, 64);
+    float se = 0.f;
+    for (int s = lane; s < S; s += 64) se += expf(log_w[b * S + s] - m);  // (each lane re-reads its own stores)
+    se = wave_sum(se);
+    if (lane == 0) {
+      const float l = m + logf(se);
+      row_max[b] = m;
+      row_sumexp[b] = se;
+      lse[b] = l;
+      acc += l - log_n;
+    }
+  }
+  if (lane == 0) sm[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    loss[0] = -t / (float)B;
+  }
+}
+
 // d loss / d log_w = -(g_loss / B) * softmax_s(log_w)
 __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log_w, const float* __restrict__ lse,
                                      const float* __restrict__ g_loss, float* __restrict__ g_logw,
@@ -224,19 +324,37 @@ __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log
 //   out[e][b][s] = (default_e ? 1 : 0) + relu( sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] * rel[e][d] ),
 //   r = (b*S + s) mod B   -- the reference tiles the [B,1] conditioner output with .repeat([S,1]) against a
 //   row-major flattening of [B,S] (ode.py:46,52-57); kept as is.
+// rng (optional, {seed lo, seed hi, step, ticket} as in vihds_theta_opts): z is drawn here instead of read
+// (counter = (e*D + d, 0xC04D, step, 0): a stream disjoint from theta's, whose second word is a parameter block < 2^16).
 __global__ void device_condition_kernel(int E, int B, int S, int D, float w_mean, float w_std,
-                                        const float* __restrict__ z, const float* __restrict__ dev1hot,
-                                        const float* __restrict__ rel, const int* __restrict__ is_default,
-                                        float* __restrict__ out) {
+                                        const float* __restrict__ z, unsigned int* rng,
+                                        const float* __restrict__ dev1hot, const float* __restrict__ rel,
+                                        const int* __restrict__ is_default, float* __restrict__ out) {
   const int n = B * S;
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+  const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = i0 < n;
+  const int i = live ? i0 : n - 1;
   const int r = i % B;
+  unsigned int k0 = 0, k1 = 0, step = 0;
+  if (rng) { k0 = rng[0]; k1 = rng[1]; step = rng[2]; }
   for (int e = 0; e < E; ++e) {
     float c = 0.f;
-    for (int d = 0; d < D; ++d) c += (w_mean + w_std * z[e * D + d]) * (dev1hot[r * D + d] * rel[e * D + d]);
+    for (int d = 0; d < D; ++d) {
+      const float hot = dev1hot[r * D + d] * rel[e * D + d];
+      float zz = 0.f;
+      if (rng) { if (hot != 0.f) zz = philox_normal((unsigned int)(e * D + d), 0xC04Du, step, 0u, k0, k1, 0); }
+      else zz = z[e * D + d];
+      c += (w_mean + w_std * zz) * hot;
+    }
     c = fmaxf(c, 0.f);
-    out[(size_t)e * n + i] = (is_default[e] ? 1.f : 0.f) + c;
+    if (live) out[(size_t)e * n + i] = (is_default[e] ? 1.f : 0.f) + c;
+  }
+  if (rng) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int ticket = atomicAdd(&rng[3], 1u);
+      if (ticket == gridDim.x - 1) { rng[2] = step + 1u; rng[3] = 0u; }
+    }
   }
 }
 
@@ -287,17 +405,20 @@ iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float
 
 // ---- launchers (called from vihds_api.hip) ---------------------------------------------------------
 void launch_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
-                      const float* p_prec, const float* lo, const float* hi, const float* u, float* theta,
-                      float* log_q, float* log_p, hipStream_t st) {
+                      const float* p_prec, const float* lo, const float* hi, float* u, float* theta, float* log_q,
+                      float* log_p, const vihds_theta_opts& o, hipStream_t st) {
   const int n = B * S, blk = 64;
   hipLaunchKernelGGL(theta_fwd_kernel, dim3((4 * n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec,
-                     p_mu, p_prec, lo, hi, u, theta, log_q, log_p);
+                     o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, o.rng, o.rng ? o.S_total : S,
+                     o.rng ? o.s_offset : 0, theta, log_q, log_p);
 }
 void launch_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
                       const float* p_prec, const float* lo, const float* hi, const float* u, const float* g_theta,
-                      const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec, hipStream_t st) {
+                      const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec,
+                      const vihds_theta_opts& o, hipStream_t st) {
   hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B, (P + THETA_BWD_PCHUNK - 1) / THETA_BWD_PCHUNK), dim3(256), 0, st,
-                     P, B, S, kind, q_mu, q_prec, p_mu, p_prec, lo, hi, u, g_theta, g_log_q, g_log_p, g_q_mu, g_q_prec);
+                     P, B, S, kind, q_mu, q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, g_theta, g_log_q,
+                     g_log_p, g_q_mu, g_q_prec);
 }
 void launch_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
                      float* row_max, float* row_sumexp, hipStream_t st) {
@@ -313,18 +434,23 @@ void launch_iwae_finish(int B, float log_n, const float* row_max, const float* r
                         hipStream_t st) {
   hipLaunchKernelGGL(iwae_finish_kernel, dim3(1), dim3(256), 0, st, B, log_n, row_max, row_sumexp, lse, loss);
 }
+void launch_iwae_loss_small(int B, int S, float log_n, const float* logp, const float* log_p, const float* log_q,
+                            float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, hipStream_t st) {
+  hipLaunchKernelGGL(iwae_loss_small_kernel, dim3(1), dim3(1024), 0, st, B, S, log_n, logp, log_p, log_q, log_w, row_max,
+                     row_sumexp, lse, loss);
+}
 void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                           float* g_neg_logw, hipStream_t st) {
   const int n = B * S, blk = 256;
   hipLaunchKernelGGL(iwae_loss_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_loss,
                      g_logw, g_neg_logw);
 }
-void launch_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z,
+void launch_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
                              const float* dev1hot, const float* rel, const int* is_default, float* out,
                              hipStream_t st) {
   const int n = B * S, blk = 256;
   hipLaunchKernelGGL(device_condition_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, E, B, S, D, w_mean, w_std,
-                     z, dev1hot, rel, is_default, out);
+                     z, rng, dev1hot, rel, is_default, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -22,8 +22,10 @@ PARAM_DEFAULTS = {
     "n_hidden_decoder_precisions": 20, "n_growth_layers": 4, "tb_gradients": False, "plot_histograms": False,
     "learning_boundaries": [250, 500], "learning_rate": 0.01, "learning_gamma": 0.2,
     # additions of this implementation (documented in DESIGN.md); every one defaults to reference behaviour
-    "u_rng": "numpy",          # "numpy": host RNG as vae.py:22-24 | "device": torch Philox on the GPU
-    "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48)
+    "u_rng": "numpy",          # "numpy": host RNG as vae.py:22-24 | "device": torch Philox on the GPU |
+                               # "kernel": drawn inside the theta kernel (vihds_theta_opts.rng)
+    "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48):
+                               # "cpu" (reference stream) | "device" (torch on the GPU) | "kernel" (in the kernel)
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
 }

@@ -30,6 +30,7 @@ class DotOperatorSamples(object):
         object.__setattr__(self, "_row_of", {})
         object.__setattr__(self, "_rebound", {})
         object.__setattr__(self, "_log_prob_cache", {})
+        object.__setattr__(self, "_u", None)
 
     @classmethod
     def from_packed(cls, names, packed):
@@ -257,8 +258,14 @@ class ChainedDistribution(object):
     def attach_image(self, kind_dev, mu, prec):
         self._image = (kind_dev, mu, prec)
 
-    def attach_packed(self, kind_dev, q_all, names, builder):
+    def attach_packed(self, kind_dev, q_all, names, builder, q_rows=None):
+        """q_all [2P,B]: means and log-precisions; q_rows [2P] (int32, device): the row of mu_p, then of log_prec_p
+        (None: [mu rows ; log_prec rows])."""
+        P = len(names)
+        if q_rows is None:
+            q_rows = torch.arange(2 * P, dtype=torch.int32, device=q_all.device)
         self._packed_q = (kind_dev, q_all, list(names))
+        self._q_rows = q_rows
         self._builder = builder
 
     def names(self):
@@ -278,7 +285,8 @@ class ChainedDistribution(object):
         if self._image is None and self._packed_q is not None:
             kind, q_all, names = self._packed_q
             P = len(names)
-            self._image = (kind, q_all[:P], q_all[P:].exp())
+            rows = self._q_rows.long()
+            self._image = (kind, q_all[rows[:P]], q_all[rows[P:]].exp())
         if self._image is None:
             mus, precs = [], []
             for d in self.distributions.values():
@@ -321,6 +329,8 @@ class ChainedDistribution(object):
             % (self.name, list_of_u.shape[-1]))
         dev = list_of_u.device
         n_batch = list_of_u.shape[0]
+        if isinstance(list_of_u, ops.KernelNormal) and self._packed_q is None:
+            raise RuntimeError("u_rng: kernel needs the encoder's packed q tables")
         if p is None:
             p_mu = p_prec = torch.ones(P, device=dev)
             inf = torch.full((P,), float("inf"), device=dev)
@@ -332,13 +342,15 @@ class ChainedDistribution(object):
             lo, hi = p.clip_image(stddevs, dev)
         if self._packed_q is not None:
             kind, q_all, _ = self._packed_q
-            theta, log_q, log_p = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi, list_of_u,
-                                                                     P + n_extra_rows)
+            theta, log_q, log_p, u_used = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi,
+                                                                             list_of_u, P + n_extra_rows, self._q_rows)
         else:
             kind, q_mu, q_prec = self.image(dev, n_batch)
             theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_prec, kind, p_mu, p_prec, lo, hi, list_of_u,
                                                                P + n_extra_rows)
         samples = DotOperatorSamples.from_packed(names, theta)
+        # the standard-normal draws behind these samples (an output when the kernel drew them)
+        object.__setattr__(samples, "_u", u_used if self._packed_q is not None else list_of_u)
         samples._log_prob_cache[id(self)] = log_q
         if p is not None:
             samples._log_prob_cache[id(p)] = log_p

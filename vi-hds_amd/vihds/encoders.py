@@ -77,39 +77,49 @@ class _Heads(nn.Module):
 
 
 class _PackQTables(torch.autograd.Function):
-    """[mu ; log_prec] tables of all P parameters, [2P, B], from the per-level pieces in ONE concatenation; the
-    backward hands each level its rows with one cat (heads) / one reduction over B (globals) instead of autograd's
-    per-slice zero-fill + copy + add chains."""
+    """Means and log-precisions of all P parameters as one [2P, B] table, level by level:
+    [local mu; local log_prec; global-cond mu; global-cond log_prec; global mu; global log_prec; const values; zeros]
+    -- ONE concatenation of the pieces as the heads emit them; the backward hands each level a contiguous row range
+    (heads) / one reduction over B (globals) instead of autograd's per-slice zero-fill + copy + add chains.
+    `rows(...)` gives the [2P] row map (mu rows, then log_prec rows) the theta kernel consumes."""
 
     @staticmethod
-    def forward(ctx, local_t, gcond_t, global_free, const_values, B):
+    def rows(nl, ng, ngl, nc):
+        mu, lp, base = [], [], 0
+        for n in (nl, ng, ngl, nc):
+            mu += list(range(base, base + n))
+            lp += list(range(base + n, base + 2 * n))
+            base += 2 * n
+        return mu + lp
+
+    @staticmethod
+    def forward(ctx, local_t, gcond_t, global_free, const_values, B, const_zeros=None):
         dev = (local_t if local_t is not None else global_free if global_free is not None else const_values).device
         nl = 0 if local_t is None else local_t.shape[0] // 2
         ng = 0 if gcond_t is None else gcond_t.shape[0] // 2
         ngl = 0 if global_free is None else global_free.shape[1]
         nc = const_values.shape[0]
         ctx.sizes = (nl, ng, ngl, nc, B)
-        mus, lps = [], []
+        parts = []
         if nl:
-            mus.append(local_t[:nl]), lps.append(local_t[nl:])
+            parts.append(local_t)
         if ng:
-            mus.append(gcond_t[:ng]), lps.append(gcond_t[ng:])
+            parts.append(gcond_t)
         if ngl:
-            mus.append(global_free[0][:, None].expand(-1, B)), lps.append(global_free[1][:, None].expand(-1, B))
+            parts.append(global_free.reshape(2 * ngl)[:, None].expand(-1, B))
         if nc:
-            mus.append(const_values[:, None].expand(-1, B))
-            lps.append(torch.zeros((), device=dev).expand(nc, B))
-        return torch.cat(mus + lps, 0)
+            zeros = const_zeros if const_zeros is not None else torch.zeros(nc, device=dev)
+            parts.append(const_values[:, None].expand(-1, B))
+            parts.append(zeros[:, None].expand(-1, B))
+        return torch.cat(parts, 0)
 
     @staticmethod
     def backward(ctx, g):
         nl, ng, ngl, nc, B = ctx.sizes
-        P = nl + ng + ngl + nc
-        g2 = g.view(2, P, B)
-        g_local = g2[:, :nl].reshape(2 * nl, B) if nl else None
-        g_gcond = g2[:, nl: nl + ng].reshape(2 * ng, B) if ng else None
-        g_glob = g2[:, nl + ng: nl + ng + ngl].sum(2) if ngl else None
-        return g_local, g_gcond, g_glob, None, None
+        g_local = g[: 2 * nl] if nl else None
+        g_gcond = g[2 * nl: 2 * (nl + ng)] if ng else None
+        g_glob = g[2 * (nl + ng): 2 * (nl + ng + ngl)].sum(1).view(2, ngl) if ngl else None
+        return g_local, g_gcond, g_glob, None, None, None
 
 
 class Encoder(nn.Module):
@@ -149,6 +159,8 @@ class Encoder(nn.Module):
         self.register_buffer("const_values", torch.tensor([d.value for d in self.const], dtype=torch.float32))
         self.register_buffer("const_zeros", torch.zeros(len(self.const), dtype=torch.float32))
         self.register_buffer("kind", torch.tensor([d.kind for d in self.descs], dtype=torch.int32))
+        self.register_buffer("q_rows", torch.tensor(_PackQTables.rows(len(self.local), len(self.gcond), len(self.glob),
+                                                                      len(self.const)), dtype=torch.int32))
         self.to(self.device)
         self.set_up_p()
 
@@ -168,7 +180,9 @@ class Encoder(nn.Module):
     def evaluate_q(self, data):
         B = data.observations.shape[0]
         obs = data.observations
-        delta_obs = obs[:, :, 1: self.n_times] - obs[:, :, : self.n_times - 1]
+        delta_obs = data.get("delta_obs", None) if hasattr(data, "get") else None  # staged with the batch (graph mode)
+        if delta_obs is None:
+            delta_obs = obs[:, :, 1: self.n_times] - obs[:, :, : self.n_times - 1]
         encoded = self.conditional(delta_obs)
         local_t = gcond_t = None
         if self.local:
@@ -178,16 +192,17 @@ class Encoder(nn.Module):
             x = ([data.inputs] if self.g_tr else []) + ([data.dev_1hot] if self.g_dv else [])
             gcond_t = self.gcond_heads(torch.cat(x, 1) if len(x) > 1 else x[0])
         P = len(self.descs)
-        q_all = _PackQTables.apply(local_t, gcond_t, self.global_free, self.const_values, B)  # [2P, B]
+        q_all = _PackQTables.apply(local_t, gcond_t, self.global_free, self.const_values, B, self.const_zeros)  # [2P, B]
         q = ChainedDistribution(name="q")
-        q.attach_packed(self.kind, q_all, self.names, lambda chain: self._build_members(chain, q_all))
+        q.attach_packed(self.kind, q_all, self.names, lambda chain: self._build_members(chain, q_all), self.q_rows)
         return q
 
     def _build_members(self, q, q_all):
         """The per-parameter TfNormal / TfLogNormal / TfConstant views (reference encoders.py:143-169, 187-253); built
         on first use only (evaluation, summaries, the reference-style call sequence)."""
         P = len(self.descs)
-        q_mu, q_lp = q_all[:P], q_all[P:]
+        rows = self.q_rows.long()
+        q_mu, q_lp = q_all[rows[:P]], q_all[rows[P:]]
         q_prec = q_lp.exp()
         n_lg = len(self.local) + len(self.gcond)
         for i, d in enumerate(self.descs):

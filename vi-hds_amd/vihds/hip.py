@@ -58,6 +58,13 @@ _LIB = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 
+class ThetaOpts(ctypes.Structure):
+    """struct vihds_theta_opts (include/vihds_hip.h)"""
+
+    _fields_ = [("q_rows", ctypes.c_void_p), ("q_prec_is_log", ctypes.c_int), ("rng", ctypes.c_void_p),
+                ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int)]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -80,13 +87,13 @@ _PROTOTYPES = {
     "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
-    "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 12),
-    "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 14),
+    "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 11 + [ctypes.POINTER(ThetaOpts), _P]),
+    "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 13 + [ctypes.POINTER(ThetaOpts), _P]),
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
-    "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 6),
+    "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 7),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 4 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

@@ -61,6 +61,7 @@ class OdeModel(nn.Module):
         self._spec_cache = {}
         self._tile_index = {}
         self._relevance_dev = {}
+        self._rng_state = None
         self._last = None
 
     # ---- device conditioning (reference ode.py:43-58) ----------------------------------------------
@@ -69,7 +70,7 @@ class OdeModel(nn.Module):
          -- the weights are not trained."""
         n_batch, n_iwae = param.shape[0], param.shape[1]
         n_inputs = dev_1hot.shape[1]
-        if self.conditioner_rng == "device" and dev_1hot.is_cuda:
+        if self.conditioner_rng in ("device", "kernel") and dev_1hot.is_cuda:
             weight = 2.0 + 1.5 * torch.randn((1, n_inputs), device=dev_1hot.device)
         else:
             weight = DeviceConditioner(n_inputs, use_bias=use_bias, activation=activation).cond.weight.detach()
@@ -113,13 +114,19 @@ class OdeModel(nn.Module):
             self._relevance_dev[key] = (rel, dflt)
         rel, dflt = self._relevance_dev[key]
         D = dev_1hot.shape[1]
-        if self.conditioner_rng == "device":
+        rng_state = None
+        if self.conditioner_rng == "kernel":  # drawn inside the kernel (no launch for the draw, graph-capturable)
+            if self._rng_state is None:
+                self._rng_state = ops.KernelNormal.new_state(int(torch.randint(0, 2 ** 62, (1,)).item()), dev)
+            z, mean, std, rng_state = None, 2.0, 1.5, self._rng_state
+        elif self.conditioner_rng == "device":
             z, mean, std = torch.randn((len(names), D), device=dev), 2.0, 1.5
         else:  # the reference's stream: a fresh DeviceConditioner per name, drawn on the host
             z = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in names], 0).to(dev)
             mean, std = 0.0, 1.0
         with torch.no_grad():
-            ops.device_condition(z, dev_1hot, rel, dflt, theta._packed[base: base + len(names)], mean, std)
+            ops.device_condition(z, dev_1hot, rel, dflt, theta._packed[base: base + len(names)], mean, std,
+                                 rng_state)
         for j, n in enumerate(names):
             theta.bind_reserved_row(n, base + j)
         return theta

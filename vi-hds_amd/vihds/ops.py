@@ -222,7 +222,7 @@ class ThetaSampleLogProb(torch.autograd.Function):
         log_p = torch.empty((B, S), device=u.device, dtype=torch.float32)
         rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_mu), hip.ptr(q_prec), hip.ptr(p_mu),
                                        hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
-                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), hip.current_stream())
+                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), None, hip.current_stream())
         hip.check(rc, "vihds_theta_fwd")
         ctx.save_for_backward(q_mu, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u)
         ctx.set_materialize_grads(False)
@@ -239,50 +239,88 @@ class ThetaSampleLogProb(torch.autograd.Function):
         rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_mu), hip.ptr(q_prec), hip.ptr(p_mu),
                                        hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
                                        hip.ptr(g_theta), hip.ptr(g_log_q), hip.ptr(g_log_p), hip.ptr(g_mu),
-                                       hip.ptr(g_prec), hip.current_stream())
+                                       hip.ptr(g_prec), None, hip.current_stream())
         hip.check(rc, "vihds_theta_bwd")
         return g_mu, g_prec, None, None, None, None, None, None, None
 
 
-class ThetaSampleLogProbPacked(torch.autograd.Function):
-    """Same kernel as ThetaSampleLogProb, fed by the encoder's single [2P,B] table ([mu rows ; log_prec rows]):
-    prec = exp(log_prec) is formed here and the backward returns ONE [2P,B] gradient (d/d mu ; d/d log_prec), so
-    autograd needs no slice / exp nodes between the encoder heads and the kernel."""
+class KernelNormal(object):
+    """Stand-in for the u [B,S,P] tensor when the theta kernel draws the standard normals itself
+    (u_rng: kernel).  `state` is the 4-word device RNG state {seed lo, seed hi, step, ticket} of
+    vihds_theta_opts.rng; (S_total, s_offset) select this rank's slice of the global draw."""
+
+    def __init__(self, shape, state, S_total=None, s_offset=0):
+        self.shape = tuple(shape)
+        self.state = state
+        self.S_total = shape[1] if S_total is None else S_total
+        self.s_offset = s_offset
+        self.device = state.device
 
     @staticmethod
-    def forward(ctx, q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows):
-        _require_cuda(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u)
-        q_all, u = _c(q_all), _c(u)
+    def new_state(seed, device):
+        seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        lo, hi = seed & 0xFFFFFFFF, seed >> 32
+        as_i32 = lambda v: v - (1 << 32) if v >= (1 << 31) else v  # noqa: E731
+        return torch.tensor([as_i32(lo), as_i32(hi), 0, 0], dtype=torch.int32, device=device)
+
+    def take(self, lo, hi):
+        B, S, P = self.shape
+        return KernelNormal((B, hi - lo, P), self.state, S_total=S, s_offset=lo)
+
+
+class ThetaSampleLogProbPacked(torch.autograd.Function):
+    """Same kernel as ThetaSampleLogProb, fed by the encoder's single [2P,B] table of means and LOG-precisions in
+    the encoder's own row order (`q_rows` [2P]: the row of mu_p, then the row of log_prec_p): the kernel
+    exponentiates, and the backward returns ONE [2P,B] gradient (d/d mu, d/d log_prec) in the same row order, so
+    autograd needs no slice / exp / mul nodes between the encoder heads and the kernel.  `u` is either the [B,S,P]
+    tensor of standard normals or a KernelNormal (the kernel then draws them and the tensor is an output)."""
+
+    @staticmethod
+    def forward(ctx, q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows, q_rows):
+        _require_cuda(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, q_rows)
+        q_all = _c(q_all)
         P = q_all.shape[0] // 2
         B = q_all.shape[1]
+        opts = hip.ThetaOpts()
+        opts.q_rows = hip.ptr(q_rows)
+        opts.q_prec_is_log = 1
+        if isinstance(u, KernelNormal):
+            rng, u = u, torch.empty(u.shape, device=q_all.device, dtype=torch.float32)
+            opts.rng, opts.S_total, opts.s_offset = rng.state.data_ptr(), rng.S_total, rng.s_offset
+        else:
+            _require_cuda(u)
+            u = _c(u)
         S = u.shape[1]
         if u.shape[0] != B or u.shape[2] != P:
             raise RuntimeError("u must be [B,S,P]")
-        q_prec = q_all[P:].exp()
         theta = torch.empty((max(n_rows, P), B, S), device=u.device, dtype=torch.float32)
         log_q = torch.empty((B, S), device=u.device, dtype=torch.float32)
         log_p = torch.empty((B, S), device=u.device, dtype=torch.float32)
-        rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_prec), hip.ptr(p_mu),
+        rc = hip.lib().vihds_theta_fwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_all), hip.ptr(p_mu),
                                        hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
-                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), hip.current_stream())
+                                       hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), ctypes.byref(opts),
+                                       hip.current_stream())
         hip.check(rc, "vihds_theta_fwd")
-        ctx.save_for_backward(q_all, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u)
+        ctx.save_for_backward(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows)
         ctx.set_materialize_grads(False)
-        return theta, log_q, log_p
+        ctx.mark_non_differentiable(u)
+        return theta, log_q, log_p, u
 
     @staticmethod
-    def backward(ctx, g_theta, g_log_q, g_log_p):
-        q_all, q_prec, kind, p_mu, p_prec, clip_lo, clip_hi, u = ctx.saved_tensors
+    def backward(ctx, g_theta, g_log_q, g_log_p, _g_u):
+        q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows = ctx.saved_tensors
         P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
         g_theta, g_log_q, g_log_p = _c(g_theta), _c(g_log_q), _c(g_log_p)
         g_all = torch.empty_like(q_all)
-        rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_prec), hip.ptr(p_mu),
+        opts = hip.ThetaOpts()
+        opts.q_rows = hip.ptr(q_rows)
+        opts.q_prec_is_log = 1
+        rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_all), hip.ptr(p_mu),
                                        hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
                                        hip.ptr(g_theta), hip.ptr(g_log_q), hip.ptr(g_log_p), hip.ptr(g_all),
-                                       hip.ptr(g_all[P:]), hip.current_stream())
+                                       hip.ptr(g_all), ctypes.byref(opts), hip.current_stream())
         hip.check(rc, "vihds_theta_bwd")
-        g_all[P:].mul_(q_prec)  # d/d log_prec = prec * d/d prec
-        return g_all, None, None, None, None, None, None, None
+        return g_all, None, None, None, None, None, None, None, None
 
 
 class IwaeRows(torch.autograd.Function):
@@ -386,13 +424,17 @@ class IwaeLoss(torch.autograd.Function):
         return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None
 
 
-def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std):
-    """OdeModel.device_conditioner applied to ones for E parameters in one launch, written into `out` [E,B,S]."""
-    _require_cuda(z, dev_1hot, relevance, is_default, out)
+def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng_state=None):
+    """OdeModel.device_conditioner applied to ones for E parameters in one launch, written into `out` [E,B,S].
+    z [E,D] standard normals, or None with `rng_state` (KernelNormal.new_state): the kernel draws them."""
+    _require_cuda(dev_1hot, relevance, is_default, out)
+    if z is None and rng_state is None:
+        raise ValueError("device_condition needs z or rng_state")
     E, B, S = out.shape
-    rc = hip.lib().vihds_device_condition(E, B, S, dev_1hot.shape[1], float(w_mean), float(w_std), hip.ptr(_c(z)),
-                                          hip.ptr(_c(dev_1hot)), hip.ptr(relevance), hip.ptr(is_default),
-                                          hip.ptr(out), hip.current_stream())
+    z = None if z is None else _c(z)
+    rc = hip.lib().vihds_device_condition(E, B, S, dev_1hot.shape[1], float(w_mean), float(w_std), hip.ptr(z),
+                                          hip.ptr(rng_state), hip.ptr(_c(dev_1hot)), hip.ptr(relevance),
+                                          hip.ptr(is_default), hip.ptr(out), hip.current_stream())
     hip.check(rc, "vihds_device_condition")
     return out
 

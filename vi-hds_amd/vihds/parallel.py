@@ -28,6 +28,8 @@ class SampleShard(object):
     def take(self, u):
         """u [B,S,P] (identical on every rank: same host seed) -> this rank's [B,S/world,P] slice."""
         lo, hi = self.bounds(u.shape[1])
+        if hasattr(u, "s_offset"):  # ops.KernelNormal: the kernel draws this rank's slice of the same global stream
+            return u.take(lo, hi)
         return u[:, lo:hi].contiguous()
 
 

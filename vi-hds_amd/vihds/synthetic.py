@@ -123,7 +123,7 @@ def simulate_observations(settings, parameters, dataset, device, seed=0, noise=0
     scale = xp.amax(dim=(0, 2), keepdim=True).clamp_min(1e-6)
     obs = xp / scale + noise * torch.randn(xp.shape, generator=g)
     obs = obs - obs.amin(dim=2, keepdim=True)
-    dataset.observations = obs.float()
+    dataset.observations = obs.float().contiguous()  # (x_predict is a permuted view: keep the plate layout [n,4,T])
 
 
 def make_args(n_iwae, seed=0, gpu=None):

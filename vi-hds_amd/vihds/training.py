@@ -30,12 +30,16 @@ def log_prob_observations(model, x_predict, x_obs, precisions, use_laplace=False
     return torch.sum(log_prob_gaussian(torch.unsqueeze(x_obs, 1), x_predict, precisions), 3)
 
 
+def _delta_obs(obs):
+    return (obs[:, :, 1:] - obs[:, :, :-1]).contiguous()
+
+
 def batch_to_device(times, device, d):
     """reference training.py:47-52"""
     d["times"] = times.to(device)
     d["dev_1hot"] = d["dev_1hot"].to(device)
     d["inputs"] = d["inputs"].to(device)
-    d["observations"] = d["observations"].to(device)
+    d["observations"] = d["observations"].to(device).contiguous()
     return attrify(d)
 
 
@@ -97,6 +101,7 @@ class Training:
         self._graphs = {}
         self._staged = {}
         self._grad_buffer = None
+        self._one = None
         self._steps = 0
 
     # ------------------------------------------------------------------------------------------------
@@ -200,7 +205,9 @@ class Training:
         Returns the loss tensor (-ELBO) without synchronising."""
         batch_results, theta, q, p = self.model(batch, self.args.train_samples)
         elbo = self.cost(batch, batch_results, theta, q, p).elbo
-        elbo.backward()
+        if self._one is None or self._one.device != elbo.device:
+            self._one = torch.ones((), device=elbo.device)
+        elbo.backward(self._one.expand_as(elbo))  # (no ones_like fill launch per step)
         if self.shard is not None:
             self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.shard.group,
                                                              self._grad_buffer)
@@ -217,7 +224,11 @@ class Training:
         rewritten (not accumulated) by every replay."""
         key = tuple(batch.observations.shape)
         if key not in self._graphs:
-            static = attrify({k: (v.clone() if isinstance(v, torch.Tensor) else v) for k, v in batch.items()})
+            static = attrify({k: (v.clone(memory_format=torch.contiguous_format) if isinstance(v, torch.Tensor) else v)
+                              for k, v in batch.items()})
+            # input-only preprocessing of the encoder (reference encoders.py:385) is done when a batch is staged, not
+            # inside every replay
+            static["delta_obs"] = _delta_obs(static.observations)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
@@ -233,6 +244,7 @@ class Training:
         if self._staged.get(key) is not batch:  # a batch that is already resident in the graph's inputs is not re-copied
             for k in ("dev_1hot", "inputs", "observations", "times"):
                 static[k].copy_(batch[k], non_blocking=True)
+            static["delta_obs"].copy_(_delta_obs(static.observations))
             self._staged[key] = batch
         g.replay()
         return loss

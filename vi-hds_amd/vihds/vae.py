@@ -18,12 +18,22 @@ class BaseVAE(nn.Module):
         self.n_theta = None
         self.u_rng = u_rng
         self.shard = shard  # vihds.parallel.SampleShard or None
+        self._rng_state = None
 
     def sample_u(self, n_batch, n_samples, device=None):
         """Standard-normal draws u [B,S,P].  "numpy" = the reference's host RNG stream (vae.py:22-24);
-        "device" = torch's Philox generator on the GPU (graph-capturable, no host->device copy)."""
+        "device" = torch's Philox generator on the GPU (graph-capturable, no host->device copy);
+        "kernel" = drawn inside the theta kernel (counter-based Philox, vihds_theta_opts.rng): no launch of its own,
+        and under S-sharding each rank draws only its slice of the same global stream."""
         if self.u_rng == "device":
             return torch.randn((n_batch, n_samples, self.n_theta), device=self.device)
+        if self.u_rng == "kernel":
+            from vihds import ops
+
+            if self._rng_state is None:  # seeded once from torch's generator so torch.manual_seed controls it
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+                self._rng_state = ops.KernelNormal.new_state(seed, self.device)
+            return ops.KernelNormal((n_batch, n_samples, self.n_theta), self._rng_state)
         u = torch.tensor(np.random.randn(n_batch, n_samples, self.n_theta).astype(np.float32))
         return u.to(self.device, non_blocking=True)
 
