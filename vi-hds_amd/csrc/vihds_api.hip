@@ -270,7 +270,7 @@ int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream) {
   if (B <= 0 || S <= 0 || n_iwae_total <= 0 || !logp || !log_w || !row_max || !row_sumexp || !lse || !loss)
     return fail(VIHDS_E_BADARG, "bad argument");
-  if ((long long)B * S <= 16384) {  // one launch; above this one block per row + a finish kernel is faster
+  if (B <= 64 && S <= 256) {  // one launch; above this one block per row + a finish kernel
     launch_iwae_loss_small(B, S, logf((float)n_iwae_total), logp, log_p, log_q, log_w, row_max, row_sumexp, lse, loss,
                            (hipStream_t)stream);
     return check_hip("vihds_iwae_loss_fwd launch");

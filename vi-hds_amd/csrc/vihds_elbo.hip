@@ -79,15 +79,30 @@ __device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, 
   }
   out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
+__device__ __forceinline__ void philox_normal4(unsigned int, unsigned int, unsigned int, unsigned int, unsigned int,
+                                               unsigned int, float*);
 __device__ __forceinline__ float philox_normal(unsigned int idx, unsigned int pblock, unsigned int step_lo,
                                                unsigned int step_hi, unsigned int k0, unsigned int k1, int q) {
+  float z[4];
+  philox_normal4(idx, pblock, step_lo, step_hi, k0, k1, z);
+  return z[q];
+}
+
+// all four normals of one counter: (r0, r1) -> (z0, z1), (r2, r3) -> (z2, z3).  v_log / v_sqrt / v_sin / v_cos
+// (v_sin_f32 and v_cos_f32 take their argument in revolutions, which is exactly u2): the draws only have to be good
+// normals, and whatever is drawn is written out as `u`, so everything downstream sees the same values.
+__device__ __forceinline__ void philox_normal4(unsigned int idx, unsigned int pblock, unsigned int step_lo,
+                                               unsigned int step_hi, unsigned int k0, unsigned int k1, float* z) {
   unsigned int r[4];
   philox4x32_10(idx, pblock, step_lo, step_hi, k0, k1, r);
-  const unsigned int x = (q & 2) ? r[2] : r[0], y = (q & 2) ? r[3] : r[1];
-  const float u1 = ((float)x + 0.5f) * 2.3283064365386963e-10f;  // exact products; (x + .5) rounds to <= 2^32
-  const float u2 = ((float)y + 0.5f) * 2.3283064365386963e-10f;
-  const float rad = sqrtf(-2.f * logf(fminf(u1, 0.99999994f)));
-  return rad * ((q & 1) ? sinf(6.283185307179586f * u2) : cosf(6.283185307179586f * u2));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const float u1 = fminf(((float)r[2 * h] + 0.5f) * 2.3283064365386963e-10f, 0.99999994f);
+    const float u2 = ((float)r[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
+    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1 = -2 ln2 log2 u1
+    z[2 * h] = rad * __builtin_amdgcn_cosf(u2);
+    z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
+  }
 }
 
 // rng: {seed lo, seed hi, step, ticket} or NULL.  With rng the kernel draws u itself and writes it to `u` (the adjoint
@@ -111,34 +126,43 @@ __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ ki
     gidx = (unsigned int)(b * S_total + s_off + (i - b * S));
   }
   float lq = 0.f, lp = 0.f;
-  for (int p = q; p < P; p += 4) {
-    const int kd = kind[p];
-    float uu;
-    if (rng) {
-      uu = philox_normal(gidx, (unsigned int)(p >> 2), step, 0u, k0, k1, q);
-      if (live) u[(size_t)i * P + p] = uu;
-    } else {
-      uu = u[(size_t)i * P + p];
+  // lane q of the quad owns parameter blocks kb = q, q+4, ... (4 consecutive parameters each): one Philox call
+  // yields exactly the block's four normals, and a lane reads / writes 16 contiguous bytes of u[b][s][:]
+  for (int kb = q; 4 * kb < P; kb += 4) {
+    float z4[4];
+    if (rng) philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = 4 * kb + jj;
+      if (p >= P) break;
+      const int kd = kind[p];
+      float uu;
+      if (rng) {
+        uu = z4[jj];
+        if (live) u[(size_t)i * P + p] = uu;
+      } else {
+        uu = u[(size_t)i * P + p];
+      }
+      const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
+      const float mu = q_mu[rm * B + b];
+      float x;
+      if (kd == KIND_CONSTANT) {
+        x = 0.f * uu + mu;  // zeros_like(u) + value (distributions.py:241-242)
+      } else {
+        const float pr = q_prec[rp * B + b];
+        const float prec = prec_is_log ? expf(pr) : pr;
+        const float sigma = 1.f / sqrtf(prec);
+        float z = mu + sigma * uu;
+        x = (kd == KIND_LOGNORMAL) ? expf(z) : z;
+        const float lo = clip_lo[p], hi = clip_hi[p];
+        x = x < lo ? lo : (x > hi ? hi : x);
+        const float v = (kd == KIND_LOGNORMAL) ? logf(x + 1e-12f) : x;
+        const float jac = (kd == KIND_LOGNORMAL) ? v : 0.f;
+        lq += normal_lp(mu, prec, v) - jac;
+        lp += normal_lp(p_mu[p], p_prec[p], v) - jac;
+      }
+      if (live) theta[(size_t)p * n + i] = x;
     }
-    const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
-    const float mu = q_mu[rm * B + b];
-    float x;
-    if (kd == KIND_CONSTANT) {
-      x = 0.f * uu + mu;  // zeros_like(u) + value (distributions.py:241-242)
-    } else {
-      const float pr = q_prec[rp * B + b];
-      const float prec = prec_is_log ? expf(pr) : pr;
-      const float sigma = 1.f / sqrtf(prec);
-      float z = mu + sigma * uu;
-      x = (kd == KIND_LOGNORMAL) ? expf(z) : z;
-      const float lo = clip_lo[p], hi = clip_hi[p];
-      x = x < lo ? lo : (x > hi ? hi : x);
-      const float v = (kd == KIND_LOGNORMAL) ? logf(x + 1e-12f) : x;
-      const float jac = (kd == KIND_LOGNORMAL) ? v : 0.f;
-      lq += normal_lp(mu, prec, v) - jac;
-      lp += normal_lp(p_mu[p], p_prec[p], v) - jac;
-    }
-    if (live) theta[(size_t)p * n + i] = x;
   }
   lq = quad_sum(lq);
   lp = quad_sum(lp);
@@ -275,21 +299,37 @@ __global__ void __launch_bounds__(1024)
 iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp, const float* __restrict__ log_p,
                        const float* __restrict__ log_q, float* __restrict__ log_w, float* __restrict__ row_max,
                        float* __restrict__ row_sumexp, float* __restrict__ lse, float* __restrict__ loss) {
+  // B <= 64 rows (wave w owns rows w, w+16, w+32, w+48), S <= 256 samples (4 per lane): everything a wave needs
+  // is loaded up front and kept in registers, so the only serial part is two wave reductions
   __shared__ float sm[16];
   const int n = B * S, lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  float acc = 0.f;
-  for (int b = wid; b < B; b += 16) {
-    float m = -INFINITY;
-    for (int s = lane; s < S; s += 64) {
-      const int i = b * S + s;
-      float lw = ((logp[i] + logp[n + i]) + logp[2 * n + i]) + logp[3 * n + i];
-      lw = lw + (log_p ? log_p[i] : 0.f) - (log_q ? log_q[i] : 0.f);
-      log_w[i] = lw;
-      m = fmaxf(m, lw);
+  float lw[4][4];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int b = wid + 16 * rr;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int sidx = lane + 64 * c;
+      float v = -INFINITY;
+      if (b < B && sidx < S) {
+        const int i = b * S + sidx;
+        v = ((logp[i] + logp[n + i]) + logp[2 * n + i]) + logp[3 * n + i];
+        v = v + (log_p ? log_p[i] : 0.f) - (log_q ? log_q[i] : 0.f);
+        log_w[i] = v;
+      }
+      lw[rr][c] = v;
     }
+  }
+  float acc = 0.f;
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int b = wid + 16 * rr;
+    if (b >= B) break;  // (uniform per wave)
+    float m = fmaxf(fmaxf(lw[rr][0], lw[rr][1]), fmaxf(lw[rr][2], lw[rr][3]));
     m = __shfl(wave_max(m), 0, 64);
     float se = 0.f;
-    for (int s = lane; s < S; s += 64) se += expf(log_w[b * S + s] - m);  // (each lane re-reads its own stores)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) se += (lane + 64 * c < S) ? expf(lw[rr][c] - m) : 0.f;
     se = wave_sum(se);
     if (lane == 0) {
       const float l = m + logf(se);
