@@ -50,7 +50,10 @@ enum vihds_model {
   VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS = 10, /* models/relay_constant.py:199 */
   VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS = 11, /* models/degrader_constant.py:195 */
   VIHDS_MODEL_DR_BLACKBOX = 12,               /* models/dr_blackbox.py:61 */
-  VIHDS_MODEL_COUNT = 13
+  VIHDS_MODEL_INDUCER_CONSTANT = 13,          /* models/inducer_constant.py:83 */
+  VIHDS_MODEL_INDUCER_CONSTANT_PRECISIONS = 14, /* models/inducer_constant.py:117 */
+  VIHDS_MODEL_DEBUG_CONSTANT = 15,            /* models/debug.py:11 */
+  VIHDS_MODEL_COUNT = 16
 };
 
 /* solvers: values of params.solver (reference vihds/ode.py:75-81, vihds/config.py:59) */

@@ -327,6 +327,49 @@ def make_auto_constant(th, cond, prec_w=None):
     return _with_precisions(core, 4, prec_w), torch.stack(init, dim=2)
 
 
+def make_inducer_constant(th, cond, prec_w=None):
+    """models/inducer_constant.py:11-80 (RHS), x0 :92-97 / :124-140.  PARITY UNPINNED: the reference classes raise at
+    construction (init_with_params, :85), so this follows the RHS class text only."""
+    B, S = th["r"].shape
+    r, K = _growth(th)
+    ara = torch.clamp(torch.exp(cond) - 1.0, 1e-12, 1e6)  # [B,1]
+    drfp = torch.clamp(th["drfp"], 1e-12, 2.0)
+    dyfp = torch.clamp(th["dyfp"], 1e-12, 2.0)
+    nA = torch.clamp(th["nA"], 0.5, 3.0)
+    rc, tlag = th["rc"], th["tlag"]
+    pbad = (ara.pow(nA) + th["eA"] * th["KAra"].pow(nA)) / (ara.pow(nA) + th["KAra"].pow(nA))
+
+    def core(t, state):
+        x, rfp, yfp, f530, f480 = torch.unbind(state[:, :, :5], dim=2)
+        gr = r * torch.sigmoid(4.0 * (t - tlag))
+        g = 1.0 - x / K
+        gamma = gr * g
+        d = [gamma * x, rc - (gamma + drfp) * rfp, rc * th["aYFP_Inducer"] * pbad - (gamma + dyfp) * yfp,
+             rc * th["a530"] - gamma * f530, rc * th["a480"] - gamma * f480]
+        return torch.stack(d, dim=2)
+
+    zero = torch.zeros([B, S])
+    init = [th["init_x"], th["init_rfp"], th["init_yfp"], zero, zero]
+    if prec_w is not None:
+        init += [th["init_prec_x"], th["init_prec_rfp"], th["init_prec_yfp"], th["init_prec_cfp"]]
+    return _with_precisions(core, 5, prec_w), torch.stack(init, dim=2)
+
+
+def make_debug_constant(th, cond, prec_w=None):
+    """models/debug.py:35-53 (RHS), x0 :17-23.  PARITY UNPINNED: the reference class is stale and cannot run."""
+    B, S = th["r"].shape
+    r = th["r"]
+
+    def core(t, state):
+        x, rfp, yfp, cfp = torch.unbind(state, dim=2)
+        gamma = r * (1.0 - x)
+        return torch.stack([x * gamma, 1.0 - (gamma + 1.0) * rfp, 1.0 - (gamma + 1.0) * yfp,
+                            1.0 - (gamma + 1.0) * cfp], dim=2)
+
+    zero = torch.zeros([B, S])
+    return core, torch.stack([th["init_x"], zero, zero, zero], dim=2)
+
+
 def make_prpr_constant(th, cond, prec_w=None):
     """models/prpr_constant.py:13-69 (RHS), x0 :79-85."""
     B, S = th["r"].shape
@@ -489,6 +532,13 @@ def observe_default(xs):
     return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
 
 
+def observe_inducer(xs):
+    """models/inducer_constant.py:106-114: [OD, OD*RFP, OD*(YFP+F530), OD*F480]."""
+    xp = [xs[:, :, 0, :], xs[:, :, 0, :] * xs[:, :, 1, :], xs[:, :, 0, :] * (xs[:, :, 2, :] + xs[:, :, 3, :]),
+          xs[:, :, 0, :] * xs[:, :, 4, :]]
+    return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
+
+
 def observe_direct(xs):
     """models/dr_blackbox.py:112-121, models/auto_constant.py:89-97: [OD, OD*s1, OD*s2, OD*s3]."""
     xp = [xs[:, :, 0, :], xs[:, :, 0, :] * xs[:, :, 1, :], xs[:, :, 0, :] * xs[:, :, 2, :],
@@ -550,6 +600,9 @@ MODEL_TABLE = {
     "relay_constant_precisions": (make_relay_constant, observe_default, True),
     "degrader_constant": (make_degrader_constant, observe_default, False),
     "degrader_constant_precisions": (make_degrader_constant, observe_default, True),
+    "inducer_constant": (make_inducer_constant, observe_inducer, False),
+    "inducer_constant_precisions": (make_inducer_constant, observe_inducer, True),
+    "debug_constant": (make_debug_constant, observe_direct, False),
 }
 
 

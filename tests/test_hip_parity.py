@@ -357,11 +357,12 @@ def _synthetic_theta(names, B, S, seed):
     return th
 
 
-@pytest.mark.parametrize("model,C", [("relay_constant", 2), ("degrader_constant", 3)])
+@pytest.mark.parametrize("model,C", [("relay_constant", 2), ("degrader_constant", 3), ("inducer_constant", 1),
+                                     ("debug_constant", 1)])
 @pytest.mark.parametrize("solver", ["modeuler", "rk4"])
 def test_relay_degrader_match_own_restatement(model, C, solver):
-    """PARITY UNPINNED: the reference classes raise at construction; this compares the HIP kernels
-    with our CPU restatement of the reference's equations."""
+    """PARITY UNPINNED: the reference classes raise at construction / call (inducer_constant.py:85,
+    debug.py:35); this compares the HIP kernels with our CPU restatement of the reference's equations."""
     from vihds import hip, ops
     import hip_util as H
 
@@ -557,6 +558,53 @@ def test_config4_blackbox_full_size_properties():
     fd = (f(wts + eps * d) - f(wts - eps * d)) / (2 * eps)
     an = (w.grad.double() * d.double()).sum()
     assert abs(float(fd - an)) / (abs(float(an)) + 1e-12) < 2e-2
+
+
+@pytest.mark.parametrize("solver", ["modeulerwhile", "midpoint"])
+def test_inducer_precisions_match_own_restatement(solver):
+    """inducer_constant_precisions (5 species + 4 neural precision states, n_hidden = 0): forward, theta and
+    network-weight gradients vs the CPU restatement.  PARITY UNPINNED (reference raises, inducer_constant.py:119)."""
+    from vihds import hip, ops
+    import hip_util as H
+
+    model, B, S, T = "inducer_constant_precisions", 4, 12, 30
+    slots = hip.model_slots(model)
+    th = _synthetic_theta(slots, B, S, 21)
+    g = torch.Generator().manual_seed(8)
+    for n in slots:
+        if n.startswith("init_prec"):
+            th[n] = torch.exp(3.0 + 0.3 * torch.randn(B, S, generator=g))
+    for v in th.values():
+        v.requires_grad_(True)
+    cond = torch.log1p(torch.tensor([0.0, 2.0, 50.0, 5000.0])[:, None] * torch.rand(B, 1, generator=g))
+    times = torch.arange(T, dtype=torch.float32) * 0.3
+    obs = torch.rand(B, 4, T, generator=g)
+    nin = 6
+    prec_w = {"prod_w": (torch.randn(4, nin, generator=g) * 0.3).requires_grad_(True),
+              "prod_b": (torch.randn(4, generator=g) * 0.1).requires_grad_(True),
+              "degr_w": (torch.randn(4, nin, generator=g) * 0.3).requires_grad_(True),
+              "degr_b": (torch.randn(4, generator=g) * 0.1).requires_grad_(True)}
+    xs, xp, prec = O.decode(model, th, cond, times, solver, prec_w=prec_w)
+    lpo = O.log_prob_observations(xp, obs, prec)
+    (lpo.sum() * 1e-3).backward()
+
+    keys = ("prod_w", "prod_b", "degr_w", "degr_b")
+    wts = torch.cat([prec_w[k].detach().reshape(-1) for k in keys]).to(DEV).requires_grad_(True)
+    theta = torch.stack([th[n].detach() for n in slots]).to(DEV).requires_grad_(True)
+    spec = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=1)
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, cond.to(DEV), times.to(DEV), obs.to(DEV), None, wts)
+    (logp.sum() * 1e-3).backward()
+    full = H.view_bsnt(traj)
+    assert rel_err(full[:, :, :5], xs) < TOL and rel_err(full[:, :, 5:], prec) < TOL
+    assert rel_err(H.view_bsnt(xpred), xp) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+    ref_w = torch.cat([prec_w[k].grad.reshape(-1) for k in keys])
+    assert rel_err(wts.grad.cpu(), ref_w) < 2e-3
+    zero = torch.zeros(B, S)
+    for i, n in enumerate(slots):
+        ref = th[n].grad if th[n].grad is not None else zero
+        scale = ref.abs().max()
+        if scale > 0 and not n.startswith("init_x"):
+            assert float((theta.grad[i].cpu() - ref).abs().max() / scale) < 2e-3, n
 
 
 def test_config5_relay_precisions_full_size_properties():

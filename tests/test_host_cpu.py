@@ -120,8 +120,10 @@ def test_lookup_has_reference_keys():
             "inducer_constant", "inducer_constant_precisions", "prpr_constant", "prpr_constant_precisions",
             "relay_constant", "relay_constant_precisions"}  # reference models/__init__.py:19-35
     assert keys <= set(models.LOOKUP)
-    with pytest.raises(NotImplementedError):
-        models.LOOKUP["inducer_constant"](None)
+    from vihds import hip
+
+    for k in keys:  # every reference key maps to a kernel model of the C ABI
+        assert getattr(models.LOOKUP[k], "model_key", None) in hip.MODELS, k
 
 
 def test_device_conditioner_reproduces_reference_values():

@@ -24,6 +24,9 @@ VIHDS_DECL(degrader_constant)
 VIHDS_DECL(dr_constant_prec_v1)
 VIHDS_DECL(dr_constant_prec_v2)
 VIHDS_DECL(auto_constant_prec)
+VIHDS_DECL(inducer_constant)
+VIHDS_DECL(inducer_constant_prec)
+VIHDS_DECL(debug_constant)
 VIHDS_DECL(prpr_constant_prec)
 VIHDS_DECL(relay_constant_prec)
 VIHDS_DECL(degrader_constant_prec)
@@ -75,6 +78,9 @@ static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
     VIHDS_ENTRY(relay_constant_prec, true),     // VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS
     VIHDS_ENTRY(degrader_constant_prec, true),  // VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS
     VIHDS_ENTRY(dr_blackbox, true),             // VIHDS_MODEL_DR_BLACKBOX
+    VIHDS_ENTRY(inducer_constant, false),       // VIHDS_MODEL_INDUCER_CONSTANT
+    VIHDS_ENTRY(inducer_constant_prec, true),   // VIHDS_MODEL_INDUCER_CONSTANT_PRECISIONS
+    VIHDS_ENTRY(debug_constant, false),         // VIHDS_MODEL_DEBUG_CONSTANT
 };
 
 static thread_local char g_err[256] = "";

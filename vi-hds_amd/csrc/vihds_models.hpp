@@ -20,7 +20,7 @@
 
 namespace vihds {
 
-enum ObserveKind { OBS_DEFAULT = 0, OBS_DIRECT = 1 };
+enum ObserveKind { OBS_DEFAULT = 0, OBS_DIRECT = 1, OBS_INDUCER = 2 };
 
 __device__ __forceinline__ float clampf(float x, float lo, float hi) {
   // torch.clamp semantics incl. NaN pass-through
@@ -341,6 +341,145 @@ struct AutoConstant {
     pb[P_a530] += v[2] * rc;
     pb[P_a480] += v[3] * rc;
     growth_vjp(G, y[0], p[P_r], p[P_K], gammab, yb[0], pb[P_r], pb[P_K], pb[P_tlag]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// inducer_constant                         reference: models/inducer_constant.py:11-80 (RHS), :92-97 (x0), :106-114
+// (observe).  The reference class itself raises at construction (init_with_params does not exist, :85): parity
+// unpinned, the equations are restated from the RHS class.  One treatment (arabinose): c[0].
+// ---------------------------------------------------------------------------------------------
+struct InducerConstant {
+  static constexpr int N = 5;   // x, rfp, yfp, f530, f480
+  static constexpr int NS = 5;
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;
+  static constexpr int NC = 1;   // arabinose
+  static constexpr int OBS = OBS_INDUCER;
+  enum Slot { S_r, S_K, S_tlag, S_rc, S_a530, S_a480, S_drfp, S_dyfp, S_aYFP, S_nA, S_eA, S_KAra,
+              S_init_x, S_init_rfp, S_init_yfp, NSLOT };
+  enum Par { P_r, P_K, P_tlag, P_rc, P_a530, P_a480, P_drfp, P_dyfp, P_aYFP, P_PBAD, NP };
+  __host__ static const char* slot_name(int s) {
+    static const char* n[] = {"r", "K", "tlag", "rc", "a530", "a480", "drfp", "dyfp", "aYFP_Inducer", "nA", "eA",
+                              "KAra", "init_x", "init_rfp", "init_yfp"};
+    return n[s];
+  }
+  __device__ static void prepare(const float* th, const float* c, float* p) {
+    p[P_r] = clampf(th[S_r], 0.f, 4.f);
+    p[P_K] = clampf(th[S_K], 0.f, 4.f);
+    p[P_tlag] = th[S_tlag];
+    p[P_rc] = th[S_rc];
+    p[P_a530] = th[S_a530];
+    p[P_a480] = th[S_a480];
+    p[P_drfp] = clampf(th[S_drfp], 1e-12f, 2.f);
+    p[P_dyfp] = clampf(th[S_dyfp], 1e-12f, 2.f);
+    p[P_aYFP] = th[S_aYFP];
+    // PBAD = (ara^nA + eA*KAra^nA) / (ara^nA + KAra^nA)          inducer_constant.py:53-55
+    const float nA = clampf(th[S_nA], 0.5f, 3.f);
+    const float an = powf(c[0], nA), kn = powf(th[S_KAra], nA);
+    p[P_PBAD] = (an + th[S_eA] * kn) / (an + kn);
+  }
+  __device__ static void prepare_vjp(const float* th, const float* c, const float*, const float* pb, float* thb) {
+    thb[S_r] = pb[P_r] * clamp_pass(th[S_r], 0.f, 4.f);
+    thb[S_K] = pb[P_K] * clamp_pass(th[S_K], 0.f, 4.f);
+    thb[S_tlag] = pb[P_tlag];
+    thb[S_rc] = pb[P_rc];
+    thb[S_a530] = pb[P_a530];
+    thb[S_a480] = pb[P_a480];
+    thb[S_drfp] = pb[P_drfp] * clamp_pass(th[S_drfp], 1e-12f, 2.f);
+    thb[S_dyfp] = pb[P_dyfp] * clamp_pass(th[S_dyfp], 1e-12f, 2.f);
+    thb[S_aYFP] = pb[P_aYFP];
+    const float nA = clampf(th[S_nA], 0.5f, 3.f);
+    const float an = powf(c[0], nA), kn = powf(th[S_KAra], nA);
+    const float num = an + th[S_eA] * kn, den = an + kn;
+    const float numb = pb[P_PBAD] / den, denb = -pb[P_PBAD] * num / (den * den);
+    const float anb = numb + denb, knb = numb * th[S_eA] + denb;
+    float nAb = 0.f, dummy = 0.f, KAb = 0.f;
+    pow_vjp(c[0], nA, an, anb, dummy, nAb);
+    pow_vjp(th[S_KAra], nA, kn, knb, KAb, nAb);
+    thb[S_nA] = nAb * clamp_pass(th[S_nA], 0.5f, 3.f);
+    thb[S_eA] = numb * kn;
+    thb[S_KAra] = KAb;
+  }
+  __device__ static void init(const float* th, const float*, float* y) {
+    y[0] = th[S_init_x]; y[1] = th[S_init_rfp]; y[2] = th[S_init_yfp]; y[3] = 0.f; y[4] = 0.f;
+  }
+  __device__ static void init_vjp(const float* yb, float* thb) {
+    thb[S_init_x] = yb[0]; thb[S_init_rfp] = yb[1]; thb[S_init_yfp] = yb[2];
+  }
+  __device__ static void rhs(float t, const float* y, const float* p, const float*, float* dy) {
+    Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
+    const float rc = p[P_rc], gm = G.gamma;
+    dy[0] = gm * y[0];
+    dy[1] = rc - (gm + p[P_drfp]) * y[1];
+    dy[2] = rc * p[P_aYFP] * p[P_PBAD] - (gm + p[P_dyfp]) * y[2];
+    dy[3] = rc * p[P_a530] - gm * y[3];
+    dy[4] = rc * p[P_a480] - gm * y[4];
+  }
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb) {
+    Growth G = growth(t, y[0], p[P_r], p[P_K], p[P_tlag]);
+    const float rc = p[P_rc], gm = G.gamma;
+    const float gammab = v[0] * y[0] - v[1] * y[1] - v[2] * y[2] - v[3] * y[3] - v[4] * y[4];
+    yb[0] += v[0] * gm;
+    yb[1] -= v[1] * (gm + p[P_drfp]);
+    yb[2] -= v[2] * (gm + p[P_dyfp]);
+    yb[3] -= v[3] * gm;
+    yb[4] -= v[4] * gm;
+    pb[P_rc] += v[1] + v[2] * p[P_aYFP] * p[P_PBAD] + v[3] * p[P_a530] + v[4] * p[P_a480];
+    pb[P_drfp] -= v[1] * y[1];
+    pb[P_dyfp] -= v[2] * y[2];
+    pb[P_aYFP] += v[2] * rc * p[P_PBAD];
+    pb[P_PBAD] += v[2] * rc * p[P_aYFP];
+    pb[P_a530] += v[3] * rc;
+    pb[P_a480] += v[4] * rc;
+    growth_vjp(G, y[0], p[P_r], p[P_K], gammab, yb[0], pb[P_r], pb[P_K], pb[P_tlag]);
+  }
+};
+
+// ---------------------------------------------------------------------------------------------
+// debug_constant                           reference: models/debug.py:11-53.  gamma = r (1 - x); dx = x gamma;
+// d s_k = 1 - (gamma + 1) s_k for the three fluorescent species; x0 = [init_x, 0, 0, 0].  The reference class is
+// stale (gen_reaction_equations has the pre-refactoring signature, debug.py:35, and observe indexes the time axis,
+// :25-31): parity unpinned; observe is taken as the evident [OD, OD*s1, OD*s2, OD*s3].
+// ---------------------------------------------------------------------------------------------
+struct DebugConstant {
+  static constexpr int N = 4;
+  static constexpr int NS = 4;
+  static constexpr bool NEURAL_PREC = false;
+  static constexpr int NW = 0;
+  static constexpr int NC = 0;
+  static constexpr int OBS = OBS_DIRECT;
+  enum Slot { S_r, S_init_x, NSLOT };
+  enum Par { P_r, NP };
+  __host__ static const char* slot_name(int s) {
+    static const char* n[] = {"r", "init_x"};
+    return n[s];
+  }
+  __device__ static void prepare(const float* th, const float*, float* p) { p[P_r] = th[S_r]; }
+  __device__ static void prepare_vjp(const float*, const float*, const float*, const float* pb, float* thb) {
+    thb[S_r] = pb[P_r];
+  }
+  __device__ static void init(const float* th, const float*, float* y) {
+    y[0] = th[S_init_x]; y[1] = 0.f; y[2] = 0.f; y[3] = 0.f;
+  }
+  __device__ static void init_vjp(const float* yb, float* thb) { thb[S_init_x] = yb[0]; }
+  __device__ static void rhs(float, const float* y, const float* p, const float*, float* dy) {
+    const float gm = p[P_r] * (1.f - y[0]);
+    dy[0] = y[0] * gm;
+    VIHDS_UNROLL for (int k = 1; k < 4; ++k) dy[k] = 1.f - (gm + 1.f) * y[k];
+  }
+  __device__ static void rhs_vjp(float, const float* y, const float* p, const float*, const float* v, float* yb,
+                                 float* pb) {
+    const float gm = p[P_r] * (1.f - y[0]);
+    float gmb = v[0] * y[0];
+    yb[0] += v[0] * gm;
+    VIHDS_UNROLL for (int k = 1; k < 4; ++k) {
+      gmb -= v[k] * y[k];
+      yb[k] -= v[k] * (gm + 1.f);
+    }
+    pb[P_r] += gmb * (1.f - y[0]);
+    yb[0] -= gmb * p[P_r];
   }
 };
 

@@ -29,6 +29,9 @@ __device__ __forceinline__ void observe(const float* y, float* xp) {
   if (OBS == OBS_DEFAULT) {  // vihds/ode.py:84-93
     xp[2] = y[0] * (y[2] + y[4]);
     xp[3] = y[0] * (y[3] + y[5]);
+  } else if (OBS == OBS_INDUCER) {  // models/inducer_constant.py:106-114: [OD, OD*RFP, OD*(YFP+F530), OD*F480]
+    xp[2] = y[0] * (y[2] + y[3]);
+    xp[3] = y[0] * y[4];
   } else {  // models/auto_constant.py:89-97, models/dr_blackbox.py:112-121
     xp[2] = y[0] * y[2];
     xp[3] = y[0] * y[3];
@@ -43,6 +46,12 @@ __device__ __forceinline__ void observe_vjp(const float* y, const float* xpb, fl
     yb[4] += xpb[2] * y[0];
     yb[3] += xpb[3] * y[0];
     yb[5] += xpb[3] * y[0];
+  } else if (OBS == OBS_INDUCER) {
+    yb[0] += xpb[0] + xpb[1] * y[1] + xpb[2] * (y[2] + y[3]) + xpb[3] * y[4];
+    yb[1] += xpb[1] * y[0];
+    yb[2] += xpb[2] * y[0];
+    yb[3] += xpb[2] * y[0];
+    yb[4] += xpb[3] * y[0];
   } else {
     yb[0] += xpb[0] + xpb[1] * y[1] + xpb[2] * y[2] + xpb[3] * y[3];
     yb[1] += xpb[1] * y[0];

@@ -24,6 +24,9 @@ MODELS = {
     "relay_constant_precisions": 10,
     "degrader_constant_precisions": 11,
     "dr_blackbox": 12,
+    "inducer_constant": 13,
+    "inducer_constant_precisions": 14,
+    "debug_constant": 15,
 }
 SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}
 

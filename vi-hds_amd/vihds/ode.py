@@ -190,6 +190,9 @@ class OdeModel(nn.Module):
         if self.observe_kind == "default":
             xp = [x0, x0 * x_sample[:, :, 1, :], x0 * (x_sample[:, :, 2, :] + x_sample[:, :, 4, :]),
                   x0 * (x_sample[:, :, 3, :] + x_sample[:, :, 5, :])]
+        elif self.observe_kind == "inducer":  # models/inducer_constant.py:106-114
+            xp = [x0, x0 * x_sample[:, :, 1, :], x0 * (x_sample[:, :, 2, :] + x_sample[:, :, 3, :]),
+                  x0 * x_sample[:, :, 4, :]]
         else:
             xp = [x0, x0 * x_sample[:, :, 1, :], x0 * x_sample[:, :, 2, :], x0 * x_sample[:, :, 3, :]]
         return torch.stack(xp, dim=-1).permute(0, 1, 3, 2)
