@@ -29,6 +29,9 @@ Pinning status (see tests/test_oracle_golden.py, tests/golden/*.npz, tests/golde
   construction (relay_constant.py:17,201; degrader_constant.py:17), so no reference output can exist; the
   functions here restate the reference's equations (relay_constant.py:28-134,220-251;
   degrader_constant.py:28-143).
+* PARITY UNPINNED: inducer_constant(_precisions) (the classes call a non-existent ``init_with_params``,
+  inducer_constant.py:85,119) and debug_constant (stale ``gen_reaction_equations`` signature, debug.py:35; its
+  ``observe`` indexes the time axis, :25-31 -- restated as the evident [OD, OD*s1, OD*s2, OD*s3]).
 """
 import math
 from collections import OrderedDict
