@@ -129,8 +129,8 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     use_graph = not a.eager and not a.host_rng
-    if shard is not None and (torch.distributed.get_backend() != "nccl" or os.environ.get("VIHDS_BENCH_MULTI_EAGER")):
-        use_graph = False  # only RCCL collectives can be captured in a hipGraph
+    if shard is not None and os.environ.get("VIHDS_BENCH_MULTI_EAGER"):
+        use_graph = False  # (multi-rank steps are captured as hipGraph segments with eager collectives in between)
     # every rank: same seed => same encoder init, same DeviceConditioner draws, same full u (sliced per rank)
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,

@@ -183,10 +183,12 @@ int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, cons
  * (w_mean=2, w_std=1.5 reproduce DeviceConditioner's init) or final weights (w_mean=0, w_std=1).
  * rng (optional; 4 device words as vihds_theta_opts.rng, a state of its own): the kernel draws z itself and advances
  * the step - the reference re-randomises the conditioner on every call (ode.py:48), this keeps that inside a
- * captured graph without a launch for the draw.  z may then be NULL. */
-int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
-                           const float* dev1hot, const float* relevance, const int* is_default, float* out,
-                           void* stream);
+ * captured graph without a launch for the draw.  z may then be NULL.
+ * (S_total, s_offset): this call covers samples s_offset.. of S_total per row (S sharded over ranks); the tiling
+ * index r is taken on the global grid, r = (b*S_total + s_offset + s) mod B.  S_total <= 0 means S_total = S. */
+int vihds_device_condition(int E, int B, int S, int S_total, int s_offset, int D, float w_mean, float w_std,
+                           const float* z, unsigned int* rng, const float* dev1hot, const float* relevance,
+                           const int* is_default, float* out, void* stream);
 
 /* Evaluation summaries (vihds/utils.py:79-99, Results.init) on device: importance-weighted mean / std of the
  * predictions, mean of the states, mean of 1/precision.  w = exp(log_w - lse).

@@ -2,6 +2,7 @@
 -> Training.cost -> backward) on the fixture's batch, with the reference's RNG streams (host numpy u, CPU-drawn
 DeviceConditioner weights), against what the reference itself produced for the same seed: loss (= -ELBO),
 trajectories, and d loss / d (every encoder parameter)."""
+import os
 import numpy as np
 import pytest
 import torch
@@ -207,3 +208,46 @@ def test_training_run_tracks_reference_trace(name, tmp_path, monkeypatch):
     assert rel.max() < 5e-2                        # fp32 rounding differences grow through Adam, slowly
     assert result is not None
     assert abs(float(result.elbo) - float(z["valid_elbo"][-1])) / abs(float(z["valid_elbo"][-1])) < 5e-2
+
+
+def _run_worker(mode, steps, s_total, ranks):
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_worker.py")
+    env = dict(os.environ)
+    env.pop("RANK", None), env.pop("WORLD_SIZE", None), env.pop("LOCAL_RANK", None)
+    if ranks == 1:
+        cmd = [sys.executable, worker, mode, str(steps), str(s_total)]
+    else:
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        # both ranks share the one GPU of the test box; gloo because a communicator cannot hold one device twice
+        env.update(VIHDS_DIST_BACKEND="gloo", VIHDS_FORCE_DEVICE="0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(ranks),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), worker, mode, str(steps), str(s_total)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("LOSSES ")][-1]
+    return json.loads(line[len("LOSSES "):])
+
+
+def test_two_ranks_sharded_step_matches_single_process_and_segmented_graph_matches_eager():
+    """S sharded over two ranks (one process per rank, both on this box's one GPU, gloo): (a) the loss trajectory equals
+    the single-process run over the same global sample set (in-kernel RNG is shard-consistent, the row statistics and
+    the gradients are exchanged); (b) the captured step -- hipGraph segments with the collectives run eagerly in
+    between -- reproduces the eager steps (its first replay is the 4th real step: three warm-up steps precede the
+    capture)."""
+    S = 16
+    single = _run_worker("eager", 8, S, 1)
+    eager2 = _run_worker("eager", 8, S, 2)
+    graph2 = _run_worker("graph", 5, S, 2)
+    for a, b in zip(single, eager2):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (single, eager2)
+    for k in range(5):
+        assert abs(graph2[k] - eager2[k + 3]) <= 2e-4 * max(1.0, abs(eager2[k + 3])), (graph2, eager2)
+    assert single[-1] < single[0]  # and it trains

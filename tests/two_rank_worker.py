@@ -1,0 +1,36 @@
+"""Worker for the multi-rank GPU test (launched by torch.distributed.run, or directly for the single-process
+reference): a few training steps of the synthetic dr_constant_icml workload with the IWAE-sample axis sharded over the
+ranks, printing the loss trajectory from rank 0."""
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "vi-hds_amd")]
+import torch  # noqa: E402
+
+from vihds import parallel, synthetic  # noqa: E402
+
+
+def main():
+    mode, steps, s_total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    shard = parallel.init_from_env()
+    rank = shard.rank if shard is not None else 0
+    dev = "cuda:%s" % os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(dev)
+    args, settings, data, parameters, model, training = synthetic.build(
+        "dr_constant_icml", 12, s_total, solver="midpoint", device=dev, seed=5, shard=shard, u_rng="kernel",
+        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0)
+    model.train()
+    batch = training.train_data
+    step = training.graph_step if mode == "graph" else training.step
+    losses = [float(step(batch)) for _ in range(steps)]
+    if rank == 0:
+        print("LOSSES " + json.dumps(losses), flush=True)
+    if shard is not None:
+        torch.distributed.barrier()
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -49,7 +49,7 @@ void launch_iwae_finish(int, float, const float*, const float*, float*, float*, 
 void launch_iwae_loss_small(int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
                             float*, hipStream_t);
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
-void launch_device_condition(int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
+void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
 void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
@@ -293,12 +293,15 @@ int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, cons
   return check_hip("vihds_iwae_loss_bwd launch");
 }
 
-int vihds_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
-                           const float* dev1hot, const float* relevance, const int* is_default, float* out,
-                           void* stream) {
+int vihds_device_condition(int E, int B, int S, int S_total, int s_offset, int D, float w_mean, float w_std,
+                           const float* z, unsigned int* rng, const float* dev1hot, const float* relevance,
+                           const int* is_default, float* out, void* stream) {
   if (E <= 0 || B <= 0 || S <= 0 || D <= 0 || (!z && !rng) || !dev1hot || !relevance || !is_default || !out)
     return fail(VIHDS_E_BADARG, "bad argument");
-  launch_device_condition(E, B, S, D, w_mean, w_std, z, rng, dev1hot, relevance, is_default, out, (hipStream_t)stream);
+  if (S_total <= 0) { S_total = S; s_offset = 0; }
+  if (s_offset < 0 || s_offset + S > S_total) return fail(VIHDS_E_BADARG, "need 0 <= s_offset, s_offset + S <= S_total");
+  launch_device_condition(E, B, S, S_total, s_offset, D, w_mean, w_std, z, rng, dev1hot, relevance, is_default, out,
+                          (hipStream_t)stream);
   return check_hip("vihds_device_condition launch");
 }
 

@@ -366,7 +366,7 @@ __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log
 //   row-major flattening of [B,S] (ode.py:46,52-57); kept as is.
 // rng (optional, {seed lo, seed hi, step, ticket} as in vihds_theta_opts): z is drawn here instead of read
 // (counter = (e*D + d, 0xC04D, step, 0): a stream disjoint from theta's, whose second word is a parameter block < 2^16).
-__global__ void device_condition_kernel(int E, int B, int S, int D, float w_mean, float w_std,
+__global__ void device_condition_kernel(int E, int B, int S, int S_total, int s_off, int D, float w_mean, float w_std,
                                         const float* __restrict__ z, unsigned int* rng,
                                         const float* __restrict__ dev1hot, const float* __restrict__ rel,
                                         const int* __restrict__ is_default, float* __restrict__ out) {
@@ -374,7 +374,10 @@ __global__ void device_condition_kernel(int E, int B, int S, int D, float w_mean
   const int i0 = blockIdx.x * blockDim.x + threadIdx.x;
   const bool live = i0 < n;
   const int i = live ? i0 : n - 1;
-  const int r = i % B;
+  // the tiling quirk is defined on the global [B, S_total] sample grid: a rank holding samples s_off.. of every row
+  // conditions them exactly as the unsharded run would
+  const int bb = i / S;
+  const int r = (int)(((long long)bb * S_total + s_off + (i - bb * S)) % B);
   unsigned int k0 = 0, k1 = 0, step = 0;
   if (rng) { k0 = rng[0]; k1 = rng[1]; step = rng[2]; }
   for (int e = 0; e < E; ++e) {
@@ -485,12 +488,13 @@ void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, co
   hipLaunchKernelGGL(iwae_loss_bwd_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, B, S, log_w, lse, g_loss,
                      g_logw, g_neg_logw);
 }
-void launch_device_condition(int E, int B, int S, int D, float w_mean, float w_std, const float* z, unsigned int* rng,
+void launch_device_condition(int E, int B, int S, int S_total, int s_off, int D, float w_mean, float w_std,
+                             const float* z, unsigned int* rng,
                              const float* dev1hot, const float* rel, const int* is_default, float* out,
                              hipStream_t st) {
   const int n = B * S, blk = 256;
-  hipLaunchKernelGGL(device_condition_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, E, B, S, D, w_mean, w_std,
-                     z, rng, dev1hot, rel, is_default, out);
+  hipLaunchKernelGGL(device_condition_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, E, B, S, S_total, s_off, D,
+                     w_mean, w_std, z, rng, dev1hot, rel, is_default, out);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -31,6 +31,7 @@ class DotOperatorSamples(object):
         object.__setattr__(self, "_rebound", {})
         object.__setattr__(self, "_log_prob_cache", {})
         object.__setattr__(self, "_u", None)
+        object.__setattr__(self, "_sample_window", None)  # (S_total, s_offset) when S is sharded over ranks
 
     @classmethod
     def from_packed(cls, names, packed):

@@ -96,7 +96,7 @@ _PROTOTYPES = {
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
-    "vihds_device_condition": (_I, [_I, _I, _I, _I, ctypes.c_float, ctypes.c_float] + [_P] * 7),
+    "vihds_device_condition": (_I, [_I] * 6 + [ctypes.c_float, ctypes.c_float] + [_P] * 7),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 4 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

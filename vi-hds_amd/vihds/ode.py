@@ -83,10 +83,12 @@ class OdeModel(nn.Module):
         # Reference quirk kept on purpose (ode.py:46,52-57): `param` is flattened row-major (k = b*S+s) but the
         # conditioner output is tiled with .repeat([S,1]) (k -> cond[k mod B]), so entry (b,s) is scaled by the
         # value of row (b*S+s) mod B, not row b.
-        key = (n_batch, n_iwae, str(dev_1hot.device))
+        window = getattr(param, "_sample_window", None) or (n_iwae, 0)  # (S_total, s_offset) under S-sharding
+        key = (n_batch, n_iwae, window, str(dev_1hot.device))
         if key not in self._tile_index:
-            k = torch.arange(n_batch * n_iwae, device=dev_1hot.device)
-            self._tile_index[key] = (k % n_batch).reshape(n_batch, n_iwae)
+            b = torch.arange(n_batch, device=dev_1hot.device)[:, None]
+            sidx = torch.arange(n_iwae, device=dev_1hot.device)[None, :]
+            self._tile_index[key] = (b * window[0] + window[1] + sidx) % n_batch
         param_cond = cond[self._tile_index[key]]
         if param_name in self.default_devices:
             return param * (1.0 + param_cond)
@@ -126,7 +128,7 @@ class OdeModel(nn.Module):
             mean, std = 0.0, 1.0
         with torch.no_grad():
             ops.device_condition(z, dev_1hot, rel, dflt, theta._packed[base: base + len(names)], mean, std,
-                                 rng_state)
+                                 rng_state, getattr(theta, "_sample_window", None))
         for j, n in enumerate(names):
             theta.bind_reserved_row(n, base + j)
         return theta

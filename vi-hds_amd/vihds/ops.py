@@ -424,7 +424,7 @@ class IwaeLoss(torch.autograd.Function):
         return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None
 
 
-def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng_state=None):
+def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng_state=None, sample_window=None):
     """OdeModel.device_conditioner applied to ones for E parameters in one launch, written into `out` [E,B,S].
     z [E,D] standard normals, or None with `rng_state` (KernelNormal.new_state): the kernel draws them."""
     _require_cuda(dev_1hot, relevance, is_default, out)
@@ -432,7 +432,8 @@ def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng
         raise ValueError("device_condition needs z or rng_state")
     E, B, S = out.shape
     z = None if z is None else _c(z)
-    rc = hip.lib().vihds_device_condition(E, B, S, dev_1hot.shape[1], float(w_mean), float(w_std), hip.ptr(z),
+    S_total, s_off = sample_window if sample_window is not None else (S, 0)  # this rank's slice of the global S axis
+    rc = hip.lib().vihds_device_condition(E, B, S, S_total, s_off, dev_1hot.shape[1], float(w_mean), float(w_std), hip.ptr(z),
                                           hip.ptr(rng_state), hip.ptr(_c(dev_1hot)), hip.ptr(relevance),
                                           hip.ptr(is_default), hip.ptr(out), hip.current_stream())
     hip.check(rc, "vihds_device_condition")

@@ -236,9 +236,13 @@ class Training:
                     self.step(static)
             torch.cuda.current_stream().wait_stream(s)
             self.optimizer.zero_grad(set_to_none=True)
-            g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                loss = self.step(static, zero_grad=False)
+            if self.shard is not None:  # cut the captured step at its collectives (vihds/parallel.py)
+                g = parallel.SegmentedGraph()
+                loss = g.capture(lambda: self.step(static, zero_grad=False))
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    loss = self.step(static, zero_grad=False)
             self._graphs[key] = (g, static, loss)
         g, static, loss = self._graphs[key]
         if self._staged.get(key) is not batch:  # a batch that is already resident in the graph's inputs is not re-copied

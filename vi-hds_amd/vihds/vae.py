@@ -46,6 +46,9 @@ class BaseVAE(nn.Module):
         ode_model = self.decoder.ode_model
         n_extra = len(ode_model.extra_theta_names) if self.decoder.condition_on_device else 0
         clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4, n_extra_rows=n_extra)
+        if self.shard is not None:
+            lo, _ = self.shard.bounds(samples)
+            object.__setattr__(clipped_theta, "_sample_window", (samples, lo))
         result, conditioned_theta = self.decoder(clipped_theta, data, writer, epoch)
         return result, conditioned_theta, q, p
 
