@@ -163,6 +163,13 @@ def main():
         raise SystemExit("non-finite loss %r after the timed steps" % final_loss)
 
     # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
+    if a.roofline_steps <= 0:
+        if rank == 0:
+            print(json.dumps({"metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)",
+                              "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
+                              "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "launch": launch_mode,
+                              "final_loss": final_loss, "note": "roofline leg skipped (--roofline-steps 0)"}))
+        return
     ops.TIMER = ops.KernelTimer()
     for _ in range(a.roofline_steps):
         training.step(batch)
@@ -178,7 +185,7 @@ def main():
     nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b}
     solver_id = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}[a.solver]
     lanes = B_ROWS * N_IWAE <= 16384  # the library's automatic choice (vihds_dr_lanes.hpp)
-    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d>(vihds::OdeArgs)" % (k[4:], solver_id)) if lanes else
+    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d%s>(vihds::OdeArgs)" % (k[4:], solver_id, ", true" if k == "ode_fwd" else "")) if lanes else
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
 
