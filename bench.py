@@ -113,6 +113,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=20)
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--lr", type=float, default=0.001,
+                    help="Adam learning rate.  The reference spec's 0.01 makes the objective run away on the synthetic "
+                         "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
+                         "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it")
     a = ap.parse_args()
 
     from vihds import ops, parallel, synthetic
@@ -135,7 +139,7 @@ def main():
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,
         u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
-        hip_graph=use_graph, nan_check_every=0)
+        hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr)
     model.train()
     batch = training.train_data
     step = training.graph_step if use_graph else training.step
@@ -159,8 +163,9 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
     final_loss = float(loss)
-    if not np.isfinite(final_loss):
-        raise SystemExit("non-finite loss %r after the timed steps" % final_loss)
+    if not np.isfinite(final_loss) or final_loss < -1e6:
+        raise SystemExit("degenerate loss %r after the timed steps (training ran away): not a valid bench run"
+                         % final_loss)
 
     # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
     if a.roofline_steps <= 0:
@@ -218,7 +223,7 @@ def main():
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
-                   "launch": launch_mode, "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
+                   "launch": launch_mode, "learning_rate": a.lr, "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": "iwae-sample shard x%d" % world},
         "final_loss": final_loss, "roofline": roofline,
     }

@@ -199,6 +199,40 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
                        float* iw_predict_mu /*[B][4][T]*/, float* iw_predict_std /*[B][4][T]*/,
                        float* iw_states /*[B][n_species][T]*/, float* iw_variance /*[B][4][T]*/, void* stream);
 
+/* q(theta | data) encoder (vihds/encoders.py): ConditionalEncoder.forward :49-55 (Conv1d -> AvgPool1d(stride 1) ->
+ * Linear -> tanh), the per-parameter Linear(n,1) heads of Q_Local :143-169 and Q_Global_Cond :187-213, Q_Global's free
+ * scalars :216-239 and Q_Constant :242-253 -- everything Encoder.evaluate_q :383-404 computes, as ONE forward launch
+ * writing the [2P][B] table of means and log-precisions the theta kernel consumes (row order = vihds_theta_opts.q_rows
+ * of the level-blocked layout: [local mu; local log_prec; gcond mu; gcond log_prec; global mu; global log_prec;
+ * constants; zeros]), and two backward launches producing every parameter gradient (fixed summation order).
+ *   delta_obs [B][C_in][L]   first differences of the observations (encoders.py:385)
+ *   inputs [B][n_tr], dev1hot [B][D]
+ *   conv_w [F][C_in][K], conv_b [F]; lin_w [H][F*Lp], lin_b [H]           (torch layouts)
+ *   local_w [2*nl][NX] (all mu heads, then all log_prec heads; NX = H + n_tr*l_tr + D*l_dv), local_b [2*nl]
+ *   gcond_w [2*ng][NG] (NG = n_tr*g_tr + D*g_dv; no bias); global_free [2][ngl]; const_values [nc]
+ *   pooled [B][F*Lp], hidden [B][H]: forward by-products the backward needs. */
+typedef struct vihds_encoder_shape {
+  int B;
+  int C_in, L;        /* conv input channels (observed signals) and length (n_times - 1) */
+  int F, K, pool;     /* filters, filter size, average-pool width (stride 1) */
+  int H;              /* hidden units */
+  int n_tr, D;        /* treatments, device depth */
+  int nl, l_tr, l_dv; /* local parameters; their heads see [hidden, treatments if l_tr, dev1hot if l_dv] */
+  int ng, g_tr, g_dv; /* global-conditioned parameters; heads see [treatments if g_tr, dev1hot if g_dv] */
+  int ngl, nc;        /* global parameters, constants */
+} vihds_encoder_shape;
+int vihds_encoder_fwd(const vihds_encoder_shape* s, const float* delta_obs, const float* inputs, const float* dev1hot,
+                      const float* conv_w, const float* conv_b, const float* lin_w, const float* lin_b,
+                      const float* local_w, const float* local_b, const float* gcond_w, const float* global_free,
+                      const float* const_values, float* q_all, float* pooled, float* hidden, void* stream);
+/* g_all [2P][B] -> gradients of every parameter tensor (each overwritten; g_local_b may be NULL with local_b).
+ * scratch: g_pre [B][H] and g_conv [B][F][Lc] (Lc = L-K+1) are work buffers of the call. */
+int vihds_encoder_bwd(const vihds_encoder_shape* s, const float* g_all, const float* delta_obs, const float* inputs,
+                      const float* dev1hot, const float* lin_w, const float* local_w, const float* pooled,
+                      const float* hidden, float* g_pre, float* g_conv, float* g_conv_w, float* g_conv_b,
+                      float* g_lin_w, float* g_lin_b, float* g_local_w, float* g_local_b, float* g_gcond_w,
+                      float* g_global_free, void* stream);
+
 /* Adam update of the encoder / decoder-network parameters (reference training.py:82,338: torch.optim.Adam, default
  * betas/eps, no weight decay, no amsgrad) as one launch over up to VIHDS_ADAM_MAX_TENSORS parameter tensors:
  *   m += (g - m)(1-beta1);  v = beta2 v + (1-beta2) g^2;  t = step+1

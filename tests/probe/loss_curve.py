@@ -10,8 +10,8 @@ steps = int(sys.argv[2]) if len(sys.argv) > 2 else 2000
 seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
 use_graph = mode == "graph"
 args, settings, data, parameters, model, training = synthetic.build(
-    "dr_constant_icml", 36, 200, solver="rk4", device="cuda:0", seed=seed, shard=None, u_rng="device",
-    conditioner_rng="device", hip_graph=use_graph, nan_check_every=0)
+    "dr_constant_icml", 36, 200, solver="rk4", device="cuda:0", seed=seed, shard=None, u_rng="kernel",
+    conditioner_rng="kernel", hip_graph=use_graph, nan_check_every=0)
 model.train()
 batch = training.train_data
 step = training.graph_step if use_graph else training.step

@@ -757,3 +757,39 @@ def test_device_condition_kernel_matches_reference_formula_and_draws_its_own_wei
         outs.append(out.clone())
     assert not torch.equal(outs[0], outs[1])
     assert state.cpu().tolist()[2:] == [2, 0]
+
+
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
+                                  "dr_constant_one_modeuler", "dr_constant_icml_full_modeuler"])
+def test_fused_encoder_matches_module_path(name):
+    """vihds_encoder_fwd / _bwd (one forward, two backward launches) against the nn.Conv1d / AvgPool1d / nn.Linear
+    modules they replace, on the same weights and the fixture's batch: the [2P,B] table of means and log-precisions
+    and the gradient of every encoder parameter for a random upstream gradient.  (The module path itself is pinned
+    to the reference by tests/test_host_cpu.py::test_encoder_initialises_to_reference_weights_and_q and the e2e
+    fixture gradients.)"""
+    import e2e_util as E
+    from vihds.vae import build_model
+
+    fx = Fixture(name)
+    args, settings, data, parameters = E.build_from_fixture(fx, gpu=0)
+    model = build_model(args, settings, data, parameters)
+    enc = model.encoder
+    batch = E.batch_from_fixture(fx, DEV)
+    g = torch.Generator().manual_seed(2)
+    outs = {}
+    for use_kernel in (True, False):
+        enc.use_kernel = use_kernel
+        enc.zero_grad(set_to_none=True)
+        q = enc(batch)
+        q_all = q._packed_q[1]
+        if "w" not in outs:
+            outs["w"] = torch.randn(q_all.shape, generator=g).to(DEV)
+        (q_all * outs["w"]).sum().backward()
+        outs[use_kernel] = (q_all.detach().clone(), {k: v.grad.clone() for k, v in enc.named_parameters()
+                                                      if v.grad is not None})
+    qa, ga = outs[True]
+    qb, gb = outs[False]
+    assert rel_err(qa, qb) < 1e-5
+    assert set(ga) == set(gb) and len(ga) >= 5
+    for k in gb:
+        assert rel_err(ga[k], gb[k]) < 2e-5, k

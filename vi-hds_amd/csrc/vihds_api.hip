@@ -51,6 +51,15 @@ void launch_iwae_loss_small(int, int, float, const float*, const float*, const f
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
+// vihds_encoder.hip
+size_t encoder_fwd_lds_bytes(const vihds_encoder_shape&);
+size_t encoder_bwd_lds_bytes(const vihds_encoder_shape&);
+void launch_encoder_fwd(const vihds_encoder_shape&, const float*, const float*, const float*, const float*, const float*,
+                        const float*, const float*, const float*, const float*, const float*, const float*, const float*,
+                        float*, float*, float*, hipStream_t);
+void launch_encoder_bwd(const vihds_encoder_shape&, const float*, const float*, const float*, const float*, const float*,
+                        const float*, const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
+                        float*, float*, float*, hipStream_t);
 void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
                          const int*, float*, float*, float*, float*, hipStream_t);
@@ -317,6 +326,50 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
   launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, theta, prec_rows, iw_predict_mu,
                       iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
   return check_hip("vihds_iw_summaries launch");
+}
+
+static int check_encoder_shape(const vihds_encoder_shape* s) {
+  if (!s) return fail(VIHDS_E_BADARG, "null shape");
+  if (s->B <= 0 || s->C_in <= 0 || s->L <= 0 || s->F <= 0 || s->K <= 0 || s->pool <= 0 || s->H <= 0)
+    return fail(VIHDS_E_BADARG, "encoder dimensions must be > 0");
+  if (s->L - s->K + 1 - s->pool + 1 <= 0) return fail(VIHDS_E_BADARG, "time axis shorter than filter + pool");
+  if (s->nl < 0 || s->ng < 0 || s->ngl < 0 || s->nc < 0 || s->n_tr < 0 || s->D < 0)
+    return fail(VIHDS_E_BADARG, "negative count");
+  if (encoder_fwd_lds_bytes(*s) > 60 * 1024 || encoder_bwd_lds_bytes(*s) > 60 * 1024)
+    return fail(VIHDS_E_UNSUPPORTED, "encoder working set exceeds the 60 KB LDS budget of the fused kernels");
+  return VIHDS_OK;
+}
+
+int vihds_encoder_fwd(const vihds_encoder_shape* s, const float* delta_obs, const float* inputs, const float* dev1hot,
+                      const float* conv_w, const float* conv_b, const float* lin_w, const float* lin_b,
+                      const float* local_w, const float* local_b, const float* gcond_w, const float* global_free,
+                      const float* const_values, float* q_all, float* pooled, float* hidden, void* stream) {
+  if (int rc = check_encoder_shape(s)) return rc;
+  if (!delta_obs || !conv_w || !conv_b || !lin_w || !lin_b || !q_all || !pooled || !hidden)
+    return fail(VIHDS_E_BADARG, "null argument");
+  if ((s->nl > 0 && !local_w) || (s->ng > 0 && !gcond_w) || (s->ngl > 0 && !global_free) || (s->nc > 0 && !const_values))
+    return fail(VIHDS_E_BADARG, "missing parameter tensor");
+  if (((s->l_tr || s->g_tr) && s->n_tr > 0 && !inputs) || ((s->l_dv || s->g_dv) && s->D > 0 && !dev1hot))
+    return fail(VIHDS_E_BADARG, "missing conditioning input");
+  launch_encoder_fwd(*s, delta_obs, inputs, dev1hot, conv_w, conv_b, lin_w, lin_b, local_w, local_b, gcond_w,
+                     global_free, const_values, q_all, pooled, hidden, (hipStream_t)stream);
+  return check_hip("vihds_encoder_fwd launch");
+}
+
+int vihds_encoder_bwd(const vihds_encoder_shape* s, const float* g_all, const float* delta_obs, const float* inputs,
+                      const float* dev1hot, const float* lin_w, const float* local_w, const float* pooled,
+                      const float* hidden, float* g_pre, float* g_conv, float* g_conv_w, float* g_conv_b,
+                      float* g_lin_w, float* g_lin_b, float* g_local_w, float* g_local_b, float* g_gcond_w,
+                      float* g_global_free, void* stream) {
+  if (int rc = check_encoder_shape(s)) return rc;
+  if (!g_all || !delta_obs || !lin_w || !pooled || !hidden || !g_pre || !g_conv || !g_conv_w || !g_conv_b || !g_lin_w ||
+      !g_lin_b)
+    return fail(VIHDS_E_BADARG, "null argument");
+  if ((s->nl > 0 && (!local_w || !g_local_w)) || (s->ng > 0 && !g_gcond_w) || (s->ngl > 0 && !g_global_free))
+    return fail(VIHDS_E_BADARG, "missing gradient tensor");
+  launch_encoder_bwd(*s, g_all, delta_obs, inputs, dev1hot, lin_w, local_w, pooled, hidden, g_pre, g_conv, g_conv_w,
+                     g_conv_b, g_lin_w, g_lin_b, g_local_w, g_local_b, g_gcond_w, g_global_free, (hipStream_t)stream);
+  return check_hip("vihds_encoder_bwd launch");
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,

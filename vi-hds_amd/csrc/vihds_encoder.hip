@@ -1,0 +1,342 @@
+// q(theta | data) encoder of the VAE (reference vihds/encoders.py): Conv1d -> AvgPool1d(stride 1) -> flatten ->
+// Linear -> tanh (ConditionalEncoder, :16-55), then one (mu, log_prec) pair of Linear(n,1) heads per local parameter
+// on [hidden, treatments?, device one-hot?] (Q_Local :126-169), bias-free heads per global-conditioned parameter on
+// [treatments?, device one-hot?] (Q_Global_Cond :172-213), free scalars per global parameter (Q_Global :216-239) and
+// fixed constants (Q_Constant :242-253).
+//
+// The arithmetic is tiny (2.6 MFLOP forward at B=36) but as framework ops it is 8 forward + 15 backward launches per
+// training step -- about half of the step once the ODE is fused, because a launch costs 4-5 us inside the step's
+// hipGraph whatever it computes.  Here: ONE forward launch (block per data row, everything staged through LDS,
+// results written straight into the theta kernel's level-blocked [2P,B] table) and TWO backward launches (per-row
+// chain, then all parameter-gradient reductions over the rows in a fixed order: deterministic).
+#include <hip/hip_runtime.h>
+
+#include "../../include/vihds_hip.h"
+
+namespace vihds {
+
+namespace {
+struct EncDims {
+  int Lc, Lp, NPOOL, NX, NG;  // conv length, pooled length, F*Lp, local head inputs, gcond head inputs
+};
+__host__ __device__ inline EncDims enc_dims(const vihds_encoder_shape& s) {
+  EncDims d;
+  d.Lc = s.L - s.K + 1;
+  d.Lp = d.Lc - s.pool + 1;
+  d.NPOOL = s.F * d.Lp;
+  d.NX = s.H + (s.l_tr ? s.n_tr : 0) + (s.l_dv ? s.D : 0);
+  d.NG = (s.g_tr ? s.n_tr : 0) + (s.g_dv ? s.D : 0);
+  return d;
+}
+__device__ __forceinline__ float wave_sum_e(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+  return v;
+}
+// head inputs of data row b: local = [hidden, treatments?, dev_1hot?]; gcond = [treatments?, dev_1hot?]
+__device__ __forceinline__ float local_input(const vihds_encoder_shape& s, const float* hid, const float* inputs,
+                                             const float* dev1hot, int b, int i) {
+  if (i < s.H) return hid[i];
+  i -= s.H;
+  if (s.l_tr) {
+    if (i < s.n_tr) return inputs[b * s.n_tr + i];
+    i -= s.n_tr;
+  }
+  return dev1hot[b * s.D + i];
+}
+__device__ __forceinline__ float gcond_input(const vihds_encoder_shape& s, const float* inputs, const float* dev1hot,
+                                             int b, int i) {
+  if (s.g_tr) {
+    if (i < s.n_tr) return inputs[b * s.n_tr + i];
+    i -= s.n_tr;
+  }
+  return dev1hot[b * s.D + i];
+}
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------------------------
+// forward: one block per data row
+// LDS: x [C_in*L] | conv weights [F*C_in*K] | conv out [F*Lc] | pooled [F*Lp] | hidden [H]
+constexpr int ENC_T = 1024;  // threads per block: these kernels are pure latency, so every phase is spread as wide as
+                             // its output count allows (760 conv outputs, 720 pooled values, 16 waves for the Linear)
+__global__ void __launch_bounds__(ENC_T)
+encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, const float* __restrict__ inputs,
+                   const float* __restrict__ dev1hot, const float* __restrict__ conv_w,
+                   const float* __restrict__ conv_b, const float* __restrict__ lin_w, const float* __restrict__ lin_b,
+                   const float* __restrict__ local_w, const float* __restrict__ local_b,
+                   const float* __restrict__ gcond_w, const float* __restrict__ global_free,
+                   const float* __restrict__ const_values, float* __restrict__ q_all, float* __restrict__ pooled_out,
+                   float* __restrict__ hidden_out) {
+  extern __shared__ float lds[];
+  const EncDims d = enc_dims(s);
+  const int b = blockIdx.x, tid = threadIdx.x, B = s.B;
+  float* x = lds;
+  float* cw = x + s.C_in * s.L;
+  float* cv = cw + s.F * s.C_in * s.K;
+  float* pl = cv + s.F * d.Lc;
+  float* hid = pl + d.NPOOL;
+  for (int q = tid; q < s.C_in * s.L; q += ENC_T) x[q] = delta_obs[(size_t)b * s.C_in * s.L + q];
+  for (int q = tid; q < s.F * s.C_in * s.K; q += ENC_T) cw[q] = conv_w[q];
+  __syncthreads();
+  // Conv1d (cross-correlation, no padding): out[o][t] = bias[o] + sum_c sum_k w[o][c][k] x[c][t+k]
+  for (int q = tid; q < s.F * d.Lc; q += ENC_T) {
+    const int o = q / d.Lc, t = q - o * d.Lc;
+    float acc = conv_b[o];
+    for (int c = 0; c < s.C_in; ++c) {
+      const float* wr = cw + (o * s.C_in + c) * s.K;
+      const float* xr = x + c * s.L + t;
+      for (int k = 0; k < s.K; ++k) acc += wr[k] * xr[k];
+    }
+    cv[q] = acc;
+  }
+  __syncthreads();
+  // AvgPool1d(pool, stride 1)
+  const float inv_pool = 1.f / (float)s.pool;
+  for (int q = tid; q < d.NPOOL; q += ENC_T) {
+    const int o = q / d.Lp, t = q - o * d.Lp;
+    float acc = 0.f;
+    for (int k = 0; k < s.pool; ++k) acc += cv[o * d.Lc + t + k];
+    const float v = acc * inv_pool;
+    pl[q] = v;
+    pooled_out[(size_t)b * d.NPOOL + q] = v;
+  }
+  __syncthreads();
+  // Linear + tanh: a wave owns output units j = wid, wid+16, ... and works on four of them at a time so that 4 x
+  // ceil(NPOOL/64) independent coalesced row loads are in flight; lanes stride over the inputs
+  const int lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = ENC_T / 64;
+  for (int j0 = wid; j0 < s.H; j0 += 4 * NW) {
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int k = lane; k < d.NPOOL; k += 64) {
+      const float pv = pl[k];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int j = j0 + u * NW;
+        if (j < s.H) acc[u] += lin_w[(size_t)j * d.NPOOL + k] * pv;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int j = j0 + u * NW;
+      const float t = wave_sum_e(acc[u]);
+      if (lane == 0 && j < s.H) {
+        const float h = tanhf(t + lin_b[j]);
+        hid[j] = h;
+        hidden_out[(size_t)b * s.H + j] = h;
+      }
+    }
+  }
+  __syncthreads();
+  // heads -> rows of the level-blocked table [local mu; local lp; gcond mu; gcond lp; global mu; global lp; const; 0]
+  const int n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
+  for (int r = tid; r < n_rows; r += ENC_T) {
+    float v;
+    if (r < 2 * s.nl) {
+      const float* wr = local_w + (size_t)r * d.NX;
+      v = local_b ? local_b[r] : 0.f;
+      for (int i = 0; i < d.NX; ++i) v += wr[i] * local_input(s, hid, inputs, dev1hot, b, i);
+    } else if (r < 2 * (s.nl + s.ng)) {
+      const int rr = r - 2 * s.nl;
+      const float* wr = gcond_w + (size_t)rr * d.NG;
+      v = 0.f;
+      for (int i = 0; i < d.NG; ++i) v += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
+    } else if (r < 2 * (s.nl + s.ng + s.ngl)) {
+      v = global_free[r - 2 * (s.nl + s.ng)];
+    } else {
+      const int rr = r - 2 * (s.nl + s.ng + s.ngl);
+      v = rr < s.nc ? const_values[rr] : 0.f;
+    }
+    q_all[(size_t)r * B + b] = v;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// backward, per-row chain: g_all[:, b] -> g_pre[b] (adjoint of the Linear's pre-activation) and g_conv[b] (adjoint of
+// the conv output).  LDS: g_x [NX] | g_pre [H] | g_pooled [F*Lp]
+__global__ void __launch_bounds__(ENC_T)
+encoder_bwd_row_kernel(vihds_encoder_shape s, const float* __restrict__ g_all, const float* __restrict__ hidden,
+                       const float* __restrict__ lin_w, const float* __restrict__ local_w,
+                       float* __restrict__ g_pre_out, float* __restrict__ g_conv_out) {
+  extern __shared__ float lds[];
+  const EncDims d = enc_dims(s);
+  const int b = blockIdx.x, tid = threadIdx.x, B = s.B;
+  float* gpre = lds;
+  float* gpl = gpre + s.H;
+  // hidden adjoint through the local heads, then tanh'
+  for (int j = tid; j < s.H; j += ENC_T) {
+    float acc = 0.f;
+    for (int r = 0; r < 2 * s.nl; ++r) acc += local_w[(size_t)r * d.NX + j] * g_all[(size_t)r * B + b];
+    const float h = hidden[(size_t)b * s.H + j];
+    const float g = acc * (1.f - h * h);
+    gpre[j] = g;
+    g_pre_out[(size_t)b * s.H + j] = g;
+  }
+  __syncthreads();
+  // pooled adjoint: g_pooled[k] = sum_j lin_w[j][k] g_pre[j]   (threads stride over k: coalesced rows; the H loads
+  // of a thread are independent)
+  for (int k = tid; k < d.NPOOL; k += ENC_T) {
+    float a0 = 0.f, a1 = 0.f;
+    int j = 0;
+    for (; j + 1 < s.H; j += 2) {
+      a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
+      a1 += lin_w[(size_t)(j + 1) * d.NPOOL + k] * gpre[j + 1];
+    }
+    if (j < s.H) a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
+    gpl[k] = a0 + a1;
+  }
+  __syncthreads();
+  // conv-output adjoint: every pooled window that contains t contributes 1/pool
+  const float inv_pool = 1.f / (float)s.pool;
+  for (int q = tid; q < s.F * d.Lc; q += ENC_T) {
+    const int o = q / d.Lc, t = q - o * d.Lc;
+    const int lo = max(0, t - s.pool + 1), hi = min(t, d.Lp - 1);
+    float acc = 0.f;
+    for (int tp = lo; tp <= hi; ++tp) acc += gpl[o * d.Lp + tp];
+    g_conv_out[(size_t)b * s.F * d.Lc + q] = acc * inv_pool;
+  }
+}
+
+// backward, parameter gradients: every output is a fixed-order sum over the data rows.  Tasks by block range (the
+// kernel lasts as long as its slowest block, so each small task has blocks of its own):
+//   lin_w  [H][F*Lp]    one thread per element, B-term dot over rows
+//   conv_w [F][C_in][K] one wave per element, lanes over (row, t)
+//   conv_b [F]          one wave per element
+//   local_w, gcond_w    one thread per element
+//   lin_b, local_b, global_free: one block together (B-term sums)
+struct EncReduceTasks {
+  int nb_lin, nb_conv, nb_convb, nb_localw, nb_gcondw;
+};
+__global__ void __launch_bounds__(256)
+encoder_bwd_reduce_kernel(vihds_encoder_shape s, EncReduceTasks tk, const float* __restrict__ g_all,
+                          const float* __restrict__ delta_obs, const float* __restrict__ inputs,
+                          const float* __restrict__ dev1hot, const float* __restrict__ pooled,
+                          const float* __restrict__ hidden, const float* __restrict__ g_pre,
+                          const float* __restrict__ g_conv, float* __restrict__ g_conv_w,
+                          float* __restrict__ g_conv_b, float* __restrict__ g_lin_w, float* __restrict__ g_lin_b,
+                          float* __restrict__ g_local_w, float* __restrict__ g_local_b,
+                          float* __restrict__ g_gcond_w, float* __restrict__ g_global_free) {
+  const EncDims d = enc_dims(s);
+  const int tid = threadIdx.x, B = s.B;
+  const int lane = tid & 63, wid = tid >> 6;
+  int blk = blockIdx.x;
+  if (blk < tk.nb_lin) {
+    const int e = blk * 256 + tid;
+    if (e >= s.H * d.NPOOL) return;
+    const int j = e / d.NPOOL, k = e - j * d.NPOOL;
+    float a0 = 0.f, a1 = 0.f;
+    int b = 0;
+    for (; b + 1 < B; b += 2) {
+      a0 += g_pre[(size_t)b * s.H + j] * pooled[(size_t)b * d.NPOOL + k];
+      a1 += g_pre[(size_t)(b + 1) * s.H + j] * pooled[(size_t)(b + 1) * d.NPOOL + k];
+    }
+    if (b < B) a0 += g_pre[(size_t)b * s.H + j] * pooled[(size_t)b * d.NPOOL + k];
+    g_lin_w[e] = a0 + a1;
+    return;
+  }
+  blk -= tk.nb_lin;
+  if (blk < tk.nb_conv) {
+    const int e = blk * 4 + wid;  // (o, c, k)
+    if (e >= s.F * s.C_in * s.K) return;
+    const int o = e / (s.C_in * s.K), c = (e / s.K) % s.C_in, k = e % s.K;
+    float acc = 0.f;
+    const int n = B * d.Lc;
+    for (int q = lane; q < n; q += 64) {
+      const int b = q / d.Lc, t = q - b * d.Lc;
+      acc += g_conv[((size_t)b * s.F + o) * d.Lc + t] * delta_obs[((size_t)b * s.C_in + c) * s.L + t + k];
+    }
+    acc = wave_sum_e(acc);
+    if (lane == 0) g_conv_w[e] = acc;
+    return;
+  }
+  blk -= tk.nb_conv;
+  if (blk < tk.nb_convb) {
+    const int o = blk * 4 + wid;
+    if (o >= s.F) return;
+    float acc = 0.f;
+    for (int q = lane; q < B * d.Lc; q += 64) {
+      const int b = q / d.Lc, t = q - b * d.Lc;
+      acc += g_conv[((size_t)b * s.F + o) * d.Lc + t];
+    }
+    acc = wave_sum_e(acc);
+    if (lane == 0) g_conv_b[o] = acc;
+    return;
+  }
+  blk -= tk.nb_convb;
+  if (blk < tk.nb_localw) {
+    const int e = blk * 256 + tid;
+    if (e >= 2 * s.nl * d.NX) return;
+    const int r = e / d.NX, i = e - r * d.NX;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b)
+      acc += g_all[(size_t)r * B + b] * local_input(s, hidden + (size_t)b * s.H, inputs, dev1hot, b, i);
+    g_local_w[e] = acc;
+    return;
+  }
+  blk -= tk.nb_localw;
+  if (blk < tk.nb_gcondw) {
+    const int e = blk * 256 + tid;
+    if (e >= 2 * s.ng * d.NG) return;
+    const int r = e / d.NG, i = e - r * d.NG;
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += g_all[(size_t)(2 * s.nl + r) * B + b] * gcond_input(s, inputs, dev1hot, b, i);
+    g_gcond_w[e] = acc;
+    return;
+  }
+  // ---- bias / free-scalar sums, one block
+  for (int j = tid; j < s.H; j += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += g_pre[(size_t)b * s.H + j];
+    g_lin_b[j] = acc;
+  }
+  if (g_local_b) {
+    for (int r = tid; r < 2 * s.nl; r += 256) {
+      float acc = 0.f;
+      for (int b = 0; b < B; ++b) acc += g_all[(size_t)r * B + b];
+      g_local_b[r] = acc;
+    }
+  }
+  for (int r = tid; r < 2 * s.ngl; r += 256) {
+    float acc = 0.f;
+    for (int b = 0; b < B; ++b) acc += g_all[(size_t)(2 * (s.nl + s.ng) + r) * B + b];
+    g_global_free[r] = acc;
+  }
+}
+
+// ---- launchers -------------------------------------------------------------------------------------------------
+size_t encoder_fwd_lds_bytes(const vihds_encoder_shape& s) {
+  const EncDims d = enc_dims(s);
+  return sizeof(float) * ((size_t)s.C_in * s.L + (size_t)s.F * s.C_in * s.K + (size_t)s.F * d.Lc + d.NPOOL + s.H);
+}
+size_t encoder_bwd_lds_bytes(const vihds_encoder_shape& s) {
+  const EncDims d = enc_dims(s);
+  return sizeof(float) * ((size_t)s.H + d.NPOOL);
+}
+void launch_encoder_fwd(const vihds_encoder_shape& s, const float* delta_obs, const float* inputs, const float* dev1hot,
+                        const float* conv_w, const float* conv_b, const float* lin_w, const float* lin_b,
+                        const float* local_w, const float* local_b, const float* gcond_w, const float* global_free,
+                        const float* const_values, float* q_all, float* pooled, float* hidden, hipStream_t st) {
+  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(s.B), dim3(ENC_T), encoder_fwd_lds_bytes(s), st, s, delta_obs, inputs,
+                     dev1hot, conv_w, conv_b, lin_w, lin_b, local_w, local_b, gcond_w, global_free, const_values, q_all,
+                     pooled, hidden);
+}
+void launch_encoder_bwd(const vihds_encoder_shape& s, const float* g_all, const float* delta_obs, const float* inputs,
+                        const float* dev1hot, const float* lin_w, const float* local_w, const float* pooled,
+                        const float* hidden, float* g_pre, float* g_conv, float* g_conv_w, float* g_conv_b,
+                        float* g_lin_w, float* g_lin_b, float* g_local_w, float* g_local_b, float* g_gcond_w,
+                        float* g_global_free, hipStream_t st) {
+  const EncDims d = enc_dims(s);
+  hipLaunchKernelGGL(encoder_bwd_row_kernel, dim3(s.B), dim3(ENC_T), encoder_bwd_lds_bytes(s), st, s, g_all, hidden,
+                     lin_w, local_w, g_pre, g_conv);
+  EncReduceTasks tk;
+  tk.nb_lin = (s.H * d.NPOOL + 255) / 256;
+  tk.nb_conv = (s.F * s.C_in * s.K + 3) / 4;
+  tk.nb_convb = (s.F + 3) / 4;
+  tk.nb_localw = (2 * s.nl * d.NX + 255) / 256;
+  tk.nb_gcondw = (2 * s.ng * d.NG + 255) / 256;
+  const int nblocks = tk.nb_lin + tk.nb_conv + tk.nb_convb + tk.nb_localw + tk.nb_gcondw + 1;
+  hipLaunchKernelGGL(encoder_bwd_reduce_kernel, dim3(nblocks), dim3(256), 0, st, s, tk, g_all,
+                     delta_obs, inputs, dev1hot, pooled, hidden, g_pre, g_conv, g_conv_w, g_conv_b, g_lin_w, g_lin_b,
+                     g_local_w, g_local_b, g_gcond_w, g_global_free);
+}
+
+}  // namespace vihds

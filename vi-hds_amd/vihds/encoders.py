@@ -161,6 +161,10 @@ class Encoder(nn.Module):
         self.register_buffer("kind", torch.tensor([d.kind for d in self.descs], dtype=torch.int32))
         self.register_buffer("q_rows", torch.tensor(_PackQTables.rows(len(self.local), len(self.gcond), len(self.glob),
                                                                       len(self.const)), dtype=torch.int32))
+        # "encoder_kernel" (default on): the fused HIP encoder on the GPU; off = the nn.Module path below (the only
+        # one on the CPU, where this class is used for construction / host-side checks)
+        self.use_kernel = bool(pd.get("encoder_kernel", True)) if hasattr(pd, "get") else True
+        self._shapes = {}
         self.to(self.device)
         self.set_up_p()
 
@@ -177,12 +181,41 @@ class Encoder(nn.Module):
                 p.add_distribution(d.name, CLASS_OF_KIND[d.kind](**kw))
         self.p = p
 
+    def _kernel_shape(self, B, data):
+        """struct vihds_encoder_shape for this encoder and batch size (cached)."""
+        from vihds import hip
+
+        if B not in self._shapes:
+            c = self.conditional
+            s = hip.EncoderShape()
+            s.B, s.C_in, s.L = B, c.conv.in_channels, self.n_times - 1
+            s.F, s.K, s.pool, s.H = c.conv.out_channels, c.conv.kernel_size[0], c.pool.kernel_size[0], c.n_outputs
+            s.n_tr, s.D = data.inputs.shape[1], data.dev_1hot.shape[1]
+            s.nl, s.l_tr, s.l_dv = len(self.local), int(self.l_tr), int(self.l_dv)
+            s.ng, s.g_tr, s.g_dv = len(self.gcond), int(self.g_tr), int(self.g_dv)
+            s.ngl, s.nc = len(self.glob), len(self.const)
+            self._shapes[B] = s
+        return self._shapes[B]
+
     def evaluate_q(self, data):
         B = data.observations.shape[0]
         obs = data.observations
         delta_obs = data.get("delta_obs", None) if hasattr(data, "get") else None  # staged with the batch (graph mode)
         if delta_obs is None:
             delta_obs = obs[:, :, 1: self.n_times] - obs[:, :, : self.n_times - 1]
+        if self.use_kernel and delta_obs.is_cuda:
+            # one forward / two backward launches instead of the 8 + 15 framework launches below
+            from vihds import ops
+
+            lh, gh = self.local_heads, self.gcond_heads
+            q_all = ops.EncoderQTables.apply(
+                self._kernel_shape(B, data), delta_obs, data.inputs, data.dev_1hot, self.conditional.conv.weight,
+                self.conditional.conv.bias, self.conditional.lin.weight, self.conditional.lin.bias,
+                None if lh is None else lh.weight, None if lh is None else lh.bias,
+                None if gh is None else gh.weight, self.global_free, self.const_values)
+            q = ChainedDistribution(name="q")
+            q.attach_packed(self.kind, q_all, self.names, lambda chain: self._build_members(chain, q_all), self.q_rows)
+            return q
         encoded = self.conditional(delta_obs)
         local_t = gcond_t = None
         if self.local:

@@ -68,6 +68,13 @@ class ThetaOpts(ctypes.Structure):
                 ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int)]
 
 
+class EncoderShape(ctypes.Structure):
+    """struct vihds_encoder_shape (include/vihds_hip.h)"""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("B", "C_in", "L", "F", "K", "pool", "H", "n_tr", "D", "nl", "l_tr", "l_dv",
+                                            "ng", "g_tr", "g_dv", "ngl", "nc")]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -97,6 +104,8 @@ _PROTOTYPES = {
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 9),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
     "vihds_device_condition": (_I, [_I] * 6 + [ctypes.c_float, ctypes.c_float] + [_P] * 7),
+    "vihds_encoder_fwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 16),
+    "vihds_encoder_bwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 19),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 4 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

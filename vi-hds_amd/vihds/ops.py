@@ -244,6 +244,58 @@ class ThetaSampleLogProb(torch.autograd.Function):
         return g_mu, g_prec, None, None, None, None, None, None, None
 
 
+class EncoderQTables(torch.autograd.Function):
+    """Encoder.evaluate_q (reference encoders.py:383-404) in one forward and two backward launches
+    (csrc/vihds_encoder.hip): returns the level-blocked [2P,B] table of means and log-precisions."""
+
+    @staticmethod
+    def forward(ctx, shape, delta_obs, inputs, dev_1hot, conv_w, conv_b, lin_w, lin_b, local_w, local_b, gcond_w,
+                global_free, const_values):
+        _require_cuda(delta_obs, conv_w, conv_b, lin_w, lin_b)
+        delta_obs, inputs, dev_1hot = _c(delta_obs), _c(inputs), _c(dev_1hot)
+        s = shape
+        B, dev = s.B, delta_obs.device
+        n_pool = s.F * (s.L - s.K + 1 - s.pool + 1)
+        q_all = torch.empty((2 * (s.nl + s.ng + s.ngl + s.nc), B), device=dev, dtype=torch.float32)
+        pooled = torch.empty((B, n_pool), device=dev, dtype=torch.float32)
+        hidden = torch.empty((B, s.H), device=dev, dtype=torch.float32)
+        rc = hip.lib().vihds_encoder_fwd(ctypes.byref(s), hip.ptr(delta_obs), hip.ptr(inputs), hip.ptr(dev_1hot),
+                                         hip.ptr(conv_w), hip.ptr(conv_b), hip.ptr(lin_w), hip.ptr(lin_b),
+                                         hip.ptr(local_w), hip.ptr(local_b), hip.ptr(gcond_w), hip.ptr(global_free),
+                                         hip.ptr(const_values), hip.ptr(q_all), hip.ptr(pooled), hip.ptr(hidden),
+                                         hip.current_stream())
+        hip.check(rc, "vihds_encoder_fwd")
+        ctx.shape = s
+        ctx.save_for_backward(delta_obs, inputs, dev_1hot, conv_w, lin_w, local_w, local_b, gcond_w, global_free,
+                              pooled, hidden)
+        ctx.hidden = hidden
+        return q_all
+
+    @staticmethod
+    def backward(ctx, g_all):
+        s = ctx.shape
+        delta_obs, inputs, dev_1hot, conv_w, lin_w, local_w, local_b, gcond_w, global_free, pooled, hidden = \
+            ctx.saved_tensors
+        g_all = _c(g_all)
+        dev = g_all.device
+        new = lambda t: None if t is None else torch.empty_like(t)  # noqa: E731
+        g_conv_w, g_lin_w, g_local_w, g_local_b, g_gcond_w, g_glob = (new(conv_w), new(lin_w), new(local_w),
+                                                                       new(local_b), new(gcond_w), new(global_free))
+        g_conv_b = torch.empty(s.F, device=dev)
+        g_lin_b = torch.empty(s.H, device=dev)
+        g_pre = torch.empty((s.B, s.H), device=dev)
+        g_conv = torch.empty((s.B, s.F, s.L - s.K + 1), device=dev)
+        rc = hip.lib().vihds_encoder_bwd(ctypes.byref(s), hip.ptr(g_all), hip.ptr(delta_obs), hip.ptr(inputs),
+                                         hip.ptr(dev_1hot), hip.ptr(lin_w), hip.ptr(local_w), hip.ptr(pooled),
+                                         hip.ptr(hidden), hip.ptr(g_pre), hip.ptr(g_conv), hip.ptr(g_conv_w),
+                                         hip.ptr(g_conv_b), hip.ptr(g_lin_w), hip.ptr(g_lin_b), hip.ptr(g_local_w),
+                                         hip.ptr(g_local_b), hip.ptr(g_gcond_w), hip.ptr(g_glob),
+                                         hip.current_stream())
+        hip.check(rc, "vihds_encoder_bwd")
+        return (None, None, None, None, g_conv_w, g_conv_b, g_lin_w, g_lin_b, g_local_w, g_local_b, g_gcond_w, g_glob,
+                None)
+
+
 class KernelNormal(object):
     """Stand-in for the u [B,S,P] tensor when the theta kernel draws the standard normals itself
     (u_rng: kernel).  `state` is the 4-word device RNG state {seed lo, seed hi, step, ticket} of
