@@ -182,6 +182,116 @@ __global__ void theta_fwd_kernel(int P, int B, int S, const int* __restrict__ ki
   }
 }
 
+// The same forward with everything that depends only on (data row, parameter) computed once per block and kept in
+// LDS: kind, mu, sigma = 1/sqrt(prec), prec, the two log-density constants -log(2 pi) + 0.5 log(prec + 1e-12), the clip
+// bounds and the prior.  A lane's per-parameter work is then u -> z -> exp -> clip -> log -> two FMAs, with no global
+// loads besides u; before, each of a lane's ~9-12 parameters cost a round of dependent table loads plus a log, a
+// sqrt and an exp of the precision.  256 threads = 64 trajectories per block, spanning nb <= 63/S + 2 data rows.
+constexpr int THETA_LDS_FIELDS = 10;
+__global__ void __launch_bounds__(256)
+theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ kind, const float* __restrict__ q_mu,
+                     const float* __restrict__ q_prec, const int* __restrict__ q_rows, int prec_is_log,
+                     const float* __restrict__ p_mu, const float* __restrict__ p_prec,
+                     const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, float* __restrict__ u,
+                     unsigned int* rng, int S_total, int s_off, float* __restrict__ theta, float* __restrict__ log_q,
+                     float* __restrict__ log_p) {
+  extern __shared__ float tab[];  // [field][nb_max * P]
+  const int n = B * S;
+  const int first = blockIdx.x * 64, last = min(first + 64, n) - 1;
+  const int b0 = first / S, nb = last / S - b0 + 1;
+  const int stride = nb_max * P;
+  float* t_kind = tab;                 // (as float: 0, 1, 2)
+  float* t_mu = tab + stride;
+  float* t_sigma = tab + 2 * stride;
+  float* t_prec = tab + 3 * stride;
+  float* t_cq = tab + 4 * stride;      // -log(2 pi) + 0.5 log(prec + 1e-12)
+  float* t_lo = tab + 5 * stride;
+  float* t_hi = tab + 6 * stride;
+  float* t_pmu = tab + 7 * stride;
+  float* t_cp = tab + 8 * stride;      // prior: the same constant
+  float* t_pprec = tab + 9 * stride;
+  for (int e = threadIdx.x; e < nb * P; e += 256) {
+    const int bb = e / P, p = e - bb * P, b = b0 + bb;
+    const int kd = kind[p];
+    const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
+    const float pr = q_prec[rp * B + b];
+    const float prec = (kd == KIND_CONSTANT) ? 1.f : (prec_is_log ? expf(pr) : pr);
+    t_kind[e] = (float)kd;
+    t_mu[e] = q_mu[rm * B + b];
+    t_sigma[e] = 1.f / sqrtf(prec);
+    t_prec[e] = prec;
+    t_cq[e] = -LOG2PI_F + 0.5f * logf(prec + 1e-12f);
+    t_lo[e] = clip_lo[p];
+    t_hi[e] = clip_hi[p];
+    t_pmu[e] = p_mu[p];
+    t_cp[e] = -LOG2PI_F + 0.5f * logf(p_prec[p] + 1e-12f);
+    t_pprec[e] = p_prec[p];
+  }
+  __syncthreads();
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i0 = t >> 2, q = t & 3;
+  const bool live = i0 < n;
+  const int i = live ? i0 : n - 1;
+  const int b = i / S;
+  const int row = (b - b0) * P;
+  unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
+  if (rng) {
+    k0 = rng[0]; k1 = rng[1]; step = rng[2];
+    gidx = (unsigned int)(b * S_total + s_off + (i - b * S));
+  }
+  float lq = 0.f, lp = 0.f;
+  for (int kb = q; 4 * kb < P; kb += 4) {
+    float z4[4];
+    if (rng) philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = 4 * kb + jj;
+      if (p >= P) break;
+      float uu;
+      if (rng) {
+        uu = z4[jj];
+        if (live) u[(size_t)i * P + p] = uu;
+      } else {
+        uu = u[(size_t)i * P + p];
+      }
+      const int e = row + p;
+      const float kdf = t_kind[e], mu = t_mu[e];
+      float x;
+      if (kdf == (float)KIND_CONSTANT) {
+        x = 0.f * uu + mu;
+      } else {
+        const bool ln = kdf == (float)KIND_LOGNORMAL;
+        const float zz = mu + t_sigma[e] * uu;
+        x = ln ? expf(zz) : zz;
+        const float lo = t_lo[e], hi = t_hi[e];
+        x = x < lo ? lo : (x > hi ? hi : x);
+        const float v = ln ? logf(x + 1e-12f) : x;
+        const float jac = ln ? v : 0.f;
+        const float dq = mu - v, dp = t_pmu[e] - v;
+        lq += t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
+        lp += t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
+      }
+      if (live) theta[(size_t)p * n + i] = x;
+    }
+  }
+  lq = quad_sum(lq);
+  lp = quad_sum(lp);
+  if (live && q == 0) {
+    if (log_q) log_q[i] = lq;
+    if (log_p) log_p[i] = lp;
+  }
+  if (rng) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const unsigned int ticket = atomicAdd(&rng[3], 1u);
+      if (ticket == gridDim.x - 1) {
+        rng[2] = step + 1u;
+        rng[3] = 0u;
+      }
+    }
+  }
+}
+
 // one block per (data row b, chunk of THETA_BWD_PCHUNK parameters); for each parameter the S per-sample
 // contributions are reduced in a fixed order (wave shuffle tree, then waves in order): deterministic gradients.
 // prec_is_log: the q precision table holds log-precisions and g_q_prec receives d/d log_prec = prec * d/d prec.
@@ -451,6 +561,14 @@ void launch_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, c
                       const float* p_prec, const float* lo, const float* hi, float* u, float* theta, float* log_q,
                       float* log_p, const vihds_theta_opts& o, hipStream_t st) {
   const int n = B * S, blk = 64;
+  const int nb_max = min(B, 63 / S + 2);
+  const size_t lds = (size_t)THETA_LDS_FIELDS * nb_max * P * sizeof(float);
+  if (lds <= 48 * 1024) {  // per-(row, parameter) constants staged in LDS
+    hipLaunchKernelGGL(theta_fwd_lds_kernel, dim3((n + 63) / 64), dim3(256), lds, st, P, B, S, nb_max, kind, q_mu,
+                       q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, o.rng, o.rng ? o.S_total : S,
+                       o.rng ? o.s_offset : 0, theta, log_q, log_p);
+    return;
+  }
   hipLaunchKernelGGL(theta_fwd_kernel, dim3((4 * n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec,
                      o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, o.rng, o.rng ? o.S_total : S,
                      o.rng ? o.s_offset : 0, theta, log_q, log_p);

@@ -128,20 +128,24 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   }
   __syncthreads();
   // heads -> rows of the level-blocked table [local mu; local lp; gcond mu; gcond lp; global mu; global lp; const; 0]
-  const int n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
-  for (int r = tid; r < n_rows; r += ENC_T) {
-    float v;
+  // rows with a dot product: one wave per row (coalesced weight row, lanes over the inputs); the rest are copies
+  const int n_dot = 2 * (s.nl + s.ng), n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
+  for (int r = wid; r < n_dot; r += NW) {
+    float acc = 0.f;
     if (r < 2 * s.nl) {
       const float* wr = local_w + (size_t)r * d.NX;
-      v = local_b ? local_b[r] : 0.f;
-      for (int i = 0; i < d.NX; ++i) v += wr[i] * local_input(s, hid, inputs, dev1hot, b, i);
-    } else if (r < 2 * (s.nl + s.ng)) {
-      const int rr = r - 2 * s.nl;
-      const float* wr = gcond_w + (size_t)rr * d.NG;
-      v = 0.f;
-      for (int i = 0; i < d.NG; ++i) v += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
-    } else if (r < 2 * (s.nl + s.ng + s.ngl)) {
-      v = global_free[r - 2 * (s.nl + s.ng)];
+      for (int i = lane; i < d.NX; i += 64) acc += wr[i] * local_input(s, hid, inputs, dev1hot, b, i);
+    } else {
+      const float* wr = gcond_w + (size_t)(r - 2 * s.nl) * d.NG;
+      for (int i = lane; i < d.NG; i += 64) acc += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
+    }
+    acc = wave_sum_e(acc);
+    if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
+  }
+  for (int r = n_dot + tid; r < n_rows; r += ENC_T) {
+    float v;
+    if (r < 2 * (s.nl + s.ng + s.ngl)) {
+      v = global_free[r - n_dot];
     } else {
       const int rr = r - 2 * (s.nl + s.ng + s.ngl);
       v = rr < s.nc ? const_values[rr] : 0.f;
@@ -223,14 +227,10 @@ encoder_bwd_reduce_kernel(vihds_encoder_shape s, EncReduceTasks tk, const float*
     const int e = blk * 256 + tid;
     if (e >= s.H * d.NPOOL) return;
     const int j = e / d.NPOOL, k = e - j * d.NPOOL;
-    float a0 = 0.f, a1 = 0.f;
-    int b = 0;
-    for (; b + 1 < B; b += 2) {
-      a0 += g_pre[(size_t)b * s.H + j] * pooled[(size_t)b * d.NPOOL + k];
-      a1 += g_pre[(size_t)(b + 1) * s.H + j] * pooled[(size_t)(b + 1) * d.NPOOL + k];
-    }
-    if (b < B) a0 += g_pre[(size_t)b * s.H + j] * pooled[(size_t)b * d.NPOOL + k];
-    g_lin_w[e] = a0 + a1;
+    float acc = 0.f;  // (one accumulator, fixed order; unrolled so the 2 x 6 loads of an iteration are in flight together)
+#pragma unroll 6
+    for (int b = 0; b < B; ++b) acc += g_pre[(size_t)b * s.H + j] * pooled[(size_t)b * d.NPOOL + k];
+    g_lin_w[e] = acc;
     return;
   }
   blk -= tk.nb_lin;
@@ -240,6 +240,7 @@ encoder_bwd_reduce_kernel(vihds_encoder_shape s, EncReduceTasks tk, const float*
     const int o = e / (s.C_in * s.K), c = (e / s.K) % s.C_in, k = e % s.K;
     float acc = 0.f;
     const int n = B * d.Lc;
+#pragma unroll 4
     for (int q = lane; q < n; q += 64) {
       const int b = q / d.Lc, t = q - b * d.Lc;
       acc += g_conv[((size_t)b * s.F + o) * d.Lc + t] * delta_obs[((size_t)b * s.C_in + c) * s.L + t + k];
