@@ -171,9 +171,14 @@ int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const flo
 /* Single-process convenience: the two calls above plus the finish, i.e. all of vihds/training.py:135-149:
  * lse[b] = row_max + log(row_sumexp), loss[0] = -mean_b(lse[b] - log(n_iwae_total)).
  * Backward: g_logw[b][s] = -(g_loss[0]/B) * exp(log_w - lse[b]); g_neg_logw (optional) receives its negation, the
- * gradient w.r.t. log_q. */
+ * gradient w.r.t. log_q.
+ * unit_g_logw / unit_g_neg_logw (optional, only where vihds_iwae_loss_unit_grad(B,S) == 1): the forward also writes
+ * the backward's outputs for g_loss = 1 -- what loss.backward() asks for in the training step -- so that step needs no
+ * backward launch for the loss. */
 int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
-                        float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, void* stream);
+                        float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, float* unit_g_logw,
+                        float* unit_g_neg_logw, void* stream);
+int vihds_iwae_loss_unit_grad(int B, int S);
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                         float* g_neg_logw, void* stream);
 

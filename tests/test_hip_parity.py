@@ -793,3 +793,31 @@ def test_fused_encoder_matches_module_path(name):
     assert set(ga) == set(gb) and len(ga) >= 5
     for k in gb:
         assert rel_err(ga[k], gb[k]) < 2e-5, k
+
+
+def test_iwae_loss_unit_gradient_fast_path_equals_backward_kernel():
+    """For small batches the IWAE forward kernel also writes d loss / d log_w for an upstream gradient of 1; a backward
+    seeded with ops.unit_gradient() returns those buffers, any other seed runs iwae_loss_bwd_kernel.  Same numbers."""
+    from vihds import ops
+
+    g = torch.Generator().manual_seed(4)
+    B, S = 36, 200
+    grads = []
+    for seed_kind in ("unit", "other", "scaled"):
+        logp = (torch.randn(4, B, S, generator=torch.Generator().manual_seed(1)) * 20).to(DEV).requires_grad_(True)
+        lp = torch.randn(B, S, generator=torch.Generator().manual_seed(2)).to(DEV).requires_grad_(True)
+        lq = torch.randn(B, S, generator=torch.Generator().manual_seed(3)).to(DEV).requires_grad_(True)
+        loss, log_w, lse = ops.iwae_loss(logp, lp, lq)
+        if seed_kind == "unit":
+            loss.backward(ops.unit_gradient(DEV))
+        elif seed_kind == "other":
+            loss.backward(torch.ones((), device=DEV))
+        else:
+            loss.backward(torch.full((), 2.0, device=DEV))
+        grads.append((logp.grad.clone(), lp.grad.clone(), lq.grad.clone()))
+    for a, b in zip(grads[0], grads[1]):
+        assert torch.equal(a, b)
+    for a, c in zip(grads[0], grads[2]):
+        assert rel_err(c, 2.0 * a) < 1e-6
+    assert rel_err(grads[0][0][0].sum(1), torch.full((B,), -1.0 / B)) < 1e-4
+    del g

@@ -408,7 +408,10 @@ iwae_finish_kernel(int B, float log_n, const float* __restrict__ row_max, const 
 __global__ void __launch_bounds__(1024)
 iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp, const float* __restrict__ log_p,
                        const float* __restrict__ log_q, float* __restrict__ log_w, float* __restrict__ row_max,
-                       float* __restrict__ row_sumexp, float* __restrict__ lse, float* __restrict__ loss) {
+                       float* __restrict__ row_sumexp, float* __restrict__ lse, float* __restrict__ loss,
+                       float* __restrict__ unit_g_logw, float* __restrict__ unit_g_neg_logw) {
+  // unit_g_logw / unit_g_neg_logw (optional): d loss / d log_w for an upstream gradient of exactly 1 -- what the
+  // training step's backward asks for -- so that step needs no launch of iwae_loss_bwd_kernel.
   // B <= 64 rows (wave w owns rows w, w+16, w+32, w+48), S <= 256 samples (4 per lane): everything a wave needs
   // is loaded up front and kept in registers, so the only serial part is two wave reductions
   __shared__ float sm[16];
@@ -441,12 +444,23 @@ iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp
 #pragma unroll
     for (int c = 0; c < 4; ++c) se += (lane + 64 * c < S) ? expf(lw[rr][c] - m) : 0.f;
     se = wave_sum(se);
+    const float l = m + logf(__shfl(se, 0, 64));
     if (lane == 0) {
-      const float l = m + logf(se);
       row_max[b] = m;
       row_sumexp[b] = se;
       lse[b] = l;
       acc += l - log_n;
+    }
+    if (unit_g_logw) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int sidx = lane + 64 * c;
+        if (sidx < S) {
+          const float g = -(1.f / (float)B) * expf(lw[rr][c] - l);  // same expression as iwae_loss_bwd_kernel, g_loss = 1
+          unit_g_logw[b * S + sidx] = g;
+          if (unit_g_neg_logw) unit_g_neg_logw[b * S + sidx] = -g;
+        }
+      }
     }
   }
   if (lane == 0) sm[wid] = acc;
@@ -596,9 +610,10 @@ void launch_iwae_finish(int B, float log_n, const float* row_max, const float* r
   hipLaunchKernelGGL(iwae_finish_kernel, dim3(1), dim3(256), 0, st, B, log_n, row_max, row_sumexp, lse, loss);
 }
 void launch_iwae_loss_small(int B, int S, float log_n, const float* logp, const float* log_p, const float* log_q,
-                            float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, hipStream_t st) {
+                            float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss,
+                            float* unit_g_logw, float* unit_g_neg_logw, hipStream_t st) {
   hipLaunchKernelGGL(iwae_loss_small_kernel, dim3(1), dim3(1024), 0, st, B, S, log_n, logp, log_p, log_q, log_w, row_max,
-                     row_sumexp, lse, loss);
+                     row_sumexp, lse, loss, unit_g_logw, unit_g_neg_logw);
 }
 void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                           float* g_neg_logw, hipStream_t st) {

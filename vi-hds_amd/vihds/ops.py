@@ -438,9 +438,23 @@ def iwae_lse(logp, log_p, log_q, group=None):
     return _LseFromLogw.apply(log_w, lse), log_w
 
 
+_UNIT = {}
+
+
+def unit_gradient(device):
+    """The scalar 1.0 to seed `loss.backward(unit_gradient(dev))` with: no ones_like fill launch per step, and the
+    IWAE loss recognises it (by address) and hands out the gradient its forward kernel already wrote."""
+    key = str(device)
+    if key not in _UNIT:
+        _UNIT[key] = torch.ones((), device=device, dtype=torch.float32)
+    return _UNIT[key]
+
+
 class IwaeLoss(torch.autograd.Function):
-    """Single-process -ELBO in two launches (rows kernel + finish) and one backward launch; the gradient w.r.t.
-    logp is returned as a stride-0 view over the four species (consumed without a copy by the ODE adjoint)."""
+    """Single-process -ELBO: one launch for small batches (rows kernel + finish otherwise); the gradient w.r.t.
+    logp is returned as a stride-0 view over the four species (consumed without a copy by the ODE adjoint).  For
+    small batches the forward kernel also writes the gradient for a unit upstream gradient, so a backward seeded with
+    unit_gradient() launches nothing here."""
 
     @staticmethod
     def forward(ctx, logp, log_p, log_q, n_total):
@@ -451,12 +465,16 @@ class IwaeLoss(torch.autograd.Function):
         log_w = torch.empty((B, S), device=dev, dtype=torch.float32)
         rows = torch.empty((3, B), device=dev, dtype=torch.float32)  # row_max, row_sumexp, lse
         loss = torch.empty((), device=dev, dtype=torch.float32)
+        ug = ugn = None
+        if any(ctx.needs_input_grad) and hip.lib().vihds_iwae_loss_unit_grad(B, S):
+            ug = torch.empty((B, S), device=dev, dtype=torch.float32)
+            ugn = torch.empty((B, S), device=dev, dtype=torch.float32) if log_q is not None else None
         rc = hip.lib().vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q),
                                            hip.ptr(log_w), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
-                                           hip.ptr(loss), hip.current_stream())
+                                           hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.current_stream())
         hip.check(rc, "vihds_iwae_loss_fwd")
         lse = rows[2]
-        ctx.save_for_backward(log_w, lse)
+        ctx.save_for_backward(log_w, lse, ug, ugn)
         ctx.has = (log_p is not None, log_q is not None)
         ctx.mark_non_differentiable(log_w, lse)
         ctx.set_materialize_grads(False)
@@ -466,8 +484,11 @@ class IwaeLoss(torch.autograd.Function):
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None:
             return None, None, None, None
-        log_w, lse = ctx.saved_tensors
+        log_w, lse, ug, ugn = ctx.saved_tensors
         B, S = log_w.shape
+        unit = _UNIT.get(str(log_w.device))
+        if ug is not None and unit is not None and g_loss.data_ptr() == unit.data_ptr():
+            return ug.unsqueeze(0).expand(4, -1, -1), ug if ctx.has[0] else None, ugn, None
         g_logw = torch.empty_like(log_w)
         g_neg = torch.empty_like(log_w) if ctx.has[1] else None
         rc = hip.lib().vihds_iwae_loss_bwd(B, S, hip.ptr(log_w), hip.ptr(lse), hip.ptr(_c(g_loss)), hip.ptr(g_logw),

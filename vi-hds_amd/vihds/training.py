@@ -205,9 +205,10 @@ class Training:
         Returns the loss tensor (-ELBO) without synchronising."""
         batch_results, theta, q, p = self.model(batch, self.args.train_samples)
         elbo = self.cost(batch, batch_results, theta, q, p).elbo
-        if self._one is None or self._one.device != elbo.device:
-            self._one = torch.ones((), device=elbo.device)
-        elbo.backward(self._one.expand_as(elbo))  # (no ones_like fill launch per step)
+        if elbo.is_cuda:
+            elbo.backward(ops.unit_gradient(elbo.device))  # no ones_like fill, and no launch for the loss's backward
+        else:
+            elbo.backward()
         if self.shard is not None:
             self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.shard.group,
                                                              self._grad_buffer)
