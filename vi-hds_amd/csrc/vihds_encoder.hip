@@ -75,6 +75,38 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   float* cv = cw + s.F * s.C_in * s.K;
   float* pl = cv + s.F * d.Lc;
   float* hid = pl + d.NPOOL;
+  const int lane = tid & 63, wid = tid >> 6;
+  constexpr int NW = ENC_T / 64;
+  // Every global read the later phases need is issued NOW, so that the kernel pays one memory round trip instead of
+  // one per phase: this wave's Linear rows (4 output units x up to 12 x 64 inputs = 48 registers per lane) and its
+  // head rows.  Shapes beyond those bounds take the plain loops further down.
+  constexpr int LIN_U = 4, LIN_C = 12, HEAD_R = 4;
+  const bool fast_lin = s.H <= LIN_U * NW && d.NPOOL <= LIN_C * 64;
+  const int n_dot = 2 * (s.nl + s.ng);
+  const bool fast_heads = d.NX <= 64 && d.NG <= 64 && n_dot <= HEAD_R * NW;
+  float lw[LIN_U][LIN_C], hw[HEAD_R], lb[LIN_U];
+  if (fast_lin) {
+#pragma unroll
+    for (int u = 0; u < LIN_U; ++u) {
+      const int j = wid + u * NW;
+      lb[u] = (j < s.H) ? lin_b[j] : 0.f;
+#pragma unroll
+      for (int c = 0; c < LIN_C; ++c) {
+        const int k = lane + 64 * c;
+        lw[u][c] = (j < s.H && k < d.NPOOL) ? lin_w[(size_t)j * d.NPOOL + k] : 0.f;
+      }
+    }
+  }
+  if (fast_heads) {
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) {
+      const int r = wid + rr * NW;
+      float w = 0.f;
+      if (r < 2 * s.nl) { if (lane < d.NX) w = local_w[(size_t)r * d.NX + lane]; }
+      else if (r < n_dot) { if (lane < d.NG) w = gcond_w[(size_t)(r - 2 * s.nl) * d.NG + lane]; }
+      hw[rr] = w;
+    }
+  }
   for (int q = tid; q < s.C_in * s.L; q += ENC_T) x[q] = delta_obs[(size_t)b * s.C_in * s.L + q];
   for (int q = tid; q < s.F * s.C_in * s.K; q += ENC_T) cw[q] = conv_w[q];
   __syncthreads();
@@ -101,46 +133,77 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
     pooled_out[(size_t)b * d.NPOOL + q] = v;
   }
   __syncthreads();
-  // Linear + tanh: a wave owns output units j = wid, wid+16, ... and works on four of them at a time so that 4 x
-  // ceil(NPOOL/64) independent coalesced row loads are in flight; lanes stride over the inputs
-  const int lane = tid & 63, wid = tid >> 6;
-  constexpr int NW = ENC_T / 64;
-  for (int j0 = wid; j0 < s.H; j0 += 4 * NW) {
-    float acc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int k = lane; k < d.NPOOL; k += 64) {
-      const float pv = pl[k];
+  // Linear + tanh: a wave owns output units j = wid, wid+16, ...; lanes stride over the inputs
+  if (fast_lin) {
+    float acc[LIN_U] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < LIN_C; ++c) {
+      const int k = lane + 64 * c;
+      const float pv = k < d.NPOOL ? pl[k] : 0.f;
+#pragma unroll
+      for (int u = 0; u < LIN_U; ++u) acc[u] += lw[u][c] * pv;
+    }
+#pragma unroll
+    for (int u = 0; u < LIN_U; ++u) {
+      const int j = wid + u * NW;
+      const float t = wave_sum_e(acc[u]);
+      if (lane == 0 && j < s.H) {
+        const float h = tanhf(t + lb[u]);
+        hid[j] = h;
+        hidden_out[(size_t)b * s.H + j] = h;
+      }
+    }
+  } else {
+    for (int j0 = wid; j0 < s.H; j0 += 4 * NW) {
+      float acc[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int k = lane; k < d.NPOOL; k += 64) {
+        const float pv = pl[k];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int j = j0 + u * NW;
+          if (j < s.H) acc[u] += lin_w[(size_t)j * d.NPOOL + k] * pv;
+        }
+      }
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * NW;
-        if (j < s.H) acc[u] += lin_w[(size_t)j * d.NPOOL + k] * pv;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int j = j0 + u * NW;
-      const float t = wave_sum_e(acc[u]);
-      if (lane == 0 && j < s.H) {
-        const float h = tanhf(t + lin_b[j]);
-        hid[j] = h;
-        hidden_out[(size_t)b * s.H + j] = h;
+        const float t = wave_sum_e(acc[u]);
+        if (lane == 0 && j < s.H) {
+          const float h = tanhf(t + lin_b[j]);
+          hid[j] = h;
+          hidden_out[(size_t)b * s.H + j] = h;
+        }
       }
     }
   }
   __syncthreads();
   // heads -> rows of the level-blocked table [local mu; local lp; gcond mu; gcond lp; global mu; global lp; const; 0]
-  // rows with a dot product: one wave per row (coalesced weight row, lanes over the inputs); the rest are copies
-  const int n_dot = 2 * (s.nl + s.ng), n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
-  for (int r = wid; r < n_dot; r += NW) {
-    float acc = 0.f;
-    if (r < 2 * s.nl) {
-      const float* wr = local_w + (size_t)r * d.NX;
-      for (int i = lane; i < d.NX; i += 64) acc += wr[i] * local_input(s, hid, inputs, dev1hot, b, i);
-    } else {
-      const float* wr = gcond_w + (size_t)(r - 2 * s.nl) * d.NG;
-      for (int i = lane; i < d.NG; i += 64) acc += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
+  // rows with a dot product: one wave per row (lanes over the inputs); the rest are copies
+  const int n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
+  if (fast_heads) {
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) {
+      const int r = wid + rr * NW;
+      if (r >= n_dot) break;  // (uniform per wave)
+      float xin = 0.f;
+      if (r < 2 * s.nl) { if (lane < d.NX) xin = local_input(s, hid, inputs, dev1hot, b, lane); }
+      else if (lane < d.NG) xin = gcond_input(s, inputs, dev1hot, b, lane);
+      const float acc = wave_sum_e(hw[rr] * xin);
+      if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
     }
-    acc = wave_sum_e(acc);
-    if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
+  } else {
+    for (int r = wid; r < n_dot; r += NW) {
+      float acc = 0.f;
+      if (r < 2 * s.nl) {
+        const float* wr = local_w + (size_t)r * d.NX;
+        for (int i = lane; i < d.NX; i += 64) acc += wr[i] * local_input(s, hid, inputs, dev1hot, b, i);
+      } else {
+        const float* wr = gcond_w + (size_t)(r - 2 * s.nl) * d.NG;
+        for (int i = lane; i < d.NG; i += 64) acc += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
+      }
+      acc = wave_sum_e(acc);
+      if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
+    }
   }
   for (int r = n_dot + tid; r < n_rows; r += ENC_T) {
     float v;
@@ -166,6 +229,14 @@ encoder_bwd_row_kernel(vihds_encoder_shape s, const float* __restrict__ g_all, c
   const int b = blockIdx.x, tid = threadIdx.x, B = s.B;
   float* gpre = lds;
   float* gpl = gpre + s.H;
+  // this thread's column of lin_w is requested first: it arrives while g_pre is being formed
+  constexpr int HMAX = 64;
+  const bool fast = s.H <= HMAX && d.NPOOL <= ENC_T;
+  float wcol[HMAX];
+  if (fast && tid < d.NPOOL) {
+#pragma unroll
+    for (int j = 0; j < HMAX; ++j) wcol[j] = j < s.H ? lin_w[(size_t)j * d.NPOOL + tid] : 0.f;
+  }
   // hidden adjoint through the local heads, then tanh'
   for (int j = tid; j < s.H; j += ENC_T) {
     float acc = 0.f;
@@ -178,15 +249,27 @@ encoder_bwd_row_kernel(vihds_encoder_shape s, const float* __restrict__ g_all, c
   __syncthreads();
   // pooled adjoint: g_pooled[k] = sum_j lin_w[j][k] g_pre[j]   (threads stride over k: coalesced rows; the H loads
   // of a thread are independent)
-  for (int k = tid; k < d.NPOOL; k += ENC_T) {
-    float a0 = 0.f, a1 = 0.f;
-    int j = 0;
-    for (; j + 1 < s.H; j += 2) {
-      a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
-      a1 += lin_w[(size_t)(j + 1) * d.NPOOL + k] * gpre[j + 1];
+  if (fast) {
+    if (tid < d.NPOOL) {
+      float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+      for (int j = 0; j < HMAX; j += 2) {
+        a0 += wcol[j] * (j < s.H ? gpre[j] : 0.f);
+        a1 += wcol[j + 1] * (j + 1 < s.H ? gpre[j + 1] : 0.f);
+      }
+      gpl[tid] = a0 + a1;
     }
-    if (j < s.H) a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
-    gpl[k] = a0 + a1;
+  } else {
+    for (int k = tid; k < d.NPOOL; k += ENC_T) {
+      float a0 = 0.f, a1 = 0.f;
+      int j = 0;
+      for (; j + 1 < s.H; j += 2) {
+        a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
+        a1 += lin_w[(size_t)(j + 1) * d.NPOOL + k] * gpre[j + 1];
+      }
+      if (j < s.H) a0 += lin_w[(size_t)j * d.NPOOL + k] * gpre[j];
+      gpl[k] = a0 + a1;
+    }
   }
   __syncthreads();
   // conv-output adjoint: every pooled window that contains t contributes 1/pool
