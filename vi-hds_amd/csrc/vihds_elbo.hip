@@ -292,8 +292,9 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
   }
 }
 
-// one block per (data row b, chunk of THETA_BWD_PCHUNK parameters); for each parameter the S per-sample
-// contributions are reduced in a fixed order (wave shuffle tree, then waves in order): deterministic gradients.
+// one block per (data row b, chunk of THETA_BWD_PCHUNK parameters), ONE WAVE PER PARAMETER: the chunk's parameters run
+// side by side instead of one after the other (each used to cost a round of loads plus two block reductions with
+// barriers); the S per-sample contributions are reduced inside the wave in a fixed order: deterministic gradients.
 // prec_is_log: the q precision table holds log-precisions and g_q_prec receives d/d log_prec = prec * d/d prec.
 constexpr int THETA_BWD_PCHUNK = 4;
 template <int BLOCK>
@@ -304,55 +305,56 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
                  const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, const float* __restrict__ u,
                  const float* __restrict__ g_theta, const float* __restrict__ g_log_q,
                  const float* __restrict__ g_log_p, float* __restrict__ g_q_mu, float* __restrict__ g_q_prec) {
-  __shared__ float sm[BLOCK / 64];
+  static_assert(BLOCK == 64 * THETA_BWD_PCHUNK, "one wave per parameter of the chunk");
   const int n = B * S;
   const int b = blockIdx.x;
-  const int p_end = min(P, (int)(blockIdx.y + 1) * THETA_BWD_PCHUNK);
-  for (int p = blockIdx.y * THETA_BWD_PCHUNK; p < p_end; ++p) {
-    const int kd = kind[p];
-    const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
-    float am = 0.f, ap = 0.f;
-    if (kd == KIND_CONSTANT) {
-      // constants carry no trainable distribution parameters in the reference (encoders.py:242-253)
-      if (threadIdx.x == 0) { g_q_mu[rm * B + b] = 0.f; g_q_prec[rp * B + b] = 0.f; }
-      continue;
-    }
-    const float mu = q_mu[rm * B + b];
-    const float prec = prec_is_log ? expf(q_prec[rp * B + b]) : q_prec[rp * B + b];
-    const float sigma = 1.f / sqrtf(prec);
-    const float pm = p_mu[p], pp = p_prec[p], lo = clip_lo[p], hi = clip_hi[p];
-    for (int s = threadIdx.x; s < S; s += BLOCK) {
-      const int i = b * S + s;
-      const float uu = u[(size_t)i * P + p];
-      const float z = mu + sigma * uu;
-      const float xr = (kd == KIND_LOGNORMAL) ? expf(z) : z;
-      const float x = xr < lo ? lo : (xr > hi ? hi : xr);
-      const float pass = (xr >= lo && xr <= hi) ? 1.f : 0.f;
-      const float glq = g_log_q ? g_log_q[i] : 0.f;
-      const float glp = g_log_p ? g_log_p[i] : 0.f;
-      float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
-      float v, dv_dx;
-      if (kd == KIND_LOGNORMAL) { v = logf(x + 1e-12f); dv_dx = 1.f / (x + 1e-12f); }
-      else { v = x; dv_dx = 1.f; }
-      const float jac = (kd == KIND_LOGNORMAL) ? 1.f : 0.f;
-      // d lq/dv = prec*(mu - v) - jac ; d lp/dv = pp*(pm - v) - jac
-      const float gv = glq * (prec * (mu - v) - jac) + glp * (pp * (pm - v) - jac);
-      gx += gv * dv_dx;
-      // back through clip and (for LogNormal) exp
-      float gz = gx * pass;
-      if (kd == KIND_LOGNORMAL) gz *= xr;
-      // z = mu + u / sqrt(prec)
-      am += gz;
-      ap += gz * uu * (-0.5f) * sigma / prec;
-      // explicit dependence of log q on (mu, prec)
-      const float d = mu - v;
-      am += glq * (-prec * d);
-      ap += glq * (0.5f / (prec + 1e-12f) - 0.5f * d * d);
-    }
-    am = block_sum<BLOCK>(am, sm);
-    ap = block_sum<BLOCK>(ap, sm);
-    if (threadIdx.x == 0) { g_q_mu[rm * B + b] = am; g_q_prec[rp * B + b] = prec_is_log ? ap * prec : ap; }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int p = blockIdx.y * THETA_BWD_PCHUNK + wid;
+  if (p >= P) return;
+  const int kd = kind[p];
+  const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
+  if (kd == KIND_CONSTANT) {
+    // constants carry no trainable distribution parameters in the reference (encoders.py:242-253)
+    if (lane == 0) { g_q_mu[rm * B + b] = 0.f; g_q_prec[rp * B + b] = 0.f; }
+    return;
   }
+  const float mu = q_mu[rm * B + b];
+  const float prec = prec_is_log ? expf(q_prec[rp * B + b]) : q_prec[rp * B + b];
+  const float sigma = 1.f / sqrtf(prec);
+  const float pm = p_mu[p], pp = p_prec[p], lo = clip_lo[p], hi = clip_hi[p];
+  float am = 0.f, ap = 0.f;
+#pragma unroll 4
+  for (int s = lane; s < S; s += 64) {
+    const int i = b * S + s;
+    const float uu = u[(size_t)i * P + p];
+    const float z = mu + sigma * uu;
+    const float xr = (kd == KIND_LOGNORMAL) ? expf(z) : z;
+    const float x = xr < lo ? lo : (xr > hi ? hi : xr);
+    const float pass = (xr >= lo && xr <= hi) ? 1.f : 0.f;
+    const float glq = g_log_q ? g_log_q[i] : 0.f;
+    const float glp = g_log_p ? g_log_p[i] : 0.f;
+    float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
+    float v, dv_dx;
+    if (kd == KIND_LOGNORMAL) { v = logf(x + 1e-12f); dv_dx = 1.f / (x + 1e-12f); }
+    else { v = x; dv_dx = 1.f; }
+    const float jac = (kd == KIND_LOGNORMAL) ? 1.f : 0.f;
+    // d lq/dv = prec*(mu - v) - jac ; d lp/dv = pp*(pm - v) - jac
+    const float gv = glq * (prec * (mu - v) - jac) + glp * (pp * (pm - v) - jac);
+    gx += gv * dv_dx;
+    // back through clip and (for LogNormal) exp
+    float gz = gx * pass;
+    if (kd == KIND_LOGNORMAL) gz *= xr;
+    // z = mu + u / sqrt(prec)
+    am += gz;
+    ap += gz * uu * (-0.5f) * sigma / prec;
+    // explicit dependence of log q on (mu, prec)
+    const float d = mu - v;
+    am += glq * (-prec * d);
+    ap += glq * (0.5f / (prec + 1e-12f) - 0.5f * d * d);
+  }
+  am = wave_sum(am);
+  ap = wave_sum(ap);
+  if (lane == 0) { g_q_mu[rm * B + b] = am; g_q_prec[rp * B + b] = prec_is_log ? ap * prec : ap; }
 }
 
 // log_w = sum_j logp[j] + log_p - log_q ; per-row max and sum-exp.  One block per row.
