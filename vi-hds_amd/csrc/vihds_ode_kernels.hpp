@@ -232,11 +232,26 @@ __device__ __forceinline__ const float* stage_weights(const OdeArgs& a, float* l
 }
 
 // ---- forward -------------------------------------------------------------------------------------
-template <class M, int SOLVER>
+// LDS_IN: the time grid and the observation rows of the data rows this block spans are staged in LDS once, so the
+// time loop holds no vector-memory loads and its trajectory / x_predict stores are never waited on (see
+// vihds_dr_lanes.hpp: with a global load in the loop every s_waitcnt vmcnt(0) for it also waits for the stores).
+template <class M, int SOLVER, bool LDS_IN>
 __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   constexpr int N = M::N;
   __shared__ float wlds[M::NW > 0 ? M::NW : 1];
+  extern __shared__ float in_lds[];  // [T] times | [nb][4][T] observations
   const float* wts = stage_weights<M>(a, wlds);
+  int ob_off = 0;
+  if (LDS_IN) {
+    const int first = blockIdx.x * blockDim.x, last = min(first + (int)blockDim.x, a.n) - 1;
+    const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+    for (int q = threadIdx.x; q < a.T; q += blockDim.x) in_lds[q] = a.times[q];
+    const float* src = a.obs + (size_t)b0 * 4 * a.T;
+    for (int q = threadIdx.x; q < nb * 4 * a.T; q += blockDim.x) in_lds[a.T + q] = src[q];
+    __syncthreads();
+    const int ii = min((int)(blockIdx.x * blockDim.x + threadIdx.x), a.n - 1);
+    ob_off = a.T + (ii / a.S - b0) * 4 * a.T;
+  }
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= a.n) return;
   const int b = i / a.S;
@@ -256,17 +271,19 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
     lp[j] = 0.f;
   }
   const float* ob = a.obs + (size_t)b * 4 * a.T;
+  auto time_at = [&](int k) { return LDS_IN ? in_lds[k] : a.times[k]; };
+  auto obs_at = [&](int j, int k) { return LDS_IN ? in_lds[ob_off + j * a.T + k] : ob[j * a.T + k]; };
   const float h0 = a.times[1] - a.times[0];
   const size_t n = a.n;
 
-  // times / observations are prefetched one step ahead so their load latency is off the dependent chain
-  float tA = a.times[0], tB = a.times[1];
+  // times / observations are fetched one step ahead so their latency is off the dependent chain
+  float tA = time_at(0), tB = time_at(1);
   float obc[4], obn[4];
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) { obc[j] = a.logp ? ob[j * a.T] : 0.f; obn[j] = 0.f; }
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) { obc[j] = a.logp ? obs_at(j, 0) : 0.f; obn[j] = 0.f; }
   for (int k = 0; k < a.T; ++k) {
-    const float tC = (k + 1 < a.T) ? a.times[k + 1] : tB;
+    const float tC = (k + 1 < a.T) ? time_at(k + 1) : tB;
     if (a.logp && k + 1 < a.T) {
-      VIHDS_UNROLL for (int j = 0; j < 4; ++j) obn[j] = ob[j * a.T + k + 1];
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) obn[j] = obs_at(j, k + 1);
     }
     if (k > 0) {
       ode_step<M, SOLVER>(tA, tB, h0, y, p, wts);
@@ -395,7 +412,12 @@ inline int pick_block(int n) { return n >= (1 << 18) ? 256 : 64; }
 template <class M, int SOLVER>
 inline void launch_fwd_s(const OdeArgs& a, hipStream_t st) {
   const int blk = pick_block(a.n);
-  hipLaunchKernelGGL((ode_fwd_kernel<M, SOLVER>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
+  const int nb = min(a.B, (blk - 1) / a.S + 2);
+  const size_t lds = ((size_t)a.T + (size_t)nb * 4 * a.T) * sizeof(float);
+  if (lds <= 32 * 1024)
+    hipLaunchKernelGGL((ode_fwd_kernel<M, SOLVER, true>), dim3((a.n + blk - 1) / blk), dim3(blk), lds, st, a);
+  else
+    hipLaunchKernelGGL((ode_fwd_kernel<M, SOLVER, false>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
 }
 template <class M, int SOLVER>
 inline void launch_bwd_s(const OdeArgs& a, hipStream_t st) {
