@@ -237,7 +237,7 @@ def main():
     nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b}
     solver_id = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}[a.solver]
     lanes = B_ROWS * N_IWAE <= 16384  # the library's automatic choice (vihds_dr_lanes.hpp)
-    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d%s>(vihds::OdeArgs)" % (k[4:], solver_id, ", true" if k == "ode_fwd" else "")) if lanes else
+    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d%s>(vihds::OdeArgs)" % (k[4:], solver_id, ", true")) if lanes else
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
 

@@ -442,15 +442,26 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
   if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
 }
 
-template <int VERSION, int SOLVER>
+template <int VERSION, int SOLVER, bool LDS_IN>
 __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   using D = DrLanes<VERSION>;
   using M = DrConstant<VERSION>;
+  extern __shared__ float lds[];
   const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int i0 = blockIdx.x * D::TPB + tl;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
+  int ob_off = 0;
+  if (LDS_IN) {  // time grid + observation rows of this block in LDS (as in the forward kernel)
+    const int first = blockIdx.x * D::TPB, last = min(first + D::TPB, a.n) - 1;
+    const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+    for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
+    const float* src = a.obs + (size_t)b0 * 4 * a.T;
+    for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
+    __syncthreads();
+    ob_off = a.T + ((b - b0) * 4 + (j & 3)) * a.T;
+  }
   DrLane L;
   float c[2], y0;
   typename D::HillTerm H;
@@ -460,23 +471,29 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   const size_t n = a.n;
   const float glp = (a.g_logp && j < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
   const float* ob = a.obs + ((size_t)b * 4 + (j & 3)) * a.T;
+  auto time_at = [&](int k) { return LDS_IN ? lds[k] : a.times[k]; };
+  auto obs_at = [&](int k) { return LDS_IN ? lds[ob_off + k] : ob[k]; };
   const float h0 = a.times[1] - a.times[0];
 
-  float ynext = a.traj_in[((size_t)(a.T - 1) * 8 + j) * n + i];
-  float ob_next = j < 4 ? ob[a.T - 1] : 0.f;
+  // The stored state is requested TWO steps ahead (a step lasts ~0.65 us; a read that misses L2 takes longer than
+  // that to come back from HBM / the infinity cache), observations, upstream gradients and times one step ahead.
+  auto traj_at = [&](int k) { return a.traj_in[((size_t)max(k, 0) * 8 + j) * n + i]; };
+  float y_cur = traj_at(a.T - 1), y_n1 = traj_at(a.T - 2);
+  float ob_next = j < 4 ? obs_at(a.T - 1) : 0.f;
   float gx_next = (a.g_xpred && j < 4) ? a.g_xpred[((size_t)(a.T - 1) * 4 + j) * n + i] : 0.f;
   float gt_next = a.g_traj ? a.g_traj[((size_t)(a.T - 1) * 8 + j) * n + i] : 0.f;
-  float tHi = a.times[a.T - 1], tLo = a.times[a.T - 1];  // step k uses (times[k], times[k+1]) = (tLo, tHi)
+  float tHi = time_at(a.T - 1), tLo = tHi;  // step k uses (times[k], times[k+1]) = (tLo, tHi)
   for (int k = a.T - 1; k >= 0; --k) {
-    const float y = ynext, obk = ob_next, gxk = gx_next, gtk = gt_next;
+    const float y = y_cur, obk = ob_next, gxk = gx_next, gtk = gt_next;
     const float tK = tLo;  // times[k]
-    if (k > 0) {  // prefetch everything the next (earlier) step needs
-      ynext = a.traj_in[((size_t)(k - 1) * 8 + j) * n + i];
-      ob_next = j < 4 ? ob[k - 1] : 0.f;
+    y_cur = y_n1;
+    if (k > 0) {
+      ob_next = j < 4 ? obs_at(k - 1) : 0.f;
       if (a.g_xpred && j < 4) gx_next = a.g_xpred[((size_t)(k - 1) * 4 + j) * n + i];
       if (a.g_traj) gt_next = a.g_traj[((size_t)(k - 1) * 8 + j) * n + i];
-      tLo = a.times[k - 1];
+      tLo = time_at(k - 1);
     }
+    if (k > 1) y_n1 = traj_at(k - 2);  // (issued last: the youngest vector load, the only one left in flight)
     if (k < a.T - 1) lam = D::template step_vjp<SOLVER>(tK, tHi, h0, y, L, lam, A);
     tHi = tK;
     // injection at time k
@@ -544,7 +561,8 @@ inline int launch_dr_lanes(bool backward, int solver, const OdeArgs& a, hipStrea
   const bool lds_in = lds <= 48 * 1024;  // long grids / many rows per block fall back to global loads in the loop
 #define VIHDS_LCASE(SV)                                                                                   \
   case SV:                                                                                                \
-    if (backward) hipLaunchKernelGGL((dr_lane_bwd_kernel<VERSION, SV>), grid, block, 0, st, a);           \
+    if (backward && lds_in) hipLaunchKernelGGL((dr_lane_bwd_kernel<VERSION, SV, true>), grid, block, lds, st, a); \
+    else if (backward) hipLaunchKernelGGL((dr_lane_bwd_kernel<VERSION, SV, false>), grid, block, 0, st, a); \
     else if (lds_in) hipLaunchKernelGGL((dr_lane_fwd_kernel<VERSION, SV, true>), grid, block, lds, st, a); \
     else hipLaunchKernelGGL((dr_lane_fwd_kernel<VERSION, SV, false>), grid, block, 0, st, a);             \
     return VIHDS_OK;
