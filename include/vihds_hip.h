@@ -179,6 +179,12 @@ int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, float* unit_g_logw,
                         float* unit_g_neg_logw, void* stream);
 int vihds_iwae_loss_unit_grad(int B, int S);
+/* S sharded over n_ranks processes: `gathered` [n_ranks][2][B] holds every rank's (row_max, row_sumexp) from
+ * vihds_iwae_fwd (one all-gather).  Computes the global lse[b] = M + log sum_r se_r exp(m_r - M), loss[0] =
+ * -mean_b(lse[b] - log n_iwae_total) and, optionally, this rank's d loss / d log_w [B][S] for a unit upstream gradient
+ * (and its negation) -- the rest of training.py:141-149 in one launch. */
+int vihds_iwae_combine(int n_ranks, int B, int S, int n_iwae_total, const float* gathered, const float* log_w,
+                       float* lse, float* loss, float* unit_g_logw, float* unit_g_neg_logw, void* stream);
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                         float* g_neg_logw, void* stream);
 

@@ -19,5 +19,5 @@ for mode in ("graph", "eager"):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(200): loss = step(batch)
     torch.cuda.synchronize()
-    print("%s world=1 %s: %.3f ms/step loss %.2f" % (dist.get_backend(), mode, (time.perf_counter() - t0) / 200 * 1e3, float(loss)), flush=True)
+    print("%s world=1 %s: %.3f ms/step loss %.2f %s" % (dist.get_backend(), mode, (time.perf_counter() - t0) / 200 * 1e3, float(loss), parallel.STATS), flush=True)
 dist.destroy_process_group()

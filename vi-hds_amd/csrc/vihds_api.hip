@@ -48,6 +48,7 @@ void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*,
 void launch_iwae_finish(int, float, const float*, const float*, float*, float*, hipStream_t);
 void launch_iwae_loss_small(int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
                             float*, float*, float*, hipStream_t);
+void launch_iwae_combine(int, int, int, float, const float*, const float*, float*, float*, float*, float*, hipStream_t);
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
@@ -295,6 +296,16 @@ int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const
   launch_iwae_fwd(B, S, logp, log_p, log_q, log_w, row_max, row_sumexp, (hipStream_t)stream);
   launch_iwae_finish(B, logf((float)n_iwae_total), row_max, row_sumexp, lse, loss, (hipStream_t)stream);
   return check_hip("vihds_iwae_loss_fwd launch");
+}
+
+int vihds_iwae_combine(int n_ranks, int B, int S, int n_iwae_total, const float* gathered, const float* log_w,
+                       float* lse, float* loss, float* unit_g_logw, float* unit_g_neg_logw, void* stream) {
+  if (n_ranks <= 0 || B <= 0 || S <= 0 || n_iwae_total <= 0 || !gathered || !lse || !loss)
+    return fail(VIHDS_E_BADARG, "bad argument");
+  if (unit_g_logw && !log_w) return fail(VIHDS_E_BADARG, "unit-gradient outputs need log_w");
+  launch_iwae_combine(n_ranks, B, S, logf((float)n_iwae_total), gathered, log_w, lse, loss, unit_g_logw,
+                      unit_g_neg_logw, (hipStream_t)stream);
+  return check_hip("vihds_iwae_combine launch");
 }
 
 /* 1 if vihds_iwae_loss_fwd can also emit the unit-upstream-gradient outputs for this shape */

@@ -474,6 +474,46 @@ iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp
   }
 }
 
+// S sharded over ranks: after the per-rank (row max, row sum-exp) pairs have been all-gathered ([N][2][B]), everything
+// that remains of the loss is ONE launch: lse[b] = M + log sum_r se_r exp(m_r - M), loss = -mean_b(lse - log n_total),
+// and (optionally) d loss / d log_w of this rank's samples for a unit upstream gradient.  One block, wave per row.
+__global__ void __launch_bounds__(1024)
+iwae_combine_kernel(int N, int B, int S, float log_n, const float* __restrict__ gathered,
+                    const float* __restrict__ log_w, float* __restrict__ lse, float* __restrict__ loss,
+                    float* __restrict__ unit_g_logw, float* __restrict__ unit_g_neg_logw) {
+  __shared__ float sm[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  float acc = 0.f;
+  for (int b = wid; b < B; b += 16) {
+    float m = -INFINITY;
+    for (int r = lane; r < N; r += 64) m = fmaxf(m, gathered[(size_t)(2 * r) * B + b]);
+    m = __shfl(wave_max(m), 0, 64);
+    float se = 0.f;
+    for (int r = lane; r < N; r += 64)
+      se += gathered[(size_t)(2 * r + 1) * B + b] * expf(gathered[(size_t)(2 * r) * B + b] - m);
+    se = __shfl(wave_sum(se), 0, 64);
+    const float l = m + logf(se);
+    if (lane == 0) {
+      lse[b] = l;
+      acc += l - log_n;
+    }
+    if (unit_g_logw) {
+      for (int sidx = lane; sidx < S; sidx += 64) {
+        const float g = -(1.f / (float)B) * expf(log_w[b * S + sidx] - l);
+        unit_g_logw[b * S + sidx] = g;
+        if (unit_g_neg_logw) unit_g_neg_logw[b * S + sidx] = -g;
+      }
+    }
+  }
+  if (lane == 0) sm[wid] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    float t = 0.f;
+    for (int w = 0; w < 16; ++w) t += sm[w];
+    loss[0] = -t / (float)B;
+  }
+}
+
 // d loss / d log_w = -(g_loss / B) * softmax_s(log_w)
 __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log_w, const float* __restrict__ lse,
                                      const float* __restrict__ g_loss, float* __restrict__ g_logw,
@@ -616,6 +656,11 @@ void launch_iwae_loss_small(int B, int S, float log_n, const float* logp, const 
                             float* unit_g_logw, float* unit_g_neg_logw, hipStream_t st) {
   hipLaunchKernelGGL(iwae_loss_small_kernel, dim3(1), dim3(1024), 0, st, B, S, log_n, logp, log_p, log_q, log_w, row_max,
                      row_sumexp, lse, loss, unit_g_logw, unit_g_neg_logw);
+}
+void launch_iwae_combine(int N, int B, int S, float log_n, const float* gathered, const float* log_w, float* lse,
+                         float* loss, float* unit_g_logw, float* unit_g_neg_logw, hipStream_t st) {
+  hipLaunchKernelGGL(iwae_combine_kernel, dim3(1), dim3(1024), 0, st, N, B, S, log_n, gathered, log_w, lse, loss,
+                     unit_g_logw, unit_g_neg_logw);
 }
 void launch_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                           float* g_neg_logw, hipStream_t st) {

@@ -103,6 +103,7 @@ _PROTOTYPES = {
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
     "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 11),
     "vihds_iwae_loss_unit_grad": (_I, [_I, _I]),
+    "vihds_iwae_combine": (_I, [_I, _I, _I, _I] + [_P] * 7),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
     "vihds_device_condition": (_I, [_I] * 6 + [ctypes.c_float, ctypes.c_float] + [_P] * 7),
     "vihds_encoder_fwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 16),

@@ -278,11 +278,19 @@ class EncoderQTables(torch.autograd.Function):
             ctx.saved_tensors
         g_all = _c(g_all)
         dev = g_all.device
-        new = lambda t: None if t is None else torch.empty_like(t)  # noqa: E731
-        g_conv_w, g_lin_w, g_local_w, g_local_b, g_gcond_w, g_glob = (new(conv_w), new(lin_w), new(local_w),
-                                                                       new(local_b), new(gcond_w), new(global_free))
-        g_conv_b = torch.empty(s.F, device=dev)
-        g_lin_b = torch.empty(s.H, device=dev)
+        # all parameter gradients are carved out of ONE buffer, in the order Encoder.parameters() lists them (the
+        # module's own global_free first, then conv.weight, conv.bias, lin.weight, lin.bias, local heads, gcond heads):
+        # a sharded step can then all-reduce the buffer in place instead of flattening and scattering
+        # (vihds/parallel.py)
+        shapes = [None if global_free is None else global_free.shape, conv_w.shape, (s.F,), lin_w.shape, (s.H,)] + \
+                 [None if t is None else t.shape for t in (local_w, local_b, gcond_w)]
+        sizes = [0 if sh is None else int(torch.Size(sh).numel()) for sh in shapes]
+        arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+        views, off = [], 0
+        for sh, k in zip(shapes, sizes):
+            views.append(None if sh is None else arena[off: off + k].view(sh))
+            off += k
+        g_glob, g_conv_w, g_conv_b, g_lin_w, g_lin_b, g_local_w, g_local_b, g_gcond_w = views
         g_pre = torch.empty((s.B, s.H), device=dev)
         g_conv = torch.empty((s.B, s.F, s.L - s.K + 1), device=dev)
         rc = hip.lib().vihds_encoder_bwd(ctypes.byref(s), hip.ptr(g_all), hip.ptr(delta_obs), hip.ptr(inputs),
@@ -497,6 +505,50 @@ class IwaeLoss(torch.autograd.Function):
         return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None
 
 
+class IwaeLossSharded(torch.autograd.Function):
+    """-ELBO with the S axis sharded over the ranks of `group`: rows kernel, ONE all-gather of the [2,B]
+    (max, sum-exp) pairs (a graph break when the step is being captured), then one combine launch giving the global
+    lse, the loss and this rank's unit-gradient backward.  Backward: no communication (the local softmax weights only
+    need the global lse)."""
+
+    @staticmethod
+    def forward(ctx, logp, log_p, log_q, n_total, group):
+        import torch.distributed as dist
+
+        from vihds.parallel import graph_break
+
+        _require_cuda(logp, log_p, log_q)
+        logp, log_p, log_q = _c(logp), _c(log_p), _c(log_q)
+        _, B, S = logp.shape
+        dev = logp.device
+        world = dist.get_world_size(group)
+        log_w = torch.empty((B, S), device=dev, dtype=torch.float32)
+        pair = torch.empty((2, B), device=dev, dtype=torch.float32)  # row_max ; row_sumexp
+        rc = hip.lib().vihds_iwae_fwd(B, S, hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q), hip.ptr(log_w),
+                                      hip.ptr(pair[0]), hip.ptr(pair[1]), hip.current_stream())
+        hip.check(rc, "vihds_iwae_fwd")
+        gathered = torch.empty((world * 2, B), device=dev, dtype=torch.float32)
+        graph_break(lambda: dist.all_gather_into_tensor(gathered, pair, group=group))
+        lse = torch.empty((B,), device=dev, dtype=torch.float32)
+        loss = torch.empty((), device=dev, dtype=torch.float32)
+        ug = ugn = None
+        if any(ctx.needs_input_grad):
+            ug = torch.empty((B, S), device=dev, dtype=torch.float32)
+            ugn = torch.empty((B, S), device=dev, dtype=torch.float32) if log_q is not None else None
+        rc = hip.lib().vihds_iwae_combine(world, B, S, int(n_total), hip.ptr(gathered), hip.ptr(log_w), hip.ptr(lse),
+                                          hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.current_stream())
+        hip.check(rc, "vihds_iwae_combine")
+        ctx.save_for_backward(log_w, lse, ug, ugn)
+        ctx.has = (log_p is not None, log_q is not None)
+        ctx.mark_non_differentiable(log_w, lse)
+        ctx.set_materialize_grads(False)
+        return loss, log_w, lse
+
+    @staticmethod
+    def backward(ctx, g_loss, _g1, _g2):  # vihds_iwae_loss_bwd with the global lse, or the unit-gradient buffers
+        return IwaeLoss.backward(ctx, g_loss, _g1, _g2) + (None,)
+
+
 def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng_state=None, sample_window=None):
     """OdeModel.device_conditioner applied to ones for E parameters in one launch, written into `out` [E,B,S].
     z [E,D] standard normals, or None with `rng_state` (KernelNormal.new_state): the kernel draws them."""
@@ -518,9 +570,8 @@ def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None):
     if group is None:
         S = n_iwae_total if n_iwae_total is not None else logp.shape[2]
         return IwaeLoss.apply(logp, log_p, log_q, S)
-    lse, log_w = iwae_lse(logp, log_p, log_q, group)
-    S = n_iwae_total if n_iwae_total is not None else log_w.shape[1]
-    return -(lse - math.log(S)).mean(), log_w, lse
+    S = n_iwae_total if n_iwae_total is not None else logp.shape[2]
+    return IwaeLossSharded.apply(logp, log_p, log_q, S, group)
 
 
 def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None):

@@ -123,19 +123,41 @@ def init_from_env(backend=None):
     return SampleShard(dist.get_rank(), dist.get_world_size())
 
 
+STATS = {"grads_in_place": 0, "grads_packed": 0}  # which path allreduce_gradients took (tests / probes)
+
+
 def allreduce_gradients(parameters, group=None, buffer=None):
-    """Sum the gradients of all parameters over ranks with ONE all-reduce of a flat buffer."""
+    """Sum the gradients of all parameters over ranks with ONE all-reduce.  If the gradients already sit back to back
+    in one buffer (the fused encoder's backward carves them out of one arena) that buffer is reduced in place -- no
+    flatten, no scatter; otherwise they are packed into `buffer`, reduced, and the .grad fields re-pointed at views
+    of it (no copy back)."""
     params = [p for p in parameters if p.grad is not None]
     if not params:
         return buffer
-    n = sum(p.grad.numel() for p in params)
-    if buffer is None or buffer.numel() != n or buffer.device != params[0].grad.device:
-        buffer = torch.empty(n, device=params[0].grad.device, dtype=params[0].grad.dtype)
-    torch.cat([p.grad.reshape(-1) for p in params], out=buffer)
+    grads = [p.grad for p in params]
+    n = sum(g.numel() for g in grads)
+    g0 = grads[0]
+    contiguous_run = all(g.is_contiguous() and g.dtype == g0.dtype for g in grads)
+    if contiguous_run:
+        ptr = g0.data_ptr()
+        for g in grads:
+            if g.data_ptr() != ptr:
+                contiguous_run = False
+                break
+            ptr += g.numel() * g.element_size()
+    if contiguous_run and g0.untyped_storage().nbytes() - (g0.data_ptr() - g0.untyped_storage().data_ptr()) >= n * g0.element_size():
+        flat = torch.empty(0, device=g0.device, dtype=g0.dtype).set_(g0.untyped_storage(), g0.storage_offset(), (n,))
+        graph_break(lambda: dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group))
+        STATS["grads_in_place"] += 1
+        return buffer
+    if buffer is None or buffer.numel() != n or buffer.device != g0.device:
+        buffer = torch.empty(n, device=g0.device, dtype=g0.dtype)
+    STATS["grads_packed"] += 1
+    torch.cat([g.reshape(-1) for g in grads], out=buffer)
     graph_break(lambda: dist.all_reduce(buffer, op=dist.ReduceOp.SUM, group=group))
     off = 0
     for p in params:
         k = p.grad.numel()
-        p.grad.copy_(buffer[off: off + k].view_as(p.grad))
+        p.grad = buffer[off: off + k].view_as(p.grad)
         off += k
     return buffer
