@@ -245,11 +245,11 @@ def main():
         return nb / (us * 1e-6) / 1e9
 
     traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_p_pmc_hbm_traffic.json")
+    pmc_file = os.path.join(ROOT, "profiles", "r01_u_pmc_hbm_traffic.json")
     if os.path.exists(pmc_file) and a.solver == "rk4":
         pmc = json.load(open(pmc_file))["kernels"].get(kname[dom])
         if pmc:
-            traffic, traffic_src = pmc["hbm_bytes_corrected"], "profiles/r01_p_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+            traffic, traffic_src = pmc["hbm_bytes_corrected"], "profiles/r01_u_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
     roofline = {
         "bound": "hbm", "kernel": kname[dom],
         "achieved": gbs(nbytes[dom], kt[dom]["mean_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
