@@ -163,6 +163,9 @@ def main():
     ap.add_argument("--device-rng", choices=["kernel", "device"], default="kernel",
                     help="kernel: u and the conditioner weights are drawn inside the HIP kernels (counter-based "
                          "Philox); device: torch.randn on the GPU")
+    ap.add_argument("--two-kernel-ode", action="store_true",
+                    help="integrate and differentiate with vihds_ode_fwd + vihds_ode_bwd (trajectory through HBM) "
+                         "instead of the fused vihds_ode_logp_grad")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -193,7 +196,7 @@ def main():
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,
         u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
-        hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr)
+        hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, fused_ode_training=not a.two_kernel_ode)
     model.train()
     batch = training.train_data
     step = training.graph_step if use_graph else training.step

@@ -121,6 +121,15 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
                   float* g_weights, float* aux, void* stream);
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
+
+/* Training fast path: the per-species log-likelihood logp [4][B][S] of vihds_ode_fwd AND, in the same launch, the
+ * gradient g_theta_unit [n_rows][B][S] that vihds_ode_bwd would return for g_logp == 1 (g_traj = g_xpred = NULL).
+ * In the ELBO d loss / d logp[j][b][s] is one number w[b][s] for all four signals (training.py:135-149) and the
+ * adjoint is linear in it, so d loss / d theta = w[b][s] * g_theta_unit: the adjoint can run right behind the forward
+ * sweep, the trajectory never leaves LDS, and neither trajectory nor x_predict is written.  dr_constant /
+ * dr_constant_v2 in the lane-split regime only; VIHDS_E_UNSUPPORTED otherwise (callers then use fwd + bwd). */
+int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                        const float* times, const float* obs, float* logp, float* g_theta_unit, void* stream);
 int vihds_blackbox_dump_fields(void);
 
 /* theta side: ChainedDistribution.sample + p.clip + q.log_prob + p.log_prob

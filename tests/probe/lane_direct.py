@@ -39,3 +39,14 @@ for (T,) in shapes:
             for _ in range(50): fn()
             e1.record(); torch.cuda.synchronize()
             print("T=%3d %-9s %-26s %.1f us" % (T, solver, name, e0.elapsed_time(e1) / 50 * 1e3))
+        glogp2 = torch.empty(4, B, S, device="cuda"); g_unit = torch.empty_like(theta)
+        def fused():
+            return L.vihds_ode_logp_grad(ctypes.byref(prob), theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(),
+                                         obs.data_ptr(), glogp2.data_ptr(), g_unit.data_ptr(), st)
+        for _ in range(5): assert fused() == 0, L.vihds_last_error()
+        torch.cuda.synchronize()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(50): fused()
+        e1.record(); torch.cuda.synchronize()
+        print("T=%3d %-9s %-26s %.1f us" % (T, solver, "fused logp + unit adjoint", e0.elapsed_time(e1) / 50 * 1e3))

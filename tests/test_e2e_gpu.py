@@ -251,3 +251,40 @@ def test_two_ranks_sharded_step_matches_single_process_and_segmented_graph_match
     for k in range(5):
         assert abs(graph2[k] - eager2[k + 3]) <= 2e-4 * max(1.0, abs(eager2[k + 3])), (graph2, eager2)
     assert single[-1] < single[0]  # and it trains
+
+
+def test_fused_training_path_matches_two_kernel_path():
+    """params.fused_ode_training: one launch (vihds_ode_logp_grad) gives the log-likelihood and the unit-weight
+    adjoint, the theta gradient is scaled by the IWAE weights afterwards, and x_states / x_predict are only computed
+    if somebody unpacks the decoder result.  Loss and every encoder-parameter gradient must equal the two-kernel path's
+    on the reference fixture, and the lazily built outputs must equal the fixture's trajectories."""
+    import e2e_util as E
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    outs = {}
+    for fused in (False, True):
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, fused_ode_training=fused)
+        model = build_model(args, settings, data, parameters)
+        training = Training(args, settings, data, parameters, model)
+        model.train()
+        batch = E.batch_from_fixture(fx, "cuda:0")
+        np.random.seed(fx.cfg["seed"] + 1)
+        torch.manual_seed(fx.cfg["seed"] + 1)
+        batch_results, theta, q, p = model(batch, fx.S)
+        if fused:
+            from vihds.decoders import LazyDecoderResult
+
+            assert isinstance(batch_results, LazyDecoderResult) and batch_results._items is None
+        elbo = training.cost(batch, batch_results, theta, q, p).elbo
+        elbo.backward()
+        if fused:
+            assert batch_results._items is None  # training never asked for the trajectories
+            x_states, x_predict, _prec = batch_results
+            assert rel_err(x_states, fx.t("x_states")) < 1e-4 and rel_err(x_predict, fx.t("x_predict")) < 1e-4
+        outs[fused] = (float(elbo), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * abs(outs[False][0])
+    assert abs(outs[True][0] - float(fx.t("loss"))) <= 1e-4 * abs(float(fx.t("loss")))
+    for k, g in outs[False][1].items():
+        assert rel_err(outs[True][1][k], g) < 1e-5, k

@@ -821,3 +821,46 @@ def test_iwae_loss_unit_gradient_fast_path_equals_backward_kernel():
         assert rel_err(c, 2.0 * a) < 1e-6
     assert rel_err(grads[0][0][0].sum(1), torch.full((B,), -1.0 / B)) < 1e-4
     del g
+
+
+@pytest.mark.parametrize("solver", ["modeuler", "modeulerwhile", "euler", "midpoint", "rk4"])
+@pytest.mark.parametrize("model", ["dr_constant", "dr_constant_v2"])
+def test_fused_logp_and_unit_adjoint_equals_forward_plus_backward(model, solver):
+    """vihds_ode_logp_grad (one launch, trajectory kept in LDS) == vihds_ode_fwd's logp and vihds_ode_bwd's gradient
+    for g_logp = 1, at the headline shape and at a ragged one (partial last block, several data rows per block)."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    for (B, S, T) in ((36, 200, 86), (7, 5, 31)):
+        slots = hip.model_slots(model)
+        th = _synthetic_theta(slots, B, S, 13)
+        theta = torch.stack([th[n] for n in slots]).to(DEV)
+        g = torch.Generator().manual_seed(6)
+        cond = torch.log1p(torch.rand(B, 2, generator=g) * 1000.0).to(DEV)
+        times = (torch.arange(T, dtype=torch.float32) * 0.1933).to(DEV)
+        obs = torch.rand(B, 4, T, generator=g).to(DEV)
+        spec = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=2, kernel_variant=2)
+        prob = spec.bind(B, S, T)
+        prob.logp_grad_broadcast = 1
+        st = torch.cuda.current_stream().cuda_stream
+        traj = torch.empty(T, 8, B, S, device=DEV); xpred = torch.empty(T, 4, B, S, device=DEV)
+        logp = torch.empty(4, B, S, device=DEV); ones = torch.ones(B, S, device=DEV)
+        g_ref = torch.empty_like(theta)
+        args = (theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(), obs.data_ptr())
+        assert L.vihds_ode_fwd(ctypes.byref(prob), *args, None, traj.data_ptr(), xpred.data_ptr(), logp.data_ptr(), st) == 0
+        assert L.vihds_ode_bwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, None, ones.data_ptr(),
+                               g_ref.data_ptr(), None, None, st) == 0
+        logp2 = torch.empty_like(logp); g_unit = torch.empty_like(theta)
+        rc = L.vihds_ode_logp_grad(ctypes.byref(prob), *args, logp2.data_ptr(), g_unit.data_ptr(), st)
+        assert rc == 0, L.vihds_last_error()
+        torch.cuda.synchronize()
+        assert rel_err(logp2, logp) < 1e-6
+        for r, n in enumerate(slots):
+            scale = g_ref[r].abs().max()
+            if scale > 0:
+                assert float((g_unit[r] - g_ref[r]).abs().max() / scale) < 1e-5, (n, B, S)
+    # outside the lane-split regime the entry point declines
+    spec1 = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=2, kernel_variant=1)
+    prob1 = spec1.bind(B, S, T)
+    assert L.vihds_ode_logp_grad(ctypes.byref(prob1), *args, logp2.data_ptr(), g_unit.data_ptr(), st) != 0

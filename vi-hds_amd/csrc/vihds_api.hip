@@ -37,6 +37,8 @@ long long bb_aux_floats(int n, int T, int solver);
 int bb_check(int L, int HS, int HP, int n_const, int C, int D);
 int bb_dump_fields();
 
+int launch_dr_constant_train_v1(int, const OdeArgs&, hipStream_t);
+int launch_dr_constant_train_v2(int, const OdeArgs&, hipStream_t);
 // vihds_elbo.hip
 void launch_theta_fwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
                       const float*, float*, float*, float*, float*, const vihds_theta_opts&, hipStream_t);
@@ -168,6 +170,26 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
   if (p->n_hidden_prec > 0) return VIHDS_E_UNSUPPORTED;  // white-box + hidden-layer precisions: no spec uses it
   const int n_in = e->n_states() - 4 + 1;
   return 2 * (4 * n_in + 4);
+}
+
+int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                        const float* times, const float* obs, float* logp, float* g_theta_unit, void* stream) {
+  if (!p || !theta || !cond || !times || !obs || !logp || !g_theta_unit) return fail(VIHDS_E_BADARG, "null argument");
+  if (p->model != VIHDS_MODEL_DR_CONSTANT && p->model != VIHDS_MODEL_DR_CONSTANT_V2)
+    return fail(VIHDS_E_UNSUPPORTED, "fused log-likelihood + adjoint exists for dr_constant / dr_constant_v2 only");
+  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver");
+  const ModelEntry* e = entry(p->model);
+  OdeArgs a;
+  if (int rc = build_args(p, e, a)) return rc;
+  if (p->C < 2) return fail(VIHDS_E_BADARG, "dr_constant needs two treatments");
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs;
+  a.logp = logp; a.g_theta = g_theta_unit;
+  const int rc = p->model == VIHDS_MODEL_DR_CONSTANT ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream)
+                                                     : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream);
+  if (rc == VIHDS_E_UNSUPPORTED)
+    return fail(rc, "shape outside the fused kernel's regime (lane-split size limit, or time grid too long for LDS)");
+  if (rc != VIHDS_OK) return fail(rc, "fused kernel launch failed");
+  return check_hip("vihds_ode_logp_grad launch");
 }
 
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {

@@ -442,10 +442,54 @@ __global__ void __launch_bounds__(256) dr_lane_fwd_kernel(OdeArgs a) {
   if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
 }
 
+// The adjoint kernels' epilogue: raw accumulators -> gradients of the theta rows (each row written by exactly one lane).
+template <int VERSION>
+__device__ __forceinline__ void dr_lane_write_adjoints(const OdeArgs& a, int i, int j, bool live, const DrLane& L,
+                                                       const float* c,
+                                                       const typename DrLanes<VERSION>::HillTerm& H,
+                                                       const typename DrLanes<VERSION>::Adj& A, float lam, float precb) {
+  using D = DrLanes<VERSION>;
+  using M = DrConstant<VERSION>;
+  const size_t n = a.n;
+  // ---- parameter adjoints -> theta rows (each slot row written by exactly one lane)
+  // c enters as ce = c e and cm = c (1 - e):  c_bar = sv e + svt (1 - e),  e_bar = c (sv - svt)
+  const bool prom = j == 2 || j == 3;
+  const float cb = prom ? A.sv * L.e + A.svt * (1.f - L.e) : A.sv;
+  const float eb = L.c * (A.sv - A.svt);
+  // c1 = K1 f1, c2 = K2 f2 with (K1, f1, K2, f2) = (KGR, fR, KGS, fS) in lane 2 and (KGS, fS, KGR, fR) in lane 3
+  const float KGRb = j == 3 ? A.c2b * L.fR : A.c1b * L.fR;
+  const float KGSb = j == 3 ? A.c1b * L.fS : A.c2b * L.fS;
+  const float fRb = sum8(prom ? (j == 3 ? A.c2b : A.c1b) * L.KGR : 0.f);
+  const float fSb = sum8(prom ? (j == 3 ? A.c1b : A.c2b) * L.KGS : 0.f);
+  const float rcb = sum8(cb * L.a);
+  const float rb = sum4(A.rb), tlagb = -4.f * sum4(A.tl);
+  const float Kb = A.gbx * L.invK * L.invK;
+  const typename D::HillAdj HA = D::hill_vjp(a, i, j, c, H, fRb, fSb);
+  if (!live) return;
+  auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
+  auto raw = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
+  const int is = D::init_slot(j);
+  if (is >= 0) put(is, lam);
+  if (j < 4) put(M::NSLOT + j, precb);
+  const int ds = D::deg_slot(j);
+  if (ds >= 0) put(ds, A.degb * clamp_pass(raw(ds), 1e-12f, (j == 6 || j == 7) ? 5.f : 2.f));
+  const int as = D::a_slot(j);
+  if (as >= 0) put(as, cb * L.rc);
+  if (j == 2) { put(M::S_e81, eb); put(M::S_KGR81, KGRb); put(M::S_KGS81, KGSb); }
+  if (j == 3) { put(M::S_e76, eb); put(M::S_KGR76, KGRb); put(M::S_KGS76, KGSb); }
+  if (j == 0) {
+    put(M::S_r, rb * clamp_pass(raw(M::S_r), 0.f, 4.f));
+    put(M::S_K, Kb * clamp_pass(raw(M::S_K), 0.f, 4.f));
+    put(M::S_tlag, tlagb);
+    put(M::S_rc, rcb);
+    put(M::S_nR, HA.nR); put(M::S_nS, HA.nS); put(M::S_H0, HA.H0); put(M::S_H1, HA.H1);
+    if (VERSION == 1) { put(M::S_H2, HA.H2); put(M::S_H3, HA.H3); }
+  }
+}
+
 template <int VERSION, int SOLVER, bool LDS_IN>
 __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   using D = DrLanes<VERSION>;
-  using M = DrConstant<VERSION>;
   extern __shared__ float lds[];
   const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int i0 = blockIdx.x * D::TPB + tl;
@@ -512,40 +556,136 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
     const float xsum = sum4(xpb * inner);
     lam += L.m0 * xsum + gtk;
   }
-  // ---- parameter adjoints -> theta rows (each slot row written by exactly one lane)
-  // c enters as ce = c e and cm = c (1 - e):  c_bar = sv e + svt (1 - e),  e_bar = c (sv - svt)
-  const bool prom = j == 2 || j == 3;
-  const float cb = prom ? A.sv * L.e + A.svt * (1.f - L.e) : A.sv;
-  const float eb = L.c * (A.sv - A.svt);
-  // c1 = K1 f1, c2 = K2 f2 with (K1, f1, K2, f2) = (KGR, fR, KGS, fS) in lane 2 and (KGS, fS, KGR, fR) in lane 3
-  const float KGRb = j == 3 ? A.c2b * L.fR : A.c1b * L.fR;
-  const float KGSb = j == 3 ? A.c1b * L.fS : A.c2b * L.fS;
-  const float fRb = sum8(prom ? (j == 3 ? A.c2b : A.c1b) * L.KGR : 0.f);
-  const float fSb = sum8(prom ? (j == 3 ? A.c1b : A.c2b) * L.KGS : 0.f);
-  const float rcb = sum8(cb * L.a);
-  const float rb = sum4(A.rb), tlagb = -4.f * sum4(A.tl);
-  const float Kb = A.gbx * L.invK * L.invK;
-  const typename D::HillAdj HA = D::hill_vjp(a, i, j, c, H, fRb, fSb);
-  if (!live) return;
-  auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
-  auto raw = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
-  const int is = D::init_slot(j);
-  if (is >= 0) put(is, lam);
-  if (j < 4) put(M::NSLOT + j, precb);
-  const int ds = D::deg_slot(j);
-  if (ds >= 0) put(ds, A.degb * clamp_pass(raw(ds), 1e-12f, (j == 6 || j == 7) ? 5.f : 2.f));
-  const int as = D::a_slot(j);
-  if (as >= 0) put(as, cb * L.rc);
-  if (j == 2) { put(M::S_e81, eb); put(M::S_KGR81, KGRb); put(M::S_KGS81, KGSb); }
-  if (j == 3) { put(M::S_e76, eb); put(M::S_KGR76, KGRb); put(M::S_KGS76, KGSb); }
-  if (j == 0) {
-    put(M::S_r, rb * clamp_pass(raw(M::S_r), 0.f, 4.f));
-    put(M::S_K, Kb * clamp_pass(raw(M::S_K), 0.f, 4.f));
-    put(M::S_tlag, tlagb);
-    put(M::S_rc, rcb);
-    put(M::S_nR, HA.nR); put(M::S_nS, HA.nS); put(M::S_H0, HA.H0); put(M::S_H1, HA.H1);
-    if (VERSION == 1) { put(M::S_H2, HA.H2); put(M::S_H3, HA.H3); }
+  dr_lane_write_adjoints<VERSION>(a, i, j, live, L, c, H, A, lam, precb);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Training step in ONE launch: log-likelihood AND the adjoint for a unit upstream gradient.
+//
+// In the ELBO, d loss / d logp[j][b][s] is the same number w[b][s] for the four observed signals (the IWAE softmax
+// weight), and the adjoint is linear in it.  So the adjoint for w = 1 can be computed right behind the forward sweep,
+// before the weights exist; the caller scales the resulting theta gradient by w[b][s] afterwards (one elementwise
+// pass).  The forward sweep then has nobody to write the trajectory for: the states of the block's 32 trajectories
+// stay in LDS ([T][256] floats = 86 KB at T = 86) and the reverse sweep reads them from there.  Compared with
+// dr_lane_fwd_kernel + dr_lane_bwd_kernel: one launch and one prologue instead of two, no trajectory / x_predict
+// stores (29.7 MB) and no trajectory reads (19.8 MB).  Outputs: logp [4][n] and the unit-weight gradient g_theta.
+template <int VERSION, int SOLVER>
+__global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_max) {
+  using D = DrLanes<VERSION>;
+  extern __shared__ float lds[];  // [T] times | [nb_max][4][T] observations | [T][256] states
+  const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const int i0 = blockIdx.x * D::TPB + tl;
+  const bool live = i0 < a.n;
+  const int i = live ? i0 : a.n - 1;
+  const int b = i / a.S;
+  const int first = blockIdx.x * D::TPB, last = min(first + D::TPB, a.n) - 1;
+  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
+  const float* src = a.obs + (size_t)b0 * 4 * a.T;
+  for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
+  __syncthreads();
+  const float* tm = lds;
+  const float* ob = lds + a.T + ((b - b0) * 4 + (j & 3)) * a.T;
+  float* ys = lds + a.T + (size_t)nb_max * 4 * a.T + threadIdx.x;  // this lane's column, stride 256
+  DrLane L;
+  float c[2], y;
+  typename D::HillTerm H;
+  D::template prepare<SOLVER>(a, i, b, j, L, c, y, H);
+  const size_t n = a.n;
+  const float h0 = tm[1] - tm[0];
+  // ---- forward sweep: states to LDS, log-likelihood accumulated
+  {
+    const float lc = LOG2PI_F - logf(L.prec);
+    float lp = 0.f;
+    float tA = tm[0], tB = tm[1];
+    float ob_cur = j < 4 ? ob[0] : 0.f;
+    for (int k = 0; k < a.T; ++k) {
+      const float tC = (k + 1 < a.T) ? tm[k + 1] : tB;
+      const float ob_next = (j < 4 && k + 1 < a.T) ? ob[k + 1] : 0.f;
+      if (k > 0) {
+        y = D::template step<SOLVER>(tA, tB, h0, y, L);
+        tA = tB;
+      }
+      tB = tC;
+      ys[(size_t)k * 256] = y;
+      float inner;
+      const float xp = D::observe(y, bcast8<0>(y), L, inner);
+      if (j < 4) {
+        const float e = xp - ob_cur;
+        lp += -0.5f * (lc + L.prec * e * e);
+      }
+      ob_cur = ob_next;
+    }
+    if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
   }
+  // ---- reverse sweep with unit weight on the four log-likelihoods
+  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  float lam = 0.f, precb = 0.f;
+  const float glp = j < 4 ? 1.f : 0.f;
+  float y_next = y;  // = state at T-1
+  float ob_next = j < 4 ? ob[a.T - 1] : 0.f;
+  float tHi = tm[a.T - 1], tLo = tHi;
+  for (int k = a.T - 1; k >= 0; --k) {
+    const float yk = y_next, obk = ob_next;
+    const float tK = tLo;
+    if (k > 0) {
+      y_next = ys[(size_t)(k - 1) * 256];
+      ob_next = j < 4 ? ob[k - 1] : 0.f;
+      tLo = tm[k - 1];
+    }
+    if (k < a.T - 1) lam = D::template step_vjp<SOLVER>(tK, tHi, h0, yk, L, lam, A);
+    tHi = tK;
+    const float x = bcast8<0>(yk);
+    float inner;
+    const float xp = D::observe(yk, x, L, inner);
+    float xpb = 0.f;
+    if (j < 4) {
+      const float e = xp - obk;
+      xpb = -glp * L.prec * e;
+      precb += glp * (0.5f / L.prec - 0.5f * e * e);
+    }
+    const float q = xpb * x;
+    lam += L.mo1 * q + dpp_mov<0x112>(0.f, L.mo2 * q);
+    const float xsum = sum4(xpb * inner);
+    lam += L.m0 * xsum;
+  }
+  dr_lane_write_adjoints<VERSION>(a, i, j, live, L, c, H, A, lam, precb);
+}
+
+inline size_t dr_lane_train_lds_bytes(const OdeArgs& a, int tpb, int* nb_max_out) {
+  const int nb = min(a.B, (tpb - 1) / a.S + 2);
+  if (nb_max_out) *nb_max_out = nb;
+  return ((size_t)a.T + (size_t)nb * 4 * a.T + (size_t)a.T * 256) * sizeof(float);
+}
+constexpr size_t DR_LANE_TRAIN_MAX_LDS = 160 * 1024;
+
+// returns VIHDS_E_UNSUPPORTED when the states of a block do not fit in LDS (long time grids)
+template <int VERSION>
+inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st) {
+  int nb_max = 0;
+  const size_t lds = dr_lane_train_lds_bytes(a, DrLanes<VERSION>::TPB, &nb_max);
+  if (lds > DR_LANE_TRAIN_MAX_LDS) return VIHDS_E_UNSUPPORTED;
+  const dim3 grid((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB), block(256);
+#define VIHDS_TCASE(SV)                                                                                         \
+  case SV: {                                                                                                    \
+    auto kern = dr_lane_train_kernel<VERSION, SV>;                                                              \
+    if (lds > 64 * 1024) {                                                                                      \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess)                                                          \
+        return VIHDS_E_HIP;                                                                                     \
+    }                                                                                                           \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a, nb_max);                                                  \
+    return VIHDS_OK;                                                                                            \
+  }
+  switch (solver) {
+    VIHDS_TCASE(VIHDS_SOLVER_MODEULER)
+    VIHDS_TCASE(VIHDS_SOLVER_MODEULERWHILE)
+    VIHDS_TCASE(VIHDS_SOLVER_EULER)
+    VIHDS_TCASE(VIHDS_SOLVER_MIDPOINT)
+    VIHDS_TCASE(VIHDS_SOLVER_RK4)
+  }
+#undef VIHDS_TCASE
+  return VIHDS_E_BADARG;
 }
 
 // LDS floats the forward kernel stages per block: the time grid + the observation rows of the batch rows one block spans

@@ -27,6 +27,8 @@ PARAM_DEFAULTS = {
     "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48):
                                # "cpu" (reference stream) | "device" (torch on the GPU) | "kernel" (in the kernel)
     "encoder_kernel": True,    # q(theta|data) encoder as fused HIP kernels on the GPU (False: nn.Conv1d / nn.Linear)
+    "fused_ode_training": False,  # training: log-likelihood + unit-weight adjoint in one launch, no trajectory written
+                               # (dr_constant family, lane-split regime; x_states / x_predict then exist on demand only)
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
 }

@@ -13,6 +13,30 @@ class DecoderResult(tuple):
     solution = None
 
 
+class LazyDecoderResult(DecoderResult):
+    """Training fast path: only the log-likelihood exists.  Unpacking or indexing the tuple computes
+    (x_states, x_predict, precisions) the ordinary way first."""
+
+    def __new__(cls, build):
+        self = super(LazyDecoderResult, cls).__new__(cls, ())
+        self._build, self._items = build, None
+        return self
+
+    def _get(self):
+        if self._items is None:
+            self._items = self._build()
+        return self._items
+
+    def __iter__(self):
+        return iter(self._get())
+
+    def __getitem__(self, k):
+        return self._get()[k]
+
+    def __len__(self):
+        return 3
+
+
 class Decoder(nn.Module):
     def __init__(self, config, condition_on_device):
         super(Decoder, self).__init__()
@@ -28,6 +52,19 @@ class Decoder(nn.Module):
             theta_conditioned = self.ode_model.condition_theta(theta, data.dev_1hot, writer, epoch)
         else:
             theta_conditioned = theta
+        fused = self.ode_model.solve_for_training(self.config, data.times, theta_conditioned, data.inputs,
+                                                  data.dev_1hot, data.get("observations", None))
+        if fused is not None:  # log-likelihood + unit-weight adjoint in one launch; the rest only on demand
+
+            def build():
+                full = fused.full()
+                xs, prec = self.ode_model.expand_precisions(theta_conditioned, data.times, full.sol)
+                return xs, self.ode_model.observe(full.sol, theta_conditioned), prec
+
+            result = LazyDecoderResult(build)
+            result.solution = fused
+            result.log_p_by_species = fused.log_p_by_species
+            return result, theta_conditioned
         solution = self.ode_model.simulate(
             self.config, data.times, theta_conditioned, data.inputs, data.dev_1hot,
             condition_on_device=self.condition_on_device, observations=data.get("observations", None),

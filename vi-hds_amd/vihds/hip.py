@@ -28,6 +28,7 @@ MODELS = {
     "inducer_constant_precisions": 14,
     "debug_constant": 15,
 }
+E_UNSUPPORTED = -2  # VIHDS_E_UNSUPPORTED (include/vihds_hip.h)
 SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
@@ -95,6 +96,7 @@ _PROTOTYPES = {
     "vihds_model_n_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
     "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
+    "vihds_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 8),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
     "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 11 + [ctypes.POINTER(ThetaOpts), _P]),

@@ -22,6 +22,27 @@ class DecodedSolution(object):
         self.log_p_by_species = logp.permute(1, 2, 0)  # [B,S,4] (reference training.py:24-33)
 
 
+class LazySolution(object):
+    """What the fused training kernel produced: the per-species log-likelihood only.  Trajectory and x_predict are
+    computed (by the ordinary forward kernel, as a fresh autograd node on the same theta) if and when somebody asks."""
+
+    def __init__(self, logp, materialise):
+        self.logp_buffer = logp
+        self.log_p_by_species = logp.permute(1, 2, 0)
+        self.has_logp = True
+        self._materialise, self._full = materialise, None
+
+    def full(self):
+        if self._full is None:
+            self._full = self._materialise()
+        return self._full
+
+    traj_buffer = property(lambda self: self.full().traj_buffer)
+    xpred_buffer = property(lambda self: self.full().xpred_buffer)
+    sol = property(lambda self: self.full().sol)
+    x_predict = property(lambda self: self.full().x_predict)
+
+
 class DeviceConditioner(nn.Module):
     """Linear(D,1) -> ReLU with weights ~ N(2, 1.5) (reference ode.py:99-116)."""
 
@@ -62,6 +83,7 @@ class OdeModel(nn.Module):
         self._tile_index = {}
         self._relevance_dev = {}
         self._rng_state = None
+        self._fused_unsupported = {}
         self._last = None
 
     # ---- device conditioning (reference ode.py:43-58) ----------------------------------------------
@@ -172,6 +194,35 @@ class OdeModel(nn.Module):
                                                       self.neural_weights())
         self._last = DecodedSolution(traj, xpred, logp)
         self._last.has_logp = observations is not None
+        return self._last
+
+    fused_training_keys = ("dr_constant", "dr_constant_v2")
+
+    def solve_for_training(self, config, times, theta, conditions, dev_1hot, observations):
+        """Training fast path (params.fused_ode_training): ONE launch gives the log-likelihood and the unit-weight
+        adjoint (ops.OdeLogLikFused); returns a LazySolution, or None when the path does not apply (then use solve)."""
+        import vihds.hip as hip
+
+        if (observations is None or self.model_key not in self.fused_training_keys or not torch.is_grad_enabled()
+                or not default_get_value(config.params, "fused_ode_training", False)):
+            return None
+        slots = hip.model_slots(self.model_key)
+        packed, row_of = theta.pack(slots)
+        if not packed.is_cuda or not packed.requires_grad:
+            return None
+        spec = self._spec(config, row_of, packed.shape[0])
+        key = (packed.shape[1], packed.shape[2], times.shape[0], config.params.solver)
+        if self._fused_unsupported.get(key):
+            return None
+        dev = packed.device
+        args = (spec, packed, conditions.to(dev), times.to(dev), observations.to(dev),
+                dev_1hot.to(dev) if dev_1hot is not None else None)
+        try:
+            logp = ops.OdeLogLikFused.apply(*args)
+        except ops.FusedTrainingUnsupported:
+            self._fused_unsupported[key] = True
+            return None
+        self._last = LazySolution(logp, lambda: self.solve(config, times, theta, conditions, dev_1hot, observations))
         return self._last
 
     # ---- reference entry points ---------------------------------------------------------------------

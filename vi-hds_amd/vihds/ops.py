@@ -154,6 +154,49 @@ class OdeSolveObserve(torch.autograd.Function):
         return None, g_theta, None, None, None, None, g_w
 
 
+class FusedTrainingUnsupported(RuntimeError):
+    """vihds_ode_logp_grad declined this (model, shape): the caller uses OdeSolveObserve instead."""
+
+
+class OdeLogLikFused(torch.autograd.Function):
+    """Training fast path (vihds_ode_logp_grad): per-species log-likelihood [4,B,S] and, in the same launch, the theta
+    gradient for a unit upstream gradient; neither trajectory nor x_predict is produced.  backward: the ELBO hands
+    back ONE [B,S] weight for all four signals (a stride-0 expand, see IwaeLoss), and the adjoint is linear in it:
+    g_theta = w * g_unit.  Any other upstream gradient falls back to the two-kernel path."""
+
+    @staticmethod
+    def forward(ctx, spec, theta, cond, times, obs, dev1hot):
+        _require_cuda(theta, cond, times, obs)
+        theta, cond, times, obs = _c(theta), _c(cond), _c(times), _c(obs)
+        R, B, S = theta.shape
+        T = times.shape[0]
+        if R != spec.n_rows:
+            raise RuntimeError("theta has %d rows, problem expects %d" % (R, spec.n_rows))
+        prob = spec.bind(B, S, T)
+        logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
+        g_unit = torch.empty_like(theta) if spec.covers_all_rows else torch.zeros_like(theta)
+        rc = _launch("ode_logp_grad", lambda: hip.lib().vihds_ode_logp_grad(
+            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+            hip.ptr(logp), hip.ptr(g_unit), hip.current_stream()))
+        if rc == hip.E_UNSUPPORTED:
+            raise FusedTrainingUnsupported(hip.lib().vihds_last_error().decode())
+        hip.check(rc, "vihds_ode_logp_grad")
+        ctx.spec = spec
+        ctx.save_for_backward(theta, cond, times, obs, dev1hot, g_unit)
+        return logp
+
+    @staticmethod
+    def backward(ctx, g_logp):
+        theta, cond, times, obs, dev1hot, g_unit = ctx.saved_tensors
+        if g_logp.dim() == 3 and g_logp.stride(0) == 0:
+            return None, g_unit * g_logp[0], None, None, None, None
+        with torch.enable_grad():  # per-species weights: the general adjoint needs the trajectory after all
+            th = theta.detach().requires_grad_(True)
+            _traj, _xpred, logp = OdeSolveObserve.apply(ctx.spec, th, cond, times, obs, dev1hot, None)
+            (g_theta,) = torch.autograd.grad(logp, th, g_logp)
+        return None, g_theta, None, None, None, None
+
+
 def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     """dr_blackbox weight gradients from the adjoint kernel's dump: the contraction over (RHS evaluation x
     trajectory) -- K ~ 10^6, M,N <= 25 -- runs as batched library GEMMs (hipBLASLt => MFMA) on strided views of

@@ -107,8 +107,9 @@ class Training:
     # ------------------------------------------------------------------------------------------------
     def cost(self, batch_data, batch_results, theta, q, p, full_output=False, writer=None, epoch=None):
         """reference training.py:127-174.  Returns {"elbo": -ELBO} (sic) or a Results object."""
-        x_states, x_predict, precisions = batch_results
         fused = getattr(batch_results, "log_p_by_species", None)
+        if fused is None or full_output:  # (the training fast path never materialises these)
+            x_states, x_predict, precisions = batch_results
         if fused is not None:
             logp = batch_results.solution.logp_buffer  # [4,B,S] straight from the ODE kernel
             log_p_by_species = fused
