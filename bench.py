@@ -75,8 +75,11 @@ def ode_kernel_times(model, settings, batch, n_iwae, n_launch):
         return L.vihds_ode_bwd(ctypes.byref(prob), *args, traj.data_ptr(), None, None, g_logp.data_ptr(),
                                g_theta.data_ptr(), None, None, st.cuda_stream)
 
+    def fused():
+        return L.vihds_ode_logp_grad(ctypes.byref(prob), *args[:5], logp.data_ptr(), g_theta.data_ptr(), st.cuda_stream)
+
     out = {}
-    for name, fn in (("ode_fwd", fwd), ("ode_bwd", bwd)):
+    for name, fn in (("ode_fwd", fwd), ("ode_bwd", bwd), ("ode_fused", fused)):
         for _ in range(3):
             hip.check(fn(), name)
         torch.cuda.synchronize()
@@ -235,33 +238,47 @@ def main():
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
     kt = ode_kernel_times(model, settings, batch, N_IWAE * world, a.roofline_steps)
     fwd_b, bwd_b = algorithmic_bytes(B_ROWS, N_IWAE)
-    dom = "ode_bwd" if kt["ode_bwd"]["mean_us"] >= kt["ode_fwd"]["mean_us"] else "ode_fwd"
-    oth = "ode_fwd" if dom == "ode_bwd" else "ode_bwd"
-    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b}
     solver_id = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}[a.solver]
     lanes = B_ROWS * N_IWAE <= 16384  # the library's automatic choice (vihds_dr_lanes.hpp)
-    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d%s>(vihds::OdeArgs)" % (k[4:], solver_id, ", true")) if lanes else
+    kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d, true>(vihds::OdeArgs)" % (k[4:], solver_id)) if lanes else
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
+    kname["ode_fused"] = "void vihds::dr_lane_train_kernel<1, %d>(vihds::OdeArgs, int)" % solver_id
+    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b}
 
     def gbs(nb, us):
         return nb / (us * 1e-6) / 1e9
 
-    traffic, traffic_src = None, None
-    pmc_file = os.path.join(ROOT, "profiles", "r01_u_pmc_hbm_traffic.json")
+    pmc_kernels = {}
+    pmc_name = "r01_v_pmc_hbm_traffic.json"
+    pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_file) and a.solver == "rk4":
-        pmc = json.load(open(pmc_file))["kernels"].get(kname[dom])
-        if pmc:
-            traffic, traffic_src = pmc["hbm_bytes_corrected"], "profiles/r01_u_pmc_hbm_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+        pmc_kernels = json.load(open(pmc_file))["kernels"]
+
+    def entry(k):
+        pmc = pmc_kernels.get(kname[k])
+        return {"kernel": kname[k], "mean_us": kt[k]["mean_us"], "achieved": gbs(nbytes[k], kt[k]["mean_us"]),
+                "algorithmic_bytes_per_launch": nbytes[k], "traffic": pmc["hbm_bytes_corrected"] if pmc else None}
+
+    fused_step = not a.two_kernel_ode and lanes
+    if fused_step:
+        dom, others = "ode_fused", ["ode_fwd", "ode_bwd"]
+    else:
+        dom = "ode_bwd" if kt["ode_bwd"]["mean_us"] >= kt["ode_fwd"]["mean_us"] else "ode_fwd"
+        others = ["ode_fwd" if dom == "ode_bwd" else "ode_bwd", "ode_fused"]
+    d = entry(dom)
     roofline = {
-        "bound": "hbm", "kernel": kname[dom],
-        "achieved": gbs(nbytes[dom], kt[dom]["mean_us"]), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": gbs(nbytes[dom], kt[dom]["mean_us"]) / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-        "algorithmic_bytes_per_launch": nbytes[dom], "mean_us": kt[dom]["mean_us"],
+        "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": d["achieved"] / HBM_PEAK_GBS, "traffic": d["traffic"],
+        "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
+                           % pmc_name) if d["traffic"] is not None else None,
+        "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "mean_us": d["mean_us"],
         "launches_timed": kt[dom]["launches"],
         "timing": "back-to-back launches of the kernel between one HIP event pair on the launch stream",
-        "other_kernel": {"kernel": kname[oth], "mean_us": kt[oth]["mean_us"],
-                         "achieved": gbs(nbytes[oth], kt[oth]["mean_us"]), "algorithmic_bytes_per_launch": nbytes[oth]},
+        "numerator_note": ("fixed SURVEY 8d numerator: the bytes the forward + adjoint pair moves when the trajectory "
+                           "goes through HBM (30.7 + 20.8 MB).  The fused kernel keeps the trajectory in LDS and itself "
+                           "moves only theta in, logp and d theta out (see traffic)") if fused_step else None,
+        "other_kernels": [entry(k) for k in others],
         "step_algorithmic_bytes": fwd_b + bwd_b,
     }
     if rank != 0:
@@ -274,7 +291,8 @@ def main():
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
-                   "launch": launch_mode, "learning_rate": a.lr, "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
+                   "launch": launch_mode, "learning_rate": a.lr,
+                   "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_ode_logp_grad (fused)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": "iwae-sample shard x%d" % world},
         "final_loss": final_loss, "roofline": roofline,
     }
