@@ -11,7 +11,7 @@ shard = parallel.SampleShard(0, 1)
 for mode in ("graph", "eager"):
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", 36, 200, solver="rk4", device="cuda:0", seed=1, shard=shard, u_rng="kernel",
-        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0)
+        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0, fused_ode_training=True)
     model.train()
     batch = training.train_data
     step = training.graph_step if mode == "graph" else training.step

@@ -20,7 +20,7 @@ def main():
     torch.cuda.set_device(dev)
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", 12, s_total, solver="midpoint", device=dev, seed=5, shard=shard, u_rng="kernel",
-        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0)
+        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0, fused_ode_training=True)
     model.train()
     batch = training.train_data
     step = training.graph_step if mode == "graph" else training.step
