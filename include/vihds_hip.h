@@ -157,6 +157,9 @@ typedef struct vihds_theta_opts {
   /* rng: this call covers samples s_offset .. s_offset+S-1 of S_total per data row (S sharded over ranks: every rank
    * gets the slice of the same global draw). */
   int S_total, s_offset;
+  /* vihds_theta_bwd only: [B][S] factor applied to g_theta (g_theta[p][b][s] * g_theta_scale[b][s]) -- lets the
+   * unit-weight gradient of vihds_ode_logp_grad be consumed without a separate scaling pass. */
+  const float* g_theta_scale;
 } vihds_theta_opts;
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
                     const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
@@ -167,6 +170,27 @@ int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, con
                     const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,
                     const float* u, const float* g_theta, const float* g_log_q, const float* g_log_p,
                     float* g_q_mu, float* g_q_prec, const vihds_theta_opts* opts /* or NULL */, void* stream);
+
+/* The decoder side of a training step in ONE launch (dr_constant / dr_constant_v2, lane-split regime): what
+ * vihds_theta_fwd, vihds_device_condition and vihds_ode_logp_grad do one after the other -- sample and clip theta with
+ * log q / log p, the device-conditioner rows, log-likelihood, unit-weight adjoint -- with theta handed from the
+ * sampling stage to the integrator inside the block.  theta [n_rows][B][S], u, log_q, log_p, logp, g_theta_unit as in
+ * those calls.  opts: q_rows / q_prec_is_log / rng / (S_total, s_offset) as for vihds_theta_fwd.  conditioner: NULL or
+ * E rows starting at first_row (>= P). */
+typedef struct vihds_conditioner {
+  int E, first_row;
+  float w_mean, w_std;
+  const float* z;        /* [E][D] standard normals, or NULL with rng */
+  unsigned int* rng;     /* 4 device words, a state of its own (see vihds_device_condition) */
+  const float* relevance; /* [E][D] */
+  const int* is_default;  /* [E] */
+} vihds_conditioner;
+int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind, const float* q_mu,
+                              const float* q_prec, const float* p_mu, const float* p_prec, const float* clip_lo,
+                              const float* clip_hi, float* u, const vihds_theta_opts* opts,
+                              const vihds_conditioner* conditioner, const float* cond, const float* dev1hot,
+                              const float* times, const float* obs, float* theta, float* log_q, float* log_p,
+                              float* logp, float* g_theta_unit, void* stream);
 
 /* IWAE reduction (vihds/training.py:135-149):  log_w = sum_j logp[j] + log_p - log_q;  per row b:
  * row_max[b] = max_s log_w, row_sumexp[b] = sum_s exp(log_w - row_max[b]).  The host finishes

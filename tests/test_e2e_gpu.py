@@ -253,11 +253,13 @@ def test_two_ranks_sharded_step_matches_single_process_and_segmented_graph_match
     assert single[-1] < single[0]  # and it trains
 
 
-def test_fused_training_path_matches_two_kernel_path():
+@pytest.mark.parametrize("decoder_step", [False, True])
+def test_fused_training_path_matches_two_kernel_path(decoder_step):
     """params.fused_ode_training: one launch (vihds_ode_logp_grad) gives the log-likelihood and the unit-weight
     adjoint, the theta gradient is scaled by the IWAE weights afterwards, and x_states / x_predict are only computed
     if somebody unpacks the decoder result.  Loss and every encoder-parameter gradient must equal the two-kernel path's
-    on the reference fixture, and the lazily built outputs must equal the fixture's trajectories."""
+    on the reference fixture, and the lazily built outputs must equal the fixture's trajectories.
+    decoder_step: sampling and device conditioning run inside the same launch too (vihds_theta_ode_logp_grad)."""
     import e2e_util as E
     from vihds.training import Training
     from vihds.vae import build_model
@@ -265,7 +267,8 @@ def test_fused_training_path_matches_two_kernel_path():
     fx = Fixture("dr_constant_icml_tiny_modeuler")
     outs = {}
     for fused in (False, True):
-        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, fused_ode_training=fused)
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, fused_ode_training=fused,
+                                                               fused_decoder_step=decoder_step)
         model = build_model(args, settings, data, parameters)
         training = Training(args, settings, data, parameters, model)
         model.train()

@@ -19,10 +19,10 @@ int launch_dr_constant_v1(bool backward, int solver, const OdeArgs& a, hipStream
   return launch_ode<DrConstant<1>>(backward, solver, a, st);
 }
 // fused log-likelihood + unit-weight adjoint (lane-split regime only)
-int launch_dr_constant_train_v1(int solver, const OdeArgs& a, hipStream_t st) {
+int launch_dr_constant_train_v1(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts) {
   const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v1());
   if (!lanes) return VIHDS_E_UNSUPPORTED;
-  return launch_dr_lane_train<1>(solver, a, st);
+  return launch_dr_lane_train<1>(solver, a, st, ts);
 }
 int n_slots_dr_constant_v1() { return DrConstant<1>::NSLOT; }
 int n_states_dr_constant_v1() { return DrConstant<1>::N; }

@@ -37,8 +37,8 @@ long long bb_aux_floats(int n, int T, int solver);
 int bb_check(int L, int HS, int HP, int n_const, int C, int D);
 int bb_dump_fields();
 
-int launch_dr_constant_train_v1(int, const OdeArgs&, hipStream_t);
-int launch_dr_constant_train_v2(int, const OdeArgs&, hipStream_t);
+int launch_dr_constant_train_v1(int, const OdeArgs&, hipStream_t, const ThetaStageArgs*);
+int launch_dr_constant_train_v2(int, const OdeArgs&, hipStream_t, const ThetaStageArgs*);
 // vihds_elbo.hip
 void launch_theta_fwd(int, int, int, const int*, const float*, const float*, const float*, const float*, const float*,
                       const float*, float*, float*, float*, float*, const vihds_theta_opts&, hipStream_t);
@@ -172,6 +172,11 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
   return 2 * (4 * n_in + 4);
 }
 
+static vihds_theta_opts theta_opts(const vihds_theta_opts* o) {
+  vihds_theta_opts d = {nullptr, 0, nullptr, 0, 0, nullptr};
+  return o ? *o : d;
+}
+
 int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                         const float* times, const float* obs, float* logp, float* g_theta_unit, void* stream) {
   if (!p || !theta || !cond || !times || !obs || !logp || !g_theta_unit) return fail(VIHDS_E_BADARG, "null argument");
@@ -184,12 +189,59 @@ int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const fl
   if (p->C < 2) return fail(VIHDS_E_BADARG, "dr_constant needs two treatments");
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs;
   a.logp = logp; a.g_theta = g_theta_unit;
-  const int rc = p->model == VIHDS_MODEL_DR_CONSTANT ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream)
-                                                     : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream);
+  const int rc = p->model == VIHDS_MODEL_DR_CONSTANT
+                     ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream, nullptr)
+                     : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream, nullptr);
   if (rc == VIHDS_E_UNSUPPORTED)
     return fail(rc, "shape outside the fused kernel's regime (lane-split size limit, or time grid too long for LDS)");
   if (rc != VIHDS_OK) return fail(rc, "fused kernel launch failed");
   return check_hip("vihds_ode_logp_grad launch");
+}
+
+int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind, const float* q_mu,
+                              const float* q_prec, const float* p_mu, const float* p_prec, const float* clip_lo,
+                              const float* clip_hi, float* u, const vihds_theta_opts* opts,
+                              const vihds_conditioner* co, const float* cond, const float* dev1hot, const float* times,
+                              const float* obs, float* theta, float* log_q, float* log_p, float* logp,
+                              float* g_theta_unit, void* stream) {
+  if (!p || !kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !cond || !times || !obs ||
+      !theta || !logp || !g_theta_unit)
+    return fail(VIHDS_E_BADARG, "null argument");
+  if (p->model != VIHDS_MODEL_DR_CONSTANT && p->model != VIHDS_MODEL_DR_CONSTANT_V2)
+    return fail(VIHDS_E_UNSUPPORTED, "the fused decoder step exists for dr_constant / dr_constant_v2 only");
+  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver");
+  if (P <= 0 || P > p->n_rows) return fail(VIHDS_E_BADARG, "P out of range");
+  const ModelEntry* e = entry(p->model);
+  OdeArgs a;
+  if (int rc = build_args(p, e, a)) return rc;
+  if (p->C < 2) return fail(VIHDS_E_BADARG, "dr_constant needs two treatments");
+  const vihds_theta_opts o = theta_opts(opts);
+  ThetaStageArgs t;
+  std::memset(&t, 0, sizeof(t));
+  t.P = P; t.kind = kind; t.q_mu = q_mu; t.q_prec = q_prec; t.q_rows = o.q_rows; t.prec_is_log = o.q_prec_is_log;
+  t.p_mu = p_mu; t.p_prec = p_prec; t.clip_lo = clip_lo; t.clip_hi = clip_hi; t.u = u; t.rng = o.rng;
+  t.S_total = p->S; t.s_off = 0;
+  if (o.S_total > 0) {
+    if (o.s_offset < 0 || o.s_offset + p->S > o.S_total) return fail(VIHDS_E_BADARG, "bad sample window");
+    t.S_total = o.S_total; t.s_off = o.s_offset;
+  }
+  t.theta = theta; t.log_q = log_q; t.log_p = log_p;
+  if (co && co->E > 0) {
+    if (!dev1hot || !co->relevance || !co->is_default || (!co->z && !co->rng) || p->D <= 0)
+      return fail(VIHDS_E_BADARG, "conditioner: missing input");
+    if (co->first_row < P || co->first_row + co->E > p->n_rows) return fail(VIHDS_E_BADARG, "conditioner rows out of range");
+    t.E = co->E; t.cond_row0 = co->first_row; t.w_mean = co->w_mean; t.w_std = co->w_std; t.z = co->z;
+    t.crng = co->rng; t.rel = co->relevance; t.is_default = co->is_default;
+  }
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs;
+  a.logp = logp; a.g_theta = g_theta_unit;
+  const int rc = p->model == VIHDS_MODEL_DR_CONSTANT
+                     ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream, &t)
+                     : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream, &t);
+  if (rc == VIHDS_E_UNSUPPORTED)
+    return fail(rc, "shape outside the fused kernel's regime (lane-split size limit, or time grid too long for LDS)");
+  if (rc != VIHDS_OK) return fail(rc, "fused kernel launch failed");
+  return check_hip("vihds_theta_ode_logp_grad launch");
 }
 
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
@@ -257,11 +309,6 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   rc = e->launch(true, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_bwd launch");
-}
-
-static vihds_theta_opts theta_opts(const vihds_theta_opts* o) {
-  vihds_theta_opts d = {nullptr, 0, nullptr, 0, 0};
-  return o ? *o : d;
 }
 
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,

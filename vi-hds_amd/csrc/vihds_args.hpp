@@ -30,4 +30,27 @@ struct OdeArgs {
   float init_latent, init_prec;
 };
 
+// Everything the sampling stage needs when it runs inside the decoder-step kernel (vihds_theta_ode_logp_grad):
+// ChainedDistribution.sample + p.clip + log q + log p, then the device conditioner rows.
+struct ThetaStageArgs {
+  int P;
+  const int* kind;
+  const float *q_mu, *q_prec;
+  const int* q_rows;
+  int prec_is_log;
+  const float *p_mu, *p_prec, *clip_lo, *clip_hi;
+  float* u;
+  unsigned int* rng;
+  int S_total, s_off;
+  float* theta;  // same buffer as OdeArgs::theta, written here
+  float *log_q, *log_p;
+  // device conditioner (E = 0: none)
+  int E, cond_row0;
+  float w_mean, w_std;
+  const float* z;
+  unsigned int* crng;
+  const float* rel;
+  const int* is_default;
+};
+
 }  // namespace vihds

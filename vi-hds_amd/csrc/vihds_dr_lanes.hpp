@@ -18,6 +18,7 @@
 
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
+#include "vihds_rng.hpp"
 
 namespace vihds {
 
@@ -570,9 +571,9 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
 // dr_lane_fwd_kernel + dr_lane_bwd_kernel: one launch and one prologue instead of two, no trajectory / x_predict
 // stores (29.7 MB) and no trajectory reads (19.8 MB).  Outputs: logp [4][n] and the unit-weight gradient g_theta.
 template <int VERSION, int SOLVER>
-__global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_max) {
+__device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max, float* lds) {
   using D = DrLanes<VERSION>;
-  extern __shared__ float lds[];  // [T] times | [nb_max][4][T] observations | [T][256] states
+  // lds: [T] times | [nb_max][4][T] observations | [T][256] states
   const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int i0 = blockIdx.x * D::TPB + tl;
   const bool live = i0 < a.n;
@@ -652,6 +653,148 @@ __global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_ma
   dr_lane_write_adjoints<VERSION>(a, i, j, live, L, c, H, A, lam, precb);
 }
 
+
+// The sampling stage of the decoder step, run by the same block before its sweeps (vihds_theta_ode_logp_grad):
+// theta = clip(sample(q, u)) with log q / log p for the block's 32 trajectories (the arithmetic of theta_fwd_lds_kernel;
+// here the 8 lanes of a trajectory own parameter blocks j, j+8, ...), then the device-conditioner rows (the
+// arithmetic of device_condition_kernel).  Writes theta / u / log_q / log_p to global memory; the sweeps read theta
+// back after the barrier.  `scratch` (>= 10 * nb_max * P floats of LDS) holds the per-(row, parameter) constants.
+__device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const ThetaStageArgs& t, int nb_max,
+                                                    float* scratch) {
+  constexpr int TPB = 32;
+  constexpr float LOG2PI = 1.8378770664093453f;
+  const int n = a.n, P = t.P, B = a.B, S = a.S;
+  const int first = blockIdx.x * TPB, last = min(first + TPB, n) - 1;
+  const int b0 = first / S, nb = last / S - b0 + 1;
+  const int stride = nb_max * P;
+  float* t_kind = scratch;
+  float* t_mu = scratch + stride;
+  float* t_sigma = scratch + 2 * stride;
+  float* t_prec = scratch + 3 * stride;
+  float* t_cq = scratch + 4 * stride;
+  float* t_lo = scratch + 5 * stride;
+  float* t_hi = scratch + 6 * stride;
+  float* t_pmu = scratch + 7 * stride;
+  float* t_cp = scratch + 8 * stride;
+  float* t_pprec = scratch + 9 * stride;
+  for (int e = threadIdx.x; e < nb * P; e += 256) {
+    const int bb = e / P, p = e - bb * P, b = b0 + bb;
+    const int kd = t.kind[p];
+    const int rm = t.q_rows ? t.q_rows[p] : p, rp = t.q_rows ? t.q_rows[P + p] : p;
+    const float pr = t.q_prec[rp * B + b];
+    const float prec = (kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(pr) : pr);
+    t_kind[e] = (float)kd;
+    t_mu[e] = t.q_mu[rm * B + b];
+    t_sigma[e] = 1.f / sqrtf(prec);
+    t_prec[e] = prec;
+    t_cq[e] = -LOG2PI + 0.5f * logf(prec + 1e-12f);
+    t_lo[e] = t.clip_lo[p];
+    t_hi[e] = t.clip_hi[p];
+    t_pmu[e] = t.p_mu[p];
+    t_cp[e] = -LOG2PI + 0.5f * logf(t.p_prec[p] + 1e-12f);
+    t_pprec[e] = t.p_prec[p];
+  }
+  __syncthreads();
+  const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
+  const int i0 = first + tl;
+  const bool live = i0 < n;
+  const int i = live ? i0 : n - 1;
+  const int b = i / S;
+  const int row = (b - b0) * P;
+  unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
+  if (t.rng) {
+    k0 = t.rng[0]; k1 = t.rng[1]; step = t.rng[2];
+    gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * S));
+  }
+  float lq = 0.f, lp = 0.f;
+  for (int kb = j; 4 * kb < P; kb += 8) {
+    float z4[4];
+    if (t.rng) philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
+#pragma unroll
+    for (int jj = 0; jj < 4; ++jj) {
+      const int p = 4 * kb + jj;
+      if (p >= P) break;
+      float uu;
+      if (t.rng) {
+        uu = z4[jj];
+        if (live) t.u[(size_t)i * P + p] = uu;
+      } else {
+        uu = t.u[(size_t)i * P + p];
+      }
+      const int e = row + p;
+      const float kdf = t_kind[e], mu = t_mu[e];
+      float x;
+      if (kdf == (float)KIND_CONSTANT) {
+        x = 0.f * uu + mu;
+      } else {
+        const bool ln = kdf == (float)KIND_LOGNORMAL;
+        const float zz = mu + t_sigma[e] * uu;
+        x = ln ? expf(zz) : zz;
+        const float lo = t_lo[e], hi = t_hi[e];
+        x = x < lo ? lo : (x > hi ? hi : x);
+        const float v = ln ? logf(x + 1e-12f) : x;
+        const float jac = ln ? v : 0.f;
+        const float dq = mu - v, dp = t_pmu[e] - v;
+        lq += t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
+        lp += t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
+      }
+      if (live) t.theta[(size_t)p * n + i] = x;
+    }
+  }
+  lq = sum8(lq);
+  lp = sum8(lp);
+  if (live && j == 0) {
+    if (t.log_q) t.log_q[i] = lq;
+    if (t.log_p) t.log_p[i] = lp;
+  }
+  // device conditioner: lane e of the trajectory's group produces row cond_row0 + e
+  if (t.E > 0) {
+    unsigned int c0 = 0, c1 = 0, cstep = 0;
+    if (t.crng) { c0 = t.crng[0]; c1 = t.crng[1]; cstep = t.crng[2]; }
+    const int r = (int)(((long long)b * t.S_total + t.s_off + (i - b * S)) % B);
+    for (int e = j; e < t.E; e += 8) {
+      float c = 0.f;
+      for (int d = 0; d < a.D; ++d) {
+        const float hot = a.dev1hot[r * a.D + d] * t.rel[e * a.D + d];
+        float zz = 0.f;
+        if (t.crng) { if (hot != 0.f) zz = philox_normal((unsigned int)(e * a.D + d), 0xC04Du, cstep, 0u, c0, c1, 0); }
+        else zz = t.z[e * a.D + d];
+        c += (t.w_mean + t.w_std * zz) * hot;
+      }
+      c = fmaxf(c, 0.f);
+      if (live) t.theta[(size_t)(t.cond_row0 + e) * n + i] = (t.is_default[e] ? 1.f : 0.f) + c;
+    }
+  }
+  __syncthreads();  // theta of this block's trajectories is in memory; the scratch region is free again
+}
+// the last block to finish advances a generator's step (every block has read it by then)
+__device__ __forceinline__ void rng_ticket(unsigned int* rng) {
+  if (rng && threadIdx.x == 0) {
+    const unsigned int step = rng[2];
+    const unsigned int ticket = atomicAdd(&rng[3], 1u);
+    if (ticket == gridDim.x - 1) {
+      rng[2] = step + 1u;
+      rng[3] = 0u;
+    }
+  }
+}
+
+template <int VERSION, int SOLVER>
+__global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_max) {
+  extern __shared__ float lds[];
+  dr_lane_train_body<VERSION, SOLVER>(a, nb_max, lds);
+}
+// sampling stage + conditioner + sweeps: the whole decoder side of a training step
+template <int VERSION, int SOLVER>
+__global__ void __launch_bounds__(256) dr_lane_train_theta_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
+  extern __shared__ float lds[];
+  dr_lane_theta_stage(a, t, nb_max, lds + a.T + (size_t)nb_max * 4 * a.T);  // scratch = the (still unused) states region
+  dr_lane_train_body<VERSION, SOLVER>(a, nb_max, lds);
+  __syncthreads();
+  rng_ticket(t.rng);
+  rng_ticket(t.crng);
+}
+
 inline size_t dr_lane_train_lds_bytes(const OdeArgs& a, int tpb, int* nb_max_out) {
   const int nb = min(a.B, (tpb - 1) / a.S + 2);
   if (nb_max_out) *nb_max_out = nb;
@@ -661,10 +804,11 @@ constexpr size_t DR_LANE_TRAIN_MAX_LDS = 160 * 1024;
 
 // returns VIHDS_E_UNSUPPORTED when the states of a block do not fit in LDS (long time grids)
 template <int VERSION>
-inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st) {
+inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
   int nb_max = 0;
   const size_t lds = dr_lane_train_lds_bytes(a, DrLanes<VERSION>::TPB, &nb_max);
   if (lds > DR_LANE_TRAIN_MAX_LDS) return VIHDS_E_UNSUPPORTED;
+  if (ts && (size_t)10 * nb_max * ts->P > (size_t)a.T * 256) return VIHDS_E_UNSUPPORTED;  // stage scratch must fit
   const dim3 grid((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB), block(256);
 #define VIHDS_TCASE(SV)                                                                                         \
   case SV: {                                                                                                    \
@@ -674,7 +818,14 @@ inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st) {
                               (int)lds) != hipSuccess)                                                          \
         return VIHDS_E_HIP;                                                                                     \
     }                                                                                                           \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a, nb_max);                                                  \
+    auto kern_t = dr_lane_train_theta_kernel<VERSION, SV>;                                                      \
+    if (ts && lds > 64 * 1024) {                                                                                \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_t), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              (int)lds) != hipSuccess)                                                          \
+        return VIHDS_E_HIP;                                                                                     \
+    }                                                                                                           \
+    if (ts) hipLaunchKernelGGL(kern_t, grid, block, lds, st, a, nb_max, *ts);                                   \
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, a, nb_max);                                             \
     return VIHDS_OK;                                                                                            \
   }
   switch (solver) {

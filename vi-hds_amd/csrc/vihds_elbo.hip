@@ -6,11 +6,11 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/vihds_hip.h"
+#include "vihds_rng.hpp"
 
 namespace vihds {
 
 constexpr float LOG2PI_F = 1.8378770664093453f;
-enum { KIND_NORMAL = 0, KIND_LOGNORMAL = 1, KIND_CONSTANT = 2 };
 
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
@@ -62,49 +62,6 @@ __device__ __forceinline__ float quad_sum(float v) {
   v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xf, 0xf, false));
   return v;
 }
-// Counter-based standard normals for u (the reference draws u ~ N(0,1)[B,S,P] on the host, vae.py:22-24; this is the
-// graph-capturable device alternative): Philox4x32-10 (Salmon et al., SC'11) keyed by the 64-bit seed, counter =
-// (global sample index b*S_total + s, parameter block p/4, step lo, step hi); the four 32-bit outputs give the four
-// normals of parameters 4k..4k+3 through two Box-Muller pairs, u1 = (x + 0.5) 2^-32, u2 = (y + 0.5) 2^-32,
-// z0 = sqrt(-2 ln u1) cos(2 pi u2), z1 = sqrt(-2 ln u1) sin(2 pi u2).  Independent of the launch geometry and of how
-// S is sharded over ranks.  tests/test_hip_parity.py re-implements it in numpy (with the Random123 known answer).
-__device__ __forceinline__ void philox4x32_10(unsigned int c0, unsigned int c1, unsigned int c2, unsigned int c3,
-                                              unsigned int k0, unsigned int k1, unsigned int* out) {
-#pragma unroll
-  for (int r = 0; r < 10; ++r) {
-    const unsigned int hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-    const unsigned int hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-    c0 = hi1 ^ c1 ^ k0; c1 = lo1; c2 = hi0 ^ c3 ^ k1; c3 = lo0;
-    k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-  }
-  out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-__device__ __forceinline__ void philox_normal4(unsigned int, unsigned int, unsigned int, unsigned int, unsigned int,
-                                               unsigned int, float*);
-__device__ __forceinline__ float philox_normal(unsigned int idx, unsigned int pblock, unsigned int step_lo,
-                                               unsigned int step_hi, unsigned int k0, unsigned int k1, int q) {
-  float z[4];
-  philox_normal4(idx, pblock, step_lo, step_hi, k0, k1, z);
-  return z[q];
-}
-
-// all four normals of one counter: (r0, r1) -> (z0, z1), (r2, r3) -> (z2, z3).  v_log / v_sqrt / v_sin / v_cos
-// (v_sin_f32 and v_cos_f32 take their argument in revolutions, which is exactly u2): the draws only have to be good
-// normals, and whatever is drawn is written out as `u`, so everything downstream sees the same values.
-__device__ __forceinline__ void philox_normal4(unsigned int idx, unsigned int pblock, unsigned int step_lo,
-                                               unsigned int step_hi, unsigned int k0, unsigned int k1, float* z) {
-  unsigned int r[4];
-  philox4x32_10(idx, pblock, step_lo, step_hi, k0, k1, r);
-#pragma unroll
-  for (int h = 0; h < 2; ++h) {
-    const float u1 = fminf(((float)r[2 * h] + 0.5f) * 2.3283064365386963e-10f, 0.99999994f);
-    const float u2 = ((float)r[2 * h + 1] + 0.5f) * 2.3283064365386963e-10f;
-    const float rad = __builtin_amdgcn_sqrtf(-1.3862943611198906f * __builtin_amdgcn_logf(u1));  // -2 ln u1 = -2 ln2 log2 u1
-    z[2 * h] = rad * __builtin_amdgcn_cosf(u2);
-    z[2 * h + 1] = rad * __builtin_amdgcn_sinf(u2);
-  }
-}
-
 // rng: {seed lo, seed hi, step, ticket} or NULL.  With rng the kernel draws u itself and writes it to `u` (the adjoint
 // and the host read it from there); the last block to finish advances the step, so replays of a captured graph get
 // fresh draws without any host-side bookkeeping.
@@ -303,8 +260,9 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
                  const float* __restrict__ q_prec, const int* __restrict__ q_rows, int prec_is_log,
                  const float* __restrict__ p_mu, const float* __restrict__ p_prec,
                  const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, const float* __restrict__ u,
-                 const float* __restrict__ g_theta, const float* __restrict__ g_log_q,
-                 const float* __restrict__ g_log_p, float* __restrict__ g_q_mu, float* __restrict__ g_q_prec) {
+                 const float* __restrict__ g_theta, const float* __restrict__ g_theta_scale,
+                 const float* __restrict__ g_log_q, const float* __restrict__ g_log_p, float* __restrict__ g_q_mu,
+                 float* __restrict__ g_q_prec) {
   static_assert(BLOCK == 64 * THETA_BWD_PCHUNK, "one wave per parameter of the chunk");
   const int n = B * S;
   const int b = blockIdx.x;
@@ -334,6 +292,7 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
     const float glq = g_log_q ? g_log_q[i] : 0.f;
     const float glp = g_log_p ? g_log_p[i] : 0.f;
     float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
+    if (g_theta_scale) gx *= g_theta_scale[i];
     float v, dv_dx;
     if (kd == KIND_LOGNORMAL) { v = logf(x + 1e-12f); dv_dx = 1.f / (x + 1e-12f); }
     else { v = x; dv_dx = 1.f; }
@@ -634,8 +593,8 @@ void launch_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, c
                       const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec,
                       const vihds_theta_opts& o, hipStream_t st) {
   hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B, (P + THETA_BWD_PCHUNK - 1) / THETA_BWD_PCHUNK), dim3(256), 0, st,
-                     P, B, S, kind, q_mu, q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, g_theta, g_log_q,
-                     g_log_p, g_q_mu, g_q_prec);
+                     P, B, S, kind, q_mu, q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, g_theta,
+                     o.g_theta_scale, g_log_q, g_log_p, g_q_mu, g_q_prec);
 }
 void launch_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
                      float* row_max, float* row_sumexp, hipStream_t st) {

@@ -29,6 +29,7 @@ PARAM_DEFAULTS = {
     "encoder_kernel": True,    # q(theta|data) encoder as fused HIP kernels on the GPU (False: nn.Conv1d / nn.Linear)
     "fused_ode_training": False,  # training: log-likelihood + unit-weight adjoint in one launch, no trajectory written
                                # (dr_constant family, lane-split regime; x_states / x_predict then exist on demand only)
+    "fused_decoder_step": True,   # with fused_ode_training: sampling + device conditioning + ODE + adjoint in ONE launch
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
 }

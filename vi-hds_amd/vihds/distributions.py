@@ -319,19 +319,14 @@ class ChainedDistribution(object):
         return self._clip_cache[key]
 
     # ---- the fused hot path ----------------------------------------------------------------------
-    def sample_clip_log_prob(self, list_of_u, p, stddevs, n_extra_rows=0):
-        """q.sample(u) -> p.clip(., stddevs) -> (theta, log q(theta), log p(theta)) in ONE kernel
-        (reference vae.py:31-34 + training.py:136-137).  log q / log p are cached on the returned theta so
-        that the later q.log_prob(theta) / p.log_prob(theta) calls (Training.cost) are free."""
+    def _kernel_inputs(self, list_of_u, p, stddevs):
+        """(names, P, p_mu, p_prec, clip_lo, clip_hi) for the theta kernels."""
         names = self.names()
         P = len(names)
         assert list_of_u.shape[-1] == P, (
             "ChainedDistribution (%s #= %d):: must give a list of u's, one for each distribution."
             % (self.name, list_of_u.shape[-1]))
         dev = list_of_u.device
-        n_batch = list_of_u.shape[0]
-        if isinstance(list_of_u, ops.KernelNormal) and self._packed_q is None:
-            raise RuntimeError("u_rng: kernel needs the encoder's packed q tables")
         if p is None:
             p_mu = p_prec = torch.ones(P, device=dev)
             inf = torch.full((P,), float("inf"), device=dev)
@@ -341,6 +336,26 @@ class ChainedDistribution(object):
             _, pm, pp = p.image(dev, 1)
             p_mu, p_prec = pm[:, 0], pp[:, 0]
             lo, hi = p.clip_image(stddevs, dev)
+        return names, P, p_mu, p_prec, lo, hi
+
+    def _wrap_samples(self, names, theta, log_q, log_p, p, u_used):
+        samples = DotOperatorSamples.from_packed(names, theta)
+        # the standard-normal draws behind these samples (an output when the kernel drew them)
+        object.__setattr__(samples, "_u", u_used)
+        samples._log_prob_cache[id(self)] = log_q
+        if p is not None:
+            samples._log_prob_cache[id(p)] = log_p
+        return samples
+
+    def sample_clip_log_prob(self, list_of_u, p, stddevs, n_extra_rows=0):
+        """q.sample(u) -> p.clip(., stddevs) -> (theta, log q(theta), log p(theta)) in ONE kernel
+        (reference vae.py:31-34 + training.py:136-137).  log q / log p are cached on the returned theta so
+        that the later q.log_prob(theta) / p.log_prob(theta) calls (Training.cost) are free."""
+        names, P, p_mu, p_prec, lo, hi = self._kernel_inputs(list_of_u, p, stddevs)
+        dev = list_of_u.device
+        n_batch = list_of_u.shape[0]
+        if isinstance(list_of_u, ops.KernelNormal) and self._packed_q is None:
+            raise RuntimeError("u_rng: kernel needs the encoder's packed q tables")
         if self._packed_q is not None:
             kind, q_all, _ = self._packed_q
             theta, log_q, log_p, u_used = ops.ThetaSampleLogProbPacked.apply(q_all, kind, p_mu, p_prec, lo, hi,
@@ -349,13 +364,21 @@ class ChainedDistribution(object):
             kind, q_mu, q_prec = self.image(dev, n_batch)
             theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_prec, kind, p_mu, p_prec, lo, hi, list_of_u,
                                                                P + n_extra_rows)
-        samples = DotOperatorSamples.from_packed(names, theta)
-        # the standard-normal draws behind these samples (an output when the kernel drew them)
-        object.__setattr__(samples, "_u", u_used if self._packed_q is not None else list_of_u)
-        samples._log_prob_cache[id(self)] = log_q
-        if p is not None:
-            samples._log_prob_cache[id(p)] = log_p
-        return samples
+            u_used = list_of_u
+        return self._wrap_samples(names, theta, log_q, log_p, p, u_used)
+
+    def decoder_step_fused(self, list_of_u, p, stddevs, n_extra_rows, spec_of, cond, times, obs, dev1hot, cond_job):
+        """sample_clip_log_prob AND the decoder (conditioner rows, log-likelihood, unit-weight adjoint) in one launch
+        (ops.DecoderStepFused).  `spec_of(names)` -> OdeProblemSpec for the packed row order.  Returns
+        (theta samples, logp [4,B,S]); raises ops.FusedTrainingUnsupported when the library declines."""
+        if self._packed_q is None:
+            raise ops.FusedTrainingUnsupported("needs the encoder's packed q tables")
+        names, P, p_mu, p_prec, lo, hi = self._kernel_inputs(list_of_u, p, stddevs)
+        kind, q_all, _ = self._packed_q
+        theta, log_q, log_p, u_used, logp = ops.DecoderStepFused.apply(
+            q_all, kind, p_mu, p_prec, lo, hi, list_of_u, P + n_extra_rows, self._q_rows, spec_of(names), cond, times,
+            obs, dev1hot, cond_job)
+        return self._wrap_samples(names, theta, log_q, log_p, p, u_used), logp
 
     # ---- reference-compatible entry points -------------------------------------------------------------
     def sample(self, list_of_u, device, stop_grad=False):

@@ -66,7 +66,15 @@ class ThetaOpts(ctypes.Structure):
     """struct vihds_theta_opts (include/vihds_hip.h)"""
 
     _fields_ = [("q_rows", ctypes.c_void_p), ("q_prec_is_log", ctypes.c_int), ("rng", ctypes.c_void_p),
-                ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int)]
+                ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int), ("g_theta_scale", ctypes.c_void_p)]
+
+
+class Conditioner(ctypes.Structure):
+    """struct vihds_conditioner (include/vihds_hip.h)"""
+
+    _fields_ = [("E", ctypes.c_int), ("first_row", ctypes.c_int), ("w_mean", ctypes.c_float), ("w_std", ctypes.c_float),
+                ("z", ctypes.c_void_p), ("rng", ctypes.c_void_p), ("relevance", ctypes.c_void_p),
+                ("is_default", ctypes.c_void_p)]
 
 
 class EncoderShape(ctypes.Structure):
@@ -97,6 +105,9 @@ _PROTOTYPES = {
     "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
     "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
     "vihds_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 8),
+    "vihds_theta_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem), _I] + [_P] * 8 + [ctypes.POINTER(ThetaOpts),
+                                                                                     ctypes.POINTER(Conditioner)]
+                                  + [_P] * 10),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
     "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 11 + [ctypes.POINTER(ThetaOpts), _P]),

@@ -119,17 +119,9 @@ class OdeModel(nn.Module):
     # names of attributes condition_theta adds to theta (rows reserved behind the sampled parameters)
     extra_theta_names = ()
 
-    def condition_ones(self, theta, names, dev_1hot):
-        """theta.<name> = device_conditioner(ones, name, dev_1hot) for several names in ONE kernel launch, written
-        straight into rows reserved in theta's packed buffer (falls back to the op-by-op path when theta has no
-        reserved rows, e.g. when it was built by hand)."""
-        n_batch, n_iwae = theta.get_n_batch(), theta.get_n_samples()
-        base = len(theta.samples)
-        if theta.n_reserved_rows() < len(names) or not dev_1hot.is_cuda:
-            ones = torch.ones((n_batch, n_iwae), device=dev_1hot.device)
-            for n in names:
-                setattr(theta, n, self.device_conditioner(ones, n, dev_1hot))
-            return theta
+    def conditioner_job(self, names, dev_1hot):
+        """(relevance [E,D], is_default [E], z or None, w_mean, w_std, rng_state or None) for the conditioner kernel:
+        a fresh N(2, 1.5) weight draw per call as in the reference (ode.py:48), on the stream `conditioner_rng` names."""
         dev = dev_1hot.device
         key = (tuple(names), str(dev))
         if key not in self._relevance_dev:
@@ -148,6 +140,20 @@ class OdeModel(nn.Module):
         else:  # the reference's stream: a fresh DeviceConditioner per name, drawn on the host
             z = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in names], 0).to(dev)
             mean, std = 0.0, 1.0
+        return rel, dflt, z, mean, std, rng_state
+
+    def condition_ones(self, theta, names, dev_1hot):
+        """theta.<name> = device_conditioner(ones, name, dev_1hot) for several names in ONE kernel launch, written
+        straight into rows reserved in theta's packed buffer (falls back to the op-by-op path when theta has no
+        reserved rows, e.g. when it was built by hand)."""
+        n_batch, n_iwae = theta.get_n_batch(), theta.get_n_samples()
+        base = len(theta.samples)
+        if theta.n_reserved_rows() < len(names) or not dev_1hot.is_cuda:
+            ones = torch.ones((n_batch, n_iwae), device=dev_1hot.device)
+            for n in names:
+                setattr(theta, n, self.device_conditioner(ones, n, dev_1hot))
+            return theta
+        rel, dflt, z, mean, std, rng_state = self.conditioner_job(names, dev_1hot)
         with torch.no_grad():
             ops.device_condition(z, dev_1hot, rel, dflt, theta._packed[base: base + len(names)], mean, std,
                                  rng_state, getattr(theta, "_sample_window", None))

@@ -197,6 +197,91 @@ class OdeLogLikFused(torch.autograd.Function):
         return None, g_theta, None, None, None, None
 
 
+class DecoderStepFused(torch.autograd.Function):
+    """The decoder side of a training step in ONE launch (vihds_theta_ode_logp_grad): theta = clip(sample(q, u)) with
+    log q / log p, the device-conditioner rows, the per-species log-likelihood and the unit-weight theta adjoint.
+    Inputs as ThetaSampleLogProbPacked + OdeLogLikFused; `cond_job` = None or (names-count E, first_row, w_mean,
+    w_std, z or None, rng_state or None, relevance, is_default).  Returns (theta, log_q, log_p, u, logp).
+    backward: one theta_bwd launch consuming g_unit scaled by the IWAE weight inside the kernel."""
+
+    @staticmethod
+    def forward(ctx, q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows, q_rows, spec, cond, times, obs, dev1hot,
+                cond_job):
+        _require_cuda(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, q_rows, cond, times, obs)
+        q_all, cond, times, obs = _c(q_all), _c(cond), _c(times), _c(obs)
+        dev1hot = _c(dev1hot)
+        P, B = q_all.shape[0] // 2, q_all.shape[1]
+        opts = hip.ThetaOpts()
+        opts.q_rows, opts.q_prec_is_log = hip.ptr(q_rows), 1
+        if isinstance(u, KernelNormal):
+            rng, u = u, torch.empty(u.shape, device=q_all.device, dtype=torch.float32)
+            opts.rng, opts.S_total, opts.s_offset = rng.state.data_ptr(), rng.S_total, rng.s_offset
+        else:
+            _require_cuda(u)
+            u = _c(u)
+        S, T = u.shape[1], times.shape[0]
+        if n_rows != spec.n_rows:
+            raise RuntimeError("theta has %d rows, problem expects %d" % (n_rows, spec.n_rows))
+        prob = spec.bind(B, S, T)
+        dev = q_all.device
+        theta = torch.empty((n_rows, B, S), device=dev, dtype=torch.float32)
+        log_q = torch.empty((B, S), device=dev, dtype=torch.float32)
+        log_p = torch.empty((B, S), device=dev, dtype=torch.float32)
+        logp = torch.empty((4, B, S), device=dev, dtype=torch.float32)
+        g_unit = torch.empty_like(theta) if spec.covers_all_rows else torch.zeros_like(theta)
+        co = None
+        if cond_job is not None:
+            E, first_row, w_mean, w_std, z, rng_state, rel, dflt = cond_job
+            co = hip.Conditioner()
+            co.E, co.first_row, co.w_mean, co.w_std = E, first_row, w_mean, w_std
+            co.z, co.rng, co.relevance, co.is_default = hip.ptr(z), hip.ptr(rng_state), hip.ptr(rel), hip.ptr(dflt)
+        rc = _launch("decoder_step", lambda: hip.lib().vihds_theta_ode_logp_grad(
+            ctypes.byref(prob), P, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_all), hip.ptr(p_mu), hip.ptr(p_prec),
+            hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u), ctypes.byref(opts),
+            ctypes.byref(co) if co is not None else None, hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+            hip.ptr(theta), hip.ptr(log_q), hip.ptr(log_p), hip.ptr(logp), hip.ptr(g_unit), hip.current_stream()))
+        if rc == hip.E_UNSUPPORTED:
+            raise FusedTrainingUnsupported(hip.lib().vihds_last_error().decode())
+        hip.check(rc, "vihds_theta_ode_logp_grad")
+        ctx.spec = spec
+        ctx.save_for_backward(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, g_unit, theta, cond, times, obs,
+                              dev1hot)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(u)
+        return theta, log_q, log_p, u, logp
+
+    @staticmethod
+    def backward(ctx, g_theta, g_log_q, g_log_p, _g_u, g_logp):
+        (q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, g_unit, theta, cond, times, obs,
+         dev1hot) = ctx.saved_tensors
+        P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
+        opts = hip.ThetaOpts()
+        opts.q_rows, opts.q_prec_is_log = hip.ptr(q_rows), 1
+        keep = None
+        if g_logp is None:
+            g_th = _c(g_theta)
+        elif g_logp.dim() == 3 and g_logp.stride(0) == 0 and g_theta is None:
+            keep = _c(g_logp[0])
+            g_th, opts.g_theta_scale = g_unit, keep.data_ptr()  # the kernel applies the IWAE weight
+        else:
+            if g_logp.dim() == 3 and g_logp.stride(0) == 0:
+                g_ode = g_unit * g_logp[0]
+            else:  # per-species weights: general adjoint through the trajectory
+                with torch.enable_grad():
+                    th = theta.detach().requires_grad_(True)
+                    _t, _x, lp = OdeSolveObserve.apply(ctx.spec, th, cond, times, obs, dev1hot, None)
+                    (g_ode,) = torch.autograd.grad(lp, th, g_logp)
+            g_th = g_ode if g_theta is None else g_ode + g_theta
+        g_log_q, g_log_p = _c(g_log_q), _c(g_log_p)
+        g_all = torch.empty_like(q_all)
+        rc = hip.lib().vihds_theta_bwd(P, B, S, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_all), hip.ptr(p_mu),
+                                       hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u),
+                                       hip.ptr(g_th), hip.ptr(g_log_q), hip.ptr(g_log_p), hip.ptr(g_all),
+                                       hip.ptr(g_all), ctypes.byref(opts), hip.current_stream())
+        hip.check(rc, "vihds_theta_bwd")
+        return (g_all,) + (None,) * 14
+
+
 def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     """dr_blackbox weight gradients from the adjoint kernel's dump: the contraction over (RHS evaluation x
     trajectory) -- K ~ 10^6, M,N <= 25 -- runs as batched library GEMMs (hipBLASLt => MFMA) on strided views of

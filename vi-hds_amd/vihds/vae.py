@@ -19,6 +19,7 @@ class BaseVAE(nn.Module):
         self.u_rng = u_rng
         self.shard = shard  # vihds.parallel.SampleShard or None
         self._rng_state = None
+        self._fused_declined = {}
 
     def sample_u(self, n_batch, n_samples, device=None):
         """Standard-normal draws u [B,S,P].  "numpy" = the reference's host RNG stream (vae.py:22-24);
@@ -45,12 +46,84 @@ class BaseVAE(nn.Module):
         p = self.encoder.p
         ode_model = self.decoder.ode_model
         n_extra = len(ode_model.extra_theta_names) if self.decoder.condition_on_device else 0
+        fused = self._decoder_step_fused(data, samples, u, q, p, n_extra)
+        if fused is not None:
+            return fused + (q, p)
         clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4, n_extra_rows=n_extra)
         if self.shard is not None:
             lo, _ = self.shard.bounds(samples)
             object.__setattr__(clipped_theta, "_sample_window", (samples, lo))
         result, conditioned_theta = self.decoder(clipped_theta, data, writer, epoch)
         return result, conditioned_theta, q, p
+
+
+def _bind_fused(BaseVAE):
+    def _decoder_step_fused(self, data, samples, u, q, p, n_extra):
+        """Training fast path (params.fused_ode_training): sampling, device conditioning, log-likelihood and the
+        unit-weight adjoint in ONE launch (ops.DecoderStepFused).  None when it does not apply."""
+        from vihds import hip, ops
+        from vihds.decoders import LazyDecoderResult
+        from vihds.ode import LazySolution
+
+        dec = self.decoder
+        ode = dec.ode_model
+        cfg = dec.config
+        obs = data.get("observations", None) if hasattr(data, "get") else None
+        if (not torch.is_grad_enabled() or obs is None or not default_get_value(cfg.params, "fused_ode_training", False)
+                or not default_get_value(cfg.params, "fused_decoder_step", True) or ode.model_key not in ode.fused_training_keys or getattr(q, "_packed_q", None) is None
+                or not obs.is_cuda or (n_extra and not dec.condition_on_device)):
+            return None
+        key = (tuple(obs.shape), samples, cfg.params.solver)
+        if self._fused_declined.get(key):
+            return None
+        extra = list(ode.extra_theta_names) if n_extra else []
+        window = None
+        if self.shard is not None:
+            lo, _ = self.shard.bounds(samples)
+            window = (samples, lo)
+
+        def spec_of(names):
+            row_of = {n: k for k, n in enumerate(list(names) + extra)}
+            return ode._spec(cfg, row_of, len(names) + len(extra))
+
+        cond_job = None
+        if extra:
+            rel, dflt, z, mean, std, rng_state = ode.conditioner_job(extra, data.dev_1hot)
+            cond_job = (len(extra), None, mean, std, z, rng_state, rel, dflt)
+        try:
+            n_q = len(q.names())
+            if cond_job is not None:
+                cond_job = (cond_job[0], n_q) + cond_job[2:]
+            if window is not None and not isinstance(u, ops.KernelNormal):
+                return None  # (the conditioner tiling needs the window; only the in-kernel draw carries it)
+            theta, logp = q.decoder_step_fused(u, p, 4, n_extra, spec_of, data.inputs, data.times.to(obs.device), obs,
+                                               data.dev_1hot, cond_job)
+        except ops.FusedTrainingUnsupported:
+            self._fused_declined[key] = True
+            return None
+        for k, n in enumerate(extra):
+            theta.bind_reserved_row(n, n_q + k)
+        if window is not None:
+            object.__setattr__(theta, "_sample_window", window)
+        if hasattr(ode, "aR") and extra:
+            ode.aR, ode.aS = getattr(theta, "aR", None), getattr(theta, "aS", None)
+        sol = LazySolution(logp, lambda: ode.solve(cfg, data.times, theta, data.inputs, data.dev_1hot, obs))
+        ode._last = sol
+
+        def build():
+            full = sol.full()
+            xs, prec = ode.expand_precisions(theta, data.times, full.sol)
+            return xs, ode.observe(full.sol, theta), prec
+
+        result = LazyDecoderResult(build)
+        result.solution = sol
+        result.log_p_by_species = sol.log_p_by_species
+        return result, theta
+
+    BaseVAE._decoder_step_fused = _decoder_step_fused
+
+
+_bind_fused(BaseVAE)
 
 
 def build_model(args, settings, dataset, parameters, shard=None):
