@@ -237,6 +237,24 @@ def main():
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
     kt = ode_kernel_times(model, settings, batch, N_IWAE * world, a.roofline_steps)
+    # the step's own decoder launch (sampling + conditioning + sweeps), re-issued back to back with its own arguments
+    rec = ops.LaunchRecorder()
+    ops.TIMER = rec
+    training.step(batch)
+    ops.TIMER = None
+    step_launch = rec.calls.get("decoder_step")
+    if step_launch is not None:
+        st = torch.cuda.current_stream()
+        for _ in range(3):
+            step_launch()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(st)
+        for _ in range(a.roofline_steps):
+            step_launch()
+        e1.record(st)
+        torch.cuda.synchronize()
+        kt["ode_step"] = {"mean_us": e0.elapsed_time(e1) * 1e3 / a.roofline_steps, "launches": a.roofline_steps}
     fwd_b, bwd_b = algorithmic_bytes(B_ROWS, N_IWAE)
     solver_id = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}[a.solver]
     lanes = B_ROWS * N_IWAE <= 16384  # the library's automatic choice (vihds_dr_lanes.hpp)
@@ -244,13 +262,16 @@ def main():
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
     kname["ode_fused"] = "void vihds::dr_lane_train_kernel<1, %d>(vihds::OdeArgs, int)" % solver_id
-    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b}
+    kname["ode_step"] = ("void vihds::dr_lane_train_theta_kernel<1, %d>(vihds::OdeArgs, int, vihds::ThetaStageArgs)"
+                         % solver_id)
+    theta_b = 4 * (2 * N_PARAMS * B_ROWS * N_IWAE + 2 * B_ROWS * N_IWAE)  # the sampling stage's u, theta, log q, log p
+    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b, "ode_step": fwd_b + bwd_b + theta_b}
 
     def gbs(nb, us):
         return nb / (us * 1e-6) / 1e9
 
     pmc_kernels = {}
-    pmc_name = "r01_v_pmc_hbm_traffic.json"
+    pmc_name = "r01_w_pmc_hbm_traffic.json"
     pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_file) and a.solver == "rk4":
         pmc_kernels = json.load(open(pmc_file))["kernels"]
@@ -261,11 +282,14 @@ def main():
                 "algorithmic_bytes_per_launch": nbytes[k], "traffic": pmc["hbm_bytes_corrected"] if pmc else None}
 
     fused_step = not a.two_kernel_ode and lanes
-    if fused_step:
+    if fused_step and "ode_step" in kt:
+        dom, others = "ode_step", ["ode_fused", "ode_fwd", "ode_bwd"]
+    elif fused_step:
         dom, others = "ode_fused", ["ode_fwd", "ode_bwd"]
     else:
         dom = "ode_bwd" if kt["ode_bwd"]["mean_us"] >= kt["ode_fwd"]["mean_us"] else "ode_fwd"
         others = ["ode_fwd" if dom == "ode_bwd" else "ode_bwd", "ode_fused"]
+    others = [k for k in others if k in kt]
     d = entry(dom)
     roofline = {
         "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -276,8 +300,9 @@ def main():
         "launches_timed": kt[dom]["launches"],
         "timing": "back-to-back launches of the kernel between one HIP event pair on the launch stream",
         "numerator_note": ("fixed SURVEY 8d numerator: the bytes the forward + adjoint pair moves when the trajectory "
-                           "goes through HBM (30.7 + 20.8 MB).  The fused kernel keeps the trajectory in LDS and itself "
-                           "moves only theta in, logp and d theta out (see traffic)") if fused_step else None,
+                           "goes through HBM (30.7 + 20.8 MB; + 2.1 MB for the sampling stage when it runs in the same "
+                           "launch).  The fused kernel keeps the trajectory in LDS and itself moves only the draws, "
+                           "theta, the log-probabilities and d theta (see traffic)") if fused_step else None,
         "other_kernels": [entry(k) for k in others],
         "step_algorithmic_bytes": fwd_b + bwd_b,
     }
@@ -292,7 +317,7 @@ def main():
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
                    "launch": launch_mode, "learning_rate": a.lr,
-                   "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_ode_logp_grad (fused)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
+                   "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": "iwae-sample shard x%d" % world},
         "final_loss": final_loss, "roofline": roofline,
     }

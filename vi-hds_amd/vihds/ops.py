@@ -37,7 +37,19 @@ class KernelTimer(object):
         return out
 
 
-TIMER = None  # set to a KernelTimer to time every ODE kernel launch
+class LaunchRecorder(object):
+    """Keeps the launch closure of every named ODE kernel launch (pointers bound, buffers kept alive by the
+    closure) so that bench.py can re-issue exactly the step's own launch back to back for its roofline leg."""
+
+    def __init__(self):
+        self.calls = {}
+
+    def launch(self, name, fn):
+        self.calls[name] = fn
+        return fn()
+
+
+TIMER = None  # set to a KernelTimer / LaunchRecorder to time / record every ODE kernel launch
 
 
 def _launch(name, fn):
