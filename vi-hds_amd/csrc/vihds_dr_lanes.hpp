@@ -823,16 +823,15 @@ inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st, co
 #define VIHDS_TCASE(SV)                                                                                         \
   case SV: {                                                                                                    \
     auto kern = dr_lane_train_kernel<VERSION, SV>;                                                              \
-    if (lds > 64 * 1024) {                                                                                      \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds) != hipSuccess)                                                          \
-        return VIHDS_E_HIP;                                                                                     \
-    }                                                                                                           \
     auto kern_t = dr_lane_train_theta_kernel<VERSION, SV>;                                                      \
-    if (ts && lds > 64 * 1024) {                                                                                \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern_t), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              (int)lds) != hipSuccess)                                                          \
+    static size_t allowed = 64 * 1024, allowed_t = 64 * 1024; /* dynamic LDS opted in to so far, per kernel */  \
+    size_t& have = ts ? allowed_t : allowed;                                                                    \
+    if (lds > have) {                                                                                           \
+      const void* f = ts ? reinterpret_cast<const void*>(kern_t) : reinterpret_cast<const void*>(kern);         \
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DR_LANE_TRAIN_MAX_LDS) !=     \
+          hipSuccess)                                                                                           \
         return VIHDS_E_HIP;                                                                                     \
+      have = DR_LANE_TRAIN_MAX_LDS;                                                                             \
     }                                                                                                           \
     if (ts) hipLaunchKernelGGL(kern_t, grid, block, lds, st, a, nb_max, *ts);                                   \
     else hipLaunchKernelGGL(kern, grid, block, lds, st, a, nb_max);                                             \
