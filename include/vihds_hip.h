@@ -277,6 +277,22 @@ int vihds_encoder_bwd(const vihds_encoder_shape* s, const float* g_all, const fl
                       float* g_lin_w, float* g_lin_b, float* g_local_w, float* g_local_b, float* g_gcond_w,
                       float* g_global_free, void* stream);
 
+/* Rectangular blocks of the Gram matrix of a field-major buffer X [n_fields][n_columns] (row stride n_columns):
+ *   out[dest0 + i*dest_stride_a + j*dest_stride_b] = sum_c X[a0+i][c] * X[b0+j][c],  i < na, j < nb, per rectangle.
+ * This is the dr_blackbox weight-gradient contraction over the adjoint kernel's dump (aux of vihds_ode_bwd: fields x
+ * (RHS evaluations x trajectories)): every weight gradient of NeuralStates / NeuralPrecisions (reference vihds/ode.py:
+ * 134-138, precisions.py:76-87, obtained there by autograd) is the dot product of a pre-activation-adjoint row and a
+ * layer-input row, and the pairs form dense rectangles.  The buffer is read once; fixed summation order.
+ * scratch: vihds_gram_scratch_floats floats. */
+#define VIHDS_GRAM_MAX_RECTS 8
+typedef struct vihds_gram_rect {
+  int a0, na, b0, nb;
+  int dest0, dest_stride_a, dest_stride_b;
+} vihds_gram_rect;
+long long vihds_gram_scratch_floats(long long n_columns, int n_rects, const vihds_gram_rect* rects);
+int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihds_gram_rect* rects, const float* X,
+                      float* scratch, float* out, void* stream);
+
 /* Adam update of the encoder / decoder-network parameters (reference training.py:82,338: torch.optim.Adam, default
  * betas/eps, no weight decay, no amsgrad) as one launch over up to VIHDS_ADAM_MAX_TENSORS parameter tensors:
  *   m += (g - m)(1-beta1);  v = beta2 v + (1-beta2) g^2;  t = step+1

@@ -54,6 +54,9 @@ void launch_iwae_combine(int, int, int, float, const float*, const float*, float
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
+// vihds_gram.hip
+long long gram_scratch_floats(long long, int, const vihds_gram_rect*);
+int launch_gram(int, long long, int, const vihds_gram_rect*, const float*, float*, float*, hipStream_t);
 // vihds_encoder.hip
 size_t encoder_fwd_lds_bytes(const vihds_encoder_shape&);
 size_t encoder_bwd_lds_bytes(const vihds_encoder_shape&);
@@ -455,6 +458,20 @@ int vihds_encoder_bwd(const vihds_encoder_shape* s, const float* g_all, const fl
   launch_encoder_bwd(*s, g_all, delta_obs, inputs, dev1hot, lin_w, local_w, pooled, hidden, g_pre, g_conv, g_conv_w,
                      g_conv_b, g_lin_w, g_lin_b, g_local_w, g_local_b, g_gcond_w, g_global_free, (hipStream_t)stream);
   return check_hip("vihds_encoder_bwd launch");
+}
+
+long long vihds_gram_scratch_floats(long long n_columns, int n_rects, const vihds_gram_rect* rects) {
+  if (n_columns <= 0 || !rects) return VIHDS_E_BADARG;
+  return gram_scratch_floats(n_columns, n_rects, rects);
+}
+
+int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihds_gram_rect* rects, const float* X,
+                      float* scratch, float* out, void* stream) {
+  if (n_fields <= 0 || n_columns <= 0 || !rects || !X || !scratch || !out) return fail(VIHDS_E_BADARG, "bad argument");
+  const int rc = launch_gram(n_fields, n_columns, n_rects, rects, X, scratch, out, (hipStream_t)stream);
+  if (rc == VIHDS_E_UNSUPPORTED) return fail(rc, "too many 4x4 register tiles (128 max) or fields (126 max) per call");
+  if (rc != VIHDS_OK) return fail(rc, "bad rectangle");
+  return check_hip("vihds_gram_blocks launch");
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,

@@ -84,6 +84,12 @@ class EncoderShape(ctypes.Structure):
                                             "ng", "g_tr", "g_dv", "ngl", "nc")]
 
 
+class GramRect(ctypes.Structure):
+    """struct vihds_gram_rect (include/vihds_hip.h)"""
+
+    _fields_ = [(n, ctypes.c_int) for n in ("a0", "na", "b0", "nb", "dest0", "dest_stride_a", "dest_stride_b")]
+
+
 ADAM_MAX_TENSORS = 32
 
 
@@ -121,6 +127,8 @@ _PROTOTYPES = {
     "vihds_device_condition": (_I, [_I] * 6 + [ctypes.c_float, ctypes.c_float] + [_P] * 7),
     "vihds_encoder_fwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 16),
     "vihds_encoder_bwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 19),
+    "vihds_gram_scratch_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _P]),
+    "vihds_gram_blocks": (_I, [_I, ctypes.c_longlong, _I] + [_P] * 5),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 4 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

@@ -100,6 +100,7 @@ class OdeProblemSpec:
         self.proto.init_prec = init_prec
         self.proto.kernel_variant = kernel_variant
         self.covers_all_rows = len({row_of[s] for s in self.slots}) == n_rows
+        self.cache = {}  # device-side constants derived from this spec
 
     def bind(self, B, S, T):
         p = hip.OdeProblem()
@@ -294,11 +295,65 @@ class DecoderStepFused(torch.autograd.Function):
         return (g_all,) + (None,) * 14
 
 
+def _blackbox_grad_plan(spec, prob, device):
+    """Index tables for the dr_blackbox weight gradients (built once per spec and device): which two dump rows every
+    Gram-type gradient entry multiplies and where it lands in the flat weight buffer (NeuralStates.flat / the order
+    DR_Blackbox.neural_weights() concatenates: Wh, bh, Wp, bp, Wd, bd of the state network, then of the precision
+    network), and where the remaining (time-invariant-input and bias) entries go."""
+    key = ("grad_plan", str(device))
+    if key in spec.cache:
+        return spec.cache[key]
+    HS, HP, L = prob.n_hidden_states, prob.n_hidden_prec, prob.n_latent_states
+    NX, nc = 4 + L, prob.n_const
+    ZA, ZD, RHS, RGS = 0, NX, 2 * NX, 2 * NX + HS
+    RY = RGS + HS
+    RT = RY + NX
+    ZAP, ZDP = RT + 1, RT + 5
+    RHP = RT + 9
+    RGP = RHP + HP
+    ws, wp = NX + nc, 1 + NX + nc  # row widths of the two hidden layers
+    o = [0]
+    for size in (HS * ws, HS, NX * HS, NX, NX * HS, NX, HP * wp, HP, 4 * HP, 4, 4 * HP, 4):
+        o.append(o[-1] + size)
+    # (a0, na, b0, nb, dest0, dest stride over a, dest stride over b)
+    rects = [(RGS, HS, RY, NX, o[0], ws, 1),          # Wh[:, :NX] = gs x y
+             (ZA, NX, RHS, HS, o[2], HS, 1),          # Wp of the states = za x hs
+             (ZD, NX, RHS, HS, o[4], HS, 1),          # Wd of the states = zd x hs
+             (RGP, HP, RT, 1, o[6], wp, 1),           # Vh[:, 0] = gp x t
+             (RGP, HP, RY, NX, o[6] + 1, wp, 1),      # Vh[:, 1:1+NX] = gp x y
+             (ZAP, 4, RHP, HP, o[8], HP, 1),          # Wp of the precisions = zap x hp
+             (ZDP, 4, RHP, HP, o[10], HP, 1)]         # Wd of the precisions = zdp x hp
+    dest = []
+    for (a0, na, b0, nb, d0, sa, sb) in rects:
+        dest += [d0 + i * sa + j * sb for i in range(na) for j in range(nb)]
+    # the rest, in the order [g_const (HS+HP rows x nc), b_hid (HS+HP), bias_sums (2NX + 8)]
+    rest = []
+    for h in range(HS):
+        rest += [o[0] + h * ws + NX + k for k in range(nc)]
+    for h in range(HP):
+        rest += [o[6] + h * wp + 1 + NX + k for k in range(nc)]
+    rest += list(range(o[1], o[2])) + list(range(o[7], o[8]))
+    rest += list(range(o[3], o[4])) + list(range(o[5], o[6])) + list(range(o[9], o[10])) + list(range(o[11], o[12]))
+    ti = lambda v, dt=torch.int32: torch.tensor(v, dtype=dt, device=device)  # noqa: E731
+    n_lat = prob.n_const - prob.C - prob.D
+    rect_arr = (hip.GramRect * len(rects))()
+    for k, r in enumerate(rects):
+        (rect_arr[k].a0, rect_arr[k].na, rect_arr[k].b0, rect_arr[k].nb, rect_arr[k].dest0, rect_arr[k].dest_stride_a,
+         rect_arr[k].dest_stride_b) = r
+    plan = {"rects": rect_arr, "n_rects": len(rects), "rest": ti(rest, torch.int64), "total": o[12],
+            "latent_rows": ti([prob.slot_row[q] for q in range(n_lat)], torch.int64)}
+    assert len(set(dest) | set(rest)) == o[12] == len(dest) + len(rest)
+    spec.cache[key] = plan
+    return plan
+
+
 def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
-    """dr_blackbox weight gradients from the adjoint kernel's dump: the contraction over (RHS evaluation x
-    trajectory) -- K ~ 10^6, M,N <= 25 -- runs as batched library GEMMs (hipBLASLt => MFMA) on strided views of
-    the dump; the time-invariant input columns and the hidden biases come from Delta = sum_evals(gs)."""
-    B, S, T = prob.B, prob.S, prob.T
+    """dr_blackbox weight gradients from the adjoint kernel's dump.  The contraction over (RHS evaluation x trajectory)
+    -- K ~ 10^6 columns, seven dense (row block x row block) rectangles -- is ONE pass over the dump
+    (vihds_gram_blocks) writing straight
+    into the flat weight-gradient buffer; the time-invariant input columns and the biases come from the dump's tail
+    (Delta = sum_evals(gs), bias sums) with a handful of small ops."""
+    B, S = prob.B, prob.S
     n = B * S
     F = hip.lib().vihds_blackbox_dump_fields()
     HS, HP, L = prob.n_hidden_states, prob.n_hidden_prec, prob.n_latent_states
@@ -306,39 +361,25 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     NP = HS + HP
     n_tail = NP + 2 * NX + 8
     E = (aux.numel() - n_tail * n) // (F * n)
-    # field-major dump; viewed [E, rows, n] so the contraction is a strided batched GEMM over the E evaluations
-    # (split-K over evaluations: a single GEMM with K = E*n ~ 10^6 runs on one workgroup in hipBLASLt)
-    D = aux[: F * E * n].view(F, E, n).permute(1, 0, 2)
+    plan = _blackbox_grad_plan(spec, prob, theta.device)
+    g_w = torch.empty(plan["total"], device=theta.device, dtype=torch.float32)
+    n_scr = hip.lib().vihds_gram_scratch_floats(E * n, plan["n_rects"], plan["rects"])
+    if n_scr <= 0:
+        raise RuntimeError("vihds_gram_scratch_floats: %s" % hip.lib().vihds_last_error().decode())
+    scratch = torch.empty(n_scr, device=theta.device, dtype=torch.float32)
+    rc = hip.lib().vihds_gram_blocks(F, E * n, plan["n_rects"], plan["rects"], hip.ptr(aux), hip.ptr(scratch),
+                                     hip.ptr(g_w), hip.current_stream())
+    hip.check(rc, "vihds_gram_blocks")
     tail = aux[F * E * n:].view(n_tail, n)
-    delta, bias_sums = tail[:NP], tail[NP:].sum(1)
-    o = 0
-    za_zd = D[:, o: o + 2 * NX]; o += 2 * NX
-    hs = D[:, o: o + HS]; o += HS
-    gs = D[:, o: o + HS]; o += HS
-    y = D[:, o: o + NX]
-    y_t = D[:, o: o + NX + 1]; o += NX + 1   # states followed by the evaluation time
-    zap_zdp = D[:, o: o + 8]; o += 8
-    hp = D[:, o: o + HP]; o += HP
-    gp = D[:, o: o + HP]; o += HP
-    g_out_s = torch.bmm(za_zd, hs.transpose(1, 2)).sum(0)     # [2NX, HS]: d Wp ; d Wd
-    g_in_s = torch.bmm(gs, y.transpose(1, 2)).sum(0)          # [HS, NX]:  d Wh[:, :NX]
-    g_out_p = torch.bmm(zap_zdp, hp.transpose(1, 2)).sum(0)   # [8, HP]
-    g_yt = torch.bmm(gp, y_t.transpose(1, 2)).sum(0)          # [HP, NX+1]
-    g_in_p = torch.cat([g_yt[:, NX:], g_yt[:, :NX]], 1)       # d Vh[:, :1+NX]: time column first, then the states
-    b_out_s, b_out_p = bias_sums[: 2 * NX], bias_sums[2 * NX:]
+    delta = tail[:NP]
     # time-invariant inputs as the kernel saw them: latent theta rows (slot order), treatments, device one-hot
-    n_lat = prob.n_const - prob.C - prob.D
-    rows = torch.tensor([prob.slot_row[q] for q in range(n_lat)], device=theta.device)
-    const = torch.cat([theta.reshape(theta.shape[0], n)[rows],
+    const = torch.cat([theta.reshape(theta.shape[0], n)[plan["latent_rows"]],
                        cond.t().unsqueeze(2).expand(-1, -1, S).reshape(prob.C, n),
                        dev1hot.t().unsqueeze(2).expand(-1, -1, S).reshape(prob.D, n)], 0)  # [n_const, n]
     g_const = delta @ const.t()                               # [HS+HP, n_const]
-    b_hid = delta.sum(1)
-    parts = [torch.cat([g_in_s, g_const[:HS]], 1).reshape(-1), b_hid[:HS], g_out_s[:NX].reshape(-1), b_out_s[:NX],
-             g_out_s[NX:].reshape(-1), b_out_s[NX:],
-             torch.cat([g_in_p, g_const[HS:]], 1).reshape(-1), b_hid[HS:], g_out_p[:4].reshape(-1),
-             b_out_p[:4], g_out_p[4:].reshape(-1), b_out_p[4:]]
-    return torch.cat(parts)
+    sums = tail.sum(1)                                        # [b_hid (HS+HP) ; bias sums (2NX + 8)]
+    g_w.index_copy_(0, plan["rest"], torch.cat([g_const.reshape(-1), sums]))
+    return g_w
 
 
 class ThetaSampleLogProb(torch.autograd.Function):

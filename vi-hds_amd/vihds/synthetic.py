@@ -55,7 +55,31 @@ def dr_constant_icml_spec(solver="rk4"):
     }
 
 
-WORKLOADS = {"dr_constant_icml": (dr_constant_icml_spec, 86)}
+def dr_blackbox_icml_spec(solver="midpoint"):
+    """The black-box ICML experiment (BASELINE config 4): same plate and devices, MLP right-hand side 27->25->6 and
+    MLP precisions 28->20->4, standard-normal z / y / x as in the reference's specs/dr_blackbox_icml.yaml."""
+    sn = {"distribution": "standard_normal"}
+    base = dr_constant_icml_spec(solver)
+    return {
+        "data": {k: v for k, v in base["data"].items() if k != "default_devices"},
+        "model": "dr_blackbox",
+        "params": {
+            "n_z": 5, "n_y": 2, "n_x": 5, "n_latent_species": 2, "n_hidden_decoder": 25,
+            "n_hidden_decoder_precisions": 20, "lambda_l2": 0.1, "lambda_l2_hidden": 0.1,
+            "learning_boundaries": [250], "learning_rate": 0.005, "learning_gamma": 0.2, "solver": solver,
+            "constant": {"init_x": 0.002, "init_rfp": 0.0, "init_yfp": 0.0, "init_cfp": 0.0},
+            "shared": {"init_data_log_precision": {"distribution": "Normal", "mu": 5000.0, "sigma": 200.0},
+                       "standard_normal": {"distribution": "Normal", "mu": 0.0, "sigma": 1.0}},
+            "global": {"x%d" % k: dict(sn) for k in range(1, 6)},
+            "global_conditioned": dict({"conditioning": {"devices": True, "treatments": False}},
+                                       **{"y%d" % k: dict(sn) for k in (1, 2)}),
+            "local": dict({"conditioning": {"devices": True, "treatments": False}},
+                          **{"z%d" % k: dict(sn) for k in range(1, 6)}),
+        },
+    }
+
+
+WORKLOADS = {"dr_constant_icml": (dr_constant_icml_spec, 86), "dr_blackbox_icml": (dr_blackbox_icml_spec, 86)}
 
 
 class SyntheticPlateDataset(Dataset):
@@ -155,7 +179,7 @@ def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=No
     idx = np.arange(n_rows)
     data = TimeSeriesDatasetPair(Subset(ds, idx), Subset(ds, idx), settings.data)
     parameters = Parameters(settings.params)
-    if settings.device.type == "cuda":
+    if settings.device.type == "cuda" and workload == "dr_constant_icml":
         simulate_observations(settings, parameters, ds, settings.device, seed)
     elif observations is not None:
         ds.observations = observations
