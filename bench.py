@@ -7,9 +7,11 @@
 One "step" = Training._run_batch semantics (reference vihds/training.py:324-340): draw u -> encoder -> sample/clip
 theta + log q/log p (theta kernel) -> integrate + observe + log-likelihood (ODE kernel) -> IWAE loss -> backward
 through all three hand-written adjoints and the encoder -> Adam.  Inputs (the 36-row batch) are resident in HBM;
-u is drawn on the device inside the step.  N > 1: the IWAE-sample axis is sharded, every rank integrates 200
-samples per row (weak scaling: global n_iwae = 200*N), two [36]-float all-reduces combine the row logsumexp and
-one flat all-reduce sums the parameter gradients; `value` counts N step-equivalents per iteration.
+u is drawn on the device inside the step.  N > 1 (weak scaling, `value` counts N step-equivalents per iteration):
+--shard rows (default) = data parallel, every rank runs the whole step on its own 36 rows x 200 samples and the
+parameter gradients are averaged with ONE all-reduce per step (global batch 36*N rows at n_iwae = 200);
+--shard samples = every rank holds the same 36 rows and 200 of the 200*N samples per row, the row (max, sum-exp)
+pairs are all-gathered and one all-reduce sums the gradients.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
 (ODE adjoint) and `cpu_baseline` (the oracle's op-by-op CPU restatement of the same step, timed here)."""
@@ -166,6 +168,10 @@ def main():
     ap.add_argument("--device-rng", choices=["kernel", "device"], default="kernel",
                     help="kernel: u and the conditioner weights are drawn inside the HIP kernels (counter-based "
                          "Philox); device: torch.randn on the GPU")
+    ap.add_argument("--shard", choices=["rows", "samples"], default="rows",
+                    help="N > 1: 'rows' = data parallel, every GPU its own 36 rows x 200 samples, gradients averaged with "
+                         "one all-reduce per step; 'samples' = the same 36 rows on every GPU, the IWAE-sample axis split "
+                         "(200 per GPU), row statistics all-gathered + one gradient all-reduce")
     ap.add_argument("--two-kernel-ode", action="store_true",
                     help="integrate and differentiate with vihds_ode_fwd + vihds_ode_bwd (trajectory through HBM) "
                          "instead of the fused vihds_ode_logp_grad")
@@ -189,15 +195,21 @@ def main():
                          % (a.gpus, world))
     shard = parallel.init_from_env()
     rank = shard.rank if shard is not None else 0
+    replica = None
+    if shard is not None and a.shard == "rows":  # data parallel over rows: replicas + one gradient all-reduce
+        replica, shard = parallel.RowReplica(shard.rank, shard.world, shard.group), None
+    multi = shard is not None or replica is not None
     local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
     use_graph = not a.eager and not a.host_rng
-    if shard is not None and os.environ.get("VIHDS_BENCH_MULTI_EAGER"):
+    if multi and os.environ.get("VIHDS_BENCH_MULTI_EAGER"):
         use_graph = False  # (multi-rank steps are captured as hipGraph segments with eager collectives in between)
-    # every rank: same seed => same encoder init, same DeviceConditioner draws, same full u (sliced per rank)
+    # every rank: same seed => same encoder init; --shard samples: same draws too (each rank takes its slice);
+    # --shard rows: own plate rows and own draws per rank
+    n_iwae_model = N_IWAE * world if shard is not None else N_IWAE
     args, settings, data, parameters, model, training = synthetic.build(
-        "dr_constant_icml", B_ROWS, N_IWAE * world, solver=a.solver, device=dev, seed=a.seed, shard=shard,
+        "dr_constant_icml", B_ROWS, n_iwae_model, solver=a.solver, device=dev, seed=a.seed, shard=shard, replica=replica,
         u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
         hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, fused_ode_training=not a.two_kernel_ode)
     model.train()
@@ -206,7 +218,7 @@ def main():
     launch_mode = "hipGraph replay" if use_graph else "eager"
     def barrier():
         torch.cuda.synchronize()
-        if shard is not None:
+        if multi:
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
@@ -218,7 +230,7 @@ def main():
         loss = step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
-    if shard is not None:
+    if multi:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
@@ -236,7 +248,7 @@ def main():
                               "final_loss": final_loss, "note": "roofline leg skipped (--roofline-steps 0)"}))
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
-    kt = ode_kernel_times(model, settings, batch, N_IWAE * world, a.roofline_steps)
+    kt = ode_kernel_times(model, settings, batch, n_iwae_model, a.roofline_steps)
     # the step's own decoder launch (sampling + conditioning + sweeps), re-issued back to back with its own arguments
     rec = ops.LaunchRecorder()
     ops.TIMER = rec
@@ -315,10 +327,14 @@ def main():
         "dtype": "f32", "data": "synthetic",
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
-                   "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": N_IWAE * world,
+                   "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
+                   "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "learning_rate": a.lr,
                    "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
-                   "parallelism": "iwae-sample shard x%d" % world},
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "data parallel over rows x%d (36 rows per GPU, one gradient all-reduce per step)" % world
+                                   if replica is not None else "iwae-sample shard x%d (all-gather of row statistics + "
+                                   "one gradient all-reduce per step)" % world)},
         "final_loss": final_loss, "roofline": roofline,
     }
     if world == 1 and not a.no_cpu_baseline:

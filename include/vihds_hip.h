@@ -309,7 +309,9 @@ typedef struct vihds_adam_tensors {
   const float* grad[VIHDS_ADAM_MAX_TENSORS]; /* NULL: tensor received no gradient this step, skipped */
 } vihds_adam_tensors;
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                    float beta1, float beta2, float eps, void* stream);
+                    float beta1, float beta2, float eps, float grad_scale, void* stream);
+/* grad_scale multiplies every gradient as it is read (1/world after a SUM all-reduce: the average of the replicas'
+ * gradients at no extra pass). */
 
 #ifdef __cplusplus
 }

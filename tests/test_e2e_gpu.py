@@ -291,3 +291,20 @@ def test_fused_training_path_matches_two_kernel_path(decoder_step):
     assert abs(outs[True][0] - float(fx.t("loss"))) <= 1e-4 * abs(float(fx.t("loss")))
     for k, g in outs[False][1].items():
         assert rel_err(outs[True][1][k], g) < 1e-5, k
+
+
+def test_two_replicas_row_data_parallel_plumbing():
+    """--shard rows: every rank runs the whole step on its own rows and the gradients are averaged (one all-reduce, the
+    1/world factor applied inside the Adam kernel).  With both replicas fed the SAME rows and draws the averaged step
+    must reproduce the single-process step exactly -- eager and as hipGraph segments around the collective -- and
+    with different rows per replica it must still train."""
+    S = 16
+    single = _run_worker("eager", 8, S, 1)
+    same_eager = _run_worker("dp-same-eager", 8, S, 2)
+    same_graph = _run_worker("dp-same-graph", 5, S, 2)
+    for a, b in zip(single, same_eager):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (single, same_eager)
+    for k in range(5):
+        assert abs(same_graph[k] - same_eager[k + 3]) <= 2e-4 * max(1.0, abs(same_eager[k + 3])), (same_graph, same_eager)
+    diff = _run_worker("dp-diff-graph", 30, S, 2)
+    assert all(np.isfinite(diff)) and min(diff[-5:]) < diff[0]

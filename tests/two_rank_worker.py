@@ -16,10 +16,16 @@ def main():
     mode, steps, s_total = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
     shard = parallel.init_from_env()
     rank = shard.rank if shard is not None else 0
+    replica = None
+    if mode.startswith("dp-"):  # data parallel over rows; "dp-same-*": every replica gets the same rows and draws
+        replica, shard = (parallel.RowReplica(shard.rank, shard.world) if shard is not None else None), None
+    same = mode.startswith("dp-same")
+    mode = mode.split("-")[-1]
     dev = "cuda:%s" % os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(dev)
     args, settings, data, parameters, model, training = synthetic.build(
-        "dr_constant_icml", 12, s_total, solver="midpoint", device=dev, seed=5, shard=shard, u_rng="kernel",
+        "dr_constant_icml", 12, s_total, solver="midpoint", device=dev, seed=5, shard=shard, replica=replica,
+        replica_same_data=same, u_rng="kernel",
         conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0, fused_ode_training=True)
     model.train()
     batch = training.train_data
@@ -27,7 +33,7 @@ def main():
     losses = [float(step(batch)) for _ in range(steps)]
     if rank == 0:
         print("LOSSES " + json.dumps(losses), flush=True)
-    if shard is not None:
+    if shard is not None or replica is not None:
         torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 

@@ -66,7 +66,8 @@ void launch_encoder_fwd(const vihds_encoder_shape&, const float*, const float*, 
 void launch_encoder_bwd(const vihds_encoder_shape&, const float*, const float*, const float*, const float*, const float*,
                         const float*, const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
                         float*, float*, float*, hipStream_t);
-void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, hipStream_t);
+void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, float,
+                 hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
                          const int*, float*, float*, float*, float*, hipStream_t);
 
@@ -475,12 +476,12 @@ int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihd
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                    float beta1, float beta2, float eps, void* stream) {
+                    float beta1, float beta2, float eps, float grad_scale, void* stream) {
   if (!t || !m || !v || !state) return fail(VIHDS_E_BADARG, "null argument");
   if (t->n < 0 || t->n > VIHDS_ADAM_MAX_TENSORS) return fail(VIHDS_E_BADARG, "tensor count out of range");
   for (int k = 0; k < t->n; ++k)
     if (t->size[k] < 0 || !t->param[k]) return fail(VIHDS_E_BADARG, "bad tensor table entry");
-  launch_adam(*t, m, v, state, lr_dev, lr, beta1, beta2, eps, (hipStream_t)stream);
+  launch_adam(*t, m, v, state, lr_dev, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
   return check_hip("vihds_adam_step launch");
 }
 

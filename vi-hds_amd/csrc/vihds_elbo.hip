@@ -643,7 +643,7 @@ void launch_device_condition(int E, int B, int S, int S_total, int s_off, int D,
 constexpr int ADAM_CHUNK = 1024;
 __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* __restrict__ m, float* __restrict__ v,
                                                    float* state, const float* lr_dev, float lr, float beta1,
-                                                   float beta2, float eps) {
+                                                   float beta2, float eps, float grad_scale) {
   // which tensor does this block belong to
   int blk = blockIdx.x, k = 0, off = 0;
   for (; k < t.n; ++k) {
@@ -661,7 +661,7 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
     const float* g = t.grad[k];
     const int end = min(t.size[k], (blk + 1) * ADAM_CHUNK);
     for (int e = blk * ADAM_CHUNK + threadIdx.x; e < end; e += 256) {
-      const float ge = g[e];
+      const float ge = g[e] * grad_scale;
       float me = m[off + e], ve = v[off + e];
       me += (ge - me) * (1.f - beta1);
       ve = ve * beta2 + (1.f - beta2) * ge * ge;
@@ -682,11 +682,12 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
 }
 
 void launch_adam(const vihds_adam_tensors& t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                 float beta1, float beta2, float eps, hipStream_t st) {
+                 float beta1, float beta2, float eps, float grad_scale, hipStream_t st) {
   int blocks = 0;
   for (int k = 0; k < t.n; ++k) blocks += (t.size[k] + ADAM_CHUNK - 1) / ADAM_CHUNK;
   if (blocks == 0) return;
-  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, m, v, state, lr_dev, lr, beta1, beta2, eps);
+  hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, m, v, state, lr_dev, lr, beta1, beta2, eps,
+                     grad_scale);
 }
 void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
                          const float* traj, const float* xpred, const float* theta, const int* prec_rows, float* mu,

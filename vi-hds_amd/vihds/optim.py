@@ -14,8 +14,9 @@ from vihds import hip
 
 
 class HipAdam(torch.optim.Optimizer):
-    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
-        super(HipAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps))
+    def __init__(self, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, grad_scale=1.0):
+        """grad_scale multiplies every gradient as the kernel reads it (1/world after a SUM all-reduce)."""
+        super(HipAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, grad_scale=grad_scale))
         self._flat = {}
 
     def _group_state(self, gi, group):
@@ -64,7 +65,8 @@ class HipAdam(torch.optim.Optimizer):
                 state = st["state"] if last else st["state"].clone()
                 rc = L.vihds_adam_step(ctypes.byref(tab), st["m"][off:].data_ptr(), st["v"][off:].data_ptr(),
                                        state.data_ptr(), hip.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
-                                       beta1, beta2, group["eps"], hip.current_stream())
+                                       beta1, beta2, group["eps"], float(group.get("grad_scale", 1.0)),
+                                       hip.current_stream())
                 hip.check(rc, "vihds_adam_step")
                 off += n_chunk
         return loss

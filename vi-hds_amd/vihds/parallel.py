@@ -96,6 +96,15 @@ def graph_break(op):
     seg._begin()
 
 
+class RowReplica(object):
+    """Data parallelism over data rows: every rank runs the whole step on its own batch of rows (its own draws, the
+    reference's per-batch semantics unchanged) and the parameter gradients are averaged -- ONE all-reduce per step
+    (the SUM is scaled by 1/world inside the Adam kernel).  No exchange in the forward pass."""
+
+    def __init__(self, rank, world, group=None):
+        self.rank, self.world, self.group = rank, world, group
+
+
 def combine_row_lse(row_max, row_sumexp, group):
     """Global row-wise logsumexp from per-rank (max, sum exp(. - max)) pairs.  ONE all-gather of the [2,B] pairs
     (288 B per rank at B=36), then every rank combines the N pairs locally: lse = M + log sum_r se_r exp(m_r - M)."""

@@ -158,8 +158,12 @@ def make_args(n_iwae, seed=0, gpu=None):
 
 
 def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=None, observations=None,
-          **param_overrides):
-    """(args, settings, data_pair, parameters, model, training) for a named synthetic workload."""
+          replica=None, replica_same_data=False, **param_overrides):
+    """(args, settings, data_pair, parameters, model, training) for a named synthetic workload.
+    shard: parallel.SampleShard (the IWAE-sample axis split over ranks).  replica: parallel.RowReplica (every rank
+    its own rows and draws, gradients averaged): the model is initialised from `seed` on every rank, the plate and the
+    random streams from a rank-specific seed (replica_same_data: from `seed` too -- every replica then computes the
+    same step, which is what the plumbing test wants)."""
     from vihds.config import Config
     from vihds.parameters import Parameters
     from vihds.training import Training
@@ -175,15 +179,18 @@ def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=No
     settings = Config(args=None, spec=spec)
     settings.device = torch.device(device)
     settings.seed = seed
-    ds = SyntheticPlateDataset(settings.data, n_rows, n_times, seed)
+    data_seed = seed if (replica is None or replica_same_data) else seed + 1009 * (replica.rank + 1)
+    ds = SyntheticPlateDataset(settings.data, n_rows, n_times, data_seed)
     idx = np.arange(n_rows)
     data = TimeSeriesDatasetPair(Subset(ds, idx), Subset(ds, idx), settings.data)
     parameters = Parameters(settings.params)
     if settings.device.type == "cuda" and workload == "dr_constant_icml":
-        simulate_observations(settings, parameters, ds, settings.device, seed)
+        simulate_observations(settings, parameters, ds, settings.device, data_seed)
     elif observations is not None:
         ds.observations = observations
     torch.manual_seed(seed)
     model = build_model(args, settings, data, parameters, shard=shard)
+    model.replica = replica
     training = Training(args, settings, data, parameters, model)
+    torch.manual_seed(data_seed + 1)  # the in-kernel generators are seeded from torch's stream at their first use
     return args, settings, data, parameters, model, training

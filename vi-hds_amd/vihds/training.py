@@ -63,6 +63,7 @@ class Training:
         self.dataset_pair = data
         self.model = model
         self.shard = getattr(model, "shard", None)
+        self.replica = getattr(model, "replica", None)  # parallel.RowReplica: gradients averaged over ranks
         p = settings.params
         on_gpu = settings.device.type == "cuda"
         self.use_graph = bool(default_get_value(p, "hip_graph", False)) and on_gpu
@@ -73,7 +74,8 @@ class Training:
         if on_gpu:
             from vihds.optim import HipAdam
 
-            self.optimizer = HipAdam(model.parameters(recurse=True), lr=self.lr)
+            self.optimizer = HipAdam(model.parameters(recurse=True), lr=self.lr,
+                                     grad_scale=1.0 / self.replica.world if self.replica is not None else 1.0)
         else:  # host-side construction only (CPU unit tests of the control flow); the decoder itself has no CPU path
             self.optimizer = torch.optim.Adam(model.parameters(recurse=True), lr=self.lr)
         self.scheduler = torch.optim.lr_scheduler.MultiStepLR(self.optimizer, p.learning_boundaries,
@@ -210,9 +212,9 @@ class Training:
             elbo.backward(ops.unit_gradient(elbo.device))  # no ones_like fill, and no launch for the loss's backward
         else:
             elbo.backward()
-        if self.shard is not None:
-            self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.shard.group,
-                                                             self._grad_buffer)
+        sync = self.shard if self.shard is not None else self.replica
+        if sync is not None:
+            self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), sync.group, self._grad_buffer)
         self.optimizer.step()
         if zero_grad:
             self.optimizer.zero_grad(set_to_none=True)
@@ -238,7 +240,7 @@ class Training:
                     self.step(static)
             torch.cuda.current_stream().wait_stream(s)
             self.optimizer.zero_grad(set_to_none=True)
-            if self.shard is not None:  # cut the captured step at its collectives (vihds/parallel.py)
+            if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
                 g = parallel.SegmentedGraph()
                 loss = g.capture(lambda: self.step(static, zero_grad=False))
             else:
