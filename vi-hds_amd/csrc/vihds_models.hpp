@@ -44,6 +44,13 @@ __device__ __forceinline__ float fdiv(float a, float b) { return a * __builtin_a
 __device__ __forceinline__ float fexp(float x) { return __expf(x); }
 #endif
 __device__ __forceinline__ float sigmoid_f(float x) { return frcp(1.f + fexp(-x)); }
+// tanh on the time-loop path (inputs of the no-hidden-layer NeuralPrecisions, precisions.py:55-61): 1 - 2/(1 + e^{2x}),
+// absolute error ~1e-7 (the libm tanhf is ~30 instructions, 13 of them per RHS evaluation of relay_constant_precisions)
+#ifdef VIHDS_PRECISE_MATH
+__device__ __forceinline__ float ftanh(float x) { return tanhf(x); }
+#else
+__device__ __forceinline__ float ftanh(float x) { return 1.f - 2.f * frcp(1.f + fexp(2.f * x)); }
+#endif
 
 // d/da a^n and d/dn a^n, matching autograd of torch.pow(tensor, tensor)
 __device__ __forceinline__ void pow_vjp(float a, float n, float an, float g, float& ab, float& nb) {
@@ -901,8 +908,8 @@ struct WithPrec {
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) thb[Core::NSLOT + j] = yb[NS + j];
   }
   __device__ static void hidden(float t, const float* y, float* h) {
-    h[0] = tanhf(t);
-    VIHDS_UNROLL for (int i = 0; i < NS; ++i) h[i + 1] = tanhf(y[i]);
+    h[0] = ftanh(t);
+    VIHDS_UNROLL for (int i = 0; i < NS; ++i) h[i + 1] = ftanh(y[i]);
   }
   __device__ static void rhs(float t, const float* y, const float* p, const float* w, float* dy) {
     Core::rhs(t, y, p, w, dy);
