@@ -864,3 +864,77 @@ def test_fused_logp_and_unit_adjoint_equals_forward_plus_backward(model, solver)
     spec1 = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=2, kernel_variant=1)
     prob1 = spec1.bind(B, S, T)
     assert L.vihds_ode_logp_grad(ctypes.byref(prob1), *args, logp2.data_ptr(), g_unit.data_ptr(), st) != 0
+
+
+def test_c_abi_rejects_bad_arguments_with_error_codes():
+    """Error behaviour of the boundary: every entry point returns a negative VIHDS_E_* code and leaves a message in
+    vihds_last_error() instead of launching (the Python stub turns that into RuntimeError)."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    slots = hip.model_slots("dr_constant")
+    B, S, T = 3, 4, 5
+    spec = ops.OdeProblemSpec("dr_constant", "rk4", {n: i for i, n in enumerate(slots)}, len(slots), C=2)
+    theta = torch.rand(len(slots), B, S, device=DEV) + 0.1
+    cond = torch.rand(B, 2, device=DEV); times = torch.arange(T, dtype=torch.float32, device=DEV) * 0.2
+    obs = torch.rand(B, 4, T, device=DEV)
+    traj = torch.empty(T, 8, B, S, device=DEV); xp = torch.empty(T, 4, B, S, device=DEV); lp = torch.empty(4, B, S, device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+    good = spec.bind(B, S, T)
+    args = (theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(), obs.data_ptr(), None, traj.data_ptr(),
+            xp.data_ptr(), lp.data_ptr(), st)
+    assert L.vihds_ode_fwd(ctypes.byref(good), *args) == 0
+    for mutate in (lambda p: setattr(p, "T", 1), lambda p: setattr(p, "B", 0), lambda p: setattr(p, "solver", 9),
+                   lambda p: setattr(p, "model", 99), lambda p: p.slot_row.__setitem__(0, 1000)):
+        bad = spec.bind(B, S, T)
+        mutate(bad)
+        rc = L.vihds_ode_fwd(ctypes.byref(bad), *args)
+        assert rc < 0 and len(L.vihds_last_error()) > 0
+    assert L.vihds_ode_fwd(ctypes.byref(good), None, *args[1:]) < 0                      # null theta
+    assert L.vihds_theta_fwd(0, B, S, *([None] * 12), st) < 0                            # P = 0
+    assert L.vihds_iwae_loss_fwd(B, S, S, None, None, None, None, None, None, None, None, None, None, st) < 0
+    assert L.vihds_device_condition(1, B, S, S, 0, 0, 0.0, 1.0, None, None, None, None, None, None, st) < 0
+    assert L.vihds_model_n_states(123) < 0 and L.vihds_model_n_slots(-1) < 0
+    # a network shape the black-box kernels were not instantiated for is declined, not mis-run
+    bslots = hip.model_slots("dr_blackbox")
+    with pytest.raises((RuntimeError, KeyError)):
+        bspec = ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(bslots)}, len(bslots), C=2,
+                                   D=7, n_hidden_prec=7, n_hidden_states=9, n_latent_states=2, n_const=21)
+        bth = torch.rand(len(bslots), B, S, device=DEV)
+        ops.OdeSolveObserve.apply(bspec, bth, cond, times, obs, torch.rand(B, 7, device=DEV),
+                                  torch.rand(64, device=DEV))
+    # and the host stub surfaces the message
+    with pytest.raises(RuntimeError, match="vihds_ode_fwd failed"):
+        ops.OdeSolveObserve.apply(spec, theta, cond, times[:1], obs[:, :, :1], None, None)
+
+
+@pytest.mark.parametrize("model", ["dr_constant", "auto_constant", "prpr_constant"])
+def test_minimal_time_grid_and_single_trajectory(model):
+    """Smallest legal problem: T = 2 time points, B = S = 1 (one trajectory, a 1/32-full block in the lane-split
+    kernels), every solver, forward and gradient against the CPU restatement."""
+    from vihds import hip, ops
+    import hip_util as H
+
+    slots = hip.model_slots(model)
+    B, S, T = 1, 1, 2
+    for solver in ("modeuler", "modeulerwhile", "euler", "midpoint", "rk4"):
+        th = _synthetic_theta(slots, B, S, 2)
+        for v in th.values():
+            v.requires_grad_(True)
+        C = 2
+        cond = torch.log1p(torch.tensor([[5.0, 250.0]]))
+        times = torch.tensor([0.0, 0.37])
+        obs = torch.rand(B, 4, T, generator=torch.Generator().manual_seed(1))
+        xs, xpred, prec = O.decode(model, th, cond, times, solver)
+        lpo = O.log_prob_observations(xpred, obs, prec)
+        lpo.sum().backward()
+        theta = torch.stack([th[n].detach() for n in slots]).to(DEV).requires_grad_(True)
+        spec = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=C)
+        traj, xp, logp = ops.OdeSolveObserve.apply(spec, theta, cond.to(DEV), times.to(DEV), obs.to(DEV), None, None)
+        logp.sum().backward()
+        assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+        for i, n in enumerate(slots):
+            ref = th[n].grad
+            if ref is not None and float(ref.abs().max()) > 0 and not n.startswith("init_"):
+                assert float((theta.grad[i].cpu() - ref).abs().max() / ref.abs().max()) < 2e-3, (n, solver)
