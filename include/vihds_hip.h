@@ -293,6 +293,17 @@ long long vihds_gram_scratch_floats(long long n_columns, int n_rects, const vihd
 int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihds_gram_rect* rects, const float* X,
                       float* scratch, float* out, void* stream);
 
+/* dr_blackbox: the weight-gradient entries that are not Gram rectangles, from the tail vihds_ode_bwd leaves behind the
+ * dump (tail = aux + F*E*B*S: Delta [HS+HP][B*S], then the output-bias adjoint sums [2*NX+8][B*S]):
+ *   g_weights[dest[h*n_const + k]]          = sum_n Delta[h][n] * const_k(n)   h < HS+HP, k < n_const
+ *   g_weights[dest[(HS+HP)*n_const + r]]    = sum_n tail[r][n]                 r < HS+HP+2*NX+8
+ * const_k(n) is what the integrator fed the hidden layers: theta row slot_row[k] for the n_const-C-D latent inputs,
+ * then cond[b][.], then dev1hot[b][.], b = n / S.  In the reference these are the autograd gradients of the
+ * time-invariant input columns and of the biases of NeuralStates / NeuralPrecisions (vihds/ode.py:119-146,
+ * precisions.py:44-87).  Fixed summation order. */
+int vihds_blackbox_tail_grads(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                              const float* tail, const int* dest, float* g_weights, void* stream);
+
 /* Adam update of the encoder / decoder-network parameters (reference training.py:82,338: torch.optim.Adam, default
  * betas/eps, no weight decay, no amsgrad) as one launch over up to VIHDS_ADAM_MAX_TENSORS parameter tensors:
  *   m += (g - m)(1-beta1);  v = beta2 v + (1-beta2) g^2;  t = step+1

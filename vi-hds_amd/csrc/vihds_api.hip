@@ -57,6 +57,8 @@ void launch_device_condition(int, int, int, int, int, int, float, float, const f
 // vihds_gram.hip
 long long gram_scratch_floats(long long, int, const vihds_gram_rect*);
 int launch_gram(int, long long, int, const vihds_gram_rect*, const float*, float*, float*, hipStream_t);
+int launch_bb_tail(int, int, int, int, int, int, int, const int*, const float*, const float*, const float*, const float*,
+                   const int*, float*, hipStream_t);
 // vihds_encoder.hip
 size_t encoder_fwd_lds_bytes(const vihds_encoder_shape&);
 size_t encoder_bwd_lds_bytes(const vihds_encoder_shape&);
@@ -473,6 +475,22 @@ int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihd
   if (rc == VIHDS_E_UNSUPPORTED) return fail(rc, "too many 4x4 register tiles (128 max) or fields (126 max) per call");
   if (rc != VIHDS_OK) return fail(rc, "bad rectangle");
   return check_hip("vihds_gram_blocks launch");
+}
+
+int vihds_blackbox_tail_grads(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                              const float* tail, const int* dest, float* g_weights, void* stream) {
+  if (!p || !theta || !dev1hot || !tail || !dest || !g_weights || (p->C > 0 && !cond))
+    return fail(VIHDS_E_BADARG, "null argument");
+  if (p->model != VIHDS_MODEL_DR_BLACKBOX) return fail(VIHDS_E_BADARG, "dr_blackbox only");
+  if (p->B <= 0 || p->S <= 0) return fail(VIHDS_E_BADARG, "B and S must be positive");
+  const int n_lat = p->n_const - p->C - p->D, NX = 4 + p->n_latent_states, NP = p->n_hidden_states + p->n_hidden_prec;
+  if (n_lat < 0 || NP <= 0) return fail(VIHDS_E_BADARG, "bad network shape");
+  for (int k = 0; k < n_lat && k < VIHDS_MAX_SLOTS; ++k)
+    if (p->slot_row[k] < 0 || p->slot_row[k] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
+  const int rc = launch_bb_tail(NP + 2 * NX + 8, NP, p->B * p->S, p->S, n_lat, p->C, p->D, p->slot_row, theta, cond,
+                                dev1hot, tail, dest, g_weights, (hipStream_t)stream);
+  if (rc) return fail(rc, "needs 1..16 latent inputs, 1..4 treatments and a 1..12 wide device one-hot");
+  return check_hip("vihds_blackbox_tail_grads launch");
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,

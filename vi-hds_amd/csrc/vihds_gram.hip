@@ -175,4 +175,81 @@ int launch_gram(int F, long long C, int n_rect, const vihds_gram_rect* rects, co
   return VIHDS_OK;
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// dr_blackbox weight gradients that are NOT Gram rectangles over the dump (include/vihds_hip.h:
+// vihds_blackbox_tail_grads).  The adjoint kernel leaves, behind the dump, Delta[h][n] = sum over RHS evaluations of
+// the hidden pre-activation adjoint of unit h for trajectory n, and the per-trajectory output-bias adjoint sums.  The
+// hidden layers' columns for the 21 time-invariant inputs (latent theta rows, treatments, device one-hot) are
+//   g_W[h][k] = sum_n Delta[h][n] * const_k(n),
+// the hidden biases sum_n Delta[h][n] and the output biases sum_n tail[r][n].  One block per tail row; the constants
+// are read where they already live (theta rows are contiguous in n; treatments / one-hot are per plate row b = n / S).
+constexpr int TAIL_LAT = 16, TAIL_C = 4, TAIL_D = 12, TAIL_ACC = TAIL_LAT + TAIL_C + TAIL_D + 1, TAIL_THREADS = 1024;
+struct BbTailArgs {
+  int n_rows, n_dot_rows, n, S, n_lat, C, D;
+  int lat_row[TAIL_LAT];
+};
+
+__global__ void __launch_bounds__(TAIL_THREADS)
+bb_tail_kernel(BbTailArgs a, const float* __restrict__ theta, const float* __restrict__ cond,
+               const float* __restrict__ dev1hot, const float* __restrict__ tail, const int* __restrict__ dest,
+               float* __restrict__ out) {
+  __shared__ float sm[TAIL_THREADS / 64][TAIL_ACC];
+  const int r = blockIdx.x, nc = a.n_lat + a.C + a.D;
+  const bool dot = r < a.n_dot_rows;
+  const float* row = tail + (size_t)r * a.n;
+  // accumulators: [0,16) latent inputs, [16,20) treatments, [20,32) device one-hot, [32] the plain row sum.  Slots past
+  // the actual counts read a clamped (valid) address and are never written out: no branch sits between the loads of
+  // one column, so they are all in flight together
+  float acc[TAIL_ACC];
+#pragma unroll
+  for (int k = 0; k < TAIL_ACC; ++k) acc[k] = 0.f;
+  for (int col = threadIdx.x; col < a.n; col += TAIL_THREADS) {
+    const float v = row[col];
+    acc[TAIL_ACC - 1] += v;
+    if (dot) {
+      const int b = col / a.S;
+      float c[TAIL_ACC - 1];
+#pragma unroll
+      for (int k = 0; k < TAIL_LAT; ++k) c[k] = theta[(size_t)a.lat_row[k] * a.n + col];
+#pragma unroll
+      for (int k = 0; k < TAIL_C; ++k) c[TAIL_LAT + k] = cond[b * a.C + min(k, a.C - 1)];
+#pragma unroll
+      for (int k = 0; k < TAIL_D; ++k) c[TAIL_LAT + TAIL_C + k] = dev1hot[b * a.D + min(k, a.D - 1)];
+#pragma unroll
+      for (int k = 0; k < TAIL_ACC - 1; ++k) acc[k] = fmaf(v, c[k], acc[k]);
+    }
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < TAIL_ACC; ++k) {
+    float t = acc[k];
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    if (lane == 0) sm[wid][k] = t;
+  }
+  __syncthreads();
+  if (threadIdx.x < TAIL_ACC) {
+    const int j = threadIdx.x;
+    float t = 0.f;
+    for (int w = 0; w < TAIL_THREADS / 64; ++w) t += sm[w][j];
+    int k = -1;  // which time-invariant input this accumulator belongs to
+    if (j < TAIL_LAT) k = j < a.n_lat ? j : -1;
+    else if (j < TAIL_LAT + TAIL_C) k = j - TAIL_LAT < a.C ? a.n_lat + (j - TAIL_LAT) : -1;
+    else if (j < TAIL_ACC - 1) k = j - TAIL_LAT - TAIL_C < a.D ? a.n_lat + a.C + (j - TAIL_LAT - TAIL_C) : -1;
+    if (j == TAIL_ACC - 1) out[dest[a.n_dot_rows * nc + r]] = t;
+    else if (dot && k >= 0) out[dest[r * nc + k]] = t;
+  }
+}
+
+int launch_bb_tail(int n_rows, int n_dot_rows, int n, int S, int n_lat, int C, int D, const int* lat_row,
+                   const float* theta, const float* cond, const float* dev1hot, const float* tail, const int* dest,
+                   float* out, hipStream_t st) {
+  if (n_lat < 1 || n_lat > TAIL_LAT || C < 1 || C > TAIL_C || D < 1 || D > TAIL_D) return VIHDS_E_UNSUPPORTED;
+  BbTailArgs a;
+  a.n_rows = n_rows; a.n_dot_rows = n_dot_rows; a.n = n; a.S = S; a.n_lat = n_lat; a.C = C; a.D = D;
+  for (int k = 0; k < TAIL_LAT; ++k) a.lat_row[k] = lat_row[k < n_lat ? k : n_lat - 1];
+  hipLaunchKernelGGL(bb_tail_kernel, dim3(n_rows), dim3(TAIL_THREADS), 0, st, a, theta, cond, dev1hot, tail, dest, out);
+  return VIHDS_OK;
+}
+
 }  // namespace vihds

@@ -3,6 +3,7 @@ two small MLPs (NeuralStates, NeuralPrecisions) whose weights live here; the ari
 import torch
 import torch.nn as nn
 
+from vihds import ops
 from vihds.ode import OdeModel
 from vihds.precisions import NeuralPrecisions
 from vihds.utils import default_get_value, variable_summaries
@@ -21,9 +22,12 @@ class NeuralStates(nn.Module):
         self.states_degradation = nn.Linear(n_hidden, n_states)
         nn.init.xavier_uniform_(self.states_degradation.weight)
 
-    def flat_weights(self):
+    def weight_tensors(self):
         mods = [self.states_hidden, self.states_production, self.states_degradation]
-        return torch.cat([t.reshape(-1) for m in mods for t in (m.weight, m.bias)])
+        return [t for m in mods for t in (m.weight, m.bias)]
+
+    def flat_weights(self):
+        return torch.cat([t.reshape(-1) for t in self.weight_tensors()])
 
     def summaries(self, writer, epoch):
         if writer is not None:
@@ -54,17 +58,36 @@ class DR_Blackbox(OdeModel):
         self.init_prec = default_get_value(p, "init_prec", 0.00001)
         self.offset_layer = nn.Linear(self.device_depth, self.n_y)
         self.neural_states = NeuralStates(n_inputs, p.n_hidden_decoder, self.n_states, n_latents)
+        # rows reserved behind the sampled parameters for the device-conditioned y (see condition_theta)
+        self.extra_theta_names = tuple("y%d|device" % (i + 1) for i in range(self.n_y))
+        self._flat = ops.FlatParameters()
 
     def condition_theta(self, theta, dev_1hot, writer, epoch):
-        """y_i += offset_layer(dev_1hot)_i (reference dr_blackbox.py:86-96); re-binds the attribute only."""
+        """y_i += offset_layer(dev_1hot)_i (reference dr_blackbox.py:86-96); re-binds the attribute only (theta.samples
+        keeps the sampled y, which is what log q / log p are taken of).  When theta sits in a packed buffer with
+        reserved rows, y + offset is written there in one launch and the simulator reads those rows; the gradient
+        to y and to the offset layer is routed by ops.OdeSolveObserve (row_offset)."""
         offset = self.offset_layer(dev_1hot)  # [B, n_y]
-        for i in range(self.n_y):
-            pname = "y%d" % (i + 1)
+        names = ["y%d" % (i + 1) for i in range(self.n_y)]
+        packed = getattr(theta, "_packed", None)
+        if packed is not None and packed.is_cuda and theta.n_reserved_rows() >= self.n_y:
+            rows = [theta._row_of.get(n) for n in names]
+            base = len(theta.samples)
+            if (None not in rows and rows == list(range(rows[0], rows[0] + self.n_y)) and rows[-1] < base
+                    and not any(n in theta._rebound for n in names)):
+                with torch.no_grad():
+                    torch.add(packed[rows[0]: rows[0] + self.n_y], offset.t().unsqueeze(2),
+                              out=packed[base: base + self.n_y])
+                for i, n in enumerate(names):
+                    theta.bind_reserved_row(n, base + i)
+                object.__setattr__(theta, "_row_offset", (offset, (rows[0], base, self.n_y)))
+                return theta
+        for i, pname in enumerate(names):
             setattr(theta, pname, getattr(theta, pname) + offset[:, i: i + 1])
         return theta
 
     def neural_weights(self):
-        return torch.cat([self.neural_states.flat_weights(), self.precisions.flat_weights()])
+        return self._flat(self.neural_states.weight_tensors() + self.precisions.weight_tensors())
 
     def problem_kwargs(self, config):
         return {

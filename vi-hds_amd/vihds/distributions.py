@@ -32,6 +32,7 @@ class DotOperatorSamples(object):
         object.__setattr__(self, "_log_prob_cache", {})
         object.__setattr__(self, "_u", None)
         object.__setattr__(self, "_sample_window", None)  # (S_total, s_offset) when S is sharded over ranks
+        object.__setattr__(self, "_row_offset", None)  # (offset [B,n], (src, dst, n)): see ops.OdeSolveObserve
 
     @classmethod
     def from_packed(cls, names, packed):

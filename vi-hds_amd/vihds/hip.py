@@ -129,6 +129,7 @@ _PROTOTYPES = {
     "vihds_encoder_bwd": (_I, [ctypes.POINTER(EncoderShape)] + [_P] * 19),
     "vihds_gram_scratch_floats": (ctypes.c_longlong, [ctypes.c_longlong, _I, _P]),
     "vihds_gram_blocks": (_I, [_I, ctypes.c_longlong, _I] + [_P] * 5),
+    "vihds_blackbox_tail_grads": (_I, [_P] * 8),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 5 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }

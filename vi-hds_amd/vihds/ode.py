@@ -195,9 +195,10 @@ class OdeModel(nn.Module):
         obs = observations
         if obs is None:  # likelihood not requested: feed zeros (logp output is then meaningless and unused)
             obs = torch.zeros((packed.shape[1], 4, times.shape[0]), device=dev)
+        row_offset, row_offset_map = getattr(theta, "_row_offset", None) or (None, None)
         traj, xpred, logp = ops.OdeSolveObserve.apply(spec, packed, conditions.to(dev), times, obs.to(dev),
                                                       dev_1hot.to(dev) if dev_1hot is not None else None,
-                                                      self.neural_weights())
+                                                      self.neural_weights(), row_offset, row_offset_map)
         self._last = DecodedSolution(traj, xpred, logp)
         self._last.has_logp = observations is not None
         return self._last

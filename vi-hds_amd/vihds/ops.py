@@ -117,10 +117,14 @@ class OdeSolveObserve(torch.autograd.Function):
         xpred [T,4,B,S]
         logp  [4,B,S]
     Any subset of the three outputs may be used downstream; unused ones cost nothing in backward.
+
+    row_offset [B,n] with row_offset_map = (src, dst, n) (optional): rows dst..dst+n-1 of theta already hold
+    theta[src+i] + row_offset[:, i] (written in place by the caller, e.g. dr_blackbox's y + offset_layer(dev_1hot)) and
+    the kernel reads those; backward then routes their gradient to rows src.. and, summed over S, to row_offset.
     """
 
     @staticmethod
-    def forward(ctx, spec, theta, cond, times, obs, dev1hot, weights):
+    def forward(ctx, spec, theta, cond, times, obs, dev1hot, weights, row_offset=None, row_offset_map=None):
         _require_cuda(theta, cond, times, obs)
         theta, cond, times, obs = _c(theta), _c(cond), _c(times), _c(obs)
         R, B, S = theta.shape
@@ -137,6 +141,7 @@ class OdeSolveObserve(torch.autograd.Function):
             hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred), hip.ptr(logp), hip.current_stream()))
         hip.check(rc, "vihds_ode_fwd")
         ctx.spec, ctx.prob = spec, prob
+        ctx.row_offset_map = row_offset_map if row_offset is not None else None
         ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
         ctx.set_materialize_grads(False)
         return traj, xpred, logp
@@ -146,7 +151,9 @@ class OdeSolveObserve(torch.autograd.Function):
         theta, cond, times, obs, traj, dev1hot, weights = ctx.saved_tensors
         # the kernel writes every slot row; rows that are not slots (if any) must read as zero
         g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
-        g_w = torch.zeros_like(weights) if weights is not None else None
+        n_aux = hip.lib().vihds_ode_bwd_aux_floats(ctypes.byref(ctx.prob))
+        # (dr_blackbox: the weight gradients come from the dump below, the kernel does not touch g_weights)
+        g_w = torch.zeros_like(weights) if weights is not None and n_aux <= 0 else None
         prob = ctx.prob
         if g_logp is not None and g_logp.dim() == 3 and g_logp.stride(0) == 0 and g_logp[0].is_contiguous():
             prob.logp_grad_broadcast = 1  # IwaeLoss hands back one [B,S] gradient for all four species: no copy
@@ -155,7 +162,6 @@ class OdeSolveObserve(torch.autograd.Function):
             prob.logp_grad_broadcast = 0
             g_logp = _c(g_logp)
         g_traj, g_xpred = _c(g_traj), _c(g_xpred)
-        n_aux = hip.lib().vihds_ode_bwd_aux_floats(ctypes.byref(ctx.prob))
         aux = torch.empty(n_aux, device=theta.device, dtype=torch.float32) if n_aux > 0 else None
         rc = _launch("ode_bwd", lambda: hip.lib().vihds_ode_bwd(
             ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
@@ -164,7 +170,65 @@ class OdeSolveObserve(torch.autograd.Function):
         hip.check(rc, "vihds_ode_bwd")
         if aux is not None and ctx.needs_input_grad[6]:
             g_w = blackbox_weight_grads(ctx.spec, ctx.prob, aux, theta, cond, dev1hot)
-        return None, g_theta, None, None, None, None, g_w
+        grads = (None, g_theta, None, None, None, None, g_w)
+        if len(ctx.needs_input_grad) > 7:
+            g_off = None
+            if ctx.row_offset_map is not None:
+                src, dst, n = ctx.row_offset_map
+                if ctx.needs_input_grad[7]:
+                    g_off = g_theta[dst:dst + n].sum(2).t()
+                g_theta[src:src + n] += g_theta[dst:dst + n]
+            grads = grads + (g_off, None)[:len(ctx.needs_input_grad) - 7]
+        return grads
+
+
+class _FlatParameterView(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, holder, *params):
+        ctx.shapes = [p.shape for p in params]
+        return holder.flat.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, o = [], 0
+        for sh in ctx.shapes:
+            n = sh.numel()
+            out.append(g[o:o + n].view(sh))
+            o += n
+        return (None,) + tuple(out)
+
+
+class FlatParameters(object):
+    """Keeps a fixed list of nn.Parameters as views of ONE flat device buffer, in the order the kernels expect the
+    weights back to back: the kernel reads them where the optimizer updates them (no concatenation per step) and the
+    flat weight gradient is handed to the parameters as views.  Re-aliases itself when a parameter's storage was
+    replaced (module.to(), a new .data)."""
+
+    def __init__(self):
+        self.flat = None
+
+    def _aliased(self, params):
+        if self.flat is None or self.flat.device != params[0].device:
+            return False
+        at = self.flat.data_ptr()
+        for p in params:
+            if p.data_ptr() != at or not p.is_contiguous():
+                return False
+            at += 4 * p.numel()
+        return at == self.flat.data_ptr() + 4 * self.flat.numel()
+
+    def __call__(self, params):
+        params = list(params)
+        if not params[0].is_cuda:  # host-side inspection only; the kernels never see CPU tensors
+            return torch.cat([p.reshape(-1) for p in params])
+        if not self._aliased(params):
+            with torch.no_grad():
+                self.flat = torch.cat([p.detach().reshape(-1).float() for p in params])
+                o = 0
+                for p in params:
+                    p.data = self.flat[o:o + p.numel()].view(p.shape)
+                    o += p.numel()
+        return _FlatParameterView.apply(self, *params)
 
 
 class FusedTrainingUnsupported(RuntimeError):
@@ -335,13 +399,11 @@ def _blackbox_grad_plan(spec, prob, device):
     rest += list(range(o[1], o[2])) + list(range(o[7], o[8]))
     rest += list(range(o[3], o[4])) + list(range(o[5], o[6])) + list(range(o[9], o[10])) + list(range(o[11], o[12]))
     ti = lambda v, dt=torch.int32: torch.tensor(v, dtype=dt, device=device)  # noqa: E731
-    n_lat = prob.n_const - prob.C - prob.D
     rect_arr = (hip.GramRect * len(rects))()
     for k, r in enumerate(rects):
         (rect_arr[k].a0, rect_arr[k].na, rect_arr[k].b0, rect_arr[k].nb, rect_arr[k].dest0, rect_arr[k].dest_stride_a,
          rect_arr[k].dest_stride_b) = r
-    plan = {"rects": rect_arr, "n_rects": len(rects), "rest": ti(rest, torch.int64), "total": o[12],
-            "latent_rows": ti([prob.slot_row[q] for q in range(n_lat)], torch.int64)}
+    plan = {"rects": rect_arr, "n_rects": len(rects), "rest": ti(rest), "total": o[12]}
     assert len(set(dest) | set(rest)) == o[12] == len(dest) + len(rest)
     spec.cache[key] = plan
     return plan
@@ -350,9 +412,9 @@ def _blackbox_grad_plan(spec, prob, device):
 def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     """dr_blackbox weight gradients from the adjoint kernel's dump.  The contraction over (RHS evaluation x trajectory)
     -- K ~ 10^6 columns, seven dense (row block x row block) rectangles -- is ONE pass over the dump
-    (vihds_gram_blocks) writing straight
-    into the flat weight-gradient buffer; the time-invariant input columns and the biases come from the dump's tail
-    (Delta = sum_evals(gs), bias sums) with a handful of small ops."""
+    (vihds_gram_blocks) writing straight into the flat weight-gradient buffer; the time-invariant input columns and
+    the biases come from the dump's tail (Delta = sum_evals(gs), bias sums) in a second launch
+    (vihds_blackbox_tail_grads)."""
     B, S = prob.B, prob.S
     n = B * S
     F = hip.lib().vihds_blackbox_dump_fields()
@@ -370,15 +432,11 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     rc = hip.lib().vihds_gram_blocks(F, E * n, plan["n_rects"], plan["rects"], hip.ptr(aux), hip.ptr(scratch),
                                      hip.ptr(g_w), hip.current_stream())
     hip.check(rc, "vihds_gram_blocks")
-    tail = aux[F * E * n:].view(n_tail, n)
-    delta = tail[:NP]
-    # time-invariant inputs as the kernel saw them: latent theta rows (slot order), treatments, device one-hot
-    const = torch.cat([theta.reshape(theta.shape[0], n)[plan["latent_rows"]],
-                       cond.t().unsqueeze(2).expand(-1, -1, S).reshape(prob.C, n),
-                       dev1hot.t().unsqueeze(2).expand(-1, -1, S).reshape(prob.D, n)], 0)  # [n_const, n]
-    g_const = delta @ const.t()                               # [HS+HP, n_const]
-    sums = tail.sum(1)                                        # [b_hid (HS+HP) ; bias sums (2NX + 8)]
-    g_w.index_copy_(0, plan["rest"], torch.cat([g_const.reshape(-1), sums]))
+    # the time-invariant input columns and the biases: one launch over the dump's tail
+    rc = hip.lib().vihds_blackbox_tail_grads(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
+                                             aux.data_ptr() + 4 * F * E * n, hip.ptr(plan["rest"]), hip.ptr(g_w),
+                                             hip.current_stream())
+    hip.check(rc, "vihds_blackbox_tail_grads")
     return g_w
 
 

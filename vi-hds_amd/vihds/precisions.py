@@ -40,6 +40,7 @@ class NeuralPrecisions(nn.Module):
             raise NotImplementedError("inverse neural precisions are not used by any reference model")
         self.dynamic = True
         self.inverse = inverse
+        self._flat = None
         self.n_inputs, self.n_outputs, self.n_hidden = n_inputs, n_outputs, n_hidden_precisions
         self.activation = "relu" if hidden_activation is nn.ReLU else "tanh"
         n_in = n_inputs + 1
@@ -56,10 +57,17 @@ class NeuralPrecisions(nn.Module):
             self.prec_degradation = nn.Linear(n_hidden_precisions, n_outputs)
             nn.init.xavier_uniform_(self.prec_degradation.weight, gain=1)
 
-    def flat_weights(self):
-        """Weights in the kernel's buffer order: [hid_w, hid_b,] prod_w, prod_b, degr_w, degr_b (row-major)."""
+    def weight_tensors(self):
+        """Parameters in the kernel's buffer order: [hid_w, hid_b,] prod_w, prod_b, degr_w, degr_b (row-major)."""
         mods = ([self.prec_hidden] if self.n_hidden >= 1 else []) + [self.prec_production, self.prec_degradation]
-        return torch.cat([t.reshape(-1) for m in mods for t in (m.weight, m.bias)])
+        return [t for m in mods for t in (m.weight, m.bias)]
+
+    def flat_weights(self):
+        """The kernel's weight buffer: the parameters themselves, kept back to back (ops.FlatParameters)."""
+        if self._flat is None:
+            from vihds import ops
+            object.__setattr__(self, "_flat", ops.FlatParameters())
+        return self._flat(self.weight_tensors())
 
     def expand(self, theta, _n_times, x_states):
         return x_states[:, :, : -self.n_outputs, :], x_states[:, :, -self.n_outputs:, :]
