@@ -938,3 +938,115 @@ def test_minimal_time_grid_and_single_trajectory(model):
             ref = th[n].grad
             if ref is not None and float(ref.abs().max()) > 0 and not n.startswith("init_"):
                 assert float((theta.grad[i].cpu() - ref).abs().max() / ref.abs().max()) < 2e-3, (n, solver)
+
+
+def _gram_reference(X, rects, total):
+    out = torch.zeros(total, dtype=torch.float64)
+    Xd = X.double().cpu()
+    for (a0, na, b0, nb, d0, sa, sb) in rects:
+        G = Xd[a0:a0 + na] @ Xd[b0:b0 + nb].t()
+        for i in range(na):
+            for j in range(nb):
+                out[d0 + i * sa + j * sb] = G[i, j]
+    return out
+
+
+@pytest.mark.parametrize("case", ["blackbox_plan", "generic_mfma", "lds_tiled"])
+def test_gram_blocks_against_torch(case):
+    """vihds_gram_blocks: every path (matrix cores with the dr_blackbox sharing pattern; matrix cores, generic
+    rectangles; LDS-tiled when the column count is not a multiple of 64) against a float64 matmul."""
+    import ctypes
+    from vihds import hip
+
+    L = hip.lib()
+    g = torch.Generator().manual_seed(5)
+    if case == "blackbox_plan":   # the rectangles of ops._blackbox_grad_plan for HS=25, HP=20, NX=6
+        F, C = 117, 64 * 250 + 32
+        HS, HP, NX = 25, 20, 6
+        ZA, ZD, RHS, RGS = 0, NX, 2 * NX, 2 * NX + HS
+        RY = RGS + HS; RT = RY + NX; ZAP, ZDP = RT + 1, RT + 5; RHP = RT + 9; RGP = RHP + HP
+        ws, wp = NX + 21, 1 + NX + 21
+        o = [0]
+        for size in (HS * ws, HS, NX * HS, NX, NX * HS, NX, HP * wp, HP, 4 * HP, 4, 4 * HP, 4):
+            o.append(o[-1] + size)
+        rects = [(RGS, HS, RY, NX, o[0], ws, 1), (ZA, NX, RHS, HS, o[2], HS, 1), (ZD, NX, RHS, HS, o[4], HS, 1),
+                 (RGP, HP, RT, 1, o[6], wp, 1), (RGP, HP, RY, NX, o[6] + 1, wp, 1), (ZAP, 4, RHP, HP, o[8], HP, 1),
+                 (ZDP, 4, RHP, HP, o[10], HP, 1)]
+        total = o[12]
+    elif case == "generic_mfma":
+        F, C = 40, 64 * 37
+        rects = [(0, 17, 20, 3, 0, 3, 1), (5, 1, 5, 1, 60, 1, 1), (30, 10, 0, 33, 100, 1, 10)]
+        total = 100 + 330
+    else:
+        F, C = 23, 1000 + 7
+        rects = [(0, 5, 5, 9, 0, 9, 1), (14, 9, 0, 2, 50, 1, 9)]
+        total = 50 + 18
+    X = torch.randn(F, C, generator=g).to(DEV)
+    arr = (hip.GramRect * len(rects))()
+    for k, r in enumerate(rects):
+        (arr[k].a0, arr[k].na, arr[k].b0, arr[k].nb, arr[k].dest0, arr[k].dest_stride_a, arr[k].dest_stride_b) = r
+    n_scr = L.vihds_gram_scratch_floats(C, len(rects), arr)
+    assert n_scr > 0
+    scratch = torch.empty(n_scr, device=DEV)
+    out = torch.full((total,), float("nan"), device=DEV)
+    rc = L.vihds_gram_blocks(F, C, len(rects), arr, X.data_ptr(), scratch.data_ptr(), out.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.vihds_last_error()
+    ref = _gram_reference(X, rects, total)
+    written = torch.zeros(total, dtype=torch.bool)
+    for (a0, na, b0, nb, d0, sa, sb) in rects:
+        for i in range(na):
+            for j in range(nb):
+                written[d0 + i * sa + j * sb] = True
+    got = out.cpu().double()
+    assert torch.isnan(got[~written]).all()          # nothing outside the rectangles' destinations is touched
+    scale = ref[written].abs().max()
+    assert float((got[written] - ref[written]).abs().max() / scale) < 2e-5
+    # same launch twice: bit-identical (fixed summation order)
+    out2 = torch.empty_like(out)
+    L.vihds_gram_blocks(F, C, len(rects), arr, X.data_ptr(), scratch.data_ptr(), out2.data_ptr(),
+                        torch.cuda.current_stream().cuda_stream)
+    assert torch.equal(out2.cpu()[written], out.cpu()[written])
+
+
+def test_blackbox_tail_grads_against_torch():
+    """vihds_blackbox_tail_grads: time-invariant-input columns and biases from the adjoint's tail, vs float64 torch."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    slots = hip.model_slots("dr_blackbox")
+    B, S = 5, 37
+    n = B * S
+    HS, HP, NX, nc, C, D = 25, 20, 6, 21, 2, 7
+    n_lat = nc - C - D
+    R = len(slots) + 3
+    row_of = {nm: (i * 2) % len(slots) if False else i for i, nm in enumerate(slots)}
+    row_of[slots[1]], row_of[slots[2]] = len(slots) + 1, len(slots)   # latents need not sit in rows 0..n_lat-1
+    spec = ops.OdeProblemSpec("dr_blackbox", "midpoint", row_of, R, C=C, D=D, n_hidden_prec=HP, n_hidden_states=HS,
+                              n_latent_states=2, n_const=nc)
+    prob = spec.bind(B, S, 9)
+    g = torch.Generator().manual_seed(11)
+    theta = torch.randn(R, B, S, generator=g).to(DEV)
+    cond = torch.rand(B, C, generator=g).to(DEV)
+    dev1hot = torch.zeros(B, D); dev1hot[torch.arange(B), torch.arange(B) % D] = 1.0
+    dev1hot = dev1hot.to(DEV)
+    NP, n_tail = HS + HP, HS + HP + 2 * NX + 8
+    tail = torch.randn(n_tail, n, generator=g).to(DEV)
+    total = NP * nc + n_tail + 13
+    perm = torch.randperm(total, generator=g)[:NP * nc + n_tail].to(torch.int32)
+    out = torch.full((total,), float("nan"), device=DEV)
+    rc = L.vihds_blackbox_tail_grads(ctypes.byref(prob), theta.data_ptr(), cond.data_ptr(), dev1hot.data_ptr(),
+                                     tail.data_ptr(), perm.to(DEV).data_ptr(), out.data_ptr(),
+                                     torch.cuda.current_stream().cuda_stream)
+    assert rc == 0, L.vihds_last_error()
+    lat_rows = [prob.slot_row[k] for k in range(n_lat)]
+    const = torch.cat([theta.cpu().double().reshape(R, n)[lat_rows],
+                       cond.cpu().double().t().unsqueeze(2).expand(-1, -1, S).reshape(C, n),
+                       dev1hot.cpu().double().t().unsqueeze(2).expand(-1, -1, S).reshape(D, n)], 0)
+    td = tail.cpu().double()
+    ref = torch.cat([(td[:NP] @ const.t()).reshape(-1), td.sum(1)])
+    got = out.cpu().double()[perm.long()]
+    assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
+    untouched = torch.ones(total, dtype=torch.bool); untouched[perm.long()] = False
+    assert torch.isnan(out.cpu()[untouched]).all()

@@ -154,10 +154,218 @@ int gram_blocks(long long C) {
   const long long n_tiles = (C + GRAM_TILE - 1) / GRAM_TILE;
   return (int)min(n_tiles, (long long)512);  // two resident blocks per CU
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same contraction on the matrix cores.  The sum over columns IS the K dimension of a GEMM, and the dump's
+// field-major layout is already what v_mfma_f32_16x16x4_f32 (exact fp32) wants from both operands: lane l supplies
+// row (l & 15) of a 16-row block at four consecutive columns 4*(l >> 4) .. +3 -- one 16-byte load, no LDS, no
+// transposes.  Every rectangle is cut into <= 16 x 16 products on the host (14 for the dr_blackbox plan); a wave walks
+// its share of the columns 64 at a time (sixteen MFMAs per product and step), the four waves of a block are added in a
+// fixed order through LDS, and a second kernel sums the per-block partials, again in a fixed order.  Rows past a
+// block's end re-read its last row (their products are never stored).
+typedef float gm_f32x4 __attribute__((ext_vector_type(4)));
+constexpr int GM_MAX_PROD = 16, GM_WAVES = 4, GM_BLOCKS = 512;
+struct GramMfmaPlan {
+  int n_prod;
+  int a_row0[GM_MAX_PROD], a_rows[GM_MAX_PROD], b_row0[GM_MAX_PROD], b_rows[GM_MAX_PROD];
+  int dest0[GM_MAX_PROD], dsa[GM_MAX_PROD], dsb[GM_MAX_PROD];
+  int out_first[GM_MAX_PROD + 1];  // prefix sums of a_rows * b_rows
+  // the distinct 16-row blocks the products are made of, in first-use order, and each product's two blocks
+  int n_tiles, t_row0[GM_MAX_PROD], t_rows[GM_MAX_PROD], pa[GM_MAX_PROD], pb[GM_MAX_PROD];
+};
+
+// Which products share which row blocks, fixed at compile time so that every block is loaded ONCE per step into
+// registers the compiler can name (a run-time block index would mean indexed registers or one load per use -- the
+// latter was measured: 28 block loads per step instead of 14 make the kernel L2-bound at 262 us).  This is the
+// dr_blackbox plan of vihds/ops.py (_blackbox_grad_plan): blocks in first-use order
+//   0 gs[0:16] 1 y 2 gs[16:] 3 za 4 hs[0:16] 5 hs[16:] 6 zd 7 gp[0:16] 8 t 9 gp[16:] 10 zap 11 hp[0:16] 12 hp[16:] 13 zdp
+// Row numbers and counts stay run-time; only the sharing pattern is matched (gram_mfma_schema_matches).
+struct BbGramSchema {
+  static constexpr int NT = 14, NPR = 14;
+  static constexpr int TA[NPR] = {0, 2, 3, 3, 6, 6, 7, 9, 7, 9, 10, 10, 13, 13};
+  static constexpr int TB[NPR] = {1, 1, 4, 5, 4, 5, 8, 8, 1, 1, 11, 12, 11, 12};
+};
+
+template <class SC>
+__global__ void __launch_bounds__(64 * GM_WAVES)
+gram_mfma_schema_kernel(long long C, GramMfmaPlan pl, const float* __restrict__ X, float* __restrict__ partial) {
+  __shared__ float red[GM_MAX_PROD * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+  gm_f32x4 acc[SC::NPR];
+  int off[SC::NT];
+#pragma unroll
+  for (int p = 0; p < SC::NPR; ++p) acc[p] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int t = 0; t < SC::NT; ++t) off[t] = (int)((long long)(pl.t_row0[t] + min(m, pl.t_rows[t] - 1)) * C);
+  // a wave takes 32 columns per step: lane (m, kq) reads columns 8*kq .. 8*kq+7 of row m of every block (two 16-byte
+  // loads), the four waves of a block take neighbouring groups: 512 contiguous bytes per dump row and block step
+  const long long n_groups = C >> 5, stride = (long long)gridDim.x * GM_WAVES;
+  for (long long g = (long long)blockIdx.x * GM_WAVES + wid; g < n_groups; g += stride) {
+    const float* base = X + (g << 5) + 8 * kq;
+    float4 v[SC::NT][2];
+#pragma unroll
+    for (int t = 0; t < SC::NT; ++t) {
+      v[t][0] = *reinterpret_cast<const float4*>(base + off[t]);
+      v[t][1] = *reinterpret_cast<const float4*>(base + off[t] + 4);
+    }
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+#pragma unroll
+      for (int p = 0; p < SC::NPR; ++p) {
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[SC::TA[p]][c].x, v[SC::TB[p]][c].x, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[SC::TA[p]][c].y, v[SC::TB[p]][c].y, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[SC::TA[p]][c].z, v[SC::TB[p]][c].z, acc[p], 0, 0, 0);
+        acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(v[SC::TA[p]][c].w, v[SC::TB[p]][c].w, acc[p], 0, 0, 0);
+      }
+    }
+  }
+  for (int wv = 0; wv < GM_WAVES; ++wv) {
+    if (wid == wv) {
+#pragma unroll
+      for (int p = 0; p < SC::NPR; ++p) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int idx = p * 256 + (4 * kq + r) * 16 + m;
+          red[idx] = (wv ? red[idx] : 0.f) + acc[p][r];
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int n_out = SC::NPR * 256;
+  for (int e = threadIdx.x; e < n_out; e += 64 * GM_WAVES) partial[(size_t)blockIdx.x * n_out + e] = red[e];
+}
+
+template <class SC>
+static bool gram_mfma_schema_matches(const GramMfmaPlan& pl) {
+  if (pl.n_prod != SC::NPR || pl.n_tiles != SC::NT) return false;
+  for (int p = 0; p < SC::NPR; ++p)
+    if (pl.pa[p] != SC::TA[p] || pl.pb[p] != SC::TB[p]) return false;
+  return true;
+}
+
+__global__ void __launch_bounds__(64 * GM_WAVES)
+gram_mfma_kernel(long long C, GramMfmaPlan pl, const float* __restrict__ X, float* __restrict__ partial) {
+  __shared__ float red[GM_MAX_PROD * 256];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, m = lane & 15, kq = lane >> 4;
+  gm_f32x4 acc[GM_MAX_PROD];
+  int off_a[GM_MAX_PROD], off_b[GM_MAX_PROD];
+#pragma unroll
+  for (int p = 0; p < GM_MAX_PROD; ++p) {
+    acc[p] = gm_f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool on = p < pl.n_prod;
+    off_a[p] = on ? (int)((long long)(pl.a_row0[p] + min(m, pl.a_rows[p] - 1)) * C) : 0;
+    off_b[p] = on ? (int)((long long)(pl.b_row0[p] + min(m, pl.b_rows[p] - 1)) * C) : 0;
+  }
+  // a wave takes 64 columns per step: lane (m, kq) reads the 16 consecutive columns 16*kq.. of row m (64 contiguous
+  // bytes, the four kq lanes together 256), and the four waves of a block take neighbouring 64-column groups -- 1 KB
+  // contiguous per dump row and block step, which is what keeps the HBM pages open.  Which column a k index of the MFMA
+  // stands for does not matter as long as both operands agree.
+  const long long n_groups = C >> 6, stride = (long long)gridDim.x * GM_WAVES;
+  for (long long g = (long long)blockIdx.x * GM_WAVES + wid; g < n_groups; g += stride) {
+    const float* base = X + (g << 6) + 16 * kq;
+#pragma unroll
+    for (int p = 0; p < GM_MAX_PROD; ++p) {
+      if (p < pl.n_prod) {
+        float4 a[4], b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          a[c] = *reinterpret_cast<const float4*>(base + off_a[p] + 4 * c);
+          b[c] = *reinterpret_cast<const float4*>(base + off_b[p] + 4 * c);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].x, b[c].x, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].y, b[c].y, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].z, b[c].z, acc[p], 0, 0, 0);
+          acc[p] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[c].w, b[c].w, acc[p], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // D layout: lane holds rows 4*kq + r (operand A's rows), column m (operand B's rows)
+  for (int wv = 0; wv < GM_WAVES; ++wv) {
+    if (wid == wv) {
+#pragma unroll
+      for (int p = 0; p < GM_MAX_PROD; ++p) {
+        if (p < pl.n_prod) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int idx = p * 256 + (4 * kq + r) * 16 + m;
+            red[idx] = (wv ? red[idx] : 0.f) + acc[p][r];
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  const int n_out = pl.n_prod * 256;
+  for (int e = threadIdx.x; e < n_out; e += 64 * GM_WAVES) partial[(size_t)blockIdx.x * n_out + e] = red[e];
+}
+
+__global__ void __launch_bounds__(256)
+gram_mfma_reduce_kernel(int n_blocks, GramMfmaPlan pl, const float* __restrict__ partial, float* __restrict__ out) {
+  const int wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6, lane = threadIdx.x & 63;
+  if (wave >= pl.out_first[pl.n_prod]) return;
+  int p = 0;
+  while (p + 1 < pl.n_prod && wave >= pl.out_first[p + 1]) ++p;
+  const int local = wave - pl.out_first[p];
+  const int i = local / pl.b_rows[p], j = local - i * pl.b_rows[p];
+  float s = 0.f;
+  for (int blk = lane; blk < n_blocks; blk += 64) s += partial[((size_t)blk * pl.n_prod + p) * 256 + i * 16 + j];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_down(s, o, 64);
+  if (lane == 0) out[pl.dest0[p] + i * pl.dsa[p] + j * pl.dsb[p]] = s;
+}
+
+// VIHDS_OK, or VIHDS_E_UNSUPPORTED when the matrix-core path does not apply (then the LDS-tiled kernels above run)
+static int gram_mfma_make_plan(int F, long long C, int n_rect, const vihds_gram_rect* rects, GramMfmaPlan& pl) {
+  if ((C & 31) != 0 || (long long)F * C >= (1ll << 31)) return VIHDS_E_UNSUPPORTED;
+  pl.n_prod = 0;
+  pl.n_tiles = 0;
+  pl.out_first[0] = 0;
+  auto tile_of = [&pl](int row0, int rows) {
+    for (int t = 0; t < pl.n_tiles; ++t)
+      if (pl.t_row0[t] == row0 && pl.t_rows[t] == rows) return t;
+    if (pl.n_tiles == GM_MAX_PROD) return -1;
+    pl.t_row0[pl.n_tiles] = row0;
+    pl.t_rows[pl.n_tiles] = rows;
+    return pl.n_tiles++;
+  };
+  for (int q = 0; q < n_rect; ++q) {
+    for (int ti = 0; 16 * ti < rects[q].na; ++ti)
+      for (int tj = 0; 16 * tj < rects[q].nb; ++tj) {
+        if (pl.n_prod == GM_MAX_PROD) return VIHDS_E_UNSUPPORTED;
+        const int p = pl.n_prod++;
+        pl.a_row0[p] = rects[q].a0 + 16 * ti;
+        pl.a_rows[p] = min(16, rects[q].na - 16 * ti);
+        pl.b_row0[p] = rects[q].b0 + 16 * tj;
+        pl.b_rows[p] = min(16, rects[q].nb - 16 * tj);
+        pl.dsa[p] = rects[q].dest_stride_a;
+        pl.dsb[p] = rects[q].dest_stride_b;
+        pl.dest0[p] = rects[q].dest0 + 16 * ti * pl.dsa[p] + 16 * tj * pl.dsb[p];
+        pl.out_first[p + 1] = pl.out_first[p] + pl.a_rows[p] * pl.b_rows[p];
+        pl.pa[p] = tile_of(pl.a_row0[p], pl.a_rows[p]);
+        pl.pb[p] = tile_of(pl.b_row0[p], pl.b_rows[p]);
+      }
+  }
+  for (int t = pl.n_tiles; t < GM_MAX_PROD; ++t) { pl.t_row0[t] = 0; pl.t_rows[t] = 1; }
+  for (int p = pl.n_prod; p < GM_MAX_PROD; ++p) {
+    pl.a_row0[p] = pl.b_row0[p] = pl.dest0[p] = pl.dsa[p] = pl.dsb[p] = 0;
+    pl.a_rows[p] = pl.b_rows[p] = 1;
+    pl.pa[p] = pl.pb[p] = -1;
+    pl.out_first[p + 1] = pl.out_first[p];
+  }
+  return VIHDS_OK;
+}
+static int gram_mfma_blocks(long long C) { return (int)min((long long)GM_BLOCKS, ((C >> 6) + GM_WAVES - 1) / GM_WAVES); }
+
 long long gram_scratch_floats(long long C, int n_rect, const vihds_gram_rect* rects) {
   GramPlan pl;
   if (gram_make_plan(n_rect, rects, pl) != VIHDS_OK) return -1;
-  return (long long)gram_blocks(C) * pl.first[n_rect] * GRAM_CG * 16;
+  const long long lds_tiled = (long long)gram_blocks(C) * pl.first[n_rect] * GRAM_CG * 16;
+  const long long mfma = (long long)GM_BLOCKS * GM_MAX_PROD * 256;
+  return max(lds_tiled, mfma);
 }
 int launch_gram(int F, long long C, int n_rect, const vihds_gram_rect* rects, const float* X, float* partial, float* out,
                 hipStream_t st) {
@@ -165,6 +373,19 @@ int launch_gram(int F, long long C, int n_rect, const vihds_gram_rect* rects, co
   if (int rc = gram_make_plan(n_rect, rects, pl)) return rc;
   for (int q = 0; q < n_rect; ++q)
     if (rects[q].a0 + rects[q].na > F || rects[q].b0 + rects[q].nb > F) return VIHDS_E_BADARG;
+  GramMfmaPlan mp;
+  const bool mfma_ok = gram_mfma_make_plan(F, C, n_rect, rects, mp) == VIHDS_OK;
+  const bool schema = mfma_ok && gram_mfma_schema_matches<BbGramSchema>(mp);
+  if (schema || (mfma_ok && (C & 63) == 0)) {  // (the generic kernel steps 64 columns at a time, the schema one 32)
+    const int nb = gram_mfma_blocks(C);
+    if (schema)
+      hipLaunchKernelGGL(gram_mfma_schema_kernel<BbGramSchema>, dim3(nb), dim3(64 * GM_WAVES), 0, st, C, mp, X, partial);
+    else
+      hipLaunchKernelGGL(gram_mfma_kernel, dim3(nb), dim3(64 * GM_WAVES), 0, st, C, mp, X, partial);
+    const int n_out = mp.out_first[mp.n_prod];
+    hipLaunchKernelGGL(gram_mfma_reduce_kernel, dim3((n_out + 3) / 4), dim3(256), 0, st, nb, mp, partial, out);
+    return VIHDS_OK;
+  }
   const size_t lds = (size_t)F * GRAM_LD * sizeof(float);
   if (lds > 64 * 1024) return VIHDS_E_UNSUPPORTED;
   const int nb = gram_blocks(C);
