@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 1
+#define VIHDS_ABI_VERSION 2
 
 /* error codes */
 #define VIHDS_OK 0
@@ -207,11 +207,15 @@ int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const flo
  * gradient w.r.t. log_q.
  * unit_g_logw / unit_g_neg_logw (optional, only where vihds_iwae_loss_unit_grad(B,S) == 1): the forward also writes
  * the backward's outputs for g_loss = 1 -- what loss.backward() asks for in the training step -- so that step needs no
- * backward launch for the loss. */
+ * backward launch for the loss.
+ * ticket (optional): a device counter the caller owns, zero before the first call and not shared between launches
+ * that may run concurrently.  With it (and S <= 1024) the reduction runs one block per row and the last block to
+ * finish takes the mean over rows and resets the counter (graph-replayable); without it B <= 64, S <= 256 run in one
+ * block and larger shapes in two launches. */
 int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, float* unit_g_logw,
-                        float* unit_g_neg_logw, void* stream);
-int vihds_iwae_loss_unit_grad(int B, int S);
+                        float* unit_g_neg_logw, unsigned int* ticket, void* stream);
+int vihds_iwae_loss_unit_grad(int B, int S, int with_ticket);
 /* S sharded over n_ranks processes: `gathered` [n_ranks][2][B] holds every rank's (row_max, row_sumexp) from
  * vihds_iwae_fwd (one all-gather).  Computes the global lse[b] = M + log sum_r se_r exp(m_r - M), loss[0] =
  * -mean_b(lse[b] - log n_iwae_total) and, optionally, this rank's d loss / d log_w [B][S] for a unit upstream gradient

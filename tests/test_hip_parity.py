@@ -893,7 +893,7 @@ def test_c_abi_rejects_bad_arguments_with_error_codes():
         assert rc < 0 and len(L.vihds_last_error()) > 0
     assert L.vihds_ode_fwd(ctypes.byref(good), None, *args[1:]) < 0                      # null theta
     assert L.vihds_theta_fwd(0, B, S, *([None] * 12), st) < 0                            # P = 0
-    assert L.vihds_iwae_loss_fwd(B, S, S, None, None, None, None, None, None, None, None, None, None, st) < 0
+    assert L.vihds_iwae_loss_fwd(B, S, S, None, None, None, None, None, None, None, None, None, None, None, st) < 0
     assert L.vihds_device_condition(1, B, S, S, 0, 0, 0.0, 1.0, None, None, None, None, None, None, st) < 0
     assert L.vihds_model_n_states(123) < 0 and L.vihds_model_n_slots(-1) < 0
     # a network shape the black-box kernels were not instantiated for is declined, not mis-run

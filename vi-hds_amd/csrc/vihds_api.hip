@@ -48,6 +48,8 @@ void launch_theta_bwd(int, int, int, const int*, const float*, const float*, con
 void launch_iwae_fwd(int, int, const float*, const float*, const float*, float*, float*, float*, hipStream_t);
 void launch_iwae_bwd(int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_iwae_finish(int, float, const float*, const float*, float*, float*, hipStream_t);
+void launch_iwae_loss_rows(int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
+                           float*, float*, float*, unsigned int*, hipStream_t);
 void launch_iwae_loss_small(int, int, float, const float*, const float*, const float*, float*, float*, float*, float*,
                             float*, float*, float*, hipStream_t);
 void launch_iwae_combine(int, int, int, float, const float*, const float*, float*, float*, float*, float*, hipStream_t);
@@ -359,17 +361,25 @@ int vihds_iwae_bwd(int B, int S, const float* log_w, const float* lse, const flo
 
 int vihds_iwae_loss_fwd(int B, int S, int n_iwae_total, const float* logp, const float* log_p, const float* log_q,
                         float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss, float* unit_g_logw,
-                        float* unit_g_neg_logw, void* stream) {
+                        float* unit_g_neg_logw, unsigned int* ticket, void* stream) {
   if (B <= 0 || S <= 0 || n_iwae_total <= 0 || !logp || !log_w || !row_max || !row_sumexp || !lse || !loss)
     return fail(VIHDS_E_BADARG, "bad argument");
-  if (B <= 64 && S <= 256) {  // one launch; above this one block per row + a finish kernel
-    launch_iwae_loss_small(B, S, logf((float)n_iwae_total), logp, log_p, log_q, log_w, row_max, row_sumexp, lse, loss,
-                           unit_g_logw, unit_g_neg_logw, (hipStream_t)stream);
+  const float log_n = logf((float)n_iwae_total);
+  if (ticket && S <= 1024) {  // one launch, block per row, the last block takes the mean over rows
+    launch_iwae_loss_rows(B, S, log_n, logp, log_p, log_q, log_w, row_max, row_sumexp, lse, loss, unit_g_logw,
+                          unit_g_neg_logw, ticket, (hipStream_t)stream);
     return check_hip("vihds_iwae_loss_fwd launch");
   }
-  if (unit_g_logw) return fail(VIHDS_E_UNSUPPORTED, "unit-gradient outputs need B <= 64 and S <= 256 (vihds_iwae_loss_unit_grad)");
+  if (B <= 64 && S <= 256) {  // one launch, one block
+    launch_iwae_loss_small(B, S, log_n, logp, log_p, log_q, log_w, row_max, row_sumexp, lse, loss, unit_g_logw,
+                           unit_g_neg_logw, (hipStream_t)stream);
+    return check_hip("vihds_iwae_loss_fwd launch");
+  }
+  if (unit_g_logw)
+    return fail(VIHDS_E_UNSUPPORTED, "unit-gradient outputs need a ticket and S <= 1024, or B <= 64 and S <= 256 "
+                                     "(vihds_iwae_loss_unit_grad)");
   launch_iwae_fwd(B, S, logp, log_p, log_q, log_w, row_max, row_sumexp, (hipStream_t)stream);
-  launch_iwae_finish(B, logf((float)n_iwae_total), row_max, row_sumexp, lse, loss, (hipStream_t)stream);
+  launch_iwae_finish(B, log_n, row_max, row_sumexp, lse, loss, (hipStream_t)stream);
   return check_hip("vihds_iwae_loss_fwd launch");
 }
 
@@ -384,7 +394,10 @@ int vihds_iwae_combine(int n_ranks, int B, int S, int n_iwae_total, const float*
 }
 
 /* 1 if vihds_iwae_loss_fwd can also emit the unit-upstream-gradient outputs for this shape */
-int vihds_iwae_loss_unit_grad(int B, int S) { return (B > 0 && S > 0 && B <= 64 && S <= 256) ? 1 : 0; }
+int vihds_iwae_loss_unit_grad(int B, int S, int with_ticket) {
+  if (B <= 0 || S <= 0) return 0;
+  return ((with_ticket && S <= 1024) || (B <= 64 && S <= 256)) ? 1 : 0;
+}
 
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                         float* g_neg_logw, void* stream) {

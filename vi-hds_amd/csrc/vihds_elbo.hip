@@ -433,6 +433,74 @@ iwae_loss_small_kernel(int B, int S, float log_n, const float* __restrict__ logp
   }
 }
 
+// The same reduction with one block per row (any B, S <= 1024) and the mean over rows taken by the last block to
+// finish: `ticket` is a zero-initialised device counter the caller keeps; the last block resets it, so the launch can
+// be replayed from a hipGraph.  At B=36, S=200 this spreads the 6 x 7200 loads and the two reductions per row over 36
+// CUs instead of one (9.6 -> ~5 us, the launch floor); the single-block kernel above stays for callers without a ticket.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+iwae_loss_rows_kernel(int B, int S, float log_n, const float* __restrict__ logp, const float* __restrict__ log_p,
+                      const float* __restrict__ log_q, float* __restrict__ log_w, float* __restrict__ row_max,
+                      float* __restrict__ row_sumexp, float* __restrict__ lse, float* __restrict__ loss,
+                      float* __restrict__ unit_g_logw, float* __restrict__ unit_g_neg_logw, unsigned int* ticket) {
+  __shared__ float sm[BLOCK / 64];
+  __shared__ int is_last;
+  const int n = B * S, b = blockIdx.x;
+  float lw[4];
+  float m = -INFINITY;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    const int sidx = threadIdx.x + BLOCK * c;
+    float v = -INFINITY;
+    if (sidx < S) {
+      const int i = b * S + sidx;
+      v = ((logp[i] + logp[n + i]) + logp[2 * n + i]) + logp[3 * n + i];
+      v = v + (log_p ? log_p[i] : 0.f) - (log_q ? log_q[i] : 0.f);
+      log_w[i] = v;
+    }
+    lw[c] = v;
+    m = fmaxf(m, v);
+  }
+  m = block_max<BLOCK>(m, sm);
+  float se = 0.f;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) se += (threadIdx.x + BLOCK * c < S) ? expf(lw[c] - m) : 0.f;
+  se = block_sum<BLOCK>(se, sm);
+  const float l = m + logf(se);
+  if (threadIdx.x == 0) {
+    row_max[b] = m;
+    row_sumexp[b] = se;
+    lse[b] = l;
+  }
+  if (unit_g_logw) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int sidx = threadIdx.x + BLOCK * c;
+      if (sidx < S) {
+        const float g = -(1.f / (float)B) * expf(lw[c] - l);  // same expression as iwae_loss_bwd_kernel, g_loss = 1
+        unit_g_logw[b * S + sidx] = g;
+        if (unit_g_neg_logw) unit_g_neg_logw[b * S + sidx] = -g;
+      }
+    }
+  }
+  // the last block to get here sees every row's lse (release: fence before the ticket; acquire: fence after it)
+  if (threadIdx.x == 0) {
+    __threadfence();
+    is_last = atomicAdd(ticket, 1u) == gridDim.x - 1;
+  }
+  __syncthreads();
+  if (!is_last) return;
+  __threadfence();
+  float acc = 0.f;
+  for (int r = threadIdx.x; r < B; r += BLOCK)
+    acc += __hip_atomic_load(&lse[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - log_n;
+  acc = block_sum<BLOCK>(acc, sm);  // fixed order: thread r takes rows r, r+BLOCK, ...; lanes, then waves
+  if (threadIdx.x == 0) {
+    loss[0] = -acc / (float)B;
+    *ticket = 0u;
+  }
+}
+
 // S sharded over ranks: after the per-rank (row max, row sum-exp) pairs have been all-gathered ([N][2][B]), everything
 // that remains of the loss is ONE launch: lse[b] = M + log sum_r se_r exp(m_r - M), loss = -mean_b(lse - log n_total),
 // and (optionally) d loss / d log_w of this rank's samples for a unit upstream gradient.  One block, wave per row.
@@ -615,6 +683,12 @@ void launch_iwae_loss_small(int B, int S, float log_n, const float* logp, const 
                             float* unit_g_logw, float* unit_g_neg_logw, hipStream_t st) {
   hipLaunchKernelGGL(iwae_loss_small_kernel, dim3(1), dim3(1024), 0, st, B, S, log_n, logp, log_p, log_q, log_w, row_max,
                      row_sumexp, lse, loss, unit_g_logw, unit_g_neg_logw);
+}
+void launch_iwae_loss_rows(int B, int S, float log_n, const float* logp, const float* log_p, const float* log_q,
+                           float* log_w, float* row_max, float* row_sumexp, float* lse, float* loss,
+                           float* unit_g_logw, float* unit_g_neg_logw, unsigned int* ticket, hipStream_t st) {
+  hipLaunchKernelGGL((iwae_loss_rows_kernel<256>), dim3(B), dim3(256), 0, st, B, S, log_n, logp, log_p, log_q, log_w,
+                     row_max, row_sumexp, lse, loss, unit_g_logw, unit_g_neg_logw, ticket);
 }
 void launch_iwae_combine(int N, int B, int S, float log_n, const float* gathered, const float* log_w, float* lse,
                          float* loss, float* unit_g_logw, float* unit_g_neg_logw, hipStream_t st) {

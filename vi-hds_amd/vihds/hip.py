@@ -120,8 +120,8 @@ _PROTOTYPES = {
     "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 13 + [ctypes.POINTER(ThetaOpts), _P]),
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
     "vihds_iwae_bwd": (_I, [_I, _I] + [_P] * 5),
-    "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 11),
-    "vihds_iwae_loss_unit_grad": (_I, [_I, _I]),
+    "vihds_iwae_loss_fwd": (_I, [_I, _I, _I] + [_P] * 12),
+    "vihds_iwae_loss_unit_grad": (_I, [_I, _I, _I]),
     "vihds_iwae_combine": (_I, [_I, _I, _I, _I] + [_P] * 7),
     "vihds_iwae_loss_bwd": (_I, [_I, _I] + [_P] * 6),
     "vihds_device_condition": (_I, [_I] * 6 + [ctypes.c_float, ctypes.c_float] + [_P] * 7),
@@ -157,7 +157,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 1:
+        if handle.vihds_abi_version() != 2:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

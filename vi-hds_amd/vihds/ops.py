@@ -697,6 +697,23 @@ def unit_gradient(device):
     return _UNIT[key]
 
 
+_TICKETS = {}
+
+
+def _iwae_ticket(device):
+    """The zero-initialised block counter vihds_iwae_loss_fwd finishes with (the kernel leaves it at zero again).  One
+    per (device, stream), because two launches that may overlap must not share it; launches being captured into a
+    hipGraph use one counter per device that was allocated beforehand (an allocation inside the capture would put a
+    memset node into every replay)."""
+    capturing = torch.cuda.is_current_stream_capturing()
+    key = (str(device), "capture" if capturing else torch.cuda.current_stream(device).cuda_stream)
+    if key not in _TICKETS:
+        _TICKETS[key] = torch.zeros(1, device=device, dtype=torch.int32)
+        if not capturing:
+            _TICKETS.setdefault((str(device), "capture"), torch.zeros(1, device=device, dtype=torch.int32))
+    return _TICKETS[key]
+
+
 class IwaeLoss(torch.autograd.Function):
     """Single-process -ELBO: one launch for small batches (rows kernel + finish otherwise); the gradient w.r.t.
     logp is returned as a stride-0 view over the four species (consumed without a copy by the ODE adjoint).  For
@@ -713,12 +730,14 @@ class IwaeLoss(torch.autograd.Function):
         rows = torch.empty((3, B), device=dev, dtype=torch.float32)  # row_max, row_sumexp, lse
         loss = torch.empty((), device=dev, dtype=torch.float32)
         ug = ugn = None
-        if any(ctx.needs_input_grad) and hip.lib().vihds_iwae_loss_unit_grad(B, S):
+        ticket = _iwae_ticket(dev)
+        if any(ctx.needs_input_grad) and hip.lib().vihds_iwae_loss_unit_grad(B, S, 1):
             ug = torch.empty((B, S), device=dev, dtype=torch.float32)
             ugn = torch.empty((B, S), device=dev, dtype=torch.float32) if log_q is not None else None
         rc = hip.lib().vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q),
                                            hip.ptr(log_w), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
-                                           hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.current_stream())
+                                           hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.ptr(ticket),
+                                           hip.current_stream())
         hip.check(rc, "vihds_iwae_loss_fwd")
         lse = rows[2]
         ctx.save_for_backward(log_w, lse, ug, ugn)
