@@ -115,7 +115,13 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
  *     the kernel fills `aux` (vihds_ode_bwd_aux_floats floats) with the field-major dump
  *     [F = vihds_blackbox_dump_fields()][E evaluations][B*S] (layer inputs and pre-activation gradients; field
  *     order in DESIGN.md 4.4) followed by Delta [HS+HP][B*S] and the output-bias adjoint sums [2*NX+8][B*S];
- *     g_weights is not touched.  aux may be NULL otherwise. */
+ *     g_weights is not touched.
+ *   - white-box models with neural precisions, aux != NULL (optional, vihds_ode_bwd_aux_floats floats): the same
+ *     scheme -- aux receives [8 + NIN][E][B*S] (fields 0..3 production and 4..7 degradation pre-activation adjoints,
+ *     8.. the NIN = 1 + core-states layer inputs tanh([t, species])), only the 8 bias gradients are ADDED into
+ *     g_weights, and the caller contracts the two weight matrices with vihds_gram_blocks (rectangles fields 0..3 x
+ *     8.. and 4..7 x 8..).  This keeps 2*4*NIN accumulators out of every thread's registers (relay: -36 % time).
+ *   aux may be NULL otherwise. */
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj,
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,

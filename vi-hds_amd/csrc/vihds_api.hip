@@ -254,8 +254,13 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
 
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!p) return VIHDS_E_BADARG;
-  if (p->model != VIHDS_MODEL_DR_BLACKBOX) return 0;
-  return bb_aux_floats(p->B * p->S, p->T, p->solver);
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX) return bb_aux_floats(p->B * p->S, p->T, p->solver);
+  const ModelEntry* e = entry(p->model);
+  if (!e) return VIHDS_E_UNSUPPORTED;
+  if (!e->neural_prec) return 0;
+  // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
+  const long long stages = p->solver == VIHDS_SOLVER_EULER ? 1 : (p->solver == VIHDS_SOLVER_RK4 ? 4 : 2);
+  return (long long)(8 + e->n_states() - 4 + 1) * (p->T - 1) * stages * p->B * p->S;
 }
 int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
 

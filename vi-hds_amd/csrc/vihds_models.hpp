@@ -928,12 +928,19 @@ struct WithPrec {
   template <class Ctx>
   __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* w, const float* v, float* yb,
                                  float* pb, Ctx& ctx) {
-    float* wb = ctx.wb;
     Core::rhs_vjp(t, y, p, w, v, yb, pb);
     __asm__ volatile("" ::: "memory");
     float h[NIN], hb[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int i = 0; i < NIN; ++i) hb[i] = 0.f;
+    float* D = nullptr;
+    size_t fs = 0;
+    if constexpr (Ctx::DUMP) {  // fields of the dump: 0..3 zab, 4..7 zdb, 8.. the layer inputs h
+      D = ctx.dump + (size_t)ctx.e * ctx.n;
+      fs = ctx.fstride;
+      ctx.e += 1;
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) D[(size_t)(8 + i) * fs] = h[i];
+    }
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       float za = w[O_BP + j], zd = w[O_BD + j];
       VIHDS_UNROLL for (int i = 0; i < NIN; ++i) {
@@ -945,11 +952,20 @@ struct WithPrec {
       yb[NS + j] -= vj * d;
       const float zab = vj * a * (1.f - a);
       const float zdb = -vj * y[NS + j] * d * (1.f - d);
-      wb[O_BP + j] += zab;
-      wb[O_BD + j] += zdb;
+      if constexpr (Ctx::DUMP) {
+        D[(size_t)j * fs] = zab;
+        D[(size_t)(4 + j) * fs] = zdb;
+        ctx.bsum[j] += zab;
+        ctx.bsum[4 + j] += zdb;
+      } else {
+        ctx.wb[O_BP + j] += zab;
+        ctx.wb[O_BD + j] += zdb;
+      }
       VIHDS_UNROLL for (int i = 0; i < NIN; ++i) {
-        wb[O_WP + j * NIN + i] += zab * h[i];
-        wb[O_WD + j * NIN + i] += zdb * h[i];
+        if constexpr (!Ctx::DUMP) {
+          ctx.wb[O_WP + j * NIN + i] += zab * h[i];
+          ctx.wb[O_WD + j * NIN + i] += zdb * h[i];
+        }
         hb[i] += w[O_WP + j * NIN + i] * zab + w[O_WD + j * NIN + i] * zdb;
       }
     }

@@ -64,8 +64,24 @@ __device__ __forceinline__ void observe_vjp(const float* y, const float* xpb, fl
 struct NoCtx {};
 template <int NW>
 struct WeightGradCtx {
+  static constexpr bool DUMP = false;
   float wb[NW];
 };
+// white-box + neural precisions with an aux buffer: instead of 2*4*NIN register accumulators per thread (which spill:
+// 0.4-0.5 KB of scratch per lane and a third of the adjoint's time for relay_constant_precisions) the adjoint stores,
+// per RHS evaluation, the 8 pre-activation adjoints and the NIN layer inputs field-major [8+NIN][E][n]; the weight
+// gradients are then two rectangles of vihds_gram_blocks over that dump.  Only the 8 bias sums stay in registers.
+struct PrecDumpCtx {
+  static constexpr bool DUMP = true;
+  float* dump;     // &aux[i]
+  size_t n;        // trajectories
+  size_t fstride;  // floats between consecutive fields = E * n
+  int e;           // evaluation counter
+  float bsum[8];
+};
+__host__ __device__ inline int ode_stages(int solver) {
+  return solver == VIHDS_SOLVER_EULER ? 1 : (solver == VIHDS_SOLVER_RK4 ? 4 : 2);
+}
 template <class M, bool BB = is_blackbox<M>::value, bool HAS_W = (M::NW > 0)>
 struct bwd_ctx {  // white-box
   using type = NoCtx;
@@ -88,6 +104,24 @@ struct bwd_ctx<M, true, true> {  // dr_blackbox
     c.e = 0;
     VIHDS_UNROLL for (int k = 0; k < 20; ++k) c.bsum[k] = 0.f;
   }
+};
+
+template <class M, bool DUMP>
+struct bwd_ctx_sel {
+  using impl = bwd_ctx<M>;
+};
+template <class M>
+struct bwd_ctx_sel<M, true> {
+  struct impl {
+    using type = PrecDumpCtx;
+    __device__ static void init(type& c, const OdeArgs& a, int i) {
+      c.dump = a.aux + i;
+      c.n = (size_t)a.n;
+      c.fstride = (size_t)(a.T - 1) * ode_stages(a.solver) * a.n;
+      c.e = 0;
+      VIHDS_UNROLL for (int k = 0; k < 8; ++k) c.bsum[k] = 0.f;
+    }
+  };
 };
 
 // ---- one step of each scheme ---------------------------------------------------------------------
@@ -317,7 +351,7 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
 }
 
 // ---- backward ------------------------------------------------------------------------------------
-template <class M, int SOLVER>
+template <class M, int SOLVER, bool DUMP = false>
 __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   constexpr int N = M::N;
   __shared__ float wlds[M::NW > 0 ? M::NW : 1];
@@ -336,8 +370,9 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   VIHDS_UNROLL for (int j = 0; j < M::NP; ++j) pb[j] = 0.f;
   // backward context: per-thread shared-weight gradient accumulators (white-box + neural precisions), or the
   // evaluation dump cursor (dr_blackbox)
-  typename bwd_ctx<M>::type wtsb;
-  bwd_ctx<M>::init(wtsb, a, i);
+  using CtxImpl = typename bwd_ctx_sel<M, DUMP>::impl;
+  typename CtxImpl::type wtsb;
+  CtxImpl::init(wtsb, a, i);
   const size_t n = a.n;
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
     precb[j] = 0.f;
@@ -397,11 +432,20 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   }
   if constexpr (!is_blackbox<M>::value && M::NW > 0) {
     if (a.g_weights) {
-      // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
-      VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) {
-        float v = live ? wtsb.wb[q] : 0.f;
-        VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+      if constexpr (DUMP) {
+        // only the biases are accumulated here; the weight matrices come from the dump (vihds_gram_blocks)
+        VIHDS_UNROLL for (int q = 0; q < 8; ++q) {
+          float v = live ? wtsb.bsum[q] : 0.f;
+          VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+          if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[(q < 4 ? M::O_BP + q : M::O_BD + (q - 4))], v);
+        }
+      } else {
+        // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
+        VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) {
+          float v = live ? wtsb.wb[q] : 0.f;
+          VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+          if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+        }
       }
     }
   }
@@ -422,6 +466,12 @@ inline void launch_fwd_s(const OdeArgs& a, hipStream_t st) {
 template <class M, int SOLVER>
 inline void launch_bwd_s(const OdeArgs& a, hipStream_t st) {
   const int blk = pick_block(a.n);
+  if constexpr (M::NEURAL_PREC && !is_blackbox<M>::value) {
+    if (a.aux) {  // dump mode: the caller contracts the weight gradients (vihds_ode_bwd, include/vihds_hip.h)
+      hipLaunchKernelGGL((ode_bwd_kernel<M, SOLVER, true>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
+      return;
+    }
+  }
   hipLaunchKernelGGL((ode_bwd_kernel<M, SOLVER>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
 }
 

@@ -152,8 +152,11 @@ class OdeSolveObserve(torch.autograd.Function):
         # the kernel writes every slot row; rows that are not slots (if any) must read as zero
         g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
         n_aux = hip.lib().vihds_ode_bwd_aux_floats(ctypes.byref(ctx.prob))
+        blackbox = ctx.spec.model == "dr_blackbox"
+        if not blackbox and not (weights is not None and ctx.needs_input_grad[6]):
+            n_aux = 0  # neural precisions: the dump is only worth it when the weight gradients are wanted
         # (dr_blackbox: the weight gradients come from the dump below, the kernel does not touch g_weights)
-        g_w = torch.zeros_like(weights) if weights is not None and n_aux <= 0 else None
+        g_w = torch.zeros_like(weights) if weights is not None and not blackbox else None
         prob = ctx.prob
         if g_logp is not None and g_logp.dim() == 3 and g_logp.stride(0) == 0 and g_logp[0].is_contiguous():
             prob.logp_grad_broadcast = 1  # IwaeLoss hands back one [B,S] gradient for all four species: no copy
@@ -169,7 +172,10 @@ class OdeSolveObserve(torch.autograd.Function):
             hip.ptr(g_w), hip.ptr(aux), hip.current_stream()))
         hip.check(rc, "vihds_ode_bwd")
         if aux is not None and ctx.needs_input_grad[6]:
-            g_w = blackbox_weight_grads(ctx.spec, ctx.prob, aux, theta, cond, dev1hot)
+            if blackbox:
+                g_w = blackbox_weight_grads(ctx.spec, ctx.prob, aux, theta, cond, dev1hot)
+            else:
+                neural_precision_weight_grads(ctx.spec, ctx.prob, aux, g_w)
         grads = (None, g_theta, None, None, None, None, g_w)
         if len(ctx.needs_input_grad) > 7:
             g_off = None
@@ -357,6 +363,32 @@ class DecoderStepFused(torch.autograd.Function):
                                        hip.ptr(g_all), ctypes.byref(opts), hip.current_stream())
         hip.check(rc, "vihds_theta_bwd")
         return (g_all,) + (None,) * 14
+
+
+def neural_precision_weight_grads(spec, prob, aux, g_w):
+    """White-box model + neural precisions: the two weight matrices of NeuralPrecisions (reference precisions.py:55-61,
+    76-87; buffer order Wp [4][NIN], bp [4], Wd [4][NIN], bd [4]) from the adjoint kernel's dump [8+NIN][E][n] --
+    production / degradation pre-activation adjoints (fields 0..3 / 4..7) times the layer inputs (fields 8..) -- written
+    into g_w by vihds_gram_blocks; the biases were already added to g_w by the kernel."""
+    NIN = spec.n_states - 4 + 1
+    F, n = 8 + NIN, prob.B * prob.S
+    C = aux.numel() // F
+    key = "prec_rects"
+    if key not in spec.cache:
+        rects = (hip.GramRect * 2)()
+        for k, (a0, d0) in enumerate(((0, 0), (4, 4 * NIN + 4))):
+            (rects[k].a0, rects[k].na, rects[k].b0, rects[k].nb, rects[k].dest0, rects[k].dest_stride_a,
+             rects[k].dest_stride_b) = (a0, 4, 8, NIN, d0, NIN, 1)
+        spec.cache[key] = rects
+    rects = spec.cache[key]
+    n_scr = hip.lib().vihds_gram_scratch_floats(C, 2, rects)
+    if n_scr <= 0:
+        raise RuntimeError("vihds_gram_scratch_floats: %s" % hip.lib().vihds_last_error().decode())
+    scratch = torch.empty(n_scr, device=aux.device, dtype=torch.float32)
+    rc = hip.lib().vihds_gram_blocks(F, C, 2, rects, hip.ptr(aux), hip.ptr(scratch), hip.ptr(g_w),
+                                     hip.current_stream())
+    hip.check(rc, "vihds_gram_blocks")
+    return g_w
 
 
 def _blackbox_grad_plan(spec, prob, device):
