@@ -911,9 +911,14 @@ struct WithPrec {
     h[0] = ftanh(t);
     VIHDS_UNROLL for (int i = 0; i < NS; ++i) h[i + 1] = ftanh(y[i]);
   }
-  __device__ static void rhs(float t, const float* y, const float* p, const float* w, float* dy) {
-    Core::rhs(t, y, p, w, dy);
-    __asm__ volatile("" ::: "memory");  // keep the LDS weight loads inside the time loop (no hoist-and-spill)
+  // The weights are read through the constant address space: the index is uniform, so these are scalar loads into
+  // SGPRs (s_load_dwordx16, one FMA operand each) -- no LDS staging and no 104 ds_reads per evaluation.  The buffer
+  // is never written by the kernels that read it (gradients go to g_weights / the dump).
+  typedef const __attribute__((address_space(4))) float* weights_ptr;
+  __device__ static void rhs(float t, const float* y, const float* p, const float* wg, float* dy) {
+    const weights_ptr w = (weights_ptr)wg;
+    Core::rhs(t, y, p, wg, dy);
+    __asm__ volatile("" ::: "memory");  // keep the weight loads inside the time loop (no hoist-and-spill)
     float h[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
@@ -926,9 +931,10 @@ struct WithPrec {
     }
   }
   template <class Ctx>
-  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* w, const float* v, float* yb,
+  __device__ static void rhs_vjp(float t, const float* y, const float* p, const float* wg, const float* v, float* yb,
                                  float* pb, Ctx& ctx) {
-    Core::rhs_vjp(t, y, p, w, v, yb, pb);
+    const weights_ptr w = (weights_ptr)wg;
+    Core::rhs_vjp(t, y, p, wg, v, yb, pb);
     __asm__ volatile("" ::: "memory");
     float h[NIN], hb[NIN];
     hidden(t, y, h);

@@ -252,16 +252,19 @@ __device__ __forceinline__ void load_theta(const OdeArgs& a, int i, int b, float
   VIHDS_UNROLL for (int q = 0; q < M::NC; ++q) c[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
 }
 
-// Shared neural weights are staged in LDS once per block; every lane reads the same address (broadcast).
+// Shared neural weights: dr_blackbox stages them in LDS once per block (every lane reads the same address:
+// broadcast); the white-box models with neural precisions read them as scalars straight from the caller's buffer
+// (WithPrec::weights_ptr).
 template <class M>
 __device__ __forceinline__ const float* stage_weights(const OdeArgs& a, float* lds) {
   if constexpr (M::NW == 0) {
     return nullptr;
-  } else {
-    if constexpr (is_blackbox<M>::value) M::stage(a, lds);
-    else for (int q = threadIdx.x; q < M::NW; q += blockDim.x) lds[q] = a.weights[q];
+  } else if constexpr (is_blackbox<M>::value) {
+    M::stage(a, lds);
     __syncthreads();
     return lds;
+  } else {
+    return a.weights;
   }
 }
 
