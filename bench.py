@@ -283,7 +283,7 @@ def main():
         return nb / (us * 1e-6) / 1e9
 
     pmc_kernels = {}
-    pmc_name = "r01_w_pmc_hbm_traffic.json"
+    pmc_name = "r01_z_pmc_hbm_traffic.json"
     pmc_file = os.path.join(ROOT, "profiles", pmc_name)
     if os.path.exists(pmc_file) and a.solver == "rk4":
         pmc_kernels = json.load(open(pmc_file))["kernels"]
