@@ -31,6 +31,9 @@ for (B, S) in [(36, 200), (36, 400), (36, 1000), (36, 2000), (234, 1000)]:
         b = timeit(lambda: L.vihds_ode_bwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, None, g.data_ptr(), g_theta.data_ptr(), None, None, st))
         row.append("variant %d: fwd %7.1f bwd %7.1f" % (variant, f, b))
         if variant == 2:
-            fu = timeit(lambda: L.vihds_ode_logp_grad(ctypes.byref(prob), *args, logp.data_ptr(), g_theta.data_ptr(), st))
-            row.append("fused %7.1f" % fu)
+            if L.vihds_ode_logp_grad(ctypes.byref(prob), *args, logp.data_ptr(), g_theta.data_ptr(), st) == 0:
+                fu = timeit(lambda: L.vihds_ode_logp_grad(ctypes.byref(prob), *args, logp.data_ptr(), g_theta.data_ptr(), st))
+                row.append("fused %7.1f" % fu)
+            else:
+                row.append("fused: declined")
     print("n=%6d (B=%d,S=%d) rk4: %s" % (B * S, B, S, " | ".join(row)), flush=True)
