@@ -1050,3 +1050,38 @@ def test_blackbox_tail_grads_against_torch():
     assert float((got - ref).abs().max() / ref.abs().max()) < 2e-5
     untouched = torch.ones(total, dtype=torch.bool); untouched[perm.long()] = False
     assert torch.isnan(out.cpu()[untouched]).all()
+
+
+def test_flat_parameters_alias_and_gradients():
+    """ops.FlatParameters: the parameters become views of one buffer in the given order (what the kernels read), stay
+    so through in-place updates, are re-aliased when a parameter's storage is replaced, and the flat gradient comes
+    back to each parameter as a view."""
+    from vihds import ops
+
+    a = torch.nn.Linear(3, 2).to(DEV)
+    b = torch.nn.Linear(2, 4).to(DEV)
+    params = [a.weight, a.bias, b.weight, b.bias]
+    before = [p.detach().clone() for p in params]
+    keeper = ops.FlatParameters()
+    flat = keeper(params)
+    assert flat.shape == (sum(p.numel() for p in params),) and flat.requires_grad
+    assert torch.equal(flat.detach(), torch.cat([p.reshape(-1) for p in before]))
+    off = 0
+    for p, p0 in zip(params, before):
+        assert p.data_ptr() == keeper.flat.data_ptr() + 4 * off and torch.equal(p.detach(), p0)
+        off += p.numel()
+    with torch.no_grad():
+        a.bias.add_(1.0)                                   # an optimizer's in-place update is seen by the flat buffer
+    assert torch.equal(keeper(params).detach()[6:8], before[1] + 1.0)
+    buf = keeper.flat
+    assert keeper(params).data_ptr() == buf.data_ptr()     # nothing re-packed while the aliasing holds
+    w = torch.arange(flat.numel(), device=DEV, dtype=torch.float32)
+    (keeper(params) * w).sum().backward()
+    off = 0
+    for p in params:
+        assert torch.equal(p.grad.reshape(-1), w[off:off + p.numel()])
+        off += p.numel()
+    b.weight.data = b.weight.data.clone() * 2.0            # storage replaced: re-aliased on the next call
+    flat2 = keeper(params)
+    assert b.weight.data_ptr() == keeper.flat.data_ptr() + 4 * 8
+    assert torch.equal(flat2.detach()[8:16], (before[2] * 2.0).reshape(-1))
