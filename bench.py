@@ -222,6 +222,8 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    if use_graph:
+        step(batch)  # setup, not a measured or warm-up step: allocator warm-up + hipGraph capture happen on first use
     for _ in range(a.warmup):
         loss = step(batch)
     barrier()
