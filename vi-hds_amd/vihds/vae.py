@@ -35,7 +35,9 @@ class BaseVAE(nn.Module):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
                 self._rng_state = ops.KernelNormal.new_state(seed, self.device)
             return ops.KernelNormal((n_batch, n_samples, self.n_theta), self._rng_state)
-        u = torch.tensor(np.random.randn(n_batch, n_samples, self.n_theta).astype(np.float32))
+        # (from_numpy: no host-side copy -- torch.tensor() of a 1 MB array goes through the intra-op thread pool, which
+        # costs ~25 ms per call on a 128-thread host)
+        u = torch.from_numpy(np.random.randn(n_batch, n_samples, self.n_theta).astype(np.float32))
         return u.to(self.device, non_blocking=True)
 
     def forward(self, data, samples, writer=None, epoch=None):
