@@ -233,7 +233,7 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
     if (o.s_offset < 0 || o.s_offset + p->S > o.S_total) return fail(VIHDS_E_BADARG, "bad sample window");
     t.S_total = o.S_total; t.s_off = o.s_offset;
   }
-  t.theta = theta; t.log_q = log_q; t.log_p = log_p;
+  t.theta = theta; t.n_rows = p->n_rows; t.log_q = log_q; t.log_p = log_p;
   if (co && co->E > 0) {
     if (!dev1hot || !co->relevance || !co->is_default || (!co->z && !co->rng) || p->D <= 0)
       return fail(VIHDS_E_BADARG, "conditioner: missing input");

@@ -43,6 +43,7 @@ struct ThetaStageArgs {
   unsigned int* rng;
   int S_total, s_off;
   float* theta;  // same buffer as OdeArgs::theta, written here
+  int n_rows;    // rows of theta
   float *log_q, *log_p;
   // device conditioner (E = 0: none)
   int E, cond_row0;

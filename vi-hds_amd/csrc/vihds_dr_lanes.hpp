@@ -570,7 +570,15 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
 // stay in LDS ([T][256] floats = 86 KB at T = 86) and the reverse sweep reads them from there.  Compared with
 // dr_lane_fwd_kernel + dr_lane_bwd_kernel: one launch and one prologue instead of two, no trajectory / x_predict
 // stores (29.7 MB) and no trajectory reads (19.8 MB).  Outputs: logp [4][n] and the unit-weight gradient g_theta.
-template <int VERSION, int SOLVER>
+// time grid and the observation rows of the batch rows this block spans -> LDS (no barrier: the caller's next one covers it)
+__device__ __forceinline__ void dr_lane_stage_inputs(const OdeArgs& a, int tpb, float* lds) {
+  const int first = blockIdx.x * tpb, last = min(first + tpb, a.n) - 1;
+  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
+  const float* src = a.obs + (size_t)b0 * 4 * a.T;
+  for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
+}
+template <int VERSION, int SOLVER, bool INPUTS_STAGED = false>
 __device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max, float* lds) {
   using D = DrLanes<VERSION>;
   // lds: [T] times | [nb_max][4][T] observations | [T][256] states
@@ -579,12 +587,11 @@ __device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max,
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
-  const int first = blockIdx.x * D::TPB, last = min(first + D::TPB, a.n) - 1;
-  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
-  for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
-  const float* src = a.obs + (size_t)b0 * 4 * a.T;
-  for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
-  __syncthreads();
+  const int b0 = (blockIdx.x * D::TPB) / a.S;
+  if (!INPUTS_STAGED) {
+    dr_lane_stage_inputs(a, D::TPB, lds);
+    __syncthreads();
+  }
   const float* tm = lds;
   const float* ob = lds + a.T + ((b - b0) * 4 + (j & 3)) * a.T;
   float* ys = lds + a.T + (size_t)nb_max * 4 * a.T + threadIdx.x;  // this lane's column, stride 256
@@ -658,7 +665,13 @@ __device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max,
 // theta = clip(sample(q, u)) with log q / log p for the block's 32 trajectories (the arithmetic of theta_fwd_lds_kernel;
 // here the 8 lanes of a trajectory own parameter blocks j, j+8, ...), then the device-conditioner rows (the
 // arithmetic of device_condition_kernel).  Writes theta / u / log_q / log_p to global memory; the sweeps read theta
-// back after the barrier.  `scratch` (>= 10 * nb_max * P floats of LDS) holds the per-(row, parameter) constants.
+// back after the barrier.  `scratch` (dr_lane_theta_stage_floats floats of LDS) holds the per-(row, parameter)
+// constants and the conditioner's tables.  (Routing theta / u through LDS tiles -- coalesced stores, sweeps reading
+// theta from LDS -- was measured slower: 100.7 vs 96.0 us.)
+// LDS floats the stage needs behind the time grid / observation rows
+__host__ __device__ inline size_t dr_lane_theta_stage_floats(int nb_max, int P, int E, int D, int B) {
+  return (size_t)10 * nb_max * P + (size_t)2 * E * D + (size_t)B * D;
+}
 __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const ThetaStageArgs& t, int nb_max,
                                                     float* scratch) {
   constexpr int TPB = 32;
@@ -677,39 +690,87 @@ __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const Thet
   float* t_pmu = scratch + 7 * stride;
   float* t_cp = scratch + 8 * stride;
   float* t_pprec = scratch + 9 * stride;
-  for (int e = threadIdx.x; e < nb * P; e += 256) {
-    const int bb = e / P, p = e - bb * P, b = b0 + bb;
-    const int kd = t.kind[p];
-    const int rm = t.q_rows ? t.q_rows[p] : p, rp = t.q_rows ? t.q_rows[P + p] : p;
-    const float pr = t.q_prec[rp * B + b];
-    const float prec = (kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(pr) : pr);
-    t_kind[e] = (float)kd;
-    t_mu[e] = t.q_mu[rm * B + b];
-    t_sigma[e] = 1.f / sqrtf(prec);
-    t_prec[e] = prec;
-    t_cq[e] = -LOG2PI + 0.5f * logf(prec + 1e-12f);
-    t_lo[e] = t.clip_lo[p];
-    t_hi[e] = t.clip_hi[p];
-    t_pmu[e] = t.p_mu[p];
-    t_cp[e] = -LOG2PI + 0.5f * logf(t.p_prec[p] + 1e-12f);
-    t_pprec[e] = t.p_prec[p];
-  }
-  __syncthreads();
+  float* t_cw = scratch + 10 * stride;      // [E*D] conditioner weights of this call
+  float* t_rel = t_cw + t.E * a.D;          // [E*D] relevance masks
+  float* t_dev = t_rel + t.E * a.D;         // [B*D] device one-hot rows (the conditioner's tiling reads any row)
   const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
   const int i0 = first + tl;
   const bool live = i0 < n;
   const int i = live ? i0 : n - 1;
   const int b = i / S;
   const int row = (b - b0) * P;
+  // -- table loads are issued first; the draws below need none of them and run while they are in flight
+  const int e1 = threadIdx.x;
+  const bool filler = e1 < nb * P;
+  int f_kd = 0, f_p = 0;
+  float f_pr = 1.f, f_mu = 0.f, f_lo = 0.f, f_hi = 0.f, f_pmu = 0.f, f_pp = 1.f;
+  if (filler) {
+    const int bb = e1 / P;
+    f_p = e1 - bb * P;
+    const int rm = t.q_rows ? t.q_rows[f_p] : f_p, rp = t.q_rows ? t.q_rows[P + f_p] : f_p;
+    f_kd = t.kind[f_p];
+    f_pr = t.q_prec[rp * B + b0 + bb];
+    f_mu = t.q_mu[rm * B + b0 + bb];
+    f_lo = t.clip_lo[f_p];
+    f_hi = t.clip_hi[f_p];
+    f_pmu = t.p_mu[f_p];
+    f_pp = t.p_prec[f_p];
+  }
+  if (t.E > 0) {  // conditioner tables: waves 2, 3 (the fillers sit in waves 0, 1)
+    const int ed = t.E * a.D;
+    for (int e = threadIdx.x - 128; e >= 0 && e < ed; e += 128) {
+      float zz;
+      if (t.crng) zz = philox_normal((unsigned int)e, 0xC04Du, t.crng[2], 0u, t.crng[0], t.crng[1], 0);
+      else zz = t.z[e];
+      t_cw[e] = t.w_mean + t.w_std * zz;
+      t_rel[e] = t.rel[e];
+    }
+    for (int e = threadIdx.x; e < B * a.D; e += 256) t_dev[e] = a.dev1hot[e];
+  }
+
   unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
   if (t.rng) {
     k0 = t.rng[0]; k1 = t.rng[1]; step = t.rng[2];
     gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * S));
   }
+  // this lane's parameter blocks are j, j + 8, (j + 16, ...): the first two are drawn ahead of the barrier
+  float za[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
+  if (t.rng) {
+    if (4 * j < P) philox_normal4(gidx, (unsigned int)j, step, 0u, k0, k1, za);
+    if (4 * (j + 8) < P) philox_normal4(gidx, (unsigned int)(j + 8), step, 0u, k0, k1, zb);
+  }
+  for (int e = e1; e < nb * P; e += 256) {
+    if (e != e1) {  // (more than 256 table entries: the remaining ones the plain way)
+      const int bb = e / P;
+      f_p = e - bb * P;
+      const int rm = t.q_rows ? t.q_rows[f_p] : f_p, rp = t.q_rows ? t.q_rows[P + f_p] : f_p;
+      f_kd = t.kind[f_p];
+      f_pr = t.q_prec[rp * B + b0 + bb];
+      f_mu = t.q_mu[rm * B + b0 + bb];
+      f_lo = t.clip_lo[f_p]; f_hi = t.clip_hi[f_p]; f_pmu = t.p_mu[f_p]; f_pp = t.p_prec[f_p];
+    }
+    const float prec = (f_kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(f_pr) : f_pr);
+    t_kind[e] = (float)f_kd;
+    t_mu[e] = f_mu;
+    t_sigma[e] = 1.f / sqrtf(prec);
+    t_prec[e] = prec;
+    t_cq[e] = -LOG2PI + 0.5f * logf(prec + 1e-12f);
+    t_lo[e] = f_lo;
+    t_hi[e] = f_hi;
+    t_pmu[e] = f_pmu;
+    t_cp[e] = -LOG2PI + 0.5f * logf(f_pp + 1e-12f);
+    t_pprec[e] = f_pp;
+  }
+  __syncthreads();
   float lq = 0.f, lp = 0.f;
-  for (int kb = j; 4 * kb < P; kb += 8) {
+  int it = 0;
+  for (int kb = j; 4 * kb < P; kb += 8, ++it) {
     float z4[4];
-    if (t.rng) philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
+    if (t.rng) {
+      if (it == 0) { z4[0] = za[0]; z4[1] = za[1]; z4[2] = za[2]; z4[3] = za[3]; }
+      else if (it == 1) { z4[0] = zb[0]; z4[1] = zb[1]; z4[2] = zb[2]; z4[3] = zb[3]; }
+      else philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
+    }
 #pragma unroll
     for (int jj = 0; jj < 4; ++jj) {
       const int p = 4 * kb + jj;
@@ -747,19 +808,15 @@ __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const Thet
     if (t.log_q) t.log_q[i] = lq;
     if (t.log_p) t.log_p[i] = lp;
   }
-  // device conditioner: lane e of the trajectory's group produces row cond_row0 + e
+  // device conditioner: lane e of the trajectory's group produces row cond_row0 + e.  Weights, masks and one-hot rows
+  // come from LDS (as global loads inside this data-dependent loop they were serialised: ~6 us of the launch)
   if (t.E > 0) {
-    unsigned int c0 = 0, c1 = 0, cstep = 0;
-    if (t.crng) { c0 = t.crng[0]; c1 = t.crng[1]; cstep = t.crng[2]; }
     const int r = (int)(((long long)b * t.S_total + t.s_off + (i - b * S)) % B);
     for (int e = j; e < t.E; e += 8) {
       float c = 0.f;
       for (int d = 0; d < a.D; ++d) {
-        const float hot = a.dev1hot[r * a.D + d] * t.rel[e * a.D + d];
-        float zz = 0.f;
-        if (t.crng) { if (hot != 0.f) zz = philox_normal((unsigned int)(e * a.D + d), 0xC04Du, cstep, 0u, c0, c1, 0); }
-        else zz = t.z[e * a.D + d];
-        c += (t.w_mean + t.w_std * zz) * hot;
+        const float hot = t_dev[r * a.D + d] * t_rel[e * a.D + d];
+        c += t_cw[e * a.D + d] * hot;  // (hot == 0 contributes exactly 0, as when the weight is not drawn for it)
       }
       c = fmaxf(c, 0.f);
       if (live) t.theta[(size_t)(t.cond_row0 + e) * n + i] = (t.is_default[e] ? 1.f : 0.f) + c;
@@ -768,8 +825,8 @@ __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const Thet
   __syncthreads();  // theta of this block's trajectories is in memory; the scratch region is free again
 }
 // the last block to finish advances a generator's step (every block has read it by then)
-__device__ __forceinline__ void rng_ticket(unsigned int* rng) {
-  if (rng && threadIdx.x == 0) {
+__device__ __forceinline__ void rng_ticket(unsigned int* rng, int thread = 0) {
+  if (rng && threadIdx.x == thread) {
     const unsigned int step = rng[2];
     const unsigned int ticket = atomicAdd(&rng[3], 1u);
     if (ticket == gridDim.x - 1) {
@@ -788,11 +845,12 @@ __global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_ma
 template <int VERSION, int SOLVER>
 __global__ void __launch_bounds__(256) dr_lane_train_theta_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
   extern __shared__ float lds[];
+  dr_lane_stage_inputs(a, DrLanes<VERSION>::TPB, lds);  // in flight during the sampling stage, whose barriers cover it
   dr_lane_theta_stage(a, t, nb_max, lds + a.T + (size_t)nb_max * 4 * a.T);  // scratch = the (still unused) states region
-  dr_lane_train_body<VERSION, SOLVER>(a, nb_max, lds);
+  dr_lane_train_body<VERSION, SOLVER, true>(a, nb_max, lds);
   __syncthreads();
-  rng_ticket(t.rng);
-  rng_ticket(t.crng);
+  rng_ticket(t.rng, 0);
+  rng_ticket(t.crng, 64);  // (another wave: the two atomic round trips overlap)
 }
 
 inline size_t dr_lane_train_lds_bytes(const OdeArgs& a, int tpb, int* nb_max_out) {
@@ -818,7 +876,8 @@ inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st, co
     return v;
   }();
   if ((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB > n_cu) return VIHDS_E_UNSUPPORTED;
-  if (ts && (size_t)10 * nb_max * ts->P > (size_t)a.T * 256) return VIHDS_E_UNSUPPORTED;  // stage scratch must fit
+  if (ts && dr_lane_theta_stage_floats(nb_max, ts->P, ts->E, a.D, a.B) > (size_t)a.T * 256)
+    return VIHDS_E_UNSUPPORTED;  // stage scratch must fit
   const dim3 grid((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB), block(256);
 #define VIHDS_TCASE(SV)                                                                                         \
   case SV: {                                                                                                    \
