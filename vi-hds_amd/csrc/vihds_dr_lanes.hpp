@@ -672,8 +672,11 @@ __device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max,
 __host__ __device__ inline size_t dr_lane_theta_stage_floats(int nb_max, int P, int E, int D, int B) {
   return (size_t)10 * nb_max * P + (size_t)2 * E * D + (size_t)B * D;
 }
-__device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const ThetaStageArgs& t, int nb_max,
-                                                    float* scratch) {
+struct RngTickets {
+  unsigned int u, c;  // this block's tickets of the two generators (valid in threads 0 and 64)
+};
+__device__ __forceinline__ RngTickets dr_lane_theta_stage(const OdeArgs& a, const ThetaStageArgs& t, int nb_max,
+                                                          float* scratch) {
   constexpr int TPB = 32;
   constexpr float LOG2PI = 1.8378770664093453f;
   const int n = a.n, P = t.P, B = a.B, S = a.S;
@@ -762,6 +765,12 @@ __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const Thet
     t_pprec[e] = f_pp;
   }
   __syncthreads();
+  // Every thread of this block has read the generators' step counters by now (the loads were complete at the barrier),
+  // so the block takes its tickets here and the atomics' round trips hide behind the sweeps; the last ticket holder
+  // advances the step at the very end of the kernel (rng_advance), when every other block is past this point too.
+  RngTickets tk = {0u, 0u};
+  if (t.rng && threadIdx.x == 0) tk.u = atomicAdd(&t.rng[3], 1u);
+  if (t.crng && threadIdx.x == 64) tk.c = atomicAdd(&t.crng[3], 1u);
   float lq = 0.f, lp = 0.f;
   int it = 0;
   for (int kb = j; 4 * kb < P; kb += 8, ++it) {
@@ -823,16 +832,13 @@ __device__ __forceinline__ void dr_lane_theta_stage(const OdeArgs& a, const Thet
     }
   }
   __syncthreads();  // theta of this block's trajectories is in memory; the scratch region is free again
+  return tk;
 }
-// the last block to finish advances a generator's step (every block has read it by then)
-__device__ __forceinline__ void rng_ticket(unsigned int* rng, int thread = 0) {
-  if (rng && threadIdx.x == thread) {
-    const unsigned int step = rng[2];
-    const unsigned int ticket = atomicAdd(&rng[3], 1u);
-    if (ticket == gridDim.x - 1) {
-      rng[2] = step + 1u;
-      rng[3] = 0u;
-    }
+// the holder of the last ticket advances a generator's step: every block has read it before taking its ticket
+__device__ __forceinline__ void rng_advance(unsigned int* rng, unsigned int ticket, int thread) {
+  if (rng && threadIdx.x == thread && ticket == gridDim.x - 1) {
+    rng[2] = rng[2] + 1u;
+    rng[3] = 0u;
   }
 }
 
@@ -846,11 +852,11 @@ template <int VERSION, int SOLVER>
 __global__ void __launch_bounds__(256) dr_lane_train_theta_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
   extern __shared__ float lds[];
   dr_lane_stage_inputs(a, DrLanes<VERSION>::TPB, lds);  // in flight during the sampling stage, whose barriers cover it
-  dr_lane_theta_stage(a, t, nb_max, lds + a.T + (size_t)nb_max * 4 * a.T);  // scratch = the (still unused) states region
+  // scratch = the (still unused) states region
+  const RngTickets tk = dr_lane_theta_stage(a, t, nb_max, lds + a.T + (size_t)nb_max * 4 * a.T);
   dr_lane_train_body<VERSION, SOLVER, true>(a, nb_max, lds);
-  __syncthreads();
-  rng_ticket(t.rng, 0);
-  rng_ticket(t.crng, 64);  // (another wave: the two atomic round trips overlap)
+  rng_advance(t.rng, tk.u, 0);
+  rng_advance(t.crng, tk.c, 64);
 }
 
 inline size_t dr_lane_train_lds_bytes(const OdeArgs& a, int tpb, int* nb_max_out) {
