@@ -184,18 +184,22 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
     t_cp[e] = -LOG2PI_F + 0.5f * logf(p_prec[p] + 1e-12f);
     t_pprec[e] = p_prec[p];
   }
+  // generator state: read before the barrier, so that every thread of the block holds the step counter when the block
+  // takes its ticket right after it; the ticket's round trip then hides behind the sampling work and the holder of the
+  // last ticket advances the counter at its end (a barrier + atomic on every block's tail cost microseconds)
+  unsigned int k0 = 0, k1 = 0, step = 0;
+  if (rng) { k0 = rng[0]; k1 = rng[1]; step = rng[2]; }
   __syncthreads();
+  unsigned int ticket = 0u;
+  if (rng && threadIdx.x == 0) ticket = atomicAdd(&rng[3], 1u);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = t >> 2, q = t & 3;
   const bool live = i0 < n;
   const int i = live ? i0 : n - 1;
   const int b = i / S;
   const int row = (b - b0) * P;
-  unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
-  if (rng) {
-    k0 = rng[0]; k1 = rng[1]; step = rng[2];
-    gidx = (unsigned int)(b * S_total + s_off + (i - b * S));
-  }
+  unsigned int gidx = 0;
+  if (rng) gidx = (unsigned int)(b * S_total + s_off + (i - b * S));
   float lq = 0.f, lp = 0.f;
   for (int kb = q; 4 * kb < P; kb += 4) {
     float z4[4];
@@ -211,23 +215,22 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
       } else {
         uu = u[(size_t)i * P + p];
       }
+      // straight-line: the lanes of a trajectory hold parameters of different kinds, a branch per kind runs every side
       const int e = row + p;
       const float kdf = t_kind[e], mu = t_mu[e];
-      float x;
-      if (kdf == (float)KIND_CONSTANT) {
-        x = 0.f * uu + mu;
-      } else {
-        const bool ln = kdf == (float)KIND_LOGNORMAL;
-        const float zz = mu + t_sigma[e] * uu;
-        x = ln ? expf(zz) : zz;
-        const float lo = t_lo[e], hi = t_hi[e];
-        x = x < lo ? lo : (x > hi ? hi : x);
-        const float v = ln ? logf(x + 1e-12f) : x;
-        const float jac = ln ? v : 0.f;
-        const float dq = mu - v, dp = t_pmu[e] - v;
-        lq += t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
-        lp += t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
-      }
+      const bool cst = kdf == (float)KIND_CONSTANT, ln = kdf == (float)KIND_LOGNORMAL;
+      const float zz = mu + t_sigma[e] * uu;
+      float x = ln ? expf(zz) : zz;
+      const float lo = t_lo[e], hi = t_hi[e];
+      x = x < lo ? lo : (x > hi ? hi : x);
+      const float v = ln ? logf(x + 1e-12f) : x;
+      const float jac = ln ? v : 0.f;
+      const float dq = mu - v, dp = t_pmu[e] - v;
+      const float tq = t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
+      const float tp = t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
+      lq += cst ? 0.f : tq;
+      lp += cst ? 0.f : tp;
+      x = cst ? 0.f * uu + mu : x;
       if (live) theta[(size_t)p * n + i] = x;
     }
   }
@@ -237,15 +240,9 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
     if (log_q) log_q[i] = lq;
     if (log_p) log_p[i] = lp;
   }
-  if (rng) {
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const unsigned int ticket = atomicAdd(&rng[3], 1u);
-      if (ticket == gridDim.x - 1) {
-        rng[2] = step + 1u;
-        rng[3] = 0u;
-      }
-    }
+  if (rng && threadIdx.x == 0 && ticket == gridDim.x - 1) {
+    rng[2] = step + 1u;
+    rng[3] = 0u;
   }
 }
 
