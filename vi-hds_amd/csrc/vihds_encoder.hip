@@ -286,9 +286,9 @@ encoder_bwd_row_kernel(vihds_encoder_shape s, const float* __restrict__ g_all, c
 // backward, parameter gradients: every output is a fixed-order sum over the data rows.  Tasks by block range (the
 // kernel lasts as long as its slowest block, so each small task has blocks of its own):
 //   lin_w  [H][F*Lp]    one thread per element, B-term dot over rows
-//   conv_w [F][C_in][K] one wave per element, lanes over (row, t) (a block per element, and a block per (o, c)
-//                       with all K taps, were both measured slower: 13.4 / 15.0 us vs 10.4 for the kernel)
-//   conv_b [F]          one wave per element
+//   conv_w [F][C_in][K] one block per element, threads over (row, t): 11 terms per thread, one batch of loads
+//                       (one wave per element = 43 dependent rounds: 9.0 us for the kernel; two waves: 8.0; a block: 6.5)
+//   conv_b [F]          one block per element
 //   local_w, gcond_w    one thread per element
 //   lin_b, local_b, global_free: one block together (B-term sums)
 struct EncReduceTasks {
@@ -319,31 +319,39 @@ encoder_bwd_reduce_kernel(vihds_encoder_shape s, EncReduceTasks tk, const float*
   }
   blk -= tk.nb_lin;
   if (blk < tk.nb_conv) {
-    const int e = blk * 4 + wid;  // (o, c, k)
-    if (e >= s.F * s.C_in * s.K) return;
+    // one block per (o, c, k): 11 rounds of B*Lc = 2 772 terms per thread at the headline shape, one batch of loads
+    __shared__ float partc[4];
+    const int e = blk;
     const int o = e / (s.C_in * s.K), c = (e / s.K) % s.C_in, k = e % s.K;
     float acc = 0.f;
     const int n = B * d.Lc;
-#pragma unroll 4
-    for (int q = lane; q < n; q += 64) {
+#pragma unroll 11
+    for (int q = tid; q < n; q += 256) {
       const int b = q / d.Lc, t = q - b * d.Lc;
       acc += g_conv[((size_t)b * s.F + o) * d.Lc + t] * delta_obs[((size_t)b * s.C_in + c) * s.L + t + k];
     }
     acc = wave_sum_e(acc);
-    if (lane == 0) g_conv_w[e] = acc;
+    if (lane == 0) partc[wid] = acc;
+    __syncthreads();
+    if (tid == 0) g_conv_w[e] = (partc[0] + partc[1]) + (partc[2] + partc[3]);
     return;
   }
   blk -= tk.nb_conv;
   if (blk < tk.nb_convb) {
-    const int o = blk * 4 + wid;
-    if (o >= s.F) return;
+    // one block per filter: B*Lc = 2 772 terms -> 11 per thread, all loads in flight at once.  (As one wave per
+    // filter with a plain loop -- 43 dependent rounds -- these ten sums were the long pole of the whole kernel.)
+    __shared__ float partb[4];
+    const int o = blk;
     float acc = 0.f;
-    for (int q = lane; q < B * d.Lc; q += 64) {
+#pragma unroll 11
+    for (int q = tid; q < B * d.Lc; q += 256) {
       const int b = q / d.Lc, t = q - b * d.Lc;
       acc += g_conv[((size_t)b * s.F + o) * d.Lc + t];
     }
     acc = wave_sum_e(acc);
-    if (lane == 0) g_conv_b[o] = acc;
+    if (lane == 0) partb[wid] = acc;
+    __syncthreads();
+    if (tid == 0) g_conv_b[o] = (partb[0] + partb[1]) + (partb[2] + partb[3]);
     return;
   }
   blk -= tk.nb_convb;
@@ -428,8 +436,8 @@ void launch_encoder_bwd(const vihds_encoder_shape& s, const float* g_all, const 
                      lin_w, local_w, g_pre, g_conv);
   EncReduceTasks tk;
   tk.nb_lin = (s.H * d.NPOOL + 255) / 256;
-  tk.nb_conv = (s.F * s.C_in * s.K + 3) / 4;
-  tk.nb_convb = (s.F + 3) / 4;
+  tk.nb_conv = s.F * s.C_in * s.K;
+  tk.nb_convb = s.F;
   tk.nb_localw = (2 * s.nl * d.NX + 255) / 256;
   tk.nb_gcondw = (2 * s.ng * d.NG + 255) / 256;
   const int nblocks = tk.nb_lin + tk.nb_conv + tk.nb_convb + tk.nb_localw + tk.nb_gcondw + 1;
