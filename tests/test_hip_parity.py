@@ -1085,3 +1085,50 @@ def test_flat_parameters_alias_and_gradients():
     flat2 = keeper(params)
     assert b.weight.data_ptr() == keeper.flat.data_ptr() + 4 * 8
     assert torch.equal(flat2.detach()[8:16], (before[2] * 2.0).reshape(-1))
+
+
+def test_gram_blocks_full_config4_size():
+    """The matrix-core contraction at the full dr_blackbox_icml size (117 fields x 170 evaluations x 7 200
+    trajectories = 573 MB) against float64 on the GPU, plus linearity in one operand (a size-independent property)."""
+    from vihds import hip
+
+    L = hip.lib()
+    F, C = 117, 170 * 7200
+    HS, HP, NX = 25, 20, 6
+    ZA, ZD, RHS, RGS = 0, NX, 2 * NX, 2 * NX + HS
+    RY = RGS + HS; RT = RY + NX; ZAP, ZDP = RT + 1, RT + 5; RHP = RT + 9; RGP = RHP + HP
+    ws, wp = NX + 21, 1 + NX + 21
+    o = [0]
+    for size in (HS * ws, HS, NX * HS, NX, NX * HS, NX, HP * wp, HP, 4 * HP, 4, 4 * HP, 4):
+        o.append(o[-1] + size)
+    rects = [(RGS, HS, RY, NX, o[0], ws, 1), (ZA, NX, RHS, HS, o[2], HS, 1), (ZD, NX, RHS, HS, o[4], HS, 1),
+             (RGP, HP, RT, 1, o[6], wp, 1), (RGP, HP, RY, NX, o[6] + 1, wp, 1), (ZAP, 4, RHP, HP, o[8], HP, 1),
+             (ZDP, 4, RHP, HP, o[10], HP, 1)]
+    g = torch.Generator(device=DEV).manual_seed(3)
+    X = torch.randn(F, C, device=DEV, generator=g)
+    arr = (hip.GramRect * len(rects))()
+    for k, r in enumerate(rects):
+        (arr[k].a0, arr[k].na, arr[k].b0, arr[k].nb, arr[k].dest0, arr[k].dest_stride_a, arr[k].dest_stride_b) = r
+    scratch = torch.empty(L.vihds_gram_scratch_floats(C, len(rects), arr), device=DEV)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(M):
+        out = torch.zeros(o[12], device=DEV)
+        assert L.vihds_gram_blocks(F, C, len(rects), arr, M.data_ptr(), scratch.data_ptr(), out.data_ptr(), st) == 0
+        return out
+
+    out = run(X)
+    worst = 0.0
+    for (a0, na, b0, nb, d0, sa, sb) in rects:
+        ref = X[a0:a0 + na].double() @ X[b0:b0 + nb].double().t()
+        idx = (d0 + sa * torch.arange(na, device=DEV)[:, None] + sb * torch.arange(nb, device=DEV)[None, :]).reshape(-1)
+        err = (out[idx].double() - ref.reshape(-1)).abs().max() / ref.abs().max()
+        worst = max(worst, float(err))
+    assert worst < 2e-5, worst
+    # linearity: scaling the "input" rows (y, t, hs, hp) by 3 scales every product by 3 (exactly, up to fp32 rounding)
+    X2 = X.clone()
+    for r0, n in ((RY, NX + 1), (RHS, HS), (RHP, HP)):
+        X2[r0:r0 + n] *= 3.0
+    out2 = run(X2)
+    written = out != 0
+    assert float(((out2 - 3.0 * out)[written].abs().max()) / out.abs().max()) < 1e-5
