@@ -102,7 +102,25 @@ class Fixture:
         return {k[len("decoder_grad/"):]: self.t(k) for k in self.z.files if k.startswith("decoder_grad/")}
 
 
-def rel_err(a, b):
+def rel_err(a, b, dim="auto"):
+    """Relative max-norm error, normalised PER SLICE along `dim`: max over slices k of
+    max|a_k - b_k| / max|b_k|.  north_star's "1e-4 relative on trajectories" is meant per species (species differ by
+    orders of magnitude, so one global max-norm would let a small species be 100 % off), per observed signal for the
+    log-likelihoods and per parameter for gradients.  dim="auto": 4-D tensors are the reference's [B,S,N,T] views ->
+    per species / signal (dim 2); everything else is one slice unless `dim` is given ([B,S,4] log-likelihoods: dim=2,
+    [P,B,S] / [P,B] parameter rows: dim=0)."""
     a = torch.as_tensor(a).detach().to(torch.float64).cpu()
     b = torch.as_tensor(b).detach().to(torch.float64).cpu()
-    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    if a.shape != b.shape:
+        raise AssertionError("shape mismatch %s vs %s" % (tuple(a.shape), tuple(b.shape)))
+    if dim == "auto":
+        dim = 2 if a.dim() == 4 else None
+    if dim is None or a.dim() == 0:
+        return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+    a = a.movedim(dim, 0).reshape(a.shape[dim], -1)
+    b = b.movedim(dim, 0).reshape(b.shape[dim], -1)
+    if a.shape[1] == 0:
+        return 0.0
+    err = (a - b).abs().max(1).values
+    ref = b.abs().max(1).values
+    return float((err / (ref + 1e-30)).max())

@@ -244,6 +244,15 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     fx["log_q"] = to_np(log_q)
     fx["log_p"] = to_np(log_p)
     fx["loss"] = to_np(loss)
+    # Results.init (utils.py:79-99) through Training.cost(full_output=True), training.py:150-172: the
+    # importance-weighted summaries of the evaluation path, on the same forward pass
+    with torch.no_grad():
+        res = training.cost(batch, result, cond_theta, q, p, full_output=True)
+    fx["iw_predict_mu"] = np.asarray(res.iw_predict_mu, np.float32)    # [B,4,T]
+    fx["iw_predict_std"] = np.asarray(res.iw_predict_std, np.float32)  # [B,4,T]
+    fx["iw_states"] = np.asarray(res.iw_states, np.float32)            # [B,N,T]
+    fx["iw_variance"] = np.asarray(res.iw_variance, np.float32)        # [B,4,T]
+    fx["results_elbo"] = np.asarray(res.elbo, np.float32)
     # decoder-side nn weights (blackbox / neural precisions) and their grads
     for n_, par in model.decoder.named_parameters():
         fx["decoder_param/" + n_] = to_np(par)

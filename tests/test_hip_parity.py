@@ -71,12 +71,12 @@ def test_ode_forward_matches_reference(name):
         assert rel_err(full[:, :, :-4], fx.t("x_states")) < TOL
         assert rel_err(full[:, :, -4:], fx.t("precisions")) < TOL
         assert rel_err(H.view_bsnt(xpred), fx.t("x_predict")) < TOL
-        assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+        assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
         return
     assert rel_err(H.view_bsnt(traj)[:, ::st], fx.t("x_states")) < TOL
     assert rel_err(H.view_bsnt(xpred)[:, ::st], fx.t("x_predict")) < TOL
-    assert rel_err(H.view_bsnt(traj).double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64)) < TOL
-    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+    assert rel_err(H.view_bsnt(traj).double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64), dim=1) < TOL
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
 
 
 @pytest.mark.parametrize("name", CONST_PREC_FIXTURES + NEURAL_PREC_FIXTURES)
@@ -103,7 +103,7 @@ def test_elbo_and_theta_gradient_match_reference(name):
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
     extra = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
     got = th.grad[: len(fx.names)].cpu() + extra
-    assert rel_err(got[live], fx.t("theta_grad")[live]) < GTOL
+    assert rel_err(got[live], fx.t("theta_grad")[live], dim=0) < GTOL
     if wts is not None:  # shared neural-precision weights: gradient reduced over all trajectories in-kernel
         ref = fx.decoder_weight_grads()
         gref = torch.cat([ref["ode_model.precisions." + k].reshape(-1) for k in
@@ -121,7 +121,7 @@ def test_theta_kernel_matches_reference(name):
     kind, q_mu, q_prec, p_mu, p_prec, lo, hi = H.theta_inputs(fx, DEV)
     theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_prec, kind, p_mu, p_prec, lo, hi, fx.t("u", DEV),
                                                        q_mu.shape[0])
-    assert rel_err(theta, fx.t("theta")) < 1e-5
+    assert rel_err(theta, fx.t("theta"), dim=0) < 1e-5
     assert torch.allclose(theta.cpu(), fx.t("theta"), rtol=1e-5, atol=0)
     assert rel_err(log_q, fx.t("log_q")) < TOL
     assert rel_err(log_p, fx.t("log_p")) < TOL
@@ -157,8 +157,8 @@ def test_full_chain_q_gradients_match_reference(name):
     gm[glob] = gm[glob].sum(1, keepdim=True).expand(-1, fx.B)
     gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, fx.B)
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
-    assert rel_err(gm[live], fx.t("q_mu_grad")[live]) < GTOL
-    assert rel_err(gl[live], fx.t("q_logprec_grad")[live]) < GTOL
+    assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < GTOL
+    assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL
 
 
 @pytest.mark.parametrize("variant", [1, 2])
@@ -178,7 +178,7 @@ def test_both_kernel_variants_match_reference(name, variant):
     st = int(fx.z["sample_stride"])
     assert rel_err(H.view_bsnt(traj)[:, ::st], fx.t("x_states")) < TOL
     assert rel_err(H.view_bsnt(xpred)[:, ::st], fx.t("x_predict")) < TOL
-    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
     loss, log_w, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
     assert rel_err(loss, fx.t("loss")) < TOL
     loss.backward()
@@ -190,7 +190,7 @@ def test_both_kernel_variants_match_reference(name, variant):
     (lw_extra * (torch.softmax(log_w.detach().cpu(), dim=1) * (-1.0 / fx.B))).sum().backward()
     extra = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
-    assert rel_err((th.grad[: len(fx.names)].cpu() + extra)[live], fx.t("theta_grad")[live]) < GTOL
+    assert rel_err((th.grad[: len(fx.names)].cpu() + extra)[live], fx.t("theta_grad")[live], dim=0) < GTOL
 
 
 @pytest.mark.parametrize("variant", [1, 2])
@@ -210,11 +210,11 @@ def test_lane_split_solvers_and_generic_gradients(solver, variant):
     th, row_of = H.pack_theta(fx, DEV)
     th.requires_grad_(True)
     _, _, traj, xpred, logp = _hip_forward(fx, solver=solver, theta=th, kernel_variant=variant)
-    assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+    assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
     ((H.view_bsnt(traj) * wa.to(DEV)).sum() + (H.view_bsnt(xpred) * wb.to(DEV)).sum() +
      (H.view_bs4(logp) * wc.to(DEV)).sum() * 1e-4).backward()
     ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
-    assert rel_err(th.grad[: len(fx.names)].cpu(), ref) < GTOL
+    assert rel_err(th.grad[: len(fx.names)].cpu(), ref, dim=0) < GTOL
 
 
 @pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4", "modeuler", "modeulerwhile"])
@@ -239,12 +239,12 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
     loss.backward()
     assert rel_err(H.view_bsnt(traj), xs) < TOL
     assert rel_err(H.view_bsnt(xpred), xp) < TOL
-    assert rel_err(H.view_bs4(logp), lpo) < TOL
+    assert rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
     assert rel_err(loss, loss_c) < TOL
     live = [i for i, k in enumerate(fx.kinds)]
     got = th.grad[: len(fx.names)].cpu()
     ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
-    assert rel_err(got[live], ref[live]) < GTOL
+    assert rel_err(got[live], ref[live], dim=0) < GTOL
 
 
 @pytest.mark.parametrize("variant", [0, 1])  # 0 = auto (MFMA formulation), 1 = VALU, one thread per trajectory
@@ -278,7 +278,7 @@ def test_blackbox_forward_and_gradients_match_reference(variant):
     assert rel_err(full[:, :, :-4], fx.t("x_states")) < TOL
     assert rel_err(full[:, :, -4:], fx.t("precisions")) < TOL
     assert rel_err(H.view_bsnt(xpred), fx.t("x_predict")) < TOL
-    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species")) < TOL
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
     loss, log_w, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
     assert rel_err(loss, fx.t("loss")) < TOL
     loss.backward()
@@ -311,7 +311,7 @@ def test_blackbox_forward_and_gradients_match_reference(variant):
     got_th[fx.names.index("y2")] += g[P + 1]
     got_th = got_th + torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
-    assert rel_err(got_th[live], fx.t("theta_grad")[live]) < GTOL
+    assert rel_err(got_th[live], fx.t("theta_grad")[live], dim=0) < GTOL
     # offset layer gradient follows from the y_cond rows by the chain rule (torch ops in the host model)
     assert rel_err((g[P:].sum(2) @ dev.cpu()), ref["ode_model.offset_layer.weight"]) < GTOL
 
@@ -335,7 +335,7 @@ def test_generic_upstream_gradients_traj_and_xpred():
     ((H.view_bsnt(traj) * wa.to(DEV)).sum() + (H.view_bsnt(xpred) * wb.to(DEV)).sum()).backward()
     got = th.grad[: len(fx.names)].cpu()
     ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
-    assert rel_err(got, ref) < GTOL
+    assert rel_err(got, ref, dim=0) < GTOL
 
 
 def _synthetic_theta(names, B, S, seed):
@@ -389,7 +389,7 @@ def test_relay_degrader_match_own_restatement(model, C, solver):
     loss, _, _ = ops.iwae_loss(logp * 1e-3, None, None)
     loss.backward()
     assert rel_err(H.view_bsnt(traj), xs) < TOL
-    assert rel_err(H.view_bs4(logp), lpo) < TOL
+    assert rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
     assert rel_err(loss, loss_c) < TOL
     ref = torch.stack([th[n].grad if th[n].grad is not None else zero for n in slots])
     # per-parameter comparison: gradients of different parameters differ by orders of magnitude
@@ -494,9 +494,15 @@ def test_iw_summaries_match_oracle():
     mu, sd, st, var = ops.iw_summaries(log_w, lse, traj, xpred, 8, theta=th, prec_rows=prow)
     r_mu, r_sd, r_st, r_var = O.importance_weighted_summaries(log_w.cpu(), fx.t("x_predict"), fx.t("x_states"),
                                                               fx.t("precisions"))
-    assert rel_err(mu, r_mu) < TOL and rel_err(st, r_st) < TOL and rel_err(var, r_var) < TOL
+    assert rel_err(mu, r_mu, dim=1) < TOL and rel_err(st, r_st, dim=1) < TOL and rel_err(var, r_var, dim=1) < TOL
     ok = torch.isfinite(r_sd)
     assert rel_err(sd.cpu()[ok], r_sd[ok]) < 1e-3
+    # and against the reference's own Results.init on the same forward pass (utils.py:79-99)
+    assert rel_err(mu, fx.t("iw_predict_mu"), dim=1) < TOL and rel_err(st, fx.t("iw_states"), dim=1) < TOL
+    assert rel_err(var, fx.t("iw_variance"), dim=1) < TOL
+    f_sd = fx.t("iw_predict_std")
+    ok = torch.isfinite(f_sd) & torch.isfinite(sd.cpu())
+    assert ok.float().mean() > 0.9 and rel_err(sd.cpu()[ok], f_sd[ok]) < 1e-3
 
 
 def test_bad_arguments_fail_loudly():
@@ -596,7 +602,7 @@ def test_inducer_precisions_match_own_restatement(solver):
     (logp.sum() * 1e-3).backward()
     full = H.view_bsnt(traj)
     assert rel_err(full[:, :, :5], xs) < TOL and rel_err(full[:, :, 5:], prec) < TOL
-    assert rel_err(H.view_bsnt(xpred), xp) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+    assert rel_err(H.view_bsnt(xpred), xp) < TOL and rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
     ref_w = torch.cat([prec_w[k].grad.reshape(-1) for k in keys])
     assert rel_err(wts.grad.cpu(), ref_w) < 2e-3
     zero = torch.zeros(B, S)
@@ -933,7 +939,7 @@ def test_minimal_time_grid_and_single_trajectory(model):
         spec = ops.OdeProblemSpec(model, solver, {n: i for i, n in enumerate(slots)}, len(slots), C=C)
         traj, xp, logp = ops.OdeSolveObserve.apply(spec, theta, cond.to(DEV), times.to(DEV), obs.to(DEV), None, None)
         logp.sum().backward()
-        assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo) < TOL
+        assert rel_err(H.view_bsnt(traj), xs) < TOL and rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
         for i, n in enumerate(slots):
             ref = th[n].grad
             if ref is not None and float(ref.abs().max()) > 0 and not n.startswith("init_"):

@@ -92,8 +92,8 @@ def test_encoder_initialises_to_reference_weights_and_q(name):
     q = enc(E.batch_from_fixture(fx, "cpu"))
     _, q_mu, q_prec = q.image("cpu", fx.B)
     live = torch.tensor([k != 2 for k in fx.kinds])
-    assert rel_err(q_mu[live], fx.t("q_mu")[live]) < 1e-5
-    assert rel_err(q_prec[live], fx.t("q_prec")[live]) < 1e-5
+    assert rel_err(q_mu[live], fx.t("q_mu")[live], dim=0) < 1e-5
+    assert rel_err(q_prec[live], fx.t("q_prec")[live], dim=0) < 1e-5
     assert q.get_tensor_names()[:2] == ["%s.mu" % fx.names[0], "%s.prec" % fx.names[0]]
 
 
@@ -155,3 +155,29 @@ def test_philox_known_answers():
     for ctr, key, want in kat:
         got = philox4x32_10(*ctr, *key)
         assert tuple(int(g) for g in got) == want
+
+
+def test_run_batch_with_nan_check_disabled_and_graph_needs_device_rng():
+    """nan_check_every: 0 means "never check" (INTEGRATION.md); Training._run_batch must not divide by it.  And a
+    captured step cannot replay host-side random draws: hip_graph with the reference's host RNGs is refused."""
+    from vihds import synthetic
+    from vihds.utils import TrainingLogData
+
+    args, settings, data, parameters, model, training = synthetic.build(
+        "dr_constant_icml", 4, 3, solver="modeuler", device="cpu", seed=0, nan_check_every=0)
+    assert training.nan_check_every == 0
+    calls = []
+    training.step = lambda batch: calls.append(1) or torch.tensor(float("nan"))
+    log = TrainingLogData()
+    assert training._run_batch(0.0, training.train_data, log) is True  # NaN not looked at, and no ZeroDivisionError
+    training.nan_check_every = 1
+    assert training._run_batch(0.0, training.train_data, log) is False
+    assert len(calls) == 2
+
+    settings.device = torch.device("cuda")  # (only the constructor's validation runs; nothing touches a GPU)
+    settings.params["hip_graph"] = True
+    settings.params["u_rng"] = "numpy"
+    with pytest.raises(ValueError, match="device-side random numbers"):
+        from vihds.training import Training
+
+        Training(args, settings, data, parameters, model)

@@ -71,8 +71,8 @@ def test_forward_matches_reference(name):
     assert rel_err(out["xs"][:, ::st], fx.t("x_states")) < 1e-5
     assert rel_err(out["xp"][:, ::st], fx.t("x_predict")) < 1e-5
     assert rel_err(out["prec"][:, ::st], fx.t("precisions")) < 1e-5
-    assert rel_err(out["xs"].double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64)) < 1e-5
-    assert rel_err(out["lpo"], fx.t("log_p_by_species")) < 1e-5
+    assert rel_err(out["xs"].double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64), dim=1) < 1e-5
+    assert rel_err(out["lpo"], fx.t("log_p_by_species"), dim=2) < 1e-5
     assert rel_err(out["log_q"], fx.t("log_q")) < 1e-5
     assert rel_err(out["log_p"], fx.t("log_p")) < 1e-5
     assert rel_err(out["loss"], fx.t("loss")) < 1e-5
@@ -87,7 +87,7 @@ def test_theta_and_weight_gradients_match_reference(name):
     got = torch.stack([th[n].grad if th[n].grad is not None else torch.zeros_like(th[n]) for n in fx.names])
     # Constant-kind entries (init_x ...) carry no grad in the reference (distributions.py:241-242)
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
-    assert rel_err(got[live], fx.t("theta_grad")[live]) < 2e-4
+    assert rel_err(got[live], fx.t("theta_grad")[live], dim=0) < 2e-4
     ref = fx.decoder_weight_grads()
     key = {"prod_w": "prec_production.weight", "prod_b": "prec_production.bias", "degr_w": "prec_degradation.weight",
            "degr_b": "prec_degradation.bias", "hid_w": "prec_hidden.weight", "hid_b": "prec_hidden.bias"}
@@ -140,8 +140,8 @@ def test_q_parameter_gradients_match_reference(name):
     gm[glob] = gm[glob].sum(1, keepdim=True).expand(-1, fx.B)
     gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, fx.B)
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
-    assert rel_err(gm[live], fx.t("q_mu_grad")[live]) < 2e-4
-    assert rel_err(gl[live], fx.t("q_logprec_grad")[live]) < 2e-4
+    assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < 2e-4
+    assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < 2e-4
 
 
 def test_unpinned_solvers_meet_reference_cv_criterion():
@@ -159,3 +159,21 @@ def test_unpinned_solvers_meet_reference_cv_criterion():
     ok = sol.mean(0).abs() > 1e-8
     cv = (sol.std(0, unbiased=False) / sol.mean(0))[ok]
     assert float(cv.abs().max()) < 0.05
+
+
+@pytest.mark.parametrize("name", ALL_FIXTURES)
+def test_importance_weighted_summaries_match_reference(name):
+    """Results.init (reference utils.py:79-99 via Training.cost(full_output=True)): pins
+    oracle.importance_weighted_summaries, the checker of vihds_iw_summaries."""
+    fx = Fixture(name)
+    with torch.no_grad():
+        out = _run_oracle(fx, fx.theta_dict())
+        log_w = out["lpo"].sum(2) + out["log_p"] - out["log_q"]
+        mu, std, states, var = O.importance_weighted_summaries(log_w, out["xp"], out["xs"], out["prec"])
+    assert rel_err(mu, fx.t("iw_predict_mu"), dim=1) < 1e-5
+    assert rel_err(states, fx.t("iw_states"), dim=1) < 1e-5
+    assert rel_err(var, fx.t("iw_variance"), dim=1) < 1e-5
+    ref_std = fx.t("iw_predict_std")
+    ok = torch.isfinite(ref_std) & torch.isfinite(std)  # (sqrt of a rounding-negative difference is NaN in both)
+    assert ok.float().mean() > 0.9
+    assert float(((std - ref_std)[ok]).abs().max() / ref_std[ok].abs().max()) < 1e-3

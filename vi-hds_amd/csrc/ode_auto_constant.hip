@@ -8,5 +8,6 @@ int launch_auto_constant(bool backward, int solver, const OdeArgs& a, hipStream_
 }
 int n_slots_auto_constant() { return AutoConstant::NSLOT; }
 int n_states_auto_constant() { return AutoConstant::N; }
+int n_cond_auto_constant() { return AutoConstant::NC; }
 const char* slot_name_auto_constant(int s) { return AutoConstant::slot_name(s); }
 }  // namespace vihds

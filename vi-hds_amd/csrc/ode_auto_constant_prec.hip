@@ -8,5 +8,6 @@ int launch_auto_constant_prec(bool backward, int solver, const OdeArgs& a, hipSt
 }
 int n_slots_auto_constant_prec() { return WithPrec<AutoConstant>::NSLOT; }
 int n_states_auto_constant_prec() { return WithPrec<AutoConstant>::N; }
+int n_cond_auto_constant_prec() { return WithPrec<AutoConstant>::NC; }
 const char* slot_name_auto_constant_prec(int s) { return WithPrec<AutoConstant>::slot_name(s); }
 }  // namespace vihds

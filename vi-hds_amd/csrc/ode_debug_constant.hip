@@ -8,5 +8,6 @@ int launch_debug_constant(bool backward, int solver, const OdeArgs& a, hipStream
 }
 int n_slots_debug_constant() { return DebugConstant::NSLOT; }
 int n_states_debug_constant() { return DebugConstant::N; }
+int n_cond_debug_constant() { return DebugConstant::NC; }
 const char* slot_name_debug_constant(int s) { return DebugConstant::slot_name(s); }
 }  // namespace vihds

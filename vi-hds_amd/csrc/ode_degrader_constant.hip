@@ -8,5 +8,6 @@ int launch_degrader_constant(bool backward, int solver, const OdeArgs& a, hipStr
 }
 int n_slots_degrader_constant() { return DegraderConstant::NSLOT; }
 int n_states_degrader_constant() { return DegraderConstant::N; }
+int n_cond_degrader_constant() { return DegraderConstant::NC; }
 const char* slot_name_degrader_constant(int s) { return DegraderConstant::slot_name(s); }
 }  // namespace vihds

@@ -8,5 +8,6 @@ int launch_degrader_constant_prec(bool backward, int solver, const OdeArgs& a, h
 }
 int n_slots_degrader_constant_prec() { return WithPrec<DegraderConstant>::NSLOT; }
 int n_states_degrader_constant_prec() { return WithPrec<DegraderConstant>::N; }
+int n_cond_degrader_constant_prec() { return WithPrec<DegraderConstant>::NC; }
 const char* slot_name_degrader_constant_prec(int s) { return WithPrec<DegraderConstant>::slot_name(s); }
 }  // namespace vihds

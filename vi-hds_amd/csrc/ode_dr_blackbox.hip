@@ -12,6 +12,7 @@ int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t 
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }
 int n_states_dr_blackbox() { return BB::N; }
+int n_cond_dr_blackbox() { return BB::NC; }
 const char* slot_name_dr_blackbox(int s) { return BB::slot_name(s); }
 int bb_n_weights(int n_const) { return BB::n_weights(n_const); }
 long long bb_aux_floats(int n, int T, int solver) {

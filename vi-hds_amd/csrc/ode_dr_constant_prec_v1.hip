@@ -8,5 +8,6 @@ int launch_dr_constant_prec_v1(bool backward, int solver, const OdeArgs& a, hipS
 }
 int n_slots_dr_constant_prec_v1() { return WithPrec<DrConstant<1>>::NSLOT; }
 int n_states_dr_constant_prec_v1() { return WithPrec<DrConstant<1>>::N; }
+int n_cond_dr_constant_prec_v1() { return WithPrec<DrConstant<1>>::NC; }
 const char* slot_name_dr_constant_prec_v1(int s) { return WithPrec<DrConstant<1>>::slot_name(s); }
 }  // namespace vihds

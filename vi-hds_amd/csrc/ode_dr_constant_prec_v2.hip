@@ -8,5 +8,6 @@ int launch_dr_constant_prec_v2(bool backward, int solver, const OdeArgs& a, hipS
 }
 int n_slots_dr_constant_prec_v2() { return WithPrec<DrConstant<2>>::NSLOT; }
 int n_states_dr_constant_prec_v2() { return WithPrec<DrConstant<2>>::N; }
+int n_cond_dr_constant_prec_v2() { return WithPrec<DrConstant<2>>::NC; }
 const char* slot_name_dr_constant_prec_v2(int s) { return WithPrec<DrConstant<2>>::slot_name(s); }
 }  // namespace vihds

@@ -26,5 +26,6 @@ int launch_dr_constant_train_v1(int solver, const OdeArgs& a, hipStream_t st, co
 }
 int n_slots_dr_constant_v1() { return DrConstant<1>::NSLOT; }
 int n_states_dr_constant_v1() { return DrConstant<1>::N; }
+int n_cond_dr_constant_v1() { return DrConstant<1>::NC; }
 const char* slot_name_dr_constant_v1(int s) { return DrConstant<1>::slot_name(s); }
 }  // namespace vihds

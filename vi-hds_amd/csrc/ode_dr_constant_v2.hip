@@ -26,5 +26,6 @@ int launch_dr_constant_train_v2(int solver, const OdeArgs& a, hipStream_t st, co
 }
 int n_slots_dr_constant_v2() { return DrConstant<2>::NSLOT; }
 int n_states_dr_constant_v2() { return DrConstant<2>::N; }
+int n_cond_dr_constant_v2() { return DrConstant<2>::NC; }
 const char* slot_name_dr_constant_v2(int s) { return DrConstant<2>::slot_name(s); }
 }  // namespace vihds

@@ -8,5 +8,6 @@ int launch_inducer_constant(bool backward, int solver, const OdeArgs& a, hipStre
 }
 int n_slots_inducer_constant() { return InducerConstant::NSLOT; }
 int n_states_inducer_constant() { return InducerConstant::N; }
+int n_cond_inducer_constant() { return InducerConstant::NC; }
 const char* slot_name_inducer_constant(int s) { return InducerConstant::slot_name(s); }
 }  // namespace vihds

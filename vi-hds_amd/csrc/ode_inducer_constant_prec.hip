@@ -8,5 +8,6 @@ int launch_inducer_constant_prec(bool backward, int solver, const OdeArgs& a, hi
 }
 int n_slots_inducer_constant_prec() { return WithPrec<InducerConstant>::NSLOT; }
 int n_states_inducer_constant_prec() { return WithPrec<InducerConstant>::N; }
+int n_cond_inducer_constant_prec() { return WithPrec<InducerConstant>::NC; }
 const char* slot_name_inducer_constant_prec(int s) { return WithPrec<InducerConstant>::slot_name(s); }
 }  // namespace vihds

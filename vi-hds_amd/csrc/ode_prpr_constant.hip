@@ -8,5 +8,6 @@ int launch_prpr_constant(bool backward, int solver, const OdeArgs& a, hipStream_
 }
 int n_slots_prpr_constant() { return PrprConstant::NSLOT; }
 int n_states_prpr_constant() { return PrprConstant::N; }
+int n_cond_prpr_constant() { return PrprConstant::NC; }
 const char* slot_name_prpr_constant(int s) { return PrprConstant::slot_name(s); }
 }  // namespace vihds

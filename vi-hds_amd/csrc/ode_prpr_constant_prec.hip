@@ -8,5 +8,6 @@ int launch_prpr_constant_prec(bool backward, int solver, const OdeArgs& a, hipSt
 }
 int n_slots_prpr_constant_prec() { return WithPrec<PrprConstant>::NSLOT; }
 int n_states_prpr_constant_prec() { return WithPrec<PrprConstant>::N; }
+int n_cond_prpr_constant_prec() { return WithPrec<PrprConstant>::NC; }
 const char* slot_name_prpr_constant_prec(int s) { return WithPrec<PrprConstant>::slot_name(s); }
 }  // namespace vihds

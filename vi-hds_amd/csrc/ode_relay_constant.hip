@@ -8,5 +8,6 @@ int launch_relay_constant(bool backward, int solver, const OdeArgs& a, hipStream
 }
 int n_slots_relay_constant() { return RelayConstant::NSLOT; }
 int n_states_relay_constant() { return RelayConstant::N; }
+int n_cond_relay_constant() { return RelayConstant::NC; }
 const char* slot_name_relay_constant(int s) { return RelayConstant::slot_name(s); }
 }  // namespace vihds

@@ -8,5 +8,6 @@ int launch_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipS
 }
 int n_slots_relay_constant_prec() { return WithPrec<RelayConstant>::NSLOT; }
 int n_states_relay_constant_prec() { return WithPrec<RelayConstant>::N; }
+int n_cond_relay_constant_prec() { return WithPrec<RelayConstant>::NC; }
 const char* slot_name_relay_constant_prec(int s) { return WithPrec<RelayConstant>::slot_name(s); }
 }  // namespace vihds

@@ -14,6 +14,7 @@ namespace vihds {
   int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
   int n_slots_##name();                                                         \
   int n_states_##name();                                                        \
+  int n_cond_##name();                                                          \
   const char* slot_name_##name(int s);
 VIHDS_DECL(dr_constant_v1)
 VIHDS_DECL(dr_constant_v2)
@@ -79,11 +80,12 @@ struct ModelEntry {
   int (*launch)(bool, int, const OdeArgs&, hipStream_t);
   int (*n_slots)();
   int (*n_states)();
+  int (*n_cond)();  // treatments the model reads per data row (cond[b*C + q], q < n_cond)
   const char* (*slot_name)(int);
   bool neural_prec;
 };
 #define VIHDS_ENTRY(name, np) \
-  { launch_##name, n_slots_##name, n_states_##name, slot_name_##name, np }
+  { launch_##name, n_slots_##name, n_states_##name, n_cond_##name, slot_name_##name, np }
 static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
     VIHDS_ENTRY(dr_constant_v1, false),     // VIHDS_MODEL_DR_CONSTANT
     VIHDS_ENTRY(dr_constant_v2, false),     // VIHDS_MODEL_DR_CONSTANT_V2
@@ -126,6 +128,9 @@ static const ModelEntry* entry(int model) {
 static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& a) {
   if (p->B <= 0 || p->S <= 0 || p->T < 2) return fail(VIHDS_E_BADARG, "B, S must be > 0 and T >= 2");
   if ((long long)p->B * p->S > 0x7fffffffLL) return fail(VIHDS_E_BADARG, "B*S exceeds int range");
+  if (p->C < e->n_cond()) return fail(VIHDS_E_BADARG, "the model reads more treatments per row than C provides");
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && p->n_const < p->C + p->D)
+    return fail(VIHDS_E_BADARG, "dr_blackbox: n_const must cover the C treatments and the D-wide device one-hot");
   const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
@@ -219,6 +224,8 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
     return fail(VIHDS_E_UNSUPPORTED, "the fused decoder step exists for dr_constant / dr_constant_v2 only");
   if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver");
   if (P <= 0 || P > p->n_rows) return fail(VIHDS_E_BADARG, "P out of range");
+  if (opts && co && opts->rng && opts->rng == co->rng)
+    return fail(VIHDS_E_BADARG, "the sampling stage and the conditioner need separate generator states");
   const ModelEntry* e = entry(p->model);
   OdeArgs a;
   if (int rc = build_args(p, e, a)) return rc;

@@ -170,3 +170,21 @@ def allreduce_gradients(parameters, group=None, buffer=None):
         p.grad = buffer[off: off + k].view_as(p.grad)
         off += k
     return buffer
+
+
+def combine_iw_summaries(summ, group):
+    """Results.init's importance-weighted summaries (reference utils.py:79-99) when the S axis is sharded: every rank
+    holds sums over ITS samples weighted with the globally normalised weights, so the mean, the states and the
+    variance add up across ranks; the standard deviation goes through the second moment (sd^2 + mu^2 is the local
+    weighted sum of x^2 + 1/prec).  One all-reduce over the four tensors back to back."""
+    mu, sd, st, var = summ
+    m2 = sd * sd + mu * mu
+    parts = [mu, m2, st, var]
+    flat = torch.cat([t.reshape(-1) for t in parts])
+    dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+    out, o = [], 0
+    for t in parts:
+        out.append(flat[o:o + t.numel()].view(t.shape))
+        o += t.numel()
+    mu, m2, st, var = out
+    return mu, (m2 - mu * mu).clamp_min(0).sqrt(), st, var

@@ -67,7 +67,15 @@ class Training:
         p = settings.params
         on_gpu = settings.device.type == "cuda"
         self.use_graph = bool(default_get_value(p, "hip_graph", False)) and on_gpu
-        self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))
+        self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
+        if self.use_graph:
+            # a captured step replays whatever the capture recorded: host-side draws (numpy u, CPU conditioner
+            # weights) would be frozen into the graph or leave a stale host pointer behind
+            u_rng = default_get_value(p, "u_rng", "numpy")
+            c_rng = default_get_value(p, "conditioner_rng", "cpu")
+            if u_rng not in ("device", "kernel") or c_rng not in ("device", "kernel"):
+                raise ValueError("hip_graph: true needs device-side random numbers (u_rng and conditioner_rng in "
+                                 "{'device', 'kernel'}); got u_rng=%r, conditioner_rng=%r" % (u_rng, c_rng))
         # capturable Adam keeps step counts on the device => the whole step can live in one hipGraph
         self.lr = torch.tensor(float(p.learning_rate), device=settings.device) if self.use_graph else p.learning_rate
         # one launch for the whole update, step counter on the device (vihds/optim.py)
@@ -151,6 +159,8 @@ class Training:
             mu = (w * x_predict).sum(1)
             summ = (mu, ((w * (x_predict ** 2 + 1.0 / precisions)).sum(1) - mu ** 2).sqrt(), (w * x_states).sum(1),
                     (w / precisions).sum(1))
+        if self.shard is not None:
+            summ = parallel.combine_iw_summaries(summ, group)
         output.init_from_device(self.model.decoder.state_names, q, theta, elbo, summ)
         return output
 
@@ -220,6 +230,49 @@ class Training:
             self.optimizer.zero_grad(set_to_none=True)
         return elbo.detach()
 
+    def _snapshot_training_state(self):
+        """Parameters + optimizer state before a capture's warm-up steps (a new batch shape, e.g. an epoch's last partial
+        batch, would otherwise take three extra optimizer steps that an eager run does not take)."""
+        params = [p.detach().clone() for p in self.model.parameters()]
+        flat = getattr(self.optimizer, "_flat", None)
+        opt = None
+        if flat:
+            opt = {gi: {k: st[k].clone() for k in ("m", "v", "state")} for gi, st in flat.items()}
+        rng = {id(t): t.clone() for t in self._rng_states()}
+        return params, opt, rng
+
+    def _rng_states(self):
+        """Device-side generator states the kernels advance (u draws, conditioner weights)."""
+        out = []
+        st = getattr(self.model, "_rng_state", None)
+        if st is not None:
+            out.append(st)
+        ode = self.model.decoder.ode_model
+        st = getattr(ode, "_rng_state", None)
+        if st is not None:
+            out.append(st)
+        return out
+
+    def _restore_training_state(self, snap):
+        params, opt, rng = snap
+        with torch.no_grad():
+            for p, q in zip(self.model.parameters(), params):
+                p.copy_(q)
+            flat = getattr(self.optimizer, "_flat", None)
+            if flat is not None:
+                for gi, st in flat.items():
+                    if opt is not None and gi in opt:
+                        for k in ("m", "v", "state"):
+                            st[k].copy_(opt[gi][k])
+                    else:  # the optimizer state was created by the warm-up: back to its initial value
+                        for k in ("m", "v", "state"):
+                            st[k].zero_()
+            for t in self._rng_states():
+                if id(t) in rng:
+                    t.copy_(rng[id(t)])
+                else:  # created (seeded) by the warm-up: keep the seed, rewind the step / ticket words
+                    t[2:].zero_()
+
     def graph_step(self, batch):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
         graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and a fixed batch shape.
@@ -235,10 +288,12 @@ class Training:
             static["delta_obs"] = _delta_obs(static.observations)
             s = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
+            snap = self._snapshot_training_state()
             with torch.cuda.stream(s):
                 for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
                     self.step(static)
             torch.cuda.current_stream().wait_stream(s)
+            self._restore_training_state(snap)  # the warm-up steps must not count as training steps
             self.optimizer.zero_grad(set_to_none=True)
             if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
                 g = parallel.SegmentedGraph()
@@ -263,7 +318,9 @@ class Training:
         train_start = time.time()
         elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
         self._steps += 1
-        if self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
+        if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
+            # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced
+            # the NaN has already been applied -- the parameters and Adam state are invalid after this message)
             print("Cannot proceed with ELBO = nan. Exiting.")
             return False
         log_data.batch_train_time += time.time() - train_start
