@@ -262,7 +262,8 @@ struct DrLanes {
   // Adjoint accumulators.  Everything that is linear in the stage adjoints is only summed here and mapped to the
   // parameters once, after the time loop (bwd kernel tail).
   struct Adj {
-    float sv, svt;    // sum v, sum v*t          -> c, e
+    float sv, svt;    // sum v, sum v*t          -> c
+    float svr;        // sum v*(1-t) = sum v*rd  -> e  (accumulated directly: sv - svt cancels when the promoter saturates)
     float degb;       // -sum v*y                -> deg
     float c1b, c2b;   // sum kb_bar * v1^2, v2^2 -> KGR, KGS, fR, fS
     float gbx;        // sum gamma_bar*gr*x      -> K
@@ -273,6 +274,7 @@ struct DrLanes {
     float yb = v * E.coef;
     A.sv += v;
     A.svt = fmaf(v, E.t, A.svt);
+    A.svr = fmaf(v, E.rd, A.svr);
     const float vy = v * y;
     A.degb -= vy;
     const float gamb = sum8(L.sgn * vy);
@@ -453,10 +455,10 @@ __device__ __forceinline__ void dr_lane_write_adjoints(const OdeArgs& a, int i, 
   using M = DrConstant<VERSION>;
   const size_t n = a.n;
   // ---- parameter adjoints -> theta rows (each slot row written by exactly one lane)
-  // c enters as ce = c e and cm = c (1 - e):  c_bar = sv e + svt (1 - e),  e_bar = c (sv - svt)
+  // c enters as ce = c e and cm = c (1 - e):  c_bar = sv e + svt (1 - e),  e_bar = c (sv - svt) = c sum v (1 - t)
   const bool prom = j == 2 || j == 3;
   const float cb = prom ? A.sv * L.e + A.svt * (1.f - L.e) : A.sv;
-  const float eb = L.c * (A.sv - A.svt);
+  const float eb = L.c * A.svr;
   // c1 = K1 f1, c2 = K2 f2 with (K1, f1, K2, f2) = (KGR, fR, KGS, fS) in lane 2 and (KGS, fS, KGR, fR) in lane 3
   const float KGRb = j == 3 ? A.c2b * L.fR : A.c1b * L.fR;
   const float KGSb = j == 3 ? A.c1b * L.fS : A.c2b * L.fS;
@@ -511,7 +513,7 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   float c[2], y0;
   typename D::HillTerm H;
   D::template prepare<SOLVER>(a, i, b, j, L, c, y0, H);
-  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const size_t n = a.n;
   const float glp = (a.g_logp && j < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
@@ -627,7 +629,7 @@ __device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max,
     if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
   }
   // ---- reverse sweep with unit weight on the four log-likelihoods
-  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const float glp = j < 4 ? 1.f : 0.f;
   float y_next = y;  // = state at T-1
