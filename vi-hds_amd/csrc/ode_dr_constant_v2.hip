@@ -21,7 +21,7 @@ int launch_dr_constant_v2(bool backward, int solver, const OdeArgs& a, hipStream
 }
 // fused log-likelihood + unit-weight adjoint (lane-split regime only)
 int launch_dr_constant_train_v2(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts) {
-  if (a.kernel_variant == 3 && !ts) return launch_dr_scan_train<2>(solver, a, st);  // time-parallel form
+  if ((a.kernel_variant & 0xff) == 3 && !ts) return launch_dr_scan_train<2>(solver, a, st);  // time-parallel form
   const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v2());
   if (!lanes) return VIHDS_E_UNSUPPORTED;
   return launch_dr_lane_train<2>(solver, a, st, ts);
