@@ -9,7 +9,7 @@ from test_hip_parity import _synthetic_theta
 DEV = "cuda"
 L = hip.lib()
 B, S, T = (int(v) for v in (sys.argv[1:4] if len(sys.argv) > 3 else (36, 200, 86)))
-names = {1: "parameters + hill", 2: "sigmoid table", 3: "x chain", 4: "level-1 maps + scan", 5: "level-1 steps, promoters, level-2 maps + scan",
+names = {1: "parameters, hill, sigmoids (waves 1-3)", 2: "x chains (wave 0) + barrier", 3: "gamma", 4: "level-1 maps + scan", 5: "level-1 steps, promoters, level-2 maps + scan",
          6: "log-likelihood", 7: "adjoint level 2 + promoters", 8: "adjoint level 1", 9: "adjoint x", 0: "epilogue (full kernel)"}
 for solver in ("rk4", "midpoint", "euler"):
     slots = hip.model_slots("dr_constant")

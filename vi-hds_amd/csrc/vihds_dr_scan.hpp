@@ -27,6 +27,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
+
 #include "vihds_dr_lanes.hpp"
 
 namespace vihds {
@@ -111,24 +113,29 @@ struct Rk {
     }
     return lam;
   }
-  // x in units of K (u = x / K): du = gr u (1 - u), with C[s] = h gr_s given.  Stage values us[s], returns u'.
-  // The dependent chain is two instructions per stage (u_s - u_s^2, then one fma with a pre-multiplied coefficient);
-  // everything else is off the chain.
-  __device__ __forceinline__ static float xstep(const float* C, float u, float* us) {
-    float p[NS], w[NS];
+  // x in units of K (u = x / K): du = gr u (1 - u).  The table entry of a stage is the coefficient its derivative gets
+  // where it is used next: T[s] = chain_coef(s) h gr_s with chain_coef(s) = a(s+1, s) (last stage: b(NS-1)).  Then
+  //   p_s = u_s - u_s^2,  u_{s+1} = base_{s+1} + T[s] p_s,  q_s = T[s] p_s  (= chain_coef(s) h k_s),
+  // and the dependent chain is two instructions per stage; the bases only need the q of EARLIER stages, with compile-time
+  // coefficient ratios.  Stage values us[s], returns u'.
+  static constexpr float chain_coef(int s) { return s + 1 < NS ? a(s + 1 < NS ? s + 1 : s, s) : b(NS - 1); }
+  __device__ __forceinline__ static float xstep(const float* T, float u, float* us) {
+    float p[NS], q[NS];
+    float v = u;
     VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-      float base = u;
-      VIHDS_UNROLL for (int r = 0; r + 1 < s; ++r)
-        if (a(s, r) != 0.f) base = fmaf(a(s, r), w[r], base);
-      const float v = (s > 0 && a(s, s > 0 ? s - 1 : 0) != 0.f) ? fmaf(a(s, s > 0 ? s - 1 : 0) * C[s > 0 ? s - 1 : 0], p[s > 0 ? s - 1 : 0], base) : base;
       us[s] = v;
       p[s] = fmaf(-v, v, v);
-      w[s] = C[s] * p[s];
+      q[s] = T[s] * p[s];
+      // base of the next stage value (of the step's result after the last stage): u + sum over r < s of the tableau
+      // weight of stage r there, expressed through q_r
+      float base = u;
+      VIHDS_UNROLL for (int r = 0; r < s; ++r) {
+        const float wgt = (s + 1 < NS ? a(s + 1 < NS ? s + 1 : s, r) : b(r)) / chain_coef(r);
+        if (wgt != 0.f) base = fmaf(wgt, q[r], base);
+      }
+      v = fmaf(T[s], p[s], base);
     }
-    float o = u;
-    VIHDS_UNROLL for (int s = 0; s + 1 < NS; ++s)
-      if (b(s) != 0.f) o = fmaf(b(s), w[s], o);
-    return fmaf(b(NS - 1) * C[NS - 1], p[NS - 1], o);
+    return v;
   }
   // NS consecutive floats from / to LDS as one access
   __device__ __forceinline__ static void load(const float* p, float* o) {
@@ -204,19 +211,36 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int DR_SCAN_TPB = 2;       // trajectories per block: one wavefront, 32 lanes each
-constexpr int DR_SCAN_THREADS = 64;
+constexpr int DR_SCAN_TPB = 8;         // trajectories per block: 4 wavefronts x 2, 32 lanes each
+constexpr int DR_SCAN_THREADS = 256;
+constexpr int DR_SCAN_NACC = 32;       // accumulators summed over the time axis in the epilogue (29 used)
 
-// LDS per block (floats): per trajectory the tables G (sigmoid) and U (x / K) [32 ITEMS + 1][NS]; per lane a record of
-// 14 + NS fields per step (states at the step's grid point, the yfp / cfp maps, log-likelihood injections, gamma adjoints)
+// LDS per block (floats).  Per lane and step, as vectors: VG[NS] (sigmoid, then gamma), VU[NS] (x / K at the stages),
+// VB[NS] (gamma adjoints), VQ[4] (observations, then log-likelihood injections), VY[4] + VZ[2] (states at the step's grid
+// point), VA[4] (yfp / cfp maps, later reverse-scan multipliers and injections); then the time grid and x(T-1)/K per
+// trajectory.  (The epilogue's reduction buffer overlays the per-step area.)
 template <int SOLVER>
 __host__ __device__ inline size_t dr_scan_lds_floats(int items) {
-  return (size_t)DR_SCAN_TPB * 2 * (32 * items + 1) * Rk<SOLVER>::NS + (size_t)(14 + Rk<SOLVER>::NS) * items * DR_SCAN_THREADS +
-         (size_t)(32 * items + 4);  // + the time grid
+  const size_t steps = (size_t)(3 * Rk<SOLVER>::NS + 14) * items * DR_SCAN_THREADS;
+  const size_t red = (size_t)DR_SCAN_NACC * DR_SCAN_THREADS + DR_SCAN_TPB * DR_SCAN_NACC;
+  return (steps > red ? steps : red) + (size_t)(32 * items + 4) + DR_SCAN_TPB;
 }
 #define VIHDS_ROLLED _Pragma("clang loop unroll(disable)")
 // profiling aid: kernel_variant = 3 | (phase << 8) makes the kernel return after that phase (tests/probe/scan_phases.py)
 #define VIHDS_SCAN_STOP(PH) if ((a.kernel_variant >> 8) == (PH)) return;
+
+template <int W>
+__device__ __forceinline__ void ldv(const float* p, float* o) {
+  if (W == 4) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[W > 1 ? 1 : 0] = v.y; o[W > 2 ? 2 : 0] = v.z; o[W > 3 ? 3 : 0] = v.w; }
+  else if (W == 2) { const float2 v = *reinterpret_cast<const float2*>(p); o[0] = v.x; o[W > 1 ? 1 : 0] = v.y; }
+  else o[0] = p[0];
+}
+template <int W>
+__device__ __forceinline__ void stv(float* p, const float* o) {
+  if (W == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[W > 1 ? 1 : 0], o[W > 2 ? 2 : 0], o[W > 3 ? 3 : 0]);
+  else if (W == 2) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[W > 1 ? 1 : 0]);
+  else p[0] = o[0];
+}
 
 template <int VERSION, int SOLVER, int ITEMS>
 __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds) {
@@ -224,47 +248,199 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
   using D = DrLanes<VERSION>;
   using R = Rk<SOLVER>;
   constexpr int NS = R::NS;
-  constexpr int KP = 32 * ITEMS + 1;
   constexpr int NT = DR_SCAN_THREADS;
-  const int lane = threadIdx.x & 63, l = lane & 31, half = lane >> 5;
-  const int i0 = blockIdx.x * DR_SCAN_TPB + half;
+  const int tid = threadIdx.x, lane = tid & 63, l = lane & 31, tib = tid >> 5, wave = tid >> 6;
+  const int i0 = blockIdx.x * DR_SCAN_TPB + tib;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
   const int K = a.T - 1;
   const size_t n = a.n;
-  float* tG = lds + (size_t)half * 2 * KP * NS;
-  float* tU = tG + KP * NS;
-  // per-lane record: field f of this lane's step m at rec[(f * ITEMS + m) * NT]  (consecutive lanes, consecutive words)
-  float* rec = lds + (size_t)DR_SCAN_TPB * 2 * KP * NS + lane;
-  float* tT = lds + (size_t)DR_SCAN_TPB * 2 * KP * NS + (size_t)(14 + NS) * ITEMS * NT;  // time grid [T]
+  // per-lane vector fields: field of width W, step m of thread t at base + (m * NT + t) * W
+  constexpr int O_G = 0, O_U = O_G + NS * ITEMS * NT, O_B = O_U + NS * ITEMS * NT, O_Q = O_B + NS * ITEMS * NT,
+                O_Y = O_Q + 4 * ITEMS * NT, O_Z = O_Y + 4 * ITEMS * NT, O_A = O_Z + 2 * ITEMS * NT,
+                O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC,
+                O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4;
+  auto VG = [&](int m) { return lds + O_G + (m * NT + tid) * NS; };
+  auto VU = [&](int m) { return lds + O_U + (m * NT + tid) * NS; };
+  auto VB = [&](int m) { return lds + O_B + (m * NT + tid) * NS; };
+  auto VQ = [&](int m) { return lds + O_Q + (m * NT + tid) * 4; };
+  auto VY = [&](int m) { return lds + O_Y + (m * NT + tid) * 4; };
+  auto VZ = [&](int m) { return lds + O_Z + (m * NT + tid) * 2; };
+  auto VA = [&](int m) { return lds + O_A + (m * NT + tid) * 4; };
+  float* tT = lds + O_T;    // time grid [T]
+  float* uK = lds + O_UK;   // x(T-1) / K per trajectory of the block
   enum { RFP, WW, LUXR, LASR, YFP, CFP, NSP };
-  enum { F_Y = 0, F_A2 = 6, F_B2 = 8, F_OFF = 8, F_Q = 10, F_GB = 14, F_TA = 6, F_TG = 7 };  // (B2 / OFF and A2 / TA,TG share)
-  auto fld = [&](int f, int m) -> float& { return rec[(f * ITEMS + m) * NT]; };
-  auto th = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
+  // theta rows of this trajectory in LDS (written once, by its 32 lanes; every lane then picks what it needs from
+  // there).  Lives in the VY area of this trajectory's first lanes, which nobody writes before the parameter stage is over.
+  // [0,64): theta rows; [64,66): fR, fS; [66,90): the Hill power terms (base, exponent, power) of lanes 0..7.
+  // (128 floats per trajectory: the two trajectories of a wavefront stay inside that wavefront's own slots.)
+  auto par_of = [&](int t) { return lds + O_Y + t * 128; };
+  float* par = par_of(tib);
+  auto th = [&](int slot) { return par[a.slot_row[slot]]; };
 
-  // the time grid -> LDS; this lane's observations -> the record fields that later hold the log-likelihood injections
-  // (issued first: their latency hides behind the parameter stage)
+  // ---- 0. the time grid -> LDS; this lane's observations -> VQ (their latency hides behind the parameter stage) ------
   const int k0 = l * ITEMS;
   const float* ob = a.obs + (size_t)b * 4 * a.T;
-  for (int k = lane; k < a.T; k += NT) tT[k] = a.times[k];
+  for (int k = tid; k < a.T; k += NT) tT[k] = a.times[k];
   VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
     const int kc = min(k0 + m, K - 1);
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) fld(F_Q + j, m) = ob[j * a.T + kc];
+    float o[4];
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) o[j] = ob[j * a.T + kc];
+    stv<4>(VQ(m), o);
+    float half_[NS];
+    VIHDS_UNROLL for (int s = 0; s < NS; ++s) half_[s] = 0.5f;
+    stv<NS>(VU(m), half_);  // (padding steps beyond T-1 keep this harmless value; the chain fills the real ones)
   }
   float obK[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) obK[j] = ob[j * a.T + K];
-  wave_sync();
+  VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+    const int slot = l + 32 * q;
+    if (slot < M::NSLOT + 4) {
+      const int row = a.slot_row[slot];
+      par[row] = a.theta[(size_t)row * n + i];
+    }
+  }
+  __syncthreads();
+  const float r = clampf(th(M::S_r), 0.f, 4.f), tlag = th(M::S_tlag);
+  const float h0 = tT[1] - tT[0];
+  // step m of this lane: grid index (clamped for the padding steps beyond K), validity, step size
+  struct Item {
+    int kc;
+    bool valid;
+    float h, t0, dt;
+  };
+  auto item = [&](int m) {
+    Item it;
+    it.valid = k0 + m < K;
+    it.kc = it.valid ? k0 + m : K - 1;
+    it.t0 = tT[it.kc];
+    it.dt = tT[it.kc + 1] - it.t0;
+    it.h = R::FIXED_H ? h0 : it.dt;
+    return it;
+  };
+  auto stage_sigmoid = [&](const Item& it, int s) { return sigmoid_f(4.f * (fmaf(R::c(s), it.dt, it.t0) - tlag)); };
+  // ---- 1. C[k][s] = chain_coef(s) h_k r sigmoid(4 (t_{k,s} - tlag)) for this lane's steps: what the x chain consumes
+  //         (state independent).  The table of the block's 8 trajectories sits where the gamma adjoints (VB) will go later. ------
+  float* tC = lds + O_B + tib * (32 * ITEMS * NS);  // [32 ITEMS][NS] of this trajectory
+  VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+    const Item it = item(m);
+    float C[NS];
+    VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = (R::chain_coef(s) * it.h * r) * stage_sigmoid(it, s);
+    stv<NS>(tC + (k0 + m) * NS, C);
+  }
+  __syncthreads();
+  VIHDS_SCAN_STOP(1)
+
+  // ---- 2. the x chains of the block's 8 trajectories, in wavefront 0, 8 lanes per trajectory (u = x / K, two dependent
+  //         instructions per stage, the table read one step ahead).  Stage values go to the owning lane's VU.  The other
+  //         wavefronts go through their parameter stage meanwhile. ---------------------------------------------------------
+  // gamma_s = gr_s (1 - u_s) at this lane's stages -> VG (after the chains; the last reader of the table)
+  auto gamma_pass = [&]() {
+    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+      const Item it = item(m);
+      float g[NS], us[NS];
+      ldv<NS>(tC + it.kc * NS, g);
+      ldv<NS>(VU(m), us);
+      const float invh = frcp(it.h);
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float gr = g[s] * (invh * (1.f / R::chain_coef(s))); g[s] = fmaf(-gr, us[s], gr); }
+      stv<NS>(VG(m), g);
+    }
+  };
+  // (Wavefront 0 meets the others at the two barriers below from its own branch: a workgroup barrier counts arrivals,
+  // it does not care which instruction a wavefront arrives from.)
+  if (wave == 0) {
+    const int t = lane >> 3;
+    const float* part = par_of(t);
+    float u = part[a.slot_row[M::SI + 0]] * frcp(clampf(part[a.slot_row[M::S_K]], 0.f, 4.f));
+    const float* Ct = lds + O_B + t * (32 * ITEMS * NS);
+    float Cn[NS];
+    ldv<NS>(Ct, Cn);
+    for (int k = 0; k < K; ++k) {
+      float C[NS], us[NS];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = Cn[s];
+      ldv<NS>(Ct + min(k + 1, K - 1) * NS, Cn);
+      u = R::xstep(C, u, us);
+      // (the 8 lanes of a group hold the same values and store them to the same address: no divergence in the loop)
+      const int L = k / ITEMS, m = k - L * ITEMS;
+      stv<NS>(lds + O_U + (m * NT + t * 32 + L) * NS, us);
+    }
+    uK[t] = u;
+    __syncthreads();  // the chains' stage values are in place
+    gamma_pass();
+    __syncthreads();  // the table is dead from here on: VB may be written
+  }
+
+  // ---- Hill fractions (dr_constant.py:58-73) of the block's trajectories, while the chains run: wavefronts 1-3 for their
+  //      own two trajectories, wavefront 1 also for wavefront 0's.  Lanes 0..7 of a half-wave hold the power terms
+  //      (v1: (K6 c6)^n, (K12 c12)^n, (1 + K6 c6 + K12 c12)^n for LuxR and LasR; v2: four terms), as in DrLanes::hill.
+  auto treatments = [&](int traj, float* c) {
+    const int bb = min(blockIdx.x * DR_SCAN_TPB + traj, a.n - 1) / a.S;
+    c[0] = clampf(expf(a.cond[bb * a.C + 0]) - 1.f, 1e-12f, 1e6f);
+    c[1] = clampf(expf(a.cond[bb * a.C + 1]) - 1.f, 1e-12f, 1e6f);
+  };
+  if (wave != 0) {
+    VIHDS_ROLLED for (int pass = 0; pass < (wave == 1 ? 2 : 1); ++pass) {
+      const int tp = pass == 0 ? tib : tib - 2;
+      float* pp = par_of(tp);
+      auto tht = [&](int slot) { return pp[a.slot_row[slot]]; };
+      float cc[2];
+      treatments(tp, cc);
+      const int j = l & 7;
+      const float nR = clampf(tht(M::S_nR), 0.5f, 3.f), nS = clampf(tht(M::S_nS), 0.5f, 3.f);
+      float base, ex, fR_, fS_;
+      if (VERSION == 1) {
+        const bool isR = j < 3;
+        const float K6 = clampf(tht(isR ? M::S_H0 : M::S_H2), 1e-12f, 1.f);
+        const float K12 = clampf(tht(isR ? M::S_H1 : M::S_H3), 1e-12f, 1.f);
+        const float ta = K6 * cc[0], tb = K12 * cc[1];
+        const int k = isR ? j : j - 3;
+        base = j >= 6 ? 1.f : (k == 0 ? ta : (k == 1 ? tb : 1.f + ta + tb));
+        ex = j >= 6 ? 1.f : (isR ? nR : nS);
+      } else {
+        const float eS6 = clampf(tht(M::S_H0), 1e-12f, 1.f), eR12 = clampf(tht(M::S_H1), 1e-12f, 1.f);
+        base = j == 0 ? cc[0] : (j == 1 ? eR12 * cc[1] : (j == 2 ? eS6 * cc[0] : (j == 3 ? cc[1] : 1.f)));
+        ex = j < 2 ? nR : (j < 4 ? nS : 1.f);
+      }
+      const float pw = powf(base, ex);
+      if (VERSION == 1) {
+        fR_ = (bcast8<0>(pw) + bcast8<1>(pw)) / bcast8<2>(pw);
+        fS_ = (bcast8<3>(pw) + bcast8<4>(pw)) / bcast8<5>(pw);
+      } else {
+        fR_ = bcast8<0>(pw) + bcast8<1>(pw);
+        fS_ = bcast8<2>(pw) + bcast8<3>(pw);
+      }
+      if (l < 8) {
+        pp[66 + l] = base;
+        pp[74 + l] = ex;
+        pp[82 + l] = pw;
+      }
+      if (l == 0) {
+        pp[64] = fR_;
+        pp[65] = fS_;
+      }
+    }
+    __syncthreads();  // the chains' stage values are in place
+    gamma_pass();
+    __syncthreads();
+  }
+  VIHDS_SCAN_STOP(2)
 
   // ---- parameters of this trajectory (every lane of its 32 holds them) -----------------------------------------
   float c[2];
-  c[0] = clampf(expf(a.cond[b * a.C + 0]) - 1.f, 1e-12f, 1e6f);
-  c[1] = clampf(expf(a.cond[b * a.C + 1]) - 1.f, 1e-12f, 1e6f);
-  const float r = clampf(th(M::S_r), 0.f, 4.f), Kc = clampf(th(M::S_K), 0.f, 4.f), invK = frcp(Kc);
-  const float tlag = th(M::S_tlag), rc = th(M::S_rc);
+  treatments(tib, c);
+  const float Kc = clampf(th(M::S_K), 0.f, 4.f), invK = frcp(Kc);
+  const float rc = th(M::S_rc);
   typename D::HillTerm H;
-  float fR, fS;
-  D::hill(a, i, l & 7, c, H, fR, fS);  // (each 8-lane group evaluates the power terms side by side)
+  H.base = par[66 + (l & 7)];
+  H.n = par[74 + (l & 7)];
+  H.pw = par[82 + (l & 7)];
+  const float fR = par[64], fS = par[65];
+  // where torch.clamp passes the gradient (bounds included), for the epilogue
+  const float pass_r = clamp_pass(th(M::S_r), 0.f, 4.f), pass_K = clamp_pass(th(M::S_K), 0.f, 4.f);
+  const float pass_d[5] = {clamp_pass(th(M::S_drfp), 1e-12f, 2.f), clamp_pass(th(M::S_dyfp), 1e-12f, 2.f),
+                           clamp_pass(th(M::S_dcfp), 1e-12f, 2.f), clamp_pass(th(M::S_dR), 1e-12f, 5.f),
+                           clamp_pass(th(M::S_dS), 1e-12f, 5.f)};
   float delta[NSP], F1[4];
   delta[RFP] = clampf(th(M::S_drfp), 1e-12f, 2.f);
   delta[WW] = 0.f;
@@ -283,67 +459,11 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
   float prec[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) prec[j] = th(M::NSLOT + j);
   float y0[NSP];
-  const float x0 = th(M::SI + 0);
   y0[RFP] = th(M::SI + 1); y0[YFP] = th(M::SI + 2); y0[CFP] = th(M::SI + 3); y0[WW] = 0.f;
   y0[LUXR] = th(M::SI + 4); y0[LASR] = th(M::SI + 5);
 
-  VIHDS_SCAN_STOP(1)
-  const float h0 = tT[1] - tT[0];
-  // step m of this lane: grid index (clamped for the padding steps beyond K), validity, step size
-  struct Item {
-    int kc;
-    bool valid;
-    float h, invh, t0, dt;
-  };
-  auto item = [&](int m) {
-    Item it;
-    it.valid = k0 + m < K;
-    it.kc = it.valid ? k0 + m : K - 1;
-    it.t0 = tT[it.kc];
-    it.dt = tT[it.kc + 1] - it.t0;
-    it.h = R::FIXED_H ? h0 : it.dt;
-    it.invh = frcp(it.h);
-    return it;
-  };
-  auto load_stage = [&](const Item& it, float* gam, float* us) {  // gamma_s = gr_s (1 - u_s) at the stages of step kc
-    float C[NS];
-    R::load(&tG[it.kc * NS], C);
-    R::load(&tU[it.kc * NS], us);
-    VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-      const float g = C[s] * it.invh;
-      gam[s] = fmaf(-g, us[s], g);
-    }
-  };
-  auto load_q = [&](int m, float* q) { VIHDS_UNROLL for (int j = 0; j < 4; ++j) q[j] = fld(F_Q + j, m); };
-  auto stage_sigmoid = [&](const Item& it, int s) { return sigmoid_f(4.f * (fmaf(R::c(s), it.dt, it.t0) - tlag)); };
-
-  // ---- 1. table C[k][s] = h_k r sigmoid(4 (t_{k,s} - tlag)): what the x chain consumes (state independent) -----------
-  VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
-    const Item it = item(m);
-    float C[NS];
-    VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = (it.h * r) * stage_sigmoid(it, s);
-    R::store(&tG[(k0 + m) * NS], C);
-  }
-  wave_sync();
-
-  VIHDS_SCAN_STOP(2)
-  // ---- 2. the x chain (u = x / K), redundantly in all lanes of the half-wave; lane 0 records the stage values ------
-  {
-    float u = x0 * invK;
-    float Cn[NS];
-    R::load(&tG[0], Cn);
-    for (int k = 0; k < K; ++k) {
-      float C[NS], us[NS];
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = Cn[s];
-      R::load(&tG[(k + 1) * NS], Cn);  // (one step ahead; the table has a padding entry behind the last step)
-      u = R::xstep(C, u, us);
-      if (l == 0) R::store(&tU[k * NS], us);
-    }
-    if (l == 0) tU[K * NS] = u;
-  }
-  wave_sync();
+  const float xK = Kc * uK[tib];  // x at the last grid point
   VIHDS_SCAN_STOP(3)
-  const float xK = Kc * tU[K * NS];  // x at the last grid point
 
   // ---- 3. level 1 (rfp, W, luxR, lasR): per-step affine maps composed over this lane's steps, scan over lanes ----------
   float ys[NSP];  // state at this lane's first grid point
@@ -352,8 +472,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) lm[j] = {1.f, 0.f};
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
-      float gam[NS], us[NS];
-      load_stage(it, gam, us);
+      float gam[NS];
+      ldv<NS>(VG(m), gam);
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
         float as[NS], Fs[NS];
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; }
@@ -380,16 +500,17 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
     Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
-      float gam[NS], us[NS];
-      load_stage(it, gam, us);
+      float gam[NS];
+      ldv<NS>(VG(m), gam);
       float YR[NS], YS[NS], dummy[NS];
+      stv<4>(VY(m), cur);
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-        fld(F_Y + j, m) = cur[j];
         float as[NS], Fs[NS];
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; }
         const float nx = R::real(it.h, as, Fs, cur[j], j == LUXR ? YR : (j == LASR ? YS : dummy));
         cur[j] = it.valid ? nx : cur[j];
       }
+      float ab[4];
       VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
         float as[NS], Fs[NS];
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
@@ -401,10 +522,11 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
         Aff st;
         R::affine(it.h, as, Fs, st.a, st.b);
         if (!it.valid) st = {1.f, 0.f};
-        fld(F_A2 + q, m) = st.a;
-        fld(F_B2 + q, m) = st.b;
+        ab[q] = st.a;
+        ab[2 + q] = st.b;
         lm[q] = after(st, lm[q]);
       }
+      stv<4>(VA(m), ab);
     }
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) yend[j] = cur[j];
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
@@ -435,17 +557,19 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
       a530b += qo[2] * x * w;  // f530 = a530 W, f480 = a480 W: their amplitudes only enter here
       a480b += qo[3] * x * w;
     };
-    float cy = ys[YFP], cc = ys[CFP];
+    float cz[2] = {ys[YFP], ys[CFP]};
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
-      const Item it = item(m);
-      fld(F_Y + YFP, m) = cy;
-      fld(F_Y + CFP, m) = cc;
-      float qo[4], obk[4];
-      load_q(m, obk);
-      point(obk, it.valid, Kc * tU[it.kc * NS], fld(F_Y + RFP, m), cy, cc, fld(F_Y + WW, m), qo);
-      VIHDS_UNROLL for (int j = 0; j < 4; ++j) fld(F_Q + j, m) = qo[j];
-      cy = fmaf(fld(F_A2 + 0, m), cy, fld(F_B2 + 0, m));  // (identity map on the padding steps)
-      cc = fmaf(fld(F_A2 + 1, m), cc, fld(F_B2 + 1, m));
+      const bool valid = k0 + m < K;
+      float qo[4], obk[4], y4[4], ab[4], us[NS];
+      ldv<4>(VQ(m), obk);
+      ldv<4>(VY(m), y4);
+      ldv<4>(VA(m), ab);
+      ldv<NS>(VU(m), us);
+      stv<2>(VZ(m), cz);
+      point(obk, valid, Kc * us[0], y4[RFP], cz[0], cz[1], y4[WW], qo);
+      stv<4>(VQ(m), qo);
+      cz[0] = fmaf(ab[0], cz[0], ab[2]);  // (identity map on the padding steps)
+      cz[1] = fmaf(ab[1], cz[1], ab[3]);
     }
     point(obK, owner_last, xK, yend[RFP], yend[YFP], yend[CFP], yend[WW], qK);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
@@ -462,19 +586,14 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
     return j == RFP ? q[1] * x : (j == YFP ? q[2] * x : (j == CFP ? q[3] * x : (j == WW ? x * fmaf(a530, q[2], a480 * q[3]) : 0.f)));
   };
   // Reverse recurrence of one species over this lane's steps:
-  //     Lambda_k = A_k (Lambda_{k+1} + post_k) + g_k,    post_k = gK at k = K-1 (the terminal injection), else 0,
-  // with (A_k, g_k) read through getA / getG.  lane_map: the composition over this lane's steps; lane_entry: Lambda
-  // entering this lane from the steps above it (0 beyond the last lane).
-  auto lane_map = [&](auto getA, auto getG, float gK) {
-    Aff lm = {1.f, 0.f};
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
-      const bool valid = k0 + m < K, last = k0 + m == K - 1;
-      const float A = getA(m);
-      Aff st = {A, fmaf(A, last ? gK : 0.f, getG(m))};
-      if (!valid) st = {1.f, 0.f};
-      lm = after(st, lm);
-    }
-    return lm;
+  //     Lambda_k = A_k (Lambda_{k+1} + post_k) + g_k,    post_k = gK at k = K-1 (the terminal injection), else 0.
+  // lane_step: one more (earlier) step in front of the composition so far; lane_entry: Lambda entering this lane from the
+  // steps above it (0 beyond the last lane).
+  auto lane_step = [&](Aff& lm, int m, float A, float g, float gK) {
+    const bool valid = k0 + m < K, last = k0 + m == K - 1;
+    Aff st = {A, fmaf(A, last ? gK : 0.f, g)};
+    if (!valid) st = {1.f, 0.f};
+    lm = after(st, lm);
   };
   auto lane_entry = [&](const Aff& lm) {
     const Aff sc = scan_down32(lm, lane);  // applied to 0: Lambda at this lane's first grid point
@@ -488,26 +607,36 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
   // level 2 (yfp, cfp) with the promoter adjoints -> stage injections for luxR / lasR
   {
     float lam[2];
-    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-      const Aff lm = lane_map([&](int m) { return fld(F_A2 + q, m); },
-                              [&](int m) { float qq[4]; load_q(m, qq); return ginj(YFP + q, qq, Kc * tU[min(k0 + m, K - 1) * NS]); },
-                              ginj(YFP + q, qK, xK));
-      lam[q] = lane_entry(lm);
+    const float gK2[2] = {ginj(YFP, qK, xK), ginj(CFP, qK, xK)};
+    {
+      Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
+      VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+        float qq[4], ab[4], us[NS];
+        ldv<4>(VQ(m), qq);
+        ldv<4>(VA(m), ab);
+        ldv<NS>(VU(m), us);
+        VIHDS_UNROLL for (int q = 0; q < 2; ++q) lane_step(lm[q], m, ab[q], ginj(YFP + q, qq, Kc * us[0]), gK2[q]);
+      }
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) lam[q] = lane_entry(lm[q]);
     }
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
-      float gam[NS], us[NS], qq[4];
-      load_stage(it, gam, us);
-      load_q(m, qq);
+      float gam[NS], us[NS], qq[4], y4[4], z2[2], ab[4];
+      ldv<NS>(VG(m), gam);
+      ldv<NS>(VU(m), us);
+      ldv<4>(VQ(m), qq);
+      ldv<4>(VY(m), y4);
+      ldv<2>(VZ(m), z2);
+      ldv<4>(VA(m), ab);
       // stage values of luxR / lasR again, promoters, stage values of yfp / cfp
       float YR[NS], YS[NS], aR_[NS], aS_[NS], FR[NS], FS[NS];
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
         aR_[s] = gam[s] + delta[LUXR]; aS_[s] = gam[s] + delta[LASR];
         FR[s] = F1[LUXR]; FS[s] = F1[LASR];
       }
-      R::real(it.h, aR_, FR, fld(F_Y + LUXR, m), YR);
-      R::real(it.h, aS_, FS, fld(F_Y + LASR, m), YS);
+      R::real(it.h, aR_, FR, y4[LUXR], YR);
+      R::real(it.h, aS_, FS, y4[LASR], YS);
       float JR[NS], JS[NS], gb[NS];
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) { JR[s] = 0.f; JS[s] = 0.f; gb[s] = 0.f; }
       VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
@@ -520,15 +649,15 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
           as[s] = gam[s] + delta[YFP + q];
           Jz[s] = 0.f;
         }
-        R::real(it.h, as, Fs, fld(F_Y + YFP + q, m), Y);
-        const float lin = lam[q] + (last ? ginj(YFP + q, qK, xK) : 0.f);  // Lambda_{k+1} (+ terminal injection)
+        R::real(it.h, as, Fs, z2[q], Y);
+        const float lin = lam[q] + (last ? gK2[q] : 0.f);  // Lambda_{k+1} (+ terminal injection)
         R::reverse(it.h, as, it.valid ? lin : 0.f, Jz, kbar);
-        if (it.valid) lam[q] = fmaf(fld(F_A2 + q, m), lin, ginj(YFP + q, qq, Kc * us[0]));
+        if (it.valid) lam[q] = fmaf(ab[q], lin, ginj(YFP + q, qq, Kc * us[0]));
         const float cm = pc[q] * (1.f - pe[q]);
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-          const float ab = -Y[s] * kbar[s];
-          gb[s] += ab;
-          degb[YFP + q] += ab;
+          const float abar = -Y[s] * kbar[s];
+          gb[s] += abar;
+          degb[YFP + q] += abar;
           sv[YFP + q] += kbar[s];
           svt[q] = fmaf(kbar[s], t[s], svt[q]);
           svr[q] = fmaf(kbar[s], rd[s], svr[q]);
@@ -543,87 +672,117 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
       // driven by Lambda_{k+1} follows after their scan)
       float kv[NS];
       const float oR = R::reverse(it.h, aR_, 0.f, JR, kv);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float ab = -YR[s] * kv[s]; gb[s] += ab; degb[LUXR] += ab; sv[LUXR] += kv[s]; }
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float abar = -YR[s] * kv[s]; gb[s] += abar; degb[LUXR] += abar; sv[LUXR] += kv[s]; }
       const float oS = R::reverse(it.h, aS_, 0.f, JS, kv);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float ab = -YS[s] * kv[s]; gb[s] += ab; degb[LASR] += ab; sv[LASR] += kv[s]; }
-      fld(F_OFF + 0, m) = it.valid ? oR : 0.f;
-      fld(F_OFF + 1, m) = it.valid ? oS : 0.f;
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) fld(F_GB + s, m) = gb[s];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float abar = -YS[s] * kv[s]; gb[s] += abar; degb[LASR] += abar; sv[LASR] += kv[s]; }
+      ab[2] = it.valid ? oR : 0.f;  // (the slots of the forward maps' offsets now carry luxR / lasR's injection-driven offsets)
+      ab[3] = it.valid ? oS : 0.f;
+      stv<4>(VA(m), ab);
+      stv<NS>(VB(m), gb);
     }
     lam0[YFP] = lam[0];
     lam0[CFP] = lam[1];
   }
   VIHDS_SCAN_STOP(7)
-  // level 1 (rfp, W, luxR, lasR): multipliers and scan, then the Lambda-driven part of the step adjoints
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {  // multiplier and injection of every step -> TA, TG
+  // level 1 in two pairs, (luxR, lasR) then (rfp, W): multipliers and injections of every step -> VA, scan, then the
+  // Lambda-driven part of the step adjoints
+  auto level1_pair = [&](auto JA, auto JB) {
+    constexpr int jA = decltype(JA)::value, jB = decltype(JB)::value;
+    constexpr bool inj = jA == LUXR;  // luxR / lasR carry the offsets left in VA by the level-2 pass
+    const float gK[2] = {ginj(jA, qK, xK), ginj(jB, qK, xK)};
+    Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
+    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
-      float gam[NS], us[NS], as[NS], Fz[NS], qq[4], A, dB;
-      load_stage(it, gam, us);
-      load_q(m, qq);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fz[s] = 0.f; }
-      R::affine(it.h, as, Fz, A, dB);
-      fld(F_TA, m) = A;
-      fld(F_TG, m) = ginj(j, qq, Kc * us[0]) + (j == LUXR ? fld(F_OFF + 0, m) : (j == LASR ? fld(F_OFF + 1, m) : 0.f));
+      float gam[NS], us[NS], qq[4], ab[4], as[NS], Fz[NS], dB;
+      ldv<NS>(VG(m), gam);
+      ldv<NS>(VU(m), us);
+      ldv<4>(VQ(m), qq);
+      ldv<4>(VA(m), ab);
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) Fz[s] = 0.f;
+      float tag[4];
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+        const int j = q == 0 ? jA : jB;
+        VIHDS_UNROLL for (int s = 0; s < NS; ++s) as[s] = gam[s] + delta[j];
+        R::affine(it.h, as, Fz, tag[q], dB);
+        tag[2 + q] = ginj(j, qq, Kc * us[0]) + (inj ? ab[2 + q] : 0.f);
+        lane_step(lm[q], m, tag[q], tag[2 + q], gK[q]);
+      }
+      stv<4>(VA(m), tag);
     }
-    const float gK = ginj(j, qK, xK);
-    float lam = lane_entry(lane_map([&](int m) { return fld(F_TA, m); }, [&](int m) { return fld(F_TG, m); }, gK));
+    float lam[2] = {lane_entry(lm[0]), lane_entry(lm[1])};
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
-      float gam[NS], us[NS], as[NS], Fs[NS], Y[NS], kbar[NS], Jz[NS];
-      load_stage(it, gam, us);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; Jz[s] = 0.f; }
-      R::real(it.h, as, Fs, fld(F_Y + j, m), Y);
-      const float lin = lam + (last ? gK : 0.f);
-      R::reverse(it.h, as, it.valid ? lin : 0.f, Jz, kbar);
-      if (it.valid) lam = fmaf(fld(F_TA, m), lin, fld(F_TG, m));
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-        const float ab = -Y[s] * kbar[s];
-        degb[j] += ab;
-        sv[j] += kbar[s];
-        fld(F_GB + s, m) += ab;
+      float gam[NS], y4[4], tag[4], gb[NS];
+      ldv<NS>(VG(m), gam);
+      ldv<4>(VY(m), y4);
+      ldv<4>(VA(m), tag);
+      ldv<NS>(VB(m), gb);
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+        const int j = q == 0 ? jA : jB;
+        float as[NS], Fs[NS], Y[NS], kbar[NS], Jz[NS];
+        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; Jz[s] = 0.f; }
+        R::real(it.h, as, Fs, y4[j], Y);
+        const float lin = lam[q] + (last ? gK[q] : 0.f);
+        R::reverse(it.h, as, it.valid ? lin : 0.f, Jz, kbar);
+        if (it.valid) lam[q] = fmaf(tag[q], lin, tag[2 + q]);
+        VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
+          const float abar = -Y[s] * kbar[s];
+          degb[j] += abar;
+          sv[j] += kbar[s];
+          gb[s] += abar;
+        }
       }
+      stv<NS>(VB(m), gb);
     }
-    lam0[j] = lam;
-  }
+    lam0[jA] = lam[0];
+    lam0[jB] = lam[1];
+  };
+  level1_pair(std::integral_constant<int, LUXR>{}, std::integral_constant<int, LASR>{});
+  level1_pair(std::integral_constant<int, RFP>{}, std::integral_constant<int, WW>{});
   VIHDS_SCAN_STOP(8)
   // x: tangent multipliers a_s = -gr_s (1 - 2 u_s), stage injections -gamma_bar gr / K, scan, then r, tlag, K
   float rb = 0.f, tlb = 0.f, gbx = 0.f, lamx;
   {
     auto x_stage = [&](int m, const Item& it, float* sg, float* us, float* ax, float* gbo, float* Jx) {
+      ldv<NS>(VU(m), us);
+      ldv<NS>(VB(m), gbo);
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
         sg[s] = stage_sigmoid(it, s);
-        us[s] = tU[it.kc * NS + s];
         const float g = r * sg[s];
         ax[s] = -g * fmaf(-2.f, us[s], 1.f);
-        gbo[s] = it.valid ? fld(F_GB + s, m) : 0.f;
+        gbo[s] = it.valid ? gbo[s] : 0.f;
         Jx[s] = -gbo[s] * g * invK;
       }
     };
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+    const float gK = qK[0] + qK[1] * yend[RFP] + qK[2] * fmaf(a530, yend[WW], yend[YFP]) + qK[3] * fmaf(a480, yend[WW], yend[CFP]);
+    Aff lm = {1.f, 0.f};
+    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
-      float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], Fz[NS], kv[NS], qq[4], A, dB;
+      float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], Fz[NS], kv[NS], qq[4], y4[4], z2[2], tag[4], A, dB;
       x_stage(m, it, sg, us, ax, gbo, Jx);
-      load_q(m, qq);
+      ldv<4>(VQ(m), qq);
+      ldv<4>(VY(m), y4);
+      ldv<2>(VZ(m), z2);
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) Fz[s] = 0.f;
       R::affine(it.h, ax, Fz, A, dB);
       const float off = it.valid ? R::reverse(it.h, ax, 0.f, Jx, kv) : 0.f;
-      const float w = fld(F_Y + WW, m);
-      fld(F_TA, m) = A;
-      fld(F_TG, m) = off + qq[0] + qq[1] * fld(F_Y + RFP, m) + qq[2] * fmaf(a530, w, fld(F_Y + YFP, m)) +
-                     qq[3] * fmaf(a480, w, fld(F_Y + CFP, m));
+      tag[0] = A;
+      tag[1] = off + qq[0] + qq[1] * y4[RFP] + qq[2] * fmaf(a530, y4[WW], z2[0]) + qq[3] * fmaf(a480, y4[WW], z2[1]);
+      tag[2] = 0.f; tag[3] = 0.f;
+      stv<4>(VA(m), tag);
+      lane_step(lm, m, tag[0], tag[1], gK);
     }
-    const float gK = qK[0] + qK[1] * yend[RFP] + qK[2] * fmaf(a530, yend[WW], yend[YFP]) + qK[3] * fmaf(a480, yend[WW], yend[CFP]);
-    float lam = lane_entry(lane_map([&](int m) { return fld(F_TA, m); }, [&](int m) { return fld(F_TG, m); }, gK));
+    float lam = lane_entry(lm);
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
-      float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], kbar[NS];
+      float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], kbar[NS], tag[4];
       x_stage(m, it, sg, us, ax, gbo, Jx);
+      ldv<4>(VA(m), tag);
       const float lin = lam + (last ? gK : 0.f);
       R::reverse(it.h, ax, it.valid ? lin : 0.f, Jx, kbar);
-      if (it.valid) lam = fmaf(fld(F_TA, m), lin, fld(F_TG, m));
+      if (it.valid) lam = fmaf(tag[0], lin, tag[1]);
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
         const float xs = Kc * us[s];
         const float gtot = fmaf(kbar[s], xs, gbo[s]);  // adjoint of gamma_s from every species
@@ -637,17 +796,36 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
     lamx = lam;
   }
   VIHDS_SCAN_STOP(9)
-  // ---- epilogue: sums over the time axis, raw accumulators -> gradients of the theta rows --------------------------------
+  // ---- epilogue: sums over the time axis through LDS (lane a of a trajectory adds up accumulator a), raw accumulators
+  //      -> gradients of the theta rows ------------------------------------------------------------------------------------
   {
     auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
-    auto raw = [&](int slot) { return a.theta[(size_t)a.slot_row[slot] * n + i]; };
-    VIHDS_UNROLL for (int j = 0; j < NSP; ++j) { sv[j] = sum32(sv[j], lane); degb[j] = sum32(degb[j], lane); }
-    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-      svt[q] = sum32(svt[q], lane); svr[q] = sum32(svr[q], lane); c1b[q] = sum32(c1b[q], lane); c2b[q] = sum32(c2b[q], lane);
+    float acc[DR_SCAN_NACC];
+    VIHDS_UNROLL for (int j = 0; j < NSP; ++j) { acc[j] = sv[j]; acc[6 + j] = degb[j]; }
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) { acc[12 + q] = svt[q]; acc[14 + q] = svr[q]; acc[16 + q] = c1b[q]; acc[18 + q] = c2b[q]; }
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) acc[20 + j] = precb[j];
+    acc[24] = rb; acc[25] = tlb; acc[26] = gbx; acc[27] = a530b; acc[28] = a480b; acc[29] = 0.f; acc[30] = 0.f; acc[31] = 0.f;
+    __syncthreads();  // every wavefront's per-step records are dead: the reduction buffer overlays them
+    float* red = lds;                       // [NACC][NT]
+    float* tot = lds + DR_SCAN_NACC * NT;   // [TPB][NACC]
+    VIHDS_UNROLL for (int q = 0; q < 29; ++q) red[q * NT + tid] = acc[q];
+    wave_sync();
+    {
+      float s4[4] = {0.f, 0.f, 0.f, 0.f};
+      const float* row = red + l * NT + tib * 32;  // accumulator l of this trajectory, its 32 lanes' partial sums
+      VIHDS_UNROLL for (int q = 0; q < 8; ++q) {
+        float v[4];
+        ldv<4>(row + 4 * q, v);
+        VIHDS_UNROLL for (int e = 0; e < 4; ++e) s4[e] += v[e];
+      }
+      tot[tib * DR_SCAN_NACC + l] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
     }
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) precb[j] = sum32(precb[j], lane);
-    rb = sum32(rb, lane); tlb = sum32(tlb, lane); gbx = sum32(gbx, lane);
-    a530b = sum32(a530b, lane); a480b = sum32(a480b, lane);
+    wave_sync();
+    VIHDS_UNROLL for (int q = 0; q < DR_SCAN_NACC / 4; ++q) ldv<4>(tot + tib * DR_SCAN_NACC + 4 * q, acc + 4 * q);
+    VIHDS_UNROLL for (int j = 0; j < NSP; ++j) { sv[j] = acc[j]; degb[j] = acc[6 + j]; }
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) { svt[q] = acc[12 + q]; svr[q] = acc[14 + q]; c1b[q] = acc[16 + q]; c2b[q] = acc[18 + q]; }
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) precb[j] = acc[20 + j];
+    rb = acc[24]; tlb = acc[25]; gbx = acc[26]; a530b = acc[27]; a480b = acc[28];
     // c P = c e + c (1 - e) t:  c_bar = sv e + svt (1 - e),  e_bar = c sum kbar (1 - t) = c svr
     float cbar[2], ebar[2];
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
@@ -662,15 +840,15 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
       put(M::SI + 1, lam0[RFP]); put(M::SI + 2, lam0[YFP]); put(M::SI + 3, lam0[CFP]);
       put(M::SI + 4, lam0[LUXR]); put(M::SI + 5, lam0[LASR]);
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) put(M::NSLOT + j, precb[j]);
-      put(M::S_r, rb * clamp_pass(raw(M::S_r), 0.f, 4.f));
-      put(M::S_K, gbx * invK * invK * clamp_pass(raw(M::S_K), 0.f, 4.f));
+      put(M::S_r, rb * pass_r);
+      put(M::S_K, gbx * invK * invK * pass_K);
       put(M::S_tlag, -4.f * tlb);
       put(M::S_rc, rcb);
-      put(M::S_drfp, degb[RFP] * clamp_pass(raw(M::S_drfp), 1e-12f, 2.f));
-      put(M::S_dyfp, degb[YFP] * clamp_pass(raw(M::S_dyfp), 1e-12f, 2.f));
-      put(M::S_dcfp, degb[CFP] * clamp_pass(raw(M::S_dcfp), 1e-12f, 2.f));
-      put(M::S_dR, degb[LUXR] * clamp_pass(raw(M::S_dR), 1e-12f, 5.f));
-      put(M::S_dS, degb[LASR] * clamp_pass(raw(M::S_dS), 1e-12f, 5.f));
+      put(M::S_drfp, degb[RFP] * pass_d[0]);
+      put(M::S_dyfp, degb[YFP] * pass_d[1]);
+      put(M::S_dcfp, degb[CFP] * pass_d[2]);
+      put(M::S_dR, degb[LUXR] * pass_d[3]);
+      put(M::S_dS, degb[LASR] * pass_d[4]);
       put(M::S_e81, ebar[0]); put(M::S_KGR81, c1b[0] * fR); put(M::S_KGS81, c2b[0] * fS);
       put(M::S_e76, ebar[1]); put(M::S_KGR76, c1b[1] * fR); put(M::S_KGS76, c2b[1] * fS);
       put(M::S_aYFP, cbar[0] * rc); put(M::S_aCFP, cbar[1] * rc);
@@ -698,7 +876,15 @@ inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st) {
 #define VIHDS_SCASE2(SV, IT)                                                                                \
   case IT: {                                                                                                \
     const size_t lds = dr_scan_lds_floats<SV>(IT) * sizeof(float);                                          \
-    hipLaunchKernelGGL((dr_scan_train_kernel<VERSION, SV, IT>), grid, block, lds, st, a);                   \
+    auto kern = dr_scan_train_kernel<VERSION, SV, IT>;                                                      \
+    static bool opted = false;                                                                              \
+    if (lds > 64 * 1024 && !opted) {                                                                        \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                              160 * 1024) != hipSuccess)                                                   \
+        return VIHDS_E_HIP;                                                                                 \
+      opted = true;                                                                                         \
+    }                                                                                                       \
+    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                      \
     return VIHDS_OK;                                                                                        \
   }
 #define VIHDS_SCASE(SV)                                   \
