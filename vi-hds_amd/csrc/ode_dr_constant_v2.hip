@@ -1,6 +1,7 @@
 // dr_constant (version 2): thread-per-trajectory kernels for large batches, lane-split kernels (8 lanes per
 // trajectory, vihds_dr_lanes.hpp) below VIHDS_LANE_SPLIT_MAX_N trajectories.
 #include <cstdlib>
+#include <string>
 
 #include "vihds_ode_kernels.hpp"
 #include "vihds_dr_lanes.hpp"
@@ -21,7 +22,17 @@ int launch_dr_constant_v2(bool backward, int solver, const OdeArgs& a, hipStream
 }
 // fused log-likelihood + unit-weight adjoint (lane-split regime only)
 int launch_dr_constant_train_v2(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts) {
-  if ((a.kernel_variant & 0xff) == 3 && !ts) return launch_dr_scan_train<2>(solver, a, st);  // time-parallel form
+  // time-parallel form (vihds_dr_scan.hpp): the default wherever it applies (any batch size, time grids up to 129
+  // points); kernel_variant 2 / VIHDS_TRAIN_KERNEL=lanes keep the lane-split training kernel
+  const int kv = a.kernel_variant & 0xff;
+  static const bool scan_default = [] {
+    const char* e = std::getenv("VIHDS_TRAIN_KERNEL");
+    return !(e && std::string(e) == "lanes");
+  }();
+  if (kv == 3 || (kv == 0 && scan_default)) {
+    const int rc = launch_dr_scan_train<2>(solver, a, st, ts);
+    if (rc != VIHDS_E_UNSUPPORTED || kv == 3) return rc;
+  }
   const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v2());
   if (!lanes) return VIHDS_E_UNSUPPORTED;
   return launch_dr_lane_train<2>(solver, a, st, ts);

@@ -242,8 +242,13 @@ __device__ __forceinline__ void stv(float* p, const float* o) {
   else p[0] = o[0];
 }
 
-template <int VERSION, int SOLVER, int ITEMS>
-__device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds) {
+// LDS floats the sampling stage's tables need (they overlay the VA area, which is dead until the yfp / cfp maps)
+__host__ __device__ inline size_t dr_scan_theta_floats(int nb_max, int P, int E, int D, int B) {
+  return (size_t)10 * nb_max * P + (size_t)2 * E * D + (size_t)B * D;
+}
+
+template <int VERSION, int SOLVER, int ITEMS, bool THETA>
+__device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds, int nb_max, const ThetaStageArgs& t) {
   using M = DrConstant<VERSION>;
   using D = DrLanes<VERSION>;
   using R = Rk<SOLVER>;
@@ -294,14 +299,138 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
   }
   float obK[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) obK[j] = ob[j * a.T + K];
-  VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-    const int slot = l + 32 * q;
-    if (slot < M::NSLOT + 4) {
-      const int row = a.slot_row[slot];
-      par[row] = a.theta[(size_t)row * n + i];
+  RngTickets tk = {0u, 0u};
+  if (!THETA) {
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int slot = l + 32 * q;
+      if (slot < M::NSLOT + 4) {
+        const int row = a.slot_row[slot];
+        par[row] = a.theta[(size_t)row * n + i];
+      }
     }
+    __syncthreads();
+  } else {
+    // ---- sampling stage of the decoder step (vihds_theta_ode_logp_grad): theta = clip(sample(q, u)) with log q / log p
+    //      (the arithmetic of theta_fwd_lds_kernel / dr_lane_theta_stage; here lane l of a trajectory owns parameters l
+    //      and l + 32), then the device-conditioner rows.  theta / u / log_q / log_p go to global memory (the API's
+    //      outputs) and theta to `par` for this kernel's own use.
+    constexpr float LOG2PI = 1.8378770664093453f;
+    const int P = t.P, B = a.B, S = a.S;
+    const int first = blockIdx.x * DR_SCAN_TPB, last = min(first + DR_SCAN_TPB, (int)n) - 1;
+    const int b0 = first / S, nb = last / S - b0 + 1;
+    const int stride = nb_max * P;
+    float* scratch = lds + O_A;
+    float* t_kind = scratch;
+    float* t_mu = scratch + stride;
+    float* t_sigma = scratch + 2 * stride;
+    float* t_prec = scratch + 3 * stride;
+    float* t_cq = scratch + 4 * stride;
+    float* t_lo = scratch + 5 * stride;
+    float* t_hi = scratch + 6 * stride;
+    float* t_pmu = scratch + 7 * stride;
+    float* t_cp = scratch + 8 * stride;
+    float* t_pprec = scratch + 9 * stride;
+    float* t_cw = scratch + 10 * stride;      // [E*D] conditioner weights of this call
+    float* t_rel = t_cw + t.E * a.D;          // [E*D] relevance masks
+    float* t_dev = t_rel + t.E * a.D;         // [B*D] device one-hot rows (the conditioner's tiling reads any row)
+    for (int e = tid; e < nb * P; e += NT) {
+      const int bb = e / P, fp = e - bb * P;
+      const int rm = t.q_rows ? t.q_rows[fp] : fp, rp = t.q_rows ? t.q_rows[P + fp] : fp;
+      const int kd = t.kind[fp];
+      const float pr = t.q_prec[rp * B + b0 + bb], pp_ = t.p_prec[fp];
+      const float prc = (kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(pr) : pr);
+      t_kind[e] = (float)kd;
+      t_mu[e] = t.q_mu[rm * B + b0 + bb];
+      t_sigma[e] = 1.f / sqrtf(prc);
+      t_prec[e] = prc;
+      t_cq[e] = -LOG2PI + 0.5f * logf(prc + 1e-12f);
+      t_lo[e] = t.clip_lo[fp];
+      t_hi[e] = t.clip_hi[fp];
+      t_pmu[e] = t.p_mu[fp];
+      t_cp[e] = -LOG2PI + 0.5f * logf(pp_ + 1e-12f);
+      t_pprec[e] = pp_;
+    }
+    if (t.E > 0) {
+      const int ed = t.E * a.D;
+      for (int e = tid; e < ed; e += NT) {
+        float zz;
+        if (t.crng) zz = philox_normal((unsigned int)e, 0xC04Du, t.crng[2], 0u, t.crng[0], t.crng[1], 0);
+        else zz = t.z[e];
+        t_cw[e] = t.w_mean + t.w_std * zz;
+        t_rel[e] = t.rel[e];
+      }
+      for (int e = tid; e < B * a.D; e += NT) t_dev[e] = a.dev1hot[e];
+    }
+    unsigned int rk0 = 0, rk1 = 0, step = 0, gidx = 0;
+    if (t.rng) {
+      rk0 = t.rng[0]; rk1 = t.rng[1]; step = t.rng[2];
+      gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * S));
+    }
+    float zd[2] = {0.f, 0.f};  // this lane's draws, ahead of the table barrier
+    if (t.rng) {
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+        const int pq = l + 32 * q;
+        if (pq < P) {
+          float z4[4];
+          philox_normal4(gidx, (unsigned int)(pq >> 2), step, 0u, rk0, rk1, z4);
+          const int e = pq & 3;
+          zd[q] = e == 0 ? z4[0] : (e == 1 ? z4[1] : (e == 2 ? z4[2] : z4[3]));
+        }
+      }
+    }
+    __syncthreads();
+    // every thread holds the generators' step counters: the block takes its tickets here, the holder of the last ticket
+    // advances the step at the very end of the kernel (rng_advance; see dr_lane_theta_stage)
+    if (t.rng && tid == 0) tk.u = atomicAdd(&t.rng[3], 1u);
+    if (t.crng && tid == 64) tk.c = atomicAdd(&t.crng[3], 1u);
+    float lq = 0.f, lp = 0.f;
+    const int row = (b - b0) * P;
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int pq = l + 32 * q;
+      if (pq < P) {
+        float uu;
+        if (t.rng) {
+          uu = zd[q];
+          if (live) t.u[(size_t)i * P + pq] = uu;
+        } else {
+          uu = t.u[(size_t)i * P + pq];
+        }
+        const int e = row + pq;
+        const float kdf = t_kind[e], mu = t_mu[e];
+        const bool cst = kdf == (float)KIND_CONSTANT, ln = kdf == (float)KIND_LOGNORMAL;
+        const float zz = mu + t_sigma[e] * uu;
+        float x = ln ? expf(zz) : zz;
+        const float lo = t_lo[e], hi = t_hi[e];
+        x = x < lo ? lo : (x > hi ? hi : x);
+        const float v = ln ? logf(x + 1e-12f) : x;
+        const float jac = ln ? v : 0.f;
+        const float dq = mu - v, dp = t_pmu[e] - v;
+        const float tq = t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
+        const float tp = t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
+        lq += cst ? 0.f : tq;
+        lp += cst ? 0.f : tp;
+        x = cst ? 0.f * uu + mu : x;
+        if (live) t.theta[(size_t)pq * n + i] = x;
+        par[pq] = x;
+      }
+    }
+    lq = sum32(lq, lane);
+    lp = sum32(lp, lane);
+    if (live && l == 0) {
+      if (t.log_q) t.log_q[i] = lq;
+      if (t.log_p) t.log_p[i] = lp;
+    }
+    if (l < t.E) {  // device conditioner (ode.py:43-58, with its .repeat tiling): lane e produces row cond_row0 + e
+      const int rr = (int)(((long long)b * t.S_total + t.s_off + (i - b * S)) % B);
+      float cc = 0.f;
+      for (int d = 0; d < a.D; ++d) cc += t_cw[l * a.D + d] * (t_dev[rr * a.D + d] * t_rel[l * a.D + d]);
+      cc = fmaxf(cc, 0.f);
+      const float val = (t.is_default[l] ? 1.f : 0.f) + cc;
+      if (live) t.theta[(size_t)(t.cond_row0 + l) * n + i] = val;
+      par[t.cond_row0 + l] = val;
+    }
+    __syncthreads();  // par complete; the tables are dead
   }
-  __syncthreads();
   const float r = clampf(th(M::S_r), 0.f, 4.f), tlag = th(M::S_tlag);
   const float h0 = tT[1] - tT[0];
   // step m of this lane: grid index (clamped for the padding steps beyond K), validity, step size
@@ -858,33 +987,55 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds)
       if (VERSION == 1) { put(M::S_H2, HA.H2); put(M::S_H3, HA.H3); }
     }
   }
+  if (THETA) {
+    rng_advance(t.rng, tk.u, 0);
+    rng_advance(t.crng, tk.c, 64);
+  }
 }
 
 template <int VERSION, int SOLVER, int ITEMS>
 __global__ void __launch_bounds__(DR_SCAN_THREADS) dr_scan_train_kernel(OdeArgs a) {
   extern __shared__ float lds[];
-  dr_scan_train_body<VERSION, SOLVER, ITEMS>(a, lds);
+  ThetaStageArgs none = {};
+  dr_scan_train_body<VERSION, SOLVER, ITEMS, false>(a, lds, 0, none);
+}
+// sampling stage + conditioner + everything above: the whole decoder side of a training step
+template <int VERSION, int SOLVER, int ITEMS>
+__global__ void __launch_bounds__(DR_SCAN_THREADS) dr_scan_train_theta_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
+  extern __shared__ float lds[];
+  dr_scan_train_body<VERSION, SOLVER, ITEMS, true>(a, lds, nb_max, t);
 }
 
-// returns VIHDS_E_UNSUPPORTED when the time grid is longer than 32 lanes x 4 steps
+// returns VIHDS_E_UNSUPPORTED when the time grid is longer than 32 lanes x 4 steps (or the sampling stage's tables do
+// not fit)
 template <int VERSION>
-inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st) {
+inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
   const int K = a.T - 1;
   const int items = (K + 31) / 32;
   if (items > 4) return VIHDS_E_UNSUPPORTED;
+  const int nb_max = min(a.B, (DR_SCAN_TPB - 1) / a.S + 2);
+  if (ts) {
+    if (ts->P > 64 || ts->n_rows > 64 || ts->E > 32) return VIHDS_E_UNSUPPORTED;
+    if (dr_scan_theta_floats(nb_max, ts->P, ts->E, a.D, a.B) > (size_t)4 * items * DR_SCAN_THREADS) return VIHDS_E_UNSUPPORTED;
+  }
+  for (int q = 0; q < DrConstant<VERSION>::NSLOT + 4; ++q)
+    if (a.slot_row[q] >= 64) return VIHDS_E_UNSUPPORTED;
   const dim3 grid((a.n + DR_SCAN_TPB - 1) / DR_SCAN_TPB), block(DR_SCAN_THREADS);
 #define VIHDS_SCASE2(SV, IT)                                                                                \
   case IT: {                                                                                                \
     const size_t lds = dr_scan_lds_floats<SV>(IT) * sizeof(float);                                          \
     auto kern = dr_scan_train_kernel<VERSION, SV, IT>;                                                      \
-    static bool opted = false;                                                                              \
-    if (lds > 64 * 1024 && !opted) {                                                                        \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, \
-                              160 * 1024) != hipSuccess)                                                   \
+    auto kern_t = dr_scan_train_theta_kernel<VERSION, SV, IT>;                                              \
+    static bool opted = false, opted_t = false;                                                             \
+    bool& have = ts ? opted_t : opted;                                                                      \
+    if (lds > 64 * 1024 && !have) {                                                                         \
+      const void* f = ts ? reinterpret_cast<const void*>(kern_t) : reinterpret_cast<const void*>(kern);     \
+      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)     \
         return VIHDS_E_HIP;                                                                                 \
-      opted = true;                                                                                         \
+      have = true;                                                                                          \
     }                                                                                                       \
-    hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                      \
+    if (ts) hipLaunchKernelGGL(kern_t, grid, block, lds, st, a, nb_max, *ts);                               \
+    else hipLaunchKernelGGL(kern, grid, block, lds, st, a);                                                 \
     return VIHDS_OK;                                                                                        \
   }
 #define VIHDS_SCASE(SV)                                   \

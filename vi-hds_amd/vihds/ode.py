@@ -177,9 +177,11 @@ class OdeModel(nn.Module):
         if key not in self._spec_cache:
             if default_get_value(config.params, "adjoint_solver", False):
                 raise NotImplementedError("adjoint_solver: the HIP path always uses the discrete adjoint")
+            kw = dict(self.problem_kwargs(config))
+            # params.kernel_variant: 0 = the library's choice, 1 thread-per-trajectory, 2 lane-split, 3 time-parallel
+            kw.setdefault("kernel_variant", int(default_get_value(config.params, "kernel_variant", 0)))
             self._spec_cache[key] = ops.OdeProblemSpec(self.model_key, config.params.solver, row_of, n_rows,
-                                                       C=self.n_treatments, D=self.device_depth,
-                                                       **self.problem_kwargs(config))
+                                                       C=self.n_treatments, D=self.device_depth, **kw)
         return self._spec_cache[key]
 
     def solve(self, config, times, theta, conditions, dev_1hot, observations=None):
