@@ -241,10 +241,27 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
     assert rel_err(H.view_bsnt(xpred), xp) < TOL
     assert rel_err(H.view_bs4(logp), lpo, dim=2) < TOL
     assert rel_err(loss, loss_c) < TOL
-    live = [i for i, k in enumerate(fx.kinds)]
     got = th.grad[: len(fx.names)].cpu()
     ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
-    assert rel_err(got[live], ref[live], dim=0) < GTOL
+    # Per parameter.  Where a gradient is a small difference of large terms (KGS_76 of dr_constant_v2: 2.5e-8 next to
+    # neighbours of 1e+2) float32 itself does not resolve it to GTOL -- the float32 oracle is then as far from its own
+    # float64 run as the kernel is.  So the yardstick is the oracle in float64, and a parameter's tolerance is GTOL or eight
+    # times the float32 oracle's own error there, whichever is larger: the kernel has to be as good as the reference's
+    # arithmetic, not better than float32 allows.
+    th64 = {k: (v.double().clone().requires_grad_(True) if v.dtype.is_floating_point else v) for k, v in fx.theta_dict().items()}
+    xs64, xp64, prec64 = O.decode(fx.model, th64, fx.t("inputs").double(), fx.t("times").double(), solver)
+    l64, _ = O.iwae_loss(O.log_prob_observations(xp64, fx.t("observations").double(), prec64), fx.t("log_p").double(),
+                         fx.t("log_q").double())
+    l64.backward()
+    for r, n in enumerate(fx.names):
+        g64 = th64[n].grad if th64[n].grad is not None else torch.zeros(fx.B, fx.S, dtype=torch.float64)
+        scale = float(g64.abs().max())
+        if scale == 0.0:
+            assert float(got[r].abs().max()) == 0.0, n
+            continue
+        e32 = float((ref[r].double() - g64).abs().max()) / scale
+        e_hip = float((got[r].double() - g64).abs().max()) / scale
+        assert e_hip < max(GTOL, 8.0 * e32), (n, e_hip, e32)
 
 
 @pytest.mark.parametrize("variant", [0, 1])  # 0 = auto (MFMA formulation), 1 = VALU, one thread per trajectory
@@ -1161,3 +1178,49 @@ def test_hip_solvers_meet_reference_cv_criterion(name, variant):
     # and every fixed-grid scheme individually within 5 % of the reference's final state, per species
     for k, solver in enumerate(("modeuler", "modeulerwhile", "midpoint", "rk4")):
         assert rel_err(sol[k + 1], sol[0], dim=2) < 0.05, solver
+
+
+@pytest.mark.parametrize("model", ["dr_constant", "dr_constant_v2"])
+@pytest.mark.parametrize("solver", ["rk4", "midpoint", "modeuler", "modeulerwhile", "euler"])
+def test_time_parallel_training_kernel_matches_forward_plus_adjoint(model, solver):
+    """kernel_variant 3 (csrc/vihds_dr_scan.hpp: x chain, per-step affine maps, prefix scans over the time axis, adjoint
+    as reverse scans) through vihds_ode_logp_grad against the forward + adjoint pair of the lane kernels (themselves
+    pinned by the reference fixtures): per-signal log-likelihoods and every parameter's unit-weight gradient, at the
+    headline shape, ragged shapes (partial blocks, several data rows per block), a non-uniform time grid, the shortest
+    grid (T = 2) and the longest the kernel takes (T = 129); beyond that it declines."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    slots = hip.model_slots(model)
+    row_of = {n: i for i, n in enumerate(slots)}
+    st = torch.cuda.current_stream().cuda_stream
+    for (B, S, T) in ((36, 200, 86), (7, 5, 31), (3, 9, 100), (5, 4, 2), (4, 8, 129)):
+        th = _synthetic_theta(slots, B, S, 13)
+        theta = torch.stack([th[n] for n in slots]).to(DEV)
+        g = torch.Generator().manual_seed(6)
+        cond = torch.log1p(torch.rand(B, 2, generator=g) * 1000.0).to(DEV)
+        times = (torch.arange(T, dtype=torch.float32) * 0.1933 + 0.003 * torch.rand(T, generator=g)).to(DEV)
+        obs = torch.rand(B, 4, T, generator=g).to(DEV)
+        prob = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=2).bind(B, S, T)
+        prob.logp_grad_broadcast = 1
+        prob3 = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=3).bind(B, S, T)
+        traj = torch.empty(T, 8, B, S, device=DEV); xpred = torch.empty(T, 4, B, S, device=DEV)
+        logp = torch.empty(4, B, S, device=DEV); ones = torch.ones(B, S, device=DEV)
+        g_ref = torch.empty_like(theta)
+        args = (theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(), obs.data_ptr())
+        assert L.vihds_ode_fwd(ctypes.byref(prob), *args, None, traj.data_ptr(), xpred.data_ptr(), logp.data_ptr(), st) == 0
+        assert L.vihds_ode_bwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, None, ones.data_ptr(),
+                               g_ref.data_ptr(), None, None, st) == 0
+        logp3 = torch.full_like(logp, float("nan")); g3 = torch.full_like(theta, float("nan"))
+        rc = L.vihds_ode_logp_grad(ctypes.byref(prob3), *args, logp3.data_ptr(), g3.data_ptr(), st)
+        assert rc == 0, L.vihds_last_error()
+        torch.cuda.synchronize()
+        assert rel_err(logp3, logp, dim=0) < 1e-5, (B, S, T)
+        assert rel_err(g3, g_ref, dim=0) < 2e-4, (B, S, T)
+    T = 130
+    prob3 = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=3).bind(4, 8, T)
+    times = (torch.arange(T, dtype=torch.float32) * 0.1).to(DEV); obs = torch.rand(4, 4, T).to(DEV)
+    lp = torch.empty(4, 4, 8, device=DEV)
+    assert L.vihds_ode_logp_grad(ctypes.byref(prob3), theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(),
+                                 obs.data_ptr(), lp.data_ptr(), g3.data_ptr(), st) == hip.E_UNSUPPORTED
