@@ -96,13 +96,13 @@ def ode_kernel_times(model, settings, batch, n_iwae, n_launch):
     return out
 
 
-def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
-    """The oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd, Adam) timed on this
-    box's host cores on the same workload.  Checker code used as a *reported baseline* only."""
+def make_oracle_step(solver, observations=None):
+    """One full training step of the oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd,
+    Adam) on the bench workload, as a closure returning its wall time.  Shared by `cpu_baseline` below and by
+    oracle/time_vs_reference.py (which times the imported reference beside it in the build container)."""
     from oracle import vihds_oracle as O
     from vihds import synthetic
 
-    all_threads = torch.get_num_threads()
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, N_IWAE, solver=solver, device="cpu", seed=0, observations=observations)
     enc = model.encoder
@@ -113,6 +113,7 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
     _, pm, pp = enc.p.image("cpu", 1)
     p_mu, p_prec = [pm[i, 0] for i in range(len(names))], [pp[i, 0] for i in range(len(names))]
     rel = {k: torch.tensor(v) for k, v in settings.data.relevance_vectors.items()}
+
     def one_step():
         t0 = time.perf_counter()
         u = torch.tensor(np.random.randn(B_ROWS, N_IWAE, len(names)).astype(np.float32))
@@ -132,10 +133,19 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
         opt.zero_grad()
         return time.perf_counter() - t0
 
-    # the tensors are tiny (7 200 elements), so more threads is not faster: probe 8 threads vs all host cores
-    # and time the baseline with whichever is quicker on this box
+    return one_step
+
+
+def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
+    """The oracle timed on this box's host cores on the same workload.  Checker code used as a *reported baseline*
+    only.  Rows for 1 thread, 8 threads and all host threads; `value` is the best of them.  `fidelity` echoes
+    oracle/cpu_fidelity.json: the same oracle step timed against the imported reference in the build container."""
+    all_threads = torch.get_num_threads()
+    one_step = make_oracle_step(solver, observations)
+    # the tensors are tiny (7 200 elements), so more threads is not faster: probe 1 / 8 / all host threads and time
+    # the baseline with whichever is quickest on this box
     probe = {}
-    for n in sorted({min(8, all_threads), all_threads}):
+    for n in sorted({1, min(8, all_threads), all_threads}):
         torch.set_num_threads(n)
         one_step()
         probe[n] = one_step()
@@ -148,13 +158,18 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
     steps = len(times_s)
     torch.set_num_threads(all_threads)
     med = float(np.median(times_s))
-    return {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
-            "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
-                      "CPU restatement of the reference path (oracle/); %d threads chosen from a probe of %s "
-                      "(s/step); box has %d host threads"
-                      % (steps, B_ROWS, N_IWAE, N_TIMES, solver, threads,
-                         {k: round(v, 2) for k, v in probe.items()}, all_threads),
-            "ms_per_step": 1e3 * med}
+    out = {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
+           "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
+                     "CPU restatement of the reference path (oracle/); %d threads chosen from a probe of %s "
+                     "(s/step); box has %d host threads"
+                     % (steps, B_ROWS, N_IWAE, N_TIMES, solver, threads,
+                        {k: round(v, 2) for k, v in probe.items()}, all_threads),
+           "ms_per_step": 1e3 * med,
+           "rows_steps_per_s": {("%d thread%s" % (k, "" if k == 1 else "s")): round(1.0 / v, 3) for k, v in probe.items()}}
+    fid = os.path.join(ROOT, "oracle", "cpu_fidelity.json")
+    if os.path.exists(fid):
+        out["fidelity"] = json.load(open(fid))
+    return out
 
 
 def main():
@@ -276,19 +291,30 @@ def main():
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
     kname["ode_fused"] = "void vihds::dr_lane_train_kernel<1, %d>(vihds::OdeArgs, int)" % solver_id
-    kname["ode_step"] = ("void vihds::dr_lane_train_theta_kernel<1, %d>(vihds::OdeArgs, int, vihds::ThetaStageArgs)"
-                         % solver_id)
+    # the library's choice for the decoder launch (csrc/ode_dr_constant_v1.hip): the time-parallel kernel whenever the
+    # grid has at most 32 x 4 steps, else the lane-split one
+    scan_items = (N_TIMES - 1 + 31) // 32
+    if scan_items <= 4 and os.environ.get("VIHDS_TRAIN_KERNEL") != "lanes":
+        kname["ode_fused"] = "void vihds::dr_scan_train_kernel<1, %d, %d>(vihds::OdeArgs)" % (solver_id, scan_items)
+        kname["ode_step"] = ("void vihds::dr_scan_train_theta_kernel<1, %d, %d>(vihds::OdeArgs, int, "
+                             "vihds::ThetaStageArgs)" % (solver_id, scan_items))
+    else:
+        kname["ode_step"] = ("void vihds::dr_lane_train_theta_kernel<1, %d>(vihds::OdeArgs, int, "
+                             "vihds::ThetaStageArgs)" % solver_id)
     theta_b = 4 * (2 * N_PARAMS * B_ROWS * N_IWAE + 2 * B_ROWS * N_IWAE)  # the sampling stage's u, theta, log q, log p
     nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b, "ode_step": fwd_b + bwd_b + theta_b}
 
     def gbs(nb, us):
         return nb / (us * 1e-6) / 1e9
 
-    pmc_kernels = {}
-    pmc_name = "r01_z_pmc_hbm_traffic.json"
-    pmc_file = os.path.join(ROOT, "profiles", pmc_name)
-    if os.path.exists(pmc_file) and a.solver == "rk4":
-        pmc_kernels = json.load(open(pmc_file))["kernels"]
+    # HBM traffic per launch from the PMC passes committed under profiles/ (newest set that has this kernel)
+    import glob
+    pmc_kernels, pmc_name = {}, None
+    for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
+        ks = json.load(open(pmc_file))["kernels"]
+        if kname["ode_step" if "ode_step" in kt else "ode_fused"] in ks:
+            pmc_kernels, pmc_name = ks, os.path.basename(pmc_file)
+            break
 
     def entry(k):
         pmc = pmc_kernels.get(kname[k])
