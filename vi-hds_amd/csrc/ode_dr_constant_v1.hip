@@ -42,3 +42,8 @@ int n_states_dr_constant_v1() { return DrConstant<1>::N; }
 int n_cond_dr_constant_v1() { return DrConstant<1>::NC; }
 const char* slot_name_dr_constant_v1(int s) { return DrConstant<1>::slot_name(s); }
 }  // namespace vihds
+#ifdef VIHDS_SCAN_STAMPS
+extern "C" int vihds_debug_scan_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vihds::vihds_scan_stamp_buf), &buf, sizeof(buf));
+}
+#endif

@@ -128,6 +128,15 @@ struct DrLanes {
   };
   __device__ static HillAdj hill_vjp(const OdeArgs& a, int i, int j, const float* c, const HillTerm& H, float fRb,
                                      float fSb) {
+    const float pass[6] = {clamp_pass(th(a, M::S_nR, i), 0.5f, 3.f), clamp_pass(th(a, M::S_nS, i), 0.5f, 3.f),
+                           clamp_pass(th(a, M::S_H0, i), 1e-12f, 1.f), clamp_pass(th(a, M::S_H1, i), 1e-12f, 1.f),
+                           VERSION == 1 ? clamp_pass(th(a, M::S_H0 + 2, i), 1e-12f, 1.f) : 0.f,
+                           VERSION == 1 ? clamp_pass(th(a, M::S_H0 + 3, i), 1e-12f, 1.f) : 0.f};
+    return hill_vjp_pass(j, c, H, fRb, fSb, pass);
+  }
+  // pass[] = where torch.clamp lets the gradient through (1 / 0) for nR, nS, H0..H3
+  __device__ static HillAdj hill_vjp_pass(int j, const float* c, const HillTerm& H, float fRb, float fSb,
+                                          const float* pass) {
     float g;
     if (VERSION == 1) {
       const float p0 = bcast8<0>(H.pw), p1 = bcast8<1>(H.pw), p2 = bcast8<2>(H.pw);
@@ -141,21 +150,20 @@ struct DrLanes {
     float ab = 0.f, nb = 0.f;
     pow_vjp(H.base, H.n, H.pw, g, ab, nb);
     HillAdj o;
-    const float nr_raw = th(a, M::S_nR, i), ns_raw = th(a, M::S_nS, i);
     if (VERSION == 1) {
-      o.nR = sum8(j < 3 ? nb : 0.f) * clamp_pass(nr_raw, 0.5f, 3.f);
-      o.nS = sum8((j >= 3 && j < 6) ? nb : 0.f) * clamp_pass(ns_raw, 0.5f, 3.f);
+      o.nR = sum8(j < 3 ? nb : 0.f) * pass[0];
+      o.nS = sum8((j >= 3 && j < 6) ? nb : 0.f) * pass[1];
       const float a0 = bcast8<0>(ab), a1 = bcast8<1>(ab), a2 = bcast8<2>(ab);
       const float a3 = bcast8<3>(ab), a4 = bcast8<4>(ab), a5 = bcast8<5>(ab);
-      o.H0 = (a0 + a2) * c[0] * clamp_pass(th(a, M::S_H0, i), 1e-12f, 1.f);
-      o.H1 = (a1 + a2) * c[1] * clamp_pass(th(a, M::S_H1, i), 1e-12f, 1.f);
-      o.H2 = (a3 + a5) * c[0] * clamp_pass(th(a, M::S_H2, i), 1e-12f, 1.f);
-      o.H3 = (a4 + a5) * c[1] * clamp_pass(th(a, M::S_H3, i), 1e-12f, 1.f);
+      o.H0 = (a0 + a2) * c[0] * pass[2];
+      o.H1 = (a1 + a2) * c[1] * pass[3];
+      o.H2 = (a3 + a5) * c[0] * pass[4];
+      o.H3 = (a4 + a5) * c[1] * pass[5];
     } else {
-      o.nR = sum8(j < 2 ? nb : 0.f) * clamp_pass(nr_raw, 0.5f, 3.f);
-      o.nS = sum8((j >= 2 && j < 4) ? nb : 0.f) * clamp_pass(ns_raw, 0.5f, 3.f);
-      o.H0 = bcast8<2>(ab) * c[0] * clamp_pass(th(a, M::S_H0, i), 1e-12f, 1.f);  // eS6
-      o.H1 = bcast8<1>(ab) * c[1] * clamp_pass(th(a, M::S_H1, i), 1e-12f, 1.f);  // eR12
+      o.nR = sum8(j < 2 ? nb : 0.f) * pass[0];
+      o.nS = sum8((j >= 2 && j < 4) ? nb : 0.f) * pass[1];
+      o.H0 = bcast8<2>(ab) * c[0] * pass[2];  // eS6
+      o.H1 = bcast8<1>(ab) * c[1] * pass[3];  // eR12
       o.H2 = 0.f; o.H3 = 0.f;
     }
     return o;

@@ -113,30 +113,6 @@ struct Rk {
     }
     return lam;
   }
-  // x in units of K (u = x / K): du = gr u (1 - u).  The table entry of a stage is the coefficient its derivative gets
-  // where it is used next: T[s] = chain_coef(s) h gr_s with chain_coef(s) = a(s+1, s) (last stage: b(NS-1)).  Then
-  //   p_s = u_s - u_s^2,  u_{s+1} = base_{s+1} + T[s] p_s,  q_s = T[s] p_s  (= chain_coef(s) h k_s),
-  // and the dependent chain is two instructions per stage; the bases only need the q of EARLIER stages, with compile-time
-  // coefficient ratios.  Stage values us[s], returns u'.
-  static constexpr float chain_coef(int s) { return s + 1 < NS ? a(s + 1 < NS ? s + 1 : s, s) : b(NS - 1); }
-  __device__ __forceinline__ static float xstep(const float* T, float u, float* us) {
-    float p[NS], q[NS];
-    float v = u;
-    VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-      us[s] = v;
-      p[s] = fmaf(-v, v, v);
-      q[s] = T[s] * p[s];
-      // base of the next stage value (of the step's result after the last stage): u + sum over r < s of the tableau
-      // weight of stage r there, expressed through q_r
-      float base = u;
-      VIHDS_UNROLL for (int r = 0; r < s; ++r) {
-        const float wgt = (s + 1 < NS ? a(s + 1 < NS ? s + 1 : s, r) : b(r)) / chain_coef(r);
-        if (wgt != 0.f) base = fmaf(wgt, q[r], base);
-      }
-      v = fmaf(T[s], p[s], base);
-    }
-    return v;
-  }
   // NS consecutive floats from / to LDS as one access
   __device__ __forceinline__ static void load(const float* p, float* o) {
     if (NS == 4) { const float4 v = *reinterpret_cast<const float4*>(p); o[0] = v.x; o[1] = v.y; o[NS > 2 ? 2 : 0] = v.z; o[NS > 3 ? 3 : 0] = v.w; }
@@ -147,6 +123,108 @@ struct Rk {
     if (NS == 4) *reinterpret_cast<float4*>(p) = make_float4(o[0], o[1], o[NS > 2 ? 2 : 0], o[NS > 3 ? 3 : 0]);
     else if (NS == 2) *reinterpret_cast<float2*>(p) = make_float2(o[0], o[NS > 1 ? 1 : 0]);
     else p[0] = o[0];
+  }
+};
+
+// ---- the x chain: x in units of K (u = x / K), du = gr u (1 - u) ------------------------------------------------------
+// With p_r = u_r - u_r^2 at the stages, every later stage value (and the step's result) is
+//     u_{s'} = u + sum_{r < s'} w(s', r) h gr_r p_r,       w(s', r) = a(s', r),  w(NS, r) = b(r),
+// so with the products |w| h gr_r TABULATED per step (state independent: r sigmoid(4 (t - tlag)) only) a step is one FMA
+// per nonzero tableau weight plus one per p_r, all of them off the dependent chain except two per stage
+// (p_s, then the last FMA of u_{s+1}).  Weights of equal magnitude on the same stage share a table entry (the sign
+// goes into the FMA): rk4 (3/8 rule) 8 entries for 10 weights, modeuler 3, midpoint 2, euler 1.
+template <int I0, int I1, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I0 < I1) {
+    f(std::integral_constant<int, I0>{});
+    static_for<I0 + 1, I1>(f);
+  }
+}
+template <int SOLVER>
+struct RkChain {
+  using R = Rk<SOLVER>;
+  static constexpr int NS = R::NS;
+  static constexpr float wgt(int s1, int r) { return s1 < NS ? R::a(s1, r) : R::b(r); }
+  static constexpr float cabs(float x) { return x < 0.f ? -x : x; }
+  // (s1, r) is the first weight of its magnitude on stage r, in the order s1 = 1..NS
+  static constexpr bool first(int s1, int r) {
+    for (int s2 = r + 1; s2 < s1; ++s2)
+      if (wgt(s2, r) != 0.f && cabs(wgt(s2, r)) == cabs(wgt(s1, r))) return false;
+    return true;
+  }
+  static constexpr int index(int s1, int r) {  // table entry of weight (s1, r); -1: the weight is zero
+    if (wgt(s1, r) == 0.f) return -1;
+    int idx = 0;
+    for (int s = 1; s <= NS; ++s)
+      for (int q = 0; q < s; ++q) {
+        if (wgt(s, q) == 0.f || !first(s, q)) continue;
+        if (q == r && cabs(wgt(s, q)) == cabs(wgt(s1, r))) return idx;
+        ++idx;
+      }
+    return -1;
+  }
+  static constexpr int count() {
+    int n = 0;
+    for (int s = 1; s <= NS; ++s)
+      for (int q = 0; q < s; ++q)
+        if (wgt(s, q) != 0.f && first(s, q)) ++n;
+    return n;
+  }
+  static constexpr int first_use(int r) {  // the first stage value (or the result) stage r's derivative enters
+    for (int s1 = r + 1; s1 <= NS; ++s1)
+      if (wgt(s1, r) != 0.f) return s1;
+    return -1;
+  }
+};
+template <int SOLVER>
+struct RkChainTab : RkChain<SOLVER> {
+  using C = RkChain<SOLVER>;
+  static constexpr int NS = C::NS;
+  static constexpr int NCOEF = C::count();
+  static constexpr int NCW = NCOEF <= 1 ? 1 : (NCOEF <= 2 ? 2 : (NCOEF <= 4 ? 4 : 8));  // entries per step, padded
+  static constexpr int LO = NCW < NS ? NCW : NS;  // entries kept in the first table (NS floats per step), rest in the second
+  static constexpr int HI = NCW - LO;
+  // table entries of one step from hgr[r] = h gr_r
+  __device__ __forceinline__ static void fill(const float* hgr, float* E) {
+    VIHDS_UNROLL for (int e = 0; e < NCW; ++e) E[e] = 0.f;
+    static_for<1, NS + 1>([&](auto S1) {
+      static_for<0, decltype(S1)::value>([&](auto Q) {
+        constexpr int s1 = decltype(S1)::value, q = decltype(Q)::value;
+        if constexpr (C::wgt(s1, q) != 0.f && C::first(s1, q)) {
+          constexpr int e = C::index(s1, q);
+          constexpr float w = C::cabs(C::wgt(s1, q));
+          E[e] = w * hgr[q];
+        }
+      });
+    });
+  }
+  // h gr_r back from the table
+  template <int r>
+  __device__ __forceinline__ static float hgr(const float* E) {
+    constexpr int s1 = C::first_use(r);
+    constexpr int e = C::index(s1, r);
+    constexpr float inv = 1.f / C::cabs(C::wgt(s1, r));
+    return E[e] * inv;
+  }
+  // one step: stage values us[s], returns u'
+  __device__ __forceinline__ static float step(const float* E, float u, float* us) {
+    float acc[NS + 1];
+    VIHDS_UNROLL for (int s = 0; s <= NS; ++s) acc[s] = u;
+    static_for<0, NS>([&](auto S) {
+      constexpr int sidx = decltype(S)::value;
+      const float v = acc[sidx];
+      us[sidx] = v;
+      const float p = fmaf(-v, v, v);
+      static_for<sidx + 1, NS + 1>([&](auto S1) {
+        constexpr int s1 = decltype(S1)::value;
+        if constexpr (C::wgt(s1, sidx) != 0.f) {
+          constexpr int e = C::index(s1, sidx);
+          constexpr bool pos = C::wgt(s1, sidx) > 0.f;
+          acc[s1] = pos ? fmaf(E[e], p, acc[s1]) : fmaf(-E[e], p, acc[s1]);
+        }
+      });
+    });
+    return acc[NS];
   }
 };
 
@@ -211,8 +289,21 @@ __device__ __forceinline__ void wave_sync() {
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-constexpr int DR_SCAN_TPB = 8;         // trajectories per block: 4 wavefronts x 2, 32 lanes each
-constexpr int DR_SCAN_THREADS = 256;
+#ifndef VIHDS_SCAN_TPB
+#define VIHDS_SCAN_TPB 8
+#endif
+constexpr int DR_SCAN_TPB = VIHDS_SCAN_TPB;  // trajectories per block: 2 per wavefront, 32 lanes each
+constexpr int DR_SCAN_THREADS = 32 * DR_SCAN_TPB;
+constexpr int DR_SCAN_CHAIN_LANES = 64 / DR_SCAN_TPB;  // lanes of wavefront 0 that walk one trajectory's x chain
+// Block barrier for data exchanged through LDS: waits for this wavefront's LDS operations only.  (__syncthreads() also
+// waits for every outstanding global store and returning atomic -- a full memory round trip on the critical path of the
+// block at each of its barriers; nothing in this kernel passes data between wavefronts through global memory.)
+__device__ __forceinline__ void block_sync_lds() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 constexpr int DR_SCAN_NACC = 32;       // accumulators summed over the time axis in the epilogue (29 used)
 
 // LDS per block (floats).  Per lane and step, as vectors: VG[NS] (sigmoid, then gamma), VU[NS] (x / K at the stages),
@@ -227,7 +318,15 @@ __host__ __device__ inline size_t dr_scan_lds_floats(int items) {
 }
 #define VIHDS_ROLLED _Pragma("clang loop unroll(disable)")
 // profiling aid: kernel_variant = 3 | (phase << 8) makes the kernel return after that phase (tests/probe/scan_phases.py)
+#ifdef VIHDS_SCAN_STAMPS
+// profiling build (tests/probe/scan_stamps.py): every wavefront writes the 100 MHz wall clock at each phase boundary
+static __device__ unsigned long long* vihds_scan_stamp_buf = nullptr;  // [blocks][waves per block][16]
+#define VIHDS_SCAN_STOP(PH)                                                                                         \
+  if (vihds_scan_stamp_buf && lane == 0)                                                                            \
+    vihds_scan_stamp_buf[((size_t)blockIdx.x * (DR_SCAN_THREADS / 64) + wave) * 16 + (PH)] = wall_clock64();
+#else
 #define VIHDS_SCAN_STOP(PH) if ((a.kernel_variant >> 8) == (PH)) return;
+#endif
 
 template <int W>
 __device__ __forceinline__ void ldv(const float* p, float* o) {
@@ -242,9 +341,10 @@ __device__ __forceinline__ void stv(float* p, const float* o) {
   else p[0] = o[0];
 }
 
-// LDS floats the sampling stage's tables need (they overlay the VA area, which is dead until the yfp / cfp maps)
-__host__ __device__ inline size_t dr_scan_theta_floats(int nb_max, int P, int E, int D, int B) {
-  return (size_t)10 * nb_max * P + (size_t)2 * E * D + (size_t)B * D;
+// LDS floats the conditioner's staged inputs need (relevance masks, the block's device one-hot rows, default flags:
+// they sit in the VG area, which holds at least items * DR_SCAN_THREADS floats and is dead until the gamma pass)
+__host__ __device__ inline size_t dr_scan_theta_floats(int E, int D) {
+  return (size_t)E * D + (size_t)DR_SCAN_TPB * D + (size_t)E;
 }
 
 template <int VERSION, int SOLVER, int ITEMS, bool THETA>
@@ -267,7 +367,9 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
                 O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC,
                 O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4;
   auto VG = [&](int m) { return lds + O_G + (m * NT + tid) * NS; };
-  auto VU = [&](int m) { return lds + O_U + (m * NT + tid) * NS; };
+  // (the stage values of x are written by the chain wavefront, for all trajectories of the block at once: a trajectory's
+  // 32 lane slots are rotated by its index, so that those eight stores fall into different LDS banks)
+  auto VU = [&](int m) { return lds + O_U + (m * NT + tib * 32 + ((l + tib) & 31)) * NS; };
   auto VB = [&](int m) { return lds + O_B + (m * NT + tid) * NS; };
   auto VQ = [&](int m) { return lds + O_Q + (m * NT + tid) * 4; };
   auto VY = [&](int m) { return lds + O_Y + (m * NT + tid) * 4; };
@@ -284,6 +386,14 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   float* par = par_of(tib);
   auto th = [&](int slot) { return par[a.slot_row[slot]]; };
 
+#ifdef VIHDS_SCAN_STAMPS
+  VIHDS_SCAN_STOP(0)
+  if (vihds_scan_stamp_buf && lane == 0) {
+    unsigned long long* sb = vihds_scan_stamp_buf + ((size_t)blockIdx.x * (DR_SCAN_THREADS / 64) + wave) * 16;
+    sb[14] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
+    sb[15] = __builtin_amdgcn_s_getreg((6 /*LDS_ALLOC*/) | (0 << 6) | (31 << 11));
+  }
+#endif
   // ---- 0. the time grid -> LDS; this lane's observations -> VQ (their latency hides behind the parameter stage) ------
   const int k0 = l * ITEMS;
   const float* ob = a.obs + (size_t)b * 4 * a.T;
@@ -299,6 +409,16 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   }
   float obK[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) obK[j] = ob[j * a.T + K];
+  // the treatments of this lane's trajectory and of the one two places down (wavefront 1 evaluates the Hill terms of
+  // wavefront 0's trajectories), and the conditioner generator's state: fetched here, used after the first barrier
+  float cond_raw[2][2];
+  VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+    const int bb = min(blockIdx.x * DR_SCAN_TPB + max(tib - 2 * q, 0), a.n - 1) / a.S;
+    cond_raw[q][0] = a.cond[bb * a.C + 0];
+    cond_raw[q][1] = a.cond[bb * a.C + 1];
+  }
+  unsigned int ck0 = 0u, ck1 = 0u, cstep = 0u;
+  if (THETA && t.crng) { ck0 = t.crng[0]; ck1 = t.crng[1]; cstep = t.crng[2]; }
   RngTickets tk = {0u, 0u};
   if (!THETA) {
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
@@ -308,108 +428,79 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         par[row] = a.theta[(size_t)row * n + i];
       }
     }
-    __syncthreads();
+    block_sync_lds();
   } else {
     // ---- sampling stage of the decoder step (vihds_theta_ode_logp_grad): theta = clip(sample(q, u)) with log q / log p
-    //      (the arithmetic of theta_fwd_lds_kernel / dr_lane_theta_stage; here lane l of a trajectory owns parameters l
-    //      and l + 32), then the device-conditioner rows.  theta / u / log_q / log_p go to global memory (the API's
-    //      outputs) and theta to `par` for this kernel's own use.
+    //      (the arithmetic of theta_fwd_lds_kernel; lane l of a trajectory owns parameters l and l + 32).  Every lane
+    //      fetches the distribution constants of its own (data row, parameter) pairs itself: no per-block table, no
+    //      barrier before the draws are used, and a wavefront never waits for another one in this stage.  theta / u /
+    //      log_q / log_p go to global memory (the API's outputs) and theta to `par` for this kernel's own use.  The
+    //      device-conditioner rows are produced later, by the last wavefront, while wavefront 0 walks the x chains.
     constexpr float LOG2PI = 1.8378770664093453f;
-    const int P = t.P, B = a.B, S = a.S;
-    const int first = blockIdx.x * DR_SCAN_TPB, last = min(first + DR_SCAN_TPB, (int)n) - 1;
-    const int b0 = first / S, nb = last / S - b0 + 1;
-    const int stride = nb_max * P;
-    float* scratch = lds + O_A;
-    float* t_kind = scratch;
-    float* t_mu = scratch + stride;
-    float* t_sigma = scratch + 2 * stride;
-    float* t_prec = scratch + 3 * stride;
-    float* t_cq = scratch + 4 * stride;
-    float* t_lo = scratch + 5 * stride;
-    float* t_hi = scratch + 6 * stride;
-    float* t_pmu = scratch + 7 * stride;
-    float* t_cp = scratch + 8 * stride;
-    float* t_pprec = scratch + 9 * stride;
-    float* t_cw = scratch + 10 * stride;      // [E*D] conditioner weights of this call
-    float* t_rel = t_cw + t.E * a.D;          // [E*D] relevance masks
-    float* t_dev = t_rel + t.E * a.D;         // [B*D] device one-hot rows (the conditioner's tiling reads any row)
-    for (int e = tid; e < nb * P; e += NT) {
-      const int bb = e / P, fp = e - bb * P;
-      const int rm = t.q_rows ? t.q_rows[fp] : fp, rp = t.q_rows ? t.q_rows[P + fp] : fp;
-      const int kd = t.kind[fp];
-      const float pr = t.q_prec[rp * B + b0 + bb], pp_ = t.p_prec[fp];
-      const float prc = (kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(pr) : pr);
-      t_kind[e] = (float)kd;
-      t_mu[e] = t.q_mu[rm * B + b0 + bb];
-      t_sigma[e] = 1.f / sqrtf(prc);
-      t_prec[e] = prc;
-      t_cq[e] = -LOG2PI + 0.5f * logf(prc + 1e-12f);
-      t_lo[e] = t.clip_lo[fp];
-      t_hi[e] = t.clip_hi[fp];
-      t_pmu[e] = t.p_mu[fp];
-      t_cp[e] = -LOG2PI + 0.5f * logf(pp_ + 1e-12f);
-      t_pprec[e] = pp_;
+    const int P = t.P, B = a.B;
+    float c_mu[2], c_pr[2], c_pp[2], c_lo[2], c_hi[2], c_pmu[2], uu[2] = {0.f, 0.f};
+    int c_kd[2];
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int pq = min(l + 32 * q, P - 1);
+      const int rm = t.q_rows ? t.q_rows[pq] : pq, rp = t.q_rows ? t.q_rows[P + pq] : pq;
+      c_kd[q] = t.kind[pq];
+      c_pp[q] = t.p_prec[pq];
+      c_lo[q] = t.clip_lo[pq];
+      c_hi[q] = t.clip_hi[pq];
+      c_pmu[q] = t.p_mu[pq];
+      c_mu[q] = t.q_mu[rm * B + b];
+      c_pr[q] = t.q_prec[rp * B + b];
+      if (!t.rng && l + 32 * q < P) uu[q] = t.u[(size_t)i * P + pq];
     }
+    if (t.rng) {
+      // one generator call per wavefront: lane l < ceil(P / 4) draws the four normals of parameter block l (counter =
+      // global sample index, block, step: vihds_rng.hpp), the trajectory's lanes pick theirs up from LDS
+      const unsigned int rk0 = t.rng[0], rk1 = t.rng[1], step = t.rng[2];
+      const unsigned int gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * a.S));
+      float* zb = lds + O_Z + tib * 64;  // (the VZ area: 64 floats per trajectory, unused until the log-likelihood)
+      float z4[4];
+      philox_normal4(gidx, (unsigned int)l, step, 0u, rk0, rk1, z4);
+      if (4 * l < P) stv<4>(zb + 4 * l, z4);
+      wave_sync();
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q)
+        if (l + 32 * q < P) uu[q] = zb[l + 32 * q];
+    }
+    // the conditioner's inputs for this block (relevance masks, default flags, the device one-hot rows its tiling
+    // selects: row (b S_total + s) mod B for sample (b, s)) -> LDS, for the wavefront that evaluates it later
+    float* t_rel = lds + O_G;                      // [E][D]   (the VG area is free until the gamma pass)
+    float* t_dev = t_rel + t.E * a.D;              // [TPB][D]
+    float* t_dfl = t_dev + DR_SCAN_TPB * a.D;      // [E]
     if (t.E > 0) {
-      const int ed = t.E * a.D;
-      for (int e = tid; e < ed; e += NT) {
-        float zz;
-        if (t.crng) zz = philox_normal((unsigned int)e, 0xC04Du, t.crng[2], 0u, t.crng[0], t.crng[1], 0);
-        else zz = t.z[e];
-        t_cw[e] = t.w_mean + t.w_std * zz;
-        t_rel[e] = t.rel[e];
+      for (int e = tid; e < t.E * a.D; e += NT) t_rel[e] = t.rel[e];
+      for (int e = tid; e < DR_SCAN_TPB * a.D; e += NT) {
+        const int tt = e / a.D, d = e - tt * a.D;
+        const int it = min(blockIdx.x * DR_SCAN_TPB + tt, a.n - 1), bt = it / a.S;
+        const int rr = (int)(((long long)bt * t.S_total + t.s_off + (it - bt * a.S)) % B);
+        t_dev[e] = a.dev1hot[rr * a.D + d];
       }
-      for (int e = tid; e < B * a.D; e += NT) t_dev[e] = a.dev1hot[e];
+      for (int e = tid; e < t.E; e += NT) t_dfl[e] = t.is_default[e] ? 1.f : 0.f;
     }
-    unsigned int rk0 = 0, rk1 = 0, step = 0, gidx = 0;
-    if (t.rng) {
-      rk0 = t.rng[0]; rk1 = t.rng[1]; step = t.rng[2];
-      gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * S));
-    }
-    float zd[2] = {0.f, 0.f};  // this lane's draws, ahead of the table barrier
-    if (t.rng) {
-      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-        const int pq = l + 32 * q;
-        if (pq < P) {
-          float z4[4];
-          philox_normal4(gidx, (unsigned int)(pq >> 2), step, 0u, rk0, rk1, z4);
-          const int e = pq & 3;
-          zd[q] = e == 0 ? z4[0] : (e == 1 ? z4[1] : (e == 2 ? z4[2] : z4[3]));
-        }
-      }
-    }
-    __syncthreads();
-    // every thread holds the generators' step counters: the block takes its tickets here, the holder of the last ticket
-    // advances the step at the very end of the kernel (rng_advance; see dr_lane_theta_stage)
-    if (t.rng && tid == 0) tk.u = atomicAdd(&t.rng[3], 1u);
-    if (t.crng && tid == 64) tk.c = atomicAdd(&t.crng[3], 1u);
     float lq = 0.f, lp = 0.f;
-    const int row = (b - b0) * P;
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const int pq = l + 32 * q;
       if (pq < P) {
-        float uu;
-        if (t.rng) {
-          uu = zd[q];
-          if (live) t.u[(size_t)i * P + pq] = uu;
-        } else {
-          uu = t.u[(size_t)i * P + pq];
-        }
-        const int e = row + pq;
-        const float kdf = t_kind[e], mu = t_mu[e];
-        const bool cst = kdf == (float)KIND_CONSTANT, ln = kdf == (float)KIND_LOGNORMAL;
-        const float zz = mu + t_sigma[e] * uu;
+        const bool cst = c_kd[q] == KIND_CONSTANT, ln = c_kd[q] == KIND_LOGNORMAL;
+        const float prc = cst ? 1.f : (t.prec_is_log ? expf(c_pr[q]) : c_pr[q]);
+        const float sigma = 1.f / sqrtf(prc);
+        const float cq = -LOG2PI + 0.5f * logf(prc + 1e-12f), cp = -LOG2PI + 0.5f * logf(c_pp[q] + 1e-12f);
+        const float mu = c_mu[q];
+        if (t.rng && live) t.u[(size_t)i * P + pq] = uu[q];
+        const float zz = mu + sigma * uu[q];
         float x = ln ? expf(zz) : zz;
-        const float lo = t_lo[e], hi = t_hi[e];
-        x = x < lo ? lo : (x > hi ? hi : x);
+        x = x < c_lo[q] ? c_lo[q] : (x > c_hi[q] ? c_hi[q] : x);
         const float v = ln ? logf(x + 1e-12f) : x;
         const float jac = ln ? v : 0.f;
-        const float dq = mu - v, dp = t_pmu[e] - v;
-        const float tq = t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
-        const float tp = t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
+        const float dq = mu - v, dp = c_pmu[q] - v;
+        const float tq = cq - 0.5f * prc * dq * dq - jac;
+        const float tp = cp - 0.5f * c_pp[q] * dp * dp - jac;
         lq += cst ? 0.f : tq;
         lp += cst ? 0.f : tp;
-        x = cst ? 0.f * uu + mu : x;
+        x = cst ? 0.f * uu[q] + mu : x;
         if (live) t.theta[(size_t)pq * n + i] = x;
         par[pq] = x;
       }
@@ -420,16 +511,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       if (t.log_q) t.log_q[i] = lq;
       if (t.log_p) t.log_p[i] = lp;
     }
-    if (l < t.E) {  // device conditioner (ode.py:43-58, with its .repeat tiling): lane e produces row cond_row0 + e
-      const int rr = (int)(((long long)b * t.S_total + t.s_off + (i - b * S)) % B);
-      float cc = 0.f;
-      for (int d = 0; d < a.D; ++d) cc += t_cw[l * a.D + d] * (t_dev[rr * a.D + d] * t_rel[l * a.D + d]);
-      cc = fmaxf(cc, 0.f);
-      const float val = (t.is_default[l] ? 1.f : 0.f) + cc;
-      if (live) t.theta[(size_t)(t.cond_row0 + l) * n + i] = val;
-      par[t.cond_row0 + l] = val;
-    }
-    __syncthreads();  // par complete; the tables are dead
+    wave_sync();  // this trajectory's theta rows are in `par` (its own lanes wrote them)
   }
   const float r = clampf(th(M::S_r), 0.f, 4.f), tlag = th(M::S_tlag);
   const float h0 = tT[1] - tT[0];
@@ -449,16 +531,24 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     return it;
   };
   auto stage_sigmoid = [&](const Item& it, int s) { return sigmoid_f(4.f * (fmaf(R::c(s), it.dt, it.t0) - tlag)); };
-  // ---- 1. C[k][s] = chain_coef(s) h_k r sigmoid(4 (t_{k,s} - tlag)) for this lane's steps: what the x chain consumes
-  //         (state independent).  The table of the block's 8 trajectories sits where the gamma adjoints (VB) will go later. ------
-  float* tC = lds + O_B + tib * (32 * ITEMS * NS);  // [32 ITEMS][NS] of this trajectory
+  // ---- 1. the x chain's coefficient table for this lane's steps (RkChainTab: |w| h_k r sigmoid(4 (t_{k,s} - tlag)), state
+  //         independent).  The tables of the block's 8 trajectories sit where the gamma adjoints (VB) and the yfp / cfp
+  //         maps (VA) will go later. --------------------------------------------------------------------------------------
+  using CT = RkChainTab<SOLVER>;
+  // (step-major: the chain wavefront reads one step of all trajectories at a time -- consecutive addresses)
+  constexpr int HIW = CT::HI > 0 ? CT::HI : 1;
+  float* tC = lds + O_B + tib * CT::LO;   // [32 ITEMS][TPB][LO]: row k of this trajectory at tC + k * TPB * LO
+  float* tC2 = lds + O_A + tib * HIW;     // [32 ITEMS][TPB][HI]
+  constexpr int TS = DR_SCAN_TPB * CT::LO, TS2 = DR_SCAN_TPB * HIW;
   VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
     const Item it = item(m);
-    float C[NS];
-    VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = (R::chain_coef(s) * it.h * r) * stage_sigmoid(it, s);
-    stv<NS>(tC + (k0 + m) * NS, C);
+    float hgr[NS], E[CT::NCW];
+    VIHDS_UNROLL for (int s = 0; s < NS; ++s) hgr[s] = (it.h * r) * stage_sigmoid(it, s);
+    CT::fill(hgr, E);
+    stv<CT::LO>(tC + (k0 + m) * TS, E);
+    if (CT::HI > 0) stv<HIW>(tC2 + (k0 + m) * TS2, E + CT::LO);
   }
-  __syncthreads();
+  block_sync_lds();  // every trajectory's parameters and coefficient table are in place
   VIHDS_SCAN_STOP(1)
 
   // ---- 2. the x chains of the block's 8 trajectories, in wavefront 0, 8 lanes per trajectory (u = x / K, two dependent
@@ -468,45 +558,79 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   auto gamma_pass = [&]() {
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
-      float g[NS], us[NS];
-      ldv<NS>(tC + it.kc * NS, g);
+      float E[CT::NCW], g[NS], us[NS];
+      ldv<CT::LO>(tC + it.kc * TS, E);
+      if (CT::HI > 0) ldv<HIW>(tC2 + it.kc * TS2, E + CT::LO);
       ldv<NS>(VU(m), us);
       const float invh = frcp(it.h);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float gr = g[s] * (invh * (1.f / R::chain_coef(s))); g[s] = fmaf(-gr, us[s], gr); }
+      static_for<0, NS>([&](auto S) {
+        constexpr int sidx = decltype(S)::value;
+        const float gr = CT::template hgr<sidx>(E) * invh;
+        g[sidx] = fmaf(-gr, us[sidx], gr);
+      });
       stv<NS>(VG(m), g);
     }
   };
   // (Wavefront 0 meets the others at the two barriers below from its own branch: a workgroup barrier counts arrivals,
   // it does not care which instruction a wavefront arrives from.)
   if (wave == 0) {
-    const int t = lane >> 3;
+    const int t = lane / DR_SCAN_CHAIN_LANES;
     const float* part = par_of(t);
     float u = part[a.slot_row[M::SI + 0]] * frcp(clampf(part[a.slot_row[M::S_K]], 0.f, 4.f));
-    const float* Ct = lds + O_B + t * (32 * ITEMS * NS);
-    float Cn[NS];
-    ldv<NS>(Ct, Cn);
-    for (int k = 0; k < K; ++k) {
-      float C[NS], us[NS];
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) C[s] = Cn[s];
-      ldv<NS>(Ct + min(k + 1, K - 1) * NS, Cn);
-      u = R::xstep(C, u, us);
-      // (the 8 lanes of a group hold the same values and store them to the same address: no divergence in the loop)
-      const int L = k / ITEMS, m = k - L * ITEMS;
-      stv<NS>(lds + O_U + (m * NT + t * 32 + L) * NS, us);
+    const float* Ct = lds + O_B + t * CT::LO;
+    const float* Ct2 = lds + O_A + t * HIW;
+    auto row = [&](int k, float* E) {
+      ldv<CT::LO>(Ct + k * TS, E);
+      if (CT::HI > 0) ldv<HIW>(Ct2 + k * TS2, E + CT::LO);
+    };
+    // One group = the ITEMS steps that belong to one lane slot L of the trajectory (their stage values go to that slot:
+    // one address computation per group).  Two groups per trip, the table rows of the next one in flight; a lone
+    // wavefront issues an instruction every 5-9 cycles whatever it is, so the loop is kept to the tableau's FMAs, the
+    // table loads and the stores.  (The lanes of a chain hold the same values and store them to the same address.)
+    auto rows = [&](int L, float (*E)[CT::NCW]) {
+      VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) row(min(L * ITEMS + m, K - 1), E[m]);
+    };
+    auto group = [&](int L, float (*E)[CT::NCW], int n_valid) {
+      float* dst = lds + O_U + (t * 32 + ((L + t) & 31)) * NS;
+      VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m)
+        if (m < n_valid) {
+          float us[NS];
+          u = CT::step(E[m], u, us);
+          stv<NS>(dst + m * NT * NS, us);
+        }
+    };
+    const int NL = K / ITEMS;  // complete groups
+    float Ea[ITEMS][CT::NCW], Eb[ITEMS][CT::NCW];
+    rows(0, Ea);
+    int L = 0;
+    for (; L + 2 <= NL; L += 2) {
+      rows(L + 1, Eb);
+      group(L, Ea, ITEMS);
+      rows(L + 2, Ea);
+      group(L + 1, Eb, ITEMS);
+    }
+    for (; L * ITEMS < K; ++L) {  // at most one complete group and a partial one
+      group(L, Ea, min(ITEMS, K - L * ITEMS));
+      rows(L + 1, Ea);
     }
     uK[t] = u;
-    __syncthreads();  // the chains' stage values are in place
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(11)
+#endif
+    block_sync_lds();  // the chains' stage values are in place
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(12)
+#endif
     gamma_pass();
-    __syncthreads();  // the table is dead from here on: VB may be written
+    block_sync_lds();  // the table is dead from here on: VB may be written
   }
 
   // ---- Hill fractions (dr_constant.py:58-73) of the block's trajectories, while the chains run: wavefronts 1-3 for their
   //      own two trajectories, wavefront 1 also for wavefront 0's.  Lanes 0..7 of a half-wave hold the power terms
   //      (v1: (K6 c6)^n, (K12 c12)^n, (1 + K6 c6 + K12 c12)^n for LuxR and LasR; v2: four terms), as in DrLanes::hill.
-  auto treatments = [&](int traj, float* c) {
-    const int bb = min(blockIdx.x * DR_SCAN_TPB + traj, a.n - 1) / a.S;
-    c[0] = clampf(expf(a.cond[bb * a.C + 0]) - 1.f, 1e-12f, 1e6f);
-    c[1] = clampf(expf(a.cond[bb * a.C + 1]) - 1.f, 1e-12f, 1e6f);
+  auto treatments = [&](int q, float* c) {  // q = 0: this lane's trajectory; 1: the one two places down
+    c[0] = clampf(expf(cond_raw[q][0]) - 1.f, 1e-12f, 1e6f);
+    c[1] = clampf(expf(cond_raw[q][1]) - 1.f, 1e-12f, 1e6f);
   };
   if (wave != 0) {
     VIHDS_ROLLED for (int pass = 0; pass < (wave == 1 ? 2 : 1); ++pass) {
@@ -514,7 +638,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       float* pp = par_of(tp);
       auto tht = [&](int slot) { return pp[a.slot_row[slot]]; };
       float cc[2];
-      treatments(tp, cc);
+      if (pass == 0) treatments(0, cc); else treatments(1, cc);
       const int j = l & 7;
       const float nR = clampf(tht(M::S_nR), 0.5f, 3.f), nS = clampf(tht(M::S_nS), 0.5f, 3.f);
       float base, ex, fR_, fS_;
@@ -549,15 +673,54 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         pp[65] = fS_;
       }
     }
-    __syncthreads();  // the chains' stage values are in place
+    if (THETA && t.E > 0 && wave == DR_SCAN_THREADS / 64 - 1) {
+      // device conditioner (ode.py:43-58, with its .repeat tiling) for the block's trajectories, off the critical path:
+      // the rows it produces (aR, aS) are first read after the chains.  One generator call for the E x D weights.
+      float* t_cw = lds + O_Z;  // [E][D] (the VZ area again: the draws it held were consumed before the last barrier)
+      const float* t_rel = lds + O_G;
+      const float* t_dev = t_rel + t.E * a.D;
+      const float* t_dfl = t_dev + DR_SCAN_TPB * a.D;
+      const int ed = t.E * a.D;
+      for (int e = lane; e < ed; e += 64) {
+        float zz;
+        if (t.crng) zz = philox_normal((unsigned int)e, 0xC04Du, cstep, 0u, ck0, ck1, 0);
+        else zz = t.z[e];
+        t_cw[e] = t.w_mean + t.w_std * zz;
+      }
+      wave_sync();
+      for (int w = lane; w < DR_SCAN_TPB * t.E; w += 64) {
+        const int tt = w / t.E, e = w - tt * t.E;
+        const int it0 = blockIdx.x * DR_SCAN_TPB + tt;
+        const bool lv = it0 < a.n;
+        const int it = lv ? it0 : a.n - 1;
+        float cc = 0.f;
+        for (int d = 0; d < a.D; ++d) cc += t_cw[e * a.D + d] * (t_dev[tt * a.D + d] * t_rel[e * a.D + d]);
+        cc = fmaxf(cc, 0.f);
+        const float val = t_dfl[e] + cc;
+        if (lv) t.theta[(size_t)(t.cond_row0 + e) * n + it] = val;
+        par_of(tt)[t.cond_row0 + e] = val;
+      }
+    }
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(11)
+#endif
+    block_sync_lds();  // the chains' stage values are in place
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(12)
+#endif
     gamma_pass();
-    __syncthreads();
+    block_sync_lds();
   }
+  // Every thread of the block has read the generators' step counters long ago: the block takes its tickets here, behind
+  // its last barrier before the epilogue (a barrier would wait for the atomics' round trips), and the holder of the last
+  // ticket advances the step at the very end of the kernel (rng_advance; see dr_lane_theta_stage).
+  if (THETA && t.rng && tid == 0) tk.u = atomicAdd(&t.rng[3], 1u);
+  if (THETA && t.crng && tid == DR_SCAN_THREADS - 64) tk.c = atomicAdd(&t.crng[3], 1u);
   VIHDS_SCAN_STOP(2)
 
   // ---- parameters of this trajectory (every lane of its 32 holds them) -----------------------------------------
   float c[2];
-  treatments(tib, c);
+  treatments(0, c);
   const float Kc = clampf(th(M::S_K), 0.f, 4.f), invK = frcp(Kc);
   const float rc = th(M::S_rc);
   typename D::HillTerm H;
@@ -567,6 +730,10 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   const float fR = par[64], fS = par[65];
   // where torch.clamp passes the gradient (bounds included), for the epilogue
   const float pass_r = clamp_pass(th(M::S_r), 0.f, 4.f), pass_K = clamp_pass(th(M::S_K), 0.f, 4.f);
+  const float pass_h[6] = {clamp_pass(th(M::S_nR), 0.5f, 3.f), clamp_pass(th(M::S_nS), 0.5f, 3.f),
+                           clamp_pass(th(M::S_H0), 1e-12f, 1.f), clamp_pass(th(M::S_H1), 1e-12f, 1.f),
+                           VERSION == 1 ? clamp_pass(th(M::S_H0 + 2), 1e-12f, 1.f) : 0.f,
+                           VERSION == 1 ? clamp_pass(th(M::S_H0 + 3), 1e-12f, 1.f) : 0.f};
   const float pass_d[5] = {clamp_pass(th(M::S_drfp), 1e-12f, 2.f), clamp_pass(th(M::S_dyfp), 1e-12f, 2.f),
                            clamp_pass(th(M::S_dcfp), 1e-12f, 2.f), clamp_pass(th(M::S_dR), 1e-12f, 5.f),
                            clamp_pass(th(M::S_dS), 1e-12f, 5.f)};
@@ -934,7 +1101,10 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) { acc[12 + q] = svt[q]; acc[14 + q] = svr[q]; acc[16 + q] = c1b[q]; acc[18 + q] = c2b[q]; }
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) acc[20 + j] = precb[j];
     acc[24] = rb; acc[25] = tlb; acc[26] = gbx; acc[27] = a530b; acc[28] = a480b; acc[29] = 0.f; acc[30] = 0.f; acc[31] = 0.f;
-    __syncthreads();  // every wavefront's per-step records are dead: the reduction buffer overlays them
+    block_sync_lds();  // every wavefront's per-step records are dead: the reduction buffer overlays them
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(13)
+#endif
     float* red = lds;                       // [NACC][NT]
     float* tot = lds + DR_SCAN_NACC * NT;   // [TPB][NACC]
     VIHDS_UNROLL for (int q = 0; q < 29; ++q) red[q * NT + tid] = acc[q];
@@ -963,7 +1133,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     const float fRb = c1b[0] * pKR[0] + c1b[1] * pKR[1], fSb = c2b[0] * pKS[0] + c2b[1] * pKS[1];
     const float rcb = sv[RFP] + sv[WW] + sv[LUXR] * aR + sv[LASR] * aS + cbar[0] * aY + cbar[1] * aC;
-    const typename D::HillAdj HA = D::hill_vjp(a, i, l & 7, c, H, fRb, fSb);
+    const typename D::HillAdj HA = D::hill_vjp_pass(l & 7, c, H, fRb, fSb, pass_h);
     if (live && l == 0) {  // (the initial-state adjoints sit in lane 0 of the trajectory)
       put(M::SI + 0, lamx);
       put(M::SI + 1, lam0[RFP]); put(M::SI + 2, lam0[YFP]); put(M::SI + 3, lam0[CFP]);
@@ -989,8 +1159,11 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   }
   if (THETA) {
     rng_advance(t.rng, tk.u, 0);
-    rng_advance(t.crng, tk.c, 64);
+    rng_advance(t.crng, tk.c, DR_SCAN_THREADS - 64);
   }
+#ifdef VIHDS_SCAN_STAMPS
+  VIHDS_SCAN_STOP(10)
+#endif
 }
 
 template <int VERSION, int SOLVER, int ITEMS>
@@ -1016,7 +1189,7 @@ inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st, co
   const int nb_max = min(a.B, (DR_SCAN_TPB - 1) / a.S + 2);
   if (ts) {
     if (ts->P > 64 || ts->n_rows > 64 || ts->E > 32) return VIHDS_E_UNSUPPORTED;
-    if (dr_scan_theta_floats(nb_max, ts->P, ts->E, a.D, a.B) > (size_t)4 * items * DR_SCAN_THREADS) return VIHDS_E_UNSUPPORTED;
+    if (dr_scan_theta_floats(ts->E, a.D) > (size_t)items * DR_SCAN_THREADS) return VIHDS_E_UNSUPPORTED;
   }
   for (int q = 0; q < DrConstant<VERSION>::NSLOT + 4; ++q)
     if (a.slot_row[q] >= 64) return VIHDS_E_UNSUPPORTED;
