@@ -96,7 +96,7 @@ def ode_kernel_times(model, settings, batch, n_iwae, n_launch):
     return out
 
 
-def make_oracle_step(solver, observations=None):
+def make_oracle_step(solver, observations=None, n_iwae=N_IWAE):
     """One full training step of the oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd,
     Adam) on the bench workload, as a closure returning its wall time.  Shared by `cpu_baseline` below and by
     oracle/time_vs_reference.py (which times the imported reference beside it in the build container)."""
@@ -104,7 +104,8 @@ def make_oracle_step(solver, observations=None):
     from vihds import synthetic
 
     args, settings, data, parameters, model, training = synthetic.build(
-        "dr_constant_icml", B_ROWS, N_IWAE, solver=solver, device="cpu", seed=0, observations=observations)
+        "dr_constant_icml", B_ROWS, n_iwae, solver=solver, device="cpu", seed=0, observations=observations)
+    N_IWAE_ = n_iwae
     enc = model.encoder
     opt = torch.optim.Adam(enc.parameters(), lr=0.01)
     batch = training.train_data
@@ -116,13 +117,13 @@ def make_oracle_step(solver, observations=None):
 
     def one_step():
         t0 = time.perf_counter()
-        u = torch.tensor(np.random.randn(B_ROWS, N_IWAE, len(names)).astype(np.float32))
+        u = torch.tensor(np.random.randn(B_ROWS, N_IWAE_, len(names)).astype(np.float32))
         q = enc(batch)
         _, q_mu, q_prec = q.image("cpu", B_ROWS)
         qm = [q_mu[i][:, None] for i in range(len(names))]
         qp = [q_prec[i][:, None] for i in range(len(names))]
         th = O.sample_clip_theta(names, kinds, qm, qp, p_mu, p_prec, u)
-        ones = torch.ones(B_ROWS, N_IWAE)
+        ones = torch.ones(B_ROWS, N_IWAE_)
         for k in ("aR", "aS"):
             w = 2.0 + 1.5 * torch.randn(1, batch.dev_1hot.shape[1])
             th[k] = O.device_conditioner(w, ones, rel[k], batch.dev_1hot, True)
@@ -136,12 +137,12 @@ def make_oracle_step(solver, observations=None):
     return one_step
 
 
-def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
+def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=N_IWAE):
     """The oracle timed on this box's host cores on the same workload.  Checker code used as a *reported baseline*
     only.  Rows for 1 thread, 8 threads and all host threads; `value` is the best of them.  `fidelity` echoes
     oracle/cpu_fidelity.json: the same oracle step timed against the imported reference in the build container."""
     all_threads = torch.get_num_threads()
-    one_step = make_oracle_step(solver, observations)
+    one_step = make_oracle_step(solver, observations, n_iwae)
     # the tensors are tiny (7 200 elements), so more threads is not faster: probe 1 / 8 / all host threads and time
     # the baseline with whichever is quickest on this box
     probe = {}
@@ -162,7 +163,7 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
            "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
                      "CPU restatement of the reference path (oracle/); %d threads chosen from a probe of %s "
                      "(s/step); box has %d host threads"
-                     % (steps, B_ROWS, N_IWAE, N_TIMES, solver, threads,
+                     % (steps, B_ROWS, n_iwae, N_TIMES, solver, threads,
                         {k: round(v, 2) for k, v in probe.items()}, all_threads),
            "ms_per_step": 1e3 * med,
            "rows_steps_per_s": {("%d thread%s" % (k, "" if k == 1 else "s")): round(1.0 / v, 3) for k, v in probe.items()}}
@@ -172,12 +173,213 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8):
     return out
 
 
+# ---- the other BASELINE configurations: same JSON contract, `--workload NAME` ------------------------
+MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (no TF32 on gfx950)
+BLACKBOX_FLOP_PER_EVAL = 3390  # 2 (27 25 + 2 25 6) + 2 (28 20 + 2 20 4) per RHS evaluation and trajectory
+WORKLOAD_TABLE = {
+    # name: (synthetic workload, rows, n_iwae, solver, mode, bound, what BASELINE.json calls it)
+    "config2": ("dr_constant_icml", 36, 200, "rk4", "train", "hbm", "configs[1]"),
+    "config3_train": ("dr_constant_icml", 36, 1000, "rk4", "train", "hbm", "configs[2], training shape (one batch, n_iwae=1000)"),
+    "config3_eval": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm", "configs[2], evaluation shape (all 234 rows, n_iwae=1000)"),
+    "config4": ("dr_blackbox_icml", 36, 200, "midpoint", "train", "mfma", "configs[3]"),
+    "config5": ("relay_constant_precisions", 36, 200, "midpoint", "train", "hbm", "configs[4]"),
+}
+LAUNCH_KERNELS = {  # launch name (ops._launch) -> substrings of the kernels it can run, for the PMC lookup
+    "decoder_step": ["dr_scan_train_theta_kernel", "dr_lane_train_theta_kernel"],
+    "ode_logp_grad": ["dr_scan_train_kernel", "dr_lane_train_kernel"],
+    "ode_fwd": ["bb_mfma_fwd_kernel", "dr_lane_fwd_kernel", "ode_fwd_kernel"],
+    "ode_bwd": ["bb_mfma_bwd_kernel", "dr_lane_bwd_kernel", "ode_bwd_kernel"],
+}
+
+
+def time_launch(fn, n):
+    st = torch.cuda.current_stream()
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(st)
+    for _ in range(n):
+        fn()
+    e1.record(st)
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e3 / n
+
+
+def run_workload(a, name):
+    """One of BASELINE.json's other configurations through the same host path: timed loop (barrier + synchronize on
+    both sides, max over ranks), then the step's own ODE launches re-issued back to back between one HIP event pair for
+    the roofline object.  N > 1: --shard samples splits the ONE batch's IWAE-sample axis over the ranks (strong
+    scaling, the partitioning BASELINE config 3 names); --shard rows replicates the batch per rank (weak)."""
+    from vihds import hip, ops, parallel, synthetic
+
+    wl, B, S, solver, mode, bound, cfg_note = WORKLOAD_TABLE[name]
+    if a.solver_given:
+        solver = a.solver
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != a.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d (launch with torch.distributed.run --nproc-per-node N)"
+                         % (a.gpus, world))
+    shard = parallel.init_from_env()
+    rank = shard.rank if shard is not None else 0
+    replica = None
+    strong = shard is not None and a.shard == "samples" and mode == "train"
+    if shard is not None and not strong:
+        replica, shard = parallel.RowReplica(shard.rank, shard.world, shard.group), None
+    if strong and S % world:
+        raise SystemExit("n_iwae=%d does not split over %d ranks" % (S, world))
+    multi = world > 1
+    local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(local_rank)
+    dev = "cuda:%d" % local_rank
+    use_graph = not a.eager and mode == "train"
+    extra = {}
+    if wl == "dr_constant_icml":
+        extra["fused_ode_training"] = not a.two_kernel_ode
+    args, settings, data, parameters, model, training = synthetic.build(
+        wl, B, S, solver=solver, device=dev, seed=a.seed, shard=shard, replica=replica, u_rng=a.device_rng,
+        conditioner_rng=a.device_rng, hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, **extra)
+    batch = training.train_data
+    if mode == "train":
+        model.train()
+        step = training.graph_step if use_graph else training.step
+    else:
+        model.eval()
+
+        def step(bt):  # training.py:183-215 (_evaluate_elbo_and_plot): forward without grad + Results.init summaries
+            with torch.no_grad():
+                results, theta, q, p = model(bt, S)
+                out = training.cost(bt, results, theta, q, p, full_output=True)
+            return out.elbo
+
+    def barrier():
+        torch.cuda.synchronize()
+        if multi:
+            torch.distributed.barrier()
+            torch.cuda.synchronize()
+
+    if use_graph:
+        step(batch)
+    for _ in range(a.warmup):
+        loss = step(batch)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        loss = step(batch)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if multi:
+        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(tt)
+    final = float(torch.as_tensor(loss).float().mean())
+    if not np.isfinite(final):
+        raise SystemExit("non-finite objective %r after the timed steps: not a valid bench run" % final)
+
+    # ---- roofline: the step's own ODE launches, re-issued back to back ---------------------------------------------
+    rec = ops.LaunchRecorder()
+    ops.TIMER = rec
+    if mode == "train":
+        training.step(batch)
+    else:
+        step(batch)
+    ops.TIMER = None
+    ode = model.decoder.ode_model
+    T = int(batch.times.shape[0])
+    P = len(model.encoder.names)
+    N = int(hip.lib().vihds_model_n_states(hip.MODELS[ode.model_key]))
+    s_local = S // world if strong else S
+    fwd_b = 4 * (P * B * s_local + B * s_local * N * T + B * s_local * 4 * T)
+    bwd_b = 4 * (B * s_local * N * T + P * B * s_local)
+    theta_b = 4 * (2 * P * B * s_local + 2 * B * s_local)
+    n_eval = (T - 1) * {"euler": 1, "rk4": 4}.get(solver, 2)
+    fwd_f = BLACKBOX_FLOP_PER_EVAL * n_eval * B * s_local
+    work = {"decoder_step": (fwd_b + bwd_b + theta_b, 3 * fwd_f), "ode_logp_grad": (fwd_b + bwd_b, 3 * fwd_f),
+            "ode_fwd": (fwd_b, fwd_f), "ode_bwd": (bwd_b, 2 * fwd_f)}
+    timed = {k: time_launch(fn, max(10, a.roofline_steps // 2)) for k, fn in rec.calls.items() if k in work}
+    import glob
+    pmc = {}
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_hbm_traffic.json" % name)), reverse=True):
+        pmc = {"file": os.path.basename(f), "kernels": json.load(open(f))["kernels"]}
+        break
+
+    def traffic_of(launch):
+        for sub in LAUNCH_KERNELS[launch]:
+            for k, v in pmc.get("kernels", {}).items():
+                if sub in k:
+                    return k, v["hbm_bytes_corrected"]
+        return None, None
+
+    def entry(k):
+        us = timed[k]
+        kname, tr = traffic_of(k)
+        if bound == "mfma":
+            ach, unit, peak, num = work[k][1] / (us * 1e-6) / 1e12, "TFLOP/s", MFMA_F32_PEAK_TFLOPS, work[k][1]
+        else:
+            ach, unit, peak, num = work[k][0] / (us * 1e-6) / 1e9, "GB/s", HBM_PEAK_GBS, work[k][0]
+        return {"launch": k, "kernel": kname, "mean_us": us, "achieved": ach, "unit": unit, "peak": peak,
+                "frac": ach / peak, "algorithmic_%s_per_launch" % ("flops" if bound == "mfma" else "bytes"): num,
+                "traffic": tr}
+
+    if rank != 0:
+        return
+    roofline = None
+    if timed:
+        dom = max(timed, key=timed.get)
+        d = entry(dom)
+        roofline = {"bound": bound, "kernel": d["kernel"] or dom, "launch": dom, "achieved": d["achieved"],
+                    "peak": d["peak"], "unit": d["unit"], "frac": d["frac"], "traffic": d["traffic"],
+                    "traffic_source": ("profiles/%s" % pmc["file"]) if d["traffic"] is not None else None,
+                    "mean_us": d["mean_us"], "launches_timed": max(10, a.roofline_steps // 2),
+                    "timing": "back-to-back launches of the step's own launch closure between one HIP event pair on the "
+                              "launch stream",
+                    "numerator_note": ("SURVEY 8d: %d flop per RHS evaluation and trajectory x %d evaluations x %d "
+                                       "trajectories forward, backward counted as 2x forward" % (BLACKBOX_FLOP_PER_EVAL, n_eval, B * s_local))
+                    if bound == "mfma" else "SURVEY 8d fixed numerator: fwd = theta + trajectory + x_predict, bwd = trajectory + d theta",
+                    "other_kernels": [entry(k) for k in timed if k != dom]}
+        mf = os.path.join(ROOT, "profiles", "%s_mfma_busy.json" % name)
+        if bound == "mfma" and os.path.exists(mf):
+            roofline["mfma_busy"] = json.load(open(mf))
+    what = "training steps" if mode == "train" else "evaluation passes"
+    scale = 1 if (strong or not multi) else world
+    out = {
+        "metric": "ELBO %s/sec (%s, n_iwae=%d)" % (what, wl, S), "value": scale * a.steps / elapsed,
+        "unit": "steps/s" if mode == "train" else "passes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+        "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "%s (BASELINE.json %s): B=%d rows x n_iwae=%d, N=%d states, T=%d, P=%d, %s, %s"
+                               % (wl, cfg_note, B, S, N, T, P, solver,
+                                  "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" if mode == "train" else
+                                  "evaluation pass (forward without grad, trajectories through HBM, IW summaries on device)"),
+                   "name": name, "solver": solver, "n_iwae_per_gpu": s_local, "n_iwae_global": S,
+                   "rows_global": B * (world if replica is not None else 1),
+                   "launch": "hipGraph replay" if use_graph else "eager", "learning_rate": a.lr,
+                   "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
+                                    "encoders.py:385) are outside the replayed step",
+                   "parallelism": ("single GPU" if world == 1 else
+                                   "iwae-sample shard x%d of ONE batch (all-gather of row statistics + one gradient all-reduce "
+                                   "per step)" % world if strong else
+                                   "data parallel over rows x%d (one gradient all-reduce per step)" % world)},
+        "final_objective": final, "roofline": roofline,
+    }
+    if world == 1 and not a.no_cpu_baseline and wl == "dr_constant_icml" and mode == "train":
+        out["cpu_baseline"] = cpu_baseline(solver, batch.observations.detach().cpu(), n_iwae=S, max_steps=4)
+        out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
+    else:
+        out["cpu_baseline"] = None
+        out["cpu_baseline_note"] = "the oracle's timed training step exists for the dr_constant training workloads only"
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--solver", default="rk4")
+    ap.add_argument("--solver", default=None)
+    ap.add_argument("--workload", choices=sorted(WORKLOAD_TABLE), default="config2",
+                    help="which BASELINE.json configuration: config2 (headline, default), config3_train / config3_eval "
+                         "(n_iwae=1000), config4 (dr_blackbox, MFMA roofline), config5 (relay)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from python instead of replaying a hipGraph")
     ap.add_argument("--host-rng", action="store_true", help="draw u with host numpy as the reference does (vae.py:22-24)")
     ap.add_argument("--device-rng", choices=["kernel", "device"], default="kernel",
@@ -199,6 +401,12 @@ def main():
                          "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
                          "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it")
     a = ap.parse_args()
+    a.solver_given = a.solver is not None
+    if a.workload != "config2":
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        return run_workload(a, a.workload)
+    a.solver = a.solver or "rk4"
 
     from vihds import ops, parallel, synthetic
 
@@ -358,6 +566,8 @@ def main():
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
                    "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "learning_rate": a.lr,
+                   "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
+                                    "encoders.py:385) are outside the replayed step",
                    "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": ("single GPU" if world == 1 else
                                    "data parallel over rows x%d (36 rows per GPU, one gradient all-reduce per step)" % world

@@ -79,7 +79,40 @@ def dr_blackbox_icml_spec(solver="midpoint"):
     }
 
 
-WORKLOADS = {"dr_constant_icml": (dr_constant_icml_spec, 86), "dr_blackbox_icml": (dr_blackbox_icml_spec, 86)}
+def relay_constant_precisions_spec(solver="midpoint"):
+    """The relay experiment (BASELINE config 5): two relay devices, 12 species + 4 neural precision states, P = 45
+    parameters, priors as in the reference's specs/relay_constant_precisions.yaml:6-97 (the reference's model classes for
+    this spec raise at construction -- relay_constant.py:17,201 -- so this workload runs on this package only)."""
+    ref = lambda k: {"distribution": k}  # noqa: E731
+    glob = {"e76": _ln(-3.0, 1.0), "e81": _ln(-3.0, 1.0), "KGR_76": _ln(2.0, 3.0), "KGR_81": _ln(-2.0, 3.0),
+            "KGS_76": _ln(-2.0, 3.0), "KGS_81": _ln(2.0, 3.0), "KR6": _ln(-6.0, 3.0), "KR12": _ln(-12.0, 3.0),
+            "KS6": _ln(-12.0, 3.0), "KS12": _ln(-6.0, 3.0), "KC6": _ln(-6.0, 3.0), "KC12": _ln(-6.0, 3.0),
+            "Klux": _ln(-2.0, 3.0), "Klas": _ln(-2.0, 3.0), "nR": _ln(0.0, 0.25), "nS": _ln(0.0, 0.25),
+            "dR": _ln(-2.0, 1.0), "dS": _ln(-2.0, 1.0), "dluxI": _ln(-2.0, 1.0), "dlasI": _ln(-2.0, 1.0),
+            "aYFP": _ln(0.0, 2.0), "aCFP": _ln(0.0, 2.0), "aR": _ln(0.0, 0.25), "aS": _ln(0.0, 0.25),
+            "drfp": ref("dfp_prec"), "dyfp": ref("dfp_prec"), "dcfp": ref("dfp_prec"), "a530": ref("auto_prec"),
+            "a480": ref("auto_prec"), "init_prec_x": ref("init_prec"), "init_prec_rfp": ref("init_prec"),
+            "init_prec_yfp": ref("init_prec"), "init_prec_cfp": ref("init_prec")}
+    local = {"conditioning": {"devices": True, "treatments": False}, "r": _ln(0.0, 0.25), "K": _ln(0.0, prec=2.0),
+             "tlag": _ln(0.0, prec=2.0), "rc": _ln(0.0, 2.0)}
+    return {
+        "data": {"devices": ["R33S175DR_P76LasI", "R33S175DR_P81LuxI"], "files": [],
+                 "signals": ["OD", "mRFP1", "EYFP", "ECFP"], "conditions": ["C6", "C12"], "separate_conditions": True},
+        "model": "relay_constant_precisions",
+        "params": {
+            "learning_boundaries": [250, 500], "learning_rate": 0.01, "learning_gamma": 0.2, "solver": solver,
+            "n_hidden_decoder_precisions": 0,
+            "constant": {"init_x": 0.002, "init_rfp": 0.0, "init_yfp": 0.0, "init_cfp": 0.0, "init_luxR": 0.0,
+                         "init_lasR": 0.0, "init_lasI": 0.0, "init_luxI": 0.0},
+            "shared": {"auto_prec": _ln(-5.0, 2.0), "dfp_prec": _ln(-2.0, 1.5), "init_prec": _ln(6.0, 2.0)},
+            "global_conditioned": {"conditioning": {"devices": True, "treatments": False}},
+            "global": glob, "local": local,
+        },
+    }
+
+
+WORKLOADS = {"dr_constant_icml": (dr_constant_icml_spec, 86), "dr_blackbox_icml": (dr_blackbox_icml_spec, 86),
+             "relay_constant_precisions": (relay_constant_precisions_spec, 99)}
 
 
 class SyntheticPlateDataset(Dataset):
