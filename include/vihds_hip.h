@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 2
+#define VIHDS_ABI_VERSION 3
 
 /* error codes */
 #define VIHDS_OK 0
@@ -63,7 +63,14 @@ enum vihds_solver {
   VIHDS_SOLVER_EULER = 2,         /* torchdiffeq==0.1 fixed-grid 'euler'    (restated; parity unpinned) */
   VIHDS_SOLVER_MIDPOINT = 3,      /* torchdiffeq==0.1 fixed-grid 'midpoint' (restated; parity unpinned) */
   VIHDS_SOLVER_RK4 = 4,           /* torchdiffeq==0.1 fixed-grid 'rk4' = 3/8 rule (restated; parity unpinned) */
-  VIHDS_SOLVER_COUNT = 5
+  /* Adaptive pairs of torchdiffeq==0.1 (vihds/ode.py:79-81, tests/test_ode_solvers.py:66-80; restated; parity unpinned).
+     With one of these, `times` passed to vihds_ode_fwd / vihds_ode_bwd is the ACCEPTED grid that
+     vihds_ode_adaptive_grid returned (which contains the output times), integrated with the pair's higher-order
+     tableau; the adjoint is the discrete adjoint of those steps. */
+  VIHDS_SOLVER_DOPRI5 = 5,        /* Dormand-Prince 5(4) */
+  VIHDS_SOLVER_BOSH3 = 6,         /* Bogacki-Shampine 3(2) */
+  VIHDS_SOLVER_ADAPTIVE_HEUN = 7, /* Heun-Euler 2(1) */
+  VIHDS_SOLVER_COUNT = 8
 };
 
 #define VIHDS_MAX_SLOTS 64
@@ -127,6 +134,21 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
                   float* g_weights, float* aux, void* stream);
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
+
+/* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
+ * odeint / odeint_adjoint, absent from the tree: restated, parity unpinned).  Step-size controller, SYNCHRONOUS on
+ * `stream` (one device round trip per trial step): walks the whole batch from times_host[0] to times_host[T-1] with ONE
+ * step size for all trajectories (error ratio = mean over all state elements of (err / (atol + rtol max(|y0|,|y1|)))^2,
+ * accepted when <= 1; next step = step / max(0.1, min(ratio^(1/(2 order)) / 0.9, 1 / dfactor)), dfactor 0.2 after a
+ * rejection), every accepted step clipped to the next output time.  Returns the number G of grid points written to
+ * grid_host (host memory, capacity max_grid), index_host[k] = position of output time k in the grid; negative: error.
+ * The caller then runs vihds_ode_fwd / vihds_ode_bwd with p->T = G and `times` = the grid (device copy): they integrate
+ * with the pair's higher-order tableau on it, and the adjoint is the discrete adjoint of those steps.
+ * workspace: vihds_ode_adaptive_workspace_floats(p) floats of device memory. */
+long long vihds_ode_adaptive_workspace_floats(const vihds_ode_problem* p);
+int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                            const float* weights, const float* times_host, float rtol, float atol, float* workspace,
+                            float* grid_host, int max_grid, int* index_host, void* stream);
 
 /* Training fast path: the per-species log-likelihood logp [4][B][S] of vihds_ode_fwd AND, in the same launch, the
  * gradient g_theta_unit [n_rows][B][S] that vihds_ode_bwd would return for g_logp == 1 (g_traj = g_xpred = NULL).

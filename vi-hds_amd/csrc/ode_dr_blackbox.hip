@@ -7,7 +7,7 @@ namespace vihds {
 using BB = Blackbox<2, 25, 20, 5, 5, 2>;
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   // kernel_variant 1 = VALU, one thread per trajectory (vihds_blackbox.hpp); otherwise the MFMA formulation
-  if (a.kernel_variant == 1) return launch_ode<BB>(backward, solver, a, st);
+  if (a.kernel_variant == 1 || solver_is_adaptive(solver) || g_adaptive_ctl) return launch_ode<BB>(backward, solver, a, st);
   return launch_bb_mfma(backward, solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }

@@ -17,7 +17,8 @@ static int lane_split_max_n_v1() {
 }
 int launch_dr_constant_v1(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v1());
-  if (lanes) return launch_dr_lanes<1>(backward, solver, a, st);
+  // (the adaptive pairs and their step-size controller exist in the thread-per-trajectory kernels only)
+  if (lanes && !solver_is_adaptive(solver) && !g_adaptive_ctl) return launch_dr_lanes<1>(backward, solver, a, st);
   return launch_ode<DrConstant<1>>(backward, solver, a, st);
 }
 // fused log-likelihood + unit-weight adjoint (lane-split regime only)

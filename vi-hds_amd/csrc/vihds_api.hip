@@ -9,6 +9,7 @@
 #include "vihds_ode_kernels.hpp"
 
 namespace vihds {
+thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
 // per-model translation units (ode_<model>.hip)
 #define VIHDS_DECL(name)                                                        \
   int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
@@ -195,7 +196,7 @@ int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const fl
   if (!p || !theta || !cond || !times || !obs || !logp || !g_theta_unit) return fail(VIHDS_E_BADARG, "null argument");
   if (p->model != VIHDS_MODEL_DR_CONSTANT && p->model != VIHDS_MODEL_DR_CONSTANT_V2)
     return fail(VIHDS_E_UNSUPPORTED, "fused log-likelihood + adjoint exists for dr_constant / dr_constant_v2 only");
-  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver");
+  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver (the fused training kernels take the fixed-grid schemes)");
   const ModelEntry* e = entry(p->model);
   OdeArgs a;
   if (int rc = build_args(p, e, a)) return rc;
@@ -222,7 +223,7 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
     return fail(VIHDS_E_BADARG, "null argument");
   if (p->model != VIHDS_MODEL_DR_CONSTANT && p->model != VIHDS_MODEL_DR_CONSTANT_V2)
     return fail(VIHDS_E_UNSUPPORTED, "the fused decoder step exists for dr_constant / dr_constant_v2 only");
-  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver");
+  if (p->solver < 0 || p->solver > VIHDS_SOLVER_RK4) return fail(VIHDS_E_BADARG, "unknown solver (the fused training kernels take the fixed-grid schemes)");
   if (P <= 0 || P > p->n_rows) return fail(VIHDS_E_BADARG, "P out of range");
   if (opts && co && opts->rng && opts->rng == co->rng)
     return fail(VIHDS_E_BADARG, "the sampling stage and the conditioner need separate generator states");
@@ -266,7 +267,7 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
   // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
-  const long long stages = p->solver == VIHDS_SOLVER_EULER ? 1 : (p->solver == VIHDS_SOLVER_RK4 ? 4 : 2);
+  const long long stages = ode_stages(p->solver);
   return (long long)(8 + e->n_states() - 4 + 1) * (p->T - 1) * stages * p->B * p->S;
 }
 int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
@@ -298,6 +299,49 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
   rc = e->launch(false, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_fwd launch");
+}
+
+long long vihds_ode_adaptive_workspace_floats(const vihds_ode_problem* p) {
+  if (!p) return VIHDS_E_BADARG;
+  const ModelEntry* e = entry(p->model);
+  if (!e) return VIHDS_E_UNSUPPORTED;
+  const long long n = (long long)p->B * p->S;
+  return 2 * (long long)e->n_states() * n + 2 * ((n + 255) / 256);
+}
+
+int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                            const float* weights, const float* times_host, float rtol, float atol, float* workspace,
+                            float* grid_host, int max_grid, int* index_host, void* stream) {
+  if (!p || !theta || !times_host || !workspace || !grid_host || !index_host || max_grid < 2)
+    return fail(VIHDS_E_BADARG, "null argument");
+  if (!solver_is_adaptive(p->solver)) return fail(VIHDS_E_BADARG, "vihds_ode_adaptive_grid needs an adaptive solver id");
+  if (!(rtol > 0.f) || !(atol > 0.f)) return fail(VIHDS_E_BADARG, "rtol and atol must be positive");
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  if (e->neural_prec) {
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+    if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
+        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox sizes outside this build");
+      if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
+    }
+  }
+  for (int k = 1; k < p->T; ++k)
+    if (!(times_host[k] > times_host[k - 1])) return fail(VIHDS_E_BADARG, "output times must increase");
+  OdeArgs a;
+  int rc = build_args(p, e, a);
+  if (rc) return rc;
+  if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.weights = weights;
+  AdaptiveCtl ctl = {times_host, rtol, atol, workspace, grid_host, max_grid, index_host, 0};
+  g_adaptive_ctl = &ctl;
+  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+  g_adaptive_ctl = nullptr;
+  if (rc == VIHDS_E_UNSUPPORTED) return fail(rc, "the accepted grid does not fit max_grid points");
+  if (rc == VIHDS_E_BADARG) return fail(rc, "step size underflow or non-finite error estimate");
+  if (rc) return fail(rc, "adaptive step controller failed");
+  if (int h = check_hip("vihds_ode_adaptive_grid")) return h;
+  return ctl.result;
 }
 
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,

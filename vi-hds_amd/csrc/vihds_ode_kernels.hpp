@@ -10,12 +10,16 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+#include <cmath>
 #include <type_traits>
+#include <vector>
 
 #include "../../include/vihds_hip.h"
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
 #include "vihds_blackbox.hpp"
+#include "vihds_rk_adaptive.hpp"
 
 namespace vihds {
 
@@ -80,6 +84,7 @@ struct PrecDumpCtx {
   float bsum[8];
 };
 __host__ __device__ inline int ode_stages(int solver) {
+  if (solver_is_adaptive(solver)) return adaptive_stages(solver);
   return solver == VIHDS_SOLVER_EULER ? 1 : (solver == VIHDS_SOLVER_RK4 ? 4 : 2);
 }
 template <class M, bool BB = is_blackbox<M>::value, bool HAS_W = (M::NW > 0)>
@@ -128,6 +133,10 @@ struct bwd_ctx_sel<M, true> {
 template <class M, int SOLVER>
 __device__ __forceinline__ void ode_step(float t0, float t1, float h0, float* y, const float* p, const float* wts) {
   constexpr int N = M::N;
+  if constexpr (solver_is_adaptive(SOLVER)) {  // the accepted grid of an adaptive pair, its higher-order tableau
+    rk_step_generic<M, Tableau<SOLVER>>(t0, t1 - t0, y, p, wts, nullptr);
+    return;
+  }
   float k1[N], k2[N], ya[N];
   if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
     // vihds/solvers.py:12-16 / :21-25
@@ -177,6 +186,13 @@ template <class M, int SOLVER, class Ctx>
 __device__ __forceinline__ void ode_step_vjp(float t0, float t1, float h0, const float* y, const float* p,
                                              const float* wts, float* lam, float* pb, Ctx& wtsb) {
   constexpr int N = M::N;
+  if constexpr (solver_is_adaptive(SOLVER)) {
+    rk_step_generic_vjp<M, Tableau<SOLVER>>(t0, t1 - t0, y, p, wts, lam, [&](float t, const float* ys, const float* v,
+                                                                             float* yb) {
+      call_vjp<M>(t, ys, p, wts, v, yb, pb, wtsb);
+    });
+    return;
+  }
   float k1[N], ya[N], v[N], w[N];
   if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
     const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
@@ -478,8 +494,29 @@ inline void launch_bwd_s(const OdeArgs& a, hipStream_t st) {
   hipLaunchKernelGGL((ode_bwd_kernel<M, SOLVER>), dim3((a.n + blk - 1) / blk), dim3(blk), 0, st, a);
 }
 
+// Request block of vihds_ode_adaptive_grid: when set (by the API, on the calling thread), the model's launcher runs the
+// step-size controller instead of a forward / adjoint launch and leaves the grid length (or an error code) in `result`.
+struct AdaptiveCtl {
+  const float* times_host;
+  float rtol, atol;
+  float* workspace;
+  float* grid_host;
+  int max_grid;
+  int* index_host;
+  int result;
+};
+extern thread_local AdaptiveCtl* g_adaptive_ctl;
+template <class M>
+inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
+                         float* grid_host, int max_grid, int* index_host, hipStream_t st);
+
 template <class M>
 inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  if (AdaptiveCtl* ctl = g_adaptive_ctl) {
+    ctl->result = adaptive_grid<M>(solver, a, ctl->times_host, ctl->rtol, ctl->atol, ctl->workspace, ctl->grid_host,
+                                   ctl->max_grid, ctl->index_host, st);
+    return ctl->result < 0 ? ctl->result : VIHDS_OK;
+  }
 #define VIHDS_CASE(SV)                                           \
   case SV:                                                       \
     if (backward) launch_bwd_s<M, SV>(a, st);                    \
@@ -491,8 +528,173 @@ inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t s
     VIHDS_CASE(VIHDS_SOLVER_EULER)
     VIHDS_CASE(VIHDS_SOLVER_MIDPOINT)
     VIHDS_CASE(VIHDS_SOLVER_RK4)
+    VIHDS_CASE(VIHDS_SOLVER_DOPRI5)
+    VIHDS_CASE(VIHDS_SOLVER_BOSH3)
+    VIHDS_CASE(VIHDS_SOLVER_ADAPTIVE_HEUN)
   }
 #undef VIHDS_CASE
+  return VIHDS_E_BADARG;
+}
+
+// ---- step-size controller of the adaptive pairs (vihds_rk_adaptive.hpp) ---------------------------------------------
+// State of the whole batch in a caller-provided workspace Y [N][n]; every launch writes one float per block to
+// `partial` (sums of squares), which the host adds up in block order (deterministic).
+// MODE 0: Y <- initial state; partial[0][blk] = sum (y0 / scale)^2, partial[1][blk] = sum (f0 / scale)^2   (scale = atol + rtol |y0|)
+// MODE 1: partial[0][blk] = sum ((f(t + h, y0 + h f0) - f0) / scale)^2                                     (initial step)
+// MODE 2: trial step of size h from Yin at t: Yout <- y', partial[0][blk] = sum (err / (atol + rtol max(|y|, |y'|)))^2
+template <class M, int SOLVER, int MODE>
+__global__ void __launch_bounds__(256) ode_trial_kernel(OdeArgs a, const float* Yin, float* Yout, float t, float h,
+                                                        float rtol, float atol, float* partial) {
+  constexpr int N = M::N;
+  __shared__ float wlds[M::NW > 0 ? M::NW : 1];
+  __shared__ float red[2][256];
+  const float* wts = stage_weights<M>(a, wlds);
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  float s0 = 0.f, s1 = 0.f;
+  if (i < a.n) {
+    const int b = i / a.S;
+    float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP], y[N];
+    load_theta<M>(a, i, b, th, prec, c);
+    if constexpr (is_blackbox<M>::value) {
+      M::prepare_bb(th, a, b, p);
+      M::init_bb(th, a, y);
+    } else {
+      M::prepare(th, c, p);
+      M::init(th, c, y);
+    }
+    const size_t n = a.n;
+    if (MODE == 0) {
+      float f0[N];
+      M::rhs(t, y, p, wts, f0);
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+        Yout[(size_t)j * n + i] = y[j];
+        const float sc = atol + rtol * fabsf(y[j]);
+        s0 += (y[j] / sc) * (y[j] / sc);
+        s1 += (f0[j] / sc) * (f0[j] / sc);
+      }
+    } else if (MODE == 1) {
+      float f0[N], f1[N], y1[N];
+      M::rhs(t, y, p, wts, f0);
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) y1[j] = y[j] + h * f0[j];
+      M::rhs(t + h, y1, p, wts, f1);
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+        const float sc = atol + rtol * fabsf(y[j]);
+        const float d = (f1[j] - f0[j]) / sc;
+        s0 += d * d;
+      }
+    } else {
+      float err[N], y0[N];
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) { y[j] = Yin[(size_t)j * n + i]; y0[j] = y[j]; }
+      rk_step_generic<M, Tableau<SOLVER>>(t, h, y, p, wts, err);
+      VIHDS_UNROLL for (int j = 0; j < N; ++j) {
+        Yout[(size_t)j * n + i] = y[j];
+        const float tol = atol + rtol * fmaxf(fabsf(y0[j]), fabsf(y[j]));
+        const float r = err[j] / tol;
+        s0 += r * r;
+      }
+    }
+  }
+  red[0][threadIdx.x] = s0;
+  red[1][threadIdx.x] = s1;
+  __syncthreads();
+  for (int w = blockDim.x / 2; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      red[0][threadIdx.x] += red[0][threadIdx.x + w];
+      red[1][threadIdx.x] += red[1][threadIdx.x + w];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    partial[blockIdx.x] = red[0][0];
+    partial[gridDim.x + blockIdx.x] = red[1][0];
+  }
+}
+
+// Host-driven controller (synchronous on `st`).  Workspace: 2 N n floats of state + 2 blocks floats of partial sums.
+// Returns the number of grid points written to grid_host (<= max_grid), or a negative error code.
+template <class M, int SOLVER>
+inline int adaptive_grid_s(const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
+                           float* grid_host, int max_grid, int* index_host, hipStream_t st) {
+  using TB = Tableau<SOLVER>;
+  constexpr int N = M::N;
+  const int blk = 256, nblk = (a.n + blk - 1) / blk;
+  float* Y0 = workspace;
+  float* Y1 = Y0 + (size_t)N * a.n;
+  float* partial = Y1 + (size_t)N * a.n;
+  std::vector<float> hp(2 * (size_t)nblk);
+  auto sums = [&](double* s0, double* s1) -> bool {
+    if (hipMemcpyAsync(hp.data(), partial, hp.size() * sizeof(float), hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    if (hipStreamSynchronize(st) != hipSuccess) return false;
+    double u = 0.0, v = 0.0;
+    for (int q = 0; q < nblk; ++q) { u += hp[q]; v += hp[nblk + q]; }
+    *s0 = u;
+    if (s1) *s1 = v;
+    return true;
+  };
+  const double cnt = (double)N * (double)a.n;
+  const float t0 = times_host[0];
+  // initial step (torchdiffeq 0.1 _select_initial_step) [recalled]
+  double q0, q1, q2;
+  hipLaunchKernelGGL((ode_trial_kernel<M, SOLVER, 0>), dim3(nblk), dim3(blk), 0, st, a, nullptr, Y0, t0, 0.f, rtol, atol, partial);
+  if (!sums(&q0, &q1)) return VIHDS_E_HIP;
+  const double d0 = std::sqrt(q0 / cnt), d1 = std::sqrt(q1 / cnt);
+  double h0 = (d0 < 1e-5 || d1 < 1e-5) ? 1e-6 : 0.01 * d0 / d1;
+  hipLaunchKernelGGL((ode_trial_kernel<M, SOLVER, 1>), dim3(nblk), dim3(blk), 0, st, a, nullptr, Y0, t0, (float)h0, rtol, atol, partial);
+  if (!sums(&q2, nullptr)) return VIHDS_E_HIP;
+  const double d2 = std::sqrt(q2 / cnt) / h0;
+  double h1 = (d1 <= 1e-15 && d2 <= 1e-15) ? std::max(1e-6, h0 * 1e-3) : std::pow(0.01 / std::max(d1, d2), 1.0 / (TB::ORDER + 1));
+  double h = std::min(100.0 * h0, h1);
+  // accepted steps, clipped to the output times
+  int ng = 0;
+  grid_host[ng++] = t0;
+  index_host[0] = 0;
+  float t = t0;
+  for (int k = 1; k < a.T; ++k) {
+    const float t_out = times_host[k];
+    while (t < t_out) {
+      if (ng >= max_grid) return VIHDS_E_UNSUPPORTED;
+      const bool clip = t + (float)h >= t_out;
+      const float t_next = clip ? t_out : t + (float)h;
+      const float hs = t_next - t;
+      if (!(hs > 0.f)) return VIHDS_E_BADARG;  // step size underflow
+      hipLaunchKernelGGL((ode_trial_kernel<M, SOLVER, 2>), dim3(nblk), dim3(blk), 0, st, a, Y0, Y1, t, hs, rtol, atol, partial);
+      double e2;
+      if (!sums(&e2, nullptr)) return VIHDS_E_HIP;
+      const double ratio = e2 / cnt;  // mean squared error ratio
+      if (!(ratio == ratio)) return VIHDS_E_BADARG;
+      const bool accept = ratio <= 1.0;
+      // torchdiffeq 0.1 _optimal_step_size(last_step, mean_error_ratio, safety 0.9, ifactor 10, dfactor 0.2, order)
+      double hn;
+      if (ratio == 0.0) hn = (double)hs * 10.0;
+      else {
+        const double dfactor = ratio < 1.0 ? 1.0 : 0.2;
+        const double er = std::sqrt(ratio);
+        const double factor = std::max(1.0 / 10.0, std::min(std::pow(er, 1.0 / TB::ORDER) / 0.9, 1.0 / dfactor));
+        hn = (double)hs / factor;
+      }
+      if (accept) {
+        t = t_next;
+        std::swap(Y0, Y1);
+        grid_host[ng++] = t;
+        // a clipped step says little about the step the controller wanted: keep the larger proposal
+        h = clip ? std::max(h, hn) : hn;
+      } else {
+        h = hn;
+      }
+    }
+    index_host[k] = ng - 1;
+  }
+  return ng;
+}
+
+template <class M>
+inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
+                         float* grid_host, int max_grid, int* index_host, hipStream_t st) {
+  switch (solver) {
+    case VIHDS_SOLVER_DOPRI5: return adaptive_grid_s<M, VIHDS_SOLVER_DOPRI5>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
+    case VIHDS_SOLVER_BOSH3: return adaptive_grid_s<M, VIHDS_SOLVER_BOSH3>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
+    case VIHDS_SOLVER_ADAPTIVE_HEUN: return adaptive_grid_s<M, VIHDS_SOLVER_ADAPTIVE_HEUN>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
+  }
   return VIHDS_E_BADARG;
 }
 

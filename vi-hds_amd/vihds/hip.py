@@ -29,7 +29,9 @@ MODELS = {
     "debug_constant": 15,
 }
 E_UNSUPPORTED = -2  # VIHDS_E_UNSUPPORTED (include/vihds_hip.h)
-SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4}
+SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4, "dopri5": 5, "bosh3": 6,
+           "adaptive_heun": 7}
+ADAPTIVE_SOLVERS = ("dopri5", "bosh3", "adaptive_heun")  # torchdiffeq's adaptive pairs (vihds_rk_adaptive.hpp)
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -110,6 +112,9 @@ _PROTOTYPES = {
     "vihds_model_n_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
     "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
+    "vihds_ode_adaptive_workspace_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_adaptive_grid": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 5 + [ctypes.c_float, ctypes.c_float] + [_P] * 2
+                                + [_I, _P, _P]),
     "vihds_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 8),
     "vihds_theta_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem), _I] + [_P] * 8 + [ctypes.POINTER(ThetaOpts),
                                                                                      ctypes.POINTER(Conditioner)]
@@ -157,7 +162,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 2:
+        if handle.vihds_abi_version() != 3:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

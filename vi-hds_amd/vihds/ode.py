@@ -5,6 +5,8 @@ loop -- and, fused in the same kernel, observe + the Gaussian log-likelihood -- 
 (vihds_ode_fwd) with a hand-written discrete adjoint (vihds_ode_bwd).  There is no torchdiffeq and no CPU path.
 """
 import numpy as np
+import math
+
 import torch
 import torch.nn as nn
 
@@ -175,8 +177,9 @@ class OdeModel(nn.Module):
     def _spec(self, config, row_of, n_rows):
         key = (config.params.solver, n_rows, tuple(sorted(row_of.items())))
         if key not in self._spec_cache:
-            if default_get_value(config.params, "adjoint_solver", False):
-                raise NotImplementedError("adjoint_solver: the HIP path always uses the discrete adjoint")
+            # params.adjoint_solver (reference ode.py:80: torchdiffeq.odeint_adjoint, the continuous adjoint) selects
+            # nothing here: every solver differentiates through the discrete adjoint of its own accepted steps, which is
+            # the gradient of what was actually computed
             kw = dict(self.problem_kwargs(config))
             # params.kernel_variant: 0 = the library's choice, 1 thread-per-trajectory, 2 lane-split, 3 time-parallel
             kw.setdefault("kernel_variant", int(default_get_value(config.params, "kernel_variant", 0)))
@@ -194,6 +197,8 @@ class OdeModel(nn.Module):
         spec = self._spec(config, row_of, packed.shape[0])
         dev = packed.device
         times = times.to(dev)
+        if config.params.solver in hip.ADAPTIVE_SOLVERS:
+            return self._solve_adaptive(config, spec, packed, row_of, times, theta, conditions, dev_1hot, observations)
         obs = observations
         if obs is None:  # likelihood not requested: feed zeros (logp output is then meaningless and unused)
             obs = torch.zeros((packed.shape[1], 4, times.shape[0]), device=dev)
@@ -201,6 +206,39 @@ class OdeModel(nn.Module):
         traj, xpred, logp = ops.OdeSolveObserve.apply(spec, packed, conditions.to(dev), times, obs.to(dev),
                                                       dev_1hot.to(dev) if dev_1hot is not None else None,
                                                       self.neural_weights(), row_offset, row_offset_map)
+        self._last = DecodedSolution(traj, xpred, logp)
+        self._last.has_logp = observations is not None
+        return self._last
+
+    def _solve_adaptive(self, config, spec, packed, row_of, times, theta, conditions, dev_1hot, observations):
+        """torchdiffeq's adaptive pairs (reference ode.py:79-81; dopri5 / bosh3 / adaptive_heun): the controller picks ONE
+        accepted grid for the batch (ops.adaptive_grid), the ordinary kernels integrate on it with the pair's
+        higher-order tableau, the rows of the output times are gathered, and the log-likelihood (observations exist at
+        the output times only) is evaluated with torch ops on the gathered x_predict -- autograd then hands the adjoint
+        kernel upstream gradients for the trajectory / x_predict on the accepted grid."""
+        dev = packed.device
+        cond = conditions.to(dev)
+        d1 = dev_1hot.to(dev) if dev_1hot is not None else None
+        weights = self.neural_weights()
+        rtol = float(default_get_value(config.params, "solver_rtol", 1e-7))  # torchdiffeq.odeint defaults
+        atol = float(default_get_value(config.params, "solver_atol", 1e-9))
+        grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol)
+        self.last_adaptive_grid = grid
+        dummy = torch.zeros((packed.shape[1], 4, grid.shape[0]), device=dev)
+        row_offset, row_offset_map = getattr(theta, "_row_offset", None) or (None, None)
+        traj_g, xpred_g, _ = ops.OdeSolveObserve.apply(spec, packed, cond, grid, dummy, d1, weights, row_offset,
+                                                       row_offset_map)
+        traj, xpred = traj_g.index_select(0, index), xpred_g.index_select(0, index)  # [T,N,B,S], [T,4,B,S]
+        if observations is not None:
+            if spec.n_species < spec.n_states:  # neural precisions: the last four states (reference precisions.py:89-94)
+                prec = traj[:, spec.n_species:, :, :]
+            else:  # constant precisions: four theta rows broadcast over time (reference precisions.py:31-35)
+                rows = [row_of[n] for n in spec.slots[-4:]]
+                prec = packed[rows][None]
+            err = xpred - observations.to(dev).permute(2, 1, 0)[:, :, :, None]
+            logp = (-0.5 * (math.log(2 * math.pi) - torch.log(prec) + prec * err * err)).sum(0)  # training.py:24-44
+        else:
+            logp = torch.zeros((4,) + tuple(packed.shape[1:]), device=dev)
         self._last = DecodedSolution(traj, xpred, logp)
         self._last.has_logp = observations is not None
         return self._last
@@ -213,7 +251,8 @@ class OdeModel(nn.Module):
         import vihds.hip as hip
 
         if (observations is None or self.model_key not in self.fused_training_keys or not torch.is_grad_enabled()
-                or not default_get_value(config.params, "fused_ode_training", False)):
+                or not default_get_value(config.params, "fused_ode_training", False)
+                or config.params.solver in hip.ADAPTIVE_SOLVERS):
             return None
         slots = hip.model_slots(self.model_key)
         packed, row_of = theta.pack(slots)

@@ -76,8 +76,8 @@ class OdeProblemSpec:
             raise KeyError("unknown model '%s'" % model)
         if solver not in hip.SOLVERS:
             raise NotImplementedError(
-                "solver '%s' is not implemented by the HIP path (available: %s); adaptive torchdiffeq solvers "
-                "are out of scope" % (solver, ", ".join(sorted(hip.SOLVERS))))
+                "solver '%s' is not implemented by the HIP path (available: %s; of torchdiffeq's adaptive solvers "
+                "dopri8 / DOP853 is not built)" % (solver, ", ".join(sorted(hip.SOLVERS))))
         self.model, self.solver = model, solver
         self.slots = hip.model_slots(model)
         self.n_states = hip.lib().vihds_model_n_states(hip.MODELS[model])
@@ -107,6 +107,30 @@ class OdeProblemSpec:
         ctypes.pointer(p)[0] = self.proto
         p.B, p.S, p.T = B, S, T
         return p
+
+
+def adaptive_grid(spec, theta, cond, times, dev1hot, weights, rtol=1e-7, atol=1e-9, max_grid=4096):
+    """Step-size controller of an adaptive solver (vihds_ode_adaptive_grid; synchronous, no gradient): the accepted
+    time grid for the whole batch -- one step size for all trajectories, as torchdiffeq 0.1 does it -- and the positions
+    of the output times in it.  Returns (grid [G] float32 tensor on the device, index [T] int64 tensor on the device)."""
+    _require_cuda(theta, cond)
+    theta, cond = _c(theta.detach()), _c(cond)
+    R, B, S = theta.shape
+    th = times.detach().to("cpu", torch.float32).contiguous()
+    T = th.shape[0]
+    prob = spec.bind(B, S, T)
+    L = hip.lib()
+    ws = torch.empty(int(L.vihds_ode_adaptive_workspace_floats(ctypes.byref(prob))), device=theta.device,
+                     dtype=torch.float32)
+    grid = torch.empty(max_grid, dtype=torch.float32)
+    index = torch.empty(T, dtype=torch.int32)
+    rc = L.vihds_ode_adaptive_grid(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(_c(dev1hot)),
+                                   hip.ptr(_c(weights.detach()) if weights is not None else None), th.data_ptr(),
+                                   float(rtol), float(atol), hip.ptr(ws), grid.data_ptr(), max_grid, index.data_ptr(),
+                                   hip.current_stream())
+    if rc < 0:
+        hip.check(rc, "vihds_ode_adaptive_grid")
+    return grid[:rc].to(theta.device), index.to(theta.device, torch.int64)
 
 
 class OdeSolveObserve(torch.autograd.Function):

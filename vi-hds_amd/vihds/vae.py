@@ -73,7 +73,8 @@ def _bind_fused(BaseVAE):
         obs = data.get("observations", None) if hasattr(data, "get") else None
         if (not torch.is_grad_enabled() or obs is None or not default_get_value(cfg.params, "fused_ode_training", False)
                 or not default_get_value(cfg.params, "fused_decoder_step", True) or ode.model_key not in ode.fused_training_keys or getattr(q, "_packed_q", None) is None
-                or not obs.is_cuda or (n_extra and not dec.condition_on_device)):
+                or not obs.is_cuda or (n_extra and not dec.condition_on_device)
+                or cfg.params.solver in hip.ADAPTIVE_SOLVERS):
             return None
         key = (tuple(obs.shape), samples, cfg.params.solver)
         if self._fused_declined.get(key):
