@@ -128,6 +128,12 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
  *     8.. the NIN = 1 + core-states layer inputs tanh([t, species])), only the 8 bias gradients are ADDED into
  *     g_weights, and the caller contracts the two weight matrices with vihds_gram_blocks (rectangles fields 0..3 x
  *     8.. and 4..7 x 8..).  This keeps 2*4*NIN accumulators out of every thread's registers (relay: -36 % time).
+ *   - the same models with a hidden layer in the precision network (p->n_hidden_prec = H >= 1, reference
+ *     precisions.py:63-74; weights = Wh [H][NIN], bh [H], Wp [4][H], bp [4], Wd [4][H], bd [4]): aux receives
+ *     [8 + NIN + 2H][E][B*S] (0..3 / 4..7 the output pre-activation adjoints, 8.. the NIN layer inputs [t, species],
+ *     then the H hidden pre-activation adjoints, then the H hidden activations); the output biases are ADDED into
+ *     g_weights, Wh / Wp / Wd are three rectangles for vihds_gram_blocks and bh the row sums of the hidden adjoints.
+ *     Without aux only g_theta is produced.
  *   aux may be NULL otherwise. */
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, const float* traj,

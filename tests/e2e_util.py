@@ -49,6 +49,9 @@ def build_from_fixture(fx, gpu=None, **param_overrides):
     """Returns (args, settings, data_pair, parameters).  Seeds torch like the reference's Config(args) does."""
     spec = json.loads(str(fx.z["spec_json"]))
     spec["params"]["solver"] = fx.solver
+    hid = "decoder_param/ode_model.precisions.prec_hidden.weight"
+    if hid in fx.z.files and fx.model != "dr_blackbox":  # recorded with --precision_hidden_layers (run_xval.py:38)
+        spec["params"]["n_hidden_decoder_precisions"] = int(fx.z[hid].shape[0])
     spec["params"].update(param_overrides)
     args = make_args(fx.S, seed=fx.cfg["seed"], gpu=gpu)
     np.random.seed(args.seed)

@@ -109,7 +109,7 @@ def to_np(x):
     return np.asarray(x)
 
 
-def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step=False):
+def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step=False, precision_hidden_layers=None):
     """Run one reference forward + cost + backward and record everything at the boundary."""
     import torch
     from vihds.config import Config
@@ -123,6 +123,7 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     parser = create_parser(True)
     args = parser.parse_args(
         ["--train_samples=%d" % n_iwae, "--test_samples=%d" % n_iwae, "--seed=%d" % seed, "specs/%s.yaml" % spec]
+        + (["--precision_hidden_layers=%d" % precision_hidden_layers] if precision_hidden_layers is not None else [])
     )
     settings = Config(args)
     settings.params.solver = solver
@@ -379,6 +380,8 @@ CASES = [
     ("auto_constant_precisions_tiny_modeuler", "auto_constant_precisions", "modeuler", 8, 4, 1),
     ("dr_blackbox_icml_tiny_modeuler", "dr_blackbox_icml", "modeuler", 8, 4, 1),
     ("prpr_constant_tiny_modeuler", "prpr_constant", "modeuler", 8, 4, 1),
+    # NeuralPrecisions with a hidden layer (reference precisions.py:63-74) through the CLI flag --precision_hidden_layers
+    ("dr_constant_precisions_hidden20_tiny_modeuler", "dr_constant_precisions", "modeuler", 8, 4, 1, 20),
 ]
 
 
@@ -403,11 +406,11 @@ def main():
             np.savez_compressed(out, **fx)
             print("wrote %s  steps=%d first=%.4f last=%.4f valid=%s" % (out, len(fx["step_losses"]), fx["step_losses"][0],
                                                                         fx["step_losses"][-1], fx["valid_elbo"]))
-    for name, spec, solver, S, rows, stride in CASES:
+    for name, spec, solver, S, rows, stride, *more in CASES:
         if a.only and a.only not in name:
             continue
         try:
-            fx = run_case(spec, solver, S, rows, 0, stride)
+            fx = run_case(spec, solver, S, rows, 0, stride, precision_hidden_layers=more[0] if more else None)
         except Exception as e:  # a reference defect is recorded, not hidden
             print("FAILED %s: %s: %s" % (name, type(e).__name__, e))
             continue

@@ -19,8 +19,11 @@ def pack_theta(fx, device):
 
 
 def spec_for(fx, row_of, n_rows, solver=None, kernel_variant=0):
+    # hidden units of the precision network, when the fixture was recorded with --precision_hidden_layers
+    key = "decoder_param/ode_model.precisions.prec_hidden.weight"
+    n_hidden_prec = int(fx.z[key].shape[0]) if (key in fx.z.files and fx.model != "dr_blackbox") else 0
     return ops.OdeProblemSpec(fx.model, solver or fx.solver, row_of, n_rows, C=fx.z["inputs"].shape[1],
-                              D=fx.z["dev_1hot"].shape[1], kernel_variant=kernel_variant)
+                              D=fx.z["dev_1hot"].shape[1], kernel_variant=kernel_variant, n_hidden_prec=n_hidden_prec)
 
 
 def view_bsnt(buf):

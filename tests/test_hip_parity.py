@@ -32,7 +32,8 @@ CONST_PREC_FIXTURES = [
 ]
 
 
-NEURAL_PREC_FIXTURES = ["dr_constant_precisions_tiny_modeuler", "auto_constant_precisions_tiny_modeuler"]
+NEURAL_PREC_FIXTURES = ["dr_constant_precisions_tiny_modeuler", "auto_constant_precisions_tiny_modeuler",
+                        "dr_constant_precisions_hidden20_tiny_modeuler"]  # (the last: NeuralPrecisions with a hidden layer)
 
 
 def _flat_prec_weights(fx, requires_grad=False):
@@ -40,7 +41,8 @@ def _flat_prec_weights(fx, requires_grad=False):
     prec_w, _, _ = fx.decoder_weights(DEV)
     if prec_w is None:
         return None
-    w = torch.cat([prec_w[k].reshape(-1) for k in ("prod_w", "prod_b", "degr_w", "degr_b")])
+    order = (("hid_w", "hid_b") if "hid_w" in prec_w else ()) + ("prod_w", "prod_b", "degr_w", "degr_b")
+    w = torch.cat([prec_w[k].reshape(-1) for k in order])
     return w.requires_grad_(requires_grad)
 
 
@@ -106,9 +108,10 @@ def test_elbo_and_theta_gradient_match_reference(name):
     assert rel_err(got[live], fx.t("theta_grad")[live], dim=0) < GTOL
     if wts is not None:  # shared neural-precision weights: gradient reduced over all trajectories in-kernel
         ref = fx.decoder_weight_grads()
-        gref = torch.cat([ref["ode_model.precisions." + k].reshape(-1) for k in
-                          ("prec_production.weight", "prec_production.bias", "prec_degradation.weight",
-                           "prec_degradation.bias")])
+        keys = ("prec_production.weight", "prec_production.bias", "prec_degradation.weight", "prec_degradation.bias")
+        if "ode_model.precisions.prec_hidden.weight" in ref:
+            keys = ("prec_hidden.weight", "prec_hidden.bias") + keys
+        gref = torch.cat([ref["ode_model.precisions." + k].reshape(-1) for k in keys])
         assert rel_err(wts.grad, gref) < GTOL
 
 
@@ -525,8 +528,8 @@ def test_iw_summaries_match_oracle():
 def test_bad_arguments_fail_loudly():
     from vihds import hip, ops
 
-    with pytest.raises(NotImplementedError):
-        ops.OdeProblemSpec("dr_constant", "dopri5", {}, 1, C=2)
+    with pytest.raises(NotImplementedError):  # torchdiffeq's DOP853: the one adaptive solver of the reference's test that is not built
+        ops.OdeProblemSpec("dr_constant", "dopri8", {}, 1, C=2)
     with pytest.raises(KeyError):
         ops.OdeProblemSpec("dr_constant", "rk4", {"r": 0}, 1, C=2)
     with pytest.raises(RuntimeError):

@@ -136,6 +136,7 @@ static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& 
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
   a.solver = p->solver; a.kernel_variant = p->kernel_variant; a.logp_grad_broadcast = p->logp_grad_broadcast; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
+  a.n_hidden_prec = (e->neural_prec && p->model != VIHDS_MODEL_DR_BLACKBOX && p->n_hidden_prec > 0) ? p->n_hidden_prec : 0;
   for (int q = 0; q < ns; ++q) {
     if (p->slot_row[q] < 0 || p->slot_row[q] >= p->n_rows) return fail(VIHDS_E_BADARG, "slot_row out of range");
     a.slot_row[q] = p->slot_row[q];
@@ -181,8 +182,9 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
       return VIHDS_E_UNSUPPORTED;
     return bb_n_weights(p->n_const);
   }
-  if (p->n_hidden_prec > 0) return VIHDS_E_UNSUPPORTED;  // white-box + hidden-layer precisions: no spec uses it
   const int n_in = e->n_states() - 4 + 1;
+  const int H = p->n_hidden_prec;
+  if (H > 0) return H * n_in + H + 2 * (4 * H + 4);  // hidden layer (reference precisions.py:63-74): Wh, bh, Wp, bp, Wd, bd
   return 2 * (4 * n_in + 4);
 }
 
@@ -268,7 +270,8 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!e->neural_prec) return 0;
   // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
   const long long stages = ode_stages(p->solver);
-  return (long long)(8 + e->n_states() - 4 + 1) * (p->T - 1) * stages * p->B * p->S;
+  const long long fields = 8 + e->n_states() - 4 + 1 + (p->n_hidden_prec > 0 ? 2 * p->n_hidden_prec : 0);
+  return fields * (p->T - 1) * stages * p->B * p->S;
 }
 int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
 
@@ -286,8 +289,8 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
         return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
                                          "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
       if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
-    } else if (p->n_hidden_prec > 0) {
-      return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
+    } else if (p->n_hidden_prec > 256) {
+      return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
     }
   }
   OdeArgs a;
@@ -359,8 +362,8 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
         return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
                                          "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
       if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
-    } else if (p->n_hidden_prec > 0) {
-      return fail(VIHDS_E_UNSUPPORTED, "neural precisions with a hidden layer are only implemented for dr_blackbox");
+    } else if (p->n_hidden_prec > 256) {
+      return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
     }
   }
   OdeArgs a;
@@ -368,6 +371,8 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   if (rc) return rc;
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
   a.g_weights = g_weights; a.aux = aux;
+  // (white-box + hidden-layer precisions without aux: the state / theta adjoints only -- the three weight matrices have
+  // no per-thread accumulators, they come from the dump; g_weights then receives nothing)
   if (p->model == VIHDS_MODEL_DR_BLACKBOX && !aux) return fail(VIHDS_E_BADARG, "dr_blackbox backward needs the aux buffer");
   a.traj_in = traj; a.g_traj = g_traj; a.g_xpred = g_xpred; a.g_logp = g_logp; a.g_theta = g_theta;
   rc = e->launch(true, p->solver, a, (hipStream_t)stream);

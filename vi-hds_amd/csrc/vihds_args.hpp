@@ -28,6 +28,7 @@ struct OdeArgs {
   float* g_theta;
   float* aux;            // backward scratch (dr_blackbox: per-evaluation dump for the weight-gradient GEMMs)
   float init_latent, init_prec;
+  int n_hidden_prec;     // white-box models with neural precisions: hidden units of the precision network (0: none)
 };
 
 // Everything the sampling stage needs when it runs inside the decoder-step kernel (vihds_theta_ode_logp_grad):

@@ -34,6 +34,15 @@
 namespace vihds {
 
 // ---- explicit Runge-Kutta tableaux of the five fixed-grid schemes, steps in units of h ----------
+// value types of the step functions: float, or two species side by side
+typedef float v2f __attribute__((ext_vector_type(2)));
+template <class T> __device__ __forceinline__ T splat(float v);
+template <> __device__ __forceinline__ float splat<float>(float v) { return v; }
+template <> __device__ __forceinline__ v2f splat<v2f>(float v) { return v2f{v, v}; }
+__device__ __forceinline__ float fm(float a, float b, float c) { return fmaf(a, b, c); }
+__device__ __forceinline__ v2f fm(v2f a, v2f b, v2f c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ v2f fm(float a, v2f b, v2f c) { return __builtin_elementwise_fma(v2f{a, a}, b, c); }
+
 template <int SOLVER>
 struct Rk {
   static constexpr int NS = SOLVER == VIHDS_SOLVER_EULER ? 1 : (SOLVER == VIHDS_SOLVER_RK4 ? 4 : 2);
@@ -62,53 +71,60 @@ struct Rk {
     return 0.f;
   }
 
+  // The three step functions below are written over a value type T: float, or v2f = two species side by side, which the
+  // compiler turns into packed fp32 instructions (v_pk_fma_f32 / v_pk_add_f32 / v_pk_mul_f32: two lanes' worth of
+  // arithmetic per issue slot) -- the species come in pairs with identical arithmetic, (rfp, W), (luxR, lasR),
+  // (yfp, cfp), and at two wavefronts per SIMD the kernel's time is its instruction count.
   // one step of dy = F_s - a_s y as the affine map y' = A y + B
-  __device__ __forceinline__ static void affine(float h, const float* a_s, const float* F, float& A, float& B) {
-    float kap[NS], rho[NS];
+  template <class T>
+  __device__ __forceinline__ static void affine(float h, const T* a_s, const T* F, T& A, T& B) {
+    T kap[NS], rho[NS];
     VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-      float al = 1.f, be = 0.f;
+      T al = splat<T>(1.f), be = splat<T>(0.f);
       VIHDS_UNROLL for (int r = 0; r < s; ++r)
         if (a(s, r) != 0.f) {
-          al = fmaf(h * a(s, r), kap[r], al);
-          be = fmaf(h * a(s, r), rho[r], be);
+          al = fm(h * a(s, r), kap[r], al);
+          be = fm(h * a(s, r), rho[r], be);
         }
       kap[s] = -a_s[s] * al;
-      rho[s] = fmaf(-a_s[s], be, F[s]);
+      rho[s] = fm(-a_s[s], be, F[s]);
     }
-    A = 1.f;
-    B = 0.f;
+    A = splat<T>(1.f);
+    B = splat<T>(0.f);
     VIHDS_UNROLL for (int s = 0; s < NS; ++s)
       if (b(s) != 0.f) {
-        A = fmaf(h * b(s), kap[s], A);
-        B = fmaf(h * b(s), rho[s], B);
+        A = fm(h * b(s), kap[s], A);
+        B = fm(h * b(s), rho[s], B);
       }
   }
   // the step itself: stage values Y[s], returns y'
-  __device__ __forceinline__ static float real(float h, const float* a_s, const float* F, float y, float* Y) {
-    float k[NS];
+  template <class T>
+  __device__ __forceinline__ static T real(float h, const T* a_s, const T* F, T y, T* Y) {
+    T k[NS];
     VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-      float v = y;
+      T v = y;
       VIHDS_UNROLL for (int r = 0; r < s; ++r)
-        if (a(s, r) != 0.f) v = fmaf(h * a(s, r), k[r], v);
+        if (a(s, r) != 0.f) v = fm(h * a(s, r), k[r], v);
       Y[s] = v;
-      k[s] = fmaf(-a_s[s], v, F[s]);
+      k[s] = fm(-a_s[s], v, F[s]);
     }
-    float o = y;
+    T o = y;
     VIHDS_UNROLL for (int s = 0; s < NS; ++s)
-      if (b(s) != 0.f) o = fmaf(h * b(s), k[s], o);
+      if (b(s) != 0.f) o = fm(h * b(s), k[s], o);
     return o;
   }
   // transposed step: lam1 = adjoint of y', J[s] = adjoints arriving at the stage values from elsewhere;
   // returns the adjoint of y, kbar[s] = adjoints of the stage derivatives.  Linear in (lam1, J).
-  __device__ __forceinline__ static float reverse(float h, const float* a_s, float lam1, const float* J, float* kbar) {
-    float Yb[NS];
-    float lam = lam1;
+  template <class T>
+  __device__ __forceinline__ static T reverse(float h, const T* a_s, T lam1, const T* J, T* kbar) {
+    T Yb[NS];
+    T lam = lam1;
     VIHDS_UNROLL for (int s = NS - 1; s >= 0; --s) {
-      float kb = (h * b(s)) * lam1;
+      T kb = (h * b(s)) * lam1;
       VIHDS_UNROLL for (int r = s + 1; r < NS; ++r)
-        if (a(r, s) != 0.f) kb = fmaf(h * a(r, s), Yb[r], kb);
+        if (a(r, s) != 0.f) kb = fm(h * a(r, s), Yb[r], kb);
       kbar[s] = kb;
-      Yb[s] = fmaf(-a_s[s], kb, J[s]);
+      Yb[s] = fm(-a_s[s], kb, J[s]);
       lam += Yb[s];
     }
     return lam;
@@ -758,27 +774,32 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   y0[RFP] = th(M::SI + 1); y0[YFP] = th(M::SI + 2); y0[CFP] = th(M::SI + 3); y0[WW] = 0.f;
   y0[LUXR] = th(M::SI + 4); y0[LASR] = th(M::SI + 5);
 
+  // species pairs for the packed step functions: (rfp, W), (luxR, lasR), (yfp, cfp)
+  const v2f delta2[3] = {{delta[RFP], delta[WW]}, {delta[LUXR], delta[LASR]}, {delta[YFP], delta[CFP]}};
+  const v2f F12[2] = {{F1[RFP], F1[WW]}, {F1[LUXR], F1[LASR]}};
+  const v2f pe2 = {pe[0], pe[1]}, pc2 = {pc[0], pc[1]}, pcR2 = {pcR[0], pcR[1]}, pcS2 = {pcS[0], pcS[1]};
+  auto rcp2 = [](v2f v) { return v2f{frcp(v.x), frcp(v.y)}; };
   const float xK = Kc * uK[tib];  // x at the last grid point
   VIHDS_SCAN_STOP(3)
 
   // ---- 3. level 1 (rfp, W, luxR, lasR): per-step affine maps composed over this lane's steps, scan over lanes ----------
   float ys[NSP];  // state at this lane's first grid point
   {
-    Aff lm[4];
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) lm[j] = {1.f, 0.f};
+    v2f la[2] = {{1.f, 1.f}, {1.f, 1.f}}, lb[2] = {{0.f, 0.f}, {0.f, 0.f}};  // composed maps of the two pairs
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
       float gam[NS];
       ldv<NS>(VG(m), gam);
-      VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-        float as[NS], Fs[NS];
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; }
-        Aff st;
-        R::affine(it.h, as, Fs, st.a, st.b);
-        if (!it.valid) st = {1.f, 0.f};
-        lm[j] = after(st, lm[j]);
+      VIHDS_UNROLL for (int jp = 0; jp < 2; ++jp) {
+        v2f as[NS], Fs[NS], A, Bb;
+        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta2[jp]; Fs[s] = F12[jp]; }
+        R::affine(it.h, as, Fs, A, Bb);
+        if (!it.valid) { A = v2f{1.f, 1.f}; Bb = v2f{0.f, 0.f}; }
+        lb[jp] = fm(A, lb[jp], Bb);  // st after lm
+        la[jp] = A * la[jp];
       }
     }
+    const Aff lm[4] = {{la[0].x, lb[0].x}, {la[0].y, lb[0].y}, {la[1].x, lb[1].x}, {la[1].y, lb[1].y}};
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       const Aff sc = scan_up32(lm[j], lane);
       const float end = fmaf(sc.a, y0[j], sc.b);
@@ -791,39 +812,39 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   //         affine maps of yfp / cfp ----------------------------------------------------------------------------------
   float yend[NSP];  // state after this lane's last valid step
   {
-    float cur[4];
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) cur[j] = ys[j];
-    Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
+    v2f cur2[2] = {{ys[RFP], ys[WW]}, {ys[LUXR], ys[LASR]}};
+    v2f la = {1.f, 1.f}, lb = {0.f, 0.f};
     VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
       float gam[NS];
       ldv<NS>(VG(m), gam);
-      float YR[NS], YS[NS], dummy[NS];
-      stv<4>(VY(m), cur);
-      VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
-        float as[NS], Fs[NS];
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; }
-        const float nx = R::real(it.h, as, Fs, cur[j], j == LUXR ? YR : (j == LASR ? YS : dummy));
-        cur[j] = it.valid ? nx : cur[j];
+      {
+        const float c4[4] = {cur2[0].x, cur2[0].y, cur2[1].x, cur2[1].y};
+        stv<4>(VY(m), c4);
       }
-      float ab[4];
-      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-        float as[NS], Fs[NS];
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-          const float kb = fmaf(pcS[q], YS[s] * YS[s], pcR[q] * (YR[s] * YR[s]));
-          const float t = kb * frcp(1.f + kb);
-          Fs[s] = pc[q] * fmaf(1.f - pe[q], t, pe[q]);
-          as[s] = gam[s] + delta[YFP + q];
-        }
-        Aff st;
-        R::affine(it.h, as, Fs, st.a, st.b);
-        if (!it.valid) st = {1.f, 0.f};
-        ab[q] = st.a;
-        ab[2 + q] = st.b;
-        lm[q] = after(st, lm[q]);
+      v2f YRS[NS], dummy[NS];  // stage values of (luxR, lasR)
+      VIHDS_UNROLL for (int jp = 0; jp < 2; ++jp) {
+        v2f as[NS], Fs[NS];
+        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta2[jp]; Fs[s] = F12[jp]; }
+        const v2f nx = R::real(it.h, as, Fs, cur2[jp], jp == 1 ? YRS : dummy);
+        cur2[jp] = it.valid ? nx : cur2[jp];
       }
+      v2f as[NS], Fs[NS], A, Bb;
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
+        const v2f kb = fm(pcS2, splat<v2f>(YRS[s].y * YRS[s].y), pcR2 * (YRS[s].x * YRS[s].x));
+        const v2f t = kb * rcp2(1.f + kb);
+        Fs[s] = pc2 * fm(1.f - pe2, t, pe2);
+        as[s] = gam[s] + delta2[2];
+      }
+      R::affine(it.h, as, Fs, A, Bb);
+      if (!it.valid) { A = v2f{1.f, 1.f}; Bb = v2f{0.f, 0.f}; }
+      const float ab[4] = {A.x, A.y, Bb.x, Bb.y};
+      lb = fm(A, lb, Bb);
+      la = A * la;
       stv<4>(VA(m), ab);
     }
+    const Aff lm[2] = {{la.x, lb.x}, {la.y, lb.y}};
+    const float cur[4] = {cur2[0].x, cur2[0].y, cur2[1].x, cur2[1].y};
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) yend[j] = cur[j];
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const Aff sc = scan_up32(lm[q], lane);
@@ -915,6 +936,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       }
       VIHDS_UNROLL for (int q = 0; q < 2; ++q) lam[q] = lane_entry(lm[q]);
     }
+    v2f dz2 = {0.f, 0.f}, sz2 = {0.f, 0.f}, drs2 = {0.f, 0.f}, srs2 = {0.f, 0.f};
+    v2f svt2 = {0.f, 0.f}, svr2 = {0.f, 0.f}, c1b2 = {0.f, 0.f}, c2b2 = {0.f, 0.f};
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
@@ -925,57 +948,69 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       ldv<4>(VY(m), y4);
       ldv<2>(VZ(m), z2);
       ldv<4>(VA(m), ab);
-      // stage values of luxR / lasR again, promoters, stage values of yfp / cfp
-      float YR[NS], YS[NS], aR_[NS], aS_[NS], FR[NS], FS[NS];
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-        aR_[s] = gam[s] + delta[LUXR]; aS_[s] = gam[s] + delta[LASR];
-        FR[s] = F1[LUXR]; FS[s] = F1[LASR];
-      }
-      R::real(it.h, aR_, FR, y4[LUXR], YR);
-      R::real(it.h, aS_, FS, y4[LASR], YS);
-      float JR[NS], JS[NS], gb[NS];
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { JR[s] = 0.f; JS[s] = 0.f; gb[s] = 0.f; }
-      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-        float as[NS], Fs[NS], t[NS], rd[NS], Y[NS], kbar[NS], Jz[NS];
+      // stage values of luxR / lasR again, promoters, stage values of yfp / cfp (pairs: see Rk)
+      v2f YRS[NS], aRS[NS], FRS[NS];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { aRS[s] = gam[s] + delta2[1]; FRS[s] = F12[1]; }
+      R::real(it.h, aRS, FRS, v2f{y4[LUXR], y4[LASR]}, YRS);
+      float gb[NS];
+      v2f JRS[NS];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { JRS[s] = v2f{0.f, 0.f}; gb[s] = 0.f; }
+      {
+        v2f as[NS], Fs[NS], t[NS], rd[NS], Y[NS], kbar[NS], Jz[NS];
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-          const float kb = fmaf(pcS[q], YS[s] * YS[s], pcR[q] * (YR[s] * YR[s]));
-          rd[s] = frcp(1.f + kb);
+          const v2f kb = fm(pcS2, splat<v2f>(YRS[s].y * YRS[s].y), pcR2 * (YRS[s].x * YRS[s].x));
+          rd[s] = rcp2(1.f + kb);
           t[s] = kb * rd[s];
-          Fs[s] = pc[q] * fmaf(1.f - pe[q], t[s], pe[q]);
-          as[s] = gam[s] + delta[YFP + q];
-          Jz[s] = 0.f;
+          Fs[s] = pc2 * fm(1.f - pe2, t[s], pe2);
+          as[s] = gam[s] + delta2[2];
+          Jz[s] = v2f{0.f, 0.f};
         }
-        R::real(it.h, as, Fs, z2[q], Y);
-        const float lin = lam[q] + (last ? gK2[q] : 0.f);  // Lambda_{k+1} (+ terminal injection)
-        R::reverse(it.h, as, it.valid ? lin : 0.f, Jz, kbar);
-        if (it.valid) lam[q] = fmaf(ab[q], lin, ginj(YFP + q, qq, Kc * us[0]));
-        const float cm = pc[q] * (1.f - pe[q]);
+        R::real(it.h, as, Fs, v2f{z2[0], z2[1]}, Y);
+        const v2f lam2 = {lam[0], lam[1]};
+        const v2f lin = lam2 + (last ? v2f{gK2[0], gK2[1]} : v2f{0.f, 0.f});  // Lambda_{k+1} (+ terminal injection)
+        R::reverse(it.h, as, it.valid ? lin : v2f{0.f, 0.f}, Jz, kbar);
+        if (it.valid) {
+          const float xg = Kc * us[0];
+          const v2f nl = fm(v2f{ab[0], ab[1]}, lin, v2f{ginj(YFP, qq, xg), ginj(CFP, qq, xg)});
+          lam[0] = nl.x;
+          lam[1] = nl.y;
+        }
+        const v2f cm = pc2 * (1.f - pe2);
         VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-          const float abar = -Y[s] * kbar[s];
-          gb[s] += abar;
-          degb[YFP + q] += abar;
-          sv[YFP + q] += kbar[s];
-          svt[q] = fmaf(kbar[s], t[s], svt[q]);
-          svr[q] = fmaf(kbar[s], rd[s], svr[q]);
-          const float kbb = (kbar[s] * cm) * (rd[s] * rd[s]);  // d t / d kb = rd^2
-          c1b[q] = fmaf(kbb, YR[s] * YR[s], c1b[q]);
-          c2b[q] = fmaf(kbb, YS[s] * YS[s], c2b[q]);
-          JR[s] = fmaf(kbb * (2.f * pcR[q]), YR[s], JR[s]);
-          JS[s] = fmaf(kbb * (2.f * pcS[q]), YS[s], JS[s]);
+          const v2f abar = -Y[s] * kbar[s];
+          gb[s] += abar.x;
+          gb[s] += abar.y;
+          dz2 += abar;
+          sz2 += kbar[s];
+          svt2 = fm(kbar[s], t[s], svt2);
+          svr2 = fm(kbar[s], rd[s], svr2);
+          const v2f kbb = (kbar[s] * cm) * (rd[s] * rd[s]);  // d t / d kb = rd^2
+          c1b2 = fm(kbb, splat<v2f>(YRS[s].x * YRS[s].x), c1b2);
+          c2b2 = fm(kbb, splat<v2f>(YRS[s].y * YRS[s].y), c2b2);
+          const v2f wR = kbb * (2.f * pcR2), wS = kbb * (2.f * pcS2);
+          JRS[s].x = fmaf(wR.y, YRS[s].x, fmaf(wR.x, YRS[s].x, JRS[s].x));
+          JRS[s].y = fmaf(wS.y, YRS[s].y, fmaf(wS.x, YRS[s].y, JRS[s].y));
         }
       }
       // the part of luxR / lasR's step adjoint that is driven by the stage injections (linear: taken here; the part
       // driven by Lambda_{k+1} follows after their scan)
-      float kv[NS];
-      const float oR = R::reverse(it.h, aR_, 0.f, JR, kv);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float abar = -YR[s] * kv[s]; gb[s] += abar; degb[LUXR] += abar; sv[LUXR] += kv[s]; }
-      const float oS = R::reverse(it.h, aS_, 0.f, JS, kv);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { const float abar = -YS[s] * kv[s]; gb[s] += abar; degb[LASR] += abar; sv[LASR] += kv[s]; }
-      ab[2] = it.valid ? oR : 0.f;  // (the slots of the forward maps' offsets now carry luxR / lasR's injection-driven offsets)
-      ab[3] = it.valid ? oS : 0.f;
+      v2f kv[NS];
+      const v2f oRS = R::reverse(it.h, aRS, v2f{0.f, 0.f}, JRS, kv);
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
+        const v2f abar = -YRS[s] * kv[s];
+        gb[s] += abar.x;
+        drs2 += abar;
+        srs2 += kv[s];
+      }
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) gb[s] += (-YRS[s] * kv[s]).y;
+      ab[2] = it.valid ? oRS.x : 0.f;  // (the slots of the forward maps' offsets now carry luxR / lasR's injection-driven offsets)
+      ab[3] = it.valid ? oRS.y : 0.f;
       stv<4>(VA(m), ab);
       stv<NS>(VB(m), gb);
     }
+    degb[YFP] += dz2.x; degb[CFP] += dz2.y; sv[YFP] += sz2.x; sv[CFP] += sz2.y;
+    degb[LUXR] += drs2.x; degb[LASR] += drs2.y; sv[LUXR] += srs2.x; sv[LASR] += srs2.y;
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) { svt[q] = q ? svt2.y : svt2.x; svr[q] = q ? svr2.y : svr2.x; c1b[q] = q ? c1b2.y : c1b2.x; c2b[q] = q ? c2b2.y : c2b2.x; }
     lam0[YFP] = lam[0];
     lam0[CFP] = lam[1];
   }
@@ -985,27 +1020,29 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   auto level1_pair = [&](auto JA, auto JB) {
     constexpr int jA = decltype(JA)::value, jB = decltype(JB)::value;
     constexpr bool inj = jA == LUXR;  // luxR / lasR carry the offsets left in VA by the level-2 pass
+    constexpr int jp = inj ? 1 : 0;   // the pair's constants (delta2 / F12)
     const float gK[2] = {ginj(jA, qK, xK), ginj(jB, qK, xK)};
     Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
-      float gam[NS], us[NS], qq[4], ab[4], as[NS], Fz[NS], dB;
+      float gam[NS], us[NS], qq[4], ab[4];
       ldv<NS>(VG(m), gam);
       ldv<NS>(VU(m), us);
       ldv<4>(VQ(m), qq);
       ldv<4>(VA(m), ab);
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) Fz[s] = 0.f;
-      float tag[4];
+      v2f as[NS], Fz[NS], A, dB;
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { Fz[s] = v2f{0.f, 0.f}; as[s] = gam[s] + delta2[jp]; }
+      R::affine(it.h, as, Fz, A, dB);
+      float tag[4] = {A.x, A.y, 0.f, 0.f};
       VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
         const int j = q == 0 ? jA : jB;
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) as[s] = gam[s] + delta[j];
-        R::affine(it.h, as, Fz, tag[q], dB);
         tag[2 + q] = ginj(j, qq, Kc * us[0]) + (inj ? ab[2 + q] : 0.f);
         lane_step(lm[q], m, tag[q], tag[2 + q], gK[q]);
       }
       stv<4>(VA(m), tag);
     }
-    float lam[2] = {lane_entry(lm[0]), lane_entry(lm[1])};
+    v2f lam = {lane_entry(lm[0]), lane_entry(lm[1])};
+    v2f d2 = {degb[jA], degb[jB]}, s2 = {sv[jA], sv[jB]};
     VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
@@ -1014,25 +1051,24 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       ldv<4>(VY(m), y4);
       ldv<4>(VA(m), tag);
       ldv<NS>(VB(m), gb);
-      VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-        const int j = q == 0 ? jA : jB;
-        float as[NS], Fs[NS], Y[NS], kbar[NS], Jz[NS];
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta[j]; Fs[s] = F1[j]; Jz[s] = 0.f; }
-        R::real(it.h, as, Fs, y4[j], Y);
-        const float lin = lam[q] + (last ? gK[q] : 0.f);
-        R::reverse(it.h, as, it.valid ? lin : 0.f, Jz, kbar);
-        if (it.valid) lam[q] = fmaf(tag[q], lin, tag[2 + q]);
-        VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
-          const float abar = -Y[s] * kbar[s];
-          degb[j] += abar;
-          sv[j] += kbar[s];
-          gb[s] += abar;
-        }
+      v2f as[NS], Fs[NS], Y[NS], kbar[NS], Jz[NS];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) { as[s] = gam[s] + delta2[jp]; Fs[s] = F12[jp]; Jz[s] = v2f{0.f, 0.f}; }
+      R::real(it.h, as, Fs, v2f{y4[jA], y4[jB]}, Y);
+      const v2f lin = lam + (last ? v2f{gK[0], gK[1]} : v2f{0.f, 0.f});
+      R::reverse(it.h, as, it.valid ? lin : v2f{0.f, 0.f}, Jz, kbar);
+      if (it.valid) lam = fm(v2f{tag[0], tag[1]}, lin, v2f{tag[2], tag[3]});
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) {
+        const v2f abar = -Y[s] * kbar[s];
+        d2 += abar;
+        s2 += kbar[s];
+        gb[s] += abar.x;
       }
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) gb[s] += (-Y[s] * kbar[s]).y;
       stv<NS>(VB(m), gb);
     }
-    lam0[jA] = lam[0];
-    lam0[jB] = lam[1];
+    degb[jA] = d2.x; degb[jB] = d2.y; sv[jA] = s2.x; sv[jB] = s2.y;
+    lam0[jA] = lam.x;
+    lam0[jB] = lam.y;
   };
   level1_pair(std::integral_constant<int, LUXR>{}, std::integral_constant<int, LASR>{});
   level1_pair(std::integral_constant<int, RFP>{}, std::integral_constant<int, WW>{});

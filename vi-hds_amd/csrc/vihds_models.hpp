@@ -886,11 +886,19 @@ struct WithPrec {
   static constexpr int NC = Core::NC;
   static constexpr int OBS = Core::OBS;
   static constexpr int NSLOT = Core::NSLOT + 4;
-  static constexpr int NP = Core::NP;
+  static constexpr int NP = Core::NP + 1;  // + the number of hidden units H (as integer bits; set by the kernels)
   static constexpr int NIN = Core::N + 1;
-  static constexpr int NW = 2 * (4 * NIN + 4);
+  static constexpr int NW = 2 * (4 * NIN + 4);  // weights without a hidden layer (H = 0)
   static constexpr bool NEURAL_PREC = true;
   static constexpr int O_WP = 0, O_BP = 4 * NIN, O_WD = 4 * NIN + 4, O_BD = 8 * NIN + 4;
+  // With a hidden layer (reference precisions.py:63-74; params.n_hidden_decoder_precisions = H >= 1, the reference's
+  // default is 20, config.py:77): weights = Wh [H][NIN], bh [H], Wp [4][H], bp [4], Wd [4][H], bd [4]; the layer input is
+  // [t, species] as it is, the hidden layer tanh(Wh x + bh), shared by production and degradation.
+  __host__ __device__ static int n_weights(int H) { return H < 1 ? NW : H * NIN + H + 2 * (4 * H + 4); }
+  __host__ __device__ static int o_bp(int H) { return H < 1 ? O_BP : H * NIN + H + 4 * H; }
+  __host__ __device__ static int o_bd(int H) { return H < 1 ? O_BD : H * NIN + H + 4 * H + 4 + 4 * H; }
+  __host__ __device__ static int dump_fields(int H) { return 8 + NIN + (H < 1 ? 0 : 2 * H); }
+  __device__ static int hidden_units(const float* p) { return __builtin_amdgcn_readfirstlane(__float_as_int(p[Core::NP])); }
   __host__ static const char* slot_name(int s) {
     static const char* n[] = {"init_prec_x", "init_prec_rfp", "init_prec_yfp", "init_prec_cfp"};
     return s < Core::NSLOT ? Core::slot_name(s) : n[s - Core::NSLOT];
@@ -915,10 +923,33 @@ struct WithPrec {
   // SGPRs (s_load_dwordx16, one FMA operand each) -- no LDS staging and no 104 ds_reads per evaluation.  The buffer
   // is never written by the kernels that read it (gradients go to g_weights / the dump).
   typedef const __attribute__((address_space(4))) float* weights_ptr;
+  // hidden-layer variant: pre-activations of the two output layers, one hidden unit at a time (H is a run-time size)
+  __device__ static void hidden_forward(weights_ptr w, int H, const float* x, float* za, float* zd) {
+    const weights_ptr Wh = w, bh = w + H * NIN, Wp = bh + H, bp = Wp + 4 * H, Wd = bp + 4, bd = Wd + 4 * H;
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) { za[j] = bp[j]; zd[j] = bd[j]; }
+    for (int u = 0; u < H; ++u) {
+      float z = bh[u];
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) z = fmaf(Wh[u * NIN + i], x[i], z);
+      const float hu = ftanh(z);
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+        za[j] = fmaf(Wp[j * H + u], hu, za[j]);
+        zd[j] = fmaf(Wd[j * H + u], hu, zd[j]);
+      }
+    }
+  }
   __device__ static void rhs(float t, const float* y, const float* p, const float* wg, float* dy) {
     const weights_ptr w = (weights_ptr)wg;
     Core::rhs(t, y, p, wg, dy);
     __asm__ volatile("" ::: "memory");  // keep the weight loads inside the time loop (no hoist-and-spill)
+    const int H = hidden_units(p);
+    if (H > 0) {
+      float x[NIN], za[4], zd[4];
+      x[0] = t;
+      VIHDS_UNROLL for (int i = 0; i < NS; ++i) x[i + 1] = y[i];
+      hidden_forward(w, H, x, za, zd);
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) dy[NS + j] = sigmoid_f(za[j]) - sigmoid_f(zd[j]) * y[NS + j];
+      return;
+    }
     float h[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
@@ -936,6 +967,54 @@ struct WithPrec {
     const weights_ptr w = (weights_ptr)wg;
     Core::rhs_vjp(t, y, p, wg, v, yb, pb);
     __asm__ volatile("" ::: "memory");
+    const int H = hidden_units(p);
+    if (H > 0) {
+      // dump fields (Ctx::DUMP): 0..3 zab, 4..7 zdb, 8.. the NIN layer inputs x, then H hidden pre-activation adjoints,
+      // then the H hidden activations; the three weight matrices are rectangles of that dump (vihds_gram_blocks).
+      // Without a dump only the state adjoint is produced (the API refuses weight gradients without aux).
+      const weights_ptr Wh = w, bh = w + H * NIN, Wp = bh + H, Wd = Wp + 4 * H + 4;
+      float x[NIN], xb[NIN], za[4], zd[4], zab[4], zdb[4];
+      x[0] = t;
+      VIHDS_UNROLL for (int i = 0; i < NS; ++i) x[i + 1] = y[i];
+      hidden_forward(w, H, x, za, zd);
+      float* D = nullptr;
+      size_t fs = 0;
+      if constexpr (Ctx::DUMP) {
+        D = ctx.dump + (size_t)ctx.e * ctx.n;
+        fs = ctx.fstride;
+        ctx.e += 1;
+        VIHDS_UNROLL for (int i = 0; i < NIN; ++i) D[(size_t)(8 + i) * fs] = x[i];
+      }
+      VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+        const float a = sigmoid_f(za[j]), d = sigmoid_f(zd[j]);
+        const float vj = v[NS + j];
+        yb[NS + j] -= vj * d;
+        zab[j] = vj * a * (1.f - a);
+        zdb[j] = -vj * y[NS + j] * d * (1.f - d);
+        if constexpr (Ctx::DUMP) {
+          D[(size_t)j * fs] = zab[j];
+          D[(size_t)(4 + j) * fs] = zdb[j];
+          ctx.bsum[j] += zab[j];
+          ctx.bsum[4 + j] += zdb[j];
+        }
+      }
+      VIHDS_UNROLL for (int i = 0; i < NIN; ++i) xb[i] = 0.f;
+      for (int u = 0; u < H; ++u) {
+        float z = bh[u];
+        VIHDS_UNROLL for (int i = 0; i < NIN; ++i) z = fmaf(Wh[u * NIN + i], x[i], z);
+        const float hu = ftanh(z);
+        float hub = 0.f;
+        VIHDS_UNROLL for (int j = 0; j < 4; ++j) hub += Wp[j * H + u] * zab[j] + Wd[j * H + u] * zdb[j];
+        const float zub = hub * (1.f - hu * hu);
+        VIHDS_UNROLL for (int i = 0; i < NIN; ++i) xb[i] = fmaf(Wh[u * NIN + i], zub, xb[i]);
+        if constexpr (Ctx::DUMP) {
+          D[(size_t)(8 + NIN + u) * fs] = zub;
+          D[(size_t)(8 + NIN + H + u) * fs] = hu;
+        }
+      }
+      VIHDS_UNROLL for (int i = 0; i < NS; ++i) yb[i] += xb[i + 1];
+      return;
+    }
     float h[NIN], hb[NIN];
     hidden(t, y, h);
     VIHDS_UNROLL for (int i = 0; i < NIN; ++i) hb[i] = 0.f;

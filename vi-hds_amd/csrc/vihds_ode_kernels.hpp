@@ -315,6 +315,7 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
     M::init_bb(th, a, y);
   } else {
     M::prepare(th, c, p);
+    if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
     M::init(th, c, y);
   }
 
@@ -381,8 +382,12 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP];
   load_theta<M>(a, i, b, th, prec, c);
-  if constexpr (is_blackbox<M>::value) M::prepare_bb(th, a, b, p);
-  else M::prepare(th, c, p);
+  if constexpr (is_blackbox<M>::value) {
+    M::prepare_bb(th, a, b, p);
+  } else {
+    M::prepare(th, c, p);
+    if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
+  }
 
   float lam[N], pb[M::NP], precb[4], glp[4];
   VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] = 0.f;
@@ -456,9 +461,10 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
         VIHDS_UNROLL for (int q = 0; q < 8; ++q) {
           float v = live ? wtsb.bsum[q] : 0.f;
           VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
-          if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[(q < 4 ? M::O_BP + q : M::O_BD + (q - 4))], v);
+          if ((threadIdx.x & 63) == 0)
+            atomicAdd(&a.g_weights[(q < 4 ? M::o_bp(a.n_hidden_prec) + q : M::o_bd(a.n_hidden_prec) + (q - 4))], v);
         }
-      } else {
+      } else if (a.n_hidden_prec < 1) {
         // shared-weight gradient: per-thread register accumulators -> wave shuffle tree -> one atomic per wave
         VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) {
           float v = live ? wtsb.wb[q] : 0.f;
@@ -560,6 +566,7 @@ __global__ void __launch_bounds__(256) ode_trial_kernel(OdeArgs a, const float* 
       M::init_bb(th, a, y);
     } else {
       M::prepare(th, c, p);
+      if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
       M::init(th, c, y);
     }
     const size_t n = a.n;

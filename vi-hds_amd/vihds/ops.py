@@ -395,23 +395,31 @@ def neural_precision_weight_grads(spec, prob, aux, g_w):
     production / degradation pre-activation adjoints (fields 0..3 / 4..7) times the layer inputs (fields 8..) -- written
     into g_w by vihds_gram_blocks; the biases were already added to g_w by the kernel."""
     NIN = spec.n_states - 4 + 1
-    F, n = 8 + NIN, prob.B * prob.S
+    H = max(int(spec.proto.n_hidden_prec), 0)
+    F, n = 8 + NIN + 2 * H, prob.B * prob.S
     C = aux.numel() // F
     key = "prec_rects"
     if key not in spec.cache:
-        rects = (hip.GramRect * 2)()
-        for k, (a0, d0) in enumerate(((0, 0), (4, 4 * NIN + 4))):
+        if H < 1:
+            plan = [(0, 4, 8, NIN, 0, NIN), (4, 4, 8, NIN, 4 * NIN + 4, NIN)]
+        else:  # hidden layer (reference precisions.py:63-74): Wh = hidden adjoints x inputs, Wp / Wd = output adjoints x hidden
+            o_wp = H * NIN + H
+            plan = [(8 + NIN, H, 8, NIN, 0, NIN), (0, 4, 8 + NIN + H, H, o_wp, H), (4, 4, 8 + NIN + H, H, o_wp + 4 * H + 4, H)]
+        rects = (hip.GramRect * len(plan))()
+        for k, (a0, na, b0, nb, d0, sa) in enumerate(plan):
             (rects[k].a0, rects[k].na, rects[k].b0, rects[k].nb, rects[k].dest0, rects[k].dest_stride_a,
-             rects[k].dest_stride_b) = (a0, 4, 8, NIN, d0, NIN, 1)
+             rects[k].dest_stride_b) = (a0, na, b0, nb, d0, sa, 1)
         spec.cache[key] = rects
     rects = spec.cache[key]
-    n_scr = hip.lib().vihds_gram_scratch_floats(C, 2, rects)
+    n_scr = hip.lib().vihds_gram_scratch_floats(C, len(rects), rects)
     if n_scr <= 0:
         raise RuntimeError("vihds_gram_scratch_floats: %s" % hip.lib().vihds_last_error().decode())
     scratch = torch.empty(n_scr, device=aux.device, dtype=torch.float32)
-    rc = hip.lib().vihds_gram_blocks(F, C, 2, rects, hip.ptr(aux), hip.ptr(scratch), hip.ptr(g_w),
+    rc = hip.lib().vihds_gram_blocks(F, C, len(rects), rects, hip.ptr(aux), hip.ptr(scratch), hip.ptr(g_w),
                                      hip.current_stream())
     hip.check(rc, "vihds_gram_blocks")
+    if H >= 1:  # hidden biases: row sums of the hidden pre-activation adjoints
+        g_w[H * NIN: H * NIN + H] = aux.view(F, C)[8 + NIN: 8 + NIN + H].sum(1)
     return g_w
 
 

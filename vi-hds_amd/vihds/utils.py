@@ -66,6 +66,24 @@ class TrainingLogData:
         self.max_val_elbo = -float("inf")
 
 
+def _to_host(tensors):
+    """numpy copies of a list of tensors through one flat buffer (one device->host transfer)."""
+    import torch
+
+    tensors = [t.detach() for t in tensors]
+    if not tensors:
+        return []
+    if not tensors[0].is_cuda or len({t.dtype for t in tensors}) != 1:
+        return [t.cpu().numpy() for t in tensors]
+    flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+    out, o = [], 0
+    for t in tensors:
+        n = t.numel()
+        out.append(flat[o:o + n].reshape(tuple(t.shape)).copy())
+        o += n
+    return out
+
+
 class Results:
     """Evaluation results with the reference's attribute names and on-disk format (vihds/utils.py:65-156).
 
@@ -88,14 +106,13 @@ class Results:
     def init_from_device(self, species_names, q, theta, elbo, summaries):
         self.species_names = species_names
         self.q_names = q.get_tensor_names()
-        self.q_values = np.array([x.detach().cpu().numpy() for x in q.get_tensors()], dtype=object)
-        self.theta = np.array([x.detach().cpu().numpy() for x in theta.get_tensors()])
-        self.elbo = elbo.detach().cpu().numpy()
+        # the reference's Results holds numpy arrays (utils.py:79-99): ONE device->host copy per group of tensors
+        # instead of one (synchronising) copy per distribution parameter and per theta row
+        self.q_values = np.array(_to_host(q.get_tensors()), dtype=object)
+        self.theta = np.array(_to_host(theta.get_tensors()))
         mu, sd, st, var = summaries
-        self.iw_predict_mu = mu.detach().cpu().numpy()
-        self.iw_predict_std = sd.detach().cpu().numpy()
-        self.iw_states = st.detach().cpu().numpy()
-        self.iw_variance = var.detach().cpu().numpy()
+        (self.elbo, self.iw_predict_mu, self.iw_predict_std, self.iw_states,
+         self.iw_variance) = _to_host([elbo, mu, sd, st, var])
 
     def dump(self, location=".vihds_cache"):
         os.makedirs(location, exist_ok=True)
