@@ -1,0 +1,39 @@
+#!/bin/bash
+# usage: bash tests/probe/profile_workloads.sh <tag>
+# The other BASELINE configurations (bench.py --workload ...): bench line + rocprofv3 kernel stats each, and the MFMA-busy
+# counters of the dr_blackbox step.  Output in gpurun_out/<tag>/ (copy what is to be kept to profiles/).
+TAG=$1
+R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O
+cd /tmp && export TMPDIR=/tmp
+for W in config3_train config3_eval config4 config5; do
+  rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -o $W -- python $R/bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline > $O/stats_$W.log 2>&1
+  cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
+  rm -rf $O/stats_$W
+done
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o mfma -- python $R/bench.py --workload config4 --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4 > $O/mfma.log 2>&1
+F=$(find $O/mfma -name "*counter_collection.csv" | head -1)
+head -1 $F > $O/${TAG}_config4_pmc_mfma_counter_collection.csv; grep "vihds" $F >> $O/${TAG}_config4_pmc_mfma_counter_collection.csv
+rm -rf $O/mfma
+cd $R
+python - $O/${TAG}_config4_pmc_mfma_counter_collection.csv profiles/config4_mfma_busy.json <<'PY'
+import csv, json, sys, collections
+busy, act = collections.defaultdict(list), collections.defaultdict(list)
+for r in csv.DictReader(open(sys.argv[1])):
+    k = r["Kernel_Name"].split("(")[0]
+    (busy if r["Counter_Name"] == "SQ_VALU_MFMA_BUSY_CYCLES" else act)[k].append(float(r["Counter_Value"]))
+out = {}
+for k in busy:
+    if k in act and sum(busy[k]) > 0:
+        b, a = sum(busy[k]) / len(busy[k]), sum(act[k]) / len(act[k])
+        # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs share the MFMA-busy cycles
+        out[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": b, "GRBM_GUI_ACTIVE": a, "mfma_busy_frac": b / (a / 8 * 1024), "dispatches": len(busy[k])}
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --workload config4 "
+                   "--steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4; mfma_busy_frac = MFMA-busy cycles / (GUI-active / 8 XCDs "
+                   "x 1024 SIMDs)", "kernels": out}, open(sys.argv[2], "w"), indent=1)
+print(json.dumps(out, indent=1)[:1500])
+PY
+cp profiles/config4_mfma_busy.json $O/
+for W in config3_train config3_eval config4 config5; do
+  python bench.py --workload $W --steps 200 --warmup 20 > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
+  tail -1 $O/${TAG}_${W}_bench.json | cut -c1-160
+done
