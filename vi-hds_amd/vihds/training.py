@@ -295,6 +295,12 @@ class Training:
             torch.cuda.current_stream().wait_stream(s)
             self._restore_training_state(snap)  # the warm-up steps must not count as training steps
             self.optimizer.zero_grad(set_to_none=True)
+            # The parameters' AccumulateGrad nodes were created during the warm-up steps, on the side stream; the capture
+            # runs on the graph's own stream, where every producer and consumer of a gradient is recorded in program
+            # order, so the "stream does not match" warning autograd prints once per capture does not apply.
+            _warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+            if _warn is not None:
+                _warn(False)
             if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
                 g = parallel.SegmentedGraph()
                 loss = g.capture(lambda: self.step(static, zero_grad=False))
