@@ -236,6 +236,7 @@ def run_workload(a, name):
     extra = {}
     if wl == "dr_constant_icml":
         extra["fused_ode_training"] = not a.two_kernel_ode
+        extra["fused_iwae_backward"] = not a.no_fused_iwae
     args, settings, data, parameters, model, training = synthetic.build(
         wl, B, S, solver=solver, device=dev, seed=a.seed, shard=shard, replica=replica, u_rng=a.device_rng,
         conditioner_rng=a.device_rng, hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, **extra)
@@ -392,6 +393,8 @@ def main():
     ap.add_argument("--two-kernel-ode", action="store_true",
                     help="integrate and differentiate with vihds_ode_fwd + vihds_ode_bwd (trajectory through HBM) "
                          "instead of the fused vihds_ode_logp_grad")
+    ap.add_argument("--no-fused-iwae", action="store_true",
+                    help="keep the IWAE loss as its own launch instead of forming it inside the theta-adjoint launch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -434,7 +437,8 @@ def main():
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", B_ROWS, n_iwae_model, solver=a.solver, device=dev, seed=a.seed, shard=shard, replica=replica,
         u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
-        hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, fused_ode_training=not a.two_kernel_ode)
+        hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, fused_ode_training=not a.two_kernel_ode,
+        fused_iwae_backward=not a.no_fused_iwae)
     model.train()
     batch = training.train_data
     step = training.graph_step if use_graph else training.step

@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 3
+#define VIHDS_ABI_VERSION 4
 
 /* error codes */
 #define VIHDS_OK 0
@@ -175,6 +175,23 @@ int vihds_blackbox_dump_fields(void);
  *                                  (distributions.py:332-336,377-381); ignored for Constant
  *   u      [B][S][P]               reference layout (vihds/vae.py:22-24)
  *   theta  [n_rows>=P][B][S] rows 0..P-1 written;  log_q, log_p [B][S] */
+/* IWAE loss folded into vihds_theta_bwd (training.py:135-149 + the backward of everything up to q): with opts->iwae set,
+ * every block forms its data row's importance weights itself -- log_w = sum_j logp[j] + log_p - log_q, row max and
+ * sum-exp, lse -- and uses d loss / d log_w = -softmax / B as the factor of g_theta and as the log q / log p upstream
+ * gradients (g_log_q, g_log_p and opts->g_theta_scale are then ignored); the blocks of parameter chunk 0 write log_w
+ * and lse, and the last of them -ELBO = -mean_b(lse - log n_iwae_total) to loss.  One launch fewer per training step:
+ * the separate vihds_iwae_loss_fwd is not needed when nothing else consumes its outputs before the backward. */
+typedef struct vihds_iwae_job {
+  const float* logp;   /* [4][B][S] */
+  const float* log_p;  /* [B][S] or NULL */
+  const float* log_q;  /* [B][S] or NULL */
+  int n_iwae_total;
+  float* log_w;        /* [B][S] */
+  float* lse;          /* [B] */
+  float* loss;         /* [1] */
+  unsigned int* ticket; /* one device word, zero before the first call, left at zero */
+} vihds_iwae_job;
+
 typedef struct vihds_theta_opts {
   /* Where q's parameters live.  NULL: parameter p is row p of q_mu and row p of q_prec.  Else [2P]: entries 0..P-1
    * are the rows of q_mu holding mu_p, entries P..2P-1 the rows of q_prec holding prec_p (the encoder's level-blocked
@@ -194,6 +211,8 @@ typedef struct vihds_theta_opts {
   /* vihds_theta_bwd only: [B][S] factor applied to g_theta (g_theta[p][b][s] * g_theta_scale[b][s]) -- lets the
    * unit-weight gradient of vihds_ode_logp_grad be consumed without a separate scaling pass. */
   const float* g_theta_scale;
+  /* vihds_theta_bwd only: NULL, or the IWAE loss to evaluate inside the launch (see vihds_iwae_job). */
+  const vihds_iwae_job* iwae;
 } vihds_theta_opts;
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec,
                     const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi,

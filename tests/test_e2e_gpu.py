@@ -294,6 +294,41 @@ def test_fused_training_path_matches_two_kernel_path(decoder_step):
         assert rel_err(outs[True][1][k], g) < 1e-5, k
 
 
+@pytest.mark.parametrize("seed_kind", ["unit", "ones"])
+def test_iwae_loss_inside_the_theta_adjoint_matches_separate_launch(seed_kind):
+    """params.fused_iwae_backward: Training.cost launches nothing for the loss; the decoder step's backward forms the
+    importance weights, the loss value, log_w and lse inside the theta-adjoint launch (vihds_iwae_job).  With the unit
+    seed Training.step uses, loss and every encoder gradient must equal the separate-launch path; a backward seeded any
+    other way falls back to the ordinary IWAE launch and must give the same numbers too."""
+    import e2e_util as E
+    from vihds import ops
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    outs = {}
+    for fused_iwae in (False, True):
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, fused_ode_training=True, fused_decoder_step=True,
+                                                               fused_iwae_backward=fused_iwae)
+        model = build_model(args, settings, data, parameters)
+        training = Training(args, settings, data, parameters, model)
+        model.train()
+        batch = E.batch_from_fixture(fx, "cuda:0")
+        np.random.seed(fx.cfg["seed"] + 1)
+        torch.manual_seed(fx.cfg["seed"] + 1)
+        batch_results, theta, q, p = model(batch, fx.S)
+        elbo = training.cost(batch, batch_results, theta, q, p).elbo
+        if fused_iwae:
+            assert len(ops._PENDING_IWAE) == 1  # nothing launched for the loss yet
+        elbo.backward(ops.unit_gradient(elbo.device) if seed_kind == "unit" else torch.ones_like(elbo))
+        assert not ops._PENDING_IWAE
+        outs[fused_iwae] = (float(elbo), {k: v.grad.clone() for k, v in model.named_parameters() if v.grad is not None})
+    assert abs(outs[True][0] - outs[False][0]) <= 1e-6 * abs(outs[False][0])
+    assert abs(outs[True][0] - float(fx.t("loss"))) <= 1e-4 * abs(float(fx.t("loss")))
+    for k, g in outs[False][1].items():
+        assert rel_err(outs[True][1][k], g) < 1e-5, k
+
+
 def test_two_replicas_row_data_parallel_plumbing():
     """--shard rows: every rank runs the whole step on its own rows and the gradients are averaged (one all-reduce, the
     1/world factor applied inside the Adam kernel).  With both replicas fed the SAME rows and draws the averaged step

@@ -189,7 +189,7 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
 }
 
 static vihds_theta_opts theta_opts(const vihds_theta_opts* o) {
-  vihds_theta_opts d = {nullptr, 0, nullptr, 0, 0, nullptr};
+  vihds_theta_opts d = {nullptr, 0, nullptr, 0, 0, nullptr, nullptr};
   return o ? *o : d;
 }
 
@@ -401,6 +401,12 @@ int vihds_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, con
   if (P <= 0 || B <= 0 || S <= 0) return fail(VIHDS_E_BADARG, "P, B, S must be > 0");
   if (!kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !g_q_mu || !g_q_prec)
     return fail(VIHDS_E_BADARG, "null argument");
+  if (opts && opts->iwae) {
+    const vihds_iwae_job* j = opts->iwae;
+    if (!j->logp || !j->log_w || !j->lse || !j->loss || !j->ticket || j->n_iwae_total <= 0)
+      return fail(VIHDS_E_BADARG, "vihds_iwae_job: null buffer or n_iwae_total <= 0");
+    if ((size_t)S * sizeof(float) > 60 * 1024) return fail(VIHDS_E_UNSUPPORTED, "vihds_iwae_job: S too large for the row buffer");
+  }
   launch_theta_bwd(P, B, S, kind, q_mu, q_prec, p_mu, p_prec, clip_lo, clip_hi, u, g_theta, g_log_q, g_log_p, g_q_mu,
                    g_q_prec, theta_opts(opts), (hipStream_t)stream);
   return check_hip("vihds_theta_bwd launch");

@@ -259,12 +259,55 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
                  const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, const float* __restrict__ u,
                  const float* __restrict__ g_theta, const float* __restrict__ g_theta_scale,
                  const float* __restrict__ g_log_q, const float* __restrict__ g_log_p, float* __restrict__ g_q_mu,
-                 float* __restrict__ g_q_prec) {
+                 float* __restrict__ g_q_prec, vihds_iwae_job iw) {
   static_assert(BLOCK == 64 * THETA_BWD_PCHUNK, "one wave per parameter of the chunk");
+  extern __shared__ float wsm[];  // [S] with an IWAE job: d loss / d log_w of this row
+  __shared__ float sm[BLOCK / 64];
+  __shared__ int is_last;
   const int n = B * S;
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int p = blockIdx.y * THETA_BWD_PCHUNK + wid;
+  const bool iwae = iw.logp != nullptr;
+  if (iwae) {
+    // the arithmetic of iwae_loss_rows_kernel, once per block (every chunk of the row repeats it: S terms)
+    float m = -INFINITY;
+    for (int s = threadIdx.x; s < S; s += BLOCK) {
+      const int i = b * S + s;
+      float v = ((iw.logp[i] + iw.logp[n + i]) + iw.logp[2 * n + i]) + iw.logp[3 * n + i];
+      v = v + (iw.log_p ? iw.log_p[i] : 0.f) - (iw.log_q ? iw.log_q[i] : 0.f);
+      wsm[s] = v;
+      if (blockIdx.y == 0) iw.log_w[i] = v;
+      m = fmaxf(m, v);
+    }
+    m = block_max<BLOCK>(m, sm);
+    float se = 0.f;
+    for (int s = threadIdx.x; s < S; s += BLOCK) se += expf(wsm[s] - m);
+    se = block_sum<BLOCK>(se, sm);
+    const float l = m + logf(se);
+    for (int s = threadIdx.x; s < S; s += BLOCK) wsm[s] = -(1.f / (float)B) * expf(wsm[s] - l);
+    if (blockIdx.y == 0) {
+      if (threadIdx.x == 0) {
+        iw.lse[b] = l;
+        __threadfence();
+        is_last = atomicAdd(iw.ticket, 1u) == gridDim.x - 1;
+      }
+      __syncthreads();
+      if (is_last) {  // every row's lse is visible: -ELBO, rows added in a fixed order
+        __threadfence();
+        const float log_n = logf((float)iw.n_iwae_total);
+        float acc = 0.f;
+        for (int r = threadIdx.x; r < B; r += BLOCK)
+          acc += __hip_atomic_load(&iw.lse[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - log_n;
+        acc = block_sum<BLOCK>(acc, sm);
+        if (threadIdx.x == 0) {
+          iw.loss[0] = -acc / (float)B;
+          *iw.ticket = 0u;
+        }
+      }
+    }
+    __syncthreads();
+  }
   if (p >= P) return;
   const int kd = kind[p];
   const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
@@ -286,10 +329,12 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
     const float xr = (kd == KIND_LOGNORMAL) ? expf(z) : z;
     const float x = xr < lo ? lo : (xr > hi ? hi : xr);
     const float pass = (xr >= lo && xr <= hi) ? 1.f : 0.f;
-    const float glq = g_log_q ? g_log_q[i] : 0.f;
-    const float glp = g_log_p ? g_log_p[i] : 0.f;
+    const float gw = iwae ? wsm[s] : 0.f;  // d loss / d log_w
+    const float glq = iwae ? (iw.log_q ? -gw : 0.f) : (g_log_q ? g_log_q[i] : 0.f);
+    const float glp = iwae ? (iw.log_p ? gw : 0.f) : (g_log_p ? g_log_p[i] : 0.f);
     float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
-    if (g_theta_scale) gx *= g_theta_scale[i];
+    if (iwae) gx *= gw;
+    else if (g_theta_scale) gx *= g_theta_scale[i];
     float v, dv_dx;
     if (kd == KIND_LOGNORMAL) { v = logf(x + 1e-12f); dv_dx = 1.f / (x + 1e-12f); }
     else { v = x; dv_dx = 1.f; }
@@ -657,9 +702,12 @@ void launch_theta_bwd(int P, int B, int S, const int* kind, const float* q_mu, c
                       const float* p_prec, const float* lo, const float* hi, const float* u, const float* g_theta,
                       const float* g_log_q, const float* g_log_p, float* g_q_mu, float* g_q_prec,
                       const vihds_theta_opts& o, hipStream_t st) {
-  hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B, (P + THETA_BWD_PCHUNK - 1) / THETA_BWD_PCHUNK), dim3(256), 0, st,
+  vihds_iwae_job iw = {};
+  if (o.iwae) iw = *o.iwae;
+  const size_t lds = o.iwae ? (size_t)S * sizeof(float) : 0;
+  hipLaunchKernelGGL((theta_bwd_kernel<256>), dim3(B, (P + THETA_BWD_PCHUNK - 1) / THETA_BWD_PCHUNK), dim3(256), lds, st,
                      P, B, S, kind, q_mu, q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, g_theta,
-                     o.g_theta_scale, g_log_q, g_log_p, g_q_mu, g_q_prec);
+                     o.g_theta_scale, g_log_q, g_log_p, g_q_mu, g_q_prec, iw);
 }
 void launch_iwae_fwd(int B, int S, const float* logp, const float* log_p, const float* log_q, float* log_w,
                      float* row_max, float* row_sumexp, hipStream_t st) {

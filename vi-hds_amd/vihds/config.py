@@ -30,6 +30,7 @@ PARAM_DEFAULTS = {
     "fused_ode_training": False,  # training: log-likelihood + unit-weight adjoint in one launch, no trajectory written
                                # (dr_constant family, lane-split regime; x_states / x_predict then exist on demand only)
     "fused_decoder_step": True,   # with fused_ode_training: sampling + device conditioning + ODE + adjoint in ONE launch
+    "fused_iwae_backward": False,  # with the two above: the IWAE loss is formed inside the theta-adjoint launch (its value exists after backward())
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
 }

@@ -64,11 +64,20 @@ _LIB = None
 _P = ctypes.c_void_p
 _I = ctypes.c_int
 
+class IwaeJob(ctypes.Structure):
+    """struct vihds_iwae_job (include/vihds_hip.h): the IWAE loss evaluated inside vihds_theta_bwd"""
+
+    _fields_ = [("logp", ctypes.c_void_p), ("log_p", ctypes.c_void_p), ("log_q", ctypes.c_void_p),
+                ("n_iwae_total", ctypes.c_int), ("log_w", ctypes.c_void_p), ("lse", ctypes.c_void_p),
+                ("loss", ctypes.c_void_p), ("ticket", ctypes.c_void_p)]
+
+
 class ThetaOpts(ctypes.Structure):
     """struct vihds_theta_opts (include/vihds_hip.h)"""
 
     _fields_ = [("q_rows", ctypes.c_void_p), ("q_prec_is_log", ctypes.c_int), ("rng", ctypes.c_void_p),
-                ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int), ("g_theta_scale", ctypes.c_void_p)]
+                ("S_total", ctypes.c_int), ("s_offset", ctypes.c_int), ("g_theta_scale", ctypes.c_void_p),
+                ("iwae", ctypes.POINTER(IwaeJob))]
 
 
 class Conditioner(ctypes.Structure):
@@ -162,7 +171,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 3:
+        if handle.vihds_abi_version() != 4:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

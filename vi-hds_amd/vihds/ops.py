@@ -364,8 +364,24 @@ class DecoderStepFused(torch.autograd.Function):
         P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
         opts = hip.ThetaOpts()
         opts.q_rows, opts.q_prec_is_log = hip.ptr(q_rows), 1
-        keep = None
-        if g_logp is None:
+        keep = job = ijob = None
+        if g_logp is not None and g_logp.dim() == 3 and g_logp.stride(0) == 0:
+            job = _PENDING_IWAE.pop(g_logp[0].data_ptr(), None)  # a deferred IwaeLoss node upstream (fused_iwae_backward)
+        if (job is not None and g_theta is None and (g_log_p is None or g_log_p.data_ptr() == job["ug"].data_ptr())
+                and (g_log_q is None or (job["ugn"] is not None and g_log_q.data_ptr() == job["ugn"].data_ptr()))):
+            # the loss and its importance weights are formed inside the theta-adjoint launch: no IWAE launch this step
+            ijob = hip.IwaeJob()
+            ijob.logp, ijob.log_p, ijob.log_q = hip.ptr(job["logp"]), hip.ptr(job["log_p"]), hip.ptr(job["log_q"])
+            ijob.n_iwae_total = job["n_total"]
+            ijob.log_w, ijob.lse, ijob.loss = hip.ptr(job["log_w"]), hip.ptr(job["rows"][2]), hip.ptr(job["loss"])
+            ijob.ticket = hip.ptr(job["ticket"])
+            opts.iwae = ctypes.pointer(ijob)
+            g_th, g_log_q, g_log_p = g_unit, None, None
+        elif job is not None:
+            _run_iwae_job(job)  # some other combination of upstream gradients: the ordinary launch, then as usual
+        if ijob is not None:
+            pass
+        elif g_logp is None:
             g_th = _c(g_theta)
         elif g_logp.dim() == 3 and g_logp.stride(0) == 0 and g_theta is None:
             keep = _c(g_logp[0])
@@ -785,7 +801,7 @@ class IwaeLoss(torch.autograd.Function):
     unit_gradient() launches nothing here."""
 
     @staticmethod
-    def forward(ctx, logp, log_p, log_q, n_total):
+    def forward(ctx, logp, log_p, log_q, n_total, defer=False):
         _require_cuda(logp, log_p, log_q)
         logp, log_p, log_q = _c(logp), _c(log_p), _c(log_q)
         _, B, S = logp.shape
@@ -798,6 +814,23 @@ class IwaeLoss(torch.autograd.Function):
         if any(ctx.needs_input_grad) and hip.lib().vihds_iwae_loss_unit_grad(B, S, 1):
             ug = torch.empty((B, S), device=dev, dtype=torch.float32)
             ugn = torch.empty((B, S), device=dev, dtype=torch.float32) if log_q is not None else None
+        ctx.deferred = None
+        if defer and ug is not None and S * 4 <= 60 * 1024:
+            # params.fused_iwae_backward: nothing is launched here.  The decoder step's backward (DecoderStepFused), which
+            # is the only consumer of this node's gradients, evaluates the loss inside its theta-adjoint launch
+            # (vihds_iwae_job) and fills `loss`, `log_w`, `lse`; the job waits in _PENDING_IWAE under the address of the
+            # (still unwritten) unit-gradient buffer this node's backward hands down.  A backward that is not seeded with
+            # the unit gradient, or a consumer that cannot take the job, runs the ordinary kernel instead (_run_iwae_job).
+            job = {"logp": logp, "log_p": log_p, "log_q": log_q, "n_total": int(n_total), "log_w": log_w, "rows": rows,
+                   "loss": loss, "ug": ug, "ugn": ugn, "ticket": ticket}
+            ctx.deferred = job
+            _PENDING_IWAE[ug.data_ptr()] = job
+            lse = rows[2]
+            ctx.save_for_backward(log_w, lse, ug, ugn)
+            ctx.has = (log_p is not None, log_q is not None)
+            ctx.mark_non_differentiable(log_w, lse)
+            ctx.set_materialize_grads(False)
+            return loss, log_w, lse
         rc = hip.lib().vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q),
                                            hip.ptr(log_w), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
                                            hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.ptr(ticket),
@@ -813,18 +846,34 @@ class IwaeLoss(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):
         if g_loss is None:
-            return None, None, None, None
+            return None, None, None, None, None
         log_w, lse, ug, ugn = ctx.saved_tensors
         B, S = log_w.shape
         unit = _UNIT.get(str(log_w.device))
         if ug is not None and unit is not None and g_loss.data_ptr() == unit.data_ptr():
-            return ug.unsqueeze(0).expand(4, -1, -1), ug if ctx.has[0] else None, ugn, None
+            return ug.unsqueeze(0).expand(4, -1, -1), ug if ctx.has[0] else None, ugn, None, None
+        if getattr(ctx, "deferred", None) is not None and _PENDING_IWAE.pop(ug.data_ptr(), None) is not None:
+            _run_iwae_job(ctx.deferred)  # general upstream gradient: the forward's kernel after all
         g_logw = torch.empty_like(log_w)
         g_neg = torch.empty_like(log_w) if ctx.has[1] else None
         rc = hip.lib().vihds_iwae_loss_bwd(B, S, hip.ptr(log_w), hip.ptr(lse), hip.ptr(_c(g_loss)), hip.ptr(g_logw),
                                            hip.ptr(g_neg), hip.current_stream())
         hip.check(rc, "vihds_iwae_loss_bwd")
-        return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None
+        return g_logw.unsqueeze(0).expand(4, -1, -1), g_logw if ctx.has[0] else None, g_neg, None, None
+
+
+_PENDING_IWAE = {}  # address of a deferred IwaeLoss node's unit-gradient buffer -> its job (see IwaeLoss.forward)
+
+
+def _run_iwae_job(job):
+    """The ordinary IWAE launch for a deferred job (fills loss, log_w, lse and the unit-gradient buffers)."""
+    logp, rows = job["logp"], job["rows"]
+    _, B, S = logp.shape
+    rc = hip.lib().vihds_iwae_loss_fwd(B, S, job["n_total"], hip.ptr(logp), hip.ptr(job["log_p"]), hip.ptr(job["log_q"]),
+                                       hip.ptr(job["log_w"]), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
+                                       hip.ptr(job["loss"]), hip.ptr(job["ug"]), hip.ptr(job["ugn"]),
+                                       hip.ptr(job["ticket"]), hip.current_stream())
+    hip.check(rc, "vihds_iwae_loss_fwd")
 
 
 class IwaeLossSharded(torch.autograd.Function):
@@ -868,7 +917,7 @@ class IwaeLossSharded(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_loss, _g1, _g2):  # vihds_iwae_loss_bwd with the global lse, or the unit-gradient buffers
-        return IwaeLoss.backward(ctx, g_loss, _g1, _g2) + (None,)
+        return IwaeLoss.backward(ctx, g_loss, _g1, _g2)
 
 
 def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng_state=None, sample_window=None):
@@ -887,11 +936,11 @@ def device_condition(z, dev_1hot, relevance, is_default, out, w_mean, w_std, rng
     return out
 
 
-def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None):
-    """-ELBO exactly as Training.cost forms it (vihds/training.py:144-149)."""
+def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None, defer=False):
+    """-ELBO exactly as Training.cost forms it (vihds/training.py:144-149).  defer: see IwaeLoss.forward."""
     if group is None:
         S = n_iwae_total if n_iwae_total is not None else logp.shape[2]
-        return IwaeLoss.apply(logp, log_p, log_q, S)
+        return IwaeLoss.apply(logp, log_p, log_q, S, defer)
     S = n_iwae_total if n_iwae_total is not None else logp.shape[2]
     return IwaeLossSharded.apply(logp, log_p, log_q, S, group)
 

@@ -132,8 +132,12 @@ class Training:
         n_local = logp.shape[2]
         n_iwae = n_local * (self.shard.world if self.shard is not None else 1)
         group = (self.shard.group or torch.distributed.group.WORLD) if self.shard is not None else None
+        # (fused decoder step + params.fused_iwae_backward: the loss is evaluated inside the step's theta-adjoint launch,
+        # i.e. `iwae_cost` holds its value once backward() has run -- Training.step returns it after that)
+        defer = (not full_output and group is None and torch.is_grad_enabled()
+                 and getattr(getattr(batch_results, "solution", None), "defer_iwae", False))
         iwae_cost, log_unnormalized_iws, lse = ops.iwae_loss(logp, log_p_theta, log_q_theta, n_iwae_total=n_iwae,
-                                                             group=group)
+                                                             group=group, defer=defer)
         if not full_output:
             return attrify({"elbo": iwae_cost})
         elbo = -iwae_cost

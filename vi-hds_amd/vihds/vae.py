@@ -111,6 +111,8 @@ def _bind_fused(BaseVAE):
         if hasattr(ode, "aR") and extra:
             ode.aR, ode.aS = getattr(theta, "aR", None), getattr(theta, "aS", None)
         sol = LazySolution(logp, lambda: ode.solve(cfg, data.times, theta, data.inputs, data.dev_1hot, obs))
+        # params.fused_iwae_backward: Training.cost may leave the IWAE loss to this step's theta-adjoint launch
+        sol.defer_iwae = bool(default_get_value(cfg.params, "fused_iwae_backward", False)) and self.shard is None
         ode._last = sol
 
         def build():
