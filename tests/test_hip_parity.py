@@ -1229,6 +1229,55 @@ def test_time_parallel_training_kernel_matches_forward_plus_adjoint(model, solve
                                  obs.data_ptr(), lp.data_ptr(), g3.data_ptr(), st) == hip.E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("B,S", [(36, 1000), (234, 1000)])
+def test_time_parallel_training_kernel_at_the_config3_sizes(B, S):
+    """BASELINE config 3's shapes (36 000 and 234 000 trajectories, T = 86, rk4) through the time-parallel training kernel:
+    against the thread-per-trajectory forward + adjoint pair (pinned by the reference fixtures), and two size-independent
+    properties -- a sub-batch of rows gives bit-identical results (no trajectory depends on its block's neighbours), and
+    the softmax-weighted gradient of a row sums like its parts."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    model, solver, T = "dr_constant", "rk4", 86
+    slots = hip.model_slots(model)
+    row_of = {n: i for i, n in enumerate(slots)}
+    st = torch.cuda.current_stream().cuda_stream
+    th = _synthetic_theta(slots, B, S, 21)
+    theta = torch.stack([th[n] for n in slots]).to(DEV)
+    g = torch.Generator().manual_seed(8)
+    cond = torch.log1p(torch.rand(B, 2, generator=g) * 1000.0).to(DEV)
+    times = (torch.arange(T, dtype=torch.float32) * 0.1933).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+
+    def run(variant, theta, cond, obs, fused):
+        b = theta.shape[1]
+        prob = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=variant).bind(b, S, T)
+        prob.logp_grad_broadcast = 1
+        logp = torch.empty(4, b, S, device=DEV)
+        gth = torch.empty_like(theta)
+        args = (theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(), obs.data_ptr())
+        if fused:
+            assert L.vihds_ode_logp_grad(ctypes.byref(prob), *args, logp.data_ptr(), gth.data_ptr(), st) == 0, L.vihds_last_error()
+        else:
+            traj = torch.empty(T, 8, b, S, device=DEV)
+            ones = torch.ones(b, S, device=DEV)
+            assert L.vihds_ode_fwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, logp.data_ptr(), st) == 0
+            assert L.vihds_ode_bwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, None, ones.data_ptr(),
+                                   gth.data_ptr(), None, None, st) == 0
+        torch.cuda.synchronize()
+        return logp, gth
+
+    lp3, g3 = run(3, theta, cond, obs, True)
+    lp1, g1 = run(1, theta, cond, obs, False)
+    assert torch.isfinite(lp3).all() and torch.isfinite(g3).all()
+    assert rel_err(lp3, lp1, dim=0) < 1e-5
+    assert rel_err(g3, g1, dim=0) < 2e-4
+    rows = slice(3, 10)
+    lps, gs = run(3, theta[:, rows].contiguous(), cond[rows].contiguous(), obs[rows].contiguous(), True)
+    assert torch.equal(lps, lp3[:, rows]) and torch.equal(gs, g3[:, rows])
+
+
 # ---- adaptive solvers (torchdiffeq's dopri5 / bosh3 / adaptive_heun; reference vihds/ode.py:79-81) ---------------------
 ADAPTIVE = ["dopri5", "bosh3", "adaptive_heun"]
 
