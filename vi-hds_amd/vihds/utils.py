@@ -66,22 +66,52 @@ class TrainingLogData:
         self.max_val_elbo = -float("inf")
 
 
-def _to_host(tensors):
-    """numpy copies of a list of tensors through one flat buffer (one device->host transfer)."""
+_PINNED = {}
+
+
+def _pinned(n, dtype):
+    """A reusable pinned staging buffer of at least n elements (pageable device->host copies run at a third of the rate)."""
+    import torch
+
+    key = str(dtype)
+    buf = _PINNED.get(key)
+    if buf is None or buf.numel() < n:
+        buf = torch.empty(max(n, 1), dtype=dtype, pin_memory=True)
+        _PINNED[key] = buf
+    return buf[:n]
+
+
+def _to_host(tensors, stack=False):
+    """numpy copies of a list of tensors through ONE device->host transfer (pinned staging).  stack: the tensors have one
+    shape and the result is a single [len, *shape] array (rows of one device buffer are copied as one block, not gathered)."""
     import torch
 
     tensors = [t.detach() for t in tensors]
     if not tensors:
-        return []
+        return np.zeros((0,)) if stack else []
     if not tensors[0].is_cuda or len({t.dtype for t in tensors}) != 1:
-        return [t.cpu().numpy() for t in tensors]
-    flat = torch.cat([t.reshape(-1) for t in tensors]).cpu().numpy()
+        out = [t.cpu().numpy() for t in tensors]
+        return np.array(out) if stack else out
+    t0 = tensors[0]
+    step = t0.numel() * t0.element_size()
+    contiguous_rows = (stack and all(t.shape == t0.shape and t.is_contiguous() for t in tensors)
+                       and all(t.data_ptr() == t0.data_ptr() + k * step for k, t in enumerate(tensors)))
+    if contiguous_rows:  # e.g. theta: consecutive rows of the packed [R,B,S] buffer
+        src = torch.as_strided(t0, (len(tensors) * t0.numel(),), (1,))
+    else:
+        src = torch.cat([t.reshape(-1) for t in tensors])
+    host = _pinned(src.numel(), src.dtype)
+    host.copy_(src, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    flat = host.numpy().copy()  # (the staging buffer is reused by the next call)
+    if stack and all(t.shape == t0.shape for t in tensors):
+        return flat.reshape((len(tensors),) + tuple(t0.shape))
     out, o = [], 0
     for t in tensors:
         n = t.numel()
-        out.append(flat[o:o + n].reshape(tuple(t.shape)).copy())
+        out.append(flat[o:o + n].reshape(tuple(t.shape)))
         o += n
-    return out
+    return np.array(out) if stack else out
 
 
 class Results:
@@ -109,7 +139,7 @@ class Results:
         # the reference's Results holds numpy arrays (utils.py:79-99): ONE device->host copy per group of tensors
         # instead of one (synchronising) copy per distribution parameter and per theta row
         self.q_values = np.array(_to_host(q.get_tensors()), dtype=object)
-        self.theta = np.array(_to_host(theta.get_tensors()))
+        self.theta = _to_host(theta.get_tensors(), stack=True)
         mu, sd, st, var = summaries
         (self.elbo, self.iw_predict_mu, self.iw_predict_std, self.iw_states,
          self.iw_variance) = _to_host([elbo, mu, sd, st, var])
