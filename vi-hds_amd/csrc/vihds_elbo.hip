@@ -269,6 +269,28 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int p = blockIdx.y * THETA_BWD_PCHUNK + wid;
   const bool iwae = iw.logp != nullptr;
+  // this wavefront's parameter: its constants and the first four rounds of its per-sample inputs are requested before
+  // the row's importance weights are formed (with an IWAE job that prologue is three block reductions long)
+  const bool has_p = p < P;
+  const int kd = has_p ? kind[p] : KIND_CONSTANT;
+  const int rm = has_p ? (q_rows ? q_rows[p] : p) : 0, rp = has_p ? (q_rows ? q_rows[P + p] : p) : 0;
+  const bool live_p = has_p && kd != KIND_CONSTANT;
+  float uu_pre[4] = {0.f, 0.f, 0.f, 0.f}, gx_pre[4] = {0.f, 0.f, 0.f, 0.f};
+  float mu = 0.f, prec_raw = 0.f, pm = 0.f, pp = 1.f, lo = 0.f, hi = 0.f;
+  if (live_p) {
+    mu = q_mu[rm * B + b];
+    prec_raw = q_prec[rp * B + b];
+    pm = p_mu[p]; pp = p_prec[p]; lo = clip_lo[p]; hi = clip_hi[p];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int sidx = lane + 64 * c;
+      if (sidx < S) {
+        const int i = b * S + sidx;
+        uu_pre[c] = u[(size_t)i * P + p];
+        gx_pre[c] = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
+      }
+    }
+  }
   if (iwae) {
     // the arithmetic of iwae_loss_rows_kernel, once per block (every chunk of the row repeats it: S terms)
     float m = -INFINITY;
@@ -308,31 +330,24 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
     }
     __syncthreads();
   }
-  if (p >= P) return;
-  const int kd = kind[p];
-  const int rm = q_rows ? q_rows[p] : p, rp = q_rows ? q_rows[P + p] : p;
+  if (!has_p) return;
   if (kd == KIND_CONSTANT) {
     // constants carry no trainable distribution parameters in the reference (encoders.py:242-253)
     if (lane == 0) { g_q_mu[rm * B + b] = 0.f; g_q_prec[rp * B + b] = 0.f; }
     return;
   }
-  const float mu = q_mu[rm * B + b];
-  const float prec = prec_is_log ? expf(q_prec[rp * B + b]) : q_prec[rp * B + b];
+  const float prec = prec_is_log ? expf(prec_raw) : prec_raw;
   const float sigma = 1.f / sqrtf(prec);
-  const float pm = p_mu[p], pp = p_prec[p], lo = clip_lo[p], hi = clip_hi[p];
   float am = 0.f, ap = 0.f;
-#pragma unroll 4
-  for (int s = lane; s < S; s += 64) {
-    const int i = b * S + s;
-    const float uu = u[(size_t)i * P + p];
+  auto body = [&](int sidx, float uu, float gx) {
+    const int i = b * S + sidx;
     const float z = mu + sigma * uu;
     const float xr = (kd == KIND_LOGNORMAL) ? expf(z) : z;
     const float x = xr < lo ? lo : (xr > hi ? hi : xr);
     const float pass = (xr >= lo && xr <= hi) ? 1.f : 0.f;
-    const float gw = iwae ? wsm[s] : 0.f;  // d loss / d log_w
+    const float gw = iwae ? wsm[sidx] : 0.f;  // d loss / d log_w
     const float glq = iwae ? (iw.log_q ? -gw : 0.f) : (g_log_q ? g_log_q[i] : 0.f);
     const float glp = iwae ? (iw.log_p ? gw : 0.f) : (g_log_p ? g_log_p[i] : 0.f);
-    float gx = g_theta ? g_theta[(size_t)p * n + i] : 0.f;
     if (iwae) gx *= gw;
     else if (g_theta_scale) gx *= g_theta_scale[i];
     float v, dv_dx;
@@ -352,6 +367,14 @@ theta_bwd_kernel(int P, int B, int S, const int* __restrict__ kind, const float*
     const float d = mu - v;
     am += glq * (-prec * d);
     ap += glq * (0.5f / (prec + 1e-12f) - 0.5f * d * d);
+  };
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (lane + 64 * c < S) body(lane + 64 * c, uu_pre[c], gx_pre[c]);
+#pragma unroll 4
+  for (int sidx = lane + 256; sidx < S; sidx += 64) {
+    const int i = b * S + sidx;
+    body(sidx, u[(size_t)i * P + p], g_theta ? g_theta[(size_t)p * n + i] : 0.f);
   }
   am = wave_sum(am);
   ap = wave_sum(ap);
