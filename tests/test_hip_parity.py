@@ -1405,3 +1405,47 @@ def test_adaptive_solvers_through_the_plugin_surface_meet_the_reference_criterio
     arr = np.array(finals)
     cv = np.std(arr, axis=0) / np.mean(arr, axis=0)
     assert np.nanmax(cv[np.isfinite(cv)]) < 0.05
+
+
+def test_adaptive_solver_on_the_blackbox_and_hidden_precision_models():
+    """The adaptive pairs run in the thread-per-trajectory kernels of every model: dr_blackbox (MLP right-hand side; the
+    matrix-core formulation hands over to the VALU kernels for them) and a white-box model with hidden-layer precisions.
+    dopri5's solution at the output times agrees with rk4 on the same times to the schemes' accuracy, and the discrete
+    adjoint gives finite gradients for theta and the shared weights."""
+    from vihds import ops
+    import hip_util as H
+
+    # dr_blackbox
+    B, S, T = 6, 16, 40
+    spec_mid, theta, wts, cond, dev, times, obs = _blackbox_problem(B, S, T)
+    spec = ops.OdeProblemSpec("dr_blackbox", "dopri5", {n: i for i, n in enumerate(spec_mid.slots)}, len(spec_mid.slots),
+                              C=2, D=7, n_hidden_prec=20, n_hidden_states=25, n_latent_states=2, n_const=12 + 2 + 7,
+                              init_latent=0.001, init_prec=1e-5)
+    spec_rk4 = ops.OdeProblemSpec("dr_blackbox", "rk4", {n: i for i, n in enumerate(spec_mid.slots)}, len(spec_mid.slots),
+                                  C=2, D=7, n_hidden_prec=20, n_hidden_states=25, n_latent_states=2, n_const=12 + 2 + 7,
+                                  init_latent=0.001, init_prec=1e-5)
+    grid, index = ops.adaptive_grid(spec, theta, cond, times.cpu(), dev, wts, 1e-5, 1e-7)
+    assert grid.shape[0] >= T and torch.equal(grid[index].cpu(), times.cpu())
+    th = theta.clone().requires_grad_(True)
+    w = wts.clone().requires_grad_(True)
+    dummy = torch.zeros(B, 4, grid.shape[0], device=DEV)
+    traj_g, xpred_g, _ = ops.OdeSolveObserve.apply(spec, th, cond, grid, dummy, dev, w)
+    sol = traj_g.index_select(0, index)
+    ref, _, _ = ops.OdeSolveObserve.apply(spec_rk4, theta, cond, times, obs, dev, wts)
+    assert rel_err(H.view_bsnt(sol), H.view_bsnt(ref)) < 2e-3
+    (xpred_g.index_select(0, index) * torch.rand(T, 4, B, S, device=DEV)).sum().backward()
+    assert torch.isfinite(th.grad).all() and torch.isfinite(w.grad).all() and float(w.grad.abs().max()) > 0
+
+    # dr_constant_precisions with a 20-unit hidden layer (reference fixture), bosh3 through the controller
+    fx = Fixture("dr_constant_precisions_hidden20_tiny_modeuler")
+    th2, row_of = H.pack_theta(fx, DEV)
+    th2.requires_grad_(True)
+    spec2 = H.spec_for(fx, row_of, th2.shape[0], "bosh3", 0)
+    w2 = _flat_prec_weights(fx, requires_grad=True)
+    grid2, index2 = ops.adaptive_grid(spec2, th2, fx.t("inputs", DEV), fx.t("times"), None, w2, 1e-5, 1e-7)
+    dummy2 = torch.zeros(fx.B, 4, grid2.shape[0], device=DEV)
+    traj2, xp2, _ = ops.OdeSolveObserve.apply(spec2, th2, fx.t("inputs", DEV), grid2, dummy2, None, w2)
+    full = H.view_bsnt(traj2.index_select(0, index2))
+    assert rel_err(full[:, :, :-4], fx.t("x_states")) < 0.05  # (the fixture is modeuler: the reference's 5 % criterion)
+    xp2.index_select(0, index2).sum().backward()
+    assert torch.isfinite(th2.grad).all() and torch.isfinite(w2.grad).all()
