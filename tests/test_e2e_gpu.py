@@ -317,7 +317,11 @@ def test_iwae_loss_inside_the_theta_adjoint_matches_separate_launch(seed_kind):
         np.random.seed(fx.cfg["seed"] + 1)
         torch.manual_seed(fx.cfg["seed"] + 1)
         batch_results, theta, q, p = model(batch, fx.S)
+        eager = training.cost(batch, batch_results, theta, q, p).elbo  # outside Training.step: never deferred
+        assert not ops._PENDING_IWAE and abs(float(eager) - float(fx.t("loss"))) <= 1e-4 * abs(float(fx.t("loss")))
+        training._in_step = True  # what Training.step sets around its own cost() call
         elbo = training.cost(batch, batch_results, theta, q, p).elbo
+        training._in_step = False
         if fused_iwae:
             assert len(ops._PENDING_IWAE) == 1  # nothing launched for the loss yet
         elbo.backward(ops.unit_gradient(elbo.device) if seed_kind == "unit" else torch.ones_like(elbo))

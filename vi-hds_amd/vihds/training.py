@@ -134,7 +134,9 @@ class Training:
         group = (self.shard.group or torch.distributed.group.WORLD) if self.shard is not None else None
         # (fused decoder step + params.fused_iwae_backward: the loss is evaluated inside the step's theta-adjoint launch,
         # i.e. `iwae_cost` holds its value once backward() has run -- Training.step returns it after that)
-        defer = (not full_output and group is None and torch.is_grad_enabled()
+        # Only inside Training.step, which is known to run backward() with the unit seed right after: a caller that
+        # evaluates cost() on its own gets the loss value immediately, as in the reference.
+        defer = (not full_output and group is None and torch.is_grad_enabled() and getattr(self, "_in_step", False)
                  and getattr(getattr(batch_results, "solution", None), "defer_iwae", False))
         iwae_cost, log_unnormalized_iws, lse = ops.iwae_loss(logp, log_p_theta, log_q_theta, n_iwae_total=n_iwae,
                                                              group=group, defer=defer)
@@ -221,7 +223,11 @@ class Training:
         """One ELBO training step on a device batch: forward, cost, backward, (gradient all-reduce), Adam.
         Returns the loss tensor (-ELBO) without synchronising."""
         batch_results, theta, q, p = self.model(batch, self.args.train_samples)
-        elbo = self.cost(batch, batch_results, theta, q, p).elbo
+        self._in_step = True
+        try:
+            elbo = self.cost(batch, batch_results, theta, q, p).elbo
+        finally:
+            self._in_step = False
         if elbo.is_cuda:
             elbo.backward(ops.unit_gradient(elbo.device))  # no ones_like fill, and no launch for the loss's backward
         else:
