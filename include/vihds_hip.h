@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 4
+#define VIHDS_ABI_VERSION 5
 
 /* error codes */
 #define VIHDS_OK 0
@@ -349,6 +349,16 @@ typedef struct vihds_gram_rect {
 long long vihds_gram_scratch_floats(long long n_columns, int n_rects, const vihds_gram_rect* rects);
 int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihds_gram_rect* rects, const float* X,
                       float* scratch, float* out, void* stream);
+
+/* dr_blackbox, matrix-core adjoint (kernel_variant 0, fixed-grid solvers): the Gram-type weight gradients are accumulated
+ * ON CHIP -- every wavefront keeps the eight 16x16 output tiles of the four rectangles in registers (32 MFMAs per RHS
+ * evaluation over tiles transposed through LDS) and leaves 8 KB of partial sums at the head of aux instead of the
+ * [117][E][B*S] dump; vihds_blackbox_gram_reduce adds them in wavefront order and scatters them into g_weights (flat
+ * weight layout).  The tail (Delta, bias sums) follows at vihds_blackbox_tail_offset_floats(p) floats into aux and is
+ * consumed by vihds_blackbox_tail_grads as before.  kernel_variant 4 keeps the dump + vihds_gram_blocks pair. */
+int vihds_blackbox_gram_on_chip(const vihds_ode_problem* p);           /* 1 / 0 */
+long long vihds_blackbox_tail_offset_floats(const vihds_ode_problem* p);
+int vihds_blackbox_gram_reduce(const vihds_ode_problem* p, const float* aux, float* g_weights, void* stream);
 
 /* dr_blackbox: the weight-gradient entries that are not Gram rectangles, from the tail vihds_ode_bwd leaves behind the
  * dump (tail = aux + F*E*B*S: Delta [HS+HP][B*S], then the output-bias adjoint sums [2*NX+8][B*S]):

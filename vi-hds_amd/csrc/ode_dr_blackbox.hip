@@ -15,8 +15,19 @@ int n_states_dr_blackbox() { return BB::N; }
 int n_cond_dr_blackbox() { return BB::NC; }
 const char* slot_name_dr_blackbox(int s) { return BB::slot_name(s); }
 int bb_n_weights(int n_const) { return BB::n_weights(n_const); }
-long long bb_aux_floats(int n, int T, int solver) {
-  return (long long)(T - 1) * BB::stages(solver) * BB::NF * n + (long long)BB::NTAIL * n;
+// kernel_variant 0 (and anything but 1 / 4) with a fixed-grid solver: the matrix-core adjoint with the Gram tiles on chip
+static bool bb_gram_mode(int solver, int kernel_variant) {
+  return kernel_variant != 1 && kernel_variant != 4 && !solver_is_adaptive(solver);
+}
+long long bb_aux_floats(int n, int T, int solver, int kernel_variant) {
+  return (long long)bb_mfma_head_floats(n, T, solver, bb_gram_mode(solver, kernel_variant)) + (long long)BB::NTAIL * n;
+}
+long long bb_tail_offset_floats(int n, int T, int solver, int kernel_variant) {
+  return (long long)bb_mfma_head_floats(n, T, solver, bb_gram_mode(solver, kernel_variant));
+}
+int bb_gram_on_chip(int solver, int kernel_variant) { return bb_gram_mode(solver, kernel_variant) ? 1 : 0; }
+void bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
+  launch_bb_gram_reduce(a, aux, g_weights, st);
 }
 int bb_check(int L, int HS, int HP, int n_const, int C, int D) {
   return L == 2 && HS == 25 && HP == 20 && n_const == BB::NLAT + C + D;

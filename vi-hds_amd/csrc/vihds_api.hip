@@ -35,7 +35,10 @@ VIHDS_DECL(degrader_constant_prec)
 VIHDS_DECL(dr_blackbox)
 #undef VIHDS_DECL
 int bb_n_weights(int n_const);
-long long bb_aux_floats(int n, int T, int solver);
+long long bb_aux_floats(int n, int T, int solver, int kernel_variant);
+long long bb_tail_offset_floats(int n, int T, int solver, int kernel_variant);
+int bb_gram_on_chip(int solver, int kernel_variant);
+void bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st);
 int bb_check(int L, int HS, int HP, int n_const, int C, int D);
 int bb_dump_fields();
 
@@ -264,7 +267,7 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
 
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!p) return VIHDS_E_BADARG;
-  if (p->model == VIHDS_MODEL_DR_BLACKBOX) return bb_aux_floats(p->B * p->S, p->T, p->solver);
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX) return bb_aux_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
@@ -274,6 +277,24 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   return fields * (p->T - 1) * stages * p->B * p->S;
 }
 int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
+int vihds_blackbox_gram_on_chip(const vihds_ode_problem* p) {
+  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return 0;
+  return bb_gram_on_chip(p->solver, p->kernel_variant);
+}
+long long vihds_blackbox_tail_offset_floats(const vihds_ode_problem* p) {
+  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return VIHDS_E_BADARG;
+  return bb_tail_offset_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
+}
+int vihds_blackbox_gram_reduce(const vihds_ode_problem* p, const float* aux, float* g_weights, void* stream) {
+  if (!p || !aux || !g_weights) return fail(VIHDS_E_BADARG, "null argument");
+  if (p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_gram_on_chip(p->solver, p->kernel_variant))
+    return fail(VIHDS_E_BADARG, "vihds_blackbox_gram_reduce: not an on-chip Gram problem (see vihds_blackbox_gram_on_chip)");
+  const ModelEntry* e = entry(p->model);
+  OdeArgs a;
+  if (int rc = build_args(p, e, a)) return rc;
+  bb_gram_reduce(a, aux, g_weights, (hipStream_t)stream);
+  return check_hip("vihds_blackbox_gram_reduce launch");
+}
 
 int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                   const float* times, const float* obs, const float* weights, float* traj, float* xpred, float* logp,

@@ -223,6 +223,75 @@ struct BbMfma {
     }
   }
 
+  // ---- weight gradients on chip (round 2) -------------------------------------------------------------------------
+  // Every Gram-type weight gradient is  G[i][j] = sum over (evaluation, trajectory) of X[i][traj] Y[j][traj]  with X a
+  // tile of pre-activation adjoints and Y a tile of layer inputs, both already in registers in the C/D layout (lane =
+  // (trajectory, quarter)).  The contraction index of an MFMA is K, so the tiles are turned into "row" layout -- lane
+  // (row i, k-slot kq), register s = T[i][trajectory 4s + kq], which is the A layout and the B layout at once -- through
+  // a per-wavefront LDS buffer (one 16-byte store and four loads per tile), and 32 MFMAs per evaluation accumulate the
+  // eight 16x16 output tiles in registers:
+  //   tiles 0,1: d z (states' 2nd layer, 16 rows) x h[m]     -> Wp / Wd        tiles 2,3: gs[m] x inputs -> Wh
+  //   tiles 4,5: d zp (precisions' 2nd layer)     x g[m]     -> Vp / Vd        tiles 6,7: gp[m] x inputs -> Vh
+  // The 573 MB per-evaluation dump and its contraction pass (vihds_gram_blocks) disappear; a wavefront leaves 8 KB of
+  // partial sums, added up in a fixed order by bb_gram_reduce_kernel.
+  static constexpr int GT_LD = 20, GT_TILE = 16 * GT_LD, GT_NT = 11, GT_WAVE = GT_NT * GT_TILE;  // floats
+  __device__ __forceinline__ static void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ static f32x4 to_rows(float* buf, const f32x4& t, int lane) {
+    const int j = lane & 15, q = lane >> 4;
+    lds_fence();
+    *reinterpret_cast<f32x4*>(buf + j * GT_LD + 4 * q) = t;  // column j (a trajectory), rows 4q .. 4q+3
+    lds_fence();
+    f32x4 o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = buf[(4 * s + q) * GT_LD + j];  // row (lane & 15), trajectory 4s + (lane >> 4)
+    return o;
+  }
+  __device__ __forceinline__ static void put_cols(float* buf, const f32x4& t, int lane) {
+    *reinterpret_cast<f32x4*>(buf + (lane & 15) * GT_LD + 4 * (lane >> 4)) = t;
+  }
+  __device__ __forceinline__ static f32x4 get_rows(const float* buf, int lane) {
+    f32x4 o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = buf[(4 * s + (lane >> 4)) * GT_LD + (lane & 15)];
+    return o;
+  }
+  __device__ __forceinline__ static void gram_acc(f32x4& G, const f32x4& X, const f32x4& Y) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) G = mfma(X[s], Y[s], G);
+  }
+  // weight index of element (tile, lane, register) of a wavefront's partial sums, or -1
+  __host__ __device__ static int gram_dest(int tile, int lane, int reg, int n_const) {
+    const BB::Off o = BB::offsets(n_const);
+    const int row = 4 * (lane >> 4) + reg, col = lane & 15, m = tile & 1;
+    // the input tile's rows: 4q = state q, 4q+1 = latent state 4+q (q < 2), row 2 = time
+    auto input_of = [](int j) { return (j & 3) == 0 ? (j >> 2) : (((j & 3) == 1 && (j >> 2) < 2) ? 4 + (j >> 2) : (j == 2 ? 6 : -1)); };
+    if (tile < 2) {
+      const int u = unit_of_h(16 * m + col, HS), st = l2s_state_h(row);
+      return (u >= 0 && st >= 0) ? ((row & 1) ? o.wd : o.wp) + st * HS + u : -1;
+    }
+    if (tile < 4) {
+      const int u = unit_of_h(16 * m + row, HS), in = input_of(col);
+      return (u >= 0 && in >= 0 && in < 6) ? o.wh + u * o.nin_s + in : -1;
+    }
+    if (tile < 6) {
+      const int u = unit_of_h(16 * m + col, HP), ou = (row & 3) < 2 ? (row >> 2) : -1;
+      return (u >= 0 && ou >= 0) ? ((row & 1) ? o.vd : o.vp) + ou * HP + u : -1;
+    }
+    const int u = unit_of_h(16 * m + row, HP), in = input_of(col);
+    return (u >= 0 && in >= 0) ? o.vh + u * o.nin_p + (in == 6 ? 0 : 1 + in) : -1;
+  }
+  __host__ __device__ static int unit_of_h(int slot, int n_units) {
+    if (slot < 16) return slot < n_units ? slot : -1;
+    const int r = (slot - 16) & 3, qq = (slot - 16) >> 2;
+    const int u = r == 0 ? 16 + qq : (r == 1 ? 20 + qq : (r == 2 && qq == 0 ? 24 : -1));
+    return (u >= 0 && u < n_units) ? u : -1;
+  }
+  __host__ __device__ static int l2s_state_h(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < 2 ? 4 + qq : -1); }
+
   struct Dump {
     float* base;     // &aux[i]
     size_t n;        // trajectories
@@ -231,9 +300,10 @@ struct BbMfma {
     float bs[6];     // running sums of dz[0..3], dzp[0..1] (-> output-bias gradients)
   };
   // (d eval / d y)^T v, accumulating Delta (hidden pre-activation adjoint sums) and dumping the evaluation's fields
+  template <bool GRAM>
   __device__ __forceinline__ static State eval_vjp(float t, const State& y, const State& v, int q, bool live,
                                                    const Weights& W, const WeightsT& WT, const f32x4 hc[2][2],
-                                                   f32x4 delta[2][2], Dump& D) {
+                                                   f32x4 delta[2][2], Dump& D, f32x4* G, float* gbuf, int lane) {
     Act A;
     eval(t, y, q, W, hc, A);
     State yb;
@@ -273,7 +343,38 @@ struct BbMfma {
     if (q < 2) yb.b += dy[1];
     // ---- dump (same field layout as vihds_blackbox.hpp: the host contraction is shared)
     D.bs[0] += dz[0]; D.bs[1] += dz[1]; D.bs[2] += dz[2]; D.bs[3] += dz[3]; D.bs[4] += dzp[0]; D.bs[5] += dzp[1];
-    if (live) {
+    if (GRAM) {
+      const float lm = live ? 1.f : 0.f;  // (tail lanes shadow the last trajectory: their adjoint rows count as zero)
+      const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
+      const f32x4 xdzp = {dzp[0] * lm, dzp[1] * lm, 0.f, 0.f};
+      // all eleven tiles are written, then all are read back: one LDS round trip per evaluation, not eleven
+      lds_fence();
+      put_cols(gbuf + 0 * GT_TILE, dz * lm, lane);
+      put_cols(gbuf + 1 * GT_TILE, xdzp, lane);
+      put_cols(gbuf + 2 * GT_TILE, xin, lane);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        put_cols(gbuf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
+        put_cols(gbuf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
+        put_cols(gbuf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
+        put_cols(gbuf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
+      }
+      lds_fence();
+      const f32x4 Xdz = get_rows(gbuf + 0 * GT_TILE, lane);
+      const f32x4 Xdzp = get_rows(gbuf + 1 * GT_TILE, lane);
+      const f32x4 Yin = get_rows(gbuf + 2 * GT_TILE, lane);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x4 Yh = get_rows(gbuf + (3 + 4 * m) * GT_TILE, lane);
+        const f32x4 Yg = get_rows(gbuf + (4 + 4 * m) * GT_TILE, lane);
+        const f32x4 Xgs = get_rows(gbuf + (5 + 4 * m) * GT_TILE, lane);
+        const f32x4 Xgp = get_rows(gbuf + (6 + 4 * m) * GT_TILE, lane);
+        gram_acc(G[0 + m], Xdz, Yh);
+        gram_acc(G[2 + m], Xgs, Yin);
+        gram_acc(G[4 + m], Xdzp, Yg);
+        gram_acc(G[6 + m], Xgp, Yin);
+      }
+    } else if (live) {
       float* Dp = D.base + (size_t)D.e * D.n;
       const size_t n = D.fstride;
 #pragma unroll
@@ -300,10 +401,11 @@ struct BbMfma {
     return yb;
   }
 
-  template <int SOLVER>
+  template <int SOLVER, bool GRAM>
   __device__ __forceinline__ static State step_vjp(float t0, float t1, float h0, const State& y, const State& lam_in,
                                                    int q, bool live, const Weights& W, const WeightsT& WT,
-                                                   const f32x4 hc[2][2], f32x4 delta[2][2], Dump& D) {
+                                                   const f32x4 hc[2][2], f32x4 delta[2][2], Dump& D, f32x4* G,
+                                                   float* gbuf, int lane) {
     Act A;
     State lam = lam_in;
     auto add = [](State& x, const State& w, float s) { x.a += s * w.a; x.b += s * w.b; x.v += s * w.v; };
@@ -313,21 +415,21 @@ struct BbMfma {
       const State k1 = eval(t0, y, q, W, hc, A);
       const State ya = axpy(y, h, k1);
       State vv = scaled(lam, 0.5f * h);
-      const State w = eval_vjp(t1, ya, vv, q, live, W, WT, hc, delta, D);
+      const State w = eval_vjp<GRAM>(t1, ya, vv, q, live, W, WT, hc, delta, D, G, gbuf, lane);
       add(lam, w, 1.f);
       add(vv, w, h);
-      add(lam, eval_vjp(t0, y, vv, q, live, W, WT, hc, delta, D), 1.f);
+      add(lam, eval_vjp<GRAM>(t0, y, vv, q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
       return lam;
     } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      add(lam, eval_vjp(t0, y, scaled(lam, t1 - t0), q, live, W, WT, hc, delta, D), 1.f);
+      add(lam, eval_vjp<GRAM>(t0, y, scaled(lam, t1 - t0), q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
       return lam;
     } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
       const float dt = t1 - t0;
       const State k1 = eval(t0, y, q, W, hc, A);
       const State ym = axpy(y, dt * 0.5f, k1);
-      const State w = eval_vjp(t0 + dt * 0.5f, ym, scaled(lam, dt), q, live, W, WT, hc, delta, D);
+      const State w = eval_vjp<GRAM>(t0 + dt * 0.5f, ym, scaled(lam, dt), q, live, W, WT, hc, delta, D, G, gbuf, lane);
       add(lam, w, 1.f);
-      add(lam, eval_vjp(t0, y, scaled(w, 0.5f * dt), q, live, W, WT, hc, delta, D), 1.f);
+      add(lam, eval_vjp<GRAM>(t0, y, scaled(w, 0.5f * dt), q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
       return lam;
     } else {
       const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
@@ -339,13 +441,13 @@ struct BbMfma {
       const State y4 = {y.a + dt * (k1.a - k2.a + k3.a), y.b + dt * (k1.b - k2.b + k3.b), y.v + dt * (k1.v - k2.v + k3.v)};
       const State k4b = scaled(lam, d8);
       State k1b = k4b, k2b = scaled(k4b, 3.f), k3b = scaled(k4b, 3.f);
-      State w = eval_vjp(t0 + dt, y4, k4b, q, live, W, WT, hc, delta, D);
+      State w = eval_vjp<GRAM>(t0 + dt, y4, k4b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
       add(lam, w, 1.f); add(k1b, w, dt); add(k2b, w, -dt); add(k3b, w, dt);
-      w = eval_vjp(t0 + 2.f * d3, y3, k3b, q, live, W, WT, hc, delta, D);
+      w = eval_vjp<GRAM>(t0 + 2.f * d3, y3, k3b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
       add(lam, w, 1.f); add(k1b, w, -d3); add(k2b, w, dt);
-      w = eval_vjp(t0 + d3, y2, k2b, q, live, W, WT, hc, delta, D);
+      w = eval_vjp<GRAM>(t0 + d3, y2, k2b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
       add(lam, w, 1.f); add(k1b, w, d3);
-      add(lam, eval_vjp(t0, y, k1b, q, live, W, WT, hc, delta, D), 1.f);
+      add(lam, eval_vjp<GRAM>(t0, y, k1b, q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
       return lam;
     }
   }
@@ -397,11 +499,23 @@ __global__ void __launch_bounds__(256) bb_mfma_fwd_kernel(OdeArgs a) {
   if (a.logp && live) a.logp[(size_t)q * n + i] = lp;
 }
 
-template <int SOLVER>
+// floats of aux ahead of the tail (Delta, bias sums): the per-evaluation dump, or the wavefronts' Gram partial sums
+__host__ __device__ inline size_t bb_mfma_head_floats(int n, int T, int solver, bool gram) {
+  using BB = BbMfma::BB;
+  if (gram) return (size_t)((n + BbMfma::TPB - 1) / BbMfma::TPB) * 4 * 8 * 256;
+  return (size_t)(T - 1) * BB::stages(solver) * BB::NF * n;
+}
+
+template <int SOLVER, bool GRAM>
 __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   using K = BbMfma;
   using BB = K::BB;
+  extern __shared__ float glds[];  // GRAM: one transposition buffer set per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  float* gbuf = glds + wave * K::GT_WAVE;
+  f32x4 G[8];
+#pragma unroll
+  for (int tq = 0; tq < 8; ++tq) G[tq] = f32x4{0.f, 0.f, 0.f, 0.f};
   const int jj = lane & 15, q = lane >> 4;
   const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
   const bool live = i0 < a.n;
@@ -439,7 +553,7 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
       ob_next = ob[k - 1];
       tLo = a.times[k - 1];
     }
-    if (k < a.T - 1) lam = K::template step_vjp<SOLVER>(tK, tHi, h0, y, lam, q, live, W, WT, hc, delta, D);
+    if (k < a.T - 1) lam = K::template step_vjp<SOLVER, GRAM>(tK, tHi, h0, y, lam, q, live, W, WT, hc, delta, D, G, gbuf, lane);
     tHi = tK;
     // injection at time k: signal q = OD (q = 0) or OD * state q; precision q is an ODE state
     const float x0 = __shfl(y.a, jj, 64);
@@ -482,8 +596,8 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
         if (c < K::NLAT) a.g_theta[(size_t)a.slot_row[c] * n + i] = gc[r];
       }
       a.g_theta[(size_t)a.slot_row[K::NLAT + q] * n + i] = lam.a;  // init_x .. init_cfp
-      // Delta [HS+HP][n] behind the evaluation dump
-      float* dd = a.aux + (size_t)(a.T - 1) * BB::stages(a.solver) * BB::NF * n;
+      // Delta [HS+HP][n] behind the evaluation dump (or behind the Gram partial sums)
+      float* dd = a.aux + bb_mfma_head_floats(a.n, a.T, a.solver, GRAM);
       _Pragma("unroll") for (int m = 0; m < 2; ++m)
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {
           const int us = K::unit_of(16 * m + 4 * q + r, K::HS), up = K::unit_of(16 * m + 4 * q + r, K::HP);
@@ -499,14 +613,47 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
       bb[(size_t)(2 * K::NX + 4 + q) * n + i] = D.bs[5];
     }
   }
+  if (GRAM) {  // this wavefront's partial Gram tiles, raw (tile, lane, register) order
+    float* gp = a.aux + ((size_t)(blockIdx.x * 4 + wave) * 8) * 256;
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f32x4*>(gp + tq * 256 + lane * 4) = G[tq];
+  }
+}
+
+// sums the wavefronts' partial tiles in wavefront order (deterministic) and scatters them into the flat weight gradient
+__global__ void __launch_bounds__(256) bb_gram_reduce_kernel(int n_waves, int n_const, const float* __restrict__ partial,
+                                                             float* __restrict__ g_weights) {
+  const int tile = blockIdx.x, e = threadIdx.x;
+  const int dest = BbMfma::gram_dest(tile, e >> 2, e & 3, n_const);
+  if (dest < 0) return;
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  const float* src = partial + (size_t)tile * 256 + e;
+  int w = 0;
+  for (; w + 4 <= n_waves; w += 4) {
+    acc0 += src[(size_t)(w + 0) * 2048];
+    acc1 += src[(size_t)(w + 1) * 2048];
+    acc2 += src[(size_t)(w + 2) * 2048];
+    acc3 += src[(size_t)(w + 3) * 2048];
+  }
+  for (; w < n_waves; ++w) acc0 += src[(size_t)w * 2048];
+  g_weights[dest] = (acc0 + acc1) + (acc2 + acc3);
+}
+inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
+  const int n_waves = ((a.n + BbMfma::TPB - 1) / BbMfma::TPB) * 4;
+  hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(8), dim3(256), 0, st, n_waves, a.n_const, aux, g_weights);
 }
 
 inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
-#define VIHDS_BCASE(SV)                                                                  \
-  case SV:                                                                               \
-    if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV>), grid, block, 0, st, a);   \
-    else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);            \
+  // kernel_variant 4: the adjoint dumps every evaluation for vihds_gram_blocks (round 1); otherwise it accumulates the
+  // Gram tiles on chip
+  const bool gram = a.kernel_variant != 4;
+  const size_t glds = (size_t)4 * BbMfma::GT_WAVE * sizeof(float);
+#define VIHDS_BCASE(SV)                                                                                  \
+  case SV:                                                                                               \
+    if (backward && gram) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, true>), grid, block, glds, st, a);  \
+    else if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, false>), grid, block, 0, st, a);       \
+    else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);                            \
     return VIHDS_OK;
   switch (solver) {
     VIHDS_BCASE(VIHDS_SOLVER_MODEULER)

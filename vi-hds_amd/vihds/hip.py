@@ -130,6 +130,9 @@ _PROTOTYPES = {
                                   + [_P] * 10),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
+    "vihds_blackbox_gram_on_chip": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_blackbox_tail_offset_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
+    "vihds_blackbox_gram_reduce": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P]),
     "vihds_theta_fwd": (_I, [_I, _I, _I] + [_P] * 11 + [ctypes.POINTER(ThetaOpts), _P]),
     "vihds_theta_bwd": (_I, [_I, _I, _I] + [_P] * 13 + [ctypes.POINTER(ThetaOpts), _P]),
     "vihds_iwae_fwd": (_I, [_I, _I] + [_P] * 7),
@@ -171,7 +174,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 4:
+        if handle.vihds_abi_version() != 5:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

@@ -497,6 +497,18 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     (vihds_blackbox_tail_grads)."""
     B, S = prob.B, prob.S
     n = B * S
+    if hip.lib().vihds_blackbox_gram_on_chip(ctypes.byref(prob)):
+        # matrix-core adjoint: the Gram tiles were accumulated on chip; add up the wavefronts' partial sums, then the tail
+        plan = _blackbox_grad_plan(spec, prob, theta.device)
+        g_w = torch.empty(plan["total"], device=theta.device, dtype=torch.float32)
+        rc = hip.lib().vihds_blackbox_gram_reduce(ctypes.byref(prob), hip.ptr(aux), hip.ptr(g_w), hip.current_stream())
+        hip.check(rc, "vihds_blackbox_gram_reduce")
+        off = int(hip.lib().vihds_blackbox_tail_offset_floats(ctypes.byref(prob)))
+        rc = hip.lib().vihds_blackbox_tail_grads(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
+                                                 aux.data_ptr() + 4 * off, hip.ptr(plan["rest"]), hip.ptr(g_w),
+                                                 hip.current_stream())
+        hip.check(rc, "vihds_blackbox_tail_grads")
+        return g_w
     F = hip.lib().vihds_blackbox_dump_fields()
     HS, HP, L = prob.n_hidden_states, prob.n_hidden_prec, prob.n_latent_states
     NX = 4 + L
