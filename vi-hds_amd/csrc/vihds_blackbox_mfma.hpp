@@ -347,31 +347,20 @@ struct BbMfma {
       const float lm = live ? 1.f : 0.f;  // (tail lanes shadow the last trajectory: their adjoint rows count as zero)
       const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
       const f32x4 xdzp = {dzp[0] * lm, dzp[1] * lm, 0.f, 0.f};
-      // all eleven tiles are written, then all are read back: one LDS round trip per evaluation, not eleven
-      lds_fence();
-      put_cols(gbuf + 0 * GT_TILE, dz * lm, lane);
-      put_cols(gbuf + 1 * GT_TILE, xdzp, lane);
-      put_cols(gbuf + 2 * GT_TILE, xin, lane);
+      // tile by tile: the MFMAs of the earlier tiles run while the later ones travel through LDS (writing all eleven
+      // first and reading them back in one batch measured slower: 357 vs 345 us)
+      const f32x4 Xdz = to_rows(gbuf + 0 * GT_TILE, dz * lm, lane);
+      const f32x4 Xdzp = to_rows(gbuf + 1 * GT_TILE, xdzp, lane);
+      const f32x4 Yin = to_rows(gbuf + 2 * GT_TILE, xin, lane);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        put_cols(gbuf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
-        put_cols(gbuf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
-        put_cols(gbuf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
-        put_cols(gbuf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
-      }
-      lds_fence();
-      const f32x4 Xdz = get_rows(gbuf + 0 * GT_TILE, lane);
-      const f32x4 Xdzp = get_rows(gbuf + 1 * GT_TILE, lane);
-      const f32x4 Yin = get_rows(gbuf + 2 * GT_TILE, lane);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const f32x4 Yh = get_rows(gbuf + (3 + 4 * m) * GT_TILE, lane);
-        const f32x4 Yg = get_rows(gbuf + (4 + 4 * m) * GT_TILE, lane);
-        const f32x4 Xgs = get_rows(gbuf + (5 + 4 * m) * GT_TILE, lane);
-        const f32x4 Xgp = get_rows(gbuf + (6 + 4 * m) * GT_TILE, lane);
+        const f32x4 Yh = to_rows(gbuf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
         gram_acc(G[0 + m], Xdz, Yh);
+        const f32x4 Xgs = to_rows(gbuf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
         gram_acc(G[2 + m], Xgs, Yin);
+        const f32x4 Yg = to_rows(gbuf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
         gram_acc(G[4 + m], Xdzp, Yg);
+        const f32x4 Xgp = to_rows(gbuf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
         gram_acc(G[6 + m], Xgp, Yin);
       }
     } else if (live) {
