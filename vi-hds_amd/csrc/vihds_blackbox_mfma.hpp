@@ -609,27 +609,38 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   }
 }
 
-// sums the wavefronts' partial tiles in wavefront order (deterministic) and scatters them into the flat weight gradient
-__global__ void __launch_bounds__(256) bb_gram_reduce_kernel(int n_waves, int n_const, const float* __restrict__ partial,
-                                                             float* __restrict__ g_weights) {
-  const int tile = blockIdx.x, e = threadIdx.x;
-  const int dest = BbMfma::gram_dest(tile, e >> 2, e & 3, n_const);
-  if (dest < 0) return;
-  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+// sums the wavefronts' partial tiles in a fixed order (deterministic) and scatters them into the flat weight gradient.
+// One block = 64 elements of a tile x 16 interleaved slices of the wavefronts (as one thread per element walking all
+// 450 wavefronts -- 113 dependent rounds of loads -- this took 39 us).
+__global__ void __launch_bounds__(1024) bb_gram_reduce_kernel(int n_waves, int n_const, const float* __restrict__ partial,
+                                                              float* __restrict__ g_weights) {
+  __shared__ float part[16][64];
+  const int tile = blockIdx.x >> 2, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
   const float* src = partial + (size_t)tile * 256 + e;
-  int w = 0;
-  for (; w + 4 <= n_waves; w += 4) {
+  float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
+  int w = slice;
+  for (; w + 48 < n_waves; w += 64) {
     acc0 += src[(size_t)(w + 0) * 2048];
-    acc1 += src[(size_t)(w + 1) * 2048];
-    acc2 += src[(size_t)(w + 2) * 2048];
-    acc3 += src[(size_t)(w + 3) * 2048];
+    acc1 += src[(size_t)(w + 16) * 2048];
+    acc2 += src[(size_t)(w + 32) * 2048];
+    acc3 += src[(size_t)(w + 48) * 2048];
   }
-  for (; w < n_waves; ++w) acc0 += src[(size_t)w * 2048];
-  g_weights[dest] = (acc0 + acc1) + (acc2 + acc3);
+  for (; w < n_waves; w += 16) acc0 += src[(size_t)w * 2048];
+  part[slice][threadIdx.x & 63] = (acc0 + acc1) + (acc2 + acc3);
+  __syncthreads();
+  if (slice == 0) {
+    const int dest = BbMfma::gram_dest(tile, e >> 2, e & 3, n_const);
+    if (dest >= 0) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x & 63];
+      g_weights[dest] = t;
+    }
+  }
 }
 inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
   const int n_waves = ((a.n + BbMfma::TPB - 1) / BbMfma::TPB) * 4;
-  hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(8), dim3(256), 0, st, n_waves, a.n_const, aux, g_weights);
+  hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(32), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
 }
 
 inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
