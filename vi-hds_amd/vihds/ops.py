@@ -843,6 +843,8 @@ class IwaeLoss(torch.autograd.Function):
             ctx.mark_non_differentiable(log_w, lse)
             ctx.set_materialize_grads(False)
             return loss, log_w, lse
+        if ug is not None:
+            _PENDING_IWAE.pop(ug.data_ptr(), None)  # (a deferred job abandoned without a backward may have owned this address)
         rc = hip.lib().vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp), hip.ptr(log_p), hip.ptr(log_q),
                                            hip.ptr(log_w), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
                                            hip.ptr(loss), hip.ptr(ug), hip.ptr(ugn), hip.ptr(ticket),

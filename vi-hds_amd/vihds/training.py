@@ -224,6 +224,7 @@ class Training:
         Returns the loss tensor (-ELBO) without synchronising."""
         batch_results, theta, q, p = self.model(batch, self.args.train_samples)
         self._in_step = True
+        ops._PENDING_IWAE.clear()  # (a deferred loss whose backward never ran must not be mistaken for this step's)
         try:
             elbo = self.cost(batch, batch_results, theta, q, p).elbo
         finally:
