@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 5
+#define VIHDS_ABI_VERSION 6
 
 /* error codes */
 #define VIHDS_OK 0
@@ -164,7 +164,21 @@ int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, cons
  * dr_constant_v2 in the lane-split regime only; VIHDS_E_UNSUPPORTED otherwise (callers then use fwd + bwd). */
 int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                         const float* times, const float* obs, float* logp, float* g_theta_unit, void* stream);
-int vihds_blackbox_dump_fields(void);
+int vihds_blackbox_dump_fields(void);  /* at the built-in (specs/dr_blackbox_icml.yaml) sizes */
+
+/* dr_blackbox at other network sizes (reference models/dr_blackbox.py:61-84 reads n_latent_species, n_hidden_decoder,
+ * n_hidden_decoder_precisions, n_z, n_x, n_y from the YAML).  The kernels are compiled per size set: the ICML set is
+ * part of this library; any other set is looked for, on first use, as
+ *     libvihds_bb_<n_latent_states>_<n_hidden_states>_<n_hidden_prec>_<n_const - C - D>.so
+ * in the directory this library was loaded from (build: make -C vi-hds_amd/csrc blackbox L=.. HS=.. HP=.. NLAT=..;
+ * thread-per-trajectory kernels, every solver, weight gradients through the dump).  A missing file makes every entry
+ * point return VIHDS_E_UNSUPPORTED with the file name and the build command in vihds_last_error().  The theta slots of
+ * a sized problem are its n_const - C - D latent inputs in YAML order (z.., x.., y..) followed by init_x, init_rfp,
+ * init_yfp, init_cfp.  The problem-level queries below answer for any model (they fall back to the vihds_model_*
+ * values); vihds_model_n_states / n_slots / slot_name describe dr_blackbox at the ICML sizes. */
+int vihds_problem_n_states(const vihds_ode_problem* p);
+int vihds_problem_n_slots(const vihds_ode_problem* p);
+int vihds_problem_dump_fields(const vihds_ode_problem* p); /* dr_blackbox only */
 
 /* theta side: ChainedDistribution.sample + p.clip + q.log_prob + p.log_prob
  * (vihds/distributions.py:64-85,119-142,327-381; vihds/vae.py:31-34) over all P parameters at once.

@@ -21,6 +21,7 @@ ALL_FIXTURES = [
     "dr_constant_precisions_hidden20_tiny_modeuler",
     "auto_constant_precisions_tiny_modeuler",
     "dr_blackbox_icml_tiny_modeuler",
+    "dr_blackbox_sized_tiny_modeuler",
     "prpr_constant_tiny_modeuler",
 ]
 

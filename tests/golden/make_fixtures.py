@@ -109,7 +109,8 @@ def to_np(x):
     return np.asarray(x)
 
 
-def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step=False, precision_hidden_layers=None):
+def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step=False, precision_hidden_layers=None,
+             params_override=None):
     """Run one reference forward + cost + backward and record everything at the boundary."""
     import torch
     from vihds.config import Config
@@ -127,6 +128,8 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     )
     settings = Config(args)
     settings.params.solver = solver
+    for k, v in (params_override or {}).items():  # e.g. dr_blackbox at other network sizes (models/dr_blackbox.py:61-84)
+        settings.params[k] = v
     data = build_datasets(args, settings)
     parameters = Parameters(settings.params)
     model = build_model(args, settings, data, parameters)
@@ -287,7 +290,9 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     import yaml
 
     with open("specs/%s.yaml" % spec) as fh:
-        fx["spec_json"] = np.array(json.dumps(yaml.safe_load(fh)))
+        spec_dict = yaml.safe_load(fh)
+    spec_dict["params"].update(params_override or {})
+    fx["spec_json"] = np.array(json.dumps(spec_dict))
     fx["devices"] = np.asarray(batch.devices)
     return fx
 
@@ -312,6 +317,8 @@ def run_training_trace(spec, solver, n_iwae, epochs, seed):
     args.heldout = None
     settings = Config(args)
     settings.params.solver = solver
+    for k, v in (params_override or {}).items():  # e.g. dr_blackbox at other network sizes (models/dr_blackbox.py:61-84)
+        settings.params[k] = v
     data = build_datasets(args, settings)
     parameters = Parameters(settings.params)
     model = build_model(args, settings, data, parameters)
@@ -382,6 +389,10 @@ CASES = [
     ("prpr_constant_tiny_modeuler", "prpr_constant", "modeuler", 8, 4, 1),
     # NeuralPrecisions with a hidden layer (reference precisions.py:63-74) through the CLI flag --precision_hidden_layers
     ("dr_constant_precisions_hidden20_tiny_modeuler", "dr_constant_precisions", "modeuler", 8, 4, 1, 20),
+    # dr_blackbox at network sizes other than the ICML spec's (models/dr_blackbox.py:61-84 reads them from the YAML's
+    # params block; overridden here after Config() parsed specs/dr_blackbox_icml.yaml)
+    ("dr_blackbox_sized_tiny_modeuler", "dr_blackbox_icml", "modeuler", 8, 4, 1, None,
+     {"n_z": 4, "n_x": 3, "n_y": 1, "n_latent_species": 3, "n_hidden_decoder": 12, "n_hidden_decoder_precisions": 6}),
 ]
 
 
@@ -410,7 +421,8 @@ def main():
         if a.only and a.only not in name:
             continue
         try:
-            fx = run_case(spec, solver, S, rows, 0, stride, precision_hidden_layers=more[0] if more else None)
+            fx = run_case(spec, solver, S, rows, 0, stride, precision_hidden_layers=more[0] if more else None,
+                          params_override=more[1] if len(more) > 1 else None)
         except Exception as e:  # a reference defect is recorded, not hidden
             print("FAILED %s: %s: %s" % (name, type(e).__name__, e))
             continue

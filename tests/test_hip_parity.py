@@ -267,14 +267,19 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
         assert e_hip < max(GTOL, 8.0 * e32), (n, e_hip, e32)
 
 
-@pytest.mark.parametrize("variant", [0, 1])  # 0 = auto (MFMA formulation), 1 = VALU, one thread per trajectory
-def test_blackbox_forward_and_gradients_match_reference(variant):
+# variant 0 = auto (MFMA formulation at the ICML sizes), 1 = VALU, one thread per trajectory; the "sized" fixture is the
+# reference run with n_z 4, n_x 3, n_y 1, n_latent_species 3, n_hidden_decoder 12, n_hidden_decoder_precisions 6
+# (models/dr_blackbox.py:61-84 reads them from the YAML): kernels of a side library, libvihds_bb_3_12_6_8.so
+@pytest.mark.parametrize("name,variant", [("dr_blackbox_icml_tiny_modeuler", 0), ("dr_blackbox_icml_tiny_modeuler", 1),
+                                          ("dr_blackbox_sized_tiny_modeuler", 0)])
+def test_blackbox_forward_and_gradients_match_reference(name, variant):
     """dr_blackbox (MLP right-hand side): trajectories, precisions, log-likelihood, d loss/d theta and the gradients
-    of all 1 760 shared MLP weights (adjoint kernel dump + batched GEMMs) against the reference's autograd."""
+    of all shared MLP weights (1 760 at the ICML sizes; adjoint kernel dump + batched GEMMs, or the on-chip Gram
+    tiles) against the reference's autograd."""
     from vihds import ops
     import hip_util as H
 
-    fx = Fixture("dr_blackbox_icml_tiny_modeuler")
+    fx = Fixture(name)
     prec_w, states_w, offset = fx.decoder_weights(DEV)
     order = ("hid_w", "hid_b", "prod_w", "prod_b", "degr_w", "degr_b")
     wts = torch.cat([states_w[k].reshape(-1) for k in order] + [prec_w[k].reshape(-1) for k in order])
@@ -283,15 +288,20 @@ def test_blackbox_forward_and_gradients_match_reference(variant):
     th = fx.t("theta", DEV)
     dev = fx.t("dev_1hot", DEV)
     off = torch.nn.functional.linear(dev, offset[0], offset[1])  # [B, n_y]; condition_theta (dr_blackbox.py:86-96)
-    ycond = torch.stack([th[fx.names.index("y%d" % (i + 1))] + off[:, i: i + 1] for i in range(2)])
+    p = fx.cfg["params"]
+    n_y = p["n_y"]
+    ycond = torch.stack([th[fx.names.index("y%d" % (i + 1))] + off[:, i: i + 1] for i in range(n_y)])
     theta = torch.cat([th, ycond], 0).requires_grad_(True)
     row_of = {n: i for i, n in enumerate(fx.names)}
-    row_of["y1"], row_of["y2"] = P, P + 1  # the simulator sees the offset y's; log q / log p the sampled ones
-    p = fx.cfg["params"]
-    spec = ops.OdeProblemSpec("dr_blackbox", fx.solver, row_of, P + 2, C=2, D=dev.shape[1],
+    for i in range(n_y):
+        row_of["y%d" % (i + 1)] = P + i  # the simulator sees the offset y's; log q / log p the sampled ones
+    slots = (["z%d" % (i + 1) for i in range(p["n_z"])] + ["x%d" % (i + 1) for i in range(p["n_x"])]
+             + ["y%d" % (i + 1) for i in range(n_y)] + ["init_x", "init_rfp", "init_yfp", "init_cfp"])
+    spec = ops.OdeProblemSpec("dr_blackbox", fx.solver, row_of, P + n_y, C=2, D=dev.shape[1],
                                n_hidden_prec=p["n_hidden_decoder_precisions"], n_hidden_states=p["n_hidden_decoder"],
                                n_latent_states=p["n_latent_species"], n_const=p["n_z"] + p["n_x"] + p["n_y"] + 2 + dev.shape[1],
-                               init_latent=p["init_latent_species"], init_prec=p["init_prec"], kernel_variant=variant)
+                               init_latent=p["init_latent_species"], init_prec=p["init_prec"], kernel_variant=variant,
+                               slots=slots)
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
                                                   fx.t("observations", DEV), dev, wts)
     full = H.view_bsnt(traj)
@@ -327,8 +337,8 @@ def test_blackbox_forward_and_gradients_match_reference(variant):
     (extra * w).sum().backward()
     g = theta.grad.cpu()
     got_th = g[:P].clone()
-    got_th[fx.names.index("y1")] += g[P]
-    got_th[fx.names.index("y2")] += g[P + 1]
+    for i in range(n_y):
+        got_th[fx.names.index("y%d" % (i + 1))] += g[P + i]
     got_th = got_th + torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
     live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
     assert rel_err(got_th[live], fx.t("theta_grad")[live], dim=0) < GTOL
@@ -892,7 +902,7 @@ def test_fused_logp_and_unit_adjoint_equals_forward_plus_backward(model, solver)
     assert L.vihds_ode_logp_grad(ctypes.byref(prob1), *args, logp2.data_ptr(), g_unit.data_ptr(), st) != 0
 
 
-def test_c_abi_rejects_bad_arguments_with_error_codes():
+def test_c_abi_rejects_bad_arguments_with_error_codes(monkeypatch):
     """Error behaviour of the boundary: every entry point returns a negative VIHDS_E_* code and leaves a message in
     vihds_last_error() instead of launching (the Python stub turns that into RuntimeError)."""
     import ctypes
@@ -922,14 +932,18 @@ def test_c_abi_rejects_bad_arguments_with_error_codes():
     assert L.vihds_iwae_loss_fwd(B, S, S, None, None, None, None, None, None, None, None, None, None, None, st) < 0
     assert L.vihds_device_condition(1, B, S, S, 0, 0, 0.0, 1.0, None, None, None, None, None, None, st) < 0
     assert L.vihds_model_n_states(123) < 0 and L.vihds_model_n_slots(-1) < 0
-    # a network shape the black-box kernels were not instantiated for is declined, not mis-run
+    # a network shape the black-box kernels are not built for (and may not be built for on demand) is declined by the
+    # host stub and by the library, not mis-run
     bslots = hip.model_slots("dr_blackbox")
-    with pytest.raises((RuntimeError, KeyError)):
-        bspec = ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(bslots)}, len(bslots), C=2,
-                                   D=7, n_hidden_prec=7, n_hidden_states=9, n_latent_states=2, n_const=21)
-        bth = torch.rand(len(bslots), B, S, device=DEV)
-        ops.OdeSolveObserve.apply(bspec, bth, cond, times, obs, torch.rand(B, 7, device=DEV),
-                                  torch.rand(64, device=DEV))
+    monkeypatch.setenv("VIHDS_BLACKBOX_JIT", "0")
+    with pytest.raises(RuntimeError, match="libvihds_bb_2_9_7_12.so"):
+        ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(bslots)}, len(bslots), C=2,
+                           D=7, n_hidden_prec=7, n_hidden_states=9, n_latent_states=2, n_const=21, slots=bslots)
+    bprob = ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(bslots)}, len(bslots), C=2, D=7,
+                               n_hidden_prec=20, n_hidden_states=25, n_latent_states=2, n_const=21).bind(B, S, T)
+    bprob.n_hidden_states = 9
+    assert L.vihds_model_n_weights(ctypes.byref(bprob)) < 0
+    assert b"libvihds_bb_2_9_20_12.so" in L.vihds_last_error()
     # and the host stub surfaces the message
     with pytest.raises(RuntimeError, match="vihds_ode_fwd failed"):
         ops.OdeSolveObserve.apply(spec, theta, cond, times[:1], obs[:, :, :1], None, None)
@@ -1449,3 +1463,68 @@ def test_adaptive_solver_on_the_blackbox_and_hidden_precision_models():
     assert rel_err(full[:, :, :-4], fx.t("x_states")) < 0.05  # (the fixture is modeuler: the reference's 5 % criterion)
     xp2.index_select(0, index2).sum().backward()
     assert torch.isfinite(th2.grad).all() and torch.isfinite(w2.grad).all()
+
+
+@pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4", "dopri5"])
+def test_sized_blackbox_every_solver_against_the_restatement(solver):
+    """dr_blackbox at network sizes other than the ICML spec's (side library libvihds_bb_3_12_6_8.so; the reference
+    fixture pins modeuler in test_blackbox_forward_and_gradients_match_reference): the other schemes against the CPU
+    restatement on the fixture's inputs and weights -- trajectories, precisions, x_predict; for dopri5 the accepted
+    grid of the library's own controller is handed to the restatement, and the weight / theta gradients of a random
+    functional of x_predict are compared with the restatement's autograd."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture("dr_blackbox_sized_tiny_modeuler")
+    p = fx.cfg["params"]
+    prec_w, states_w, offset = fx.decoder_weights("cpu")
+    order = ("hid_w", "hid_b", "prod_w", "prod_b", "degr_w", "degr_b")
+    for w in list(prec_w.values()) + list(states_w.values()):
+        w.requires_grad_(True)
+    wts = torch.cat([states_w[k].detach().reshape(-1) for k in order] + [prec_w[k].detach().reshape(-1) for k in order])
+    wts = wts.to(DEV).requires_grad_(True)
+    n_y = p["n_y"]
+    th_cpu = fx.theta_dict(requires_grad=True)
+    dev = fx.t("dev_1hot")
+    off = torch.nn.functional.linear(dev, offset[0], offset[1])
+    th_sim = dict(th_cpu)
+    for i in range(n_y):
+        th_sim["y%d" % (i + 1)] = th_cpu["y%d" % (i + 1)] + off[:, i: i + 1]
+    slots = (["z%d" % (i + 1) for i in range(p["n_z"])] + ["x%d" % (i + 1) for i in range(p["n_x"])]
+             + ["y%d" % (i + 1) for i in range(n_y)] + ["init_x", "init_rfp", "init_yfp", "init_cfp"])
+    theta = torch.stack([th_sim[n].detach().expand(fx.B, fx.S) for n in slots]).to(DEV).requires_grad_(True)
+    D = dev.shape[1]
+    spec = ops.OdeProblemSpec("dr_blackbox", solver, {n: i for i, n in enumerate(slots)}, len(slots), C=2, D=D,
+                               n_hidden_prec=p["n_hidden_decoder_precisions"], n_hidden_states=p["n_hidden_decoder"],
+                               n_latent_states=p["n_latent_species"], n_const=p["n_z"] + p["n_x"] + n_y + 2 + D,
+                               init_latent=p["init_latent_species"], init_prec=p["init_prec"], slots=slots)
+    assert spec.n_states == 4 + p["n_latent_species"] + 4
+    cond, times = fx.t("inputs", DEV), fx.t("times", DEV)
+    bb = dict(dev_1hot=dev, states_w=states_w, prec_w=prec_w, n_x=p["n_x"], n_y=n_y, n_z=p["n_z"],
+              n_latent_species=p["n_latent_species"], init_latent_species=p["init_latent_species"],
+              init_prec=p["init_prec"])
+    if solver == "dopri5":
+        grid, index = ops.adaptive_grid(spec, theta.detach(), cond, times.cpu(), dev.to(DEV), wts.detach(), 1e-5, 1e-7)
+        assert torch.equal(grid[index].cpu(), times.cpu())
+        dummy = torch.zeros(fx.B, 4, grid.shape[0], device=DEV)
+        traj_g, xpred_g, _ = ops.OdeSolveObserve.apply(spec, theta, cond, grid, dummy, dev.to(DEV), wts)
+        traj, xpred = traj_g.index_select(0, index), xpred_g.index_select(0, index)
+        xs, xp, prec = O.decode("dr_blackbox", th_sim, fx.t("inputs"), fx.t("times"), solver, prec_w=prec_w, blackbox=bb,
+                                grid=([float(v) for v in grid.cpu()], [int(k) for k in index.cpu()]))
+    else:
+        traj, xpred, _ = ops.OdeSolveObserve.apply(spec, theta, cond, times, fx.t("observations", DEV), dev.to(DEV), wts)
+        xs, xp, prec = O.decode("dr_blackbox", th_sim, fx.t("inputs"), fx.t("times"), solver, prec_w=prec_w, blackbox=bb)
+    full = H.view_bsnt(traj)
+    assert rel_err(full[:, :, :-4], xs.detach()) < TOL
+    assert rel_err(full[:, :, -4:], prec.detach()) < TOL
+    assert rel_err(H.view_bsnt(xpred), xp.detach()) < TOL
+    g = torch.Generator().manual_seed(5)
+    coef = torch.rand(xp.shape, generator=g)                           # [B,S,4,T]
+    (H.view_bsnt(xpred) * coef.to(DEV)).sum().backward()
+    (xp * coef).sum().backward()
+    gref = torch.cat([states_w[k].grad.reshape(-1) for k in order] + [prec_w[k].grad.reshape(-1) for k in order])
+    assert rel_err(wts.grad, gref) < GTOL
+    # (d / d(y + offset) = d / dy: the leaves are the fixture's theta rows)
+    th_ref = torch.stack([th_cpu[n].grad if th_cpu[n].grad is not None else torch.zeros(fx.B, fx.S) for n in slots])
+    live = th_ref.abs().amax(dim=(1, 2)) > 0
+    assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL

@@ -1,12 +1,19 @@
 // C ABI (include/vihds_hip.h): argument checking, model registry and dispatch to the kernel launchers.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <tuple>
 
 #include "../../include/vihds_hip.h"
 #include "vihds_ode_kernels.hpp"
+#include "vihds_bb_variant.hpp"
 
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
@@ -129,13 +136,67 @@ static const ModelEntry* entry(int model) {
   return kModels[model].launch ? &kModels[model] : nullptr;
 }
 
-static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& a) {
+// ---- dr_blackbox size sets (vihds_bb_variant.hpp) --------------------------------------------------------------------
+// The ICML sizes are built in (bb_check); any other set is looked for as libvihds_bb_<L>_<HS>_<HP>_<NLAT>.so in the
+// directory this library was loaded from, once per process.
+static bool bb_sizes_ok(const vihds_ode_problem* p) {
+  return p->n_latent_states >= 0 && p->n_hidden_states > 0 && p->n_hidden_prec > 0 && p->n_const >= p->C + p->D &&
+         p->C >= 0 && p->D >= 0;
+}
+static bool bb_builtin(const vihds_ode_problem* p) {
+  return bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D) != 0;
+}
+static const BbVariant* bb_sized(const vihds_ode_problem* p) {
+  static std::mutex mu;
+  static std::map<std::tuple<int, int, int, int>, const BbVariant*> loaded;
+  if (!bb_sizes_ok(p)) {
+    fail(VIHDS_E_BADARG, "dr_blackbox: bad network sizes (n_const must cover the C treatments and the D-wide one-hot)");
+    return nullptr;
+  }
+  const int nlat = p->n_const - p->C - p->D;
+  const auto key = std::make_tuple(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, nlat);
+  std::lock_guard<std::mutex> lock(mu);
+  auto it = loaded.find(key);
+  if (it != loaded.end()) return it->second;
+  char name[96];
+  std::snprintf(name, sizeof(name), "libvihds_bb_%d_%d_%d_%d.so", p->n_latent_states, p->n_hidden_states,
+                p->n_hidden_prec, nlat);
+  std::string path = name;
+  Dl_info info;
+  if (dladdr((const void*)&vihds_abi_version, &info) && info.dli_fname) {
+    const std::string self = info.dli_fname;
+    const size_t cut = self.rfind('/');
+    if (cut != std::string::npos) path = self.substr(0, cut + 1) + name;
+  }
+  const BbVariant* v = nullptr;
+  if (void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
+    typedef const BbVariant* (*entry_fn)(void);
+    if (entry_fn f = (entry_fn)dlsym(h, "vihds_bb_variant")) v = f();
+    if (v && (v->L != p->n_latent_states || v->HS != p->n_hidden_states || v->HP != p->n_hidden_prec || v->NLAT != nlat))
+      v = nullptr;
+  }
+  if (!v) {
+    std::snprintf(g_err, sizeof(g_err),
+                  "dr_blackbox at n_latent_species=%d n_hidden_decoder=%d n_hidden_decoder_precisions=%d n_z+n_x+n_y=%d: "
+                  "%s not found (make -C vi-hds_amd/csrc blackbox L=%d HS=%d HP=%d NLAT=%d)",
+                  p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, nlat, name, p->n_latent_states,
+                  p->n_hidden_states, p->n_hidden_prec, nlat);
+    return nullptr;  // (not cached: the file may be built later in this process)
+  }
+  loaded[key] = v;
+  return v;
+}
+static long long bb_sized_dump_floats(const BbVariant* v, const vihds_ode_problem* p) {
+  return (long long)(p->T - 1) * ode_stages(p->solver) * v->dump_fields * p->B * p->S;
+}
+
+static int build_args(const vihds_ode_problem* p, const ModelEntry* e, OdeArgs& a, const BbVariant* v = nullptr) {
   if (p->B <= 0 || p->S <= 0 || p->T < 2) return fail(VIHDS_E_BADARG, "B, S must be > 0 and T >= 2");
   if ((long long)p->B * p->S > 0x7fffffffLL) return fail(VIHDS_E_BADARG, "B*S exceeds int range");
   if (p->C < e->n_cond()) return fail(VIHDS_E_BADARG, "the model reads more treatments per row than C provides");
   if (p->model == VIHDS_MODEL_DR_BLACKBOX && p->n_const < p->C + p->D)
     return fail(VIHDS_E_BADARG, "dr_blackbox: n_const must cover the C treatments and the D-wide device one-hot");
-  const int ns = e->n_slots() + (e->neural_prec ? 0 : 4);
+  const int ns = v ? v->n_slots : e->n_slots() + (e->neural_prec ? 0 : 4);
   std::memset(&a, 0, sizeof(a));
   a.B = p->B; a.S = p->S; a.T = p->T; a.C = p->C; a.n = p->B * p->S;
   a.solver = p->solver; a.kernel_variant = p->kernel_variant; a.logp_grad_broadcast = p->logp_grad_broadcast; a.D = p->D; a.n_const = p->n_const; a.init_latent = p->init_latent; a.init_prec = p->init_prec;
@@ -181,9 +242,9 @@ int vihds_model_n_weights(const vihds_ode_problem* p) {
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
   if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
-    if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
-      return VIHDS_E_UNSUPPORTED;
-    return bb_n_weights(p->n_const);
+    if (bb_builtin(p)) return bb_n_weights(p->n_const);
+    const BbVariant* v = bb_sized(p);
+    return v ? v->n_weights(p->n_const) : VIHDS_E_UNSUPPORTED;
   }
   const int n_in = e->n_states() - 4 + 1;
   const int H = p->n_hidden_prec;
@@ -267,7 +328,11 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
 
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!p) return VIHDS_E_BADARG;
-  if (p->model == VIHDS_MODEL_DR_BLACKBOX) return bb_aux_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+    if (bb_builtin(p)) return bb_aux_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
+    const BbVariant* v = bb_sized(p);
+    return v ? bb_sized_dump_floats(v, p) + (long long)v->n_tail * p->B * p->S : VIHDS_E_UNSUPPORTED;
+  }
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
@@ -277,17 +342,43 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   return fields * (p->T - 1) * stages * p->B * p->S;
 }
 int vihds_blackbox_dump_fields(void) { return bb_dump_fields(); }
+int vihds_problem_dump_fields(const vihds_ode_problem* p) {
+  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return VIHDS_E_BADARG;
+  if (bb_builtin(p)) return bb_dump_fields();
+  const BbVariant* v = bb_sized(p);
+  return v ? v->dump_fields : VIHDS_E_UNSUPPORTED;
+}
+int vihds_problem_n_states(const vihds_ode_problem* p) {
+  if (!p) return VIHDS_E_BADARG;
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && !bb_builtin(p)) {
+    const BbVariant* v = bb_sized(p);
+    return v ? v->n_states : VIHDS_E_UNSUPPORTED;
+  }
+  return vihds_model_n_states(p->model);
+}
+int vihds_problem_n_slots(const vihds_ode_problem* p) {
+  if (!p) return VIHDS_E_BADARG;
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && !bb_builtin(p)) {
+    const BbVariant* v = bb_sized(p);
+    return v ? v->n_slots : VIHDS_E_UNSUPPORTED;
+  }
+  return vihds_model_n_slots(p->model);
+}
 int vihds_blackbox_gram_on_chip(const vihds_ode_problem* p) {
-  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return 0;
+  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_builtin(p)) return 0;
   return bb_gram_on_chip(p->solver, p->kernel_variant);
 }
 long long vihds_blackbox_tail_offset_floats(const vihds_ode_problem* p) {
   if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return VIHDS_E_BADARG;
+  if (!bb_builtin(p)) {
+    const BbVariant* v = bb_sized(p);
+    return v ? bb_sized_dump_floats(v, p) : VIHDS_E_UNSUPPORTED;
+  }
   return bb_tail_offset_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
 }
 int vihds_blackbox_gram_reduce(const vihds_ode_problem* p, const float* aux, float* g_weights, void* stream) {
   if (!p || !aux || !g_weights) return fail(VIHDS_E_BADARG, "null argument");
-  if (p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_gram_on_chip(p->solver, p->kernel_variant))
+  if (p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_builtin(p) || !bb_gram_on_chip(p->solver, p->kernel_variant))
     return fail(VIHDS_E_BADARG, "vihds_blackbox_gram_reduce: not an on-chip Gram problem (see vihds_blackbox_gram_on_chip)");
   const ModelEntry* e = entry(p->model);
   OdeArgs a;
@@ -300,27 +391,26 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* times, const float* obs, const float* weights, float* traj, float* xpred, float* logp,
                   void* stream) {
   if (!p || !theta || !times) return fail(VIHDS_E_BADARG, "null problem/theta/times");
+  const BbVariant* sized = nullptr;
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (logp && !obs) return fail(VIHDS_E_BADARG, "logp requested without obs");
   if (e->neural_prec) {
     if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
     if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
-      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
-        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
-                                         "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
+      if (!bb_builtin(p) && !(sized = bb_sized(p))) return VIHDS_E_UNSUPPORTED;
       if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
     } else if (p->n_hidden_prec > 256) {
       return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
     }
   }
   OdeArgs a;
-  int rc = build_args(p, e, a);
+  int rc = build_args(p, e, a, sized);
   if (rc) return rc;
   if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
   a.traj = traj; a.xpred = xpred; a.logp = logp;
-  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+  rc = sized ? sized->launch(false, p->solver, a, (hipStream_t)stream, nullptr) : e->launch(false, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_fwd launch");
 }
@@ -330,7 +420,9 @@ long long vihds_ode_adaptive_workspace_floats(const vihds_ode_problem* p) {
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   const long long n = (long long)p->B * p->S;
-  return 2 * (long long)e->n_states() * n + 2 * ((n + 255) / 256);
+  const int n_states = vihds_problem_n_states(p);
+  if (n_states < 0) return n_states;
+  return 2 * (long long)n_states * n + 2 * ((n + 255) / 256);
 }
 
 int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
@@ -340,27 +432,31 @@ int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, cons
     return fail(VIHDS_E_BADARG, "null argument");
   if (!solver_is_adaptive(p->solver)) return fail(VIHDS_E_BADARG, "vihds_ode_adaptive_grid needs an adaptive solver id");
   if (!(rtol > 0.f) || !(atol > 0.f)) return fail(VIHDS_E_BADARG, "rtol and atol must be positive");
+  const BbVariant* sized = nullptr;
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (e->neural_prec) {
     if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
     if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
-      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
-        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox sizes outside this build");
+      if (!bb_builtin(p) && !(sized = bb_sized(p))) return VIHDS_E_UNSUPPORTED;
       if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
     }
   }
   for (int k = 1; k < p->T; ++k)
     if (!(times_host[k] > times_host[k - 1])) return fail(VIHDS_E_BADARG, "output times must increase");
   OdeArgs a;
-  int rc = build_args(p, e, a);
+  int rc = build_args(p, e, a, sized);
   if (rc) return rc;
   if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.weights = weights;
   AdaptiveCtl ctl = {times_host, rtol, atol, workspace, grid_host, max_grid, index_host, 0};
-  g_adaptive_ctl = &ctl;
-  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
-  g_adaptive_ctl = nullptr;
+  if (sized) {
+    rc = sized->launch(false, p->solver, a, (hipStream_t)stream, &ctl);
+  } else {
+    g_adaptive_ctl = &ctl;
+    rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+    g_adaptive_ctl = nullptr;
+  }
   if (rc == VIHDS_E_UNSUPPORTED) return fail(rc, "the accepted grid does not fit max_grid points");
   if (rc == VIHDS_E_BADARG) return fail(rc, "step size underflow or non-finite error estimate");
   if (rc) return fail(rc, "adaptive step controller failed");
@@ -373,22 +469,21 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* g_xpred, const float* g_logp, float* g_theta, float* g_weights, float* aux,
                   void* stream) {
   if (!p || !theta || !times || !traj || !g_theta) return fail(VIHDS_E_BADARG, "null problem/theta/times/traj/g_theta");
+  const BbVariant* sized = nullptr;
   const ModelEntry* e = entry(p->model);
   if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
   if (!obs) return fail(VIHDS_E_BADARG, "null obs");
   if (e->neural_prec) {
     if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
     if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
-      if (!bb_check(p->n_latent_states, p->n_hidden_states, p->n_hidden_prec, p->n_const, p->C, p->D))
-        return fail(VIHDS_E_UNSUPPORTED, "dr_blackbox is built for n_latent_species=2, n_hidden_decoder=25, "
-                                         "n_hidden_decoder_precisions=20, n_z=5, n_x=5, n_y=2 (specs/dr_blackbox_icml.yaml)");
+      if (!bb_builtin(p) && !(sized = bb_sized(p))) return VIHDS_E_UNSUPPORTED;
       if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
     } else if (p->n_hidden_prec > 256) {
       return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
     }
   }
   OdeArgs a;
-  int rc = build_args(p, e, a);
+  int rc = build_args(p, e, a, sized);
   if (rc) return rc;
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
   a.g_weights = g_weights; a.aux = aux;
@@ -396,7 +491,7 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   // no per-thread accumulators, they come from the dump; g_weights then receives nothing)
   if (p->model == VIHDS_MODEL_DR_BLACKBOX && !aux) return fail(VIHDS_E_BADARG, "dr_blackbox backward needs the aux buffer");
   a.traj_in = traj; a.g_traj = g_traj; a.g_xpred = g_xpred; a.g_logp = g_logp; a.g_theta = g_theta;
-  rc = e->launch(true, p->solver, a, (hipStream_t)stream);
+  rc = sized ? sized->launch(true, p->solver, a, (hipStream_t)stream, nullptr) : e->launch(true, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_bwd launch");
 }

@@ -27,12 +27,13 @@ namespace vihds {
 template <class M>
 struct is_blackbox : std::false_type {};
 
+constexpr int BB_BSUM_MAX = 2 * (4 + 12) + 8;  // up to 12 latent species
 struct BlackboxCtx {
   float* dump;    // &aux[i]
   size_t n;       // trajectories
   size_t fstride; // floats between consecutive fields = E * n  (dump layout [F][E][n])
   int e;          // evaluation counter
-  float bsum[20]; // running sums of the second-layer pre-activation adjoints (-> output-bias gradients)
+  float bsum[BB_BSUM_MAX]; // running sums of the second-layer pre-activation adjoints (-> output-bias gradients): 2 NX + 8 used
 };
 
 __device__ __forceinline__ float bb_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.f + __expf(-x)); }
@@ -40,6 +41,7 @@ __device__ __forceinline__ float bb_sigmoid(float x) { return __builtin_amdgcn_r
 template <int L, int HS, int HP, int NZ, int NXG, int NY>
 struct Blackbox {
   static constexpr int NX = 4 + L;       // states of the NeuralStates net
+  static_assert(2 * NX + 8 <= BB_BSUM_MAX, "dr_blackbox: at most 12 latent species");
   static constexpr int N = NX + 4;       // + 4 precision states
   static constexpr int NS = NX;          // x_states handed back by NeuralPrecisions.expand
   static constexpr int NC = 0;

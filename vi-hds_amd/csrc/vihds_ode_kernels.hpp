@@ -107,7 +107,7 @@ struct bwd_ctx<M, true, true> {  // dr_blackbox
     c.n = (size_t)a.n;
     c.fstride = (size_t)(a.T - 1) * M::stages(a.solver) * a.n;
     c.e = 0;
-    VIHDS_UNROLL for (int k = 0; k < 20; ++k) c.bsum[k] = 0.f;
+    VIHDS_UNROLL for (int k = 0; k < 2 * M::NX + 8; ++k) c.bsum[k] = 0.f;
   }
 };
 

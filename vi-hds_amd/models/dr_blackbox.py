@@ -67,6 +67,8 @@ class DR_Blackbox(OdeModel):
         keeps the sampled y, which is what log q / log p are taken of).  When theta sits in a packed buffer with
         reserved rows, y + offset is written there in one launch and the simulator reads those rows; the gradient
         to y and to the offset layer is routed by ops.OdeSolveObserve (row_offset)."""
+        if self.n_y == 0:
+            return theta
         offset = self.offset_layer(dev_1hot)  # [B, n_y]
         names = ["y%d" % (i + 1) for i in range(self.n_y)]
         packed = getattr(theta, "_packed", None)
@@ -89,8 +91,14 @@ class DR_Blackbox(OdeModel):
     def neural_weights(self):
         return self._flat(self.neural_states.weight_tensors() + self.precisions.weight_tensors())
 
+    def kernel_slots(self):
+        """reference dr_blackbox.py:34-52: latents z (locals), x (globals), then the device-conditioned y."""
+        return (["z%d" % (i + 1) for i in range(self.n_z)] + ["x%d" % (i + 1) for i in range(self.n_x)]
+                + ["y%d" % (i + 1) for i in range(self.n_y)] + ["init_x", "init_rfp", "init_yfp", "init_cfp"])
+
     def problem_kwargs(self, config):
         return {
+            "slots": self.kernel_slots(),
             "n_hidden_prec": int(self.n_hidden_precisions), "n_hidden_states": int(self.n_hidden),
             "n_latent_states": int(self.n_latent_species),
             "n_const": self.n_x + self.n_y + self.n_z + self.n_treatments + self.device_depth,

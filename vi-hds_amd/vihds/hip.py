@@ -6,6 +6,7 @@ CPU fallback: if the library is missing or a call fails, a RuntimeError is raise
 """
 import ctypes
 import os
+import sys
 
 VIHDS_MAX_SLOTS = 64
 
@@ -130,6 +131,9 @@ _PROTOTYPES = {
                                   + [_P] * 10),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
+    "vihds_problem_n_states": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_problem_n_slots": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_problem_dump_fields": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_gram_on_chip": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_tail_offset_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_gram_reduce": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P]),
@@ -174,7 +178,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 5:
+        if handle.vihds_abi_version() != 6:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB
@@ -198,6 +202,37 @@ def model_slots(model_key):
     if n < 0:
         raise RuntimeError("model '%s' is not supported by this build of libvihds_hip.so" % model_key)
     return [L.vihds_model_slot_name(m, s).decode() for s in range(n)]
+
+
+BLACKBOX_BUILTIN = (2, 25, 20, 12)  # n_latent_species, n_hidden_decoder, n_hidden_decoder_precisions, n_z + n_x + n_y
+
+
+def blackbox_variant_path(L, HS, HP, NLAT):
+    return os.path.join(os.path.dirname(library_path()), "libvihds_bb_%d_%d_%d_%d.so" % (L, HS, HP, NLAT))
+
+
+def ensure_blackbox_variant(L, HS, HP, NLAT):
+    """dr_blackbox kernels are compiled per network size (csrc/vihds_bb_variant.hpp): the ICML sizes are part of
+    libvihds_hip.so, any other set is a side library next to it.  Build it here (hipcc, one to several minutes, once --
+    it stays in vi-hds_amd/lib/) when it is missing; raise loudly when that is not possible or switched off
+    (VIHDS_BLACKBOX_JIT=0).  No CPU fallback."""
+    key = (int(L), int(HS), int(HP), int(NLAT))
+    if key == BLACKBOX_BUILTIN:
+        return None
+    path = blackbox_variant_path(*key)
+    if not os.path.exists(path):
+        import subprocess
+
+        csrc = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "csrc")
+        cmd = ["make", "-C", csrc, "blackbox", "L=%d" % key[0], "HS=%d" % key[1], "HP=%d" % key[2], "NLAT=%d" % key[3]]
+        if (os.environ.get("VIHDS_BLACKBOX_JIT", "1") == "0" or "VIHDS_HIP_LIB" in os.environ
+                or not os.path.exists(os.path.join(csrc, "sized", "ode_dr_blackbox_sized.hip"))):
+            raise RuntimeError("dr_blackbox at sizes %s needs %s (build: %s)" % (key, path, " ".join(cmd)))
+        sys.stderr.write("[vihds] building the dr_blackbox kernels for sizes %s: %s\n" % (key, " ".join(cmd)))
+        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if res.returncode != 0 or not os.path.exists(path):
+            raise RuntimeError("building %s failed:\n%s" % (path, res.stdout[-2000:]))
+    return path
 
 
 def ptr(t):

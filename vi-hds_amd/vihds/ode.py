@@ -174,6 +174,13 @@ class OdeModel(nn.Module):
     def problem_kwargs(self, config):
         return {}
 
+    def kernel_slots(self):
+        """Parameter names in the order the kernel reads them (the library's table; dr_blackbox builds its own from
+        n_z / n_x / n_y)."""
+        import vihds.hip as hip
+
+        return hip.model_slots(self.model_key)
+
     def _spec(self, config, row_of, n_rows):
         key = (config.params.solver, n_rows, tuple(sorted(row_of.items())))
         if key not in self._spec_cache:
@@ -192,7 +199,7 @@ class OdeModel(nn.Module):
         log-likelihood.  Returns a DecodedSolution."""
         import vihds.hip as hip
 
-        slots = hip.model_slots(self.model_key)
+        slots = self.kernel_slots()
         packed, row_of = theta.pack(slots)
         spec = self._spec(config, row_of, packed.shape[0])
         dev = packed.device
@@ -254,7 +261,7 @@ class OdeModel(nn.Module):
                 or not default_get_value(config.params, "fused_ode_training", False)
                 or config.params.solver in hip.ADAPTIVE_SOLVERS):
             return None
-        slots = hip.model_slots(self.model_key)
+        slots = self.kernel_slots()
         packed, row_of = theta.pack(slots)
         if not packed.is_cuda or not packed.requires_grad:
             return None

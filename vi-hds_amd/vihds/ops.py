@@ -71,7 +71,7 @@ class OdeProblemSpec:
     """Host-side description of one decoder problem (struct vihds_ode_problem) for a fixed model/solver."""
 
     def __init__(self, model, solver, row_of, n_rows, C, D=0, n_hidden_prec=0, n_hidden_states=0,
-                 n_latent_states=0, n_const=0, init_latent=0.001, init_prec=1e-5, kernel_variant=0):
+                 n_latent_states=0, n_const=0, init_latent=0.001, init_prec=1e-5, kernel_variant=0, slots=None):
         if model not in hip.MODELS:
             raise KeyError("unknown model '%s'" % model)
         if solver not in hip.SOLVERS:
@@ -79,9 +79,18 @@ class OdeProblemSpec:
                 "solver '%s' is not implemented by the HIP path (available: %s; of torchdiffeq's adaptive solvers "
                 "dopri8 / DOP853 is not built)" % (solver, ", ".join(sorted(hip.SOLVERS))))
         self.model, self.solver = model, solver
-        self.slots = hip.model_slots(model)
-        self.n_states = hip.lib().vihds_model_n_states(hip.MODELS[model])
-        self.n_species = hip.lib().vihds_model_n_species(hip.MODELS[model])
+        sized = False
+        if model == "dr_blackbox":
+            # network sizes other than specs/dr_blackbox_icml.yaml: per-size kernels in a side library (built on first
+            # use); the latent slot names depend on n_z / n_x / n_y, so the plugin hands them in (`slots`)
+            sizes = (n_latent_states, n_hidden_states, n_hidden_prec, n_const - C - D)
+            sized = sizes != hip.BLACKBOX_BUILTIN
+            if sized:
+                hip.ensure_blackbox_variant(*sizes)
+                if slots is None or len(slots) != sizes[3] + 4:
+                    raise KeyError("dr_blackbox at sizes %s: pass the %d slot names (latents z.., x.., y.. then "
+                                   "init_x, init_rfp, init_yfp, init_cfp)" % (sizes, sizes[3] + 4))
+        self.slots = list(slots) if (sized and slots is not None) else hip.model_slots(model)
         missing = [s for s in self.slots if s not in row_of]
         if missing:
             raise KeyError("model '%s' needs parameters %s which the spec does not define" % (model, missing))
@@ -99,6 +108,14 @@ class OdeProblemSpec:
         self.proto.init_latent = init_latent
         self.proto.init_prec = init_prec
         self.proto.kernel_variant = kernel_variant
+        if sized:
+            self.n_states = hip.lib().vihds_problem_n_states(ctypes.byref(self.proto))
+            if self.n_states < 0:
+                hip.check(self.n_states, "vihds_problem_n_states")
+            self.n_species = self.n_states - 4
+        else:
+            self.n_states = hip.lib().vihds_model_n_states(hip.MODELS[model])
+            self.n_species = hip.lib().vihds_model_n_species(hip.MODELS[model])
         self.covers_all_rows = len({row_of[s] for s in self.slots}) == n_rows
         self.cache = {}  # device-side constants derived from this spec
 
@@ -509,7 +526,7 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
                                                  hip.current_stream())
         hip.check(rc, "vihds_blackbox_tail_grads")
         return g_w
-    F = hip.lib().vihds_blackbox_dump_fields()
+    F = hip.lib().vihds_problem_dump_fields(ctypes.byref(prob))
     HS, HP, L = prob.n_hidden_states, prob.n_hidden_prec, prob.n_latent_states
     NX = 4 + L
     NP = HS + HP
@@ -518,12 +535,22 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     plan = _blackbox_grad_plan(spec, prob, theta.device)
     g_w = torch.empty(plan["total"], device=theta.device, dtype=torch.float32)
     n_scr = hip.lib().vihds_gram_scratch_floats(E * n, plan["n_rects"], plan["rects"])
-    if n_scr <= 0:
-        raise RuntimeError("vihds_gram_scratch_floats: %s" % hip.lib().vihds_last_error().decode())
-    scratch = torch.empty(n_scr, device=theta.device, dtype=torch.float32)
-    rc = hip.lib().vihds_gram_blocks(F, E * n, plan["n_rects"], plan["rects"], hip.ptr(aux), hip.ptr(scratch),
-                                     hip.ptr(g_w), hip.current_stream())
-    hip.check(rc, "vihds_gram_blocks")
+    rc = hip.E_UNSUPPORTED
+    if n_scr > 0:
+        scratch = torch.empty(n_scr, device=theta.device, dtype=torch.float32)
+        rc = hip.lib().vihds_gram_blocks(F, E * n, plan["n_rects"], plan["rects"], hip.ptr(aux), hip.ptr(scratch),
+                                         hip.ptr(g_w), hip.current_stream())
+    if rc == hip.E_UNSUPPORTED:
+        # a network too wide for the one-pass contraction kernels (vihds_gram.hip: <= 16 16-row tile products, or
+        # <= 126 dump fields): the seven rectangles as plain library GEMMs over the dump, on the device
+        X = aux[: F * E * n].view(F, E * n)
+        for r in plan["rects"]:
+            blk = X[r.a0: r.a0 + r.na] @ X[r.b0: r.b0 + r.nb].t()
+            idx = (r.dest0 + r.dest_stride_a * torch.arange(r.na, device=X.device)[:, None]
+                   + r.dest_stride_b * torch.arange(r.nb, device=X.device)[None, :])
+            g_w[idx.reshape(-1)] = blk.reshape(-1)
+    else:
+        hip.check(rc, "vihds_gram_blocks")
     # the time-invariant input columns and the biases: one launch over the dump's tail
     rc = hip.lib().vihds_blackbox_tail_grads(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
                                              aux.data_ptr() + 4 * F * E * n, hip.ptr(plan["rest"]), hip.ptr(g_w),

@@ -172,7 +172,7 @@ def simulate_observations(settings, parameters, dataset, device, seed=0, noise=0
             v = z.exp() if d.kind == 1 else z
         th.add(d.name, v.to(device))
     dev1 = dataset.dev_1hot.to(device)
-    for name in hip.model_slots(ode.model_key):
+    for name in ode.kernel_slots():
         if name not in th.samples:  # aR / aS of the double-receiver family
             setattr(th, name, torch.full((n, 1), 1.5, device=device))
     sol = ode.solve(settings, dataset.times, th, dataset.inputs.to(device), dev1)
