@@ -1528,3 +1528,58 @@ def test_sized_blackbox_every_solver_against_the_restatement(solver):
     th_ref = torch.stack([th_cpu[n].grad if th_cpu[n].grad is not None else torch.zeros(fx.B, fx.S) for n in slots])
     live = th_ref.abs().amax(dim=(1, 2)) > 0
     assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL
+
+
+def test_wide_blackbox_default_hidden_size_against_the_restatement():
+    """dr_blackbox with the reference's DEFAULT n_hidden_decoder = 50 (vihds/config.py:71 -- what a YAML that omits the
+    key gets; 167 dump fields: past the one-pass contraction kernels' limits, so the weight gradients take the
+    library-GEMM route of ops.blackbox_weight_grads): libvihds_bb_2_50_20_12.so on the ICML fixture's inputs with
+    seeded random weights, rk4, forward and every gradient against the CPU restatement's autograd.  The side library
+    takes ~3 min to build: the test runs when it is present (it travels with the tree) or VIHDS_TEST_BUILD_WIDE=1."""
+    import os
+    from vihds import hip, ops
+    import hip_util as H
+
+    sizes = (2, 50, 20, 12)
+    if not os.path.exists(hip.blackbox_variant_path(*sizes)) and os.environ.get("VIHDS_TEST_BUILD_WIDE", "0") != "1":
+        pytest.skip("libvihds_bb_2_50_20_12.so not built (make -C vi-hds_amd/csrc blackbox L=2 HS=50 HP=20 NLAT=12)")
+    fx = Fixture("dr_blackbox_icml_tiny_modeuler")
+    L, HS, HP, NLAT = sizes
+    NX, D, C = 4 + L, fx.t("dev_1hot").shape[1], 2
+    nc = NLAT + C + D
+    g = torch.Generator().manual_seed(21)
+    rnd = lambda *shape: ((torch.rand(*shape, generator=g) - 0.5) * 0.6).requires_grad_(True)  # noqa: E731
+    states_w = {"hid_w": rnd(HS, NX + nc), "hid_b": rnd(HS), "prod_w": rnd(NX, HS), "prod_b": rnd(NX),
+                "degr_w": rnd(NX, HS), "degr_b": rnd(NX)}
+    prec_w = {"hid_w": rnd(HP, 1 + NX + nc), "hid_b": rnd(HP), "prod_w": rnd(4, HP), "prod_b": rnd(4),
+              "degr_w": rnd(4, HP), "degr_b": rnd(4)}
+    order = ("hid_w", "hid_b", "prod_w", "prod_b", "degr_w", "degr_b")
+    wts = torch.cat([states_w[k].detach().reshape(-1) for k in order] + [prec_w[k].detach().reshape(-1) for k in order])
+    wts = wts.to(DEV).requires_grad_(True)
+    th_cpu = fx.theta_dict(requires_grad=True)
+    slots = hip.model_slots("dr_blackbox")
+    theta = torch.stack([th_cpu[n].detach().expand(fx.B, fx.S) for n in slots]).to(DEV).requires_grad_(True)
+    spec = ops.OdeProblemSpec("dr_blackbox", "rk4", {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
+                               n_hidden_prec=HP, n_hidden_states=HS, n_latent_states=L, n_const=nc, slots=slots)
+    dev = fx.t("dev_1hot")
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
+                                                  fx.t("observations", DEV), dev.to(DEV), wts)
+    bb = dict(dev_1hot=dev, states_w=states_w, prec_w=prec_w, n_x=5, n_y=2, n_z=5, n_latent_species=L,
+              init_latent_species=0.001, init_prec=1e-5)
+    xs, xp, prec = O.decode("dr_blackbox", th_cpu, fx.t("inputs"), fx.t("times"), "rk4", prec_w=prec_w, blackbox=bb)
+    lpo = O.log_prob_observations(xp, fx.t("observations"), prec)
+    full = H.view_bsnt(traj)
+    assert rel_err(full[:, :, :-4], xs.detach()) < TOL
+    assert rel_err(full[:, :, -4:], prec.detach()) < TOL
+    assert rel_err(H.view_bs4(logp), lpo.detach(), dim=2) < TOL
+    coef = torch.rand(lpo.shape, generator=g)  # [B,S,4]
+    (H.view_bs4(logp) * coef.to(DEV)).sum().backward()
+    (lpo * coef).sum().backward()
+    o = 0
+    for name, blk in [("states." + k, states_w[k].grad) for k in order] + [("prec." + k, prec_w[k].grad) for k in order]:
+        k = blk.numel()
+        assert rel_err(wts.grad[o: o + k], blk.reshape(-1)) < 2e-3, name
+        o += k
+    th_ref = torch.stack([th_cpu[n].grad if th_cpu[n].grad is not None else torch.zeros(fx.B, fx.S) for n in slots])
+    live = th_ref.abs().amax(dim=(1, 2)) > 0
+    assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL

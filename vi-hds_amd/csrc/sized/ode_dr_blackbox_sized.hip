@@ -1,6 +1,9 @@
 // One dr_blackbox size set as a side library (see ../vihds_bb_variant.hpp); built with
 //   -DVIHDS_BB_L=<n_latent_species> -DVIHDS_BB_HS=<n_hidden_decoder> -DVIHDS_BB_HP=<n_hidden_decoder_precisions>
 //   -DVIHDS_BB_NLAT=<n_z + n_x + n_y>
+// as nine objects compiled in parallel (Makefile, target `blackbox`): one per solver (-DVIHDS_ONLY_SOLVER=<id>: the
+// kernels of that solver behind vihds_bb_launch_<id>) and the table object (no VIHDS_ONLY_SOLVER: the BbVariant
+// record that dispatches to them).
 #include "../vihds_ode_kernels.hpp"
 #include "../vihds_bb_variant.hpp"
 
@@ -9,14 +12,37 @@
 #endif
 
 namespace vihds {
-thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own copy (it does not link against libvihds_hip.so)
 using BBV = Blackbox<VIHDS_BB_L, VIHDS_BB_HS, VIHDS_BB_HP, VIHDS_BB_NLAT, 0, 0>;
-static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
-static int launch_sized(bool backward, int solver, const OdeArgs& a, hipStream_t st, AdaptiveCtl* ctl) {
+typedef int (*bb_launch_fn)(bool, int, const OdeArgs&, hipStream_t, AdaptiveCtl*);
+}  // namespace vihds
+
+#define VIHDS_BB_CAT2(a, b) a##b
+#define VIHDS_BB_CAT(a, b) VIHDS_BB_CAT2(a, b)
+
+#ifdef VIHDS_ONLY_SOLVER
+extern "C" int VIHDS_BB_CAT(vihds_bb_launch_, VIHDS_ONLY_SOLVER)(bool backward, int solver, const vihds::OdeArgs& a,
+                                                                hipStream_t st, vihds::AdaptiveCtl* ctl) {
+  using namespace vihds;
   g_adaptive_ctl = ctl;
   const int rc = launch_ode<BBV>(backward, solver, a, st);
   g_adaptive_ctl = nullptr;
   return rc;
+}
+#else
+#define VIHDS_BB_DECL(k) \
+  extern "C" int vihds_bb_launch_##k(bool, int, const vihds::OdeArgs&, hipStream_t, vihds::AdaptiveCtl*);
+VIHDS_BB_DECL(0) VIHDS_BB_DECL(1) VIHDS_BB_DECL(2) VIHDS_BB_DECL(3) VIHDS_BB_DECL(4) VIHDS_BB_DECL(5) VIHDS_BB_DECL(6)
+VIHDS_BB_DECL(7)
+static_assert(VIHDS_SOLVER_COUNT == 8, "one object per solver: extend the table and the Makefile");
+namespace vihds {
+thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own (it does not link against libvihds_hip.so)
+static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
+static int launch_sized(bool backward, int solver, const OdeArgs& a, hipStream_t st, AdaptiveCtl* ctl) {
+  static const bb_launch_fn table[VIHDS_SOLVER_COUNT] = {vihds_bb_launch_0, vihds_bb_launch_1, vihds_bb_launch_2,
+                                                         vihds_bb_launch_3, vihds_bb_launch_4, vihds_bb_launch_5,
+                                                         vihds_bb_launch_6, vihds_bb_launch_7};
+  if (solver < 0 || solver >= VIHDS_SOLVER_COUNT) return VIHDS_E_BADARG;
+  return table[solver](backward, solver, a, st, ctl);
 }
 }  // namespace vihds
 
@@ -26,3 +52,4 @@ extern "C" const vihds::BbVariant* vihds_bb_variant(void) {
                               BBV::NF,    BBV::NTAIL,  n_weights_sized, launch_sized};
   return &v;
 }
+#endif

@@ -512,22 +512,37 @@ struct AdaptiveCtl {
   int result;
 };
 extern thread_local AdaptiveCtl* g_adaptive_ctl;
-template <class M>
+template <class M, int ONLY>
 inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
                          float* grid_host, int max_grid, int* index_host, hipStream_t st);
 
-template <class M>
+// -DVIHDS_ONLY_SOLVER=<id>: this translation unit holds the kernels of one solver only (the per-size dr_blackbox side
+// libraries compile their eight solvers as eight objects in parallel: sized/ode_dr_blackbox_sized.hip)
+// (ONLY is a template parameter of the dispatchers so that the eight objects hold eight DIFFERENT functions: the same
+// inline function with different bodies would be folded into one by the linker)
+#ifdef VIHDS_ONLY_SOLVER
+constexpr int kOnlySolver = VIHDS_ONLY_SOLVER;
+#else
+constexpr int kOnlySolver = -1;
+#endif
+template <int ONLY>
+constexpr bool solver_built_in(int sv) { return ONLY < 0 || sv == ONLY; }
+
+template <class M, int ONLY = kOnlySolver>
 inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   if (AdaptiveCtl* ctl = g_adaptive_ctl) {
-    ctl->result = adaptive_grid<M>(solver, a, ctl->times_host, ctl->rtol, ctl->atol, ctl->workspace, ctl->grid_host,
+    ctl->result = adaptive_grid<M, ONLY>(solver, a, ctl->times_host, ctl->rtol, ctl->atol, ctl->workspace, ctl->grid_host,
                                    ctl->max_grid, ctl->index_host, st);
     return ctl->result < 0 ? ctl->result : VIHDS_OK;
   }
 #define VIHDS_CASE(SV)                                           \
   case SV:                                                       \
-    if (backward) launch_bwd_s<M, SV>(a, st);                    \
-    else launch_fwd_s<M, SV>(a, st);                             \
-    return VIHDS_OK;
+    if constexpr (solver_built_in<ONLY>(SV)) {                            \
+      if (backward) launch_bwd_s<M, SV>(a, st);                  \
+      else launch_fwd_s<M, SV>(a, st);                           \
+      return VIHDS_OK;                                           \
+    }                                                            \
+    break;
   switch (solver) {
     VIHDS_CASE(VIHDS_SOLVER_MODEULER)
     VIHDS_CASE(VIHDS_SOLVER_MODEULERWHILE)
@@ -694,14 +709,19 @@ inline int adaptive_grid_s(const OdeArgs& a, const float* times_host, float rtol
   return ng;
 }
 
-template <class M>
+template <class M, int ONLY>
 inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
                          float* grid_host, int max_grid, int* index_host, hipStream_t st) {
+#define VIHDS_CASE(SV)       \
+  case SV:                   \
+    if constexpr (solver_built_in<ONLY>(SV)) return adaptive_grid_s<M, SV>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st); \
+    break;
   switch (solver) {
-    case VIHDS_SOLVER_DOPRI5: return adaptive_grid_s<M, VIHDS_SOLVER_DOPRI5>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
-    case VIHDS_SOLVER_BOSH3: return adaptive_grid_s<M, VIHDS_SOLVER_BOSH3>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
-    case VIHDS_SOLVER_ADAPTIVE_HEUN: return adaptive_grid_s<M, VIHDS_SOLVER_ADAPTIVE_HEUN>(a, times_host, rtol, atol, workspace, grid_host, max_grid, index_host, st);
+    VIHDS_CASE(VIHDS_SOLVER_DOPRI5)
+    VIHDS_CASE(VIHDS_SOLVER_BOSH3)
+    VIHDS_CASE(VIHDS_SOLVER_ADAPTIVE_HEUN)
   }
+#undef VIHDS_CASE
   return VIHDS_E_BADARG;
 }
 
