@@ -500,7 +500,32 @@ def _blackbox_grad_plan(spec, prob, device):
     for k, r in enumerate(rects):
         (rect_arr[k].a0, rect_arr[k].na, rect_arr[k].b0, rect_arr[k].nb, rect_arr[k].dest0, rect_arr[k].dest_stride_a,
          rect_arr[k].dest_stride_b) = r
-    plan = {"rects": rect_arr, "n_rects": len(rects), "rest": ti(rest), "total": o[12]}
+    # groups of rectangles that fit one vihds_gram_blocks plan each (vihds_gram.hip: GM_MAX_PROD = 16 products and 16
+    # distinct 16-row blocks on the matrix cores; 128 4x4 register tiles in the LDS-tiled kernel), greedy in order
+    def cost(group):
+        blocks, prods, tiles = set(), 0, 0
+        for (a0, na, b0, nb, _, _, _) in group:
+            ta = [(a0 + 16 * i, min(16, na - 16 * i)) for i in range((na + 15) // 16)]
+            tb = [(b0 + 16 * i, min(16, nb - 16 * i)) for i in range((nb + 15) // 16)]
+            blocks |= set(ta) | set(tb)
+            prods += len(ta) * len(tb)
+            tiles += ((na + 3) // 4) * ((nb + 3) // 4)
+        return prods <= 16 and len(blocks) <= 16 and tiles <= 128
+    groups, cur = [], []
+    for r in rects:
+        if cur and not cost(cur + [r]):
+            groups.append(cur)
+            cur = []
+        cur.append(r)
+    groups.append(cur)
+    group_arrs, k0 = [], 0
+    for grp in groups:
+        arr = (hip.GramRect * len(grp))()
+        for k in range(len(grp)):
+            ctypes.pointer(arr[k])[0] = rect_arr[k0 + k]
+        k0 += len(grp)
+        group_arrs.append(arr)
+    plan = {"rects": rect_arr, "n_rects": len(rects), "groups": group_arrs, "rest": ti(rest), "total": o[12]}
     assert len(set(dest) | set(rest)) == o[12] == len(dest) + len(rest)
     spec.cache[key] = plan
     return plan
@@ -534,23 +559,27 @@ def blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot):
     E = (aux.numel() - n_tail * n) // (F * n)
     plan = _blackbox_grad_plan(spec, prob, theta.device)
     g_w = torch.empty(plan["total"], device=theta.device, dtype=torch.float32)
-    n_scr = hip.lib().vihds_gram_scratch_floats(E * n, plan["n_rects"], plan["rects"])
-    rc = hip.E_UNSUPPORTED
-    if n_scr > 0:
-        scratch = torch.empty(n_scr, device=theta.device, dtype=torch.float32)
-        rc = hip.lib().vihds_gram_blocks(F, E * n, plan["n_rects"], plan["rects"], hip.ptr(aux), hip.ptr(scratch),
-                                         hip.ptr(g_w), hip.current_stream())
-    if rc == hip.E_UNSUPPORTED:
-        # a network too wide for the one-pass contraction kernels (vihds_gram.hip: <= 16 16-row tile products, or
-        # <= 126 dump fields): the seven rectangles as plain library GEMMs over the dump, on the device
-        X = aux[: F * E * n].view(F, E * n)
-        for r in plan["rects"]:
-            blk = X[r.a0: r.a0 + r.na] @ X[r.b0: r.b0 + r.nb].t()
-            idx = (r.dest0 + r.dest_stride_a * torch.arange(r.na, device=X.device)[:, None]
-                   + r.dest_stride_b * torch.arange(r.nb, device=X.device)[None, :])
-            g_w[idx.reshape(-1)] = blk.reshape(-1)
-    else:
-        hip.check(rc, "vihds_gram_blocks")
+    # one pass over the dump when the seven rectangles fit the contraction kernels' plan (<= 16 products of 16-row
+    # blocks, <= 16 distinct blocks: the ICML sizes), otherwise one pass per group of rectangles that does (a wider
+    # network, e.g. the default n_hidden_decoder = 50: two groups)
+    for group in plan["groups"]:
+        n_scr = hip.lib().vihds_gram_scratch_floats(E * n, len(group), group)
+        rc = hip.E_UNSUPPORTED
+        if n_scr > 0:
+            scratch = torch.empty(n_scr, device=theta.device, dtype=torch.float32)
+            rc = hip.lib().vihds_gram_blocks(F, E * n, len(group), group, hip.ptr(aux), hip.ptr(scratch), hip.ptr(g_w),
+                                             hip.current_stream())
+        if rc == hip.E_UNSUPPORTED:
+            # outside the kernels' regime (a single rectangle past the plan limits, or a column count that is not a
+            # multiple of 64 with more than 126 dump fields): the rectangles as library GEMMs over the dump, on the device
+            X = aux[: F * E * n].view(F, E * n)
+            for r in group:
+                blk = X[r.a0: r.a0 + r.na] @ X[r.b0: r.b0 + r.nb].t()
+                idx = (r.dest0 + r.dest_stride_a * torch.arange(r.na, device=X.device)[:, None]
+                       + r.dest_stride_b * torch.arange(r.nb, device=X.device)[None, :])
+                g_w[idx.reshape(-1)] = blk.reshape(-1)
+        else:
+            hip.check(rc, "vihds_gram_blocks")
     # the time-invariant input columns and the biases: one launch over the dump's tail
     rc = hip.lib().vihds_blackbox_tail_grads(ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot),
                                              aux.data_ptr() + 4 * F * E * n, hip.ptr(plan["rest"]), hip.ptr(g_w),
