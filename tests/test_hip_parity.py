@@ -1530,12 +1530,15 @@ def test_sized_blackbox_every_solver_against_the_restatement(solver):
     assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL
 
 
-def test_wide_blackbox_default_hidden_size_against_the_restatement():
+@pytest.mark.parametrize("solver", ["rk4", "euler"])
+def test_wide_blackbox_default_hidden_size_against_the_restatement(solver):
     """dr_blackbox with the reference's DEFAULT n_hidden_decoder = 50 (vihds/config.py:71 -- what a YAML that omits the
-    key gets; 167 dump fields: past the one-pass contraction kernels' limits, so the weight gradients take the
-    library-GEMM route of ops.blackbox_weight_grads): libvihds_bb_2_50_20_12.so on the ICML fixture's inputs with
-    seeded random weights, rk4, forward and every gradient against the CPU restatement's autograd.  The side library
-    takes ~3 min to build: the test runs when it is present (it travels with the tree) or VIHDS_TEST_BUILD_WIDE=1."""
+    key gets; 167 dump fields and 20 tile products: past ONE contraction plan): libvihds_bb_2_50_20_12.so on the ICML
+    fixture's inputs with seeded random weights, forward and every gradient against the CPU restatement's autograd.
+    rk4: 10 880 dump columns, the weight gradients go through two plan-sized vihds_gram_blocks passes; euler: 2 720
+    columns (not a multiple of 64, too many fields for the LDS-tiled kernel), the library-GEMM route of
+    ops.blackbox_weight_grads.  The test runs when the side library is present (it travels with the tree) or
+    VIHDS_TEST_BUILD_WIDE=1."""
     import os
     from vihds import hip, ops
     import hip_util as H
@@ -1559,14 +1562,14 @@ def test_wide_blackbox_default_hidden_size_against_the_restatement():
     th_cpu = fx.theta_dict(requires_grad=True)
     slots = hip.model_slots("dr_blackbox")
     theta = torch.stack([th_cpu[n].detach().expand(fx.B, fx.S) for n in slots]).to(DEV).requires_grad_(True)
-    spec = ops.OdeProblemSpec("dr_blackbox", "rk4", {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
+    spec = ops.OdeProblemSpec("dr_blackbox", solver, {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
                                n_hidden_prec=HP, n_hidden_states=HS, n_latent_states=L, n_const=nc, slots=slots)
     dev = fx.t("dev_1hot")
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
                                                   fx.t("observations", DEV), dev.to(DEV), wts)
     bb = dict(dev_1hot=dev, states_w=states_w, prec_w=prec_w, n_x=5, n_y=2, n_z=5, n_latent_species=L,
               init_latent_species=0.001, init_prec=1e-5)
-    xs, xp, prec = O.decode("dr_blackbox", th_cpu, fx.t("inputs"), fx.t("times"), "rk4", prec_w=prec_w, blackbox=bb)
+    xs, xp, prec = O.decode("dr_blackbox", th_cpu, fx.t("inputs"), fx.t("times"), solver, prec_w=prec_w, blackbox=bb)
     lpo = O.log_prob_observations(xp, fx.t("observations"), prec)
     full = H.view_bsnt(traj)
     assert rel_err(full[:, :, :-4], xs.detach()) < TOL
