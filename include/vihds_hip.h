@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 6
+#define VIHDS_ABI_VERSION 7
 
 /* error codes */
 #define VIHDS_OK 0
@@ -70,7 +70,9 @@ enum vihds_solver {
   VIHDS_SOLVER_DOPRI5 = 5,        /* Dormand-Prince 5(4) */
   VIHDS_SOLVER_BOSH3 = 6,         /* Bogacki-Shampine 3(2) */
   VIHDS_SOLVER_ADAPTIVE_HEUN = 7, /* Heun-Euler 2(1) */
-  VIHDS_SOLVER_COUNT = 8
+  VIHDS_SOLVER_DOPRI8 = 8,        /* `solver: dopri8`: an 8th-order Dormand-Prince pair -- Hairer's DOP853 (12 stages), NOT
+                                     torchdiffeq's 8(7) 13-stage tableau (unavailable offline); same controller */
+  VIHDS_SOLVER_COUNT = 9
 };
 
 #define VIHDS_MAX_SLOTS 64
@@ -141,7 +143,7 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   float* g_weights, float* aux, void* stream);
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
 
-/* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
+/* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN / DOPRI8; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
  * odeint / odeint_adjoint, absent from the tree: restated, parity unpinned).  Step-size controller, SYNCHRONOUS on
  * `stream` (one device round trip per trial step): walks the whole batch from times_host[0] to times_host[T-1] with ONE
  * step size for all trajectories (error ratio = mean over all state elements of (err / (atol + rtol max(|y0|,|y1|)))^2,

@@ -178,6 +178,21 @@ ADAPTIVE_TABLEAUS = {
 }
 
 
+def _dop853_tableau():
+    """`solver: dopri8` as the HIP path runs it: Hairer's 12-stage Dormand-Prince 8(5,3) pair (DOP853) from scipy's
+    coefficient tables, error estimate = the pair's 5th-order one (E5) -- a stand-in for torchdiffeq==0.1's dopri8
+    (Dormand-Prince 8(7), 13 stages), whose tableau is not available offline: same family, order and controller, NOT
+    the same coefficients (vi-hds_amd/csrc/vihds_dop853_tableau.hpp).  Parity unpinned like the other adaptive pairs."""
+    from scipy.integrate._ivp import dop853_coefficients as d
+
+    ns = d.N_STAGES
+    a = [[float(d.A[s, r]) for r in range(s)] for s in range(ns)] + [[float(v) for v in d.B]]
+    return dict(order=8, c=[float(v) for v in d.C[:ns]] + [1.0], a=a, e=[float(v) for v in d.E5])
+
+
+ADAPTIVE_TABLEAUS["dopri8"] = _dop853_tableau()
+
+
 def _rk_pair_step(tab, func, t, h, y, with_error):
     """One step of the propagated (higher-order) solution; the last row of `a` holds its weights (FSAL form)."""
     ns = len(tab["a"]) - 1

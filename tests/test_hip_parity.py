@@ -538,8 +538,8 @@ def test_iw_summaries_match_oracle():
 def test_bad_arguments_fail_loudly():
     from vihds import hip, ops
 
-    with pytest.raises(NotImplementedError):  # torchdiffeq's DOP853: the one adaptive solver of the reference's test that is not built
-        ops.OdeProblemSpec("dr_constant", "dopri8", {}, 1, C=2)
+    with pytest.raises(NotImplementedError):  # a solver name neither the reference nor torchdiffeq knows
+        ops.OdeProblemSpec("dr_constant", "rk45", {}, 1, C=2)
     with pytest.raises(KeyError):
         ops.OdeProblemSpec("dr_constant", "rk4", {"r": 0}, 1, C=2)
     with pytest.raises(RuntimeError):
@@ -1293,7 +1293,7 @@ def test_time_parallel_training_kernel_at_the_config3_sizes(B, S):
 
 
 # ---- adaptive solvers (torchdiffeq's dopri5 / bosh3 / adaptive_heun; reference vihds/ode.py:79-81) ---------------------
-ADAPTIVE = ["dopri5", "bosh3", "adaptive_heun"]
+ADAPTIVE = ["dopri5", "bosh3", "adaptive_heun", "dopri8"]  # ("dopri8": the DOP853 coefficients, vihds_dop853_tableau.hpp)
 
 
 @pytest.mark.parametrize("solver", ADAPTIVE)
@@ -1363,7 +1363,7 @@ def test_adaptive_controller_grid_and_solution(solver):
     fx = Fixture("dr_constant_icml_tiny_modeuler")
     th, row_of = H.pack_theta(fx, DEV)
     spec = H.spec_for(fx, row_of, th.shape[0], solver, 0)
-    rtol, atol = (1e-5, 1e-7) if solver != "dopri5" else (1e-6, 1e-8)
+    rtol, atol = (1e-5, 1e-7) if solver not in ("dopri5", "dopri8") else (1e-6, 1e-8)
     grid, index = ops.adaptive_grid(spec, th, fx.t("inputs", DEV), fx.t("times"), None, None, rtol, atol)
     gh = grid.cpu()
     assert (gh[1:] > gh[:-1]).all()
@@ -1387,7 +1387,7 @@ def test_adaptive_controller_grid_and_solution(solver):
 
 
 def test_adaptive_solvers_through_the_plugin_surface_meet_the_reference_criterion():
-    """reference tests/test_ode_solvers.py:66-89: the final states of modeuler, modeulerwhile, dopri5, midpoint, rk4 (+ the
+    """reference tests/test_ode_solvers.py:66-89: the final states of modeuler, modeulerwhile, dopri5, dopri8, midpoint, rk4 (+ the
     other adaptive pairs here) and of the `adjoint_solver` variants agree to a coefficient of variation < 5 %; and a
     training step with an adaptive solver runs end to end (loss finite, gradients on every encoder parameter)."""
     import e2e_util as E
@@ -1396,8 +1396,8 @@ def test_adaptive_solvers_through_the_plugin_surface_meet_the_reference_criterio
 
     finals = []
     for solver, adjoint in [("modeuler", False), ("modeulerwhile", False), ("dopri5", False), ("bosh3", False),
-                            ("adaptive_heun", False), ("midpoint", False), ("rk4", False), ("dopri5", True),
-                            ("midpoint", True), ("rk4", True)]:
+                            ("adaptive_heun", False), ("dopri8", False), ("midpoint", False), ("rk4", False),
+                            ("dopri5", True), ("dopri8", True), ("midpoint", True), ("rk4", True)]:
         fx = Fixture("dr_constant_icml_tiny_modeuler")
         args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, adjoint_solver=adjoint, solver_rtol=1e-5,
                                                                 solver_atol=1e-7)

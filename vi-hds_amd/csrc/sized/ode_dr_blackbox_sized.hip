@@ -1,7 +1,7 @@
 // One dr_blackbox size set as a side library (see ../vihds_bb_variant.hpp); built with
 //   -DVIHDS_BB_L=<n_latent_species> -DVIHDS_BB_HS=<n_hidden_decoder> -DVIHDS_BB_HP=<n_hidden_decoder_precisions>
 //   -DVIHDS_BB_NLAT=<n_z + n_x + n_y>
-// as nine objects compiled in parallel (Makefile, target `blackbox`): one per solver (-DVIHDS_ONLY_SOLVER=<id>: the
+// as ten objects compiled in parallel (Makefile, target `blackbox`): one per solver (-DVIHDS_ONLY_SOLVER=<id>: the
 // kernels of that solver behind vihds_bb_launch_<id>) and the table object (no VIHDS_ONLY_SOLVER: the BbVariant
 // record that dispatches to them).
 #include "../vihds_ode_kernels.hpp"
@@ -32,15 +32,15 @@ extern "C" int VIHDS_BB_CAT(vihds_bb_launch_, VIHDS_ONLY_SOLVER)(bool backward, 
 #define VIHDS_BB_DECL(k) \
   extern "C" int vihds_bb_launch_##k(bool, int, const vihds::OdeArgs&, hipStream_t, vihds::AdaptiveCtl*);
 VIHDS_BB_DECL(0) VIHDS_BB_DECL(1) VIHDS_BB_DECL(2) VIHDS_BB_DECL(3) VIHDS_BB_DECL(4) VIHDS_BB_DECL(5) VIHDS_BB_DECL(6)
-VIHDS_BB_DECL(7)
-static_assert(VIHDS_SOLVER_COUNT == 8, "one object per solver: extend the table and the Makefile");
+VIHDS_BB_DECL(7) VIHDS_BB_DECL(8)
+static_assert(VIHDS_SOLVER_COUNT == 9, "one object per solver: extend the table and the Makefile");
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own (it does not link against libvihds_hip.so)
 static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
 static int launch_sized(bool backward, int solver, const OdeArgs& a, hipStream_t st, AdaptiveCtl* ctl) {
   static const bb_launch_fn table[VIHDS_SOLVER_COUNT] = {vihds_bb_launch_0, vihds_bb_launch_1, vihds_bb_launch_2,
                                                          vihds_bb_launch_3, vihds_bb_launch_4, vihds_bb_launch_5,
-                                                         vihds_bb_launch_6, vihds_bb_launch_7};
+                                                         vihds_bb_launch_6, vihds_bb_launch_7, vihds_bb_launch_8};
   if (solver < 0 || solver >= VIHDS_SOLVER_COUNT) return VIHDS_E_BADARG;
   return table[solver](backward, solver, a, st, ctl);
 }

@@ -169,7 +169,7 @@ struct Blackbox {
     for (int k = 0; k < 2 * NX + 8; ++k) d[(size_t)(NP + k) * a.n + i] = ctx.bsum[k];
   }
   __host__ __device__ static int stages(int solver) {
-    if (solver >= VIHDS_SOLVER_DOPRI5) return solver == VIHDS_SOLVER_DOPRI5 ? 6 : (solver == VIHDS_SOLVER_BOSH3 ? 3 : 2);
+    if (solver >= VIHDS_SOLVER_DOPRI5) return adaptive_stages(solver);
     return solver == VIHDS_SOLVER_EULER ? 1 : (solver == VIHDS_SOLVER_RK4 ? 4 : 2);
   }
   __device__ static int dump_evals(const OdeArgs& a) { return (a.T - 1) * stages(a.solver); }

@@ -18,8 +18,8 @@
 #include "../../include/vihds_hip.h"
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
-#include "vihds_blackbox.hpp"
 #include "vihds_rk_adaptive.hpp"
+#include "vihds_blackbox.hpp"
 
 namespace vihds {
 
@@ -552,6 +552,7 @@ inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t s
     VIHDS_CASE(VIHDS_SOLVER_DOPRI5)
     VIHDS_CASE(VIHDS_SOLVER_BOSH3)
     VIHDS_CASE(VIHDS_SOLVER_ADAPTIVE_HEUN)
+    VIHDS_CASE(VIHDS_SOLVER_DOPRI8)
   }
 #undef VIHDS_CASE
   return VIHDS_E_BADARG;
@@ -720,6 +721,7 @@ inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, 
     VIHDS_CASE(VIHDS_SOLVER_DOPRI5)
     VIHDS_CASE(VIHDS_SOLVER_BOSH3)
     VIHDS_CASE(VIHDS_SOLVER_ADAPTIVE_HEUN)
+    VIHDS_CASE(VIHDS_SOLVER_DOPRI8)
   }
 #undef VIHDS_CASE
   return VIHDS_E_BADARG;

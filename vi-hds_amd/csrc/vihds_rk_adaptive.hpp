@@ -8,6 +8,8 @@
 // the accepted steps (torchdiffeq differentiates through its python loop, or -- odeint_adjoint -- integrates the
 // continuous adjoint backwards; `adjoint_solver: true` maps to the same discrete adjoint here).
 //
+// `dopri8` is served by a same-order stand-in (DOP853), see Tableau<VIHDS_SOLVER_DOPRI8> below.
+//
 // Structure: (1) the controller (vihds_ode_adaptive_grid, synchronous, host-driven) walks the batch through trial steps
 // with `ode_trial_kernel` and returns the accepted time grid; (2) the ordinary fixed-grid forward / adjoint kernels then
 // integrate on that grid with the pair's higher-order tableau (`rk_step_generic`, `rk_step_generic_vjp`).
@@ -15,6 +17,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/vihds_hip.h"
+#include "vihds_dop853_tableau.hpp"
 
 namespace vihds {
 
@@ -78,9 +81,21 @@ struct Tableau<VIHDS_SOLVER_ADAPTIVE_HEUN> {
   static constexpr float e(int s) { return s == 0 ? -0.5f : (s == 1 ? 0.5f : 0.f); }
 };
 
-constexpr bool solver_is_adaptive(int solver) { return solver >= VIHDS_SOLVER_DOPRI5 && solver <= VIHDS_SOLVER_ADAPTIVE_HEUN; }
+// `solver: dopri8`: the 12-stage Dormand-Prince 8(5,3) pair (DOP853; vihds_dop853_tableau.hpp says why not torchdiffeq's
+// own 8(7) tableau), FSAL form like the others: evaluation 13 = f(t + h, y') carries the last error weight
+template <>
+struct Tableau<VIHDS_SOLVER_DOPRI8> {
+  static constexpr int NS = Dop853Tab::NS;
+  static constexpr int ORDER = 8;
+  static constexpr float c(int s) { return Dop853Tab::c(s); }
+  static constexpr float a(int s, int r) { return Dop853Tab::a(s, r); }
+  static constexpr float b(int s) { return Dop853Tab::a(NS, s); }
+  static constexpr float e(int s) { return Dop853Tab::e(s); }
+};
+
+constexpr bool solver_is_adaptive(int solver) { return solver >= VIHDS_SOLVER_DOPRI5 && solver <= VIHDS_SOLVER_DOPRI8; }
 __host__ __device__ constexpr int adaptive_stages(int solver) {
-  return solver == VIHDS_SOLVER_DOPRI5 ? 6 : (solver == VIHDS_SOLVER_BOSH3 ? 3 : 2);
+  return solver == VIHDS_SOLVER_DOPRI8 ? 12 : (solver == VIHDS_SOLVER_DOPRI5 ? 6 : (solver == VIHDS_SOLVER_BOSH3 ? 3 : 2));
 }
 
 // one step y -> y' of the propagated solution; err (optional) = the embedded error estimate (one more evaluation,

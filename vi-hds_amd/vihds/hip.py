@@ -31,8 +31,10 @@ MODELS = {
 }
 E_UNSUPPORTED = -2  # VIHDS_E_UNSUPPORTED (include/vihds_hip.h)
 SOLVERS = {"modeuler": 0, "modeulerwhile": 1, "euler": 2, "midpoint": 3, "rk4": 4, "dopri5": 5, "bosh3": 6,
-           "adaptive_heun": 7}
-ADAPTIVE_SOLVERS = ("dopri5", "bosh3", "adaptive_heun")  # torchdiffeq's adaptive pairs (vihds_rk_adaptive.hpp)
+           "adaptive_heun": 7, "dopri8": 8}
+# torchdiffeq's adaptive pairs (vihds_rk_adaptive.hpp); "dopri8" runs an 8th-order Dormand-Prince pair with Hairer's
+# DOP853 coefficients, not torchdiffeq's own 8(7) tableau (vihds_dop853_tableau.hpp)
+ADAPTIVE_SOLVERS = ("dopri5", "bosh3", "adaptive_heun", "dopri8")
 
 _c_float_p = ctypes.c_void_p  # device pointers travel as integers (tensor.data_ptr())
 
@@ -178,7 +180,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 6:
+        if handle.vihds_abi_version() != 7:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

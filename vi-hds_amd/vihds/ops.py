@@ -76,8 +76,7 @@ class OdeProblemSpec:
             raise KeyError("unknown model '%s'" % model)
         if solver not in hip.SOLVERS:
             raise NotImplementedError(
-                "solver '%s' is not implemented by the HIP path (available: %s; of torchdiffeq's adaptive solvers "
-                "dopri8 / DOP853 is not built)" % (solver, ", ".join(sorted(hip.SOLVERS))))
+                "solver '%s' is not implemented by the HIP path (available: %s)" % (solver, ", ".join(sorted(hip.SOLVERS))))
         self.model, self.solver = model, solver
         sized = False
         if model == "dr_blackbox":
