@@ -53,3 +53,19 @@ for hs in (25, 50):
     ops.blackbox_weight_grads = orig
     for k, v in tm.t.items():
         print("    %-32s %.3f ms" % (k, 1e3 * sum(v[1:]) / max(len(v) - 1, 1)))
+
+# the same 50-unit step replayed from a hipGraph (two contraction passes and all)
+args, settings, data, parameters, model, training = synthetic.build(
+    "dr_blackbox_icml", 36, 200, solver="midpoint", device="cuda:0", seed=1, u_rng="kernel", conditioner_rng="kernel",
+    hip_graph=True, nan_check_every=0, learning_rate=0.001, n_hidden_decoder=50)
+model.train()
+batch = training.train_data
+for _ in range(3):
+    loss = training.graph_step(batch)
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(20):
+    loss = training.graph_step(batch)
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / 20
+print("n_hidden_decoder 50, hipGraph replay: %.3f ms/step = %.0f steps/s, loss %.4f" % (dt * 1e3, 1.0 / dt, float(loss)))
