@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 7
+#define VIHDS_ABI_VERSION 8
 
 /* error codes */
 #define VIHDS_OK 0
@@ -293,6 +293,17 @@ int vihds_iwae_combine(int n_ranks, int B, int S, int n_iwae_total, const float*
                        float* lse, float* loss, float* unit_g_logw, float* unit_g_neg_logw, void* stream);
 int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, const float* g_loss, float* g_logw,
                         float* g_neg_logw, void* stream);
+
+/* dr_blackbox's condition_theta (reference models/dr_blackbox.py:86-96): y_i += offset_layer(dev_1hot)_i with
+ * offset_layer = Linear(D, n).  theta [n_rows][B][S]; W [n][D], bias [n], dev1hot [B][D].
+ * fwd: theta[dst_row + i][b][s] = theta[src_row + i][b][s] + W[i,:] . dev1hot[b,:] + bias[i]   (the simulator's slots
+ *      for y point at the dst rows; the src rows keep the sampled y that log q / log p are taken of).
+ * bwd: g_theta[src_row + i] += g_theta[dst_row + i];  g_wb (n*D + n floats, or NULL) = the layer's weight gradient
+ *      [n][D] (sum over b, s of g_theta[dst_row + i][b][s] dev1hot[b][d]) followed by its bias gradient [n]. */
+int vihds_offset_rows_fwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* W,
+                          const float* bias, const float* dev1hot, float* theta, void* stream);
+int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* dev1hot,
+                          float* g_theta, float* g_wb, void* stream);
 
 /* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
  * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *

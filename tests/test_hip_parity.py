@@ -1586,3 +1586,48 @@ def test_wide_blackbox_default_hidden_size_against_the_restatement(solver):
     th_ref = torch.stack([th_cpu[n].grad if th_cpu[n].grad is not None else torch.zeros(fx.B, fx.S) for n in slots])
     live = th_ref.abs().amax(dim=(1, 2)) > 0
     assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL
+
+
+def test_offset_rows_against_torch():
+    """vihds_offset_rows_fwd / _bwd (dr_blackbox's condition_theta, reference models/dr_blackbox.py:86-96: y_i +=
+    Linear(D, n_y)(dev_1hot)_i) against torch: the conditioned rows, the routing of their gradient back to the sampled
+    rows and the layer's weight / bias gradients, through ops.OffsetRows + the "linear" row_offset route's kernel."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    g = torch.Generator().manual_seed(4)
+    for (B, S, D, n, R, src, dst) in [(36, 200, 7, 2, 20, 10, 16), (3, 5, 1, 1, 4, 0, 3), (5, 70, 12, 3, 9, 2, 6)]:
+        W = torch.randn(n, D, generator=g).to(DEV).requires_grad_(True)
+        bias = torch.randn(n, generator=g).to(DEV).requires_grad_(True)
+        dev = torch.zeros(B, D)
+        dev[torch.arange(B), torch.arange(B) % D] = 1.0
+        dev = (dev + 0.1 * torch.rand(B, D, generator=g)).to(DEV)
+        theta = torch.randn(R, B, S, generator=g).to(DEV)
+        want = theta.clone()
+        off = torch.nn.functional.linear(dev, W, bias)                      # [B,n]
+        want[dst:dst + n] = theta[src:src + n] + off.t().unsqueeze(2)
+        token = ops.OffsetRows.apply(W, bias, dev, theta, src, dst)
+        assert torch.allclose(theta, want, rtol=1e-6, atol=1e-6)
+        # backward: the kernel the simulator's backward calls, then the token's gradient through OffsetRows.backward
+        g_theta = torch.randn(R, B, S, generator=g).to(DEV)
+        g_ref = g_theta.clone()
+        g_ref[src:src + n] += g_theta[dst:dst + n]
+        (off * g_theta[dst:dst + n].sum(2).t()).sum().backward()
+        gW_ref, gb_ref = W.grad.clone(), bias.grad.clone()
+        W.grad = bias.grad = None
+        g_wb = torch.empty(n * D + n, device=DEV)
+        rc = L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, dev.data_ptr(), g_theta.data_ptr(), g_wb.data_ptr(),
+                                     hip.current_stream())
+        assert rc == 0, L.vihds_last_error()
+        assert torch.allclose(g_theta, g_ref, rtol=1e-6, atol=1e-6)
+        token.backward(g_wb)
+        assert rel_err(W.grad, gW_ref) < 1e-5 and rel_err(bias.grad, gb_ref) < 1e-5
+        # add-only mode (no layer gradients wanted) and argument checks
+        g2 = torch.ones(R, B, S, device=DEV)
+        assert L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, dev.data_ptr(), g2.data_ptr(), None, hip.current_stream()) == 0
+        assert float(g2[src:src + n].min()) == 2.0 and float(g2.sum()) == R * B * S + n * B * S
+        assert L.vihds_offset_rows_fwd(B, S, D, n, R, src, src, W.data_ptr(), bias.data_ptr(), dev.data_ptr(),
+                                       theta.data_ptr(), hip.current_stream()) < 0   # overlapping rows
+        assert L.vihds_offset_rows_fwd(B, S, D, n, R, src, R, W.data_ptr(), bias.data_ptr(), dev.data_ptr(),
+                                       theta.data_ptr(), hip.current_stream()) < 0   # rows past the buffer

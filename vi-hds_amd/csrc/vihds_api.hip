@@ -68,6 +68,9 @@ void launch_iwae_combine(int, int, int, float, const float*, const float*, float
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
+// vihds_offset.hip
+void launch_offset_rows_fwd(int, int, int, int, int, int, const float*, const float*, const float*, float*, hipStream_t);
+void launch_offset_rows_bwd(int, int, int, int, int, int, const float*, float*, float*, hipStream_t);
 // vihds_gram.hip
 long long gram_scratch_floats(long long, int, const vihds_gram_rect*);
 int launch_gram(int, long long, int, const vihds_gram_rect*, const float*, float*, float*, hipStream_t);
@@ -687,6 +690,30 @@ int vihds_blackbox_tail_grads(const vihds_ode_problem* p, const float* theta, co
                                 dev1hot, tail, dest, g_weights, (hipStream_t)stream);
   if (rc) return fail(rc, "needs 1..16 latent inputs, 1..4 treatments and a 1..12 wide device one-hot");
   return check_hip("vihds_blackbox_tail_grads launch");
+}
+
+static int offset_rows_check(int B, int S, int D, int n, int n_rows, int src_row, int dst_row) {
+  if (B <= 0 || S <= 0 || D <= 0 || n <= 0) return fail(VIHDS_E_BADARG, "B, S, D, n must be positive");
+  if (B > 8192) return fail(VIHDS_E_UNSUPPORTED, "at most 8192 data rows");
+  if (src_row < 0 || dst_row < 0 || src_row + n > n_rows || dst_row + n > n_rows)
+    return fail(VIHDS_E_BADARG, "theta rows out of range");
+  if (src_row < dst_row + n && dst_row < src_row + n) return fail(VIHDS_E_BADARG, "source and destination rows overlap");
+  return VIHDS_OK;
+}
+int vihds_offset_rows_fwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* W,
+                          const float* bias, const float* dev1hot, float* theta, void* stream) {
+  if (!W || !bias || !dev1hot || !theta) return fail(VIHDS_E_BADARG, "null argument");
+  if (int rc = offset_rows_check(B, S, D, n, n_rows, src_row, dst_row)) return rc;
+  launch_offset_rows_fwd(B, S, D, n, src_row, dst_row, W, bias, dev1hot, theta, (hipStream_t)stream);
+  return check_hip("vihds_offset_rows_fwd launch");
+}
+int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* dev1hot,
+                          float* g_theta, float* g_wb, void* stream) {
+  if (!dev1hot || !g_theta) return fail(VIHDS_E_BADARG, "null argument");
+  if (int rc = offset_rows_check(B, S, D, n, n_rows, src_row, dst_row)) return rc;
+  if (D + 1 > 1024) return fail(VIHDS_E_UNSUPPORTED, "device one-hot wider than 1023");
+  launch_offset_rows_bwd(B, S, D, n, src_row, dst_row, dev1hot, g_theta, g_wb, (hipStream_t)stream);
+  return check_hip("vihds_offset_rows_bwd launch");
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,

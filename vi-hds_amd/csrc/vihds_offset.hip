@@ -1,0 +1,67 @@
+// dr_blackbox's condition_theta (reference models/dr_blackbox.py:86-96): y_i += offset_layer(dev_1hot)_i, a Linear(D, n_y)
+// on the device one-hot added to n_y theta rows for every sample.  Forward: one launch writes the conditioned rows
+// (the simulator reads those; theta's own y rows keep the sampled values log q / log p are taken of).  Backward: one
+// launch routes the conditioned rows' gradient back to the y rows and forms the layer's weight and bias gradients
+// (what autograd's Linear backward, a row sum and an add did in six launches).
+#include <hip/hip_runtime.h>
+
+#include "../../include/vihds_hip.h"
+
+namespace vihds {
+
+// grid (B, n): theta[dst+i][b][:] = theta[src+i][b][:] + W[i,:] . dev1hot[b,:] + bias[i]
+__global__ void __launch_bounds__(256) offset_rows_fwd_kernel(int B, int S, int D, int src, int dst,
+                                                              const float* __restrict__ W, const float* __restrict__ bias,
+                                                              const float* __restrict__ dev1hot, float* __restrict__ theta) {
+  const int b = blockIdx.x, i = blockIdx.y;
+  float off = bias[i];
+  for (int d = 0; d < D; ++d) off = fmaf(W[i * D + d], dev1hot[b * D + d], off);
+  const float* in = theta + ((size_t)(src + i) * B + b) * S;
+  float* out = theta + ((size_t)(dst + i) * B + b) * S;
+  for (int s = threadIdx.x; s < S; s += blockDim.x) out[s] = in[s] + off;
+}
+
+// grid (n), 1024 threads: wavefront w sums the rows b = w, w + 16, ... of g_theta[dst+i] over the samples while adding
+// them into g_theta[src+i]; then g_W[i][d] = sum_b rs[b] dev1hot[b][d], g_bias[i] = sum_b rs[b] (fixed order)
+constexpr int OFFSET_BWD_THREADS = 1024;
+__global__ void __launch_bounds__(OFFSET_BWD_THREADS)
+offset_rows_bwd_kernel(int B, int S, int D, int n, int src, int dst, const float* __restrict__ dev1hot,
+                       float* __restrict__ g_theta, float* __restrict__ g_wb) {
+  extern __shared__ float rs[];  // [B]
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  for (int b = wave; b < B; b += n_waves) {
+    const float* gd = g_theta + ((size_t)(dst + i) * B + b) * S;
+    float* gs = g_theta + ((size_t)(src + i) * B + b) * S;
+    float acc = 0.f;
+    for (int s = lane; s < S; s += 64) {
+      const float g = gd[s];
+      acc += g;
+      gs[s] += g;
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+    if (lane == 0) rs[b] = acc;
+  }
+  __syncthreads();
+  if (g_wb == nullptr) return;
+  if ((int)threadIdx.x < D) {
+    float w = 0.f;
+    for (int b = 0; b < B; ++b) w = fmaf(rs[b], dev1hot[b * D + threadIdx.x], w);
+    g_wb[i * D + threadIdx.x] = w;
+  } else if ((int)threadIdx.x == D) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += rs[b];
+    g_wb[n * D + i] = s;
+  }
+}
+
+void launch_offset_rows_fwd(int B, int S, int D, int n, int src, int dst, const float* W, const float* bias,
+                            const float* dev1hot, float* theta, hipStream_t st) {
+  hipLaunchKernelGGL(offset_rows_fwd_kernel, dim3(B, n), dim3(256), 0, st, B, S, D, src, dst, W, bias, dev1hot, theta);
+}
+void launch_offset_rows_bwd(int B, int S, int D, int n, int src, int dst, const float* dev1hot, float* g_theta, float* g_wb,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(offset_rows_bwd_kernel, dim3(n), dim3(OFFSET_BWD_THREADS), (size_t)B * sizeof(float), st, B, S, D, n,
+                     src, dst, dev1hot, g_theta, g_wb);
+}
+}  // namespace vihds

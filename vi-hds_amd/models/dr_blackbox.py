@@ -69,21 +69,22 @@ class DR_Blackbox(OdeModel):
         to y and to the offset layer is routed by ops.OdeSolveObserve (row_offset)."""
         if self.n_y == 0:
             return theta
-        offset = self.offset_layer(dev_1hot)  # [B, n_y]
         names = ["y%d" % (i + 1) for i in range(self.n_y)]
         packed = getattr(theta, "_packed", None)
-        if packed is not None and packed.is_cuda and theta.n_reserved_rows() >= self.n_y:
+        if packed is not None and packed.is_cuda and packed.is_contiguous() and theta.n_reserved_rows() >= self.n_y:
             rows = [theta._row_of.get(n) for n in names]
             base = len(theta.samples)
             if (None not in rows and rows == list(range(rows[0], rows[0] + self.n_y)) and rows[-1] < base
                     and not any(n in theta._rebound for n in names)):
-                with torch.no_grad():
-                    torch.add(packed[rows[0]: rows[0] + self.n_y], offset.t().unsqueeze(2),
-                              out=packed[base: base + self.n_y])
+                # one launch: offset layer + the add into the reserved rows (ops.OffsetRows); its token carries the
+                # layer's gradients back from the simulator's backward (one more launch there)
+                token = ops.OffsetRows.apply(self.offset_layer.weight, self.offset_layer.bias, dev_1hot, packed.detach(),
+                                             rows[0], base)
                 for i, n in enumerate(names):
                     theta.bind_reserved_row(n, base + i)
-                object.__setattr__(theta, "_row_offset", (offset, (rows[0], base, self.n_y)))
+                object.__setattr__(theta, "_row_offset", (token, (rows[0], base, self.n_y, "linear")))
                 return theta
+        offset = self.offset_layer(dev_1hot)  # [B, n_y]
         for i, pname in enumerate(names):
             setattr(theta, pname, getattr(theta, pname) + offset[:, i: i + 1])
         return theta

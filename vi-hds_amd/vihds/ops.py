@@ -161,6 +161,9 @@ class OdeSolveObserve(torch.autograd.Function):
     row_offset [B,n] with row_offset_map = (src, dst, n) (optional): rows dst..dst+n-1 of theta already hold
     theta[src+i] + row_offset[:, i] (written in place by the caller, e.g. dr_blackbox's y + offset_layer(dev_1hot)) and
     the kernel reads those; backward then routes their gradient to rows src.. and, summed over S, to row_offset.
+    row_offset_map = (src, dst, n, "linear"): the rows were written by OffsetRows (offset = Linear(D, n) of dev1hot) and
+    row_offset is its token [n*D + n]; backward hands it the layer's weight and bias gradients from ONE launch
+    (vihds_offset_rows_bwd) that also routes the row gradients.
     """
 
     @staticmethod
@@ -219,13 +222,48 @@ class OdeSolveObserve(torch.autograd.Function):
         grads = (None, g_theta, None, None, None, None, g_w)
         if len(ctx.needs_input_grad) > 7:
             g_off = None
-            if ctx.row_offset_map is not None:
+            if ctx.row_offset_map is not None and len(ctx.row_offset_map) == 4:
+                src, dst, n, _ = ctx.row_offset_map
+                R, B, S = theta.shape
+                D = dev1hot.shape[1]
+                if ctx.needs_input_grad[7]:
+                    g_off = torch.empty(n * D + n, device=theta.device, dtype=torch.float32)
+                rc = hip.lib().vihds_offset_rows_bwd(B, S, D, n, R, src, dst, hip.ptr(dev1hot), hip.ptr(g_theta),
+                                                     hip.ptr(g_off), hip.current_stream())
+                hip.check(rc, "vihds_offset_rows_bwd")
+            elif ctx.row_offset_map is not None:
                 src, dst, n = ctx.row_offset_map
                 if ctx.needs_input_grad[7]:
                     g_off = g_theta[dst:dst + n].sum(2).t()
                 g_theta[src:src + n] += g_theta[dst:dst + n]
             grads = grads + (g_off, None)[:len(ctx.needs_input_grad) - 7]
         return grads
+
+
+class OffsetRows(torch.autograd.Function):
+    """dr_blackbox's condition_theta (reference models/dr_blackbox.py:86-96) in one launch: rows dst.. of the packed theta
+    buffer <- rows src.. + Linear(D, n)(dev1hot), written in place (the buffer's autograd history is untouched: the rows
+    are reserved scratch rows of it).  Returns a token [n*D + n] to hand to OdeSolveObserve as row_offset with
+    row_offset_map = (src, dst, n, "linear"); the gradient that comes back for it is [g_weight | g_bias]."""
+
+    @staticmethod
+    def forward(ctx, weight, bias, dev1hot, packed, src, dst):
+        _require_cuda(weight, bias, dev1hot, packed)
+        n, D = weight.shape
+        R, B, S = packed.shape
+        rc = hip.lib().vihds_offset_rows_fwd(B, S, D, n, R, src, dst, hip.ptr(_c(weight)), hip.ptr(_c(bias)),
+                                             hip.ptr(_c(dev1hot)), hip.ptr(packed), hip.current_stream())
+        hip.check(rc, "vihds_offset_rows_fwd")
+        ctx.shape = (n, D)
+        ctx.set_materialize_grads(False)
+        return torch.empty(n * D + n, device=packed.device, dtype=torch.float32)
+
+    @staticmethod
+    def backward(ctx, g):
+        if g is None:
+            return None, None, None, None, None, None
+        n, D = ctx.shape
+        return g[: n * D].view(n, D), g[n * D:], None, None, None, None
 
 
 class _FlatParameterView(torch.autograd.Function):
