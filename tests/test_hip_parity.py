@@ -1049,14 +1049,14 @@ def test_gram_blocks_against_torch(case):
     assert torch.equal(out2.cpu()[written], out.cpu()[written])
 
 
-def test_blackbox_tail_grads_against_torch():
+@pytest.mark.parametrize("B,S", [(5, 37), (36, 200), (9, 1000)])
+def test_blackbox_tail_grads_against_torch(B, S):
     """vihds_blackbox_tail_grads: time-invariant-input columns and biases from the adjoint's tail, vs float64 torch."""
     import ctypes
     from vihds import hip, ops
 
     L = hip.lib()
     slots = hip.model_slots("dr_blackbox")
-    B, S = 5, 37
     n = B * S
     HS, HP, NX, nc, C, D = 25, 20, 6, 21, 2, 7
     n_lat = nc - C - D
