@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 8
+#define VIHDS_ABI_VERSION 9
 
 /* error codes */
 #define VIHDS_OK 0
@@ -298,12 +298,13 @@ int vihds_iwae_loss_bwd(int B, int S, const float* log_w, const float* lse, cons
  * offset_layer = Linear(D, n).  theta [n_rows][B][S]; W [n][D], bias [n], dev1hot [B][D].
  * fwd: theta[dst_row + i][b][s] = theta[src_row + i][b][s] + W[i,:] . dev1hot[b,:] + bias[i]   (the simulator's slots
  *      for y point at the dst rows; the src rows keep the sampled y that log q / log p are taken of).
- * bwd: g_theta[src_row + i] += g_theta[dst_row + i];  g_wb (n*D + n floats, or NULL) = the layer's weight gradient
+ * bwd: g_theta[src_row + i] += g_theta[dst_row + i] (accumulate = 0: '=', for callers that left the src rows of g_theta
+ *      unwritten and so need no zero fill);  g_wb (n*D + n floats, or NULL) = the layer's weight gradient
  *      [n][D] (sum over b, s of g_theta[dst_row + i][b][s] dev1hot[b][d]) followed by its bias gradient [n]. */
 int vihds_offset_rows_fwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* W,
                           const float* bias, const float* dev1hot, float* theta, void* stream);
-int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* dev1hot,
-                          float* g_theta, float* g_wb, void* stream);
+int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, int accumulate,
+                          const float* dev1hot, float* g_theta, float* g_wb, void* stream);
 
 /* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
  * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *

@@ -1617,7 +1617,7 @@ def test_offset_rows_against_torch():
         gW_ref, gb_ref = W.grad.clone(), bias.grad.clone()
         W.grad = bias.grad = None
         g_wb = torch.empty(n * D + n, device=DEV)
-        rc = L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, dev.data_ptr(), g_theta.data_ptr(), g_wb.data_ptr(),
+        rc = L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, 1, dev.data_ptr(), g_theta.data_ptr(), g_wb.data_ptr(),
                                      hip.current_stream())
         assert rc == 0, L.vihds_last_error()
         assert torch.allclose(g_theta, g_ref, rtol=1e-6, atol=1e-6)
@@ -1625,8 +1625,13 @@ def test_offset_rows_against_torch():
         assert rel_err(W.grad, gW_ref) < 1e-5 and rel_err(bias.grad, gb_ref) < 1e-5
         # add-only mode (no layer gradients wanted) and argument checks
         g2 = torch.ones(R, B, S, device=DEV)
-        assert L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, dev.data_ptr(), g2.data_ptr(), None, hip.current_stream()) == 0
+        assert L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, 1, dev.data_ptr(), g2.data_ptr(), None, hip.current_stream()) == 0
         assert float(g2[src:src + n].min()) == 2.0 and float(g2.sum()) == R * B * S + n * B * S
+        # assign mode: the source rows need not be initialised
+        g3 = torch.ones(R, B, S, device=DEV)
+        g3[src:src + n] = float("nan")
+        assert L.vihds_offset_rows_bwd(B, S, D, n, R, src, dst, 0, dev.data_ptr(), g3.data_ptr(), None, hip.current_stream()) == 0
+        assert float(g3.sum()) == R * B * S
         assert L.vihds_offset_rows_fwd(B, S, D, n, R, src, src, W.data_ptr(), bias.data_ptr(), dev.data_ptr(),
                                        theta.data_ptr(), hip.current_stream()) < 0   # overlapping rows
         assert L.vihds_offset_rows_fwd(B, S, D, n, R, src, R, W.data_ptr(), bias.data_ptr(), dev.data_ptr(),

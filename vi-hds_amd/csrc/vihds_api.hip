@@ -70,7 +70,7 @@ void launch_device_condition(int, int, int, int, int, int, float, float, const f
                              float*, hipStream_t);
 // vihds_offset.hip
 void launch_offset_rows_fwd(int, int, int, int, int, int, const float*, const float*, const float*, float*, hipStream_t);
-void launch_offset_rows_bwd(int, int, int, int, int, int, const float*, float*, float*, hipStream_t);
+void launch_offset_rows_bwd(int, int, int, int, int, int, int, const float*, float*, float*, hipStream_t);
 // vihds_gram.hip
 long long gram_scratch_floats(long long, int, const vihds_gram_rect*);
 int launch_gram(int, long long, int, const vihds_gram_rect*, const float*, float*, float*, hipStream_t);
@@ -707,12 +707,12 @@ int vihds_offset_rows_fwd(int B, int S, int D, int n, int n_rows, int src_row, i
   launch_offset_rows_fwd(B, S, D, n, src_row, dst_row, W, bias, dev1hot, theta, (hipStream_t)stream);
   return check_hip("vihds_offset_rows_fwd launch");
 }
-int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, const float* dev1hot,
-                          float* g_theta, float* g_wb, void* stream) {
+int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, int accumulate,
+                          const float* dev1hot, float* g_theta, float* g_wb, void* stream) {
   if (!dev1hot || !g_theta) return fail(VIHDS_E_BADARG, "null argument");
   if (int rc = offset_rows_check(B, S, D, n, n_rows, src_row, dst_row)) return rc;
   if (D + 1 > 1024) return fail(VIHDS_E_UNSUPPORTED, "device one-hot wider than 1023");
-  launch_offset_rows_bwd(B, S, D, n, src_row, dst_row, dev1hot, g_theta, g_wb, (hipStream_t)stream);
+  launch_offset_rows_bwd(B, S, D, n, src_row, dst_row, accumulate, dev1hot, g_theta, g_wb, (hipStream_t)stream);
   return check_hip("vihds_offset_rows_bwd launch");
 }
 

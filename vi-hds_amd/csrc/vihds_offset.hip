@@ -22,11 +22,11 @@ __global__ void __launch_bounds__(256) offset_rows_fwd_kernel(int B, int S, int 
 }
 
 // grid (n), 1024 threads: wavefront w sums the rows b = w, w + 16, ... of g_theta[dst+i] over the samples while adding
-// them into g_theta[src+i]; then g_W[i][d] = sum_b rs[b] dev1hot[b][d], g_bias[i] = sum_b rs[b] (fixed order)
+// them into g_theta[src+i] (accumulate = 0: assigning them -- the caller left those rows unwritten); then g_W[i][d] = sum_b rs[b] dev1hot[b][d], g_bias[i] = sum_b rs[b] (fixed order)
 constexpr int OFFSET_BWD_THREADS = 1024;
 __global__ void __launch_bounds__(OFFSET_BWD_THREADS)
-offset_rows_bwd_kernel(int B, int S, int D, int n, int src, int dst, const float* __restrict__ dev1hot,
-                       float* __restrict__ g_theta, float* __restrict__ g_wb) {
+offset_rows_bwd_kernel(int B, int S, int D, int n, int src, int dst, int accumulate,
+                       const float* __restrict__ dev1hot, float* __restrict__ g_theta, float* __restrict__ g_wb) {
   extern __shared__ float rs[];  // [B]
   const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
   for (int b = wave; b < B; b += n_waves) {
@@ -36,7 +36,7 @@ offset_rows_bwd_kernel(int B, int S, int D, int n, int src, int dst, const float
     for (int s = lane; s < S; s += 64) {
       const float g = gd[s];
       acc += g;
-      gs[s] += g;
+      gs[s] = accumulate ? gs[s] + g : g;
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
@@ -59,9 +59,9 @@ void launch_offset_rows_fwd(int B, int S, int D, int n, int src, int dst, const 
                             const float* dev1hot, float* theta, hipStream_t st) {
   hipLaunchKernelGGL(offset_rows_fwd_kernel, dim3(B, n), dim3(256), 0, st, B, S, D, src, dst, W, bias, dev1hot, theta);
 }
-void launch_offset_rows_bwd(int B, int S, int D, int n, int src, int dst, const float* dev1hot, float* g_theta, float* g_wb,
-                            hipStream_t st) {
+void launch_offset_rows_bwd(int B, int S, int D, int n, int src, int dst, int accumulate, const float* dev1hot,
+                            float* g_theta, float* g_wb, hipStream_t st) {
   hipLaunchKernelGGL(offset_rows_bwd_kernel, dim3(n), dim3(OFFSET_BWD_THREADS), (size_t)B * sizeof(float), st, B, S, D, n,
-                     src, dst, dev1hot, g_theta, g_wb);
+                     src, dst, accumulate, dev1hot, g_theta, g_wb);
 }
 }  // namespace vihds

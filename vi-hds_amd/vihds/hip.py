@@ -154,7 +154,7 @@ _PROTOTYPES = {
     "vihds_gram_blocks": (_I, [_I, ctypes.c_longlong, _I] + [_P] * 5),
     "vihds_blackbox_tail_grads": (_I, [_P] * 8),
     "vihds_offset_rows_fwd": (_I, [_I] * 7 + [_P] * 5),
-    "vihds_offset_rows_bwd": (_I, [_I] * 7 + [_P] * 4),
+    "vihds_offset_rows_bwd": (_I, [_I] * 8 + [_P] * 4),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 5 + [_P]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }
@@ -182,7 +182,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 8:
+        if handle.vihds_abi_version() != 9:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

@@ -116,6 +116,7 @@ class OdeProblemSpec:
             self.n_states = hip.lib().vihds_model_n_states(hip.MODELS[model])
             self.n_species = hip.lib().vihds_model_n_species(hip.MODELS[model])
         self.covers_all_rows = len({row_of[s] for s in self.slots}) == n_rows
+        self.unwritten_rows = sorted(set(range(n_rows)) - {row_of[s] for s in self.slots})  # rows the adjoint leaves alone
         self.cache = {}  # device-side constants derived from this spec
 
     def bind(self, B, S, T):
@@ -192,8 +193,12 @@ class OdeSolveObserve(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_traj, g_xpred, g_logp):
         theta, cond, times, obs, traj, dev1hot, weights = ctx.saved_tensors
-        # the kernel writes every slot row; rows that are not slots (if any) must read as zero
-        g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
+        # the kernel writes every slot row; rows that are not slots (if any) must read as zero -- unless they are exactly
+        # the rows the "linear" row-offset launch below assigns (dr_blackbox: the sampled y rows)
+        rom = ctx.row_offset_map
+        assign_src = (rom is not None and len(rom) == 4
+                      and ctx.spec.unwritten_rows == list(range(rom[0], rom[0] + rom[2])))
+        g_theta = torch.empty_like(theta) if (ctx.spec.covers_all_rows or assign_src) else torch.zeros_like(theta)
         n_aux = hip.lib().vihds_ode_bwd_aux_floats(ctypes.byref(ctx.prob))
         blackbox = ctx.spec.model == "dr_blackbox"
         if not blackbox and not (weights is not None and ctx.needs_input_grad[6]):
@@ -228,8 +233,8 @@ class OdeSolveObserve(torch.autograd.Function):
                 D = dev1hot.shape[1]
                 if ctx.needs_input_grad[7]:
                     g_off = torch.empty(n * D + n, device=theta.device, dtype=torch.float32)
-                rc = hip.lib().vihds_offset_rows_bwd(B, S, D, n, R, src, dst, hip.ptr(dev1hot), hip.ptr(g_theta),
-                                                     hip.ptr(g_off), hip.current_stream())
+                rc = hip.lib().vihds_offset_rows_bwd(B, S, D, n, R, src, dst, 0 if assign_src else 1, hip.ptr(dev1hot),
+                                                     hip.ptr(g_theta), hip.ptr(g_off), hip.current_stream())
                 hip.check(rc, "vihds_offset_rows_bwd")
             elif ctx.row_offset_map is not None:
                 src, dst, n = ctx.row_offset_map
