@@ -232,10 +232,21 @@ def ensure_blackbox_variant(L, HS, HP, NLAT):
         if (os.environ.get("VIHDS_BLACKBOX_JIT", "1") == "0" or "VIHDS_HIP_LIB" in os.environ
                 or not os.path.exists(os.path.join(csrc, "sized", "ode_dr_blackbox_sized.hip"))):
             raise RuntimeError("dr_blackbox at sizes %s needs %s (build: %s)" % (key, path, " ".join(cmd)))
-        sys.stderr.write("[vihds] building the dr_blackbox kernels for sizes %s: %s\n" % (key, " ".join(cmd)))
-        res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if res.returncode != 0 or not os.path.exists(path):
-            raise RuntimeError("building %s failed:\n%s" % (path, res.stdout[-2000:]))
+        # one builder at a time (several ranks of one job meet here together): an exclusive lock on a file next to the
+        # library, and a second look once it is held
+        import fcntl
+
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(os.path.join(os.path.dirname(path), ".blackbox_build.lock"), "w") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                if not os.path.exists(path):
+                    sys.stderr.write("[vihds] building the dr_blackbox kernels for sizes %s: %s\n" % (key, " ".join(cmd)))
+                    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                    if res.returncode != 0 or not os.path.exists(path):
+                        raise RuntimeError("building %s failed:\n%s" % (path, res.stdout[-2000:]))
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     return path
 
 
