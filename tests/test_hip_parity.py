@@ -706,6 +706,36 @@ def test_adam_step_matches_torch_adam(n_tensors, lr_on_device):
         assert rel_err(d.detach().cpu(), r.detach()) < 2e-6, k
 
 
+def test_adam_step_skips_non_finite_gradient_elements():
+    """A NaN / inf gradient element leaves its parameter and both moments untouched (the reference never reaches
+    optimizer.step with a NaN ELBO, training.py:331-334; here the NaN check runs after the launch); the finite
+    elements of the same tensor are updated as torch.optim.Adam updates them."""
+    from vihds.optim import HipAdam
+
+    g = torch.Generator().manual_seed(11)
+    p0 = torch.randn(1000, generator=g)
+    ref = p0.clone().requires_grad_(True)
+    dev = p0.clone().to(DEV).requires_grad_(True)
+    opt_ref, opt = torch.optim.Adam([ref], lr=0.01), HipAdam([dev], lr=0.01)
+    gr = torch.randn(1000, generator=g)
+    bad = gr.clone()
+    bad[::7] = float("nan")
+    bad[3::50] = float("inf")
+    ref.grad, dev.grad = gr.clone(), bad.to(DEV)
+    opt_ref.step()
+    opt.step()
+    ok = torch.isfinite(bad)
+    out = dev.detach().cpu()
+    assert torch.isfinite(out).all()
+    assert torch.equal(out[~ok], p0[~ok])
+    assert rel_err(out[ok], ref.detach()[ok]) < 2e-6
+    # an all-NaN step (what a NaN loss produces) changes nothing
+    before = dev.detach().clone()
+    dev.grad = torch.full((1000,), float("nan"), device=DEV)
+    opt.step()
+    assert torch.equal(dev.detach(), before)
+
+
 def test_theta_kernel_draws_its_own_normals():
     """u_rng: kernel -- the theta kernel draws u ~ N(0,1) (Philox4x32-10 + Box-Muller), writes it out, advances the
     device-side step; the draws match the numpy restatement, are independent of S-sharding, and theta / log q / log p

@@ -804,6 +804,10 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
     const int end = min(t.size[k], (blk + 1) * ADAM_CHUNK);
     for (int e = blk * ADAM_CHUNK + threadIdx.x; e < end; e += 256) {
       const float ge = g[e] * grad_scale;
+      // a non-finite gradient element (a NaN loss reaches every encoder gradient) leaves its parameter and moments as
+      // they were: the reference stops before optimizer.step on a NaN ELBO (training.py:331-334), here the check comes
+      // after the launch, so the update itself must not poison the state
+      if (!(fabsf(ge) <= 3.402823466e38f)) continue;
       float me = m[off + e], ve = v[off + e];
       me += (ge - me) * (1.f - beta1);
       ve = ve * beta2 + (1.f - beta2) * ge * ge;

@@ -337,7 +337,8 @@ class Training:
         self._steps += 1
         if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
             # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced
-            # the NaN has already been applied -- the parameters and Adam state are invalid after this message)
+            # the NaN has already been launched -- HipAdam's kernel skips non-finite gradient elements, so the
+            # parameters and moments are those of the last finite step)
             print("Cannot proceed with ELBO = nan. Exiting.")
             return False
         log_data.batch_train_time += time.time() - train_start
