@@ -535,6 +535,38 @@ def test_iw_summaries_match_oracle():
     assert ok.float().mean() > 0.9 and rel_err(sd.cpu()[ok], f_sd[ok]) < 1e-3
 
 
+@pytest.mark.parametrize("n_species,S,from_theta", [(8, 1000, True), (12, 77, False), (16, 300, False),
+                                                    (17, 130, False), (20, 1, True)])
+def test_iw_summaries_shapes_against_float64(n_species, S, from_theta):
+    """vihds_iw_summaries on synthetic buffers: the one-pass kernel (up to 16 species) and the row-by-row kernel behind it
+    (more), ragged sample counts (not a multiple of the block, a single sample), precisions from theta rows or from
+    the trajectory buffer's last four species -- against Results.init's formulas (utils.py:79-99) in float64."""
+    from vihds import ops
+
+    B, T = 5, 7
+    g = torch.Generator().manual_seed(100 + n_species)
+    N = n_species + (0 if from_theta else 4)
+    traj = torch.rand(T, N, B, S, generator=g) + 0.5
+    xpred = torch.rand(T, 4, B, S, generator=g) * 3.0
+    log_w = torch.randn(B, S, generator=g) * 2.0
+    theta = torch.rand(9, B, S, generator=g) + 0.5 if from_theta else None
+    prow = [7, 2, 5, 3]
+    lse = torch.logsumexp(log_w, 1)
+    mu, sd, st, var = ops.iw_summaries(log_w.to(DEV), lse.to(DEV), traj.to(DEV), xpred.to(DEV), n_species,
+                                       theta=theta.to(DEV) if from_theta else None,
+                                       prec_rows=prow if from_theta else None)
+    w = torch.softmax(log_w.double(), 1)  # [B,S]
+    prec = (theta[prow].double() if from_theta else traj[:, n_species:n_species + 4].double())
+    prec = prec[None].expand(T, 4, B, S) if from_theta else prec
+    r_mu = torch.einsum("bs,tjbs->bjt", w, xpred.double())
+    r_var = torch.einsum("bs,tjbs->bjt", w, 1.0 / prec)
+    r_sq = torch.einsum("bs,tjbs->bjt", w, xpred.double() ** 2 + 1.0 / prec)
+    r_st = torch.einsum("bs,tjbs->bjt", w, traj[:, :n_species].double())
+    assert rel_err(mu.cpu().double(), r_mu) < 1e-5 and rel_err(var.cpu().double(), r_var) < 1e-5
+    assert rel_err(st.cpu().double(), r_st) < 1e-5
+    assert rel_err(sd.cpu().double(), (r_sq - r_mu ** 2).sqrt()) < 1e-3
+
+
 def test_bad_arguments_fail_loudly():
     from vihds import hip, ops
 

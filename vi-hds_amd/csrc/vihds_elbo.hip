@@ -660,9 +660,82 @@ __global__ void device_condition_kernel(int E, int B, int S, int S_total, int s_
 }
 
 // Results.init (vihds/utils.py:79-99): one block per (b, t); rows of the [T][*][B][S] buffers are contiguous in s.
+// ONE pass over the block's samples: a thread forms the importance weight of a sample once and feeds the 12 + n_species
+// accumulators from 4 + 4 + n_species independent row loads (all in flight together); one barrier for all the block
+// sums.  Every sum is taken in the order iw_summaries_rows_kernel takes it (thread-serial over s, wavefront tree,
+// wavefronts in order), so the two kernels agree bit for bit.
+constexpr int IWS_MAXSP = 16;
 template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
+                    const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
+                    const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3, float* __restrict__ mu_out,
+                    float* __restrict__ std_out, float* __restrict__ states_out, float* __restrict__ var_out) {
+  constexpr int NW = BLOCK / 64, NV = 12 + IWS_MAXSP;
+  __shared__ float sm[NW][NV];
+  const int b = blockIdx.x, t = blockIdx.y;
+  const size_t n = (size_t)B * S;
+  const float l = lse[b];
+  const int prow[4] = {pr0, pr1, pr2, pr3};
+  float acc[NV];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+  for (int s = threadIdx.x; s < S; s += BLOCK) {
+    const size_t i = (size_t)b * S + s;
+    float xp[4], pc[4], st[IWS_MAXSP];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      xp[j] = xpred[((size_t)t * 4 + j) * n + i];
+      pc[j] = theta ? theta[(size_t)prow[j] * n + i] : traj[((size_t)t * N_total + n_species + j) * n + i];
+    }
+#pragma unroll
+    for (int j = 0; j < IWS_MAXSP; ++j) st[j] = j < n_species ? traj[((size_t)t * N_total + j) * n + i] : 0.f;
+    const float w = expf(log_w[i] - l);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float iv = 1.f / pc[j];
+      acc[3 * j] += w * xp[j];
+      acc[3 * j + 1] += w * (xp[j] * xp[j] + iv);
+      acc[3 * j + 2] += w * iv;
+    }
+#pragma unroll
+    for (int j = 0; j < IWS_MAXSP; ++j) acc[12 + j] += w * st[j];
+  }
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    if (k < 12 + n_species) {
+      const float v = wave_sum(acc[k]);
+      if (lane == 0) sm[wid][k] = v;
+    }
+  }
+  __syncthreads();
+  const int k = threadIdx.x;
+  if (k < 4) {
+    float r[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) {
+      r[q] = 0.f;
+#pragma unroll
+      for (int w = 0; w < NW; ++w) r[q] += sm[w][3 * k + q];
+    }
+    const size_t o = ((size_t)b * 4 + k) * T + t;
+    mu_out[o] = r[0];
+    std_out[o] = sqrtf(r[1] - r[0] * r[0]);
+    var_out[o] = r[2];
+  } else if (k >= 64 && k < 64 + n_species) {
+    const int j = k - 64;
+    float r = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) r += sm[w][12 + j];
+    states_out[((size_t)b * n_species + j) * T + t] = r;
+  }
+}
+
+// The same, one pass over the samples per output row (any number of species): the fallback of iw_summaries_kernel.
+template <int BLOCK>
+__global__ void __launch_bounds__(BLOCK)
+iw_summaries_rows_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
                     const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
                     const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3, float* __restrict__ mu_out,
                     float* __restrict__ std_out, float* __restrict__ states_out, float* __restrict__ var_out) {
@@ -840,8 +913,12 @@ void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const 
                          float* sd, float* states, float* var, hipStream_t st) {
   int r[4] = {0, 0, 0, 0};
   if (theta && prec_rows) for (int j = 0; j < 4; ++j) r[j] = prec_rows[j];
-  hipLaunchKernelGGL((iw_summaries_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species, log_w, lse,
-                     traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+  if (n_species <= IWS_MAXSP)
+    hipLaunchKernelGGL((iw_summaries_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species, log_w,
+                       lse, traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+  else
+    hipLaunchKernelGGL((iw_summaries_rows_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species,
+                       log_w, lse, traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
 }
 
 }  // namespace vihds
