@@ -536,10 +536,11 @@ def test_iw_summaries_match_oracle():
 
 
 @pytest.mark.parametrize("n_species,S,from_theta", [(8, 1000, True), (12, 77, False), (16, 300, False),
-                                                    (17, 130, False), (20, 1, True)])
+                                                    (17, 130, False), (20, 1, True), (12, 2052, False),
+                                                    (16, 1026, True)])
 def test_iw_summaries_shapes_against_float64(n_species, S, from_theta):
     """vihds_iw_summaries on synthetic buffers: the one-pass kernel (up to 16 species) and the row-by-row kernel behind it
-    (more), ragged sample counts (not a multiple of the block, a single sample), precisions from theta rows or from
+    (more), ragged sample counts (not a multiple of the block, several rounds per thread, a single sample), precisions from theta rows or from
     the trajectory buffer's last four species -- against Results.init's formulas (utils.py:79-99) in float64."""
     from vihds import ops
 
