@@ -568,6 +568,44 @@ def test_iw_summaries_shapes_against_float64(n_species, S, from_theta):
     assert rel_err(sd.cpu().double(), (r_sq - r_mu ** 2).sqrt()) < 1e-3
 
 
+def test_iw_summaries_full_evaluation_size_properties():
+    """BASELINE config 3's evaluation shape (B=234, n_iwae=1000, T=86, 8 species: 644 MB of trajectories + 322 MB of
+    predictions through vihds_iw_summaries), checked through properties that do not need a CPU pass of that size:
+    (i) the importance weights of a row sum to one, so a quantity that is the same for every sample comes back
+    unchanged (states, mu), var = 1/precision and std = sqrt(1/precision); (ii) linearity, bit for bit: doubling the
+    trajectories and predictions doubles states and mu exactly; (iii) one row against float64 on the host."""
+    from vihds import ops
+
+    B, S, T, N = 234, 1000, 86, 8
+    g = torch.Generator(device=DEV).manual_seed(3)
+    log_w = torch.randn(B, S, device=DEV, generator=g) * 3.0
+    lse = torch.logsumexp(log_w, 1)
+    theta = torch.full((6, B, S), 2.0, device=DEV)
+    prow = [1, 2, 4, 5]
+    level = torch.rand(T, N, 1, 1, device=DEV, generator=g) + 0.5
+    plevel = torch.rand(T, 4, 1, 1, device=DEV, generator=g) * 3.0
+    mu, sd, st, var = ops.iw_summaries(log_w, lse, level.expand(T, N, B, S).contiguous(),
+                                       plevel.expand(T, 4, B, S).contiguous(), N, theta=theta, prec_rows=prow)
+    want_st = level[:, :, 0, 0].t()[None].expand(B, N, T)
+    want_mu = plevel[:, :, 0, 0].t()[None].expand(B, 4, T)
+    assert rel_err(st, want_st, dim=1) < 2e-6 and rel_err(mu, want_mu, dim=1) < 2e-6
+    assert rel_err(var, torch.full((B, 4, T), 0.5)) < 2e-6
+    assert rel_err(sd, torch.full((B, 4, T), math.sqrt(0.5))) < 1e-4
+    # (ii) + (iii) on random buffers
+    traj = torch.rand(T, N, B, S, device=DEV, generator=g) + 0.5
+    xpred = torch.rand(T, 4, B, S, device=DEV, generator=g) * 3.0
+    mu1, sd1, st1, var1 = ops.iw_summaries(log_w, lse, traj, xpred, N, theta=theta, prec_rows=prow)
+    mu2, _, st2, var2 = ops.iw_summaries(log_w, lse, traj * 2.0, xpred * 2.0, N, theta=theta, prec_rows=prow)
+    assert torch.equal(st2, st1 * 2.0) and torch.equal(mu2, mu1 * 2.0) and torch.equal(var2, var1)
+    b = 117
+    w = torch.softmax(log_w[b].double().cpu(), 0)
+    r_st = torch.einsum("s,tjs->jt", w, traj[:, :, b].double().cpu())
+    r_mu = torch.einsum("s,tjs->jt", w, xpred[:, :, b].double().cpu())
+    r_sq = torch.einsum("s,tjs->jt", w, xpred[:, :, b].double().cpu() ** 2 + 0.5)
+    assert rel_err(st1[b], r_st, dim=0) < 1e-5 and rel_err(mu1[b], r_mu, dim=0) < 1e-5
+    assert rel_err(sd1[b], (r_sq - r_mu ** 2).sqrt(), dim=0) < 1e-3
+
+
 def test_bad_arguments_fail_loudly():
     from vihds import hip, ops
 
