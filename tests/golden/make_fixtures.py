@@ -297,7 +297,7 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     return fx
 
 
-def run_training_trace(spec, solver, n_iwae, epochs, seed):
+def run_training_trace(spec, solver, n_iwae, epochs, seed, params_override=None):
     """Run the reference's own Training.run() (run_xval.run_on_split) for a few epochs and record the loss of
     every training step plus the evaluation ELBOs, together with the processed dataset it ran on, so the GPU
     build can be driven through the identical sequence (same seeds => same shuffles, u draws and conditioner
@@ -399,7 +399,11 @@ CASES = [
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--out", default=HERE, help="directory the .npz files are written to (default: next to this script; "
+                    "a scratch directory lets a regeneration be compared with the committed files)")
     a = ap.parse_args()
+    out_dir = os.path.abspath(a.out)
+    os.makedirs(out_dir, exist_ok=True)
     install_standins()
     sys.path.insert(0, REF)
     os.chdir(REF)  # reference resolves specs/ and data/ relative to cwd
@@ -410,10 +414,12 @@ def main():
     if not a.only or "trace" in a.only:
         for name, spec, solver, S, epochs in [("trace_dr_constant_icml_modeuler", "dr_constant_icml", "modeuler", 20, 4),
                                               ("trace_auto_constant_modeuler", "auto_constant", "modeuler", 20, 6)]:
+            if a.only and a.only not in name:
+                continue
             fx = run_training_trace(spec, solver, S, epochs, 0)
             fx["provenance"] = np.array(PROVENANCE + " [training trace: run_on_split semantics, losses per step] torch %s numpy %s"
                                         % (torch.__version__, np.__version__))
-            out = os.path.join(HERE, name + ".npz")
+            out = os.path.join(out_dir, name + ".npz")
             np.savez_compressed(out, **fx)
             print("wrote %s  steps=%d first=%.4f last=%.4f valid=%s" % (out, len(fx["step_losses"]), fx["step_losses"][0],
                                                                         fx["step_losses"][-1], fx["valid_elbo"]))
@@ -429,7 +435,7 @@ def main():
         fx["provenance"] = np.array(
             PROVENANCE + "torch %s numpy %s python %s" % (torch.__version__, np.__version__, sys.version.split()[0])
         )
-        out = os.path.join(HERE, name + ".npz")
+        out = os.path.join(out_dir, name + ".npz")
         np.savez_compressed(out, **fx)
         print("wrote %s  loss=%s  (%.1f kB)" % (out, fx["loss"], os.path.getsize(out) / 1e3))
 

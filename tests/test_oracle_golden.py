@@ -200,3 +200,72 @@ def test_adaptive_oracle_solvers_agree_with_the_pinned_scheme(solver):
     rhs64, x064 = O.MODEL_TABLE[fx.model][0](th64, fx.t("inputs").double())
     ref = O.simulate(rhs64, x064, fine, "rk4")[..., ::16].float()
     assert rel_err(sol, ref) < (5e-4 if solver in ("dopri5", "dopri8") else 5e-3)  # (rtol 1e-6 / 1e-4; per-species max-norm)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# the committed fixture recipe itself (run_training_trace referenced a name that was not in scope)
+def _load_recipe():
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "make_fixtures.py")
+    spec = importlib.util.spec_from_file_location("make_fixtures", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod, path
+
+
+def test_fixture_recipe_has_no_unbound_names():
+    """Every function of tests/golden/make_fixtures.py compiles and only reads names that are parameters, locals,
+    module globals or builtins (the defect was a NameError at run time, invisible to an import)."""
+    import builtins
+    import inspect
+
+    mod, _ = _load_recipe()
+    sig = inspect.signature(mod.run_training_trace)
+    assert "params_override" in sig.parameters and sig.parameters["params_override"].default is None
+    assert "params_override" in inspect.signature(mod.run_case).parameters
+    for name, fn in inspect.getmembers(mod, inspect.isfunction):
+        if fn.__module__ != mod.__name__:
+            continue
+        stack = [fn.__code__]
+        while stack:  # nested functions / lambdas / comprehensions too
+            code = stack.pop()
+            stack += [c for c in code.co_consts if inspect.iscode(c)]
+            for g in code.co_names:
+                if g in code.co_varnames or g in code.co_freevars or g in code.co_cellvars:
+                    continue
+                ok = hasattr(builtins, g) or g in vars(mod)
+                # attribute names and imported-module members also live in co_names: only flag what looks like a bare
+                # global read, i.e. a name some LOAD_GLOBAL instruction refers to
+                if not ok:
+                    import dis
+
+                    loads = {i.argval for i in dis.get_instructions(code) if i.opname == "LOAD_GLOBAL"}
+                    assert g not in loads, "%s reads the undefined global %r" % (name, g)
+
+
+@pytest.mark.skipif(not __import__("os").path.isdir("/root/reference/vihds"),
+                    reason="the reference is only present in the build container")
+def test_training_trace_fixture_regenerates_bit_exactly(tmp_path):
+    """Re-run the recipe's trace leg against the imported reference and compare with the committed file (6 training steps
+    of auto_constant + one validation pass: seconds)."""
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    _, path = _load_recipe()
+    subprocess.check_call([sys.executable, path, "--only", "trace_auto", "--out", str(tmp_path)],
+                          stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    import os
+
+    new = np.load(os.path.join(str(tmp_path), "trace_auto_constant_modeuler.npz"))
+    old = np.load(os.path.join(os.path.dirname(path), "trace_auto_constant_modeuler.npz"))
+    for k in old.files:
+        if k == "provenance":
+            continue
+        if old[k].dtype.kind == "U":
+            assert str(old[k]) == str(new[k]), k
+        else:
+            assert np.array_equal(old[k], new[k]), k

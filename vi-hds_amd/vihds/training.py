@@ -233,6 +233,15 @@ class Training:
             elbo.backward(ops.unit_gradient(elbo.device))  # no ones_like fill, and no launch for the loss's backward
         else:
             elbo.backward()
+        if ops._PENDING_IWAE:
+            # a deferred loss (fused_iwae_backward) is only evaluated if the decoder step's backward took the job; if it
+            # did not (the log-likelihood had a second consumer, a hook, ...) the gradients just computed are garbage
+            for job in list(ops._PENDING_IWAE.values()):
+                ops._run_iwae_job(job)
+            ops._PENDING_IWAE.clear()
+            raise RuntimeError("fused_iwae_backward: the decoder step's backward did not evaluate the deferred IWAE loss "
+                               "(its gradient did not arrive as the unit-gradient broadcast); set "
+                               "params.fused_iwae_backward: false for this model / training loop")
         sync = self.shard if self.shard is not None else self.replica
         if sync is not None:
             self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), sync.group, self._grad_buffer)
@@ -298,8 +307,10 @@ class Training:
             # inside every replay
             static["delta_obs"] = _delta_obs(static.observations)
             s = torch.cuda.Stream()
-            s.wait_stream(torch.cuda.current_stream())
+            # the snapshot's clone kernels are enqueued on the current stream BEFORE the side stream is made to wait for
+            # it, so the warm-up steps (which run Adam and advance the generator states) are ordered after the copies
             snap = self._snapshot_training_state()
+            s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
                     self.step(static)
@@ -312,13 +323,17 @@ class Training:
             _warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
             if _warn is not None:
                 _warn(False)
-            if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
-                g = parallel.SegmentedGraph()
-                loss = g.capture(lambda: self.step(static, zero_grad=False))
-            else:
-                g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
-                    loss = self.step(static, zero_grad=False)
+            try:
+                if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
+                    g = parallel.SegmentedGraph()
+                    loss = g.capture(lambda: self.step(static, zero_grad=False))
+                else:
+                    g = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(g):
+                        loss = self.step(static, zero_grad=False)
+            finally:
+                if _warn is not None:
+                    _warn(True)  # only the capture itself is exempt, not the rest of the process
             self._graphs[key] = (g, static, loss)
         g, static, loss = self._graphs[key]
         if self._staged.get(key) is not batch:  # a batch that is already resident in the graph's inputs is not re-copied
