@@ -237,6 +237,7 @@ def run_workload(a, name):
     if wl == "dr_constant_icml":
         extra["fused_ode_training"] = not a.two_kernel_ode
         extra["fused_iwae_backward"] = not a.no_fused_iwae
+        extra["fused_step_tail"] = not a.no_step_tail
     args, settings, data, parameters, model, training = synthetic.build(
         wl, B, S, solver=solver, device=dev, seed=a.seed, shard=shard, replica=replica, u_rng=a.device_rng,
         conditioner_rng=a.device_rng, hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, **extra)
@@ -395,6 +396,9 @@ def main():
                          "instead of the fused vihds_ode_logp_grad")
     ap.add_argument("--no-fused-iwae", action="store_true",
                     help="keep the IWAE loss as its own launch instead of forming it inside the theta-adjoint launch")
+    ap.add_argument("--no-step-tail", action="store_true",
+                    help="keep IWAE loss + theta adjoint, the encoder adjoint (two launches) and Adam as the five launches of "
+                         "round 2 instead of vihds_step_tail's two")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -439,7 +443,7 @@ def main():
         "dr_constant_icml", B_ROWS, n_iwae_model, solver=a.solver, device=dev, seed=a.seed, shard=shard, replica=replica,
         u_rng="numpy" if a.host_rng else a.device_rng, conditioner_rng="cpu" if a.host_rng else a.device_rng,
         hip_graph=use_graph, nan_check_every=0, learning_rate=a.lr, fused_ode_training=not a.two_kernel_ode,
-        fused_iwae_backward=not a.no_fused_iwae)
+        fused_iwae_backward=not a.no_fused_iwae, fused_step_tail=not a.no_step_tail)
     model.train()
     batch = training.train_data
     step = training.graph_step if use_graph else training.step
@@ -573,7 +577,7 @@ def main():
                    "launch": launch_mode, "learning_rate": a.lr,
                    "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
                                     "encoders.py:385) are outside the replayed step",
-                   "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
+                   "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "tail": "loss + backward + Adam: five launches" if (a.no_step_tail or multi) else "vihds_step_tail (IWAE loss + theta adjoint + encoder adjoint + Adam in two launches)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
                    "parallelism": ("single GPU" if world == 1 else
                                    "data parallel over rows x%d (36 rows per GPU, one gradient all-reduce per step)" % world
                                    if replica is not None else "iwae-sample shard x%d (all-gather of row statistics + "

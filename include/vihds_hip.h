@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 9
+#define VIHDS_ABI_VERSION 10
 
 /* error codes */
 #define VIHDS_OK 0
@@ -415,9 +415,54 @@ typedef struct vihds_adam_tensors {
   const float* grad[VIHDS_ADAM_MAX_TENSORS]; /* NULL: tensor received no gradient this step, skipped */
 } vihds_adam_tensors;
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                    float beta1, float beta2, float eps, float grad_scale, void* stream);
+                    float beta1, float beta2, float eps, float grad_scale, const float* gate, void* stream);
 /* grad_scale multiplies every gradient as it is read (1/world after a SUM all-reduce: the average of the replicas'
- * gradients at no extra pass). */
+ * gradients at no extra pass).
+ * gate (optional): one device float, the step's loss (-ELBO).  When it is not finite the launch updates NOTHING and
+ * does not count as a step -- the reference stops before optimizer.step on a NaN ELBO (training.py:331-334); the host
+ * reads the same value to report it.  (Without a gate, and always as a second line of defence, a non-finite gradient
+ * ELEMENT leaves its parameter and moments untouched.) */
+
+/* The rest of a training step behind the decoder launch, for a single process whose trainable parameters are the
+ * encoder's: IWAE loss (training.py:135-149), the backward through theta / log q / log p to q's tables, the backward
+ * through the encoder, and Adam (training.py:334-337) -- what vihds_theta_bwd (with a vihds_iwae_job) +
+ * vihds_encoder_bwd + vihds_adam_step do in five launches -- in TWO: one block per data row for everything that
+ * needs no other row (importance weights, theta adjoint, the encoder's per-row chain), then every parameter gradient
+ * as a fixed-order sum over the rows with the Adam update applied by the thread that formed it, and -ELBO.  Neither
+ * launch contains a fence, a ticket or a returning atomic.  A non-finite loss (some row's lse not finite) skips the
+ * whole update and the step count.
+ *   theta side: as vihds_theta_bwd with opts->q_rows / q_prec_is_log = 1 / opts->iwae (iwae.ticket is not used);
+ *     q_all [2P][B] is the encoder's table (means and LOG-precisions), g_all [2P][B] receives its gradient;
+ *     g_theta_unit [>= P][B][S] is vihds_theta_ode_logp_grad's unit-weight gradient.
+ *   encoder side: as vihds_encoder_bwd (g_pre [B][H], g_conv [B][F][Lc]: work buffers).
+ *   tensors, in this order: 0 global_free [2][ngl], 1 conv_w, 2 conv_b, 3 lin_w, 4 lin_b, 5 local_w, 6 local_b,
+ *     7 gcond_w: param[k] (updated in place), grad[k] (written: the gradients stay observable), mv_offset[k] = offset
+ *     of tensor k in the flat m / v buffers.  An absent tensor (no parameters at that level) has param[k] = NULL.
+ *   state: FOUR device floats {step count, (unused), 1/(1-beta1^t), sqrt(1-beta2^t)}: the first launch counts the
+ *     step and writes the two bias corrections for the second.  state = NULL: gradients and loss only, no update.
+ * VIHDS_E_UNSUPPORTED when the row working set (S importance weights + the encoder's row buffers) exceeds 60 KB of LDS. */
+typedef struct vihds_step_tail_args {
+  int P, S;
+  const int* kind;
+  const float* q_all;
+  const int* q_rows;
+  const float *p_mu, *p_prec, *clip_lo, *clip_hi;
+  const float* u;
+  const float* g_theta_unit;
+  vihds_iwae_job iwae;
+  float* g_all;
+  const float *delta_obs, *inputs, *dev1hot, *lin_w, *local_w, *pooled, *hidden;
+  float *g_pre, *g_conv;
+  float* param[8];
+  float* grad[8];
+  int mv_offset[8];
+  float *m, *v, *state;
+  const float* lr_dev;
+  float lr, beta1, beta2, eps;
+} vihds_step_tail_args;
+int vihds_step_tail(const vihds_encoder_shape* s, const vihds_step_tail_args* a, void* stream);
+int vihds_step_tail_supported(const vihds_encoder_shape* s, int P, int S); /* 1 / 0: shapes vihds_step_tail takes (LDS budget,
+                                                                             at most 10 filter taps) */
 
 #ifdef __cplusplus
 }

@@ -434,3 +434,96 @@ def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver):
         assert set(ref_grads) == set(got_grads), tag
         for k, g in ref_grads.items():
             assert rel_err(got_grads[k], g) < 1e-3, (tag, k)
+
+
+def _tail_run(tail, graph, n_steps, B=8, S=24, poison_at=None, **extra):
+    """n_steps training steps of the synthetic dr_constant_icml plate through Training.step / graph_step with the bench's
+    fast keys; returns (losses, last gradients, parameters after, optimizer step count, kernel names of one step)."""
+    from vihds import ops, synthetic
+
+    kw = dict(solver="rk4", seed=3, u_rng="kernel", conditioner_rng="kernel", nan_check_every=0, learning_rate=0.01,
+              fused_ode_training=True, fused_decoder_step=True, fused_iwae_backward=True, fused_step_tail=tail)
+    kw.update(extra)
+    args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", B, S, device="cuda:0",
+                                                                        hip_graph=graph, **kw)
+    model.train()
+    batch = training.train_data
+    losses, launched = [], []
+    clean = batch.observations.clone()
+    for k in range(n_steps):
+        if poison_at is not None:
+            # (in place: a captured step reads the batch from the buffers it was staged in)
+            batch.observations.copy_(clean)
+            if k == poison_at:
+                batch.observations[1, 2, 5] = float("nan")
+            training._staged.clear()
+        if graph:
+            loss = training.graph_step(batch)
+        else:
+            rec = ops.LaunchRecorder()
+            ops.TIMER = rec
+            try:  # (zero_grad only on the last step: autograd ACCUMULATES into .grad when it is left standing)
+                loss = training.step(batch, zero_grad=k < n_steps - 1)
+            finally:
+                ops.TIMER = None
+            launched = list(rec.calls)
+        losses.append(float(loss))
+    torch.cuda.synchronize()
+    grads = {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}
+    params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    return losses, grads, params, training.optimizer.step_count(), launched
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_step_tail_matches_the_five_launch_path(graph):
+    """params.fused_step_tail: IWAE loss + theta adjoint + encoder adjoint + Adam as vihds_step_tail's two launches
+    (row blocks, then gradient sums with the update applied in place) against the same step as vihds_theta_bwd (with the
+    IWAE job) + vihds_encoder_bwd (two launches) + vihds_adam_step: same draws (in-kernel generators, same seeds), so the
+    loss of every step, the last step's gradient of every encoder parameter, every parameter after 5 Adam steps and the
+    step counter must agree -- eagerly and replayed from the step's hipGraph."""
+    # ONE step from the same initial state: the tail's own arithmetic (v_exp / v_log / v_rcp in the theta adjoint, DPP
+    # scan sums) against the five-launch path's, before any Adam step can amplify a rounding difference
+    ref1 = _tail_run(False, graph, 1)
+    got1 = _tail_run(True, graph, 1)
+    assert abs(ref1[0][0] - got1[0][0]) <= 1e-6 * abs(ref1[0][0])
+    assert set(ref1[1]) == set(got1[1])
+    for k, g in ref1[1].items():
+        assert rel_err(got1[1][k], g) < 1e-5, k
+    for k, v in ref1[2].items():
+        assert rel_err(got1[2][k], v) < 1e-6, k
+    # five steps: Adam's first updates are lr * sign-like (m / sqrt(v)), so rounding-level gradient differences show up
+    # at the 1e-6 .. 1e-5 level in later losses
+    ref = _tail_run(False, graph, 5)
+    got = _tail_run(True, graph, 5)
+    if not graph:
+        assert "step_tail" in got[4] and "step_tail" not in ref[4], (got[4], ref[4])
+    for a, b in zip(ref[0], got[0]):
+        assert abs(a - b) <= 2e-5 * max(1.0, abs(a)), (ref[0], got[0])
+    assert set(ref[1]) == set(got[1])
+    for k, g in ref[1].items():
+        assert rel_err(got[1][k], g) < 2e-4, k
+    for k, v in ref[2].items():
+        assert rel_err(got[2][k], v) < 1e-4, k
+    assert ref[3] == got[3] == 5
+
+
+@pytest.mark.parametrize("tail", [False, True])
+def test_non_finite_loss_skips_the_whole_update(tail):
+    """The reference stops before optimizer.step on a NaN ELBO (training.py:331-334).  Here the launches of the step are
+    already queued when the host could look, so the update is gated on the device: a step whose loss is not finite leaves
+    every parameter, both Adam moments and the step count exactly as they were -- all or nothing -- with the separate Adam
+    launch (vihds_adam_step's `gate`) and with vihds_step_tail alike; the next finite step trains on."""
+    clean = _tail_run(tail, False, 2)
+    bad = _tail_run(tail, False, 3, poison_at=1)
+    assert np.isfinite(bad[0][0]) and not np.isfinite(bad[0][1]) and np.isfinite(bad[0][2]), bad[0]
+    assert bad[3] == 2  # the poisoned step did not count
+    # step 0 (finite) + step 1 (skipped) + step 2 (finite, same draws as the clean run's step... no: the generators moved
+    # on during the skipped step, so only the FIRST step is comparable value for value)
+    assert abs(bad[0][0] - clean[0][0]) <= 1e-6 * max(1.0, abs(clean[0][0]))
+    for k, v in bad[2].items():
+        assert torch.isfinite(v).all(), k
+    one = _tail_run(tail, False, 1)
+    two = _tail_run(tail, False, 2, poison_at=1)
+    for k, v in one[2].items():
+        assert torch.equal(two[2][k], v), k  # bit for bit what the single finite step left
+    assert two[3] == 1

@@ -805,6 +805,19 @@ def test_adam_step_skips_non_finite_gradient_elements():
     dev.grad = torch.full((1000,), float("nan"), device=DEV)
     opt.step()
     assert torch.equal(dev.detach(), before)
+    # the loss gate (vihds_adam_step's `gate`): a non-finite loss switches the whole launch off, finite gradient elements
+    # and the step count included; a finite one lets it through
+    n0 = opt.step_count()
+    dev.grad = gr.to(DEV)
+    opt.gate = torch.tensor(float("nan"), device=DEV)
+    opt.step()
+    assert torch.equal(dev.detach(), before) and opt.step_count() == n0
+    opt.gate = torch.tensor(float("inf"), device=DEV)
+    opt.step()
+    assert torch.equal(dev.detach(), before) and opt.step_count() == n0
+    opt.gate = torch.tensor(-12.5, device=DEV)
+    opt.step()
+    assert not torch.equal(dev.detach(), before) and opt.step_count() == n0 + 1
 
 
 def test_theta_kernel_draws_its_own_normals():

@@ -85,7 +85,9 @@ void launch_encoder_fwd(const vihds_encoder_shape&, const float*, const float*, 
 void launch_encoder_bwd(const vihds_encoder_shape&, const float*, const float*, const float*, const float*, const float*,
                         const float*, const float*, const float*, float*, float*, float*, float*, float*, float*, float*,
                         float*, float*, float*, hipStream_t);
-void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, float,
+bool step_tail_supported(const vihds_encoder_shape&, int, int);
+void launch_step_tail(const vihds_encoder_shape&, const vihds_step_tail_args&, hipStream_t);
+void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, float, const float*,
                  hipStream_t);
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
                          const int*, float*, float*, float*, float*, hipStream_t);
@@ -717,13 +719,45 @@ int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, i
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                    float beta1, float beta2, float eps, float grad_scale, void* stream) {
+                    float beta1, float beta2, float eps, float grad_scale, const float* gate, void* stream) {
   if (!t || !m || !v || !state) return fail(VIHDS_E_BADARG, "null argument");
   if (t->n < 0 || t->n > VIHDS_ADAM_MAX_TENSORS) return fail(VIHDS_E_BADARG, "tensor count out of range");
   for (int k = 0; k < t->n; ++k)
     if (t->size[k] < 0 || !t->param[k]) return fail(VIHDS_E_BADARG, "bad tensor table entry");
-  launch_adam(*t, m, v, state, lr_dev, lr, beta1, beta2, eps, grad_scale, (hipStream_t)stream);
+  launch_adam(*t, m, v, state, lr_dev, lr, beta1, beta2, eps, grad_scale, gate, (hipStream_t)stream);
   return check_hip("vihds_adam_step launch");
+}
+
+int vihds_step_tail_supported(const vihds_encoder_shape* s, int P, int S) {
+  if (!s || P <= 0 || S <= 0 || check_encoder_shape(s) != VIHDS_OK) return 0;
+  return step_tail_supported(*s, P, S) ? 1 : 0;
+}
+
+int vihds_step_tail(const vihds_encoder_shape* s, const vihds_step_tail_args* a, void* stream) {
+  if (int rc = check_encoder_shape(s)) return rc;
+  if (!a) return fail(VIHDS_E_BADARG, "null argument");
+  if (a->P <= 0 || a->S <= 0) return fail(VIHDS_E_BADARG, "P, S must be > 0");
+  if (!a->kind || !a->q_all || !a->q_rows || !a->p_mu || !a->p_prec || !a->clip_lo || !a->clip_hi || !a->u ||
+      !a->g_theta_unit || !a->g_all)
+    return fail(VIHDS_E_BADARG, "null theta-side argument");
+  const vihds_iwae_job& j = a->iwae;
+  if (!j.logp || !j.log_w || !j.lse || !j.loss || j.n_iwae_total <= 0)
+    return fail(VIHDS_E_BADARG, "vihds_iwae_job: null buffer or n_iwae_total <= 0");
+  if (!a->delta_obs || !a->lin_w || !a->pooled || !a->hidden || !a->g_pre || !a->g_conv)
+    return fail(VIHDS_E_BADARG, "null encoder-side argument");
+  if (s->nl > 0 && !a->local_w) return fail(VIHDS_E_BADARG, "missing local head weights");
+  if (((s->l_tr || s->g_tr) && s->n_tr > 0 && !a->inputs) || ((s->l_dv || s->g_dv) && s->D > 0 && !a->dev1hot))
+    return fail(VIHDS_E_BADARG, "missing conditioning input");
+  const bool need[8] = {s->ngl > 0, true, true, true, true, s->nl > 0, false, s->ng > 0};
+  for (int k = 0; k < 8; ++k) {
+    if (need[k] && (!a->param[k] || !a->grad[k])) return fail(VIHDS_E_BADARG, "missing parameter / gradient tensor");
+    if (a->param[k] && (!a->grad[k] || a->mv_offset[k] < 0)) return fail(VIHDS_E_BADARG, "bad tensor table entry");
+  }
+  if (a->state && (!a->m || !a->v)) return fail(VIHDS_E_BADARG, "state without moment buffers");
+  if (!step_tail_supported(*s, a->P, a->S))
+    return fail(VIHDS_E_UNSUPPORTED, "vihds_step_tail: working set exceeds the 60 KB LDS budget (or more than 10 filter taps)");
+  launch_step_tail(*s, *a, (hipStream_t)stream);
+  return check_hip("vihds_step_tail launch");
 }
 
 }  // extern "C"

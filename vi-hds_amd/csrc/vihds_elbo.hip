@@ -858,7 +858,8 @@ void launch_device_condition(int E, int B, int S, int S_total, int s_off, int D,
 constexpr int ADAM_CHUNK = 1024;
 __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* __restrict__ m, float* __restrict__ v,
                                                    float* state, const float* lr_dev, float lr, float beta1,
-                                                   float beta2, float eps, float grad_scale) {
+                                                   float beta2, float eps, float grad_scale,
+                                                   const float* __restrict__ gate) {
   // which tensor does this block belong to
   int blk = blockIdx.x, k = 0, off = 0;
   for (; k < t.n; ++k) {
@@ -868,7 +869,10 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
     off += t.size[k];
   }
   const float step = state[0] + 1.f;
-  if (k < t.n && t.grad[k] != nullptr) {
+  // gate = the step's loss: not finite -> nothing is updated and the step is not counted (all or nothing per step: the
+  // reference stops before optimizer.step on a NaN ELBO, training.py:331-334)
+  const bool open = gate == nullptr || fabsf(gate[0]) <= 3.402823466e38f;
+  if (open && k < t.n && t.grad[k] != nullptr) {
     const float bc1 = 1.f - powf(beta1, step);
     const float bc2_sqrt = sqrtf(1.f - powf(beta2, step));
     const float step_size = (lr_dev ? lr_dev[0] : lr) / bc1;
@@ -877,9 +881,8 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
     const int end = min(t.size[k], (blk + 1) * ADAM_CHUNK);
     for (int e = blk * ADAM_CHUNK + threadIdx.x; e < end; e += 256) {
       const float ge = g[e] * grad_scale;
-      // a non-finite gradient element (a NaN loss reaches every encoder gradient) leaves its parameter and moments as
-      // they were: the reference stops before optimizer.step on a NaN ELBO (training.py:331-334), here the check comes
-      // after the launch, so the update itself must not poison the state
+      // second line of defence (a finite loss with an overflowed gradient element): that element's parameter and
+      // moments stay as they were
       if (!(fabsf(ge) <= 3.402823466e38f)) continue;
       float me = m[off + e], ve = v[off + e];
       me += (ge - me) * (1.f - beta1);
@@ -894,19 +897,19 @@ __global__ void __launch_bounds__(256) adam_kernel(vihds_adam_tensors t, float* 
   if (threadIdx.x == 0) {
     const float ticket = atomicAdd(&state[1], 1.f);
     if (ticket == (float)(gridDim.x - 1)) {
-      state[0] = step;
+      if (open) state[0] = step;
       state[1] = 0.f;
     }
   }
 }
 
 void launch_adam(const vihds_adam_tensors& t, float* m, float* v, float* state, const float* lr_dev, float lr,
-                 float beta1, float beta2, float eps, float grad_scale, hipStream_t st) {
+                 float beta1, float beta2, float eps, float grad_scale, const float* gate, hipStream_t st) {
   int blocks = 0;
   for (int k = 0; k < t.n; ++k) blocks += (t.size[k] + ADAM_CHUNK - 1) / ADAM_CHUNK;
   if (blocks == 0) return;
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, m, v, state, lr_dev, lr, beta1, beta2, eps,
-                     grad_scale);
+                     grad_scale, gate);
 }
 void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
                          const float* traj, const float* xpred, const float* theta, const int* prec_rows, float* mu,

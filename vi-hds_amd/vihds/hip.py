@@ -114,6 +114,21 @@ class AdamTensors(ctypes.Structure):
                 ("param", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grad", ctypes.c_void_p * ADAM_MAX_TENSORS)]
 
 
+class StepTailArgs(ctypes.Structure):
+    """struct vihds_step_tail_args (include/vihds_hip.h)"""
+
+    _fields_ = [("P", ctypes.c_int), ("S", ctypes.c_int), ("kind", ctypes.c_void_p), ("q_all", ctypes.c_void_p),
+                ("q_rows", ctypes.c_void_p), ("p_mu", ctypes.c_void_p), ("p_prec", ctypes.c_void_p),
+                ("clip_lo", ctypes.c_void_p), ("clip_hi", ctypes.c_void_p), ("u", ctypes.c_void_p),
+                ("g_theta_unit", ctypes.c_void_p), ("iwae", IwaeJob), ("g_all", ctypes.c_void_p),
+                ("delta_obs", ctypes.c_void_p), ("inputs", ctypes.c_void_p), ("dev1hot", ctypes.c_void_p),
+                ("lin_w", ctypes.c_void_p), ("local_w", ctypes.c_void_p), ("pooled", ctypes.c_void_p),
+                ("hidden", ctypes.c_void_p), ("g_pre", ctypes.c_void_p), ("g_conv", ctypes.c_void_p),
+                ("param", ctypes.c_void_p * 8), ("grad", ctypes.c_void_p * 8), ("mv_offset", ctypes.c_int * 8),
+                ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("state", ctypes.c_void_p), ("lr_dev", ctypes.c_void_p),
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+
+
 _PROTOTYPES = {
     "vihds_abi_version": (_I, []),
     "vihds_last_error": (ctypes.c_char_p, []),
@@ -155,7 +170,9 @@ _PROTOTYPES = {
     "vihds_blackbox_tail_grads": (_I, [_P] * 8),
     "vihds_offset_rows_fwd": (_I, [_I] * 7 + [_P] * 5),
     "vihds_offset_rows_bwd": (_I, [_I] * 8 + [_P] * 4),
-    "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 5 + [_P]),
+    "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 5 + [_P, _P]),
+    "vihds_step_tail": (_I, [ctypes.POINTER(EncoderShape), ctypes.POINTER(StepTailArgs), _P]),
+    "vihds_step_tail_supported": (_I, [ctypes.POINTER(EncoderShape), _I, _I]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }
 
@@ -182,7 +199,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 9:
+        if handle.vihds_abi_version() != 10:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

@@ -988,6 +988,99 @@ def _run_iwae_job(job):
     hip.check(rc, "vihds_iwae_loss_fwd")
 
 
+class StepTail(object):
+    """Host side of vihds_step_tail (params.fused_step_tail): everything of a training step behind the decoder launch --
+    IWAE loss, the backward through theta / log q / log p to q's tables and through the encoder, Adam -- in two launches
+    instead of five, for a single process whose trainable parameters are exactly the encoder's.  It takes what the
+    step's forward left in its autograd nodes (DecoderStepFused: draws, unit-weight theta gradient, q tables;
+    EncoderQTables: pooled / hidden activations) and the deferred IWAE job, launches, and hands the gradients to the
+    parameters' .grad as views of one arena; autograd's backward and optimizer.step() are not run for that step."""
+
+    def __init__(self, encoder, optimizer):
+        lh, gh = encoder.local_heads, encoder.gcond_heads
+        c = encoder.conditional
+        self.tensors = [encoder.global_free, c.conv.weight, c.conv.bias, c.lin.weight, c.lin.bias,
+                        None if lh is None else lh.weight, None if lh is None else lh.bias,
+                        None if gh is None else gh.weight]
+        self.optimizer = optimizer
+        self._arena = {}
+
+    def applicable(self):
+        """Single parameter group holding exactly the encoder's tensors, HipAdam on the GPU."""
+        from vihds.optim import HipAdam
+
+        opt = self.optimizer
+        if not isinstance(opt, HipAdam) or len(opt.param_groups) != 1:
+            return False
+        group = [p for p in opt.param_groups[0]["params"] if p.requires_grad]
+        mine = [t for t in self.tensors if t is not None]
+        return len(group) == len(mine) and {id(p) for p in group} == {id(t) for t in mine} and all(t.is_cuda for t in mine)
+
+    def launch(self, dec_node, enc_node, job):
+        (q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, g_unit, _theta, _cond, _times, _obs,
+         _dev1hot) = dec_node.saved_tensors
+        delta_obs, inputs, dev_1hot, _cw, lin_w, local_w, _lb, _gw, _gf, pooled, hidden = enc_node.saved_tensors
+        s = enc_node.shape
+        P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
+        dev = q_all.device
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        st = opt._group_state(0, group)
+        offsets, off = {}, 0
+        for prm in st["params"]:
+            offsets[id(prm)] = off
+            off += prm.numel()
+        key = (B, str(dev))
+        if key not in self._arena or torch.cuda.is_current_stream_capturing():
+            # (a capture gets buffers of its own from the graph's pool: they must stay put for every replay)
+            sizes = [0 if t is None else t.numel() for t in self.tensors]
+            arena = torch.empty(sum(sizes), device=dev, dtype=torch.float32)
+            Lc = s.L - s.K + 1
+            bufs = (arena, sizes, torch.empty((2 * P, B), device=dev), torch.empty((B, s.H), device=dev),
+                    torch.empty((B, s.F, Lc), device=dev))
+            if torch.cuda.is_current_stream_capturing():
+                self._arena[key + ("capture", len(self._arena))] = bufs
+            else:
+                self._arena[key] = bufs
+        else:
+            bufs = self._arena[key]
+        arena, sizes, g_all, g_pre, g_conv = bufs
+        a = hip.StepTailArgs()
+        a.P, a.S = P, S
+        a.kind, a.q_all, a.q_rows = hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_rows)
+        a.p_mu, a.p_prec, a.clip_lo, a.clip_hi = hip.ptr(p_mu), hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi)
+        a.u, a.g_theta_unit = hip.ptr(u), hip.ptr(g_unit)
+        a.iwae.logp, a.iwae.log_p, a.iwae.log_q = hip.ptr(job["logp"]), hip.ptr(job["log_p"]), hip.ptr(job["log_q"])
+        a.iwae.n_iwae_total = job["n_total"]
+        a.iwae.log_w, a.iwae.lse, a.iwae.loss = hip.ptr(job["log_w"]), hip.ptr(job["rows"][2]), hip.ptr(job["loss"])
+        a.g_all = hip.ptr(g_all)
+        a.delta_obs, a.inputs, a.dev1hot = hip.ptr(delta_obs), hip.ptr(inputs), hip.ptr(dev_1hot)
+        a.lin_w, a.local_w, a.pooled, a.hidden = hip.ptr(lin_w), hip.ptr(local_w), hip.ptr(pooled), hip.ptr(hidden)
+        a.g_pre, a.g_conv = hip.ptr(g_pre), hip.ptr(g_conv)
+        views, o = [], 0
+        for k, t in enumerate(self.tensors):
+            if t is None:
+                views.append(None)
+                continue
+            if not t.is_contiguous():
+                raise RuntimeError("vihds_step_tail needs contiguous parameters")
+            views.append(arena[o:o + sizes[k]].view(t.shape))
+            a.param[k], a.grad[k], a.mv_offset[k] = t.data_ptr(), views[-1].data_ptr(), offsets[id(t)]
+            o += sizes[k]
+        lr = group["lr"]
+        a.m, a.v, a.state = st["m"].data_ptr(), st["v"].data_ptr(), st["state"].data_ptr()
+        a.lr_dev = hip.ptr(lr) if isinstance(lr, torch.Tensor) else None
+        a.lr = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
+        a.beta1, a.beta2 = group["betas"]
+        a.eps = group["eps"]
+        rc = _launch("step_tail", lambda: hip.lib().vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream()))
+        hip.check(rc, "vihds_step_tail")
+        for t, v in zip(self.tensors, views):
+            if t is not None:
+                t.grad = v
+        return job["loss"]
+
+
 class IwaeLossSharded(torch.autograd.Function):
     """-ELBO with the S axis sharded over the ranks of `group`: rows kernel, ONE all-gather of the [2,B]
     (max, sum-exp) pairs (a graph break when the step is being captured), then one combine launch giving the global

@@ -18,6 +18,7 @@ class HipAdam(torch.optim.Optimizer):
         """grad_scale multiplies every gradient as the kernel reads it (1/world after a SUM all-reduce)."""
         super(HipAdam, self).__init__(params, dict(lr=lr, betas=betas, eps=eps, grad_scale=grad_scale))
         self._flat = {}
+        self.gate = None  # one device float (the step's loss): a non-finite value makes step() a no-op on the device
 
     def _group_state(self, gi, group):
         st = self._flat.get(gi)
@@ -29,7 +30,7 @@ class HipAdam(torch.optim.Optimizer):
             total = sum(p.numel() for p in ps)
             dev = ps[0].device
             st = {"params": ps, "m": torch.zeros(total, device=dev), "v": torch.zeros(total, device=dev),
-                  "state": torch.zeros(2, device=dev)}
+                  "state": torch.zeros(4, device=dev)}  # {step count, block ticket, 2 words of vihds_step_tail}
             self._flat[gi] = st
         return st
 
@@ -66,7 +67,7 @@ class HipAdam(torch.optim.Optimizer):
                 rc = L.vihds_adam_step(ctypes.byref(tab), st["m"][off:].data_ptr(), st["v"][off:].data_ptr(),
                                        state.data_ptr(), hip.ptr(lr_dev), 0.0 if lr_dev is not None else float(lr),
                                        beta1, beta2, group["eps"], float(group.get("grad_scale", 1.0)),
-                                       hip.current_stream())
+                                       hip.ptr(self.gate), hip.current_stream())
                 hip.check(rc, "vihds_adam_step")
                 off += n_chunk
         return loss

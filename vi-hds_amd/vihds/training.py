@@ -108,6 +108,11 @@ class Training:
         else:
             self.train_path = self.valid_path = None
         self.empty_cache = True
+        # the step's tail (loss, backward, Adam) as two launches: vihds_step_tail (off by default: reference call sequence)
+        self.fused_tail = bool(default_get_value(p, "fused_step_tail", False)) and on_gpu
+        self._tail, self._tail_ok, self._tail_shapes = None, False, {}
+        if on_gpu:
+            self.optimizer.gate = None
         self._graphs = {}
         self._staged = {}
         self._grad_buffer = None
@@ -229,6 +234,11 @@ class Training:
             elbo = self.cost(batch, batch_results, theta, q, p).elbo
         finally:
             self._in_step = False
+        if self._step_tail(batch_results, q) is not None:
+            # params.fused_step_tail: loss, backward and Adam ran as vihds_step_tail's two launches
+            if zero_grad:
+                self.optimizer.zero_grad(set_to_none=True)
+            return elbo.detach()
         if elbo.is_cuda:
             elbo.backward(ops.unit_gradient(elbo.device))  # no ones_like fill, and no launch for the loss's backward
         else:
@@ -245,10 +255,43 @@ class Training:
         sync = self.shard if self.shard is not None else self.replica
         if sync is not None:
             self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), sync.group, self._grad_buffer)
+        if elbo.is_cuda:
+            # a non-finite loss makes the update a no-op on the device, step count included (the reference stops before
+            # optimizer.step on a NaN ELBO, training.py:331-334; here the host reads the loss after the launches)
+            self.optimizer.gate = elbo.detach()
         self.optimizer.step()
         if zero_grad:
             self.optimizer.zero_grad(set_to_none=True)
         return elbo.detach()
+
+    def _step_tail(self, batch_results, q):
+        """params.fused_step_tail (single process, fused decoder step with a deferred IWAE loss, all trainable parameters
+        in the encoder): hand the rest of the step to ops.StepTail.  Returns the loss tensor, or None when it does not
+        apply (the caller then runs autograd's backward and optimizer.step())."""
+        if not self.fused_tail or self.shard is not None or self.replica is not None or len(ops._PENDING_IWAE) != 1:
+            return None
+        sol = getattr(batch_results, "solution", None)
+        dec_node = getattr(getattr(sol, "logp_buffer", None), "grad_fn", None)
+        packed = getattr(q, "_packed_q", None)
+        enc_node = getattr(packed[1], "grad_fn", None) if packed is not None else None
+        if (type(dec_node).__name__ != "DecoderStepFusedBackward" or type(enc_node).__name__ != "EncoderQTablesBackward"):
+            return None
+        if self._tail is None:
+            self._tail = ops.StepTail(self.model.encoder, self.optimizer)
+            self._tail_ok = self._tail.applicable()
+        if not self._tail_ok:
+            return None
+        q_all, u = dec_node.saved_tensors[0], dec_node.saved_tensors[6]
+        key = (q_all.shape, u.shape[1])
+        if key not in self._tail_shapes:  # (the library declines shapes past its LDS budget: the five-launch path then)
+            from vihds import hip
+
+            self._tail_shapes[key] = bool(hip.lib().vihds_step_tail_supported(enc_node.shape, q_all.shape[0] // 2, u.shape[1]))
+        if not self._tail_shapes[key]:
+            return None
+        (job,) = ops._PENDING_IWAE.values()
+        ops._PENDING_IWAE.clear()
+        return self._tail.launch(dec_node, enc_node, job)
 
     def _snapshot_training_state(self):
         """Parameters + optimizer state before a capture's warm-up steps (a new batch shape, e.g. an epoch's last partial
@@ -351,9 +394,10 @@ class Training:
         elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
         self._steps += 1
         if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
-            # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced
-            # the NaN has already been launched -- HipAdam's kernel skips non-finite gradient elements, so the
-            # parameters and moments are those of the last finite step)
+            # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced the
+            # NaN has already been launched -- the Adam launch is gated on the loss on the device (vihds_adam_step's
+            # `gate`, vihds_step_tail's row check), so parameters, moments and the step count are those of the last
+            # finite step)
             print("Cannot proceed with ELBO = nan. Exiting.")
             return False
         log_data.batch_train_time += time.time() - train_start
