@@ -399,6 +399,9 @@ def main():
     ap.add_argument("--no-step-tail", action="store_true",
                     help="keep IWAE loss + theta adjoint, the encoder adjoint (two launches) and Adam as the five launches of "
                          "round 2 instead of vihds_step_tail's two")
+    ap.add_argument("--steps-per-graph", type=int, default=8,
+                    help="consecutive training steps captured into one hipGraph (single process, resident batch); 1 = one "
+                         "graph launch per step as in round 2")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -454,14 +457,27 @@ def main():
             torch.distributed.barrier()
             torch.cuda.synchronize()
 
+    # steps per graph launch: between two graph launches the GPU idles 6-8 us (measured: rocprofv3 kernel trace), so the
+    # resident-batch replay captures G consecutive steps per graph; K timed steps = K // G launches of that graph plus
+    # K % G launches of the one-step graph -- exactly K optimizer steps either way
+    G = max(1, a.steps_per_graph) if (use_graph and not multi) else 1
+
+    def run_steps(k):
+        out = None
+        for _ in range(k // G):
+            out = training.graph_step(batch, repeat=G) if G > 1 else step(batch)
+        for _ in range(k % G if G > 1 else 0):
+            out = step(batch)
+        return out
+
     if use_graph:
         step(batch)  # setup, not a measured or warm-up step: allocator warm-up + hipGraph capture happen on first use
-    for _ in range(a.warmup):
-        loss = step(batch)
+        if G > 1:
+            training.graph_step(batch, repeat=G)  # (same for the G-step graph: G untimed steps)
+    loss = run_steps(a.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
-        loss = step(batch)
+    loss = run_steps(a.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if multi:
@@ -574,7 +590,7 @@ def main():
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
                    "rows_global": B_ROWS * (world if replica is not None else 1),
-                   "launch": launch_mode, "learning_rate": a.lr,
+                   "launch": launch_mode, "steps_per_graph_launch": G, "learning_rate": a.lr,
                    "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
                                     "encoders.py:385) are outside the replayed step",
                    "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "tail": "loss + backward + Adam: five launches" if (a.no_step_tail or multi) else "vihds_step_tail (IWAE loss + theta adjoint + encoder adjoint + Adam in two launches)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),

@@ -527,3 +527,32 @@ def test_non_finite_loss_skips_the_whole_update(tail):
     for k, v in one[2].items():
         assert torch.equal(two[2][k], v), k  # bit for bit what the single finite step left
     assert two[3] == 1
+
+
+@pytest.mark.parametrize("tail", [False, True])
+def test_multi_step_graph_matches_one_step_graphs(tail):
+    """graph_step(batch, repeat=3): three consecutive training steps captured into ONE hipGraph (what bench.py replays to
+    amortise the idle time between graph launches).  Two launches of it must walk the same loss sequence, and leave the
+    same parameters and step count, as six launches of the one-step graph -- with the five-launch tail (whose autograd
+    gradients must not accumulate from one captured step into the next) and with vihds_step_tail."""
+    from vihds import synthetic
+
+    kw = dict(solver="rk4", seed=3, u_rng="kernel", conditioner_rng="kernel", nan_check_every=0, learning_rate=0.01,
+              fused_ode_training=True, fused_decoder_step=True, fused_iwae_backward=True, fused_step_tail=tail)
+    runs = {}
+    for repeat in (1, 3):
+        args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 8, 24, device="cuda:0",
+                                                                            hip_graph=True, **kw)
+        model.train()
+        batch = training.train_data
+        losses = []
+        for _ in range(6 // repeat):
+            last = training.graph_step(batch, repeat=repeat)
+            losses += [float(x) for x in training.last_losses] if repeat > 1 else [float(last)]
+        torch.cuda.synchronize()
+        runs[repeat] = (losses, {k: v.detach().clone() for k, v in model.named_parameters()}, training.optimizer.step_count())
+    assert len(runs[3][0]) == 6 and runs[1][2] == runs[3][2] == 6
+    for a, b in zip(runs[1][0], runs[3][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs[1][0], runs[3][0])
+    for k, v in runs[1][1].items():
+        assert rel_err(runs[3][1][k], v) < 1e-6, k

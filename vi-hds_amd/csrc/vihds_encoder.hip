@@ -33,6 +33,21 @@ __device__ __forceinline__ float wave_sum_e(float v) {
   for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
   return v;
 }
+// the same sum as a DPP scan (row_shr 1, 2, 4, 8, row_bcast 15, 31; total in lane 63, returned uniformly): six dependent
+// VALU steps instead of six ds_bpermute round trips through the LDS crossbar -- the forward kernel is a chain of such sums
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float enc_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_total_e(float v) {
+  v += enc_dpp<0x111, 0xf>(v);
+  v += enc_dpp<0x112, 0xf>(v);
+  v += enc_dpp<0x114, 0xf>(v);
+  v += enc_dpp<0x118, 0xf>(v);
+  v += enc_dpp<0x142, 0xa>(v);
+  v += enc_dpp<0x143, 0xc>(v);
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
 // head inputs of data row b: local = [hidden, treatments?, dev_1hot?]; gcond = [treatments?, dev_1hot?]
 __device__ __forceinline__ float local_input(const vihds_encoder_shape& s, const float* hid, const float* inputs,
                                              const float* dev1hot, int b, int i) {
@@ -56,7 +71,7 @@ __device__ __forceinline__ float gcond_input(const vihds_encoder_shape& s, const
 
 // ---------------------------------------------------------------------------------------------------------------
 // forward: one block per data row
-// LDS: x [C_in*L] | conv weights [F*C_in*K] | conv out [F*Lc] | pooled [F*Lp] | hidden [H]
+// LDS: x [C_in*L] | conv weights [F*C_in*K] | conv bias [F] | conv out [F*Lc] | pooled [F*Lp] | hidden [H]
 constexpr int ENC_T = 1024;  // threads per block: these kernels are pure latency, so every phase is spread as wide as
                              // its output count allows (760 conv outputs, 720 pooled values, 16 waves for the Linear)
 __global__ void __launch_bounds__(ENC_T)
@@ -72,7 +87,8 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   const int b = blockIdx.x, tid = threadIdx.x, B = s.B;
   float* x = lds;
   float* cw = x + s.C_in * s.L;
-  float* cv = cw + s.F * s.C_in * s.K;
+  float* cb = cw + s.F * s.C_in * s.K;  // conv bias (read per conv output: from LDS, not a global load behind the barrier)
+  float* cv = cb + s.F;
   float* pl = cv + s.F * d.Lc;
   float* hid = pl + d.NPOOL;
   const int lane = tid & 63, wid = tid >> 6;
@@ -109,13 +125,40 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   }
   for (int q = tid; q < s.C_in * s.L; q += ENC_T) x[q] = delta_obs[(size_t)b * s.C_in * s.L + q];
   for (int q = tid; q < s.F * s.C_in * s.K; q += ENC_T) cw[q] = conv_w[q];
+  for (int q = tid; q < s.F; q += ENC_T) cb[q] = conv_b[q];
+  // rows of the table that are plain copies (global free scalars, constants, zeros): nothing to wait for, written now
+  {
+    const int n_rows_all = 2 * (s.nl + s.ng + s.ngl + s.nc), n_dot0 = 2 * (s.nl + s.ng);
+    for (int r = n_dot0 + tid; r < n_rows_all; r += ENC_T) {
+      float v;
+      if (r < 2 * (s.nl + s.ng + s.ngl)) {
+        v = global_free[r - n_dot0];
+      } else {
+        const int rr = r - 2 * (s.nl + s.ng + s.ngl);
+        v = rr < s.nc ? const_values[rr] : 0.f;
+      }
+      q_all[(size_t)r * B + b] = v;
+    }
+  }
+  // what the heads multiply besides the hidden units (treatments, device one-hot) and their biases: requested here, used
+  // after the last barrier (as loads in the head phase they were one more memory round trip at the kernel's tail)
+  float xl_pre = 0.f, xg_pre = 0.f, hb[HEAD_R] = {0.f, 0.f, 0.f, 0.f};
+  if (fast_heads) {
+    if (lane >= s.H && lane < d.NX) xl_pre = local_input(s, nullptr, inputs, dev1hot, b, lane);
+    if (lane < d.NG) xg_pre = gcond_input(s, inputs, dev1hot, b, lane);
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) {
+      const int r = wid + rr * NW;
+      if (r < 2 * s.nl && local_b) hb[rr] = local_b[r];
+    }
+  }
   __syncthreads();
   // Conv1d (cross-correlation, no padding): out[o][t] = bias[o] + sum_c sum_k w[o][c][k] x[c][t+k]
   for (int q = tid; q < s.F * d.Lc; q += ENC_T) {
     const int o = q / d.Lc, t = q - o * d.Lc;
     // two accumulators and an unrolled tap loop: the LDS reads of several taps are in flight together (as one
     // dependent chain of C_in*K = 40 read-read-FMA steps this phase took 1.75 us)
-    float acc0 = conv_b[o], acc1 = 0.f;
+    float acc0 = cb[o], acc1 = 0.f;
     for (int c = 0; c < s.C_in; ++c) {
       const float* wr = cw + (o * s.C_in + c) * s.K;
       const float* xr = x + c * s.L + t;
@@ -154,7 +197,7 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
 #pragma unroll
     for (int u = 0; u < LIN_U; ++u) {
       const int j = wid + u * NW;
-      const float t = wave_sum_e(acc[u]);
+      const float t = wave_total_e(acc[u]);
       if (lane == 0 && j < s.H) {
         const float h = tanhf(t + lb[u]);
         hid[j] = h;
@@ -175,7 +218,7 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int j = j0 + u * NW;
-        const float t = wave_sum_e(acc[u]);
+        const float t = wave_total_e(acc[u]);
         if (lane == 0 && j < s.H) {
           const float h = tanhf(t + lin_b[j]);
           hid[j] = h;
@@ -187,17 +230,16 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   __syncthreads();
   // heads -> rows of the level-blocked table [local mu; local lp; gcond mu; gcond lp; global mu; global lp; const; 0]
   // rows with a dot product: one wave per row (lanes over the inputs); the rest are copies
-  const int n_rows = 2 * (s.nl + s.ng + s.ngl + s.nc);
   if (fast_heads) {
 #pragma unroll
     for (int rr = 0; rr < HEAD_R; ++rr) {
       const int r = wid + rr * NW;
       if (r >= n_dot) break;  // (uniform per wave)
       float xin = 0.f;
-      if (r < 2 * s.nl) { if (lane < d.NX) xin = local_input(s, hid, inputs, dev1hot, b, lane); }
-      else if (lane < d.NG) xin = gcond_input(s, inputs, dev1hot, b, lane);
-      const float acc = wave_sum_e(hw[rr] * xin);
-      if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
+      if (r < 2 * s.nl) { if (lane < d.NX) xin = lane < s.H ? hid[lane] : xl_pre; }
+      else if (lane < d.NG) xin = xg_pre;
+      const float acc = wave_total_e(hw[rr] * xin);
+      if (lane == 0) q_all[(size_t)r * B + b] = acc + hb[rr];
     }
   } else {
     for (int r = wid; r < n_dot; r += NW) {
@@ -209,19 +251,9 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
         const float* wr = gcond_w + (size_t)(r - 2 * s.nl) * d.NG;
         for (int i = lane; i < d.NG; i += 64) acc += wr[i] * gcond_input(s, inputs, dev1hot, b, i);
       }
-      acc = wave_sum_e(acc);
+      acc = wave_total_e(acc);
       if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
     }
-  }
-  for (int r = n_dot + tid; r < n_rows; r += ENC_T) {
-    float v;
-    if (r < 2 * (s.nl + s.ng + s.ngl)) {
-      v = global_free[r - n_dot];
-    } else {
-      const int rr = r - 2 * (s.nl + s.ng + s.ngl);
-      v = rr < s.nc ? const_values[rr] : 0.f;
-    }
-    q_all[(size_t)r * B + b] = v;
   }
 }
 
@@ -420,7 +452,7 @@ encoder_bwd_reduce_kernel(vihds_encoder_shape s, EncReduceTasks tk, const float*
 // ---- launchers -------------------------------------------------------------------------------------------------
 size_t encoder_fwd_lds_bytes(const vihds_encoder_shape& s) {
   const EncDims d = enc_dims(s);
-  return sizeof(float) * ((size_t)s.C_in * s.L + (size_t)s.F * s.C_in * s.K + (size_t)s.F * d.Lc + d.NPOOL + s.H);
+  return sizeof(float) * ((size_t)s.C_in * s.L + (size_t)s.F * s.C_in * s.K + s.F + (size_t)s.F * d.Lc + d.NPOOL + s.H);
 }
 size_t encoder_bwd_lds_bytes(const vihds_encoder_shape& s) {
   const EncDims d = enc_dims(s);

@@ -336,13 +336,20 @@ class Training:
                 else:  # created (seeded) by the warm-up: keep the seed, rewind the step / ticket words
                     t[2:].zero_()
 
-    def graph_step(self, batch):
+    def graph_step(self, batch, repeat=1):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
         graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and a fixed batch shape.
         Capture follows PyTorch's whole-network recipe: warm up on a side stream, drop the .grad tensors, then
         capture forward + backward + optimizer.step() so the gradients live in the graph's private pool and are
-        rewritten (not accumulated) by every replay."""
-        key = tuple(batch.observations.shape)
+        rewritten (not accumulated) by every replay.
+        repeat > 1: that many CONSECUTIVE steps on this batch in one graph (the same launches `repeat` times over, each
+        with its own draws and its own Adam step: the generators and the step counter live on the device) -- between two
+        graph launches the GPU idles for 6-8 us, which at ~90 us per step is worth amortising when the batch is resident
+        anyway.  Returns the loss of the last step; all of them are in self.last_losses."""
+        repeat = int(repeat)
+        if repeat > 1 and (self.shard is not None or self.replica is not None):
+            raise ValueError("graph_step(repeat > 1) is for single-process steps (the multi-rank step is cut at its collectives)")
+        key = tuple(batch.observations.shape) + ((repeat,) if repeat > 1 else ())
         if key not in self._graphs:
             static = attrify({k: (v.clone(memory_format=torch.contiguous_format) if isinstance(v, torch.Tensor) else v)
                               for k, v in batch.items()})
@@ -373,7 +380,9 @@ class Training:
                 else:
                     g = torch.cuda.CUDAGraph()
                     with torch.cuda.graph(g):
-                        loss = self.step(static, zero_grad=False)
+                        # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
+                        loss = [self.step(static, zero_grad=k < repeat - 1) for k in range(repeat)]
+                        loss = loss[0] if repeat == 1 else loss
             finally:
                 if _warn is not None:
                     _warn(True)  # only the capture itself is exempt, not the rest of the process
@@ -385,6 +394,9 @@ class Training:
             static["delta_obs"].copy_(_delta_obs(static.observations))
             self._staged[key] = batch
         g.replay()
+        if repeat > 1:
+            self.last_losses = loss
+            return loss[-1]
         return loss
 
     def _run_batch(self, epoch_start, batch, log_data):
