@@ -350,8 +350,9 @@ def test_two_replicas_row_data_parallel_plumbing():
     assert all(np.isfinite(diff)) and min(diff[-5:]) < diff[0]
 
 
+@pytest.mark.parametrize("tail", [False, True])
 @pytest.mark.parametrize("solver", ["rk4", "modeuler"])
-def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver):
+def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver, tail):
     """The launch bench.py times, checked directly: synthetic dr_constant_icml batch, B=36, S=200, T=86, in-kernel
     Philox for u and the conditioner weights, vihds_theta_ode_logp_grad (sampling + conditioning + integration +
     log-likelihood + unit-weight adjoint in one launch) -> IWAE loss -> theta adjoint -> encoder adjoint, once
@@ -364,8 +365,10 @@ def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver):
     from vihds import ops, synthetic
 
     B, S = 36, 200
+    # tail: the rest of the step as vihds_step_tail's two launches (bench.py's default) instead of theta adjoint + encoder
+    # adjoint + Adam as five; the encoder gradients it leaves in .grad are checked against the same oracle numbers
     kw = dict(solver=solver, seed=1, u_rng="kernel", conditioner_rng="kernel", nan_check_every=0, learning_rate=0.001,
-              fused_ode_training=True)
+              fused_ode_training=True, fused_iwae_backward=tail, fused_step_tail=tail)
     twin = None
     for graph in (False, True):
         args, settings, data, parameters, model, training = synthetic.build(
@@ -432,8 +435,10 @@ def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver):
         assert rel_err(loss, out["loss"]) < 1e-4, tag
         ref_grads = {k: v.grad for k, v in c_model.named_parameters() if v.grad is not None}
         assert set(ref_grads) == set(got_grads), tag
-        for k, g in ref_grads.items():
-            assert rel_err(got_grads[k], g) < 1e-3, (tag, k)
+        errs = {k: float(rel_err(got_grads[k], g)) for k, g in ref_grads.items()}
+        print("encoder-gradient errors vs oracle (%s, %s): %s" % (solver, tag, {k: "%.1e" % v for k, v in errs.items()}))
+        for k, e in errs.items():
+            assert e < 2e-5, (tag, k, errs)
 
 
 def _tail_run(tail, graph, n_steps, B=8, S=24, poison_at=None, **extra):

@@ -1750,3 +1750,92 @@ def test_offset_rows_against_torch():
                                        theta.data_ptr(), hip.current_stream()) < 0   # overlapping rows
         assert L.vihds_offset_rows_fwd(B, S, D, n, R, src, R, W.data_ptr(), bias.data_ptr(), dev.data_ptr(),
                                        theta.data_ptr(), hip.current_stream()) < 0   # rows past the buffer
+
+
+def _conditioner_weights_from_fixture(fx):
+    """The reference re-draws the device conditioner's weights on every call (ode.py:48) and the fixtures keep only its
+    OUTPUT rows (extra_theta = aR, aS [E,B,S]).  With one-hot device blocks each output is default + relu(w[e][hot column])
+    (ode.py:43-58), so the weights that produced the rows can be read back exactly: w = out - default for the hot, relevant
+    column of the row the reference's tiling picked, r = (b S + s) mod B."""
+    import json
+
+    cfg = json.loads(str(fx.z["config_json"]))
+    names = list(fx.extra_names)
+    rel = np.stack([np.asarray(cfg["relevance"][n], np.float32) for n in names])
+    dflt = np.array([1 if n in cfg["default_devices"] else 0 for n in names], np.int32)
+    d1 = fx.z["dev_1hot"]
+    extra = fx.z["extra_theta"]
+    E, B, S = extra.shape
+    w = np.full(rel.shape, -1.0, np.float32)  # (a column never seen, or one the relu cut off: any negative weight)
+    for e in range(E):
+        for b in range(B):
+            for s in range(S):
+                r = (b * S + s) % B
+                hot = np.nonzero(d1[r] * rel[e])[0]
+                assert len(hot) <= 1
+                c = np.float32(extra[e, b, s]) - np.float32(dflt[e])
+                if len(hot) == 1 and c > 0:
+                    w[e, hot[0]] = c
+                else:
+                    assert c == 0
+    return torch.tensor(w), torch.tensor(rel), torch.tensor(dflt)
+
+
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "dr_constant_icml_full_modeuler",
+                                  "dr_constant_one_s5_modeulerwhile", "dr_constant_v2_tiny_modeuler"])
+def test_time_parallel_kernel_matches_reference_fixture(name):
+    """The kernel family bench.py times (kernel_variant 3: the time axis in parallel, csrc/vihds_dr_scan.hpp), compared
+    DIRECTLY with outputs of the reference (before, it was checked against the lane kernels and the
+    oracle only): (a) vihds_ode_logp_grad on the fixture's theta -- per-signal log-likelihood, loss, d loss / d theta;
+    (b) vihds_theta_ode_logp_grad, the bench's decoder launch, fed the fixture's u and the conditioner weights read back
+    from the fixture's aR / aS rows -- theta, aR / aS, log q, log p, log-likelihood, loss, and through vihds_theta_bwd
+    d loss / d mu and d loss / d log-precision of every parameter, against the reference's autograd."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture(name)
+    P, B, S = len(fx.names), fx.B, fx.S
+    # ---- (a)
+    th, row_of = H.pack_theta(fx, DEV)
+    th.requires_grad_(True)
+    spec3 = H.spec_for(fx, row_of, th.shape[0], fx.solver, 3)
+    logp = ops.OdeLogLikFused.apply(spec3, th, fx.t("inputs", DEV), fx.t("times", DEV), fx.t("observations", DEV), None)
+    assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
+    loss, log_w, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
+    assert rel_err(loss, fx.t("loss")) < TOL
+    loss.backward()
+    thc = fx.theta_dict(requires_grad=True)
+    qm, qp = fx.q_params()
+    pm, pp = fx.p_params()
+    vals = [thc[n] for n in fx.names]
+    lw_extra = O.chained_log_prob(fx.kinds, pm, pp, vals) - O.chained_log_prob(fx.kinds, qm, qp, vals)
+    (lw_extra * (torch.softmax(log_w.detach().cpu(), dim=1) * (-1.0 / B))).sum().backward()
+    extra = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(B, S) for n in fx.names])
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    assert rel_err((th.grad[:P].cpu() + extra)[live], fx.t("theta_grad")[live], dim=0) < GTOL
+    # ---- (b)
+    kind, q_mu, q_prec, p_mu, p_prec, lo, hi = H.theta_inputs(fx, DEV)
+    q_all = torch.cat([q_mu, q_prec.log()], 0).contiguous().requires_grad_(True)
+    rows = torch.arange(2 * P, dtype=torch.int32, device=DEV)
+    cond_job = None
+    if fx.extra_names:
+        w, rel, dflt = _conditioner_weights_from_fixture(fx)
+        cond_job = (len(fx.extra_names), P, 0.0, 1.0, w.to(DEV), None, rel.to(DEV), dflt.to(DEV))
+    theta, log_q, log_p, _u, logp2 = ops.DecoderStepFused.apply(
+        q_all, kind, p_mu, p_prec, lo, hi, fx.t("u", DEV), P + len(fx.extra_names), rows, spec3, fx.t("inputs", DEV),
+        fx.t("times", DEV), fx.t("observations", DEV), fx.t("dev_1hot", DEV), cond_job)
+    assert rel_err(theta[:P], fx.t("theta"), dim=0) < 1e-5
+    if fx.extra_names:
+        assert torch.equal(theta[P:].cpu(), fx.t("extra_theta"))
+    assert rel_err(log_q, fx.t("log_q")) < TOL and rel_err(log_p, fx.t("log_p")) < TOL
+    assert rel_err(H.view_bs4(logp2), fx.t("log_p_by_species"), dim=2) < TOL
+    loss2, _, _ = ops.iwae_loss(logp2, log_p, log_q)
+    assert rel_err(loss2, fx.t("loss")) < TOL
+    loss2.backward()
+    g = q_all.grad.cpu()
+    glob = fx.t("q_is_global").bool()
+    gm, gl = g[:P].clone(), g[P:].clone()
+    gm[glob] = gm[glob].sum(1, keepdim=True).expand(-1, B)
+    gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, B)
+    assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < GTOL
+    assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL
