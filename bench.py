@@ -17,6 +17,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` 
 (ODE adjoint) and `cpu_baseline` (the oracle's op-by-op CPU restatement of the same step, timed here)."""
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -373,6 +374,67 @@ def run_workload(a, name):
     print(json.dumps(out))
 
 
+def strong_scaling_leg(a, dev, world, rank):
+    """BASELINE config 3's partitioning next to the headline's weak-scaling line: ONE batch (36 rows, n_iwae = 1000) with its
+    IWAE-sample axis sharded over the ranks (all-gather of the row statistics + one gradient all-reduce per step; same code
+    as `--workload config3_train --shard samples`).  Returned as an object of the same JSON line; a failure is reported
+    in it, never raised (the headline line must come out)."""
+    from vihds import parallel, synthetic
+
+    S = 1000
+    try:
+        if S % world:
+            return {"skipped": "n_iwae=%d does not split over %d ranks" % (S, world)}
+        shard = parallel.SampleShard(rank, world)
+        args, settings, data, parameters, model, training = synthetic.build(
+            "dr_constant_icml", B_ROWS, S, solver=a.solver, device=dev, seed=a.seed, shard=shard, u_rng=a.device_rng,
+            conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=0, learning_rate=a.lr,
+            fused_ode_training=not a.two_kernel_ode)
+        model.train()
+        batch = training.train_data
+        step = training.step if a.eager else training.graph_step
+        step(batch)
+        for _ in range(5):
+            step(batch)
+        n = 50
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            loss = step(batch)
+        torch.cuda.synchronize()
+        torch.distributed.barrier()
+        el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
+        el = float(el)
+        return {"workload": "config3_train: ONE batch of 36 rows, n_iwae=1000 sharded over the ranks (--shard samples)",
+                "scaling": "strong", "value": n / el, "unit": "steps/s", "ms_per_step": 1e3 * el / n, "steps": n,
+                "n_iwae_per_gpu": S // world, "final_loss": float(loss)}
+    except Exception as e:  # noqa: BLE001
+        return {"error": "%s: %s" % (type(e).__name__, e)}
+
+
+def issue_bound(kernel_name, mean_us):
+    """HBM is demonstrably not what bounds the headline launch (measured traffic is ~10x below the algorithmic bytes: the
+    trajectory stays in LDS), VALU issue is the nearer ceiling: instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, a pass
+    of its own; newest profiles/r*_pmc_valu.json holding this kernel) / 1024 SIMDs x the measured issue interval of a busy
+    SIMD (tests/micro/issue_rate.hip: one wavefront instruction per ~2.7 cycles with >= 4 wavefronts resident, 2.4 GHz)."""
+    import glob
+
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")), reverse=True):
+        ks = json.load(open(f))["kernels"]
+        if kernel_name in ks:
+            insts = ks[kernel_name]["SQ_INSTS_VALU"]
+            cyc, clk, simds = 2.7, 2.4e9, 1024
+            t_us = insts / simds * cyc / clk * 1e6
+            return {"valu_insts_per_launch": insts, "simds": simds, "cycles_per_inst": cyc, "clock_hz": clk,
+                    "issue_time_us": t_us, "frac": t_us / mean_us, "source": "profiles/" + os.path.basename(f),
+                    "note": "fraction of the launch that pure VALU issue on all 1024 SIMDs would take: the kernel's distance "
+                            "from its own (instruction-count) ceiling; the rest is serial phases and idle SIMDs"}
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -402,6 +464,9 @@ def main():
     ap.add_argument("--steps-per-graph", type=int, default=8,
                     help="consecutive training steps captured into one hipGraph (single process, resident batch); 1 = one "
                          "graph launch per step as in round 2")
+    ap.add_argument("--no-strong-leg", dest="strong_leg", action="store_false",
+                    help="N > 1: skip the extra strong-scaling measurement (config 3's one batch, n_iwae=1000, sample-sharded) "
+                         "that is otherwise added to the line as `strong_scaling_config3`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -412,6 +477,20 @@ def main():
                          "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
     a = ap.parse_args()
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
+        # hand the same arguments on; rank 0 of that job prints the line
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd, env=env))
     a.solver_given = a.solver is not None
     if a.workload != "config2":
         if not torch.cuda.is_available():
@@ -484,18 +563,43 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t)
+    # a short timed window (the driver's --steps 20 is ~2 ms) is also reported over >= 0.5 s of the same replay
+    long_run = None
+    if use_graph and elapsed < 0.25:
+        n_long = int(math.ceil(0.5 / max(elapsed / a.steps, 1e-6) / G)) * G
+        barrier()
+        t1 = time.perf_counter()
+        loss = run_steps(n_long)
+        barrier()
+        el = time.perf_counter() - t1
+        if multi:
+            tl = torch.tensor([el], device=dev, dtype=torch.float64)
+            torch.distributed.all_reduce(tl, op=torch.distributed.ReduceOp.MAX)
+            el = float(tl)
+        long_run = {"steps": n_long, "value": world * n_long / el, "ms_per_step": 1e3 * el / n_long}
     final_loss = float(loss)
     if not np.isfinite(final_loss) or final_loss < -1e6:
         raise SystemExit("degenerate loss %r after the timed steps (training ran away): not a valid bench run"
                          % final_loss)
 
+    rank_devices = ["rank 0: %s (%s)" % (dev, torch.cuda.get_device_name(local_rank))]
+    strong = None
+    if multi:
+        gathered = [None] * world
+        torch.distributed.all_gather_object(gathered, "rank %d: %s (%s)" % (rank, dev, torch.cuda.get_device_name(local_rank)))
+        rank_devices = gathered
+        if a.strong_leg:
+            strong = strong_scaling_leg(a, dev, world, rank)
     # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
     if a.roofline_steps <= 0:
         if rank == 0:
             print(json.dumps({"metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)",
                               "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "launch": launch_mode,
-                              "final_loss": final_loss, "note": "roofline leg skipped (--roofline-steps 0)"}))
+                              "final_loss": final_loss, "world_size": world, "rank_devices": rank_devices,
+                              "value_long": long_run["value"] if long_run else None,
+                              "strong_scaling_config3": strong, "scaling": "weak",
+                              "note": "roofline leg skipped (--roofline-steps 0)"}))
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
     kt = ode_kernel_times(model, settings, batch, n_iwae_model, a.roofline_steps)
@@ -535,7 +639,9 @@ def main():
         kname["ode_step"] = ("void vihds::dr_lane_train_theta_kernel<1, %d>(vihds::OdeArgs, int, "
                              "vihds::ThetaStageArgs)" % solver_id)
     theta_b = 4 * (2 * N_PARAMS * B_ROWS * N_IWAE + 2 * B_ROWS * N_IWAE)  # the sampling stage's u, theta, log q, log p
-    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b, "ode_step": fwd_b + bwd_b + theta_b}
+    # SURVEY 8d's fixed numerator for every form of the decoder launch: 30 729 600 + 20 822 400 = 51 552 000 B; the
+    # sampling stage's bytes (theta_b) are reported next to it, never added to it
+    nbytes = {"ode_fwd": fwd_b, "ode_bwd": bwd_b, "ode_fused": fwd_b + bwd_b, "ode_step": fwd_b + bwd_b}
 
     def gbs(nb, us):
         return nb / (us * 1e-6) / 1e9
@@ -573,9 +679,12 @@ def main():
         "launches_timed": kt[dom]["launches"],
         "timing": "back-to-back launches of the kernel between one HIP event pair on the launch stream",
         "numerator_note": ("fixed SURVEY 8d numerator: the bytes the forward + adjoint pair moves when the trajectory "
-                           "goes through HBM (30.7 + 20.8 MB; + 2.1 MB for the sampling stage when it runs in the same "
-                           "launch).  The fused kernel keeps the trajectory in LDS and itself moves only the draws, "
-                           "theta, the log-probabilities and d theta (see traffic)") if fused_step else None,
+                           "goes through HBM (30 729 600 + 20 822 400 B).  The fused kernel keeps the trajectory in LDS and "
+                           "itself moves only the draws, theta, the log-probabilities and d theta (see traffic); the "
+                           "sampling stage that runs in the same launch is NOT in the numerator (theta_stage_bytes)")
+        if fused_step else None,
+        "theta_stage_bytes": theta_b if (fused_step and "ode_step" in kt) else None,
+        "issue_bound": issue_bound(d["kernel"], d["mean_us"]),
         "other_kernels": [entry(k) for k in others],
         "step_algorithmic_bytes": fwd_b + bwd_b,
     }
@@ -586,11 +695,15 @@ def main():
         "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        "value_long": long_run["value"] if long_run else None,
+        "ms_per_step_long": long_run["ms_per_step"] if long_run else None,
+        "steps_long": long_run["steps"] if long_run else None,
         "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, "
                                "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver,
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
                    "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "steps_per_graph_launch": G, "learning_rate": a.lr,
+                   "world_size": torch.distributed.get_world_size() if multi else 1, "rank_devices": rank_devices,
                    "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
                                     "encoders.py:385) are outside the replayed step",
                    "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "tail": "loss + backward + Adam: five launches" if (a.no_step_tail or multi) else "vihds_step_tail (IWAE loss + theta adjoint + encoder adjoint + Adam in two launches)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
@@ -598,7 +711,7 @@ def main():
                                    "data parallel over rows x%d (36 rows per GPU, one gradient all-reduce per step)" % world
                                    if replica is not None else "iwae-sample shard x%d (all-gather of row statistics + "
                                    "one gradient all-reduce per step)" % world)},
-        "final_loss": final_loss, "roofline": roofline,
+        "final_loss": final_loss, "roofline": roofline, "strong_scaling_config3": strong,
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.solver, batch.observations.detach().cpu())

@@ -561,3 +561,25 @@ def test_multi_step_graph_matches_one_step_graphs(tail):
         assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs[1][0], runs[3][0])
     for k, v in runs[1][1].items():
         assert rel_err(runs[3][1][k], v) < 1e-6, k
+
+
+def test_bench_gpus_2_self_launch_on_one_device():
+    """The driver's plain command for a scaling run, `python bench.py --gpus N`, with N = 2 ranks sharing this box's one GPU
+    over gloo: bench.py starts the ranks itself, rank 0 prints ONE JSON line whose value counts both replicas' steps, names
+    the world size and every rank's device, and carries the strong-scaling leg (config 3's one batch, sample-sharded)."""
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(VIHDS_DIST_BACKEND="gloo", VIHDS_FORCE_DEVICE="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "10", "--warmup", "2",
+                        "--roofline-steps", "0", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-3000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["value"] > 0 and np.isfinite(out["final_loss"])

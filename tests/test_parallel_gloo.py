@@ -80,3 +80,21 @@ def test_two_rank_gloo(tmp_path):
     port = _free_port()
     mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     assert (tmp_path / "ok0").exists() and (tmp_path / "ok1").exists()
+
+
+def test_bench_gpus_n_launches_its_own_ranks():
+    """`python bench.py --gpus 2` as typed (no torch.distributed.run around it, WORLD_SIZE unset) must start the two ranks
+    itself.  Without a GPU the ranks then stop at bench.py's own "needs an MI355X" check -- which proves they were
+    started: the old behaviour was an argument error before anything ran."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["VIHDS_DIST_BACKEND"] = "gloo"
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1",
+                        "--roofline-steps", "0", "--no-cpu-baseline"], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, text=True, timeout=600)
+    assert "but WORLD_SIZE=1" not in r.stdout, r.stdout[-2000:]
+    if not torch.cuda.is_available():
+        assert r.returncode != 0 and "needs an MI355X" in r.stdout, r.stdout[-2000:]

@@ -18,30 +18,30 @@ from vihds.vae import build_model  # noqa: E402
 
 
 def create_parser(with_split):
-    parser = argparse.ArgumentParser(description="VI-HDS")
-    parser.add_argument("yaml", type=str, help="Name of yaml spec file")
+    """The reference's command line (run_xval.py:17-57): same flags, types and defaults -- that is the CLI boundary a spec /
+    script written for vi-hds relies on; the help texts are this package's own."""
+    parser = argparse.ArgumentParser(description="vi-hds on MI355X: IWAE training of one cross-validation split")
+    parser.add_argument("yaml", type=str, help="experiment definition (a specs/*.yaml file of the reference loads unchanged)")
     parser.add_argument("--experiment", type=str, default="unnamed",
-                        help="Name for experiment, also location of tensorboard and saved results")
-    parser.add_argument("--seed", type=int, default=None, help="Random seed (default: 0)")
-    parser.add_argument("--epochs", type=int, default=1000, help="Training epochs")
-    parser.add_argument("--test_epoch", type=int, default=20, help="Frequency of calling test")
-    parser.add_argument("--plot_epoch", type=int, default=100, help="Frequency of plotting figures")
-    parser.add_argument("--train_samples", type=int, default=200,
-                        help="Number of samples from q, per datapoint, during training")
-    parser.add_argument("--test_samples", type=int, default=1000,
-                        help="Number of samples from q, per datapoint, during testing")
-    parser.add_argument("--dreg", type=bool, default=True, help="Use DReG estimator")
+                        help="experiment name: sub-directory for TensorBoard logs and cached results")
+    parser.add_argument("--seed", type=int, default=None, help="seed of numpy / torch (0 when omitted)")
+    parser.add_argument("--epochs", type=int, default=1000, help="passes over the training rows")
+    parser.add_argument("--test_epoch", type=int, default=20, help="evaluate train / validation ELBO every this many epochs")
+    parser.add_argument("--plot_epoch", type=int, default=100, help="accepted for compatibility (figures are out of scope here)")
+    parser.add_argument("--train_samples", type=int, default=200, help="IWAE samples per data row in a training step")
+    parser.add_argument("--test_samples", type=int, default=1000, help="IWAE samples per data row in an evaluation pass")
+    parser.add_argument("--dreg", type=bool, default=True, help="accepted for compatibility (the reference never reads it either)")
     parser.add_argument("--precision_hidden_layers", type=int, default=None,
-                        help="Number of hidden layers to use in neural precisions")
-    parser.add_argument("--verbose", action="store_true", default=False,
-                        help="Print more information about parameter setup")
-    parser.add_argument("--gpu", type=int, default=None, help="Use GPU device (default None is CPU mode")
+                        help="hidden units of the neural-precision network (overrides n_hidden_decoder_precisions)")
+    parser.add_argument("--verbose", action="store_true", default=False, help="print the parameter tables while they are built")
+    parser.add_argument("--gpu", type=int, default=None,
+                        help="index of the MI355X to run on; without it only host-side construction works (no CPU kernels)")
     if with_split:
         group = parser.add_mutually_exclusive_group()
-        group.add_argument("--heldout", type=str, help="name of held-out device, e.g. R33S32_Y81C76")
-        group.add_argument("--split", type=int, default=1, help="Specify split in 1:folds for cross-validation")
-        group.add_argument("--figures", action="store_true", default=False, help="Create figures (default: False)")
-    parser.add_argument("--folds", type=int, default=4, help="Cross-validation folds")
+        group.add_argument("--heldout", type=str, help="hold out every row of this device, e.g. R33S32_Y81C76")
+        group.add_argument("--split", type=int, default=1, help="which of the `folds` cross-validation splits is validated on")
+        group.add_argument("--figures", action="store_true", default=False, help="accepted for compatibility (no figures here)")
+    parser.add_argument("--folds", type=int, default=4, help="number of cross-validation splits")
     return parser
 
 
