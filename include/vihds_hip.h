@@ -142,6 +142,11 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
                   float* g_weights, float* aux, void* stream);
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
+/* 1: vihds_ode_bwd itself completes g_weights for this problem (relay_constant_precisions below 16 384 trajectories on a
+ * fixed-grid solver: sixteen lanes per trajectory, the precision network's weight gradients accumulated per lane, one
+ * partial row per block in aux -- vihds_ode_bwd_aux_floats is then that small size -- and added up in block order by a
+ * second launch of the same call); 0: aux receives the dump described above and the caller contracts it. */
+int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p);
 
 /* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN / DOPRI8; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
  * odeint / odeint_adjoint, absent from the tree: restated, parity unpinned).  Step-size controller, SYNCHRONOUS on

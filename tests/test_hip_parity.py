@@ -1839,3 +1839,91 @@ def test_time_parallel_kernel_matches_reference_fixture(name):
     gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, B)
     assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < GTOL
     assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL
+
+
+def _relay_problem(model, B, S, T, seed, dt=0.25):
+    from vihds import hip
+
+    slots = hip.model_slots(model)
+    th = _synthetic_theta(slots, B, S, seed)
+    for n in slots:
+        if n.startswith("init_prec"):
+            th[n] = torch.exp(3.0 + 0.3 * torch.randn(B, S, generator=torch.Generator().manual_seed(9)))
+    theta = torch.stack([th[n] for n in slots]).to(DEV)
+    g = torch.Generator().manual_seed(seed + 1)
+    cond = torch.log1p(torch.tensor([0.0, 5.0, 250.0, 5000.0, 25000.0])[torch.arange(B) % 5][:, None].repeat(1, 2) *
+                       torch.rand(B, 2, generator=g)).to(DEV)
+    # (an uneven grid: modeuler's fixed h and modeulerwhile's per-step h must differ)
+    times = (torch.arange(T, dtype=torch.float32) * dt + 0.03 * torch.rand(T, generator=g).cumsum(0)).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+    wts = None
+    if model.endswith("_precisions"):
+        wts = (torch.randn(2 * (4 * 13 + 4), generator=g) * 0.2).to(DEV)
+    return slots, theta, cond, times, obs, wts
+
+
+@pytest.mark.parametrize("model", ["relay_constant", "relay_constant_precisions"])
+@pytest.mark.parametrize("solver", ["modeuler", "modeulerwhile", "euler", "midpoint", "rk4"])
+def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
+    """relay_constant(_precisions) with sixteen lanes per trajectory (csrc/vihds_relay_lanes.hpp: the automatic choice
+    below 16 384 trajectories) against the one-thread-per-trajectory kernels (kernel_variant 1, themselves checked against
+    the restatement of the reference's equations): trajectories, predictions, log-likelihood, every theta gradient --
+    with upstream gradients on all three outputs -- and the precision network's weight gradients (per-lane accumulators
+    and a block-ordered sum there, the dump + vihds_gram_blocks contraction here).  A ragged size (n not a multiple of
+    the 16 trajectories of a block, blocks spanning data rows)."""
+    from vihds import ops
+
+    B, S, T = 5, 13, 30
+    slots, theta, cond, times, obs, wts = _relay_problem(model, B, S, T, 21)
+    row_of = {n: i for i, n in enumerate(slots)}
+    outs = {}
+    g = torch.Generator().manual_seed(2)
+    N = 16 if wts is not None else 12
+    up = (torch.randn(T, N, B, S, generator=g).to(DEV) * 1e-3, torch.randn(T, 4, B, S, generator=g).to(DEV) * 1e-3,
+          torch.randn(4, B, S, generator=g).to(DEV) * 1e-3)
+    for variant in (1, 0):
+        spec = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=variant)
+        th = theta.clone().requires_grad_(True)
+        w = wts.clone().requires_grad_(True) if wts is not None else None
+        traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, w)
+        ((traj * up[0]).sum() + (xpred * up[1]).sum() + (logp * up[2]).sum()).backward()
+        outs[variant] = (traj.detach(), xpred.detach(), logp.detach(), th.grad.clone(), None if w is None else w.grad.clone())
+    ref, got = outs[1], outs[0]
+    assert traj.shape == (T, N, B, S)
+    assert rel_err(got[0], ref[0], dim=1) < 1e-5
+    assert rel_err(got[1], ref[1], dim=1) < 1e-5
+    assert rel_err(got[2], ref[2], dim=0) < 1e-5
+    for i, n in enumerate(slots):
+        scale = ref[3][i].abs().max()
+        if scale > 0:
+            assert float((got[3][i] - ref[3][i]).abs().max() / scale) < 2e-4, n
+        else:
+            assert float(got[3][i].abs().max()) == 0.0, n
+    if wts is not None:
+        assert rel_err(got[4], ref[4]) < 2e-4
+
+
+def test_relay_lane_kernels_at_config5_size():
+    """BASELINE config 5's shape (relay_constant_precisions, B=36, S=200, T=99, midpoint): lane kernels vs
+    thread-per-trajectory -- log-likelihood, the gradient of its sum w.r.t. theta and the network weights."""
+    from vihds import ops
+
+    B, S, T = 36, 200, 99
+    slots, theta, cond, times, obs, wts = _relay_problem("relay_constant_precisions", B, S, T, 3, dt=0.17)
+    row_of = {n: i for i, n in enumerate(slots)}
+    outs = {}
+    for variant in (1, 0):
+        spec = ops.OdeProblemSpec("relay_constant_precisions", "midpoint", row_of, len(slots), C=2, kernel_variant=variant)
+        th = theta.clone().requires_grad_(True)
+        w = wts.clone().requires_grad_(True)
+        traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, w)
+        (logp.sum() * 1e-3).backward()
+        outs[variant] = (traj.detach(), logp.detach(), th.grad.clone(), w.grad.clone())
+    ref, got = outs[1], outs[0]
+    assert torch.isfinite(got[0]).all() and torch.isfinite(got[2]).all()
+    assert rel_err(got[0], ref[0], dim=1) < 1e-5 and rel_err(got[1], ref[1], dim=0) < 1e-5
+    for i, n in enumerate(slots):
+        scale = ref[2][i].abs().max()
+        if scale > 0:
+            assert float((got[2][i] - ref[2][i]).abs().max() / scale) < 5e-4, n
+    assert rel_err(got[3], ref[3]) < 5e-4

@@ -1,9 +1,16 @@
 // Instantiates the fused forward / adjoint ODE kernels for one model (one translation unit per model so the
 // library builds in parallel).  Model definition: vihds_models.hpp.
 #include "vihds_ode_kernels.hpp"
+#include "vihds_relay_lanes.hpp"
 
 namespace vihds {
 int launch_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  // below 16 384 trajectories: sixteen lanes per trajectory (vihds_relay_lanes.hpp); the adaptive controller, a hidden
+  // layer in the precision network and kernel_variant 1 keep one thread per trajectory.  (A backward that wants the
+  // network's weight gradients brings the small per-block buffer of vihds_ode_bwd_aux_floats in `aux`.)
+  if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&
+      !(backward && true && a.g_weights && !a.aux))
+    return relay_lanes_launch<true>(backward, solver, a, st);
   return launch_ode<WithPrec<RelayConstant>>(backward, solver, a, st);
 }
 int n_slots_relay_constant_prec() { return WithPrec<RelayConstant>::NSLOT; }

@@ -15,6 +15,8 @@
 #include "vihds_ode_kernels.hpp"
 #include "vihds_bb_variant.hpp"
 
+#include "vihds_relay_lanes.hpp"
+
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
 // per-model translation units (ode_<model>.hip)
@@ -331,6 +333,12 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
   return check_hip("vihds_theta_ode_logp_grad launch");
 }
 
+int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p) {
+  if (!p) return 0;
+  return p->model == VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS &&
+         relay_lanes_applicable(p->B * p->S, p->solver, p->kernel_variant, p->n_hidden_prec) ? 1 : 0;
+}
+
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (!p) return VIHDS_E_BADARG;
   if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
@@ -341,6 +349,7 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
+  if (vihds_ode_bwd_reduces_weights(p)) return relay_lanes_aux_floats(p->B * p->S);  // one partial row per block
   // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
   const long long stages = ode_stages(p->solver);
   const long long fields = 8 + e->n_states() - 4 + 1 + (p->n_hidden_prec > 0 ? 2 * p->n_hidden_prec : 0);

@@ -1,0 +1,630 @@
+// relay_constant / relay_constant_precisions with SIXTEEN LANES PER TRAJECTORY (reference models/relay_constant.py:13-134
+// RHS, :199-251 states, vihds/precisions.py:55-61,76-87 neural precisions without a hidden layer; BASELINE config 5).
+//
+// The thread-per-trajectory kernels (vihds_ode_kernels.hpp) put 7 200 trajectories on 113 wavefronts: each walks its
+// ~200 RHS evaluations of ~340 instructions alone on a SIMD, and the launch lasts as long as that serial instruction
+// stream (forward 207 us, adjoint 464 us at B=36, S=200, T=99, midpoint: 3.5 % / 1.3 % of the HBM roofline).  Here one
+// lane owns one ODE state -- 12 species + the 4 neural precision states = 16 lanes, 4 trajectories per wavefront, 1 800
+// wavefronts -- and every state obeys the same form
+//
+//     dy_l = F0_l + cP_l P_l(luxR, lasR) + cQ_l Q_l(x, I_l) + [prec] sigma(zp_l) - (s_l gamma(x, t) + deg_l + [prec] sigma(zd_l)) y_l
+//
+// with per-lane constants (s = -1 for OD itself, +1 for the diluted species, 0 for the AHL quadratures and the precisions;
+// P = the promoter of the lane: P81 for yfp / luxI, P76 for cfp / lasI; Q = x I / (1 + I / K) with I = luxI for c6, lasI
+// for c12; zp, zd = the precision network's rows of the lane), so the RHS is one straight-line evaluation for all lanes.
+// What a lane needs from the others (x, luxR, lasR, its I, the tanh'd network inputs) goes through a 48-float LDS patch of
+// the trajectory: one wavefront's LDS operations are served in order, so no barrier is involved.  The adjoint sends back
+// through the same patch the network's pre-activation adjoints (to every input lane) and the quadratures' x / I adjoints,
+// and sums over the 16 lanes (gamma's adjoint, the promoters' luxR / lasR adjoints) are four DPP steps.
+//
+// Every parameter gradient is accumulated per lane as the adjoint of that lane's OWN constants (8 numbers) plus the
+// lane-uniform growth adjoints; one lane maps them to the model's prepared parameters after the time loop and hands them
+// to RelayConstant::prepare_vjp / init_vjp -- the same code the thread-per-trajectory adjoint ends with.  The precision
+// network's weight gradients are per-lane accumulators too (lane 12+o owns row o of both matrices: 2 x 13 + 2 numbers),
+// added up over the block's 16 trajectories through LDS, left as one partial row per block in `aux` and summed in block
+// order by relay_lane_wreduce_kernel (fixed order: deterministic; no 120 MB dump, no contraction pass).
+//
+// Schemes: the five fixed-grid ones as explicit Runge-Kutta tableaux (same stages and weights as ode_step /
+// ode_step_vjp; the sums are taken in tableau order, a rounding-level difference).  The adjoint is the discrete adjoint.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "../../include/vihds_hip.h"
+#include "vihds_args.hpp"
+#include "vihds_models.hpp"
+
+namespace vihds {
+
+constexpr int RL_G = 16;                 // lanes per trajectory
+constexpr int RL_T = 256;                // threads per block
+constexpr int RL_TR = RL_T / RL_G;       // trajectories per block
+constexpr int RL_NIN = 13;               // network inputs: t, 12 species
+constexpr int RL_NWROW = 2 * RL_NIN + 2; // weight-gradient numbers per precision lane
+constexpr int RL_NWG = 4 * RL_NWROW;     // per block partial row (112)
+constexpr int RL_PATCH = 48;             // LDS floats per trajectory: y [16] | h [16] | adjoint scratch [16]
+constexpr float RL_LOG2PI = 1.8378770664093453f;
+typedef float rl_v2 __attribute__((ext_vector_type(2)));  // (production, degradation) pairs: v_pk_fma_f32
+
+__host__ __device__ inline bool relay_lanes_applicable(int n, int solver, int kernel_variant, int n_hidden_prec) {
+  return kernel_variant != 1 && n <= 16384 && solver >= VIHDS_SOLVER_MODEULER && solver <= VIHDS_SOLVER_RK4 &&
+         n_hidden_prec < 1;
+}
+__host__ __device__ inline long long relay_lanes_aux_floats(int n) {
+  return (long long)((n + RL_TR - 1) / RL_TR) * RL_NWG;
+}
+
+// ---- tableaux -----------------------------------------------------------------------------------------------------
+template <int SOLVER>
+struct RlTab {
+  static constexpr int S = SOLVER == VIHDS_SOLVER_EULER ? 1 : (SOLVER == VIHDS_SOLVER_RK4 ? 4 : 2);
+  // Y_i = y + h sum_j A(i, j) k_j ;  y' = y + h sum_i B(i) k_i
+  __device__ static constexpr float A(int i, int j) {
+    if (SOLVER == VIHDS_SOLVER_MIDPOINT) return (i == 1 && j == 0) ? 0.5f : 0.f;
+    if (SOLVER == VIHDS_SOLVER_RK4) {  // torchdiffeq 0.1 rk4_alt_step_func (3/8 rule)
+      if (i == 1) return j == 0 ? (1.f / 3.f) : 0.f;
+      if (i == 2) return j == 0 ? -(1.f / 3.f) : (j == 1 ? 1.f : 0.f);
+      if (i == 3) return j == 1 ? -1.f : 1.f;
+      return 0.f;
+    }
+    return (i == 1 && j == 0) ? 1.f : 0.f;  // Heun (vihds/solvers.py:12-16)
+  }
+  __device__ static constexpr float B(int i) {
+    if (SOLVER == VIHDS_SOLVER_EULER) return 1.f;
+    if (SOLVER == VIHDS_SOLVER_MIDPOINT) return i == 1 ? 1.f : 0.f;
+    if (SOLVER == VIHDS_SOLVER_RK4) return (i == 0 || i == 3) ? 0.125f : 0.375f;
+    return 0.5f;
+  }
+  // step size and stage times: modeuler uses h = times[1] - times[0] for every step and evaluates stage 2 at t1
+  __device__ static float h(float t0, float t1, float h0) { return SOLVER == VIHDS_SOLVER_MODEULER ? h0 : t1 - t0; }
+  __device__ static float ts(int i, float t0, float t1) {
+    if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) return i == 0 ? t0 : t1;
+    const float dt = t1 - t0;
+    if (SOLVER == VIHDS_SOLVER_MIDPOINT) return i == 0 ? t0 : t0 + dt * 0.5f;
+    if (SOLVER == VIHDS_SOLVER_RK4) {
+      const float d3 = dt * (1.f / 3.f);
+      return i == 0 ? t0 : (i == 1 ? t0 + d3 : (i == 2 ? t0 + 2.f * d3 : t0 + dt));
+    }
+    return t0;
+  }
+};
+
+// ---- cross-lane helpers (16-lane groups = DPP rows) ------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ float rl_dpp(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float rl_sum16(float v) {  // every lane of the row gets the row's sum
+  v += rl_dpp<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += rl_dpp<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += rl_dpp<0x141>(v);  // row_half_mirror
+  v += rl_dpp<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ __forceinline__ void rl_wave_fence() {  // keep LDS writes ahead of the reads that follow (same wavefront)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// ---- per-lane model ------------------------------------------------------------------------------------------------
+struct RlLane {
+  // shared by the 16 lanes of a trajectory
+  float r, iKx, tlag, rKx;  // growth rate, 1 / K, lag, (unused slot kept for alignment of the struct in registers)
+  // this lane
+  float gsgn, deg, F0, cP, e, aR, aS, cQ, iK, isP;
+  int isrc, l;
+  rl_v2 w2[RL_NIN], b2;                  // rows (production, degradation) of the precision network (precision lanes; zeros elsewhere)
+  float cw[8];                           // column of both matrices that multiplies this lane's tanh (species lanes)
+};
+struct RlEval {  // what one RHS evaluation leaves behind for its VJP
+  float x, luxR, lasR, I, sig, gr, g, gamma, a, den, P, denq, Q, sp, sd, hl;
+};
+
+// publish (Y_l, tanh) and evaluate dy_l.  `pt` = this trajectory's LDS patch.
+template <bool PREC>
+__device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float* pt, RlEval& E, float* hv) {
+  const int l = c.l;
+  pt[l] = Y;
+  if (PREC) {
+    const float hl = ftanh(l == 12 ? t : Y);
+    E.hl = hl;
+    if (l <= 12) pt[16 + (l == 12 ? 0 : l + 1)] = hl;
+  }
+  rl_wave_fence();
+  E.x = pt[0]; E.luxR = pt[6]; E.lasR = pt[7]; E.I = pt[c.isrc];
+  E.sig = sigmoid_f(4.f * (t - c.tlag));
+  E.gr = c.r * E.sig;
+  E.g = 1.f - E.x * c.iKx;
+  E.gamma = E.gr * E.g;
+  E.a = c.aR * E.luxR * E.luxR + c.aS * E.lasR * E.lasR;
+  E.den = 1.f + E.a;
+  E.P = fdiv(c.e + E.a, E.den);
+  E.denq = 1.f + E.I * c.iK;
+  E.Q = fdiv(E.x * E.I, E.denq);
+  float dy = c.F0 + c.cP * E.P + c.cQ * E.Q;
+  float D = c.gsgn * E.gamma + c.deg;
+  E.sp = 0.f; E.sd = 0.f;
+  if (PREC) {
+    const float4* h4 = reinterpret_cast<const float4*>(pt + 16);
+    const float4 ha = h4[0], hb = h4[1], hc = h4[2];
+    hv[0] = ha.x; hv[1] = ha.y; hv[2] = ha.z; hv[3] = ha.w; hv[4] = hb.x; hv[5] = hb.y; hv[6] = hb.z; hv[7] = hb.w;
+    hv[8] = hc.x; hv[9] = hc.y; hv[10] = hc.z; hv[11] = hc.w; hv[12] = pt[28];
+    rl_v2 z2 = c.b2, z2b = rl_v2{0.f, 0.f};  // (two chains: back-to-back dependent packed FMAs cost a wait state each)
+#pragma unroll
+    for (int j = 0; j + 1 < RL_NIN; j += 2) { z2 += c.w2[j] * hv[j]; z2b += c.w2[j + 1] * hv[j + 1]; }
+    z2 += c.w2[RL_NIN - 1] * hv[RL_NIN - 1];
+    z2 += z2b;
+    E.sp = sigmoid_f(z2.x); E.sd = sigmoid_f(z2.y);
+    dy += c.isP * E.sp;
+    D += c.isP * E.sd;
+  }
+  rl_wave_fence();  // (the patch is rewritten by the next evaluation: reads first)
+  return dy - D * Y;
+}
+
+// per-lane adjoint accumulators
+struct RlAcc {
+  float F0b, cPb, eb, aRb, aSb, cQb, iKb, degb;  // adjoints of the lane's own constants
+  float rb, Kb, tlagb;                            // growth parameters (the same numbers in every lane of the trajectory)
+  rl_v2 w2b[RL_NIN], b2b;                         // precision lanes: rows of the weight gradients (production, degradation)
+};
+
+// VJP of one evaluation whose forward quantities (E, hv) are at hand: v = adjoint of dy_l; returns the adjoint of Y_l;
+// accumulates parameter adjoints.  Uses only the scratch third of the patch.
+template <bool PREC>
+__device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, const RlEval& E, const float* hv, float* pt,
+                                             RlAcc& A) {
+  const int l = c.l;
+  const float D = c.gsgn * E.gamma + c.deg + (PREC ? c.isP * E.sd : 0.f);
+  float yb = -v * D;
+  A.F0b += v;
+  A.cPb += v * E.P;
+  A.cQb += v * E.Q;
+  A.degb -= v * Y;
+  const float gammab = rl_sum16(-v * c.gsgn * Y);
+  // promoter
+  const float Pb = v * c.cP;
+  const float nb = fdiv(Pb, E.den);
+  const float sP = nb * (1.f - E.P);
+  A.eb += nb;
+  A.aRb += sP * E.luxR * E.luxR;
+  A.aSb += sP * E.lasR * E.lasR;
+  const float bRt = rl_sum16(sP * c.aR), bSt = rl_sum16(sP * c.aS);
+  // quadrature Q = x I / (1 + I iK)
+  const float Qb = v * c.cQ;
+  const float iden = frcp(E.denq);
+  const float xq = Qb * E.I * iden, Iq = Qb * E.x * iden * iden;
+  A.iKb -= Qb * E.x * E.I * E.I * iden * iden;
+  // precision network
+  if (PREC) {
+    rl_v2 zb;
+    zb.x = c.isP * v * E.sp * (1.f - E.sp);
+    zb.y = -c.isP * v * Y * E.sd * (1.f - E.sd);
+#pragma unroll
+    for (int j = 0; j < RL_NIN; ++j) A.w2b[j] += zb * hv[j];
+    A.b2b += zb;
+    if (l >= 12) { pt[32 + (l - 12)] = zb.x; pt[36 + (l - 12)] = zb.y; }
+  }
+  if (l == 10 || l == 11) { pt[40 + (l - 10)] = xq; pt[42 + (l - 10)] = Iq; }
+  rl_wave_fence();
+  const float4 q4 = *reinterpret_cast<const float4*>(pt + 40);
+  if (PREC) {
+    const float4 za = *reinterpret_cast<const float4*>(pt + 32), zd4 = *reinterpret_cast<const float4*>(pt + 36);
+    const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
+                     c.cw[6] * zd4.z + c.cw[7] * zd4.w;
+    if (l < 12) yb += hb * (1.f - E.hl * E.hl);
+  }
+  // growth: gamma = gr (1 - x / K)
+  const float grb = gammab * E.g, gb = gammab * E.gr;
+  A.Kb += gb * E.x * c.iKx * c.iKx;
+  A.rb += grb * E.sig;
+  A.tlagb -= 4.f * grb * c.r * E.sig * (1.f - E.sig);
+  if (l == 0) yb += -gb * c.iKx + q4.x + q4.y;
+  if (l == 6) yb += 2.f * E.luxR * bRt;
+  if (l == 7) yb += 2.f * E.lasR * bSt;
+  if (l == 8) yb += q4.z;
+  if (l == 9) yb += q4.w;
+  rl_wave_fence();
+  return yb;
+}
+// ... with the forward quantities recomputed first
+template <bool PREC>
+__device__ __forceinline__ float rl_rhs_vjp(const RlLane& c, float t, float Y, float v, float* pt, RlAcc& A) {
+  RlEval E;
+  float hv[RL_NIN];
+  (void)rl_rhs<PREC>(c, t, Y, pt, E, hv);
+  return rl_vjp_core<PREC>(c, Y, v, E, hv, pt, A);
+}
+
+// per-lane constants from theta (every lane loads the slots: cached, once per kernel)
+template <bool PREC>
+__device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, RlLane& c, float* th, float* cc, float* p,
+                                         float& y0, float* prec_const) {
+  using M = RelayConstant;
+#pragma unroll
+  for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
+  float pinit[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) pinit[j] = a.theta[(size_t)a.slot_row[M::NSLOT + j] * a.n + i];  // init_prec_* or prec_*
+#pragma unroll
+  for (int q = 0; q < 2; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+  M::prepare(th, cc, p);
+  float yi[12];
+  M::init(th, cc, yi);
+  const float rc = p[M::P_rc];
+  c.l = l;
+  c.r = p[M::P_r]; c.iKx = frcp(p[M::P_K]); c.tlag = p[M::P_tlag]; c.rKx = 0.f;
+  c.gsgn = l == 0 ? -1.f : (l <= 9 ? 1.f : 0.f);
+  c.deg = 0.f; c.F0 = 0.f; c.cP = 0.f; c.e = 0.f; c.aR = 0.f; c.aS = 0.f; c.cQ = 0.f; c.iK = 0.f; c.isrc = 0;
+  c.isP = (PREC && l >= 12) ? 1.f : 0.f;
+  y0 = 0.f;
+#pragma unroll
+  for (int j = 0; j < 12; ++j) if (l == j) y0 = yi[j];
+  const float fR = p[M::P_fR], fS = p[M::P_fS];
+  switch (l) {
+    case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
+    case 2: c.deg = p[M::P_dyfp]; c.cP = rc * p[M::P_aYFP]; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
+    case 3: c.deg = p[M::P_dcfp]; c.cP = rc * p[M::P_aCFP]; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
+    case 4: c.F0 = rc * p[M::P_a530]; break;
+    case 5: c.F0 = rc * p[M::P_a480]; break;
+    case 6: c.deg = p[M::P_dR]; c.F0 = rc * p[M::P_aR]; break;
+    case 7: c.deg = p[M::P_dS]; c.F0 = rc * p[M::P_aS]; break;
+    case 8: c.deg = p[M::P_dluxI]; c.cP = rc; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
+    case 9: c.deg = p[M::P_dlasI]; c.cP = rc; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
+    case 10: c.cQ = p[M::P_KC6] * rc; c.iK = frcp(p[M::P_Klux]); c.isrc = 8; break;
+    case 11: c.cQ = p[M::P_KC12] * rc; c.iK = frcp(p[M::P_Klas]); c.isrc = 9; break;
+    default: break;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
+  c.b2 = rl_v2{0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < RL_NIN; ++j) c.w2[j] = rl_v2{0.f, 0.f};
+#pragma unroll
+  for (int j = 0; j < 8; ++j) c.cw[j] = 0.f;
+  if (PREC) {
+    // weights: Wp [4][13], bp [4], Wd [4][13], bd [4] (reference precisions.py:55-61)
+    const float* w = a.weights;
+    if (l >= 12) {
+      const int o = l - 12;
+      y0 = pinit[o];
+#pragma unroll
+      for (int j = 0; j < RL_NIN; ++j) c.w2[j] = rl_v2{w[o * RL_NIN + j], w[4 * RL_NIN + 4 + o * RL_NIN + j]};
+      c.b2 = rl_v2{w[4 * RL_NIN + o], w[8 * RL_NIN + 4 + o]};
+    } else {
+#pragma unroll
+      for (int o = 0; o < 4; ++o) { c.cw[o] = w[o * RL_NIN + l + 1]; c.cw[4 + o] = w[4 * RL_NIN + 4 + o * RL_NIN + l + 1]; }
+    }
+  }
+}
+
+// ---- forward -------------------------------------------------------------------------------------------------------
+// dynamic LDS: times [T] | obs rows [nb][4][T]
+template <bool PREC, int SOLVER>
+__global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
+  using M = RelayConstant;
+  using Tab = RlTab<SOLVER>;
+  constexpr int N = PREC ? 16 : 12;
+  __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
+  extern __shared__ float in_lds[];
+  const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
+  const int i0 = blockIdx.x * RL_TR + g;
+  const bool live = i0 < a.n;
+  const int i = live ? i0 : a.n - 1;
+  const int b = i / a.S;
+  // time grid and the observation rows of the block's data rows -> LDS (no vector loads inside the time loop)
+  const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
+  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
+  if (a.obs) {
+    const float* src = a.obs + (size_t)b0 * 4 * a.T;
+    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
+  }
+  RlLane c;
+  float th[M::NSLOT], cc[2], p[M::NP], y, pconst[4];
+  rl_setup<PREC>(a, i, b, l, c, th, cc, p, y, pconst);
+  __syncthreads();
+  const float* tl = in_lds;
+  const float* ob = in_lds + a.T + (b - b0) * 4 * a.T;
+  float* pt = patch[g];
+  const float h0 = tl[1] - tl[0];
+  const size_t n = a.n;
+  float lp = 0.f;
+  const int j = l & 3;  // observed signal of lanes 0..3
+  const float lc = PREC ? 0.f : RL_LOG2PI - logf(pconst[j]);
+  for (int k = 0; k < a.T; ++k) {
+    if (k > 0) {
+      const float t0 = tl[k - 1], t1 = tl[k];
+      const float h = Tab::h(t0, t1, h0);
+      float kk[Tab::S];
+#pragma unroll
+      for (int s = 0; s < Tab::S; ++s) {
+        float Y = y;
+#pragma unroll
+        for (int q = 0; q < s; ++q)
+          if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
+        RlEval E;
+        float hv[RL_NIN];
+        kk[s] = rl_rhs<PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+      }
+      float acc = 0.f;
+#pragma unroll
+      for (int s = 0; s < Tab::S; ++s)
+        if (Tab::B(s) != 0.f) acc += Tab::B(s) * kk[s];
+      y += h * acc;
+    }
+    if (a.traj && live && l < N) a.traj[((size_t)k * N + l) * n + i] = y;
+    if (a.xpred || a.logp) {
+      pt[l] = y;
+      rl_wave_fence();
+      if (l < 4) {
+        const float x = pt[0];
+        const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
+        const float xp = x * inner;
+        if (a.xpred && live) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
+        if (a.logp) {
+          const float e = xp - ob[j * a.T + k];
+          if (PREC) {
+            const float pr = pt[12 + j];
+            lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
+          } else {
+            lp += -0.5f * (lc + pconst[j] * e * e);
+          }
+        }
+      }
+      rl_wave_fence();
+    }
+  }
+  if (a.logp && live && l < 4) a.logp[(size_t)j * n + i] = lp;
+}
+
+// ---- adjoint -------------------------------------------------------------------------------------------------------
+template <bool PREC, int SOLVER>
+__global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
+  using M = RelayConstant;
+  using Tab = RlTab<SOLVER>;
+  constexpr int N = PREC ? 16 : 12;
+  __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
+  __shared__ float tab[RL_TR][RL_G][10];   // epilogue: per-lane accumulators of a trajectory
+  __shared__ float wred[PREC ? RL_TR : 1][PREC ? RL_NWG : 1];
+  extern __shared__ float in_lds[];
+  const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
+  const int i0 = blockIdx.x * RL_TR + g;
+  const bool live = i0 < a.n;
+  const int i = live ? i0 : a.n - 1;  // tail trajectories shadow the last one (they take part in the exchanges)
+  const int b = i / a.S;
+  const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
+  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
+  {
+    const float* src = a.obs + (size_t)b0 * 4 * a.T;
+    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
+  }
+  RlLane c;
+  float pconst[4];
+  {  // (theta and the prepared parameters are not kept across the time loop: the epilogue's one lane fetches them again)
+    float th[M::NSLOT], cc[2], p[M::NP], y_unused;
+    rl_setup<PREC>(a, i, b, l, c, th, cc, p, y_unused, pconst);
+  }
+  __syncthreads();
+  const float* tl = in_lds;
+  const float* ob = in_lds + a.T + (b - b0) * 4 * a.T;
+  float* pt = patch[g];
+  const float h0 = tl[1] - tl[0];
+  const size_t n = a.n;
+  const int j = l & 3;
+  RlAcc A;
+  A.F0b = A.cPb = A.eb = A.aRb = A.aSb = A.cQb = A.iKb = A.degb = A.rb = A.Kb = A.tlagb = 0.f;
+  A.b2b = rl_v2{0.f, 0.f};
+#pragma unroll
+  for (int q = 0; q < RL_NIN; ++q) A.w2b[q] = rl_v2{0.f, 0.f};
+  float lam = 0.f, precb = 0.f;
+  const float glp = (a.g_logp && l < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
+  const int lr = l < N ? l : 0;  // row this lane reads from the stored trajectory
+  float yn = a.traj_in[((size_t)(a.T - 1) * N + lr) * n + i];
+  for (int k = a.T - 1; k >= 0; --k) {
+    const float y = yn;
+    if (k > 0) yn = a.traj_in[((size_t)(k - 1) * N + lr) * n + i];  // (one step ahead of its use)
+    if (k < a.T - 1) {
+      // reverse of step k -> k+1: recompute the stage states, then pull lam back through the stages
+      const float t0 = tl[k], t1 = tl[k + 1];
+      const float h = Tab::h(t0, t1, h0);
+      if constexpr (Tab::S <= 2) {
+        // one or two stages: every stage is evaluated ONCE (its forward quantities kept for its own VJP)
+        RlEval E0, E1;
+        float hv0[RL_NIN], hv1[RL_NIN];
+        const float k0 = rl_rhs<PREC>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
+        float Y1 = y;
+        if constexpr (Tab::S == 2) {
+          Y1 = y + (Tab::A(1, 0) * h) * k0;
+          (void)rl_rhs<PREC>(c, Tab::ts(1, t0, t1), Y1, pt, E1, hv1);
+          float kb0 = (Tab::B(0) * h) * lam;
+          const float Yb1 = rl_vjp_core<PREC>(c, Y1, (Tab::B(1) * h) * lam, E1, hv1, pt, A);
+          lam += Yb1;
+          kb0 += (Tab::A(1, 0) * h) * Yb1;
+          lam += rl_vjp_core<PREC>(c, y, kb0, E0, hv0, pt, A);
+        } else {
+          lam += rl_vjp_core<PREC>(c, y, (Tab::B(0) * h) * lam, E0, hv0, pt, A);
+        }
+      } else {
+        float Ys[Tab::S], kk[Tab::S], kb[Tab::S];
+#pragma unroll
+        for (int s = 0; s < Tab::S; ++s) {
+          float Y = y;
+#pragma unroll
+          for (int q = 0; q < s; ++q)
+            if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
+          Ys[s] = Y;
+          if (s + 1 < Tab::S) {  // (the last stage's derivative is not needed to rebuild the states)
+            RlEval E;
+            float hv[RL_NIN];
+            kk[s] = rl_rhs<PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+          }
+        }
+#pragma unroll
+        for (int s = 0; s < Tab::S; ++s) kb[s] = (Tab::B(s) * h) * lam;
+#pragma unroll
+        for (int s = Tab::S - 1; s >= 0; --s) {
+          const float Yb = rl_rhs_vjp<PREC>(c, Tab::ts(s, t0, t1), Ys[s], kb[s], pt, A);
+          lam += Yb;
+#pragma unroll
+          for (int q = 0; q < s; ++q)
+            if (Tab::A(s, q) != 0.f) kb[q] += (Tab::A(s, q) * h) * Yb;
+        }
+      }
+    }
+    // gradient injected at time k: log-likelihood, x_predict and trajectory upstream gradients
+    pt[l] = y;
+    rl_wave_fence();
+    const float x = pt[0];
+    float xpb = 0.f, prb = 0.f;
+    if (l < 4) {
+      const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
+      const float e = x * inner - ob[j * a.T + k];
+      const float pr = PREC ? pt[12 + j] : pconst[j];
+      xpb = -glp * pr * e;
+      prb = glp * (0.5f / pr - 0.5f * e * e);
+      if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
+      pt[32 + j] = xpb;
+      pt[36 + j] = prb;
+      if (!PREC) precb += prb;
+    }
+    const float y1 = pt[1], y2 = pt[2], y3 = pt[3], y4 = pt[4], y5 = pt[5];
+    rl_wave_fence();
+    const float4 xb4 = *reinterpret_cast<const float4*>(pt + 32);
+    float inj = 0.f;
+    if (l == 0) inj = xb4.x + xb4.y * y1 + xb4.z * (y2 + y4) + xb4.w * (y3 + y5);
+    else if (l == 1) inj = xb4.y * x;
+    else if (l == 2 || l == 4) inj = xb4.z * x;
+    else if (l == 3 || l == 5) inj = xb4.w * x;
+    else if (PREC && l >= 12) inj = pt[36 + (l - 12)];
+    lam += inj;
+    if (a.g_traj && l < N) lam += a.g_traj[((size_t)k * N + l) * n + i];
+    rl_wave_fence();
+  }
+  // ---- epilogue: per-lane constants' adjoints -> adjoints of the model's prepared parameters -> theta ---------------
+  {
+    float* r = tab[g][l];
+    r[0] = A.F0b; r[1] = A.cPb; r[2] = A.eb; r[3] = A.aRb; r[4] = A.aSb; r[5] = A.cQb; r[6] = A.iKb; r[7] = A.degb;
+    r[8] = lam;
+    r[9] = precb;
+  }
+  rl_wave_fence();
+  if (l == 0) {
+    float th[M::NSLOT], cc[2], p[M::NP], pb[M::NP], thb[M::NSLOT], lam0[12];
+#pragma unroll
+    for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+    M::prepare(th, cc, p);
+#pragma unroll
+    for (int q = 0; q < M::NP; ++q) pb[q] = 0.f;
+    auto T_ = [&](int lane, int f) { return tab[g][lane][f]; };
+    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
+    pb[M::P_r] = A.rb; pb[M::P_K] = A.Kb; pb[M::P_tlag] = A.tlagb;
+    pb[M::P_rc] = T_(1, 0) + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480] + T_(6, 0) * p[M::P_aR] + T_(7, 0) * p[M::P_aS] +
+                  T_(2, 1) * p[M::P_aYFP] + T_(3, 1) * p[M::P_aCFP] + T_(8, 1) + T_(9, 1) + T_(10, 5) * p[M::P_KC6] +
+                  T_(11, 5) * p[M::P_KC12];
+    pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7); pb[M::P_dR] = T_(6, 7); pb[M::P_dS] = T_(7, 7);
+    pb[M::P_dluxI] = T_(8, 7); pb[M::P_dlasI] = T_(9, 7);
+    pb[M::P_e81] = T_(2, 2) + T_(8, 2); pb[M::P_e76] = T_(3, 2) + T_(9, 2);
+    pb[M::P_KGR81] = (T_(2, 3) + T_(8, 3)) * fR; pb[M::P_KGS81] = (T_(2, 4) + T_(8, 4)) * fS;
+    pb[M::P_KGR76] = (T_(3, 3) + T_(9, 3)) * fR; pb[M::P_KGS76] = (T_(3, 4) + T_(9, 4)) * fS;
+    pb[M::P_fR] = (T_(2, 3) + T_(8, 3)) * p[M::P_KGR81] + (T_(3, 3) + T_(9, 3)) * p[M::P_KGR76];
+    pb[M::P_fS] = (T_(2, 4) + T_(8, 4)) * p[M::P_KGS81] + (T_(3, 4) + T_(9, 4)) * p[M::P_KGS76];
+    pb[M::P_aYFP] = T_(2, 1) * rc; pb[M::P_aCFP] = T_(3, 1) * rc;
+    pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc; pb[M::P_aR] = T_(6, 0) * rc; pb[M::P_aS] = T_(7, 0) * rc;
+    pb[M::P_KC6] = T_(10, 5) * rc; pb[M::P_KC12] = T_(11, 5) * rc;
+    const float iKl = frcp(p[M::P_Klux]), iKs = frcp(p[M::P_Klas]);
+    pb[M::P_Klux] = -T_(10, 6) * iKl * iKl; pb[M::P_Klas] = -T_(11, 6) * iKs * iKs;
+#pragma unroll
+    for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
+    M::prepare_vjp(th, cc, p, pb, thb);
+#pragma unroll
+    for (int q = 0; q < 12; ++q) lam0[q] = T_(q, 8);
+    M::init_vjp(lam0, thb);
+    if (live) {
+#pragma unroll
+      for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)  // init_prec_* (neural: the adjoint of the initial precision state) or prec_*
+        a.g_theta[(size_t)a.slot_row[M::NSLOT + q] * n + i] = PREC ? T_(12 + q, 8) : T_(q, 9);
+    }
+  }
+  if (PREC) {
+    // weight gradients: rows of the precision lanes, summed over the block's trajectories in trajectory order
+    if (l >= 12) {
+      float* w = wred[g] + (l - 12) * RL_NWROW;
+#pragma unroll
+      for (int q = 0; q < RL_NIN; ++q) { w[q] = live ? A.w2b[q].x : 0.f; w[RL_NIN + q] = live ? A.w2b[q].y : 0.f; }
+      w[2 * RL_NIN] = live ? A.b2b.x : 0.f;
+      w[2 * RL_NIN + 1] = live ? A.b2b.y : 0.f;
+    }
+    __syncthreads();
+    if (tid < RL_NWG && a.aux) {
+      float acc = 0.f;
+#pragma unroll
+      for (int q = 0; q < RL_TR; ++q) acc += wred[q][tid];
+      a.aux[(size_t)blockIdx.x * RL_NWG + tid] = acc;
+    }
+  }
+}
+
+// partial rows [nblocks][4][2*13+2] (rows: Wp row, Wd row, bp, bd of output o) -> ADDED into g_weights
+// (Wp [4][13], bp [4], Wd [4][13], bd [4]); blocks in order
+// One wavefront per element: lane q adds rows q, q + 64, ... (all requested together), then the lanes' sums are added by a
+// DPP scan -- a fixed order.
+static __global__ void __launch_bounds__(256) relay_lane_wreduce_kernel(const float* __restrict__ partial, int nblocks,
+                                                                        float* __restrict__ g_weights) {
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  if (e >= RL_NWG) return;
+  float acc = 0.f;
+  for (int b0 = 0; b0 < nblocks; b0 += 64 * 8) {
+    float v[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) v[q] = partial[(size_t)min(b0 + lane + 64 * q, nblocks - 1) * RL_NWG + e];
+#pragma unroll
+    for (int q = 0; q < 8; ++q)
+      if (b0 + lane + 64 * q < nblocks) acc += v[q];
+  }
+  // inclusive scan over the wavefront (row_shr 1, 2, 4, 8, row_bcast 15, 31): lane 63 holds the total
+#define RL_SCAN(CTRL, RM) acc += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, acc), CTRL, RM, 0xf, false))
+  RL_SCAN(0x111, 0xf); RL_SCAN(0x112, 0xf); RL_SCAN(0x114, 0xf); RL_SCAN(0x118, 0xf); RL_SCAN(0x142, 0xa); RL_SCAN(0x143, 0xc);
+#undef RL_SCAN
+  if (lane != 63) return;
+  const int o = e / RL_NWROW, q = e - o * RL_NWROW;
+  int dst;
+  if (q < RL_NIN) dst = o * RL_NIN + q;                                       // Wp[o][q]
+  else if (q < 2 * RL_NIN) dst = 4 * RL_NIN + 4 + o * RL_NIN + (q - RL_NIN);  // Wd[o][.]
+  else if (q == 2 * RL_NIN) dst = 4 * RL_NIN + o;                             // bp[o]
+  else dst = 8 * RL_NIN + 4 + o;                                              // bd[o]
+  g_weights[dst] += acc;
+}
+
+// ---- launch ---------------------------------------------------------------------------------------------------------
+template <bool PREC, int SOLVER>
+inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st) {
+  const int nblk = (a.n + RL_TR - 1) / RL_TR;
+  const int nb_max = min(a.B, (RL_TR - 1) / a.S + 2);
+  const size_t lds = sizeof(float) * ((size_t)a.T + (size_t)nb_max * 4 * a.T);
+  if (!backward) {
+    hipLaunchKernelGGL((relay_lane_fwd_kernel<PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+  } else {
+    hipLaunchKernelGGL((relay_lane_bwd_kernel<PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+    if (PREC && a.g_weights && a.aux)
+      hipLaunchKernelGGL(relay_lane_wreduce_kernel, dim3((RL_NWG + 3) / 4), dim3(256), 0, st, a.aux, nblk, a.g_weights);
+  }
+}
+template <bool PREC>
+inline int relay_lanes_launch(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  switch (solver) {
+    case VIHDS_SOLVER_MODEULER: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MODEULER>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MODEULERWHILE: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_EULER: relay_lanes_launch_s<PREC, VIHDS_SOLVER_EULER>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MIDPOINT: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MIDPOINT>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_RK4: relay_lanes_launch_s<PREC, VIHDS_SOLVER_RK4>(backward, a, st); return VIHDS_OK;
+  }
+  return VIHDS_E_BADARG;
+}
+
+}  // namespace vihds

@@ -147,6 +147,7 @@ _PROTOTYPES = {
                                                                                      ctypes.POINTER(Conditioner)]
                                   + [_P] * 10),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_bwd_reduces_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
     "vihds_problem_n_states": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_problem_n_slots": (_I, [ctypes.POINTER(OdeProblem)]),

@@ -219,7 +219,10 @@ class OdeSolveObserve(torch.autograd.Function):
             hip.ptr(weights), hip.ptr(traj), hip.ptr(g_traj), hip.ptr(g_xpred), hip.ptr(g_logp), hip.ptr(g_theta),
             hip.ptr(g_w), hip.ptr(aux), hip.current_stream()))
         hip.check(rc, "vihds_ode_bwd")
-        if aux is not None and ctx.needs_input_grad[6]:
+        if aux is not None and ctx.needs_input_grad[6] and not blackbox and hip.lib().vihds_ode_bwd_reduces_weights(
+                ctypes.byref(ctx.prob)):
+            pass  # (lane-split relay adjoint: the call above has already added the weight gradients up into g_w)
+        elif aux is not None and ctx.needs_input_grad[6]:
             if blackbox:
                 g_w = blackbox_weight_grads(ctx.spec, ctx.prob, aux, theta, cond, dev1hot)
             else:
