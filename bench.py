@@ -97,7 +97,7 @@ def ode_kernel_times(model, settings, batch, n_iwae, n_launch):
     return out
 
 
-def make_oracle_step(solver, observations=None, n_iwae=N_IWAE):
+def make_oracle_step(solver, observations=None, n_iwae=N_IWAE, workload="dr_constant_icml"):
     """One full training step of the oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd,
     Adam) on the bench workload, as a closure returning its wall time.  Shared by `cpu_baseline` below and by
     oracle/time_vs_reference.py (which times the imported reference beside it in the build container)."""
@@ -105,10 +105,19 @@ def make_oracle_step(solver, observations=None, n_iwae=N_IWAE):
     from vihds import synthetic
 
     args, settings, data, parameters, model, training = synthetic.build(
-        "dr_constant_icml", B_ROWS, n_iwae, solver=solver, device="cpu", seed=0, observations=observations)
+        workload, B_ROWS, n_iwae, solver=solver, device="cpu", seed=0, observations=observations)
     N_IWAE_ = n_iwae
     enc = model.encoder
-    opt = torch.optim.Adam(enc.parameters(), lr=0.01)
+    model_key = settings.model
+    # relay_constant_precisions (config 5): aR / aS are sampled parameters (no device conditioner) and the precision network's
+    # two Linear layers train with the encoder
+    conditioned = [k for k in ("aR", "aS") if k not in enc.names]
+    prec = getattr(model.decoder.ode_model, "precisions", None)
+    prec_w = None
+    if getattr(prec, "dynamic", False):
+        prec_w = {"prod_w": prec.prec_production.weight, "prod_b": prec.prec_production.bias,
+                  "degr_w": prec.prec_degradation.weight, "degr_b": prec.prec_degradation.bias}
+    opt = torch.optim.Adam(list(enc.parameters()) + (list(prec.parameters()) if prec_w is not None else []), lr=0.01)
     batch = training.train_data
     names = enc.names
     kinds = [d.kind for d in enc.descs]
@@ -125,11 +134,11 @@ def make_oracle_step(solver, observations=None, n_iwae=N_IWAE):
         qp = [q_prec[i][:, None] for i in range(len(names))]
         th = O.sample_clip_theta(names, kinds, qm, qp, p_mu, p_prec, u)
         ones = torch.ones(B_ROWS, N_IWAE_)
-        for k in ("aR", "aS"):
+        for k in conditioned:
             w = 2.0 + 1.5 * torch.randn(1, batch.dev_1hot.shape[1])
             th[k] = O.device_conditioner(w, ones, rel[k], batch.dev_1hot, True)
-        out = O.elbo_from_theta("dr_constant", names, kinds, th, qm, qp, p_mu, p_prec, batch.inputs, batch.times,
-                                batch.observations, solver)
+        out = O.elbo_from_theta(model_key, names, kinds, th, qm, qp, p_mu, p_prec, batch.inputs, batch.times,
+                                batch.observations, solver, prec_w=prec_w)
         out["loss"].backward()
         opt.step()
         opt.zero_grad()
@@ -138,12 +147,13 @@ def make_oracle_step(solver, observations=None, n_iwae=N_IWAE):
     return one_step
 
 
-def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=N_IWAE):
+def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=N_IWAE, workload="dr_constant_icml",
+                 n_times=None):
     """The oracle timed on this box's host cores on the same workload.  Checker code used as a *reported baseline*
     only.  Rows for 1 thread, 8 threads and all host threads; `value` is the best of them.  `fidelity` echoes
     oracle/cpu_fidelity.json: the same oracle step timed against the imported reference in the build container."""
     all_threads = torch.get_num_threads()
-    one_step = make_oracle_step(solver, observations, n_iwae)
+    one_step = make_oracle_step(solver, observations, n_iwae, workload)
     # the tensors are tiny (7 200 elements), so more threads is not faster: probe 1 / 8 / all host threads and time
     # the baseline with whichever is quickest on this box
     probe = {}
@@ -164,13 +174,16 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=
            "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
                      "CPU restatement of the reference path (oracle/); %d threads chosen from a probe of %s "
                      "(s/step); box has %d host threads"
-                     % (steps, B_ROWS, n_iwae, N_TIMES, solver, threads,
+                     % (steps, B_ROWS, n_iwae, n_times or N_TIMES, solver, threads,
                         {k: round(v, 2) for k, v in probe.items()}, all_threads),
            "ms_per_step": 1e3 * med,
            "rows_steps_per_s": {("%d thread%s" % (k, "" if k == 1 else "s")): round(1.0 / v, 3) for k, v in probe.items()}}
     fid = os.path.join(ROOT, "oracle", "cpu_fidelity.json")
-    if os.path.exists(fid):
+    if os.path.exists(fid) and workload == "dr_constant_icml":
         out["fidelity"] = json.load(open(fid))
+    if workload != "dr_constant_icml":
+        out["note"] = ("no reference timing can exist beside this one: the reference's classes for this model raise at "
+                       "construction (relay_constant.py:17,201); the oracle restates its equations")
     return out
 
 
@@ -365,13 +378,70 @@ def run_workload(a, name):
                                    "data parallel over rows x%d (one gradient all-reduce per step)" % world)},
         "final_objective": final, "roofline": roofline,
     }
-    if world == 1 and not a.no_cpu_baseline and wl == "dr_constant_icml" and mode == "train":
-        out["cpu_baseline"] = cpu_baseline(solver, batch.observations.detach().cpu(), n_iwae=S, max_steps=4)
+    if world == 1 and not a.no_cpu_baseline and wl in ("dr_constant_icml", "relay_constant_precisions") and mode == "train":
+        out["cpu_baseline"] = cpu_baseline(solver, batch.observations.detach().cpu(), n_iwae=S, max_steps=4, workload=wl,
+                                           n_times=T)
         out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
     else:
         out["cpu_baseline"] = None
-        out["cpu_baseline_note"] = "the oracle's timed training step exists for the dr_constant training workloads only"
+        out["cpu_baseline_note"] = "the oracle's timed training step exists for the white-box training workloads only"
     print(json.dumps(out))
+
+
+def run_loop_workload(a):
+    """`Training.run()` itself -- the loop a user of run_xval.py runs (reference training.py:342-383) -- on a synthetic
+    dr_constant_icml plate of the reference's size: 234 training rows in batches of 36 (six full batches and a ragged one of
+    18 per epoch, shuffled by the reference's own DataLoader sampler), n_iwae = 200, evaluation of the training and the
+    validation rows at 1000 samples every `test_epoch` epochs (the reference's default, 20), with the fast keys of the
+    headline bench.  `value` = optimizer steps / wall time of run(), evaluations and host work included.  Two legs: the NaN
+    check once per epoch (nan_check_every = 7), and after every step as the reference has it (a device synchronisation per
+    step)."""
+    import contextlib
+    import io
+
+    from vihds import synthetic
+
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or a.gpus != 1:
+        raise SystemExit("--workload run_loop is a single-process measurement")
+    torch.cuda.set_device(0)
+    solver = a.solver or "rk4"
+    n_rows, n_batch, S, S_eval = 234, 36, 200, 1000
+    epochs, test_epoch = max(100, a.steps // 7), 20
+    legs = {}
+    for name, check in (("nan_check_per_epoch", 7), ("nan_check_every_step", 1)):
+        args, settings, data, parameters, model, training = synthetic.build(
+            "dr_constant_icml", n_rows, S, solver=solver, device="cuda:0", seed=a.seed, n_batch=n_batch, u_rng=a.device_rng,
+            conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=check, learning_rate=a.lr,
+            fused_ode_training=True, fused_iwae_backward=True, fused_step_tail=not a.no_step_tail)
+        args.epochs, args.test_epoch, args.test_samples = 2, 1, S_eval
+        with contextlib.redirect_stdout(io.StringIO()):
+            training.run()  # captures, allocator warm-up, one evaluation: not timed
+        args.epochs, args.test_epoch = epochs, test_epoch
+        steps_per_epoch = (n_rows + n_batch - 1) // n_batch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        buf = io.StringIO()
+        with contextlib.redirect_stdout(buf):
+            out = training.run()
+        torch.cuda.synchronize()
+        el = time.perf_counter() - t0
+        n_steps, n_eval = epochs * steps_per_epoch, epochs // test_epoch
+        legs[name] = {"value": n_steps / el, "ms_per_step": 1e3 * el / n_steps, "wall_s": el, "epochs": epochs, "steps": n_steps,
+                      "evaluations": n_eval, "final_validation_elbo": float(out.elbo) if out is not None else None}
+    best = legs["nan_check_per_epoch"]
+    print(json.dumps({
+        "metric": "ELBO training steps/sec through Training.run() (dr_constant_icml, n_iwae=200)", "value": best["value"],
+        "unit": "steps/s", "n_gpus": 1, "steps": best["steps"], "warmup": 2 * 7, "ms_per_step": best["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "Training.run(): %d rows in batches of %d (ragged last batch of %d), n_iwae=%d, T=86, %s, "
+                               "evaluation of train + validation rows at n_iwae=%d every %d epochs; rows resident in HBM, "
+                               "batches gathered on the device by row index (vihds_gather_batch), one hipGraph per batch "
+                               "size holding gather + step" % (n_rows, n_batch, n_rows % n_batch, S, solver, S_eval, test_epoch),
+                   "name": "run_loop", "launch": "eager" if a.eager else "hipGraph replay (one step per launch)",
+                   "learning_rate": a.lr},
+        "legs": legs, "roofline": None, "cpu_baseline": None,
+        "note": "end-to-end loop figure next to the headline's resident-batch replay (python bench.py): the difference is the "
+                "per-step host work (sampler, index copy, graph launch), the ragged batch and the evaluations"}))
 
 
 def strong_scaling_leg(a, dev, world, rank):
@@ -441,7 +511,7 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--solver", default=None)
-    ap.add_argument("--workload", choices=sorted(WORKLOAD_TABLE), default="config2",
+    ap.add_argument("--workload", choices=sorted(WORKLOAD_TABLE) + ["run_loop"], default="config2",
                     help="which BASELINE.json configuration: config2 (headline, default), config3_train / config3_eval "
                          "(n_iwae=1000), config4 (dr_blackbox, MFMA roofline), config5 (relay)")
     ap.add_argument("--eager", action="store_true", help="launch every kernel from python instead of replaying a hipGraph")
@@ -495,6 +565,8 @@ def main():
     if a.workload != "config2":
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        if a.workload == "run_loop":
+            return run_loop_workload(a)
         return run_workload(a, a.workload)
     a.solver = a.solver or "rk4"
 

@@ -311,6 +311,16 @@ int vihds_offset_rows_fwd(int B, int S, int D, int n, int n_rows, int src_row, i
 int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, int dst_row, int accumulate,
                           const float* dev1hot, float* g_theta, float* g_wb, void* stream);
 
+/* Device-resident batching (reference training.py:108-113,55-68: DataLoader(shuffle=True) + collate_merged build every
+ * batch on the host): the whole training set stays in HBM (obs_src [n_src][C4][T], inputs_src [n_src][n_tr], dev1hot_src
+ * [n_src][D]) and a step's batch is gathered by row index -- idx [B] int64 on the device, e.g. one batch of the epoch's
+ * permutation -- into obs [B][C4][T], inputs [B][n_tr], dev1hot [B][D], with delta_obs [B][C4][T-1] (the encoder's first
+ * differences, encoders.py:385; may be NULL) formed on the way.  One launch; capturable (the index buffer is refreshed
+ * between replays). */
+int vihds_gather_batch(int B, int n_src, int C4, int T, int n_tr, int D, const long long* idx, const float* obs_src,
+                       const float* inputs_src, const float* dev1hot_src, float* obs, float* inputs, float* dev1hot,
+                       float* delta_obs, void* stream);
+
 /* OdeModel.device_conditioner applied to a tensor of ones (vihds/ode.py:43-58; models/dr_constant.py:124-131), for E
  * parameters at once: out[e][b][s] = (is_default[e] ? 1 : 0) + relu(sum_d (w_mean + w_std*z[e][d]) * dev1hot[r][d] *
  * relevance[e][d]) with r = (b*S+s) mod B (the reference's .repeat tiling, kept).  z [E][D] are standard normals

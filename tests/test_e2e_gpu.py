@@ -583,3 +583,39 @@ def test_bench_gpus_2_self_launch_on_one_device():
     assert len(lines) == 1, r.stdout[-3000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and np.isfinite(out["final_loss"])
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_step_rows_gathers_on_the_device_what_the_host_loader_would_stack(graph):
+    """Device-resident batching (Training.step_rows / vihds_gather_batch): a step on rows picked by index from the resident
+    training set -- eagerly, and as one hipGraph per batch size holding gather + step, full and ragged batches alternating
+    -- must walk the loss sequence of steps on the same batches built on the host (index, copy, delta_obs with torch ops)."""
+    from vihds import synthetic
+    from vihds.utils import attrify
+
+    kw = dict(solver="rk4", seed=5, u_rng="kernel", conditioner_rng="kernel", nan_check_every=0, learning_rate=0.01,
+              fused_ode_training=True, fused_decoder_step=True, fused_iwae_backward=True, fused_step_tail=True, n_batch=8)
+    g = torch.Generator().manual_seed(0)
+    picks = [torch.randperm(20, generator=g)[:n] for n in (8, 8, 4, 8, 4, 8)]
+    runs = {}
+    for mode in ("host", "rows"):
+        args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                            hip_graph=graph and mode == "rows", **kw)
+        model.train()
+        src = training.train_data
+        losses = []
+        for rows in picks:
+            if mode == "rows":
+                losses.append(float(training.step_rows(rows)))
+            else:
+                r = rows.to("cuda:0")
+                obs = src.observations[r].contiguous()
+                batch = attrify({"observations": obs, "inputs": src.inputs[r].contiguous(),
+                                 "dev_1hot": src.dev_1hot[r].contiguous(), "times": src.times, "devices": None,
+                                 "delta_obs": (obs[:, :, 1:] - obs[:, :, :-1]).contiguous()})
+                losses.append(float(training.step(batch)))
+        runs[mode] = (losses, {k: v.detach().clone() for k, v in model.named_parameters()})
+    for a, b in zip(runs["host"][0], runs["rows"][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs["host"][0], runs["rows"][0])
+    for k, v in runs["host"][1].items():
+        assert rel_err(runs["rows"][1][k], v) < 1e-6, k

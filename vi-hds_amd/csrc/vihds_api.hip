@@ -71,6 +71,8 @@ void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, fl
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
 // vihds_offset.hip
+void launch_gather_batch(int, int, int, int, int, int, const long long*, const float*, const float*, const float*, float*, float*,
+                         float*, float*, hipStream_t);
 void launch_offset_rows_fwd(int, int, int, int, int, int, const float*, const float*, const float*, float*, hipStream_t);
 void launch_offset_rows_bwd(int, int, int, int, int, int, int, const float*, float*, float*, hipStream_t);
 // vihds_gram.hip
@@ -725,6 +727,17 @@ int vihds_offset_rows_bwd(int B, int S, int D, int n, int n_rows, int src_row, i
   if (D + 1 > 1024) return fail(VIHDS_E_UNSUPPORTED, "device one-hot wider than 1023");
   launch_offset_rows_bwd(B, S, D, n, src_row, dst_row, accumulate, dev1hot, g_theta, g_wb, (hipStream_t)stream);
   return check_hip("vihds_offset_rows_bwd launch");
+}
+
+int vihds_gather_batch(int B, int n_src, int C4, int T, int n_tr, int D, const long long* idx, const float* obs_src,
+                       const float* inputs_src, const float* dev1hot_src, float* obs, float* inputs, float* dev1hot,
+                       float* delta_obs, void* stream) {
+  if (B <= 0 || n_src <= 0 || C4 <= 0 || T <= 1 || n_tr < 0 || D < 0) return fail(VIHDS_E_BADARG, "bad sizes");
+  if (!idx || !obs_src || !obs || (n_tr > 0 && (!inputs_src || !inputs)) || (D > 0 && (!dev1hot_src || !dev1hot)))
+    return fail(VIHDS_E_BADARG, "null argument");
+  launch_gather_batch(B, n_src, C4, T, n_tr, D, idx, obs_src, inputs_src, dev1hot_src, obs, inputs, dev1hot, delta_obs,
+                      (hipStream_t)stream);
+  return check_hip("vihds_gather_batch launch");
 }
 
 int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* state, const float* lr_dev, float lr,

@@ -64,4 +64,35 @@ void launch_offset_rows_bwd(int B, int S, int D, int n, int src, int dst, int ac
   hipLaunchKernelGGL(offset_rows_bwd_kernel, dim3(n), dim3(OFFSET_BWD_THREADS), (size_t)B * sizeof(float), st, B, S, D, n,
                      src, dst, accumulate, dev1hot, g_theta, g_wb);
 }
+// Device-resident batching (reference training.py:108-113: DataLoader(shuffle) + collate_merged :55-68 stack the rows of a
+// batch on the host every step): rows idx[0..B) of the training set, which is resident in HBM as a whole, -> the step's
+// batch buffers, and the encoder's input-only preprocessing delta_obs[b][c][t] = obs[b][c][t+1] - obs[b][c][t]
+// (encoders.py:385) while the row is at hand.  One block per batch row.
+__global__ void __launch_bounds__(256) gather_batch_kernel(int n_src, int CT, int T, int n_tr, int D,
+                                                           const long long* __restrict__ idx,
+                                                           const float* __restrict__ obs_src,
+                                                           const float* __restrict__ inputs_src,
+                                                           const float* __restrict__ dev1hot_src, float* __restrict__ obs,
+                                                           float* __restrict__ inputs, float* __restrict__ dev1hot,
+                                                           float* __restrict__ delta_obs) {
+  const int b = blockIdx.x;
+  long long r = idx[b];
+  r = r < 0 ? 0 : (r >= n_src ? n_src - 1 : r);  // (an index outside the set is clamped, never dereferenced)
+  const float* o = obs_src + (size_t)r * CT;
+  for (int q = threadIdx.x; q < CT; q += 256) {
+    const float v = o[q];
+    obs[(size_t)b * CT + q] = v;
+    const int c = q / T, t = q - c * T;
+    if (delta_obs && t + 1 < T) delta_obs[((size_t)b * (CT / T) + c) * (T - 1) + t] = o[q + 1] - v;
+  }
+  for (int q = threadIdx.x; q < n_tr; q += 256) inputs[(size_t)b * n_tr + q] = inputs_src[(size_t)r * n_tr + q];
+  for (int q = threadIdx.x; q < D; q += 256) dev1hot[(size_t)b * D + q] = dev1hot_src[(size_t)r * D + q];
+}
+void launch_gather_batch(int B, int n_src, int C4, int T, int n_tr, int D, const long long* idx, const float* obs_src,
+                         const float* inputs_src, const float* dev1hot_src, float* obs, float* inputs, float* dev1hot,
+                         float* delta_obs, hipStream_t st) {
+  hipLaunchKernelGGL(gather_batch_kernel, dim3(B), dim3(256), 0, st, n_src, C4 * T, T, n_tr, D, idx, obs_src, inputs_src,
+                     dev1hot_src, obs, inputs, dev1hot, delta_obs);
+}
+
 }  // namespace vihds

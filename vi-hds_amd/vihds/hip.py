@@ -171,6 +171,7 @@ _PROTOTYPES = {
     "vihds_blackbox_tail_grads": (_I, [_P] * 8),
     "vihds_offset_rows_fwd": (_I, [_I] * 7 + [_P] * 5),
     "vihds_offset_rows_bwd": (_I, [_I] * 8 + [_P] * 4),
+    "vihds_gather_batch": (_I, [_I] * 6 + [_P] * 8 + [_P]),
     "vihds_adam_step": (_I, [ctypes.POINTER(AdamTensors), _P, _P, _P, _P] + [ctypes.c_float] * 5 + [_P, _P]),
     "vihds_step_tail": (_I, [ctypes.POINTER(EncoderShape), ctypes.POINTER(StepTailArgs), _P]),
     "vihds_step_tail_supported": (_I, [ctypes.POINTER(EncoderShape), _I, _I]),

@@ -191,7 +191,7 @@ def make_args(n_iwae, seed=0, gpu=None):
 
 
 def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=None, observations=None,
-          replica=None, replica_same_data=False, **param_overrides):
+          replica=None, replica_same_data=False, n_batch=None, **param_overrides):
     """(args, settings, data_pair, parameters, model, training) for a named synthetic workload.
     shard: parallel.SampleShard (the IWAE-sample axis split over ranks).  replica: parallel.RowReplica (every rank
     its own rows and draws, gradients averaged): the model is initialised from `seed` on every rank, the plate and the
@@ -205,7 +205,7 @@ def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=No
     spec_fn, n_times = WORKLOADS[workload]
     spec = spec_fn(solver)
     spec["params"].update(param_overrides)
-    spec["params"]["n_batch"] = n_rows
+    spec["params"]["n_batch"] = n_batch or n_rows  # (n_batch < n_rows: several batches per epoch, the last one ragged)
     args = make_args(n_iwae, seed)
     np.random.seed(seed)
     torch.manual_seed(seed)

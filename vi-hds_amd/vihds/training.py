@@ -54,6 +54,19 @@ def collate_merged(times, device, batch):
     return batch_to_device(times, device, dd)
 
 
+class _RowIndices(torch.utils.data.Dataset):
+    """range(n) as a dataset: what DataLoader shuffles when the rows themselves already live on the device."""
+
+    def __init__(self, n):
+        self.n = int(n)
+
+    def __len__(self):
+        return self.n
+
+    def __getitem__(self, i):
+        return int(i)
+
+
 class Training:
     """Orchestrates IWAE training of the VAE (reference training.py:71-383)."""
 
@@ -93,12 +106,22 @@ class Training:
         self.n_batch = min(p.n_batch, data.n_train)
         self.train_data = batch_to_device(data.train.dataset.times, settings.device,
                                           data.train.dataset[data.train.indices])
+        for k in ("dev_1hot", "inputs", "observations"):  # (vihds_gather_batch reads them as fp32 rows)
+            self.train_data[k] = self.train_data[k].float().contiguous()
         self.valid_data = batch_to_device(data.test.dataset.times, settings.device,
                                           data.test.dataset[data.test.indices])
-        self.train_loader = DataLoader(
+        # The training rows are resident on the device as a whole (self.train_data); the loader only decides WHICH rows make
+        # up a batch.  It is the reference's DataLoader(shuffle=True) (training.py:108-113) over a dataset of the same
+        # length, so it consumes torch's generator exactly as the reference's loader does (same shuffles under the same
+        # seed: tests/golden/trace_*.npz), but yields row indices; the rows are gathered on the device
+        # (vihds_gather_batch) instead of being stacked sample by sample on the host every step.
+        self.train_loader = DataLoader(dataset=_RowIndices(data.n_train if hasattr(data, "n_train") else len(data.train)),
+                                       batch_size=self.n_batch, shuffle=True,
+                                       collate_fn=lambda rows: torch.tensor(rows, dtype=torch.int64))
+        self.host_loader = DataLoader(
             dataset=data.train, batch_size=self.n_batch, shuffle=True,
             collate_fn=functools.partial(collate_merged, data.train.dataset.times, settings.device),
-        )
+        )  # (the reference's own loader: kept for callers that want host-built batches; Training.run does not use it)
         if settings.trainer is not None:
             held_out_name = args.heldout or "%d_of_%d" % (args.split, args.folds)
             self.train_path = os.path.join(settings.trainer.tb_log_dir, "train_%s" % held_out_name)
@@ -336,6 +359,51 @@ class Training:
                 else:  # created (seeded) by the warm-up: keep the seed, rewind the step / ticket words
                     t[2:].zero_()
 
+    def _capture(self, static, repeat, prologue=None):
+        """Warm up on a side stream (rolled back afterwards), then capture `repeat` steps on the buffers `static` --
+        behind `prologue()` when given (e.g. the gather that fills them) -- into a hipGraph.  Returns (graph, static, loss)."""
+        s = torch.cuda.Stream()
+        # the snapshot's clone kernels are enqueued on the current stream BEFORE the side stream is made to wait for
+        # it, so the warm-up steps (which run Adam and advance the generator states) are ordered after the copies
+        snap = self._snapshot_training_state()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
+                if prologue is not None:
+                    prologue()
+                self.step(static)
+        torch.cuda.current_stream().wait_stream(s)
+        self._restore_training_state(snap)  # the warm-up steps must not count as training steps
+        self.optimizer.zero_grad(set_to_none=True)
+        # The parameters' AccumulateGrad nodes were created during the warm-up steps, on the side stream; the capture
+        # runs on the graph's own stream, where every producer and consumer of a gradient is recorded in program
+        # order, so the "stream does not match" warning autograd prints once per capture does not apply.
+        _warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
+        if _warn is not None:
+            _warn(False)
+        try:
+            if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
+                g = parallel.SegmentedGraph()
+
+                def fn():
+                    if prologue is not None:
+                        prologue()
+                    return self.step(static, zero_grad=False)
+
+                loss = g.capture(fn)
+            else:
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    if prologue is not None:
+                        prologue()
+                    # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
+                    loss = [self.step(static, zero_grad=k < repeat - 1) for k in range(repeat)]
+                    loss = loss[0] if repeat == 1 else loss
+        finally:
+            if _warn is not None:
+                _warn(True)  # only the capture itself is exempt, not the rest of the process
+        return g, static, loss
+
     def graph_step(self, batch, repeat=1):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
         graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and a fixed batch shape.
@@ -356,37 +424,7 @@ class Training:
             # input-only preprocessing of the encoder (reference encoders.py:385) is done when a batch is staged, not
             # inside every replay
             static["delta_obs"] = _delta_obs(static.observations)
-            s = torch.cuda.Stream()
-            # the snapshot's clone kernels are enqueued on the current stream BEFORE the side stream is made to wait for
-            # it, so the warm-up steps (which run Adam and advance the generator states) are ordered after the copies
-            snap = self._snapshot_training_state()
-            s.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(s):
-                for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
-                    self.step(static)
-            torch.cuda.current_stream().wait_stream(s)
-            self._restore_training_state(snap)  # the warm-up steps must not count as training steps
-            self.optimizer.zero_grad(set_to_none=True)
-            # The parameters' AccumulateGrad nodes were created during the warm-up steps, on the side stream; the capture
-            # runs on the graph's own stream, where every producer and consumer of a gradient is recorded in program
-            # order, so the "stream does not match" warning autograd prints once per capture does not apply.
-            _warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
-            if _warn is not None:
-                _warn(False)
-            try:
-                if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
-                    g = parallel.SegmentedGraph()
-                    loss = g.capture(lambda: self.step(static, zero_grad=False))
-                else:
-                    g = torch.cuda.CUDAGraph()
-                    with torch.cuda.graph(g):
-                        # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
-                        loss = [self.step(static, zero_grad=k < repeat - 1) for k in range(repeat)]
-                        loss = loss[0] if repeat == 1 else loss
-            finally:
-                if _warn is not None:
-                    _warn(True)  # only the capture itself is exempt, not the rest of the process
-            self._graphs[key] = (g, static, loss)
+            self._graphs[key] = self._capture(static, repeat)
         g, static, loss = self._graphs[key]
         if self._staged.get(key) is not batch:  # a batch that is already resident in the graph's inputs is not re-copied
             for k in ("dev_1hot", "inputs", "observations", "times"):
@@ -399,11 +437,58 @@ class Training:
             return loss[-1]
         return loss
 
+    # ------------------------------------------------------------------------------------------------
+    def gather_rows(self, rows, out=None):
+        """Batch = rows `rows` (int64 tensor on the device) of the resident training set, gathered by ONE launch
+        (vihds_gather_batch; delta_obs, the encoder's input-only preprocessing, formed on the way).  `out`: buffers of a
+        previous call with the same number of rows, written in place (the captured step's inputs)."""
+        from vihds import hip
+
+        src = self.train_data
+        B = int(rows.shape[0])
+        n_src, C4, T = src.observations.shape
+        n_tr, D = src.inputs.shape[1], src.dev_1hot.shape[1]
+        dev = src.observations.device
+        if out is None:
+            out = attrify({"observations": torch.empty((B, C4, T), device=dev), "inputs": torch.empty((B, n_tr), device=dev),
+                           "dev_1hot": torch.empty((B, D), device=dev), "delta_obs": torch.empty((B, C4, T - 1), device=dev),
+                           "times": src.times, "devices": None})
+        rc = hip.lib().vihds_gather_batch(B, n_src, C4, T, n_tr, D, hip.ptr(rows), hip.ptr(src.observations),
+                                          hip.ptr(src.inputs), hip.ptr(src.dev_1hot), hip.ptr(out.observations),
+                                          hip.ptr(out.inputs), hip.ptr(out.dev_1hot), hip.ptr(out.delta_obs),
+                                          hip.current_stream())
+        hip.check(rc, "vihds_gather_batch")
+        return out
+
+    def step_rows(self, rows_host):
+        """One training step on the rows `rows_host` (host int64 tensor) of the resident training set: eager, or -- with
+        params.hip_graph -- one hipGraph per batch size holding the gather and the step; per step the host then only
+        refreshes the graph's index buffer (one small copy) and launches it."""
+        n = int(rows_host.shape[0])
+        dev = self.train_data.observations.device
+        if not self.use_graph:
+            return self.step(self.gather_rows(rows_host.to(dev, non_blocking=True)))
+        key = ("rows", n)
+        if key not in self._graphs:
+            idx = rows_host.to(dev).clone()
+            static = self.gather_rows(idx)
+            pinned = torch.empty(n, dtype=torch.int64).pin_memory()
+            self._graphs[key] = self._capture(static, 1, prologue=lambda: self.gather_rows(idx, out=static)) + (idx, pinned)
+        g, static, loss, idx, pinned = self._graphs[key]
+        pinned.copy_(rows_host)
+        idx.copy_(pinned, non_blocking=True)
+        g.replay()
+        return loss
+
     def _run_batch(self, epoch_start, batch, log_data):
-        """reference training.py:324-340"""
+        """reference training.py:324-340.  `batch`: a batch of the reference's form, or the row indices of one (host int64
+        tensor: what self.train_loader yields)."""
         log_data.batch_feed_time += time.time() - epoch_start
         train_start = time.time()
-        elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
+        if isinstance(batch, torch.Tensor):
+            elbo = self.step_rows(batch)
+        else:
+            elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
         self._steps += 1
         if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
             # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced the
