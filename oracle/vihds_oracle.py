@@ -162,8 +162,16 @@ SOLVERS = {
 # ---- adaptive pairs (torchdiffeq==0.1 odeint with method dopri5 / bosh3 / adaptive_heun; vihds/ode.py:79-81).  Third
 # party, absent: restated from the published algorithm, parity unpinned.  One step size for the whole batch; error ratio =
 # mean over all elements of (err / (atol + rtol max(|y0|, |y1|)))^2; step factor of _optimal_step_size (safety 0.9, ifactor
-# 10, dfactor 0.2).  As in the HIP path (and unlike torchdiffeq, which interpolates) accepted steps are clipped to the output
-# times, and gradients flow through the accepted steps with the step sizes held constant.
+# 10, dfactor 0.2).  TWO restatements live here, and they are kept apart on purpose:
+#   * `odeint_adaptive` -- THE DEPENDENCY's algorithm (AdaptiveStepsizeODESolver.advance): steps are NOT clipped to the
+#     output times; the solver steps past an output time and evaluates the 4th-order interpolant `_interp_fit` of the
+#     accepted step that contains it (dopri5: y_mid from DPS_C_MID; bosh3 / adaptive_heun: their `mid` rows).  This is
+#     what the product is measured AGAINST (tests/test_hip_parity.py::test_adaptive_product_vs_the_dependencys_algorithm).
+#   * `adaptive_grid` + `integrate_on_grid` -- a twin of the PRODUCT's controller (vihds_ode_adaptive_grid: accepted
+#     steps clipped to the output times, then the pair's propagated solution on that grid, discrete adjoint).  It is test
+#     infrastructure for the kernels' controller and for the fixed-grid kernels on ragged grids, not a statement about
+#     torchdiffeq; the product's deliberate difference from the dependency (clipping instead of interpolation) is the
+#     measured quantity of the test named above.
 ADAPTIVE_TABLEAUS = {
     "dopri5": dict(
         order=5, c=[0, 1 / 5, 3 / 10, 4 / 5, 8 / 9, 1, 1],
@@ -261,6 +269,107 @@ def adaptive_grid(solver, func, x0, times, rtol=1e-7, atol=1e-9, max_grid=4096):
                     h = hn
             index.append(len(grid) - 1)
     return grid, index
+
+
+# y_mid weights of the accepted step (torchdiffeq: DPS_C_MID in dopri5.py; `mid` of the Bogacki-Shampine and Heun-Euler
+# solvers) for the 4th-order interpolant
+ADAPTIVE_MID = {
+    "dopri5": [6025192743 / 30085553152 / 2, 0, 51252292925 / 65400821598 / 2, -2691868925 / 45128329728 / 2,
+               187940372067 / 1594534317056 / 2, -1776094331 / 19743644256 / 2, 11237099 / 235043384 / 2],
+    "bosh3": [0.0, 0.5, 0.0, 0.0],
+    "adaptive_heun": [0.5, 0.0],
+}
+
+
+def _interp_fit(y0, y1, y_mid, f0, f1, dt):
+    """torchdiffeq interp.py `_interp_fit`: coefficients of the quartic through y0, y_mid, y1 with end slopes f0, f1."""
+    a = 2 * dt * (f1 - f0) - 8 * (y1 + y0) + 16 * y_mid
+    b = dt * (5 * f0 - 3 * f1) + 18 * y0 + 14 * y1 - 32 * y_mid
+    c = dt * (f1 - 4 * f0) - 11 * y0 - 5 * y1 + 16 * y_mid
+    return [a, b, c, dt * f0, y0]
+
+
+def _interp_evaluate(coef, t0, t1, t):
+    """torchdiffeq interp.py `_interp_evaluate`: Horner-free power form in x = (t - t0) / (t1 - t0)."""
+    x = (t - t0) / (t1 - t0)
+    total = coef[-1]
+    xp = 1.0
+    for c in reversed(coef[:-1]):
+        xp = xp * x
+        total = total + c * xp
+    return total
+
+
+def odeint_adaptive(solver, func, x0, times, rtol=1e-7, atol=1e-9, max_steps=100000):
+    """torchdiffeq==0.1 `odeint(func, y0, t, method=solver)` for the adaptive pairs, restated (the call site is
+    vihds/ode.py:79-81; the dependency is absent, parity unpinned): AdaptiveStepsizeODESolver.integrate -> for every output
+    time `advance(next_t)`: take adaptive steps WHILE next_t > t1 of the last accepted step (steps are not shortened to hit
+    the output time), then return the interpolant of that step at next_t.  One step size for the whole batch;
+    `_select_initial_step`, `_compute_error_ratio`, `_optimal_step_size` (safety 0.9, ifactor 10, dfactor 0.2) as published.
+    Differentiable through the accepted steps and the interpolant with the step sizes held constant (torchdiffeq's graph
+    also runs through the step-size arithmetic: an O(tolerance) contribution that is not restated).
+    Returns (solution [T, ...], number of accepted steps, number of rejected steps)."""
+    tab, mid = ADAPTIVE_TABLEAUS[solver], ADAPTIVE_MID[solver]
+    ns = len(tab["a"]) - 1
+    call = func
+    f = lambda tt, yy: call(torch.as_tensor(tt, dtype=yy.dtype), yy)  # noqa: E731
+    t0 = float(times[0])
+    y = x0
+    with torch.no_grad():
+        f0 = f(t0, y)
+        scale = atol + rtol * y.abs()
+        rms = lambda v: float((v.double() ** 2).mean().sqrt())  # noqa: E731
+        d0, d1 = rms(y / scale), rms(f0 / scale)
+        h0 = 1e-6 if (d0 < 1e-5 or d1 < 1e-5) else 0.01 * d0 / d1
+        f1 = f(t0 + h0, y + h0 * f0)
+        d2 = rms((f1 - f0) / scale) / h0
+        h1 = max(1e-6, h0 * 1e-3) if (d1 <= 1e-15 and d2 <= 1e-15) else (0.01 / max(d1, d2)) ** (1.0 / (tab["order"] + 1))
+        dt = min(100.0 * h0, h1)
+    f_cur = f(t0, y)
+    ta, tb = t0, t0                      # the last accepted step spans [ta, tb]
+    coef = [torch.zeros_like(y)] * 4 + [y]
+    out, n_acc, n_rej = [y], 0, 0
+    for k in range(1, len(times)):
+        t_out = float(times[k])
+        while t_out > tb:
+            if n_acc + n_rej >= max_steps:
+                raise RuntimeError("odeint_adaptive: max_steps exceeded")
+            ks = [f_cur]
+            for s_ in range(1, ns):
+                ya = y
+                for r, w in enumerate(tab["a"][s_]):
+                    if w != 0:
+                        ya = ya + (dt * w) * ks[r]
+                ks.append(f(tb + tab["c"][s_] * dt, ya))
+            y1 = y
+            for r, w in enumerate(tab["a"][ns]):
+                if w != 0:
+                    y1 = y1 + (dt * w) * ks[r]
+            f_new = f(tb + dt, y1)       # FSAL: the last stage of these pairs is f(t + dt, y1)
+            kall = ks + [f_new]
+            err = sum((dt * w) * kall[r] for r, w in enumerate(tab["e"]) if w != 0)
+            with torch.no_grad():
+                tol = atol + rtol * torch.maximum(y.abs(), y1.abs())
+                ratio = float(((err / tol).double() ** 2).mean())
+            if ratio == 0.0:
+                dt_next = dt * 10.0
+            else:
+                dfactor = 1.0 if ratio < 1.0 else 0.2
+                dt_next = dt / max(0.1, min(ratio ** (0.5 / tab["order"]) / 0.9, 1.0 / dfactor))
+            if ratio <= 1.0:
+                y_mid = y
+                for r, w in enumerate(mid):
+                    if w != 0:
+                        y_mid = y_mid + (dt * w) * kall[r]
+                coef = _interp_fit(y, y1, y_mid, f_cur, f_new, dt)
+                ta, tb = tb, tb + dt
+                y, f_cur = y1, f_new
+                n_acc += 1
+            else:
+                n_rej += 1
+            dt = dt_next
+        out.append(_interp_evaluate(coef, ta, tb, t_out))
+    return torch.stack(out), n_acc, n_rej
 
 
 def integrate_on_grid(solver, func, x0, grid):

@@ -1927,3 +1927,82 @@ def test_relay_lane_kernels_at_config5_size():
         if scale > 0:
             assert float((got[2][i] - ref[2][i]).abs().max() / scale) < 5e-4, n
     assert rel_err(got[3], ref[3]) < 5e-4
+
+
+@pytest.mark.parametrize("solver", ["dopri5", "bosh3", "adaptive_heun"])
+def test_adaptive_product_vs_the_dependencys_algorithm(solver):
+    """The product's ONE deliberate difference from torchdiffeq's adaptive driver, measured: the HIP path
+    clips accepted steps to the output times and reads the solution at grid points (vihds_ode_adaptive_grid + the pair's
+    tableau on the accepted grid, discrete adjoint); torchdiffeq steps past an output time and evaluates the accepted
+    step's quartic interpolant there.  Against `oracle.odeint_adaptive` -- the restatement of the DEPENDENCY's algorithm,
+    not of the kernels -- on a reference fixture's theta: trajectories at the output times and the gradient of a
+    log-likelihood-like scalar w.r.t. every theta row.  Both are solutions of the same ODE to the same tolerance, so they
+    must agree to a small multiple of it; the measured figures are printed (and recorded in DESIGN.md section 4.6)."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    rtol, atol = (1e-6, 1e-8) if solver == "dopri5" else (1e-5, 1e-7)
+    # ---- product
+    th, row_of = H.pack_theta(fx, DEV)
+    th.requires_grad_(True)
+    spec = H.spec_for(fx, row_of, th.shape[0], solver, 0)
+    grid, index = ops.adaptive_grid(spec, th.detach(), fx.t("inputs", DEV), fx.t("times"), None, None, rtol, atol)
+    dummy = torch.zeros(fx.B, 4, grid.shape[0], device=DEV)
+    traj_g, _, _ = ops.OdeSolveObserve.apply(spec, th, fx.t("inputs", DEV), grid, dummy, None, None)
+    sol = H.view_bsnt(traj_g.index_select(0, index))  # [B,S,N,T]
+    wgt = torch.linspace(0.5, 1.5, sol.shape[2] * sol.shape[3]).reshape(sol.shape[2], sol.shape[3])
+    (sol * wgt.to(DEV)).sum().backward()
+    # ---- the dependency's algorithm
+    thc = fx.theta_dict(requires_grad=True)
+    for n in fx.extra_names:
+        thc[n].requires_grad_(True)
+    rhs, x0 = O.MODEL_TABLE[fx.model][0](thc, fx.t("inputs"))
+    ref, n_acc, n_rej = O.odeint_adaptive(solver, rhs, x0, fx.t("times"), rtol, atol)
+    ref = ref.permute(1, 2, 3, 0)
+    (ref * wgt).sum().backward()
+    e_sol = float(rel_err(sol, ref))
+    names = list(fx.names) + list(fx.extra_names)
+    e_grad = 0.0
+    for i, n in enumerate(names):
+        g_ref = thc[n].grad
+        if g_ref is None or float(g_ref.abs().max()) == 0.0:
+            continue
+        e_grad = max(e_grad, float((th.grad[i].cpu() - g_ref).abs().max() / g_ref.abs().max()))
+    print("adaptive %s: product grid %d points (clipped) vs dependency %d accepted + %d rejected steps (interpolated); "
+          "solution difference %.2e, gradient difference %.2e (rtol %.0e)" % (solver, grid.shape[0], n_acc, n_rej, e_sol,
+                                                                              e_grad, rtol))
+    assert e_sol < 200 * rtol and e_grad < 2e-3
+
+
+@pytest.mark.parametrize("solver", ["dopri5", "bosh3", "adaptive_heun"])
+def test_adaptive_solvers_at_torchdiffeqs_default_tolerances(solver):
+    """`solver: dopri5 / bosh3 / adaptive_heun` with NO solver_rtol / solver_atol in the spec, i.e. torchdiffeq's defaults
+    1e-7 / 1e-9: the accepted-grid buffer grows from params.solver_max_grid (4096) as the controller needs, and
+    a tolerance the fp32 state cannot resolve ends in a RuntimeError that names the tolerances -- never in a silent
+    truncation.  dopri5 and bosh3 must run (and agree with the modified-Euler fixture by the reference's 5 % criterion)."""
+    import e2e_util as E
+    from vihds.vae import build_model
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    args, settings, data, parameters = E.build_from_fixture(fx, gpu=0)
+    settings.params.solver = solver
+    assert "solver_rtol" not in settings.params and "solver_atol" not in settings.params
+    model = build_model(args, settings, data, parameters)
+    from vihds.training import Training
+
+    Training(args, settings, data, parameters, model)  # (sets model.n_theta)
+    model.eval()
+    batch = E.batch_from_fixture(fx, settings.device)
+    torch.manual_seed(3)
+    np.random.seed(3)
+    try:
+        with torch.no_grad():
+            results, theta, q, p = model(batch, fx.S)
+    except RuntimeError as e:
+        assert solver == "adaptive_heun" and "solver_rtol" in str(e), e
+        return
+    x_states = results[0]
+    n_grid = int(model.decoder.ode_model.last_adaptive_grid.shape[0])
+    print("%s at rtol 1e-7 / atol 1e-9: %d accepted grid points" % (solver, n_grid))
+    assert torch.isfinite(x_states).all() and n_grid >= fx.t("times").shape[0]

@@ -269,3 +269,30 @@ def test_training_trace_fixture_regenerates_bit_exactly(tmp_path):
             assert str(old[k]) == str(new[k]), k
         else:
             assert np.array_equal(old[k], new[k]), k
+
+
+@pytest.mark.parametrize("solver", ["dopri5", "bosh3", "adaptive_heun"])
+def test_dependency_algorithm_steps_past_output_times_and_interpolates(solver):
+    """`odeint_adaptive`: the restatement of torchdiffeq 0.1's own adaptive driver (no clipping to the output times; the
+    quartic `_interp_fit` interpolant of the accepted step that contains an output time).  Properties of that algorithm:
+    it takes fewer accepted steps than the output grid forces on a clipped controller when the tolerance is loose; its
+    solution still meets the tolerance against a finely resolved rk4; the interpolant reproduces both ends of a step."""
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    th = fx.theta_dict()
+    rhs, x0 = O.MODEL_TABLE[fx.model][0](th, fx.t("inputs"))
+    rtol, atol = (1e-6, 1e-8) if solver == "dopri5" else (1e-4, 1e-6)
+    sol, n_acc, n_rej = O.odeint_adaptive(solver, rhs, x0, fx.t("times"), rtol, atol)
+    assert sol.shape[0] == fx.t("times").shape[0] and n_acc > 0
+    grid, _ = O.adaptive_grid(solver, rhs, x0, fx.t("times"), rtol, atol)
+    if solver == "dopri5":  # the 5th-order pair wants steps longer than the output spacing: clipping adds steps
+        assert n_acc < len(grid) - 1, (n_acc, len(grid))
+    t = fx.t("times").double()
+    fine = torch.cat([(t[:-1, None] + (t[1:, None] - t[:-1, None]) * torch.arange(16).double()[None] / 16).reshape(-1), t[-1:]])
+    th64 = {k: (v.double() if v.dtype.is_floating_point else v) for k, v in th.items()}
+    rhs64, x064 = O.MODEL_TABLE[fx.model][0](th64, fx.t("inputs").double())
+    ref = O.simulate(rhs64, x064, fine, "rk4")[..., ::16].float()
+    assert rel_err(sol.permute(1, 2, 3, 0), ref) < (5e-4 if solver == "dopri5" else 5e-3)
+    y0, y1, f0, f1 = torch.randn(3), torch.randn(3), torch.randn(3), torch.randn(3)
+    coef = O._interp_fit(y0, y1, 0.5 * (y0 + y1), f0, f1, 0.3)
+    assert torch.allclose(O._interp_evaluate(coef, 1.0, 1.3, 1.0), y0, atol=1e-6)
+    assert torch.allclose(O._interp_evaluate(coef, 1.0, 1.3, 1.3), y1, atol=1e-5)

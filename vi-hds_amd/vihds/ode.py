@@ -229,7 +229,24 @@ class OdeModel(nn.Module):
         weights = self.neural_weights()
         rtol = float(default_get_value(config.params, "solver_rtol", 1e-7))  # torchdiffeq.odeint defaults
         atol = float(default_get_value(config.params, "solver_atol", 1e-9))
-        grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol)
+        # The accepted grid lives in a caller-sized buffer: params.solver_max_grid (default 4096 points); when the controller
+        # runs out of it the buffer is doubled up to 2^17 points before giving up with a message that names the cause --
+        # all arithmetic is fp32, so tolerances near its epsilon (torchdiffeq's defaults 1e-7 / 1e-9 with a low-order pair
+        # such as adaptive_heun) ask for step sizes the state cannot resolve
+        max_grid = int(default_get_value(config.params, "solver_max_grid", 4096))
+        while True:
+            try:
+                grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol, max_grid=max_grid)
+                break
+            except RuntimeError as e:
+                if "max_grid" not in str(e) and "grid" not in str(e):
+                    raise
+                if max_grid >= (1 << 17):
+                    raise RuntimeError(
+                        "solver %r with rtol=%g, atol=%g needs more than %d accepted steps on this batch: in fp32 a relative "
+                        "tolerance below ~1e-6 is at rounding level for a low-order pair -- raise params.solver_rtol / "
+                        "solver_atol (or params.solver_max_grid)" % (config.params.solver, rtol, atol, max_grid)) from e
+                max_grid *= 4
         self.last_adaptive_grid = grid
         dummy = torch.zeros((packed.shape[1], 4, grid.shape[0]), device=dev)
         row_offset, row_offset_map = getattr(theta, "_row_offset", None) or (None, None)
