@@ -366,7 +366,7 @@ def run_workload(a, name):
         "config": {"workload": "%s (BASELINE.json %s): B=%d rows x n_iwae=%d, N=%d states, T=%d, P=%d, %s, %s"
                                % (wl, cfg_note, B, S, N, T, P, solver,
                                   "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" if mode == "train" else
-                                  "evaluation pass (forward without grad, trajectories through HBM, IW summaries on device)"),
+                                  "evaluation pass (forward without grad, trajectories through HBM, IW summaries on device; the [B,.,T] summaries, q and the ELBO are copied to the host, the theta samples [P,B,S] stay on the device until Results.theta / dump() reads them)"),
                    "name": name, "solver": solver, "n_iwae_per_gpu": s_local, "n_iwae_global": S,
                    "rows_global": B * (world if replica is not None else 1),
                    "launch": "hipGraph replay" if use_graph else "eager", "learning_rate": a.lr,

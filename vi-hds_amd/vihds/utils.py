@@ -126,7 +126,8 @@ class Results:
         self.species_names = None
         self.q_names = None
         self.q_values = None
-        self.theta = None
+        self._theta_host = None
+        self._theta_dev = None
         self.elbo = None
         self.iw_predict_mu = None
         self.iw_predict_std = None
@@ -139,10 +140,24 @@ class Results:
         # the reference's Results holds numpy arrays (utils.py:79-99): ONE device->host copy per group of tensors
         # instead of one (synchronising) copy per distribution parameter and per theta row
         self.q_values = np.array(_to_host(q.get_tensors()), dtype=object)
-        self.theta = _to_host(theta.get_tensors(), stack=True)
+        # theta [P,B,S] is by far the largest member (33 MB at 234 rows x 1000 samples: the pass's device->host copy was
+        # 80 % of its time) and only dump() / a reader of `.theta` ever looks at it: it stays on the device until then
+        self._theta_dev, self._theta_host = list(theta.get_tensors()), None
         mu, sd, st, var = summaries
         (self.elbo, self.iw_predict_mu, self.iw_predict_std, self.iw_states,
          self.iw_variance) = _to_host([elbo, mu, sd, st, var])
+
+    @property
+    def theta(self):
+        """numpy [P,B,S] as in the reference's Results (utils.py:83); copied from the device on first use."""
+        if self._theta_host is None and self._theta_dev is not None:
+            self._theta_host = _to_host(self._theta_dev, stack=True)
+            self._theta_dev = None
+        return self._theta_host
+
+    @theta.setter
+    def theta(self, value):
+        self._theta_host, self._theta_dev = value, None
 
     def dump(self, location=".vihds_cache"):
         os.makedirs(location, exist_ok=True)
