@@ -35,6 +35,22 @@ __device__ __forceinline__ float wave_sum_e(float v) {
 }
 // the same sum as a DPP scan (row_shr 1, 2, 4, 8, row_bcast 15, 31; total in lane 63, returned uniformly): six dependent
 // VALU steps instead of six ds_bpermute round trips through the LDS crossbar -- the forward kernel is a chain of such sums
+#ifdef VIHDS_TAIL_STAMPS
+// profiling build (tests/probe/enc_stamps.py): every wavefront writes the 100 MHz wall clock at each phase boundary
+static __device__ unsigned long long* vihds_enc_stamp_buf = nullptr;  // [256 blocks][16 waves][8]
+#define VIHDS_ENC_STOP(PH)                                                                          \
+  if (vihds_enc_stamp_buf && (threadIdx.x & 63) == 0 && blockIdx.x < 256)                              \
+    vihds_enc_stamp_buf[(((size_t)blockIdx.x) * 16 + (threadIdx.x >> 6)) * 8 + (PH)] = wall_clock64();
+#else
+#define VIHDS_ENC_STOP(PH)
+#endif
+// barrier for phases that hand data over through LDS only (`__syncthreads()` also drains every outstanding global load)
+__device__ __forceinline__ void enc_sync_lds() {
+  asm volatile("" ::: "memory");
+  __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0); vmcnt / expcnt untouched
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+}
 template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ float enc_dpp(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
@@ -93,6 +109,7 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   float* hid = pl + d.NPOOL;
   const int lane = tid & 63, wid = tid >> 6;
   constexpr int NW = ENC_T / 64;
+  VIHDS_ENC_STOP(0)
   // Every global read the later phases need is issued NOW, so that the kernel pays one memory round trip instead of
   // one per phase: this wave's Linear rows (4 output units x up to 12 x 64 inputs = 48 registers per lane) and its
   // head rows.  Shapes beyond those bounds take the plain loops further down.
@@ -100,32 +117,21 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   const bool fast_lin = s.H <= LIN_U * NW && d.NPOOL <= LIN_C * 64;
   const int n_dot = 2 * (s.nl + s.ng);
   const bool fast_heads = d.NX <= 64 && d.NG <= 64 && n_dot <= HEAD_R * NW;
-  float lw[LIN_U][LIN_C], hw[HEAD_R], lb[LIN_U];
-  if (fast_lin) {
-#pragma unroll
-    for (int u = 0; u < LIN_U; ++u) {
-      const int j = wid + u * NW;
-      lb[u] = (j < s.H) ? lin_b[j] : 0.f;
-#pragma unroll
-      for (int c = 0; c < LIN_C; ++c) {
-        const int k = lane + 64 * c;
-        lw[u][c] = (j < s.H && k < d.NPOOL) ? lin_w[(size_t)j * d.NPOOL + k] : 0.f;
-      }
-    }
+  // inputs -> LDS.  First pass of every staging loop through registers: all its loads are requested before the first LDS
+  // store (a plain `lds[q] = global[q]` loop is a load -> wait -> store round trip of its own; three of them in a row
+  // were 1.5 us of this kernel), then the rare further passes.
+  {
+    const int nx = s.C_in * s.L, ncw = s.F * s.C_in * s.K;
+    const float rx = delta_obs[(size_t)b * nx + min(tid, nx - 1)];
+    const float rcw = conv_w[min(tid, ncw - 1)];
+    const float rcb = conv_b[min(tid, s.F - 1)];
+    if (tid < nx) x[tid] = rx;
+    if (tid < ncw) cw[tid] = rcw;
+    if (tid < s.F) cb[tid] = rcb;
+    for (int q = tid + ENC_T; q < nx; q += ENC_T) x[q] = delta_obs[(size_t)b * nx + q];
+    for (int q = tid + ENC_T; q < ncw; q += ENC_T) cw[q] = conv_w[q];
+    for (int q = tid + ENC_T; q < s.F; q += ENC_T) cb[q] = conv_b[q];
   }
-  if (fast_heads) {
-#pragma unroll
-    for (int rr = 0; rr < HEAD_R; ++rr) {
-      const int r = wid + rr * NW;
-      float w = 0.f;
-      if (r < 2 * s.nl) { if (lane < d.NX) w = local_w[(size_t)r * d.NX + lane]; }
-      else if (r < n_dot) { if (lane < d.NG) w = gcond_w[(size_t)(r - 2 * s.nl) * d.NG + lane]; }
-      hw[rr] = w;
-    }
-  }
-  for (int q = tid; q < s.C_in * s.L; q += ENC_T) x[q] = delta_obs[(size_t)b * s.C_in * s.L + q];
-  for (int q = tid; q < s.F * s.C_in * s.K; q += ENC_T) cw[q] = conv_w[q];
-  for (int q = tid; q < s.F; q += ENC_T) cb[q] = conv_b[q];
   // rows of the table that are plain copies (global free scalars, constants, zeros): nothing to wait for, written now
   {
     const int n_rows_all = 2 * (s.nl + s.ng + s.ngl + s.nc), n_dot0 = 2 * (s.nl + s.ng);
@@ -144,35 +150,122 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   // after the last barrier (as loads in the head phase they were one more memory round trip at the kernel's tail)
   float xl_pre = 0.f, xg_pre = 0.f, hb[HEAD_R] = {0.f, 0.f, 0.f, 0.f};
   if (fast_heads) {
-    if (lane >= s.H && lane < d.NX) xl_pre = local_input(s, nullptr, inputs, dev1hot, b, lane);
-    if (lane < d.NG) xg_pre = gcond_input(s, inputs, dev1hot, b, lane);
+    // (pointers selected, loads unconditional, values selected afterwards)
+    const float* pl_ = lin_b;
+    if (lane >= s.H && lane < d.NX) {
+      int i = lane - s.H;
+      if (s.l_tr && i < s.n_tr) pl_ = inputs + b * s.n_tr + i;
+      else pl_ = dev1hot + b * s.D + (i - (s.l_tr ? s.n_tr : 0));
+    }
+    const float* pg_ = lin_b;
+    if (lane < d.NG) {
+      if (s.g_tr && lane < s.n_tr) pg_ = inputs + b * s.n_tr + lane;
+      else pg_ = dev1hot + b * s.D + (lane - (s.g_tr ? s.n_tr : 0));
+    }
+    const float vl = *pl_, vg = *pg_;
+    float hbv[HEAD_R];
 #pragma unroll
     for (int rr = 0; rr < HEAD_R; ++rr) {
       const int r = wid + rr * NW;
-      if (r < 2 * s.nl && local_b) hb[rr] = local_b[r];
+      hbv[rr] = *((r < 2 * s.nl && local_b) ? local_b + r : lin_b);
+    }
+    xl_pre = (lane >= s.H && lane < d.NX) ? vl : 0.f;
+    xg_pre = lane < d.NG ? vg : 0.f;
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) hb[rr] = (wid + rr * NW < 2 * s.nl && local_b) ? hbv[rr] : 0.f;
+  }
+  // The block's big load -- this wavefront's Linear rows, 48 values per lane, 144 KB per block -- is requested only NOW,
+  // behind the waits of the small loads above and ahead of barriers that do not wait for it (enc_sync_lds): it lands
+  // while the convolution and the pooling run.  (Requested first, every barrier's vmcnt(0) made the conv wait for it.)
+  float hw[HEAD_R];
+  if (fast_heads) {
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) {
+      // (one unconditional load through a selected pointer each, all four requested before any is looked at: under nested
+      // branches every one of them was a memory round trip of its own; rows / lanes that do not exist read lin_b[0])
+      const int r = wid + rr * NW;
+      const bool is_l = r < 2 * s.nl, is_g = !is_l && r < n_dot;
+      const float* wp = lin_b;
+      if (is_l && lane < d.NX) wp = local_w + (size_t)r * d.NX + lane;
+      if (is_g && lane < d.NG) wp = gcond_w + (size_t)(r - 2 * s.nl) * d.NG + lane;
+      hw[rr] = *wp;
+    }
+#pragma unroll
+    for (int rr = 0; rr < HEAD_R; ++rr) {
+      const int r = wid + rr * NW;
+      const bool is_l = r < 2 * s.nl, is_g = !is_l && r < n_dot;
+      if (!((is_l && lane < d.NX) || (is_g && lane < d.NG))) hw[rr] = 0.f;
     }
   }
-  __syncthreads();
+  VIHDS_ENC_STOP(1)
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  VIHDS_ENC_STOP(2)
+  float lw[LIN_U][LIN_C], lb[LIN_U];
+  auto load_unit = [&](int u) {  // this wavefront's Linear row u: 12 loads per lane + its bias
+    // (unconditional, clamped addresses and NO select behind them: a column past the pooled vector meets pv = 0 below and
+    // a row past H is never written out -- a load under a branch gets a wait at the join, a select behind every load
+    // serialises the batch)
+    const int j = min(wid + u * NW, s.H - 1);
+    lb[u] = lin_b[j];
+#pragma unroll
+    for (int c = 0; c < LIN_C; ++c) lw[u][c] = lin_w[(size_t)j * d.NPOOL + min(lane + 64 * c, d.NPOOL - 1)];
+  };
+  enc_sync_lds();
+  VIHDS_ENC_STOP(3)
   // Conv1d (cross-correlation, no padding): out[o][t] = bias[o] + sum_c sum_k w[o][c][k] x[c][t+k]
-  for (int q = tid; q < s.F * d.Lc; q += ENC_T) {
-    const int o = q / d.Lc, t = q - o * d.Lc;
-    // two accumulators and an unrolled tap loop: the LDS reads of several taps are in flight together (as one
-    // dependent chain of C_in*K = 40 read-read-FMA steps this phase took 1.75 us)
+  // The block's big load (the Linear rows: 144 KB) is issued IN BETWEEN the convolution's input channels: issuing 52 loads
+  // per lane back to back keeps a wavefront waiting on the load queue for ~2.5 us (stamps: tests/probe/enc_stamps.py)
+  // while the convolution needs LDS and VALU only -- one row's 13 loads, one channel's taps, and so on.
+  const bool interleave = fast_lin && s.F * d.Lc <= ENC_T && s.C_in <= LIN_U;
+  if (interleave) {
+    const int q = tid;
+    const bool has = q < s.F * d.Lc;
+    const int o = has ? q / d.Lc : 0, t = has ? q - o * d.Lc : 0;
     float acc0 = cb[o], acc1 = 0.f;
-    for (int c = 0; c < s.C_in; ++c) {
-      const float* wr = cw + (o * s.C_in + c) * s.K;
-      const float* xr = x + c * s.L + t;
-      int k = 0;
+#pragma unroll
+    for (int c = 0; c < LIN_U; ++c) {
+      load_unit(c);
+      asm volatile("" ::: "memory");
+      if (c < s.C_in) {
+        const float* wr = cw + (o * s.C_in + c) * s.K;
+        const float* xr = x + c * s.L + t;
+        int k = 0;
 #pragma unroll 5
-      for (; k + 1 < s.K; k += 2) {
-        acc0 += wr[k] * xr[k];
-        acc1 += wr[k + 1] * xr[k + 1];
+        for (; k + 1 < s.K; k += 2) {
+          acc0 += wr[k] * xr[k];
+          acc1 += wr[k + 1] * xr[k + 1];
+        }
+        if (k < s.K) acc0 += wr[k] * xr[k];
       }
-      if (k < s.K) acc0 += wr[k] * xr[k];
+      asm volatile("" ::: "memory");
     }
-    cv[q] = acc0 + acc1;
+    if (has) cv[q] = acc0 + acc1;
+  } else {
+    if (fast_lin) {
+#pragma unroll
+      for (int u = 0; u < LIN_U; ++u) load_unit(u);
+    }
+    for (int q = tid; q < s.F * d.Lc; q += ENC_T) {
+      const int o = q / d.Lc, t = q - o * d.Lc;
+      // two accumulators and an unrolled tap loop: the LDS reads of several taps are in flight together (as one
+      // dependent chain of C_in*K = 40 read-read-FMA steps this phase took 1.75 us)
+      float acc0 = cb[o], acc1 = 0.f;
+      for (int c = 0; c < s.C_in; ++c) {
+        const float* wr = cw + (o * s.C_in + c) * s.K;
+        const float* xr = x + c * s.L + t;
+        int k = 0;
+#pragma unroll 5
+        for (; k + 1 < s.K; k += 2) {
+          acc0 += wr[k] * xr[k];
+          acc1 += wr[k + 1] * xr[k + 1];
+        }
+        if (k < s.K) acc0 += wr[k] * xr[k];
+      }
+      cv[q] = acc0 + acc1;
+    }
   }
-  __syncthreads();
+  enc_sync_lds();
+  VIHDS_ENC_STOP(4)
   // AvgPool1d(pool, stride 1)
   const float inv_pool = 1.f / (float)s.pool;
   for (int q = tid; q < d.NPOOL; q += ENC_T) {
@@ -183,7 +276,8 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
     pl[q] = v;
     pooled_out[(size_t)b * d.NPOOL + q] = v;
   }
-  __syncthreads();
+  enc_sync_lds();
+  VIHDS_ENC_STOP(5)
   // Linear + tanh: a wave owns output units j = wid, wid+16, ...; lanes stride over the inputs
   if (fast_lin) {
     float acc[LIN_U] = {0.f, 0.f, 0.f, 0.f};
@@ -227,7 +321,8 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
       }
     }
   }
-  __syncthreads();
+  enc_sync_lds();
+  VIHDS_ENC_STOP(6)
   // heads -> rows of the level-blocked table [local mu; local lp; gcond mu; gcond lp; global mu; global lp; const; 0]
   // rows with a dot product: one wave per row (lanes over the inputs); the rest are copies
   if (fast_heads) {
@@ -255,6 +350,7 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
       if (lane == 0) q_all[(size_t)r * B + b] = acc + ((r < 2 * s.nl && local_b) ? local_b[r] : 0.f);
     }
   }
+  VIHDS_ENC_STOP(7)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -487,3 +583,8 @@ void launch_encoder_bwd(const vihds_encoder_shape& s, const float* g_all, const 
 }
 
 }  // namespace vihds
+#ifdef VIHDS_TAIL_STAMPS
+extern "C" int vihds_debug_enc_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vihds::vihds_enc_stamp_buf), &buf, sizeof(buf));
+}
+#endif
