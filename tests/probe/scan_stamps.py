@@ -41,8 +41,8 @@ st = buf.cpu().numpy().reshape(nblk, nw, 16).astype(np.float64)
 t0 = st[:, :, 0].min()
 us = (st - t0) / 100.0  # 100 MHz
 us[st == 0] = np.nan
-order = [0, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8, 9, 13, 10]
-names = {0: "start", 11: "own work: chain (wave 0) / hill, conditioner", 12: "barrier B", 1: "(sampling stage,) sigmoid table, barrier",
+order = [0, 14, 15, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8, 9, 13, 10]
+names = {0: "start", 14: "requests, row indirection, draws", 15: "sampling arithmetic, stores", 11: "own work: chain (wave 0) / hill, conditioner", 12: "barrier B", 1: "(sampling stage,) sigmoid table, barrier",
          2: "gamma pass, barrier C", 3: "parameters", 4: "level-1 maps + scan", 5: "level-1 steps, level-2 maps + scan",
          6: "log-likelihood", 7: "adjoint level 2", 8: "adjoint level 1", 9: "adjoint x", 13: "epilogue barrier", 10: "epilogue (end)"}
 print("launch: first start 0, last end %.1f us; %d blocks x %d waves" % (np.nanmax(us[:, :, 10]), nblk, nw))
@@ -65,16 +65,3 @@ for ph in order[1:]:
             print("      wave %d own work: median %5.2f  max %5.2f" % (w, np.nanmedian(d[:, w]), np.nanmax(d[:, w])))
     prev = ph
 
-hw = buf.cpu().numpy().reshape(nblk, nw, 16)[:, :, 14]
-lds_alloc = buf.cpu().numpy().reshape(nblk, nw, 16)[:, :, 15]
-simd = (hw >> 4) & 3
-slot = hw & 15
-cu = (hw >> 8) & 15
-sh = (hw >> 12) & 1
-se = (hw >> 13) & 7
-print("simd id of waves 0..3, first 12 blocks:", simd[:12].tolist())
-print("wave slot of waves 0..3, first 12 blocks:", slot[:12].tolist())
-print("lds base (blocks 0..11, wave 0):", (lds_alloc[:12, 0] & 0xff).tolist())
-import collections
-print("simd-of-wave-0 histogram:", collections.Counter(simd[:, 0].tolist()))
-print("all waves: simd == wave index? %.3f" % (simd == np.arange(nw)[None, :]).mean())

@@ -310,6 +310,7 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 constexpr int DR_SCAN_TPB = VIHDS_SCAN_TPB;  // trajectories per block: 2 per wavefront, 32 lanes each
 constexpr int DR_SCAN_THREADS = 32 * DR_SCAN_TPB;
+static_assert(DR_SCAN_THREADS % 64 == 0 && DR_SCAN_THREADS >= 128, "the x chains run in wavefront 0 beside at least one other wavefront");
 constexpr int DR_SCAN_CHAIN_LANES = 64 / DR_SCAN_TPB;  // lanes of wavefront 0 that walk one trajectory's x chain
 // Block barrier for data exchanged through LDS: waits for this wavefront's LDS operations only.  (__syncthreads() also
 // waits for every outstanding global store and returning atomic -- a full memory round trip on the critical path of the
@@ -329,7 +330,7 @@ constexpr int DR_SCAN_NACC = 32;       // accumulators summed over the time axis
 template <int SOLVER>
 __host__ __device__ inline size_t dr_scan_lds_floats(int items) {
   const size_t steps = (size_t)(3 * Rk<SOLVER>::NS + 14) * items * DR_SCAN_THREADS;
-  const size_t red = (size_t)DR_SCAN_NACC * DR_SCAN_THREADS + DR_SCAN_TPB * DR_SCAN_NACC;
+  const size_t red = (size_t)DR_SCAN_NACC * DR_SCAN_THREADS + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64;
   return (steps > red ? steps : red) + (size_t)(32 * items + 4) + DR_SCAN_TPB;
 }
 #define VIHDS_ROLLED _Pragma("clang loop unroll(disable)")
@@ -380,7 +381,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   // per-lane vector fields: field of width W, step m of thread t at base + (m * NT + t) * W
   constexpr int O_G = 0, O_U = O_G + NS * ITEMS * NT, O_B = O_U + NS * ITEMS * NT, O_Q = O_B + NS * ITEMS * NT,
                 O_Y = O_Q + 4 * ITEMS * NT, O_Z = O_Y + 4 * ITEMS * NT, O_A = O_Z + 2 * ITEMS * NT,
-                O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC,
+                O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64,
                 O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4;
   auto VG = [&](int m) { return lds + O_G + (m * NT + tid) * NS; };
   // (the stage values of x are written by the chain wavefront, for all trajectories of the block at once: a trajectory's
@@ -406,24 +407,33 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   VIHDS_SCAN_STOP(0)
   if (vihds_scan_stamp_buf && lane == 0) {
     unsigned long long* sb = vihds_scan_stamp_buf + ((size_t)blockIdx.x * (DR_SCAN_THREADS / 64) + wave) * 16;
-    sb[14] = __builtin_amdgcn_s_getreg((4 /*HW_ID*/) | (0 << 6) | (31 << 11));
-    sb[15] = __builtin_amdgcn_s_getreg((6 /*LDS_ALLOC*/) | (0 << 6) | (31 << 11));
   }
 #endif
-  // ---- 0. the time grid -> LDS; this lane's observations -> VQ (their latency hides behind the parameter stage) ------
+  // ---- 0. Every global load of the block's first stage is requested HERE, as one batch, before anything waits for any
+  //         of them: the stage is a chain of memory round trips (about 1 us each), not arithmetic, and a `lds[k] =
+  //         global[k]` loop or a load under a branch makes the wavefront sit out a whole round trip by itself
+  //         (s_waitcnt vmcnt(0) inside the loop / at the join).  Order: the q_rows indirection first -- q_mu / q_prec behind
+  //         it are the only dependent pair --, then the time grid, the observations, the treatments, the prior's
+  //         constants and the conditioner's inputs; the first pass of every staging loop is an unconditional load from a
+  //         clamped index whose value is dropped by the lanes that are past the end.
   const int k0 = l * ITEMS;
   const float* ob = a.obs + (size_t)b * 4 * a.T;
-  for (int k = tid; k < a.T; k += NT) tT[k] = a.times[k];
+  constexpr int TW = DR_SCAN_THREADS / 64 >= 3 ? 2 : DR_SCAN_THREADS / 64 - 1;  // the wavefront that takes the tickets
+  int q_raw[2][2] = {{0, 0}, {0, 0}}, pqc[2] = {0, 0};
+  if (THETA) {
+    const int* qr = t.q_rows ? t.q_rows : t.kind;  // (no table: rows in parameter order; the loads stay in bounds)
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      pqc[q] = min(l + 32 * q, t.P - 1);
+      q_raw[q][0] = qr[t.q_rows ? pqc[q] : 0];
+      q_raw[q][1] = qr[t.q_rows ? t.P + pqc[q] : 0];
+    }
+  }
+  const float t_mine = a.times[min(tid, a.T - 1)];
+  float o_in[ITEMS][4], obK[4];
   VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
     const int kc = min(k0 + m, K - 1);
-    float o[4];
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) o[j] = ob[j * a.T + kc];
-    stv<4>(VQ(m), o);
-    float half_[NS];
-    VIHDS_UNROLL for (int s = 0; s < NS; ++s) half_[s] = 0.5f;
-    stv<NS>(VU(m), half_);  // (padding steps beyond T-1 keep this harmless value; the chain fills the real ones)
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) o_in[m][j] = ob[j * a.T + kc];
   }
-  float obK[4];
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) obK[j] = ob[j * a.T + K];
   // the treatments of this lane's trajectory and of the one two places down (wavefront 1 evaluates the Hill terms of
   // wavefront 0's trajectories), and the conditioner generator's state: fetched here, used after the first barrier
@@ -433,10 +443,24 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     cond_raw[q][0] = a.cond[bb * a.C + 0];
     cond_raw[q][1] = a.cond[bb * a.C + 1];
   }
+  // the theta rows this lane writes the gradients of in the epilogue (slots l and l + 32)
+  int out_row[2];
+  VIHDS_UNROLL for (int q = 0; q < 2; ++q) out_row[q] = a.slot_row[min(l + 32 * q, M::NSLOT + 3)];
   unsigned int ck0 = 0u, ck1 = 0u, cstep = 0u;
   if (THETA && t.crng) { ck0 = t.crng[0]; ck1 = t.crng[1]; cstep = t.crng[2]; }
   RngTickets tk = {0u, 0u};
+  auto stage_grid_and_observations = [&]() {
+    if (tid < a.T) tT[tid] = t_mine;
+    VIHDS_ROLLED for (int k = tid + NT; k < a.T; k += NT) tT[k] = a.times[k];
+    VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
+      stv<4>(VQ(m), o_in[m]);
+      float half_[NS];
+      VIHDS_UNROLL for (int s = 0; s < NS; ++s) half_[s] = 0.5f;
+      stv<NS>(VU(m), half_);  // (padding steps beyond T-1 keep this harmless value; the chain fills the real ones)
+    }
+  };
   if (!THETA) {
+    stage_grid_and_observations();
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const int slot = l + 32 * q;
       if (slot < M::NSLOT + 4) {
@@ -457,16 +481,42 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     float c_mu[2], c_pr[2], c_pp[2], c_lo[2], c_hi[2], c_pmu[2], uu[2] = {0.f, 0.f};
     int c_kd[2];
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-      const int pq = min(l + 32 * q, P - 1);
-      const int rm = t.q_rows ? t.q_rows[pq] : pq, rp = t.q_rows ? t.q_rows[P + pq] : pq;
+      const int pq = pqc[q];
       c_kd[q] = t.kind[pq];
       c_pp[q] = t.p_prec[pq];
       c_lo[q] = t.clip_lo[pq];
       c_hi[q] = t.clip_hi[pq];
       c_pmu[q] = t.p_mu[pq];
+    }
+    if (!t.rng) {
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) uu[q] = t.u[(size_t)i * P + pqc[q]];
+    }
+    // the conditioner's inputs for this block (relevance masks, default flags, the device one-hot rows its tiling
+    // selects: row (b S_total + s) mod B for sample (b, s)) -> LDS, for the wavefront that evaluates it later
+    float* t_rel = lds + O_G;                      // [E][D]   (the VG area is free until the gamma pass)
+    float* t_dev = t_rel + t.E * a.D;              // [TPB][D]
+    float* t_dfl = t_dev + DR_SCAN_TPB * a.D;      // [E]
+    const bool cnd = t.E > 0;
+    const int Dd = max(a.D, 1), ed = max(t.E * a.D, 1), td = DR_SCAN_TPB * Dd;
+    auto dev_row = [&](int e) {  // element e of the block's [TPB][D] one-hot rows: its address in dev1hot
+      const int tt = e / Dd, d = e - tt * Dd;
+      const int it = min(blockIdx.x * DR_SCAN_TPB + tt, a.n - 1), bt = it / a.S;
+      // (b S_total + s < B S_total = the number of samples of the whole job: it fits 32 bits, as a.n does)
+      const unsigned int rr = ((unsigned int)bt * (unsigned int)t.S_total + (unsigned int)(t.s_off + (it - bt * a.S))) % (unsigned int)B;
+      return (int)(__umul24(rr, (unsigned int)Dd) + (unsigned int)d);  // (24-bit factors: checked by the launcher)
+    };
+    // (no conditioner: the same loads from addresses that exist, so that nothing here sits under a branch)
+    const float* relp = cnd ? t.rel : a.times;
+    const float* devp = cnd ? a.dev1hot : a.times;
+    const int* dflp = cnd ? t.is_default : t.kind;
+    const float pre_rel = relp[cnd ? min(tid, ed - 1) : 0];
+    const float pre_dev = devp[cnd ? dev_row(min(tid, td - 1)) : 0];
+    int pre_dfl = dflp[cnd ? min(tid, t.E - 1) : 0];
+    // (the dependent pair: the rows of mu_p / log-precision_p in the encoder's table)
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int rm = t.q_rows ? q_raw[q][0] : pqc[q], rp = t.q_rows ? q_raw[q][1] : pqc[q];
       c_mu[q] = t.q_mu[rm * B + b];
       c_pr[q] = t.q_prec[rp * B + b];
-      if (!t.rng && l + 32 * q < P) uu[q] = t.u[(size_t)i * P + pq];
     }
     if (t.rng) {
       // one generator call per wavefront: lane l < ceil(P / 4) draws the four normals of parameter block l (counter =
@@ -481,53 +531,62 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       VIHDS_UNROLL for (int q = 0; q < 2; ++q)
         if (l + 32 * q < P) uu[q] = zb[l + 32 * q];
     }
-    // the conditioner's inputs for this block (relevance masks, default flags, the device one-hot rows its tiling
-    // selects: row (b S_total + s) mod B for sample (b, s)) -> LDS, for the wavefront that evaluates it later
-    float* t_rel = lds + O_G;                      // [E][D]   (the VG area is free until the gamma pass)
-    float* t_dev = t_rel + t.E * a.D;              // [TPB][D]
-    float* t_dfl = t_dev + DR_SCAN_TPB * a.D;      // [E]
-    if (t.E > 0) {
-      for (int e = tid; e < t.E * a.D; e += NT) t_rel[e] = t.rel[e];
-      for (int e = tid; e < DR_SCAN_TPB * a.D; e += NT) {
-        const int tt = e / a.D, d = e - tt * a.D;
-        const int it = min(blockIdx.x * DR_SCAN_TPB + tt, a.n - 1), bt = it / a.S;
-        const int rr = (int)(((long long)bt * t.S_total + t.s_off + (it - bt * a.S)) % B);
-        t_dev[e] = a.dev1hot[rr * a.D + d];
-      }
-      for (int e = tid; e < t.E; e += NT) t_dfl[e] = t.is_default[e] ? 1.f : 0.f;
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(14)
+#endif
+    stage_grid_and_observations();
+    if (cnd) {
+      asm volatile("" : "+v"(pre_dfl));  // (keeps the flag's comparison here, behind the requests above)
+      if (tid < ed) t_rel[tid] = pre_rel;
+      if (tid < td) t_dev[tid] = pre_dev;
+      if (tid < t.E) t_dfl[tid] = pre_dfl ? 1.f : 0.f;
+      VIHDS_ROLLED for (int e = tid + NT; e < ed; e += NT) t_rel[e] = t.rel[e];
+      VIHDS_ROLLED for (int e = tid + NT; e < td; e += NT) t_dev[e] = a.dev1hot[dev_row(e)];
+      VIHDS_ROLLED for (int e = tid + NT; e < t.E; e += NT) t_dfl[e] = t.is_default[e] ? 1.f : 0.f;
     }
-    float lq = 0.f, lp = 0.f;
+    float lq = 0.f, lp = 0.f, xo[2] = {0.f, 0.f};
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-      const int pq = l + 32 * q;
-      if (pq < P) {
-        const bool cst = c_kd[q] == KIND_CONSTANT, ln = c_kd[q] == KIND_LOGNORMAL;
-        const float prc = cst ? 1.f : (t.prec_is_log ? expf(c_pr[q]) : c_pr[q]);
-        const float sigma = 1.f / sqrtf(prc);
-        const float cq = -LOG2PI + 0.5f * logf(prc + 1e-12f), cp = -LOG2PI + 0.5f * logf(c_pp[q] + 1e-12f);
-        const float mu = c_mu[q];
-        if (t.rng && live) t.u[(size_t)i * P + pq] = uu[q];
-        const float zz = mu + sigma * uu[q];
-        float x = ln ? expf(zz) : zz;
-        x = x < c_lo[q] ? c_lo[q] : (x > c_hi[q] ? c_hi[q] : x);
-        const float v = ln ? logf(x + 1e-12f) : x;
-        const float jac = ln ? v : 0.f;
-        const float dq = mu - v, dp = c_pmu[q] - v;
-        const float tq = cq - 0.5f * prc * dq * dq - jac;
-        const float tp = cp - 0.5f * c_pp[q] * dp * dp - jac;
-        lq += cst ? 0.f : tq;
-        lp += cst ? 0.f : tp;
-        x = cst ? 0.f * uu[q] + mu : x;
-        if (live) t.theta[(size_t)pq * n + i] = x;
-        par[pq] = x;
-      }
+      const bool cst = c_kd[q] == KIND_CONSTANT, ln = c_kd[q] == KIND_LOGNORMAL;
+      // (v_exp_f32 / v_log_f32 / v_rsq_f32, 1 ulp: the libm sequences of these six calls were ~300 instructions of a
+      // stage every wavefront of the block goes through before the x chains can start)
+      const float prc = cst ? 1.f : (t.prec_is_log ? __expf(c_pr[q]) : c_pr[q]);
+      const float sigma = __builtin_amdgcn_rsqf(prc);
+      const float cq = -LOG2PI + 0.5f * __logf(prc + 1e-12f), cp = -LOG2PI + 0.5f * __logf(c_pp[q] + 1e-12f);
+      const float mu = c_mu[q];
+      const float zz = mu + sigma * uu[q];
+      float x = ln ? __expf(zz) : zz;
+      x = x < c_lo[q] ? c_lo[q] : (x > c_hi[q] ? c_hi[q] : x);
+      const float v = ln ? __logf(x + 1e-12f) : x;
+      const float jac = ln ? v : 0.f;
+      const float dq = mu - v, dp = c_pmu[q] - v;
+      const float tq = cq - 0.5f * prc * dq * dq - jac;
+      const float tp = cp - 0.5f * c_pp[q] * dp * dp - jac;
+      const bool on = l + 32 * q < P && !cst;
+      lq += on ? tq : 0.f;
+      lp += on ? tp : 0.f;
+      xo[q] = cst ? 0.f * uu[q] + mu : x;
+      if (l + 32 * q < P) par[l + 32 * q] = xo[q];
     }
     lq = sum32(lq, lane);
     lp = sum32(lp, lane);
+    // Everything this stage asked memory for has been consumed: from here on the wavefront only stores (a wait for a
+    // load issued before a store would also wait for the store's acknowledgement -- loads and stores share vmcnt).
+    __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int pq = l + 32 * q;
+      if (live && pq < P) {
+        if (t.rng) t.u[(size_t)i * P + pq] = uu[q];
+        t.theta[(size_t)pq * n + i] = xo[q];
+      }
+    }
     if (live && l == 0) {
       if (t.log_q) t.log_q[i] = lq;
       if (t.log_p) t.log_p[i] = lp;
     }
     wave_sync();  // this trajectory's theta rows are in `par` (its own lanes wrote them)
+#ifdef VIHDS_SCAN_STAMPS
+    VIHDS_SCAN_STOP(15)
+#endif
   }
   const float r = clampf(th(M::S_r), 0.f, 4.f), tlag = th(M::S_tlag);
   const float h0 = tT[1] - tT[0];
@@ -649,6 +708,15 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     c[1] = clampf(expf(cond_raw[q][1]) - 1.f, 1e-12f, 1e6f);
   };
   if (wave != 0) {
+    // Every thread of the block read the generators' step counters before the barrier above (scalar loads, complete at its
+    // lgkmcnt(0)), so the block may take its tickets: the wavefront with the least to do until the chains are through
+    // does, and the atomics' round trips (the compiler waits for a returning atomic at the end of the branch) fall
+    // into its wait for barrier B.  The holder of the last ticket advances the step at the very end of the kernel
+    // (rng_advance; see dr_lane_theta_stage).
+    if (THETA && tid == TW * 64) {
+      if (t.rng) tk.u = atomicAdd(&t.rng[3], 1u);
+      if (t.crng) tk.c = atomicAdd(&t.crng[3], 1u);
+    }
     VIHDS_ROLLED for (int pass = 0; pass < (wave == 1 ? 2 : 1); ++pass) {
       const int tp = pass == 0 ? tib : tib - 2;
       float* pp = par_of(tp);
@@ -727,11 +795,6 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     gamma_pass();
     block_sync_lds();
   }
-  // Every thread of the block has read the generators' step counters long ago: the block takes its tickets here, behind
-  // its last barrier before the epilogue (a barrier would wait for the atomics' round trips), and the holder of the last
-  // ticket advances the step at the very end of the kernel (rng_advance; see dr_lane_theta_stage).
-  if (THETA && t.rng && tid == 0) tk.u = atomicAdd(&t.rng[3], 1u);
-  if (THETA && t.crng && tid == DR_SCAN_THREADS - 64) tk.c = atomicAdd(&t.crng[3], 1u);
   VIHDS_SCAN_STOP(2)
 
   // ---- parameters of this trajectory (every lane of its 32 holds them) -----------------------------------------
@@ -1131,7 +1194,14 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   // ---- epilogue: sums over the time axis through LDS (lane a of a trajectory adds up accumulator a), raw accumulators
   //      -> gradients of the theta rows ------------------------------------------------------------------------------------
   {
-    auto put = [&](int slot, float v) { a.g_theta[(size_t)a.slot_row[slot] * n + i] = v; };
+    // The gradients leave through LDS: lane 0 of the trajectory lays them out in slot order (constant offsets), then lane
+    // l stores slots l and l + 32 -- two store instructions per wavefront instead of one per slot with two lanes at work.
+    unsigned long long put_mask = 0ull;
+    float* gout = lds + DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC + tib * 64;  // [TPB][64], behind `tot`
+    auto put = [&](int slot, float v) {
+      gout[slot] = v;
+      put_mask |= 1ull << slot;
+    };
     float acc[DR_SCAN_NACC];
     VIHDS_UNROLL for (int j = 0; j < NSP; ++j) { acc[j] = sv[j]; acc[6 + j] = degb[j]; }
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) { acc[12 + q] = svt[q]; acc[14 + q] = svr[q]; acc[16 + q] = c1b[q]; acc[18 + q] = c2b[q]; }
@@ -1170,7 +1240,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     const float fRb = c1b[0] * pKR[0] + c1b[1] * pKR[1], fSb = c2b[0] * pKS[0] + c2b[1] * pKS[1];
     const float rcb = sv[RFP] + sv[WW] + sv[LUXR] * aR + sv[LASR] * aS + cbar[0] * aY + cbar[1] * aC;
     const typename D::HillAdj HA = D::hill_vjp_pass(l & 7, c, H, fRb, fSb, pass_h);
-    if (live && l == 0) {  // (the initial-state adjoints sit in lane 0 of the trajectory)
+    if (l == 0) {  // (the initial-state adjoints sit in lane 0 of the trajectory)
       put(M::SI + 0, lamx);
       put(M::SI + 1, lam0[RFP]); put(M::SI + 2, lam0[YFP]); put(M::SI + 3, lam0[CFP]);
       put(M::SI + 4, lam0[LUXR]); put(M::SI + 5, lam0[LASR]);
@@ -1192,10 +1262,17 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       put(M::S_nR, HA.nR); put(M::S_nS, HA.nS); put(M::S_H0, HA.H0); put(M::S_H1, HA.H1);
       if (VERSION == 1) { put(M::S_H2, HA.H2); put(M::S_H3, HA.H3); }
     }
+    put_mask = (unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)put_mask) |
+               ((unsigned long long)(unsigned int)__builtin_amdgcn_readfirstlane((int)(unsigned int)(put_mask >> 32)) << 32);
+    wave_sync();
+    VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
+      const int slot = l + 32 * q;
+      if (live && ((put_mask >> slot) & 1ull)) a.g_theta[(size_t)out_row[q] * n + i] = gout[slot];
+    }
   }
   if (THETA) {
-    rng_advance(t.rng, tk.u, 0);
-    rng_advance(t.crng, tk.c, DR_SCAN_THREADS - 64);
+    rng_advance(t.rng, tk.u, TW * 64);
+    rng_advance(t.crng, tk.c, TW * 64);
   }
 #ifdef VIHDS_SCAN_STAMPS
   VIHDS_SCAN_STOP(10)
@@ -1226,6 +1303,7 @@ inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st, co
   if (ts) {
     if (ts->P > 64 || ts->n_rows > 64 || ts->E > 32) return VIHDS_E_UNSUPPORTED;
     if (dr_scan_theta_floats(ts->E, a.D) > (size_t)items * DR_SCAN_THREADS) return VIHDS_E_UNSUPPORTED;
+    if (a.B >= (1 << 24) || a.D >= (1 << 24)) return VIHDS_E_UNSUPPORTED;
   }
   for (int q = 0; q < DrConstant<VERSION>::NSLOT + 4; ++q)
     if (a.slot_row[q] >= 64) return VIHDS_E_UNSUPPORTED;
