@@ -35,6 +35,9 @@ struct BbMfma {
   using BB = Blackbox<2, 25, 20, 5, 5, 2>;
   static constexpr int NX = 6, HS = 25, HP = 20, NLAT = 12;
   static constexpr int TPW = 16, TPB = 64;  // trajectories per wave / per 256-thread block
+  // adjoint with on-chip weight gradients: a block is GMAINS main wavefronts (16 trajectories each) + as many helpers
+  static constexpr int GMAINS = 2, GTPB = GMAINS * TPW;
+  __host__ __device__ static int gram_groups(int n) { return ((n + GTPB - 1) / GTPB) * GMAINS; }
   static constexpr int KS = 7, KP = 5;      // second-layer K-steps (states, precisions)
 
   __device__ static f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -240,16 +243,6 @@ struct BbMfma {
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   }
-  __device__ __forceinline__ static f32x4 to_rows(float* buf, const f32x4& t, int lane) {
-    const int j = lane & 15, q = lane >> 4;
-    lds_fence();
-    *reinterpret_cast<f32x4*>(buf + j * GT_LD + 4 * q) = t;  // column j (a trajectory), rows 4q .. 4q+3
-    lds_fence();
-    f32x4 o;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = buf[(4 * s + q) * GT_LD + j];  // row (lane & 15), trajectory 4s + (lane >> 4)
-    return o;
-  }
   __device__ __forceinline__ static void put_cols(float* buf, const f32x4& t, int lane) {
     *reinterpret_cast<f32x4*>(buf + (lane & 15) * GT_LD + 4 * (lane >> 4)) = t;
   }
@@ -262,6 +255,36 @@ struct BbMfma {
   __device__ __forceinline__ static void gram_acc(f32x4& G, const f32x4& X, const f32x4& Y) {
 #pragma unroll
     for (int s = 0; s < 4; ++s) G = mfma(X[s], Y[s], G);
+  }
+  // workgroup barrier for data handed over through LDS (waits for this wavefront's LDS operations only: the main
+  // wavefronts keep their global prefetches in flight across it)
+  __device__ __forceinline__ static void pair_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // The helper wavefront of a 16-trajectory group: per evaluation, the group's eleven tiles as rows and the 32 MFMAs of
+  // the eight Gram tiles (same order of accumulation as when the main wavefront did this itself).
+  __device__ __forceinline__ static void gram_helper(int n_eval, const float* gbuf, f32x4* G, int lane) {
+    for (int e = 0; e < n_eval; ++e) {
+      pair_sync();
+      const float* buf = gbuf + (e & 1) * GT_WAVE;
+      const f32x4 Xdz = get_rows(buf + 0 * GT_TILE, lane);
+      const f32x4 Xdzp = get_rows(buf + 1 * GT_TILE, lane);
+      const f32x4 Yin = get_rows(buf + 2 * GT_TILE, lane);
+#pragma unroll
+      for (int m = 0; m < 2; ++m) {
+        const f32x4 Yh = get_rows(buf + (3 + 4 * m) * GT_TILE, lane);
+        gram_acc(G[0 + m], Xdz, Yh);
+        const f32x4 Xgs = get_rows(buf + (5 + 4 * m) * GT_TILE, lane);
+        gram_acc(G[2 + m], Xgs, Yin);
+        const f32x4 Yg = get_rows(buf + (4 + 4 * m) * GT_TILE, lane);
+        gram_acc(G[4 + m], Xdzp, Yg);
+        const f32x4 Xgp = get_rows(buf + (6 + 4 * m) * GT_TILE, lane);
+        gram_acc(G[6 + m], Xgp, Yin);
+      }
+    }
   }
   // weight index of element (tile, lane, register) of a wavefront's partial sums, or -1
   __host__ __device__ static int gram_dest(int tile, int lane, int reg, int n_const) {
@@ -347,22 +370,22 @@ struct BbMfma {
       const float lm = live ? 1.f : 0.f;  // (tail lanes shadow the last trajectory: their adjoint rows count as zero)
       const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
       const f32x4 xdzp = {dzp[0] * lm, dzp[1] * lm, 0.f, 0.f};
-      // tile by tile: the MFMAs of the earlier tiles run while the later ones travel through LDS (writing all eleven
-      // first and reading them back in one batch measured slower: 357 vs 345 us)
-      const f32x4 Xdz = to_rows(gbuf + 0 * GT_TILE, dz * lm, lane);
-      const f32x4 Xdzp = to_rows(gbuf + 1 * GT_TILE, xdzp, lane);
-      const f32x4 Yin = to_rows(gbuf + 2 * GT_TILE, xin, lane);
+      // The eleven tiles go to the group's helper wavefront (gram_helper) through LDS, as columns (one 16-byte store each);
+      // the helper turns them into rows and runs the 32 Gram MFMAs while this wavefront is already in its next evaluation.
+      // Two buffers, one workgroup barrier per evaluation: the helper has read buffer e & 1 before it arrives at barrier
+      // e + 1, and this wavefront writes that buffer again only behind barrier e + 1.
+      float* buf = gbuf + (D.e & 1) * GT_WAVE;
+      put_cols(buf + 0 * GT_TILE, dz * lm, lane);
+      put_cols(buf + 1 * GT_TILE, xdzp, lane);
+      put_cols(buf + 2 * GT_TILE, xin, lane);
 #pragma unroll
       for (int m = 0; m < 2; ++m) {
-        const f32x4 Yh = to_rows(gbuf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
-        gram_acc(G[0 + m], Xdz, Yh);
-        const f32x4 Xgs = to_rows(gbuf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
-        gram_acc(G[2 + m], Xgs, Yin);
-        const f32x4 Yg = to_rows(gbuf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
-        gram_acc(G[4 + m], Xdzp, Yg);
-        const f32x4 Xgp = to_rows(gbuf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
-        gram_acc(G[6 + m], Xgp, Yin);
+        put_cols(buf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
+        put_cols(buf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
+        put_cols(buf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
+        put_cols(buf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
       }
+      pair_sync();
     } else if (live) {
       float* Dp = D.base + (size_t)D.e * D.n;
       const size_t n = D.fstride;
@@ -491,7 +514,7 @@ __global__ void __launch_bounds__(256) bb_mfma_fwd_kernel(OdeArgs a) {
 // floats of aux ahead of the tail (Delta, bias sums): the per-evaluation dump, or the wavefronts' Gram partial sums
 __host__ __device__ inline size_t bb_mfma_head_floats(int n, int T, int solver, bool gram) {
   using BB = BbMfma::BB;
-  if (gram) return (size_t)((n + BbMfma::TPB - 1) / BbMfma::TPB) * 4 * 8 * 256;
+  if (gram) return (size_t)BbMfma::gram_groups(n) * 8 * 256;
   return (size_t)(T - 1) * BB::stages(solver) * BB::NF * n;
 }
 
@@ -499,14 +522,24 @@ template <int SOLVER, bool GRAM>
 __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   using K = BbMfma;
   using BB = K::BB;
-  extern __shared__ float glds[];  // GRAM: one transposition buffer set per wavefront
+  extern __shared__ float glds[];  // GRAM: two hand-over buffers (11 tiles each) per 16-trajectory group
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  float* gbuf = glds + wave * K::GT_WAVE;
-  f32x4 G[8];
+  constexpr int MAINS = GRAM ? K::GMAINS : 4;
+  float* gbuf = glds + (wave % MAINS) * 2 * K::GT_WAVE;
+  if (GRAM && wave >= MAINS) {
+    // helper of group blockIdx.x * MAINS + (wave - MAINS): the Gram tiles of its 16 trajectories, left as partial sums
+    f32x4 G[8];
 #pragma unroll
-  for (int tq = 0; tq < 8; ++tq) G[tq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int tq = 0; tq < 8; ++tq) G[tq] = f32x4{0.f, 0.f, 0.f, 0.f};
+    K::gram_helper((a.T - 1) * BB::stages(SOLVER), gbuf, G, lane);
+    float* gp = a.aux + ((size_t)(blockIdx.x * MAINS + (wave - MAINS)) * 8) * 256;
+#pragma unroll
+    for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f32x4*>(gp + tq * 256 + lane * 4) = G[tq];
+    return;
+  }
+  f32x4* G = nullptr;
   const int jj = lane & 15, q = lane >> 4;
-  const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
+  const int i0 = (blockIdx.x * MAINS + wave) * K::TPW + jj;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
@@ -602,11 +635,6 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
       bb[(size_t)(2 * K::NX + 4 + q) * n + i] = D.bs[5];
     }
   }
-  if (GRAM) {  // this wavefront's partial Gram tiles, raw (tile, lane, register) order
-    float* gp = a.aux + ((size_t)(blockIdx.x * 4 + wave) * 8) * 256;
-#pragma unroll
-    for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f32x4*>(gp + tq * 256 + lane * 4) = G[tq];
-  }
 }
 
 // sums the wavefronts' partial tiles in a fixed order (deterministic) and scatters them into the flat weight gradient.
@@ -639,19 +667,20 @@ __global__ void __launch_bounds__(1024) bb_gram_reduce_kernel(int n_waves, int n
   }
 }
 inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
-  const int n_waves = ((a.n + BbMfma::TPB - 1) / BbMfma::TPB) * 4;
+  const int n_waves = BbMfma::gram_groups(a.n);
   hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(32), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
 }
 
 inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
   // kernel_variant 4: the adjoint dumps every evaluation for vihds_gram_blocks (round 1); otherwise it accumulates the
-  // Gram tiles on chip
+  // Gram tiles on chip, in helper wavefronts: GMAINS main + GMAINS helper wavefronts per block
   const bool gram = a.kernel_variant != 4;
-  const size_t glds = (size_t)4 * BbMfma::GT_WAVE * sizeof(float);
+  const dim3 ggrid((a.n + BbMfma::GTPB - 1) / BbMfma::GTPB);
+  const size_t glds = (size_t)BbMfma::GMAINS * 2 * BbMfma::GT_WAVE * sizeof(float);
 #define VIHDS_BCASE(SV)                                                                                  \
   case SV:                                                                                               \
-    if (backward && gram) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, true>), grid, block, glds, st, a);  \
+    if (backward && gram) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, true>), ggrid, block, glds, st, a); \
     else if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, false>), grid, block, 0, st, a);       \
     else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);                            \
     return VIHDS_OK;
