@@ -1,14 +1,17 @@
 // dr_blackbox kernels for the configuration of the reference's specs/dr_blackbox_icml.yaml:17-31
 // (n_latent_species 2, n_hidden_decoder 25, n_hidden_decoder_precisions 20, n_z 5, n_x 5, n_y 2).
 #include "vihds_ode_kernels.hpp"
-#include "vihds_blackbox_mfma.hpp"
+#include "vihds_blackbox_split.hpp"
 
 namespace vihds {
 using BB = Blackbox<2, 25, 20, 5, 5, 2>;
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   // kernel_variant 1 = VALU, one thread per trajectory (vihds_blackbox.hpp); otherwise the MFMA formulation
   if (a.kernel_variant == 1 || solver_is_adaptive(solver) || g_adaptive_ctl) return launch_ode<BB>(backward, solver, a, st);
-  return launch_bb_mfma(backward, solver, a, st);
+  // kernel_variant 4: one wavefront per 16 trajectories, the adjoint dumping every evaluation (vihds_blackbox_mfma.hpp);
+  // otherwise the two networks on two wavefronts and the Gram tiles on two more (vihds_blackbox_split.hpp)
+  if (a.kernel_variant == 4) return launch_bb_mfma(backward, solver, a, st);
+  return launch_bb_split(backward, solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }
 int n_states_dr_blackbox() { return BB::N; }
@@ -34,3 +37,8 @@ int bb_check(int L, int HS, int HP, int n_const, int C, int D) {
 }
 int bb_dump_fields() { return BB::NF; }
 }  // namespace vihds
+#ifdef VIHDS_BB_STAMPS
+extern "C" int vihds_debug_bb_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vihds::vihds_bb_stamp_buf), &buf, sizeof(buf));
+}
+#endif

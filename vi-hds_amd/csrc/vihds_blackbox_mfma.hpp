@@ -35,9 +35,8 @@ struct BbMfma {
   using BB = Blackbox<2, 25, 20, 5, 5, 2>;
   static constexpr int NX = 6, HS = 25, HP = 20, NLAT = 12;
   static constexpr int TPW = 16, TPB = 64;  // trajectories per wave / per 256-thread block
-  // adjoint with on-chip weight gradients: a block is GMAINS main wavefronts (16 trajectories each) + as many helpers
-  static constexpr int GMAINS = 2, GTPB = GMAINS * TPW;
-  __host__ __device__ static int gram_groups(int n) { return ((n + GTPB - 1) / GTPB) * GMAINS; }
+  // 16-trajectory groups = partial Gram tile sets the adjoint with on-chip weight gradients leaves (vihds_blackbox_split.hpp)
+  __host__ __device__ static int gram_groups(int n) { return (n + TPW - 1) / TPW; }
   static constexpr int KS = 7, KP = 5;      // second-layer K-steps (states, precisions)
 
   __device__ static f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
@@ -264,28 +263,6 @@ struct BbMfma {
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  // The helper wavefront of a 16-trajectory group: per evaluation, the group's eleven tiles as rows and the 32 MFMAs of
-  // the eight Gram tiles (same order of accumulation as when the main wavefront did this itself).
-  __device__ __forceinline__ static void gram_helper(int n_eval, const float* gbuf, f32x4* G, int lane) {
-    for (int e = 0; e < n_eval; ++e) {
-      pair_sync();
-      const float* buf = gbuf + (e & 1) * GT_WAVE;
-      const f32x4 Xdz = get_rows(buf + 0 * GT_TILE, lane);
-      const f32x4 Xdzp = get_rows(buf + 1 * GT_TILE, lane);
-      const f32x4 Yin = get_rows(buf + 2 * GT_TILE, lane);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        const f32x4 Yh = get_rows(buf + (3 + 4 * m) * GT_TILE, lane);
-        gram_acc(G[0 + m], Xdz, Yh);
-        const f32x4 Xgs = get_rows(buf + (5 + 4 * m) * GT_TILE, lane);
-        gram_acc(G[2 + m], Xgs, Yin);
-        const f32x4 Yg = get_rows(buf + (4 + 4 * m) * GT_TILE, lane);
-        gram_acc(G[4 + m], Xdzp, Yg);
-        const f32x4 Xgp = get_rows(buf + (6 + 4 * m) * GT_TILE, lane);
-        gram_acc(G[6 + m], Xgp, Yin);
-      }
-    }
-  }
   // weight index of element (tile, lane, register) of a wavefront's partial sums, or -1
   __host__ __device__ static int gram_dest(int tile, int lane, int reg, int n_const) {
     const BB::Off o = BB::offsets(n_const);
@@ -366,27 +343,7 @@ struct BbMfma {
     if (q < 2) yb.b += dy[1];
     // ---- dump (same field layout as vihds_blackbox.hpp: the host contraction is shared)
     D.bs[0] += dz[0]; D.bs[1] += dz[1]; D.bs[2] += dz[2]; D.bs[3] += dz[3]; D.bs[4] += dzp[0]; D.bs[5] += dzp[1];
-    if (GRAM) {
-      const float lm = live ? 1.f : 0.f;  // (tail lanes shadow the last trajectory: their adjoint rows count as zero)
-      const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
-      const f32x4 xdzp = {dzp[0] * lm, dzp[1] * lm, 0.f, 0.f};
-      // The eleven tiles go to the group's helper wavefront (gram_helper) through LDS, as columns (one 16-byte store each);
-      // the helper turns them into rows and runs the 32 Gram MFMAs while this wavefront is already in its next evaluation.
-      // Two buffers, one workgroup barrier per evaluation: the helper has read buffer e & 1 before it arrives at barrier
-      // e + 1, and this wavefront writes that buffer again only behind barrier e + 1.
-      float* buf = gbuf + (D.e & 1) * GT_WAVE;
-      put_cols(buf + 0 * GT_TILE, dz * lm, lane);
-      put_cols(buf + 1 * GT_TILE, xdzp, lane);
-      put_cols(buf + 2 * GT_TILE, xin, lane);
-#pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        put_cols(buf + (3 + 4 * m) * GT_TILE, A.h[m], lane);
-        put_cols(buf + (5 + 4 * m) * GT_TILE, gs[m] * lm, lane);
-        put_cols(buf + (4 + 4 * m) * GT_TILE, A.g[m], lane);
-        put_cols(buf + (6 + 4 * m) * GT_TILE, gp[m] * lm, lane);
-      }
-      pair_sync();
-    } else if (live) {
+    if (live) {
       float* Dp = D.base + (size_t)D.e * D.n;
       const size_t n = D.fstride;
 #pragma unroll
@@ -522,24 +479,12 @@ template <int SOLVER, bool GRAM>
 __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   using K = BbMfma;
   using BB = K::BB;
-  extern __shared__ float glds[];  // GRAM: two hand-over buffers (11 tiles each) per 16-trajectory group
+  static_assert(!GRAM, "on-chip weight gradients: bb_split_bwd_kernel (vihds_blackbox_split.hpp)");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  constexpr int MAINS = GRAM ? K::GMAINS : 4;
-  float* gbuf = glds + (wave % MAINS) * 2 * K::GT_WAVE;
-  if (GRAM && wave >= MAINS) {
-    // helper of group blockIdx.x * MAINS + (wave - MAINS): the Gram tiles of its 16 trajectories, left as partial sums
-    f32x4 G[8];
-#pragma unroll
-    for (int tq = 0; tq < 8; ++tq) G[tq] = f32x4{0.f, 0.f, 0.f, 0.f};
-    K::gram_helper((a.T - 1) * BB::stages(SOLVER), gbuf, G, lane);
-    float* gp = a.aux + ((size_t)(blockIdx.x * MAINS + (wave - MAINS)) * 8) * 256;
-#pragma unroll
-    for (int tq = 0; tq < 8; ++tq) *reinterpret_cast<f32x4*>(gp + tq * 256 + lane * 4) = G[tq];
-    return;
-  }
   f32x4* G = nullptr;
+  float* gbuf = nullptr;
   const int jj = lane & 15, q = lane >> 4;
-  const int i0 = (blockIdx.x * MAINS + wave) * K::TPW + jj;
+  const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
@@ -671,17 +616,13 @@ inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_w
   hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(32), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
 }
 
+// the one-wavefront-per-group kernels: forward, and the adjoint that dumps every evaluation for vihds_gram_blocks
+// (kernel_variant 4, round 1's weight-gradient path).  The default path is vihds_blackbox_split.hpp.
 inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
-  // kernel_variant 4: the adjoint dumps every evaluation for vihds_gram_blocks (round 1); otherwise it accumulates the
-  // Gram tiles on chip, in helper wavefronts: GMAINS main + GMAINS helper wavefronts per block
-  const bool gram = a.kernel_variant != 4;
-  const dim3 ggrid((a.n + BbMfma::GTPB - 1) / BbMfma::GTPB);
-  const size_t glds = (size_t)BbMfma::GMAINS * 2 * BbMfma::GT_WAVE * sizeof(float);
 #define VIHDS_BCASE(SV)                                                                                  \
   case SV:                                                                                               \
-    if (backward && gram) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, true>), ggrid, block, glds, st, a); \
-    else if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, false>), grid, block, 0, st, a);       \
+    if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, false>), grid, block, 0, st, a);            \
     else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);                            \
     return VIHDS_OK;
   switch (solver) {
