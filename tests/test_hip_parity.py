@@ -621,7 +621,7 @@ def test_bad_arguments_fail_loudly():
 # BASELINE configs 4 and 5 at full size (dr_blackbox 36x200, T=86; relay_constant_precisions 36x200, N=16, T=99):
 # size-independent properties -- shard consistency (bit-exact) and a directional finite-difference derivative
 # ---------------------------------------------------------------------------------------------------
-def _blackbox_problem(B, S, T, seed=0):
+def _blackbox_problem(B, S, T, seed=0, solver="midpoint", variant=0):
     from vihds import hip, ops
 
     g = torch.Generator().manual_seed(seed)
@@ -631,9 +631,9 @@ def _blackbox_problem(B, S, T, seed=0):
     theta = torch.stack([th[n] for n in slots]).to(DEV)
     C, D = 2, 7
     n_const = 12 + C + D
-    spec = ops.OdeProblemSpec("dr_blackbox", "midpoint", {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
+    spec = ops.OdeProblemSpec("dr_blackbox", solver, {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
                                n_hidden_prec=20, n_hidden_states=25, n_latent_states=2, n_const=n_const,
-                               init_latent=0.001, init_prec=1e-5)
+                               init_latent=0.001, init_prec=1e-5, kernel_variant=variant)
     n_w = hip.lib().vihds_model_n_weights(__import__("ctypes").byref(spec.bind(B, S, T)))
     assert n_w == 1760
     wts = (torch.randn(n_w, generator=g) * 0.3).to(DEV)
@@ -642,6 +642,32 @@ def _blackbox_problem(B, S, T, seed=0):
     times = (torch.arange(T, dtype=torch.float32) * 0.1933).to(DEV)
     obs = torch.rand(B, 4, T, generator=g).to(DEV)
     return spec, theta, wts, cond, dev, times, obs
+
+
+@pytest.mark.parametrize("solver", ["modeuler", "modeulerwhile", "euler", "midpoint", "rk4"])
+def test_blackbox_cooperating_wavefronts_match_thread_per_trajectory(solver):
+    """csrc/vihds_blackbox_split.hpp (the default at the ICML sizes: NeuralStates and NeuralPrecisions on two wavefronts
+    per 16 trajectories, Gram tiles on two more) against the one-thread-per-trajectory kernels (variant 1, pinned by the
+    reference fixture and the restatement) and the one-wavefront kernels with the evaluation dump (variant 4), for every
+    fixed-grid scheme, at a ragged size (n = 35: two full groups and three trajectories), with cotangents on all three
+    outputs: trajectories, predictions, log-likelihoods, d/d theta and all 1 760 weight gradients."""
+    from vihds import ops
+
+    B, S, T = 5, 7, 23
+    out = {}
+    for variant in (0, 1, 4):
+        spec, theta, wts, cond, dev, times, obs = _blackbox_problem(B, S, T, seed=3, solver=solver, variant=variant)
+        theta = theta.clone().requires_grad_(True)
+        wts = wts.clone().requires_grad_(True)
+        traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, cond, times, obs, dev, wts)
+        g = torch.Generator(device=DEV).manual_seed(5)
+        ct = [torch.randn(t.shape, device=DEV, generator=g) for t in (traj, xpred, logp)]
+        ((traj * ct[0]).sum() * 1e-2 + (xpred * ct[1]).sum() * 1e-2 + (logp * ct[2]).sum() * 1e-3).backward()
+        out[variant] = [t.detach().cpu() for t in (traj, xpred, logp, theta.grad, wts.grad)]
+    for variant in (0, 4):
+        for name, got, ref, tol in zip(("traj", "xpred", "logp", "g_theta", "g_weights"), out[variant], out[1],
+                                       (1e-5, 1e-5, 1e-5, 2e-4, 2e-4)):
+            assert rel_err(got, ref) < tol, (variant, name)
 
 
 def test_config4_blackbox_full_size_properties():
