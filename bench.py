@@ -201,8 +201,8 @@ WORKLOAD_TABLE = {
 LAUNCH_KERNELS = {  # launch name (ops._launch) -> substrings of the kernels it can run, for the PMC lookup
     "decoder_step": ["dr_scan_train_theta_kernel", "dr_lane_train_theta_kernel"],
     "ode_logp_grad": ["dr_scan_train_kernel", "dr_lane_train_kernel"],
-    "ode_fwd": ["bb_mfma_fwd_kernel", "dr_lane_fwd_kernel", "ode_fwd_kernel"],
-    "ode_bwd": ["bb_mfma_bwd_kernel", "dr_lane_bwd_kernel", "ode_bwd_kernel"],
+    "ode_fwd": ["bb_split_fwd_kernel", "bb_mfma_fwd_kernel", "relay_lane_fwd_kernel", "dr_lane_fwd_kernel", "ode_fwd_kernel"],
+    "ode_bwd": ["bb_split_bwd_kernel", "bb_mfma_bwd_kernel", "relay_lane_bwd_kernel", "dr_lane_bwd_kernel", "ode_bwd_kernel"],
 }
 
 
