@@ -619,3 +619,41 @@ def test_step_rows_gathers_on_the_device_what_the_host_loader_would_stack(graph)
         assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs["host"][0], runs["rows"][0])
     for k, v in runs["host"][1].items():
         assert rel_err(runs["rows"][1][k], v) < 1e-6, k
+
+
+def test_epoch_graph_walks_the_same_steps_as_one_graph_per_step():
+    """Training.epoch_rows (what run() uses with hip_graph when the NaN check is at most once per epoch): all the steps of
+    an epoch -- full batches and the ragged one, gather + step each -- in ONE hipGraph launch fed by one copy of the epoch's
+    row indices, against the same batches through Training.step_rows (one graph launch per step): same losses, same
+    parameters after two epochs; and run() itself takes that path and counts the steps."""
+    from vihds import synthetic
+
+    kw = dict(solver="rk4", seed=5, u_rng="kernel", conditioner_rng="kernel", learning_rate=0.01, hip_graph=True,
+              fused_ode_training=True, fused_decoder_step=True, fused_iwae_backward=True, fused_step_tail=True, n_batch=8)
+    g = torch.Generator().manual_seed(1)
+    epochs = [list(torch.randperm(20, generator=g).split(8)) for _ in range(2)]  # 8 + 8 + 4 rows, twice
+    runs = {}
+    for mode in ("steps", "epoch"):
+        args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                            nan_check_every=0, **kw)
+        model.train()
+        losses = []
+        for batches in epochs:
+            if mode == "epoch":
+                losses += [float(l) for l in training.epoch_rows(batches)]
+            else:
+                losses += [float(training.step_rows(rows)) for rows in batches]
+        runs[mode] = (losses, {k: v.detach().clone() for k, v in model.named_parameters()})
+    assert len(runs["epoch"][0]) == 6
+    for a, b in zip(runs["steps"][0], runs["epoch"][0]):
+        assert abs(a - b) <= 1e-6 * max(1.0, abs(a)), (runs["steps"][0], runs["epoch"][0])
+    for k, v in runs["steps"][1].items():
+        assert rel_err(runs["epoch"][1][k], v) < 1e-6, k
+    # run(): three epochs of three batches, NaN check once per epoch -> three graph launches, nine steps
+    args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                        nan_check_every=3, **kw)
+    args.epochs, args.test_epoch, args.test_samples = 3, 3, 32
+    assert training.epoch_graph
+    out = training.run()
+    assert training._steps == 9 and any(k[0] == "epoch" for k in training._graphs if isinstance(k[0], str))
+    assert out is not None and np.isfinite(float(out.elbo))

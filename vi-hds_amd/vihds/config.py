@@ -33,6 +33,8 @@ PARAM_DEFAULTS = {
     "fused_iwae_backward": False,  # with the two above: the IWAE loss is formed inside the theta-adjoint launch (its value exists after backward())
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
+    "lazy_cache_dump": False,  # True: the best evaluation's Results are written to .vihds_cache once, when run() ends
+    "epoch_graph": True,       # with hip_graph and nan_check_every = 0 or >= the batches of an epoch: one graph launch per epoch
 }
 
 

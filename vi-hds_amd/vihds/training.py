@@ -81,6 +81,9 @@ class Training:
         on_gpu = settings.device.type == "cuda"
         self.use_graph = bool(default_get_value(p, "hip_graph", False)) and on_gpu
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
+        # run(): with hip_graph, a single process and a NaN check at most once per epoch, an epoch is ONE graph launch
+        self.epoch_graph = (self.use_graph and bool(default_get_value(p, "epoch_graph", True)) and self.shard is None
+                            and self.replica is None)
         if self.use_graph:
             # a captured step replays whatever the capture recorded: host-side draws (numpy u, CPU conditioner
             # weights) would be frozen into the graph or leave a stale host pointer behind
@@ -131,6 +134,10 @@ class Training:
         else:
             self.train_path = self.valid_path = None
         self.empty_cache = True
+        # the best evaluation's results go to the on-disk cache (utils.py:127-141 in the reference) at every improvement, as
+        # the reference does, or -- lazy_cache_dump -- once, when run() leaves its loop (also on an exception): same final cache
+        self.lazy_cache_dump = bool(default_get_value(p, "lazy_cache_dump", False))
+        self._best_output = None
         # the step's tail (loss, backward, Adam) as two launches: vihds_step_tail (off by default: reference call sequence)
         self.fused_tail = bool(default_get_value(p, "fused_step_tail", False)) and on_gpu
         self._tail, self._tail_ok, self._tail_shapes = None, False, {}
@@ -240,7 +247,10 @@ class Training:
               % (valid_output.elbo, log_data.total_test_time / log_data.n_test, log_data.total_test_time))
         if valid_output.elbo > log_data.max_val_elbo:
             log_data.max_val_elbo = valid_output.elbo
-            valid_output.dump()
+            if self.lazy_cache_dump:
+                self._best_output = valid_output  # written once, when run() leaves its loop (nine files per improvement otherwise)
+            else:
+                valid_output.dump()
             self.empty_cache = False
         log_data.training_elbo_list.append(train_output.elbo)
         log_data.validation_elbo_list.append(valid_output.elbo)
@@ -362,16 +372,27 @@ class Training:
     def _capture(self, static, repeat, prologue=None):
         """Warm up on a side stream (rolled back afterwards), then capture `repeat` steps on the buffers `static` --
         behind `prologue()` when given (e.g. the gather that fills them) -- into a hipGraph.  Returns (graph, static, loss)."""
+        g, losses = self._capture_segments([(static, prologue if k == 0 else None) for k in range(repeat)])
+        return g, static, (losses[0] if repeat == 1 else losses)
+
+    def _capture_segments(self, segments):
+        """One hipGraph holding len(segments) consecutive training steps: segment k = `prologue_k()` (or nothing), then the
+        step on the buffers `static_k`.  Returns (graph, [loss_k])."""
         s = torch.cuda.Stream()
         # the snapshot's clone kernels are enqueued on the current stream BEFORE the side stream is made to wait for
         # it, so the warm-up steps (which run Adam and advance the generator states) are ordered after the copies
         snap = self._snapshot_training_state()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
-            for _ in range(3):  # allocator warm-up, lazy initialisations, Adam state
-                if prologue is not None:
-                    prologue()
-                self.step(static)
+            seen = set()
+            for static, prologue in segments:  # allocator warm-up, lazy initialisations, Adam state: once per batch shape
+                if id(static) in seen and prologue is None:
+                    continue
+                seen.add(id(static))
+                for _ in range(3):
+                    if prologue is not None:
+                        prologue()
+                    self.step(static)
         torch.cuda.current_stream().wait_stream(s)
         self._restore_training_state(snap)  # the warm-up steps must not count as training steps
         self.optimizer.zero_grad(set_to_none=True)
@@ -383,6 +404,9 @@ class Training:
             _warn(False)
         try:
             if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
+                if len(segments) != 1:
+                    raise ValueError("several steps per graph are for single-process steps")
+                static, prologue = segments[0]
                 g = parallel.SegmentedGraph()
 
                 def fn():
@@ -390,19 +414,20 @@ class Training:
                         prologue()
                     return self.step(static, zero_grad=False)
 
-                loss = g.capture(fn)
+                loss = [g.capture(fn)]
             else:
                 g = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(g):
-                    if prologue is not None:
-                        prologue()
-                    # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
-                    loss = [self.step(static, zero_grad=k < repeat - 1) for k in range(repeat)]
-                    loss = loss[0] if repeat == 1 else loss
+                    loss = []
+                    for k, (static, prologue) in enumerate(segments):
+                        if prologue is not None:
+                            prologue()
+                        # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
+                        loss.append(self.step(static, zero_grad=k < len(segments) - 1))
         finally:
             if _warn is not None:
                 _warn(True)  # only the capture itself is exempt, not the rest of the process
-        return g, static, loss
+        return g, loss
 
     def graph_step(self, batch, repeat=1):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
@@ -480,6 +505,31 @@ class Training:
         g.replay()
         return loss
 
+    def epoch_rows(self, batches):
+        """All the steps of one epoch -- `batches`: the loader's row-index tensors, in order -- as ONE hipGraph launch: the
+        epoch's indices travel in one pinned copy, every step is gather + step on the buffers of its batch size.  One graph
+        per sequence of batch sizes (an epoch of the reference's loader is always the same sequence: full batches, then
+        the ragged one).  Returns the steps' losses (device scalars)."""
+        sizes = tuple(int(b.shape[0]) for b in batches)
+        dev = self.train_data.observations.device
+        key = ("epoch",) + sizes
+        if key not in self._graphs:
+            idx = torch.cat(list(batches)).to(dev).clone()
+            pinned = torch.empty(int(idx.shape[0]), dtype=torch.int64).pin_memory()
+            statics, segments, o = {}, [], 0
+            for n in sizes:
+                view = idx[o: o + n]
+                if n not in statics:
+                    statics[n] = self.gather_rows(view)
+                segments.append((statics[n], (lambda v=view, st=statics[n]: self.gather_rows(v, out=st))))
+                o += n
+            self._graphs[key] = self._capture_segments(segments) + (idx, pinned)
+        g, losses, idx, pinned = self._graphs[key]
+        torch.cat(list(batches), out=pinned)
+        idx.copy_(pinned, non_blocking=True)
+        g.replay()
+        return losses
+
     def _run_batch(self, epoch_start, batch, log_data):
         """reference training.py:324-340.  `batch`: a batch of the reference's form, or the row indices of one (host int64
         tensor: what self.train_loader yields)."""
@@ -520,18 +570,58 @@ class Training:
         iterating = True
         epoch = 1
         valid_output = None
-        while iterating is True and (epoch < self.args.epochs + 1):
-            self.model.train()
-            epoch_start = time.time()
-            for batch in self.train_loader:
-                if iterating:
-                    iterating = self._run_batch(epoch_start, batch, log_data)
-            log_data.total_train_time += time.time() - epoch_start
-            if iterating and (np.mod(epoch, self.args.test_epoch) == 0):
-                self.model.eval()
-                valid_output = self._evaluate_elbo_and_plot(epoch, log_data, train_writer, valid_writer)
-            self.scheduler.step()
-            epoch += 1
+        pending = None  # epoch-graph path: the losses of the epoch launched last, not looked at yet
+
+        def settle():
+            """NaN check of the epoch launched last (training.py:331-334 looks at every step's ELBO; here: at the epoch's
+            ELBOs, before anything else is launched -- every update is gated on its own loss on the device either way)."""
+            nonlocal pending
+            ok = True
+            if pending is not None and self.nan_check_every > 0:
+                if bool(torch.isnan(torch.stack([l.detach().reshape(()) for l in pending])).any()):
+                    print("Cannot proceed with ELBO = nan. Exiting.")
+                    ok = False
+            pending = None
+            return ok
+
+        try:
+            while iterating is True and (epoch < self.args.epochs + 1):
+                self.model.train()
+                epoch_start = time.time()
+                batches = None
+                if self.epoch_graph:
+                    # the sampler's draws for the epoch (same generator stream as iterating the loader step by step); this host
+                    # work runs while the GPU is still in the previous epoch: its losses are looked at only afterwards
+                    batches = list(self.train_loader)
+                    if not all(isinstance(b, torch.Tensor) for b in batches):
+                        batches = None
+                iterating = settle()
+                if not iterating:
+                    break
+                if batches is not None and (self.nan_check_every == 0 or self.nan_check_every >= len(batches)):
+                    # the whole epoch in one graph launch
+                    log_data.batch_feed_time += time.time() - epoch_start
+                    train_start = time.time()
+                    pending = self.epoch_rows(batches)
+                    self._steps += len(batches)
+                    log_data.batch_train_time += time.time() - train_start
+                else:
+                    for batch in (batches if batches is not None else self.train_loader):
+                        if iterating:
+                            iterating = self._run_batch(epoch_start, batch, log_data)
+                log_data.total_train_time += time.time() - epoch_start
+                if iterating and (np.mod(epoch, self.args.test_epoch) == 0):
+                    iterating = settle()
+                    if iterating:
+                        self.model.eval()
+                        valid_output = self._evaluate_elbo_and_plot(epoch, log_data, train_writer, valid_writer)
+                self.scheduler.step()
+                epoch += 1
+            settle()
+        finally:
+            if self._best_output is not None:
+                self._best_output.dump()
+                self._best_output = None
         for w in (train_writer, valid_writer):
             if w is not None:
                 w.close()
