@@ -1,6 +1,7 @@
 """Ad-hoc probe: a dr_blackbox training step at BASELINE config 4's shape (B=36, S=200, T=86, midpoint) with the
 reference's DEFAULT n_hidden_decoder = 50 (vihds/config.py:71), i.e. through the per-size side library
-libvihds_bb_2_50_20_12.so (thread-per-trajectory kernels + library-GEMM weight gradients), next to the ICML sizes
+libvihds_bb_2_50_20_12.so (round 3: its matrix-core kernels on cooperating wavefronts; thread-per-trajectory kernels +
+vihds_gram_blocks before), next to the ICML sizes
 (matrix-core kernels of libvihds_hip.so).  Prints the step time and, with synchronising timers around them, the ODE
 launches and the weight-gradient contraction."""
 import os, sys, time

@@ -1670,15 +1670,17 @@ def test_sized_blackbox_every_solver_against_the_restatement(solver):
     assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL
 
 
-@pytest.mark.parametrize("solver", ["rk4", "euler"])
-def test_wide_blackbox_default_hidden_size_against_the_restatement(solver):
+@pytest.mark.parametrize("variant", [0, 1])
+@pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint", "modeuler"])
+def test_wide_blackbox_default_hidden_size_against_the_restatement(solver, variant):
     """dr_blackbox with the reference's DEFAULT n_hidden_decoder = 50 (vihds/config.py:71 -- what a YAML that omits the
-    key gets; 167 dump fields and 20 tile products: past ONE contraction plan): libvihds_bb_2_50_20_12.so on the ICML
-    fixture's inputs with seeded random weights, forward and every gradient against the CPU restatement's autograd.
-    rk4: 10 880 dump columns, the weight gradients go through two plan-sized vihds_gram_blocks passes; euler: 2 720
-    columns (not a multiple of 64, too many fields for the LDS-tiled kernel), the library-GEMM route of
-    ops.blackbox_weight_grads.  The test runs when the side library is present (it travels with the tree) or
-    VIHDS_TEST_BUILD_WIDE=1."""
+    key gets): libvihds_bb_2_50_20_12.so on the ICML fixture's inputs with seeded random weights, forward and every
+    gradient against the CPU restatement's autograd.  variant 0 (the default): the matrix-core kernels on cooperating
+    wavefronts at four / two hidden tiles, weight gradients on chip (csrc/vihds_blackbox_split.hpp, round 3).  variant 1:
+    one thread per trajectory with 167 dump fields and 20 tile products, past ONE contraction plan -- rk4: 10 880 dump
+    columns, two plan-sized vihds_gram_blocks passes; euler: 2 720 columns (not a multiple of 64, too many fields for
+    the LDS-tiled kernel), the library-GEMM route of ops.blackbox_weight_grads.  The test runs when the side library is
+    present (it travels with the tree) or VIHDS_TEST_BUILD_WIDE=1."""
     import os
     from vihds import hip, ops
     import hip_util as H
@@ -1703,7 +1705,9 @@ def test_wide_blackbox_default_hidden_size_against_the_restatement(solver):
     slots = hip.model_slots("dr_blackbox")
     theta = torch.stack([th_cpu[n].detach().expand(fx.B, fx.S) for n in slots]).to(DEV).requires_grad_(True)
     spec = ops.OdeProblemSpec("dr_blackbox", solver, {n: i for i, n in enumerate(slots)}, len(slots), C=C, D=D,
-                               n_hidden_prec=HP, n_hidden_states=HS, n_latent_states=L, n_const=nc, slots=slots)
+                               n_hidden_prec=HP, n_hidden_states=HS, n_latent_states=L, n_const=nc, slots=slots,
+                               kernel_variant=variant)
+    assert bool(hip.lib().vihds_blackbox_gram_on_chip(__import__("ctypes").byref(spec.bind(fx.B, fx.S, int(fx.t("times").shape[0]))))) == (variant == 0)
     dev = fx.t("dev_1hot")
     traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
                                                   fx.t("observations", DEV), dev.to(DEV), wts)

@@ -11,7 +11,7 @@ int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t 
   // kernel_variant 4: one wavefront per 16 trajectories, the adjoint dumping every evaluation (vihds_blackbox_mfma.hpp);
   // otherwise the two networks on two wavefronts and the Gram tiles on two more (vihds_blackbox_split.hpp)
   if (a.kernel_variant == 4) return launch_bb_mfma(backward, solver, a, st);
-  return launch_bb_split(backward, solver, a, st);
+  return launch_bb_split<BbMfma>(backward, solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }
 int n_states_dr_blackbox() { return BB::N; }
@@ -30,7 +30,7 @@ long long bb_tail_offset_floats(int n, int T, int solver, int kernel_variant) {
 }
 int bb_gram_on_chip(int solver, int kernel_variant) { return bb_gram_mode(solver, kernel_variant) ? 1 : 0; }
 void bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
-  launch_bb_gram_reduce(a, aux, g_weights, st);
+  launch_bb_gram_reduce<BbMfma>(a, aux, g_weights, st);
 }
 int bb_check(int L, int HS, int HP, int n_const, int C, int D) {
   return L == 2 && HS == 25 && HP == 20 && n_const == BB::NLAT + C + D;

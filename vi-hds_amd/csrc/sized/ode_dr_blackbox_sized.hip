@@ -6,6 +6,7 @@
 // record that dispatches to them).
 #include "../vihds_ode_kernels.hpp"
 #include "../vihds_bb_variant.hpp"
+#include "../vihds_blackbox_split.hpp"
 
 #if !defined(VIHDS_BB_L) || !defined(VIHDS_BB_HS) || !defined(VIHDS_BB_HP) || !defined(VIHDS_BB_NLAT)
 #error "define VIHDS_BB_L, VIHDS_BB_HS, VIHDS_BB_HP and VIHDS_BB_NLAT"
@@ -14,6 +15,12 @@
 namespace vihds {
 using BBV = Blackbox<VIHDS_BB_L, VIHDS_BB_HS, VIHDS_BB_HP, VIHDS_BB_NLAT, 0, 0>;
 typedef int (*bb_launch_fn)(bool, int, const OdeArgs&, hipStream_t, AdaptiveCtl*);
+// the matrix-core formulation exists for this size set
+constexpr bool BBV_MFMA = VIHDS_BB_L == 2 && VIHDS_BB_HS <= 64 && VIHDS_BB_HP <= 32 && VIHDS_BB_NLAT <= 16;
+using KV = BbMfmaT<BBV, BBV_MFMA ? VIHDS_BB_HS : 16, BBV_MFMA ? VIHDS_BB_HP : 16, BBV_MFMA ? VIHDS_BB_NLAT : 16>;
+__host__ inline bool bbv_takes_mfma(int solver, const OdeArgs& a, AdaptiveCtl* ctl) {
+  return BBV_MFMA && !ctl && a.kernel_variant != 1 && solver >= VIHDS_SOLVER_MODEULER && solver <= VIHDS_SOLVER_RK4;
+}
 }  // namespace vihds
 
 #define VIHDS_BB_CAT2(a, b) a##b
@@ -23,6 +30,11 @@ typedef int (*bb_launch_fn)(bool, int, const OdeArgs&, hipStream_t, AdaptiveCtl*
 extern "C" int VIHDS_BB_CAT(vihds_bb_launch_, VIHDS_ONLY_SOLVER)(bool backward, int solver, const vihds::OdeArgs& a,
                                                                 hipStream_t st, vihds::AdaptiveCtl* ctl) {
   using namespace vihds;
+#if VIHDS_ONLY_SOLVER <= 4
+  static_assert(VIHDS_SOLVER_RK4 == 4 && VIHDS_SOLVER_MODEULER == 0, "fixed-grid schemes are solvers 0..4");
+  if constexpr (BBV_MFMA)
+    if (bbv_takes_mfma(solver, a, ctl)) return launch_bb_split_solver<KV, VIHDS_ONLY_SOLVER>(backward, a, st);
+#endif
   g_adaptive_ctl = ctl;
   const int rc = launch_ode<BBV>(backward, solver, a, st);
   g_adaptive_ctl = nullptr;
@@ -37,6 +49,10 @@ static_assert(VIHDS_SOLVER_COUNT == 9, "one object per solver: extend the table 
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own (it does not link against libvihds_hip.so)
 static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
+static long long gram_floats_sized(int n) { return BBV_MFMA ? (long long)KV::gram_floats(n) : -1; }
+static void gram_reduce_sized(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
+  if constexpr (BBV_MFMA) launch_bb_gram_reduce<KV>(a, aux, g_weights, st);
+}
 static int launch_sized(bool backward, int solver, const OdeArgs& a, hipStream_t st, AdaptiveCtl* ctl) {
   static const bb_launch_fn table[VIHDS_SOLVER_COUNT] = {vihds_bb_launch_0, vihds_bb_launch_1, vihds_bb_launch_2,
                                                          vihds_bb_launch_3, vihds_bb_launch_4, vihds_bb_launch_5,
@@ -46,10 +62,11 @@ static int launch_sized(bool backward, int solver, const OdeArgs& a, hipStream_t
 }
 }  // namespace vihds
 
-extern "C" const vihds::BbVariant* vihds_bb_variant(void) {
+extern "C" const vihds::BbVariant* vihds_bb_variant_v2(void) {
   using namespace vihds;
   static const BbVariant v = {VIHDS_BB_L, VIHDS_BB_HS, VIHDS_BB_HP, VIHDS_BB_NLAT, BBV::N, BBV::NSLOT,
-                              BBV::NF,    BBV::NTAIL,  n_weights_sized, launch_sized};
+                              BBV::NF,    BBV::NTAIL,  n_weights_sized, launch_sized,
+                              BBV_MFMA ? 1 : 0, gram_floats_sized, gram_reduce_sized};
   return &v;
 }
 #endif

@@ -180,7 +180,7 @@ static const BbVariant* bb_sized(const vihds_ode_problem* p) {
   const BbVariant* v = nullptr;
   if (void* h = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL)) {
     typedef const BbVariant* (*entry_fn)(void);
-    if (entry_fn f = (entry_fn)dlsym(h, "vihds_bb_variant")) v = f();
+    if (entry_fn f = (entry_fn)dlsym(h, "vihds_bb_variant_v2")) v = f();
     if (v && (v->L != p->n_latent_states || v->HS != p->n_hidden_states || v->HP != p->n_hidden_prec || v->NLAT != nlat))
       v = nullptr;
   }
@@ -194,6 +194,10 @@ static const BbVariant* bb_sized(const vihds_ode_problem* p) {
   }
   loaded[key] = v;
   return v;
+}
+// a side library's matrix-core kernels with the weight gradients on chip apply (same rule as its launch function)
+static bool bb_sized_gram(const BbVariant* v, const vihds_ode_problem* p) {
+  return v->mfma && p->kernel_variant != 1 && p->solver >= VIHDS_SOLVER_MODEULER && p->solver <= VIHDS_SOLVER_RK4;
 }
 static long long bb_sized_dump_floats(const BbVariant* v, const vihds_ode_problem* p) {
   return (long long)(p->T - 1) * ode_stages(p->solver) * v->dump_fields * p->B * p->S;
@@ -346,6 +350,7 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
     if (bb_builtin(p)) return bb_aux_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
     const BbVariant* v = bb_sized(p);
+    if (v && bb_sized_gram(v, p)) return v->gram_floats(p->B * p->S) + (long long)v->n_tail * p->B * p->S;
     return v ? bb_sized_dump_floats(v, p) + (long long)v->n_tail * p->B * p->S : VIHDS_E_UNSUPPORTED;
   }
   const ModelEntry* e = entry(p->model);
@@ -381,25 +386,32 @@ int vihds_problem_n_slots(const vihds_ode_problem* p) {
   return vihds_model_n_slots(p->model);
 }
 int vihds_blackbox_gram_on_chip(const vihds_ode_problem* p) {
-  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_builtin(p)) return 0;
+  if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return 0;
+  if (!bb_builtin(p)) {
+    const BbVariant* v = bb_sized(p);
+    return v && bb_sized_gram(v, p) ? 1 : 0;
+  }
   return bb_gram_on_chip(p->solver, p->kernel_variant);
 }
 long long vihds_blackbox_tail_offset_floats(const vihds_ode_problem* p) {
   if (!p || p->model != VIHDS_MODEL_DR_BLACKBOX) return VIHDS_E_BADARG;
   if (!bb_builtin(p)) {
     const BbVariant* v = bb_sized(p);
+    if (v && bb_sized_gram(v, p)) return v->gram_floats(p->B * p->S);
     return v ? bb_sized_dump_floats(v, p) : VIHDS_E_UNSUPPORTED;
   }
   return bb_tail_offset_floats(p->B * p->S, p->T, p->solver, p->kernel_variant);
 }
 int vihds_blackbox_gram_reduce(const vihds_ode_problem* p, const float* aux, float* g_weights, void* stream) {
   if (!p || !aux || !g_weights) return fail(VIHDS_E_BADARG, "null argument");
-  if (p->model != VIHDS_MODEL_DR_BLACKBOX || !bb_builtin(p) || !bb_gram_on_chip(p->solver, p->kernel_variant))
+  if (p->model != VIHDS_MODEL_DR_BLACKBOX || !vihds_blackbox_gram_on_chip(p))
     return fail(VIHDS_E_BADARG, "vihds_blackbox_gram_reduce: not an on-chip Gram problem (see vihds_blackbox_gram_on_chip)");
   const ModelEntry* e = entry(p->model);
+  const BbVariant* v = bb_builtin(p) ? nullptr : bb_sized(p);
   OdeArgs a;
-  if (int rc = build_args(p, e, a)) return rc;
-  bb_gram_reduce(a, aux, g_weights, (hipStream_t)stream);
+  if (int rc = build_args(p, e, a, v)) return rc;
+  if (v) v->gram_reduce(a, aux, g_weights, (hipStream_t)stream);
+  else bb_gram_reduce(a, aux, g_weights, (hipStream_t)stream);
   return check_hip("vihds_blackbox_gram_reduce launch");
 }
 

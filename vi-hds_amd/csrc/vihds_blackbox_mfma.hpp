@@ -14,7 +14,8 @@
 // lane that owns it (row 4q+0 = prod_q, 4q+1 = degr_q, 4q+2 = prod_{4+q}, 4q+3 = degr_{4+q}).
 //
 // Hidden units are renumbered into "slots" so that the 25 (states) / 20 (precisions) units need only 7 / 5 K-steps:
-//   slots 0..15 = units 0..15;  tile 1: register 0 -> units 16..19 (q = 0..3), register 1 -> 20..23, register 2, q=0 -> 24.
+//   slots 0..15 = units 0..15;  tile 1: register 0 -> units 16..19 (q = 0..3), register 1 -> 20..23, register 2, q=0 -> 24
+// (in general: full tiles keep their order, the last tile's units fill register 0 of the four quarters first).
 //
 // Per RHS evaluation: 20 MFMAs forward (8 first-layer, 12 second-layer); the adjoint adds 24 transposed ones.  The
 // 21 time-invariant inputs are folded into the first layers' accumulator initial values by 24 MFMAs in the prologue.
@@ -31,33 +32,45 @@ namespace vihds {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct BbMfma {
-  using BB = Blackbox<2, 25, 20, 5, 5, 2>;
-  static constexpr int NX = 6, HS = 25, HP = 20, NLAT = 12;
+// The size-generic part (round 3): everything the cooperating-wavefront kernels (vihds_blackbox_split.hpp) use, for
+// n_latent_species = 2 and up to 64 / 32 hidden units (MS / MP tiles of 16) -- the reference's default
+// n_hidden_decoder = 50 (vihds/config.py:71) included -- and up to 16 latent theta inputs.
+template <class BBT, int HSV, int HPV, int NLATV>
+struct BbMfmaT {
+  using BB = BBT;
+  static constexpr int NX = 6, HS = HSV, HP = HPV, NLAT = NLATV;
   static constexpr int TPW = 16, TPB = 64;  // trajectories per wave / per 256-thread block
   // 16-trajectory groups = partial Gram tile sets the adjoint with on-chip weight gradients leaves (vihds_blackbox_split.hpp)
   __host__ __device__ static int gram_groups(int n) { return (n + TPW - 1) / TPW; }
-  static constexpr int KS = 7, KP = 5;      // second-layer K-steps (states, precisions)
+  // hidden tiles of 16 slots; second-layer K-steps: four per full tile, ceil(units / 4) for the last one (its units are
+  // numbered down the registers first: unit j of the tile sits in register j / 4 of quarter j % 4)
+  __host__ __device__ static constexpr int tiles(int n) { return (n + 15) / 16; }
+  __host__ __device__ static constexpr int ksteps(int n) { return 4 * (tiles(n) - 1) + (n - 16 * (tiles(n) - 1) + 3) / 4; }
+  static constexpr int MS = tiles(HS), MP = tiles(HP), MT = MS > MP ? MS : MP;
+  static constexpr int KS = ksteps(HS), KP = ksteps(HP);  // (25 / 20 units: 7 / 5)
+  static constexpr int NG = 2 * MS + 2 * MP;               // Gram tiles per 16-trajectory group
+  static_assert(MS <= 4 && MP <= 2 && NLAT <= 16, "matrix-core dr_blackbox: at most 64 / 32 hidden units, 16 latent inputs");
 
   __device__ static f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
-  // hidden slot (0..31) -> unit id or -1
-  __device__ static int unit_of(int slot, int n_units) {
-    if (slot < 16) return slot < n_units ? slot : -1;
-    const int r = (slot - 16) & 3, qq = (slot - 16) >> 2;
-    const int u = r == 0 ? 16 + qq : (r == 1 ? 20 + qq : (r == 2 && qq == 0 ? 24 : -1));
-    return (u >= 0 && u < n_units) ? u : -1;
+  // hidden slot (16 m + 4 q + r) -> unit id or -1
+  __host__ __device__ static int unit_of(int slot, int n_units) {
+    const int M = (n_units + 15) / 16, m = slot >> 4;
+    if (m >= M) return -1;
+    if (m < M - 1) return slot;
+    const int base = 16 * (M - 1), local = slot - base, r = local & 3, qq = local >> 2, j = 4 * r + qq;
+    return j < n_units - base ? base + j : -1;
   }
   // K-step s of a second layer -> (tile m, register r)
-  __device__ __host__ static constexpr int step_m(int s) { return s < 4 ? 0 : 1; }
-  __device__ __host__ static constexpr int step_r(int s) { return s < 4 ? s : s - 4; }
+  __device__ __host__ static constexpr int step_m(int s) { return s >> 2; }
+  __device__ __host__ static constexpr int step_r(int s) { return s & 3; }
 
   struct Weights {  // A operands (one VGPR each) and second-layer biases, gathered once per kernel
-    float w1s[2][2], w2s[KS], w1p[2][2], w2p[KP];
+    float w1s[MS][2], w2s[KS], w1p[MP][2], w2p[KP];
     f32x4 b2s, b2p;
   };
   struct WeightsT {  // transposed operands for the adjoint
-    float w2sT[2][4], w1sT[KS], w2pT[2][2], w1pT[KP];
+    float w2sT[MS][4], w1sT[KS], w2pT[MP][2], w1pT[KP];
   };
 
   // input feature of first-layer K-step s for k-slot kq: 0..5 state, 6 = time, -1 = none
@@ -68,15 +81,15 @@ struct BbMfma {
   __device__ static int l2p_out(int i) { return (i & 3) < 2 ? (i >> 2) : -1; }
 
   __device__ static void gather(const OdeArgs& a, int lane, Weights& W) {
-    const BB::Off o = BB::offsets(a.n_const);
+    const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
     const int i = lane & 15, kq = lane >> 4;
-    _Pragma("unroll") for (int m = 0; m < 2; ++m)
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {
         const int in = l1_input(s, kq);
         const int us = unit_of(16 * m + i, HS), up = unit_of(16 * m + i, HP);
-        W.w1s[m][s] = (us >= 0 && in >= 0 && in < 6) ? w[o.wh + us * o.nin_s + in] : 0.f;
-        W.w1p[m][s] = (up >= 0 && in >= 0) ? w[o.vh + up * o.nin_p + (in == 6 ? 0 : 1 + in)] : 0.f;
+        if (m < MS) W.w1s[m < MS ? m : 0][s] = (us >= 0 && in >= 0 && in < 6) ? w[o.wh + us * o.nin_s + in] : 0.f;
+        if (m < MP) W.w1p[m < MP ? m : 0][s] = (up >= 0 && in >= 0) ? w[o.vh + up * o.nin_p + (in == 6 ? 0 : 1 + in)] : 0.f;
       }
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {
       const int u = unit_of(16 * step_m(s) + 4 * kq + step_r(s), HS);
@@ -99,19 +112,19 @@ struct BbMfma {
     }
   }
   __device__ static void gather_t(const OdeArgs& a, int lane, WeightsT& W) {
-    const BB::Off o = BB::offsets(a.n_const);
+    const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
     const int i = lane & 15, kq = lane >> 4;
     // d h[slot 16m+i] = sum_rows W2[row][unit] d z[row]; K-step r carries rows 4kq + r
-    _Pragma("unroll") for (int m = 0; m < 2; ++m) {
+    _Pragma("unroll") for (int m = 0; m < MT; ++m) {
       const int us = unit_of(16 * m + i, HS), up = unit_of(16 * m + i, HP);
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {
         const int row = 4 * kq + r, st = l2s_state(row);
-        W.w2sT[m][r] = (us >= 0 && st >= 0) ? w[(l2s_degr(row) ? o.wd : o.wp) + st * HS + us] : 0.f;
+        if (m < MS) W.w2sT[m < MS ? m : 0][r] = (us >= 0 && st >= 0) ? w[(l2s_degr(row) ? o.wd : o.wp) + st * HS + us] : 0.f;
       }
       _Pragma("unroll") for (int r = 0; r < 2; ++r) {
         const int row = 4 * kq + r, ou = l2p_out(row);
-        W.w2pT[m][r] = (up >= 0 && ou >= 0) ? w[((row & 1) ? o.vd : o.vp) + ou * HP + up] : 0.f;
+        if (m < MP) W.w2pT[m < MP ? m : 0][r] = (up >= 0 && ou >= 0) ? w[((row & 1) ? o.vd : o.vp) + ou * HP + up] : 0.f;
       }
     }
     // d y[row i]: row 4q'+0 = state q', row 4q'+1 = state 4+q' (q' < 2); K-step (m, r) carries hidden slot 16m + 4kq + r
@@ -134,11 +147,11 @@ struct BbMfma {
     return 0.f;
   }
   // hoisted first-layer accumulator initial values hc[net][tile] (C layout) via MFMA over the constant inputs
-  __device__ static void hoist(const OdeArgs& a, int lane, int i, int b, f32x4 hc[2][2]) {
-    const BB::Off o = BB::offsets(a.n_const);
+  __device__ static void hoist(const OdeArgs& a, int lane, int i, int b, f32x4 hc[2][MT]) {
+    const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
     const int ii = lane & 15, kq = lane >> 4, q = lane >> 4;
-    _Pragma("unroll") for (int m = 0; m < 2; ++m)
+    _Pragma("unroll") for (int m = 0; m < MT; ++m)
       _Pragma("unroll") for (int r = 0; r < 4; ++r) {
         const int us = unit_of(16 * m + 4 * q + r, HS), up = unit_of(16 * m + 4 * q + r, HP);
         hc[0][m][r] = us >= 0 ? w[o.bh + us] : 0.f;
@@ -148,16 +161,85 @@ struct BbMfma {
     for (int s = 0; s < nsteps; ++s) {
       const int c = 4 * s + kq;
       const float bval = const_input(a, c, i, b);
-      _Pragma("unroll") for (int m = 0; m < 2; ++m) {
+      _Pragma("unroll") for (int m = 0; m < MT; ++m) {
         const int us = unit_of(16 * m + ii, HS), up = unit_of(16 * m + ii, HP);
         const float as_ = (us >= 0 && c < a.n_const) ? w[o.wh + us * o.nin_s + NX + c] : 0.f;
         const float ap_ = (up >= 0 && c < a.n_const) ? w[o.vh + up * o.nin_p + 1 + NX + c] : 0.f;
-        hc[0][m] = mfma(as_, bval, hc[0][m]);
-        hc[1][m] = mfma(ap_, bval, hc[1][m]);
+        if (m < MS) hc[0][m] = mfma(as_, bval, hc[0][m]);
+        if (m < MP) hc[1][m] = mfma(ap_, bval, hc[1][m]);
       }
     }
   }
 
+  // ---- weight gradients on chip (round 2) -------------------------------------------------------------------------
+  // Every Gram-type weight gradient is  G[i][j] = sum over (evaluation, trajectory) of X[i][traj] Y[j][traj]  with X a
+  // tile of pre-activation adjoints and Y a tile of layer inputs, both already in registers in the C/D layout (lane =
+  // (trajectory, quarter)).  The contraction index of an MFMA is K, so the tiles are turned into "row" layout -- lane
+  // (row i, k-slot kq), register s = T[i][trajectory 4s + kq], which is the A layout and the B layout at once -- through
+  // a per-wavefront LDS buffer (one 16-byte store and four loads per tile), and 32 MFMAs per evaluation accumulate the
+  // eight 16x16 output tiles in registers:
+  //   tiles 0,1: d z (states' 2nd layer, 16 rows) x h[m]     -> Wp / Wd        tiles 2,3: gs[m] x inputs -> Wh
+  //   tiles 4,5: d zp (precisions' 2nd layer)     x g[m]     -> Vp / Vd        tiles 6,7: gp[m] x inputs -> Vh
+  // The 573 MB per-evaluation dump and its contraction pass (vihds_gram_blocks) disappear; a wavefront leaves 8 KB of
+  // partial sums, added up in a fixed order by bb_gram_reduce_kernel.
+  static constexpr int GT_LD = 20, GT_TILE = 16 * GT_LD, GT_NT = 3 + 2 * MS + 2 * MP, GT_WAVE = GT_NT * GT_TILE;  // floats
+  // LDS tile slots of one hand-over: dz, dzp, inputs, then h[m], gs[m] (states), g[m], gp[m] (precisions)
+  static constexpr int T_DZ = 0, T_DZP = 1, T_IN = 2, T_H = 3, T_GS = T_H + MS, T_G = T_GS + MS, T_GP = T_G + MP;
+  __device__ __forceinline__ static void lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  }
+  __device__ __forceinline__ static void put_cols(float* buf, const f32x4& t, int lane) {
+    *reinterpret_cast<f32x4*>(buf + (lane & 15) * GT_LD + 4 * (lane >> 4)) = t;
+  }
+  __device__ __forceinline__ static f32x4 get_rows(const float* buf, int lane) {
+    f32x4 o;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) o[s] = buf[(4 * s + (lane >> 4)) * GT_LD + (lane & 15)];
+    return o;
+  }
+  __device__ __forceinline__ static void gram_acc(f32x4& G, const f32x4& X, const f32x4& Y) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) G = mfma(X[s], Y[s], G);
+  }
+  // workgroup barrier for data handed over through LDS (waits for this wavefront's LDS operations only: the main
+  // wavefronts keep their global prefetches in flight across it)
+  __device__ __forceinline__ static void pair_sync() {
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  // weight index of element (tile, lane, register) of a group's partial sums, or -1.  Tiles: [0, MS) dz x h[m] -> Wp / Wd;
+  // [MS, 2 MS) gs[m] x inputs -> Wh; [2 MS, 2 MS + MP) dzp x g[m] -> Vp / Vd; [2 MS + MP, NG) gp[m] x inputs -> Vh
+  __host__ __device__ static int gram_dest(int tile, int lane, int reg, int n_const) {
+    const typename BB::Off o = BB::offsets(n_const);
+    const int row = 4 * (lane >> 4) + reg, col = lane & 15;
+    // the input tile's rows: 4q = state q, 4q+1 = latent state 4+q (q < 2), row 2 = time
+    auto input_of = [](int j) { return (j & 3) == 0 ? (j >> 2) : (((j & 3) == 1 && (j >> 2) < 2) ? 4 + (j >> 2) : (j == 2 ? 6 : -1)); };
+    if (tile < MS) {
+      const int u = unit_of(16 * tile + col, HS), st = l2s_state_h(row);
+      return (u >= 0 && st >= 0) ? ((row & 1) ? o.wd : o.wp) + st * HS + u : -1;
+    }
+    if (tile < 2 * MS) {
+      const int u = unit_of(16 * (tile - MS) + row, HS), in = input_of(col);
+      return (u >= 0 && in >= 0 && in < 6) ? o.wh + u * o.nin_s + in : -1;
+    }
+    if (tile < 2 * MS + MP) {
+      const int u = unit_of(16 * (tile - 2 * MS) + col, HP), ou = (row & 3) < 2 ? (row >> 2) : -1;
+      return (u >= 0 && ou >= 0) ? ((row & 1) ? o.vd : o.vp) + ou * HP + u : -1;
+    }
+    const int u = unit_of(16 * (tile - 2 * MS - MP) + row, HP), in = input_of(col);
+    return (u >= 0 && in >= 0) ? o.vh + u * o.nin_p + (in == 6 ? 0 : 1 + in) : -1;
+  }
+  __host__ __device__ static int l2s_state_h(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < 2 ? 4 + qq : -1); }
+  // floats of aux ahead of the tail when the Gram tiles are accumulated on chip
+  __host__ __device__ static size_t gram_floats(int n) { return (size_t)gram_groups(n) * NG * 256; }
+};
+
+// ---- the ICML sizes (specs/dr_blackbox_icml.yaml:17-31) with the one-wavefront-per-group formulation on top -------------
+struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 25, 20, 12> {
   struct State {  // one lane's share of a trajectory: state q, latent state 4+q (q < 2), precision q
     float a, b, v;
   };
@@ -224,73 +306,6 @@ struct BbMfma {
               y.v + (k1.v + 3.f * k2.v + 3.f * k3.v + k4.v) * d8};
     }
   }
-
-  // ---- weight gradients on chip (round 2) -------------------------------------------------------------------------
-  // Every Gram-type weight gradient is  G[i][j] = sum over (evaluation, trajectory) of X[i][traj] Y[j][traj]  with X a
-  // tile of pre-activation adjoints and Y a tile of layer inputs, both already in registers in the C/D layout (lane =
-  // (trajectory, quarter)).  The contraction index of an MFMA is K, so the tiles are turned into "row" layout -- lane
-  // (row i, k-slot kq), register s = T[i][trajectory 4s + kq], which is the A layout and the B layout at once -- through
-  // a per-wavefront LDS buffer (one 16-byte store and four loads per tile), and 32 MFMAs per evaluation accumulate the
-  // eight 16x16 output tiles in registers:
-  //   tiles 0,1: d z (states' 2nd layer, 16 rows) x h[m]     -> Wp / Wd        tiles 2,3: gs[m] x inputs -> Wh
-  //   tiles 4,5: d zp (precisions' 2nd layer)     x g[m]     -> Vp / Vd        tiles 6,7: gp[m] x inputs -> Vh
-  // The 573 MB per-evaluation dump and its contraction pass (vihds_gram_blocks) disappear; a wavefront leaves 8 KB of
-  // partial sums, added up in a fixed order by bb_gram_reduce_kernel.
-  static constexpr int GT_LD = 20, GT_TILE = 16 * GT_LD, GT_NT = 11, GT_WAVE = GT_NT * GT_TILE;  // floats
-  __device__ __forceinline__ static void lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
-  __device__ __forceinline__ static void put_cols(float* buf, const f32x4& t, int lane) {
-    *reinterpret_cast<f32x4*>(buf + (lane & 15) * GT_LD + 4 * (lane >> 4)) = t;
-  }
-  __device__ __forceinline__ static f32x4 get_rows(const float* buf, int lane) {
-    f32x4 o;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) o[s] = buf[(4 * s + (lane >> 4)) * GT_LD + (lane & 15)];
-    return o;
-  }
-  __device__ __forceinline__ static void gram_acc(f32x4& G, const f32x4& X, const f32x4& Y) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) G = mfma(X[s], Y[s], G);
-  }
-  // workgroup barrier for data handed over through LDS (waits for this wavefront's LDS operations only: the main
-  // wavefronts keep their global prefetches in flight across it)
-  __device__ __forceinline__ static void pair_sync() {
-    asm volatile("" ::: "memory");
-    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-  }
-  // weight index of element (tile, lane, register) of a wavefront's partial sums, or -1
-  __host__ __device__ static int gram_dest(int tile, int lane, int reg, int n_const) {
-    const BB::Off o = BB::offsets(n_const);
-    const int row = 4 * (lane >> 4) + reg, col = lane & 15, m = tile & 1;
-    // the input tile's rows: 4q = state q, 4q+1 = latent state 4+q (q < 2), row 2 = time
-    auto input_of = [](int j) { return (j & 3) == 0 ? (j >> 2) : (((j & 3) == 1 && (j >> 2) < 2) ? 4 + (j >> 2) : (j == 2 ? 6 : -1)); };
-    if (tile < 2) {
-      const int u = unit_of_h(16 * m + col, HS), st = l2s_state_h(row);
-      return (u >= 0 && st >= 0) ? ((row & 1) ? o.wd : o.wp) + st * HS + u : -1;
-    }
-    if (tile < 4) {
-      const int u = unit_of_h(16 * m + row, HS), in = input_of(col);
-      return (u >= 0 && in >= 0 && in < 6) ? o.wh + u * o.nin_s + in : -1;
-    }
-    if (tile < 6) {
-      const int u = unit_of_h(16 * m + col, HP), ou = (row & 3) < 2 ? (row >> 2) : -1;
-      return (u >= 0 && ou >= 0) ? ((row & 1) ? o.vd : o.vp) + ou * HP + u : -1;
-    }
-    const int u = unit_of_h(16 * m + row, HP), in = input_of(col);
-    return (u >= 0 && in >= 0) ? o.vh + u * o.nin_p + (in == 6 ? 0 : 1 + in) : -1;
-  }
-  __host__ __device__ static int unit_of_h(int slot, int n_units) {
-    if (slot < 16) return slot < n_units ? slot : -1;
-    const int r = (slot - 16) & 3, qq = (slot - 16) >> 2;
-    const int u = r == 0 ? 16 + qq : (r == 1 ? 20 + qq : (r == 2 && qq == 0 ? 24 : -1));
-    return (u >= 0 && u < n_units) ? u : -1;
-  }
-  __host__ __device__ static int l2s_state_h(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < 2 ? 4 + qq : -1); }
 
   struct Dump {
     float* base;     // &aux[i]
@@ -471,7 +486,7 @@ __global__ void __launch_bounds__(256) bb_mfma_fwd_kernel(OdeArgs a) {
 // floats of aux ahead of the tail (Delta, bias sums): the per-evaluation dump, or the wavefronts' Gram partial sums
 __host__ __device__ inline size_t bb_mfma_head_floats(int n, int T, int solver, bool gram) {
   using BB = BbMfma::BB;
-  if (gram) return (size_t)BbMfma::gram_groups(n) * 8 * 256;
+  if (gram) return BbMfma::gram_floats(n);
   return (size_t)(T - 1) * BB::stages(solver) * BB::NF * n;
 }
 
@@ -585,24 +600,26 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
 // sums the wavefronts' partial tiles in a fixed order (deterministic) and scatters them into the flat weight gradient.
 // One block = 64 elements of a tile x 16 interleaved slices of the wavefronts (as one thread per element walking all
 // 450 wavefronts -- 113 dependent rounds of loads -- this took 39 us).
+template <class K>
 __global__ void __launch_bounds__(1024) bb_gram_reduce_kernel(int n_waves, int n_const, const float* __restrict__ partial,
                                                               float* __restrict__ g_weights) {
   __shared__ float part[16][64];
+  constexpr size_t SET = (size_t)K::NG * 256;  // floats of one group's partial tiles
   const int tile = blockIdx.x >> 2, e = (blockIdx.x & 3) * 64 + (threadIdx.x & 63), slice = threadIdx.x >> 6;
   const float* src = partial + (size_t)tile * 256 + e;
   float acc0 = 0.f, acc1 = 0.f, acc2 = 0.f, acc3 = 0.f;
   int w = slice;
   for (; w + 48 < n_waves; w += 64) {
-    acc0 += src[(size_t)(w + 0) * 2048];
-    acc1 += src[(size_t)(w + 16) * 2048];
-    acc2 += src[(size_t)(w + 32) * 2048];
-    acc3 += src[(size_t)(w + 48) * 2048];
+    acc0 += src[(size_t)(w + 0) * SET];
+    acc1 += src[(size_t)(w + 16) * SET];
+    acc2 += src[(size_t)(w + 32) * SET];
+    acc3 += src[(size_t)(w + 48) * SET];
   }
-  for (; w < n_waves; w += 16) acc0 += src[(size_t)w * 2048];
+  for (; w < n_waves; w += 16) acc0 += src[(size_t)w * SET];
   part[slice][threadIdx.x & 63] = (acc0 + acc1) + (acc2 + acc3);
   __syncthreads();
   if (slice == 0) {
-    const int dest = BbMfma::gram_dest(tile, e >> 2, e & 3, n_const);
+    const int dest = K::gram_dest(tile, e >> 2, e & 3, n_const);
     if (dest >= 0) {
       float t = 0.f;
 #pragma unroll
@@ -611,13 +628,15 @@ __global__ void __launch_bounds__(1024) bb_gram_reduce_kernel(int n_waves, int n
     }
   }
 }
+template <class K>
 inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
-  const int n_waves = BbMfma::gram_groups(a.n);
-  hipLaunchKernelGGL(bb_gram_reduce_kernel, dim3(32), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
+  const int n_waves = K::gram_groups(a.n);
+  hipLaunchKernelGGL((bb_gram_reduce_kernel<K>), dim3(K::NG * 4), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
 }
 
 // the one-wavefront-per-group kernels: forward, and the adjoint that dumps every evaluation for vihds_gram_blocks
 // (kernel_variant 4, round 1's weight-gradient path).  The default path is vihds_blackbox_split.hpp.
+template <class KDUMMY = BbMfma>  // (a template so that a side library that only wants BbMfmaT does not compile these kernels)
 inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
 #define VIHDS_BCASE(SV)                                                                                  \

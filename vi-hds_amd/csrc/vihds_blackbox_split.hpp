@@ -37,9 +37,13 @@ static __device__ unsigned long long* vihds_bb_stamp_buf = nullptr;
 #define VIHDS_BB_STOP
 #endif
 
-struct BbSplit {
-  using K = BbMfma;
-  using BB = K::BB;
+template <class KT>
+struct BbSplitT {
+  using K = KT;
+  using BB = typename K::BB;
+  using Weights = typename K::Weights;
+  using WeightsT = typename K::WeightsT;
+  static constexpr int MT = K::MT;
   // LDS of the adjoint (floats): tiles [2][GT_WAVE] | inputs [2][64][2] | input adjoints [2][64][2] | gc [64][4]
   static constexpr int O_IN = 2 * K::GT_WAVE, O_DY = O_IN + 256, O_GC = O_DY + 256, LDS_BWD = O_GC + 256;
   static constexpr int LDS_FWD = 256;  // inputs [2][64][2]
@@ -56,44 +60,34 @@ struct BbSplit {
 
   // ---- one network: first layer (two tiles, two K-steps) -> ReLU -> second layer -> pre-sigmoid outputs ---------------
   template <int NET>
-  __device__ __forceinline__ static f32x4 net_eval(float b0, float b1, const K::Weights& W, const f32x4 hc[2][2], f32x4 h[2]) {
-    f32x4 h0, h1;
-    if (NET == 0) {
-      h0 = K::mfma(W.w1s[0][1], b1, K::mfma(W.w1s[0][0], b0, hc[0][0]));
-      h1 = K::mfma(W.w1s[1][1], b1, K::mfma(W.w1s[1][0], b0, hc[0][1]));
-    } else {
-      h0 = K::mfma(W.w1p[0][1], b1, K::mfma(W.w1p[0][0], b0, hc[1][0]));
-      h1 = K::mfma(W.w1p[1][1], b1, K::mfma(W.w1p[1][0], b0, hc[1][1]));
+  __device__ __forceinline__ static f32x4 net_eval(float b0, float b1, const Weights& W, const f32x4 hc[2][MT],
+                                                   f32x4 h[NET == 0 ? K::MS : K::MP]) {
+    constexpr int M = NET == 0 ? K::MS : K::MP, KN = NET == 0 ? K::KS : K::KP;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      if (NET == 0) h[m] = K::mfma(W.w1s[m < K::MS ? m : 0][1], b1, K::mfma(W.w1s[m < K::MS ? m : 0][0], b0, hc[0][m]));
+      else h[m] = K::mfma(W.w1p[m < K::MP ? m : 0][1], b1, K::mfma(W.w1p[m < K::MP ? m : 0][0], b0, hc[1][m]));
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) { h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f); }
+    for (int m = 0; m < M; ++m)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.f);
     f32x4 z = NET == 0 ? W.b2s : W.b2p;
-    if (NET == 0) {
 #pragma unroll
-      for (int s = 0; s < K::KS; ++s) z = K::mfma(W.w2s[s], K::step_m(s) ? h1[K::step_r(s)] : h0[K::step_r(s)], z);
-    } else {
-#pragma unroll
-      for (int s = 0; s < K::KP; ++s) z = K::mfma(W.w2p[s], K::step_m(s) ? h1[K::step_r(s)] : h0[K::step_r(s)], z);
-    }
-    h[0] = h0; h[1] = h1;
+    for (int s = 0; s < KN; ++s) z = K::mfma(NET == 0 ? W.w2s[s < K::KS ? s : 0] : W.w2p[s < K::KP ? s : 0], h[K::step_m(s)][K::step_r(s)], z);
     return z;
   }
   // transposed layers: second-layer adjoint dz -> hidden pre-activation adjoints g (masked by the ReLU, added to delta)
   // -> input adjoint (rows 4q'+0 = state q', 4q'+1 = latent state 4+q')
   template <int NET>
-  __device__ __forceinline__ static f32x4 net_vjp(const f32x4& dz, const f32x4 h[2], const K::WeightsT& WT, f32x4 g[2],
-                                                  f32x4 delta[2]) {
+  __device__ __forceinline__ static f32x4 net_vjp(const f32x4& dz, const f32x4* h, const WeightsT& WT, f32x4* g, f32x4* delta) {
+    constexpr int M = NET == 0 ? K::MS : K::MP, KN = NET == 0 ? K::KS : K::KP, NR = NET == 0 ? 4 : 2;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int m = 0; m < 2; ++m) {
+    for (int m = 0; m < M; ++m) {
       f32x4 acc = zero;
-      if (NET == 0) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = K::mfma(WT.w2sT[m][r], dz[r], acc);
-      } else {
-#pragma unroll
-        for (int r = 0; r < 2; ++r) acc = K::mfma(WT.w2pT[m][r], dz[r], acc);
-      }
+      for (int r = 0; r < NR; ++r) acc = K::mfma(NET == 0 ? WT.w2sT[m < K::MS ? m : 0][r] : WT.w2pT[m < K::MP ? m : 0][r < 2 ? r : 0], dz[r], acc);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         g[m][r] = h[m][r] > 0.f ? acc[r] : 0.f;
@@ -101,13 +95,8 @@ struct BbSplit {
       }
     }
     f32x4 dy = zero;
-    if (NET == 0) {
 #pragma unroll
-      for (int s = 0; s < K::KS; ++s) dy = K::mfma(WT.w1sT[s], g[K::step_m(s)][K::step_r(s)], dy);
-    } else {
-#pragma unroll
-      for (int s = 0; s < K::KP; ++s) dy = K::mfma(WT.w1pT[s], g[K::step_m(s)][K::step_r(s)], dy);
-    }
+    for (int s = 0; s < KN; ++s) dy = K::mfma(NET == 0 ? WT.w1sT[s < K::KS ? s : 0] : WT.w1pT[s < K::KP ? s : 0], g[K::step_m(s)][K::step_r(s)], dy);
     return dy;
   }
 
@@ -121,8 +110,8 @@ struct BbSplit {
   // forward
   // ======================================================================================================================
   struct FwdA {
-    const K::Weights& W;
-    const f32x4 (*hc)[2];
+    const Weights& W;
+    const f32x4 (*hc)[MT];
     float* pub;  // [2][64][2]
     int lane, q, e;
     // publish the inputs of the next evaluation, hand over, evaluate the state network there
@@ -131,7 +120,7 @@ struct BbSplit {
       *reinterpret_cast<float2*>(pub + ((e & 1) * 64 + lane) * 2) = make_float2(b0, b1);
       ++e;
       sync();
-      f32x4 h[2];
+      f32x4 h[K::MS];
       const f32x4 z = net_eval<0>(b0, b1, W, hc, h);
       SA d;
       d.a = bb_sigmoid(z[0]) - bb_sigmoid(z[1]) * y.a;
@@ -140,8 +129,8 @@ struct BbSplit {
     }
   };
   struct FwdB {
-    const K::Weights& W;
-    const f32x4 (*hc)[2];
+    const Weights& W;
+    const f32x4 (*hc)[MT];
     const float* pub;
     int lane, e;
     float b0, b1;  // the inputs of the last hand-over
@@ -152,7 +141,7 @@ struct BbSplit {
       b0 = in.x; b1 = in.y;
     }
     __device__ __forceinline__ float rate(float v) {  // dv/dt at the inputs last taken
-      f32x4 g[2];
+      f32x4 g[K::MP];
       const f32x4 zp = net_eval<1>(b0, b1, W, hc, g);
       return bb_sigmoid(zp[0]) - bb_sigmoid(zp[1]) * v;
     }
@@ -214,10 +203,9 @@ struct BbSplit {
 };
 
 // grid: one block of two wavefronts per 16 trajectories
-template <int SOLVER>
+template <class K, int SOLVER>
 __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
-  using K = BbMfma;
-  using S = BbSplit;
+  using S = BbSplitT<K>;
   __shared__ float pub[S::LDS_FWD];
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
   const int jj = lane & 15, q = lane >> 4;
@@ -226,14 +214,14 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
   const size_t n = a.n;
-  K::Weights W;
+  typename K::Weights W;
   K::gather(a, lane, W);
-  f32x4 hc[2][2];
+  f32x4 hc[2][K::MT];
   K::hoist(a, lane, i, b, hc);
   const float h0 = a.times[1] - a.times[0];
   if (role == 0) {
-    S::FwdA F = {W, hc, pub, lane, q, 0};
-    S::SA y;
+    typename S::FwdA F = {W, hc, pub, lane, q, 0};
+    typename S::SA y;
     y.a = a.theta[(size_t)a.slot_row[K::NLAT + q] * n + i];  // init_x, init_rfp, init_yfp, init_cfp
     y.b = q < 2 ? a.init_latent : 0.f;
     float tA = a.times[0], tB = a.times[1];
@@ -256,7 +244,7 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
     *reinterpret_cast<float2*>(pub + ((F.e & 1) * 64 + lane) * 2) = make_float2(y.a, S::in1(y, tA, q));
     S::sync();
   } else {
-    S::FwdB F = {W, hc, pub, lane, 0, 0.f, 0.f};
+    typename S::FwdB F = {W, hc, pub, lane, 0, 0.f, 0.f};
     float v = a.init_prec, lp = 0.f;
     const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
     float ob_cur = a.logp ? ob[0] : 0.f;
@@ -284,11 +272,10 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
 // ======================================================================================================================
 // grid: one block of four wavefronts (A, B, H1, H2) per 16 trajectories.  aux: the groups' partial Gram tiles
 // [group][8][256] (H1 tiles 0-3, H2 tiles 4-7), then the tail (Delta, bias sums) exactly as bb_mfma_bwd_kernel leaves it.
-template <int SOLVER>
+template <class K, int SOLVER>
 __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
-  using K = BbMfma;
-  using S = BbSplit;
-  using BB = K::BB;
+  using S = BbSplitT<K>;
+  using BB = typename K::BB;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_BWD];
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
   const int jj = lane & 15, q = lane >> 4;
@@ -303,7 +290,11 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   if (role >= 2) {
     // ---- Gram helpers: H1 (role 2) the state network's tiles 0-3, H2 (role 3) the precision network's 4-7 --------------
     const bool st = role == 2;
-    f32x4 G[4] = {zero, zero, zero, zero};
+    constexpr int MH = K::MS > K::MP ? K::MS : K::MP;
+    const int M = st ? K::MS : K::MP;  // tiles of this helper's network: G[m] = dz x h[m], G[MH + m] = g[m] x inputs
+    f32x4 G[2 * MH];
+#pragma unroll
+    for (int tq = 0; tq < 2 * MH; ++tq) G[tq] = zero;
     int e = 0;
     for (int k = 0; k < n_steps; ++k) {
 #ifdef VIHDS_BB_STAMPS
@@ -319,22 +310,28 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
         VIHDS_BB_STOP
         const float* buf = lds + (e & 1) * K::GT_WAVE;
         ++e;
-        const f32x4 X2 = K::get_rows(buf + (st ? 0 : 1) * K::GT_TILE, lane);  // dz | dzp
-        const f32x4 Yin = K::get_rows(buf + 2 * K::GT_TILE, lane);
+        const f32x4 X2 = K::get_rows(buf + (st ? K::T_DZ : K::T_DZP) * K::GT_TILE, lane);
+        const f32x4 Yin = K::get_rows(buf + K::T_IN * K::GT_TILE, lane);
 #pragma unroll
-        for (int m = 0; m < 2; ++m) {
-          const f32x4 Yh = K::get_rows(buf + ((st ? 3 : 4) + 4 * m) * K::GT_TILE, lane);  // h[m] | g[m]
-          K::gram_acc(G[0 + m], X2, Yh);
-          const f32x4 Xg = K::get_rows(buf + ((st ? 5 : 6) + 4 * m) * K::GT_TILE, lane);  // gs[m] | gp[m]
-          K::gram_acc(G[2 + m], Xg, Yin);
+        for (int m = 0; m < MH; ++m) {
+          if (m < M) {
+            const f32x4 Yh = K::get_rows(buf + ((st ? K::T_H : K::T_G) + m) * K::GT_TILE, lane);
+            K::gram_acc(G[m], X2, Yh);
+            const f32x4 Xg = K::get_rows(buf + ((st ? K::T_GS : K::T_GP) + m) * K::GT_TILE, lane);
+            K::gram_acc(G[MH + m], Xg, Yin);
+          }
         }
         VIHDS_BB_STOP
       }
     }
     S::sync();  // (the epilogue's hand-over between A and B)
-    float* gp = a.aux + ((size_t)blockIdx.x * 8 + (st ? 0 : 4)) * 256;
+    float* gp = a.aux + ((size_t)blockIdx.x * K::NG + (st ? 0 : 2 * K::MS)) * 256;  // tile order: see K::gram_dest
 #pragma unroll
-    for (int tq = 0; tq < 4; ++tq) *reinterpret_cast<f32x4*>(gp + tq * 256 + lane * 4) = G[tq];
+    for (int m = 0; m < MH; ++m)
+      if (m < M) {
+        *reinterpret_cast<f32x4*>(gp + m * 256 + lane * 4) = G[m];
+        *reinterpret_cast<f32x4*>(gp + (M + m) * 256 + lane * 4) = G[MH + m];
+      }
     return;
   }
 
@@ -344,13 +341,15 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   const size_t n = a.n;
   const float lm = live ? 1.f : 0.f;  // (tail lanes shadow the last trajectory: their adjoint rows count as zero)
-  K::Weights W;
-  K::WeightsT WT;
+  typename K::Weights W;
+  typename K::WeightsT WT;
   K::gather(a, lane, W);
   K::gather_t(a, lane, WT);
-  f32x4 hc[2][2];
+  f32x4 hc[2][K::MT];
   K::hoist(a, lane, i, b, hc);
-  f32x4 delta[2] = {zero, zero};
+  f32x4 delta[K::MT];
+#pragma unroll
+  for (int m = 0; m < K::MT; ++m) delta[m] = zero;
   const float glp = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)q * n) + i] : 0.f;
   const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
   const float h0 = a.times[1] - a.times[0];
@@ -369,12 +368,12 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   Y3 ynext = load_state(a.T - 1);
   float ob_next = ob[a.T - 1];
   float tHi = a.times[a.T - 1], tLo = tHi;
-  float* dd = a.aux + (size_t)gridDim.x * 8 * 256;  // Delta [HS+HP][n] behind the Gram partial sums
+  float* dd = a.aux + (size_t)gridDim.x * K::NG * 256;  // Delta [HS+HP][n] behind the Gram partial sums
   float* bbp = dd + (size_t)BB::NP * n;              // output-bias adjoint sums
 
   if (role == 0) {
     // ================================ wave A: NeuralStates ============================================================
-    using SA = S::SA;
+    using SA = typename S::SA;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     SA lam = {0.f, 0.f};
     auto publish = [&](const SA& y, float t) {
@@ -385,10 +384,10 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     // One evaluation of the state network: the hidden tiles and the four sigmoids.  An evaluation point that is visited
     // twice in a step (the grid point by every scheme but Euler; rk4's stage points) is evaluated ONCE: the adjoint sweep
     // reuses what the forward pass of the step left (12 registers per point) instead of running the network again.
-    struct ActA { f32x4 h[2]; float sa, sd, sa2, sd2; };
+    struct ActA { f32x4 h[K::MS]; float sa, sd, sa2, sd2; };
     auto act = [&](float t, const SA& y) {
       ActA A;
-      const f32x4 z = S::net_eval<0>(y.a, S::in1(y, t, q), W, hc, A.h);
+      const f32x4 z = S::template net_eval<0>(y.a, S::in1(y, t, q), W, hc, A.h);
       A.sa = bb_sigmoid(z[0]); A.sd = bb_sigmoid(z[1]); A.sa2 = bb_sigmoid(z[2]); A.sd2 = bb_sigmoid(z[3]);
       return A;
     };
@@ -399,7 +398,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       return d;
     };
     auto eval_vjp = [&](float t, const SA& y, const SA& v, const ActA& A) {
-      f32x4 gs[2];
+      f32x4 gs[K::MS];
       SA yb;
       yb.a = -v.a * A.sd;
       yb.b = q < 2 ? -v.b * A.sd2 : 0.f;
@@ -408,16 +407,16 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       dz[1] = -v.a * y.a * A.sd * (1.f - A.sd);
       dz[2] = q < 2 ? v.b * A.sa2 * (1.f - A.sa2) : 0.f;
       dz[3] = q < 2 ? -v.b * y.b * A.sd2 * (1.f - A.sd2) : 0.f;
-      const f32x4 dy = S::net_vjp<0>(dz, A.h, WT, gs, delta);
+      const f32x4 dy = S::template net_vjp<0>(dz, A.h, WT, gs, delta);
       bs[0] += dz[0]; bs[1] += dz[1]; bs[2] += dz[2]; bs[3] += dz[3];
       float* buf = lds + (e_vjp & 1) * K::GT_WAVE;
       const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
-      K::put_cols(buf + 0 * K::GT_TILE, dz * lm, lane);
-      K::put_cols(buf + 2 * K::GT_TILE, xin, lane);
+      K::put_cols(buf + K::T_DZ * K::GT_TILE, dz * lm, lane);
+      K::put_cols(buf + K::T_IN * K::GT_TILE, xin, lane);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        K::put_cols(buf + (3 + 4 * m) * K::GT_TILE, A.h[m], lane);
-        K::put_cols(buf + (5 + 4 * m) * K::GT_TILE, gs[m] * lm, lane);
+      for (int m = 0; m < K::MS; ++m) {
+        K::put_cols(buf + (K::T_H + m) * K::GT_TILE, A.h[m], lane);
+        K::put_cols(buf + (K::T_GS + m) * K::GT_TILE, gs[m] * lm, lane);
       }
       VIHDS_BB_STOP
       S::sync();
@@ -509,7 +508,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     }
     // d loss / d latent theta through the hoisted inputs: (Wc^T)[const x slot] . Delta[slot x traj]; the precision
     // network's share comes from wave B
-    const BB::Off o = BB::offsets(a.n_const);
+    const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
     f32x4 gc = zero;  // rows = constants 0..15 (only the 12 latents are theta)
     _Pragma("unroll") for (int s = 0; s < K::KS; ++s) {
@@ -525,7 +524,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
         if (c < K::NLAT) a.g_theta[(size_t)a.slot_row[c] * n + i] = gc[r] + gcp[r];
       }
       a.g_theta[(size_t)a.slot_row[K::NLAT + q] * n + i] = lam.a;  // init_x .. init_cfp
-      _Pragma("unroll") for (int m = 0; m < 2; ++m)
+      _Pragma("unroll") for (int m = 0; m < K::MS; ++m)
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {
           const int us = K::unit_of(16 * m + 4 * q + r, K::HS);
           if (us >= 0) dd[(size_t)us * n + i] = delta[m][r];
@@ -546,28 +545,28 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       ++e_in;
       return In{in.x, in.y};
     };
-    struct ActB { f32x4 g[2]; float pa, pd; };  // (see ActA)
+    struct ActB { f32x4 g[K::MP]; float pa, pd; };  // (see ActA)
     auto act = [&](const In& in) {
       ActB A;
-      const f32x4 zp = S::net_eval<1>(in.b0, in.b1, W, hc, A.g);
+      const f32x4 zp = S::template net_eval<1>(in.b0, in.b1, W, hc, A.g);
       A.pa = bb_sigmoid(zp[0]); A.pd = bb_sigmoid(zp[1]);
       return A;
     };
     auto rate = [&](const ActB& A, float v) { return A.pa - A.pd * v; };
     auto eval_vjp = [&](float yv, float vv, const ActB& A) {
-      f32x4 gp[2];
+      f32x4 gp[K::MP];
       const float ybv = -vv * A.pd;
       f32x4 dzp = zero;
       dzp[0] = vv * A.pa * (1.f - A.pa);
       dzp[1] = -vv * yv * A.pd * (1.f - A.pd);
-      const f32x4 dy = S::net_vjp<1>(dzp, A.g, WT, gp, delta);
+      const f32x4 dy = S::template net_vjp<1>(dzp, A.g, WT, gp, delta);
       bs[0] += dzp[0]; bs[1] += dzp[1];
       float* buf = lds + (e_vjp & 1) * K::GT_WAVE;
-      K::put_cols(buf + 1 * K::GT_TILE, dzp * lm, lane);
+      K::put_cols(buf + K::T_DZP * K::GT_TILE, dzp * lm, lane);
 #pragma unroll
-      for (int m = 0; m < 2; ++m) {
-        K::put_cols(buf + (4 + 4 * m) * K::GT_TILE, A.g[m], lane);
-        K::put_cols(buf + (6 + 4 * m) * K::GT_TILE, gp[m] * lm, lane);
+      for (int m = 0; m < K::MP; ++m) {
+        K::put_cols(buf + (K::T_G + m) * K::GT_TILE, A.g[m], lane);
+        K::put_cols(buf + (K::T_GP + m) * K::GT_TILE, gp[m] * lm, lane);
       }
       *reinterpret_cast<float2*>(pub_dy + ((e_vjp & 1) * 64 + lane) * 2) = make_float2(dy[0], dy[1]);
       ++e_vjp;
@@ -643,7 +642,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       lam += glp * (0.5f / y.v - 0.5f * e * e);
       if (a.g_traj) lam += a.g_traj[((size_t)k * 10 + 6 + q) * n + i];
     }
-    const BB::Off o = BB::offsets(a.n_const);
+    const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
     f32x4 gc = zero;
     _Pragma("unroll") for (int s = 0; s < K::KP; ++s) {
@@ -654,7 +653,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     *reinterpret_cast<f32x4*>(pub_gc + lane * 4) = gc;
     S::sync();
     if (live) {
-      _Pragma("unroll") for (int m = 0; m < 2; ++m)
+      _Pragma("unroll") for (int m = 0; m < K::MP; ++m)
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {
           const int up = K::unit_of(16 * m + 4 * q + r, K::HP);
           if (up >= 0) dd[(size_t)(K::HS + up) * n + i] = delta[m][r];
@@ -665,24 +664,23 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   }
 }
 
-// partial Gram tile sets the split adjoint leaves (one per 16-trajectory group)
-__host__ __device__ inline int bb_split_groups(int n) { return (n + BbMfma::TPW - 1) / BbMfma::TPW; }
-
+// one fixed-grid scheme (a side library compiles one scheme per object: csrc/sized/)
+template <class K, int SV>
+inline int launch_bb_split_solver(bool backward, const OdeArgs& a, hipStream_t st) {
+  const dim3 grid(K::gram_groups(a.n));
+  if (backward) hipLaunchKernelGGL((bb_split_bwd_kernel<K, SV>), grid, dim3(256), 0, st, a);
+  else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(128), 0, st, a);
+  return VIHDS_OK;
+}
+template <class K>
 inline int launch_bb_split(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
-  const dim3 grid(bb_split_groups(a.n));
-#define VIHDS_BSCASE(SV)                                                                             \
-  case SV:                                                                                           \
-    if (backward) hipLaunchKernelGGL((bb_split_bwd_kernel<SV>), grid, dim3(256), 0, st, a);          \
-    else hipLaunchKernelGGL((bb_split_fwd_kernel<SV>), grid, dim3(128), 0, st, a);                   \
-    return VIHDS_OK;
   switch (solver) {
-    VIHDS_BSCASE(VIHDS_SOLVER_MODEULER)
-    VIHDS_BSCASE(VIHDS_SOLVER_MODEULERWHILE)
-    VIHDS_BSCASE(VIHDS_SOLVER_EULER)
-    VIHDS_BSCASE(VIHDS_SOLVER_MIDPOINT)
-    VIHDS_BSCASE(VIHDS_SOLVER_RK4)
+    case VIHDS_SOLVER_MODEULER: return launch_bb_split_solver<K, VIHDS_SOLVER_MODEULER>(backward, a, st);
+    case VIHDS_SOLVER_MODEULERWHILE: return launch_bb_split_solver<K, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st);
+    case VIHDS_SOLVER_EULER: return launch_bb_split_solver<K, VIHDS_SOLVER_EULER>(backward, a, st);
+    case VIHDS_SOLVER_MIDPOINT: return launch_bb_split_solver<K, VIHDS_SOLVER_MIDPOINT>(backward, a, st);
+    case VIHDS_SOLVER_RK4: return launch_bb_split_solver<K, VIHDS_SOLVER_RK4>(backward, a, st);
   }
-#undef VIHDS_BSCASE
   return VIHDS_E_BADARG;
 }
 

@@ -243,6 +243,12 @@ def ensure_blackbox_variant(L, HS, HP, NLAT):
     if key == BLACKBOX_BUILTIN:
         return None
     path = blackbox_variant_path(*key)
+    if os.path.exists(path):
+        # a side library of an earlier layout of the BbVariant record (no `vihds_bb_variant_v2`): rebuild it
+        with open(path, "rb") as f:
+            stale = b"vihds_bb_variant_v2" not in f.read()
+        if stale and os.environ.get("VIHDS_BLACKBOX_JIT", "1") != "0" and "VIHDS_HIP_LIB" not in os.environ:
+            os.remove(path)
     if not os.path.exists(path):
         import subprocess
 
