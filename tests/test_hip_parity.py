@@ -267,11 +267,12 @@ def test_all_solvers_match_oracle_forward_and_gradient(name, solver):
         assert e_hip < max(GTOL, 8.0 * e32), (n, e_hip, e32)
 
 
-# variant 0 = auto (MFMA formulation at the ICML sizes), 1 = VALU, one thread per trajectory; the "sized" fixture is the
+# variant 0 = auto (matrix-core kernels: the ICML sizes, and since round 3 every size set of <= 3 latent species and
+# <= 64 / 32 hidden units, the "sized" fixture's included), 1 = VALU, one thread per trajectory; the "sized" fixture is the
 # reference run with n_z 4, n_x 3, n_y 1, n_latent_species 3, n_hidden_decoder 12, n_hidden_decoder_precisions 6
 # (models/dr_blackbox.py:61-84 reads them from the YAML): kernels of a side library, libvihds_bb_3_12_6_8.so
 @pytest.mark.parametrize("name,variant", [("dr_blackbox_icml_tiny_modeuler", 0), ("dr_blackbox_icml_tiny_modeuler", 1),
-                                          ("dr_blackbox_sized_tiny_modeuler", 0)])
+                                          ("dr_blackbox_sized_tiny_modeuler", 0), ("dr_blackbox_sized_tiny_modeuler", 1)])
 def test_blackbox_forward_and_gradients_match_reference(name, variant):
     """dr_blackbox (MLP right-hand side): trajectories, precisions, log-likelihood, d loss/d theta and the gradients
     of all shared MLP weights (1 760 at the ICML sizes; adjoint kernel dump + batched GEMMs, or the on-chip Gram

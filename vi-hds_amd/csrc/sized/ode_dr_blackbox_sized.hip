@@ -16,8 +16,9 @@ namespace vihds {
 using BBV = Blackbox<VIHDS_BB_L, VIHDS_BB_HS, VIHDS_BB_HP, VIHDS_BB_NLAT, 0, 0>;
 typedef int (*bb_launch_fn)(bool, int, const OdeArgs&, hipStream_t, AdaptiveCtl*);
 // the matrix-core formulation exists for this size set
-constexpr bool BBV_MFMA = VIHDS_BB_L == 2 && VIHDS_BB_HS <= 64 && VIHDS_BB_HP <= 32 && VIHDS_BB_NLAT <= 16;
-using KV = BbMfmaT<BBV, BBV_MFMA ? VIHDS_BB_HS : 16, BBV_MFMA ? VIHDS_BB_HP : 16, BBV_MFMA ? VIHDS_BB_NLAT : 16>;
+constexpr bool BBV_MFMA = VIHDS_BB_L >= 1 && VIHDS_BB_L <= 3 && VIHDS_BB_HS <= 64 && VIHDS_BB_HP <= 32 && VIHDS_BB_NLAT <= 16;
+using KV = BbMfmaT<BBV, BBV_MFMA ? VIHDS_BB_L : 2, BBV_MFMA ? VIHDS_BB_HS : 16, BBV_MFMA ? VIHDS_BB_HP : 16,
+                   BBV_MFMA ? VIHDS_BB_NLAT : 16>;
 __host__ inline bool bbv_takes_mfma(int solver, const OdeArgs& a, AdaptiveCtl* ctl) {
   return BBV_MFMA && !ctl && a.kernel_variant != 1 && solver >= VIHDS_SOLVER_MODEULER && solver <= VIHDS_SOLVER_RK4;
 }

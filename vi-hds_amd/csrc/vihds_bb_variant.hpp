@@ -3,8 +3,8 @@
 // templates over the sizes (fully unrolled MLPs, state in registers), so every size set is its own build: the ICML
 // sizes live in libvihds_hip.so (with the matrix-core formulation), any other set is a side library
 //   libvihds_bb_<L>_<HS>_<HP>_<NLAT>.so      (make -C vi-hds_amd/csrc blackbox L=.. HS=.. HP=.. NLAT=..)
-// next to it, holding the thread-per-trajectory kernels (vihds_blackbox.hpp) of every solver and -- for two latent species
-// and up to 64 / 32 hidden units -- the matrix-core kernels (vihds_blackbox_split.hpp), loaded on first use
+// next to it, holding the thread-per-trajectory kernels (vihds_blackbox.hpp) of every solver and -- for up to three latent
+// species and 64 / 32 hidden units -- the matrix-core kernels (vihds_blackbox_split.hpp), loaded on first use
 // (vihds_api.hip: bb_lookup).  NLAT = n_z + n_x + n_y (the kernels only see the total: z, x, y are consecutive slots).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -23,7 +23,7 @@ struct BbVariant {
   // ctl != nullptr: run the step-size controller of an adaptive solver instead of the integration
   int (*launch)(bool backward, int solver, const OdeArgs& a, hipStream_t st, AdaptiveCtl* ctl);
   // Matrix-core kernels on cooperating wavefronts with the weight gradients on chip (vihds_blackbox_split.hpp): built into
-  // the side library when n_latent_species = 2, at most 64 / 32 hidden units and 16 latent inputs -- the reference's
+  // the side library for at most 3 latent species, 64 / 32 hidden units and 16 latent inputs -- the reference's
   // default n_hidden_decoder = 50 included.  `launch` then takes them for kernel_variant != 1 on a fixed-grid solver.
   int mfma;
   long long (*gram_floats)(int n);  // floats of aux ahead of the tail in that mode

@@ -35,10 +35,10 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // The size-generic part (round 3): everything the cooperating-wavefront kernels (vihds_blackbox_split.hpp) use, for
 // n_latent_species = 2 and up to 64 / 32 hidden units (MS / MP tiles of 16) -- the reference's default
 // n_hidden_decoder = 50 (vihds/config.py:71) included -- and up to 16 latent theta inputs.
-template <class BBT, int HSV, int HPV, int NLATV>
+template <class BBT, int LV, int HSV, int HPV, int NLATV>
 struct BbMfmaT {
   using BB = BBT;
-  static constexpr int NX = 6, HS = HSV, HP = HPV, NLAT = NLATV;
+  static constexpr int L = LV, NX = 4 + LV, NST = 8 + LV, HS = HSV, HP = HPV, NLAT = NLATV;  // NST: ODE states (species, latents, precisions)
   static constexpr int TPW = 16, TPB = 64;  // trajectories per wave / per 256-thread block
   // 16-trajectory groups = partial Gram tile sets the adjoint with on-chip weight gradients leaves (vihds_blackbox_split.hpp)
   __host__ __device__ static int gram_groups(int n) { return (n + TPW - 1) / TPW; }
@@ -49,7 +49,8 @@ struct BbMfmaT {
   static constexpr int MS = tiles(HS), MP = tiles(HP), MT = MS > MP ? MS : MP;
   static constexpr int KS = ksteps(HS), KP = ksteps(HP);  // (25 / 20 units: 7 / 5)
   static constexpr int NG = 2 * MS + 2 * MP;               // Gram tiles per 16-trajectory group
-  static_assert(MS <= 4 && MP <= 2 && NLAT <= 16, "matrix-core dr_blackbox: at most 64 / 32 hidden units, 16 latent inputs");
+  static_assert(L >= 1 && L <= 3 && MS <= 4 && MP <= 2 && NLAT <= 16,
+                "matrix-core dr_blackbox: at most 3 latent species (4 + L states and the time fill two K-steps), 64 / 32 hidden units, 16 latent inputs");
 
   __device__ static f32x4 mfma(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 
@@ -74,9 +75,9 @@ struct BbMfmaT {
   };
 
   // input feature of first-layer K-step s for k-slot kq: 0..5 state, 6 = time, -1 = none
-  __device__ static int l1_input(int s, int kq) { return s == 0 ? kq : (kq < 2 ? 4 + kq : (kq == 2 ? 6 : -1)); }
+  __device__ static int l1_input(int s, int kq) { return s == 0 ? kq : (kq < L ? 4 + kq : (kq == L ? NX : -1)); }
   // output row i (0..15) of the states' second layer -> (is_degradation, state) or state = -1
-  __device__ static int l2s_state(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < 2 ? 4 + qq : -1); }
+  __device__ static int l2s_state(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < L ? 4 + qq : -1); }
   __device__ static int l2s_degr(int i) { return i & 1; }
   __device__ static int l2p_out(int i) { return (i & 3) < 2 ? (i >> 2) : -1; }
 
@@ -88,8 +89,8 @@ struct BbMfmaT {
       _Pragma("unroll") for (int s = 0; s < 2; ++s) {
         const int in = l1_input(s, kq);
         const int us = unit_of(16 * m + i, HS), up = unit_of(16 * m + i, HP);
-        if (m < MS) W.w1s[m < MS ? m : 0][s] = (us >= 0 && in >= 0 && in < 6) ? w[o.wh + us * o.nin_s + in] : 0.f;
-        if (m < MP) W.w1p[m < MP ? m : 0][s] = (up >= 0 && in >= 0) ? w[o.vh + up * o.nin_p + (in == 6 ? 0 : 1 + in)] : 0.f;
+        if (m < MS) W.w1s[m < MS ? m : 0][s] = (us >= 0 && in >= 0 && in < NX) ? w[o.wh + us * o.nin_s + in] : 0.f;
+        if (m < MP) W.w1p[m < MP ? m : 0][s] = (up >= 0 && in >= 0) ? w[o.vh + up * o.nin_p + (in == NX ? 0 : 1 + in)] : 0.f;
       }
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {
       const int u = unit_of(16 * step_m(s) + 4 * kq + step_r(s), HS);
@@ -128,7 +129,7 @@ struct BbMfmaT {
       }
     }
     // d y[row i]: row 4q'+0 = state q', row 4q'+1 = state 4+q' (q' < 2); K-step (m, r) carries hidden slot 16m + 4kq + r
-    const int st = (i & 3) == 0 ? (i >> 2) : (((i & 3) == 1 && (i >> 2) < 2) ? 4 + (i >> 2) : -1);
+    const int st = (i & 3) == 0 ? (i >> 2) : (((i & 3) == 1 && (i >> 2) < L) ? 4 + (i >> 2) : -1);
     _Pragma("unroll") for (int s = 0; s < KS; ++s) {
       const int u = unit_of(16 * step_m(s) + 4 * kq + step_r(s), HS);
       W.w1sT[s] = (u >= 0 && st >= 0) ? w[o.wh + u * o.nin_s + st] : 0.f;
@@ -217,29 +218,29 @@ struct BbMfmaT {
     const typename BB::Off o = BB::offsets(n_const);
     const int row = 4 * (lane >> 4) + reg, col = lane & 15;
     // the input tile's rows: 4q = state q, 4q+1 = latent state 4+q (q < 2), row 2 = time
-    auto input_of = [](int j) { return (j & 3) == 0 ? (j >> 2) : (((j & 3) == 1 && (j >> 2) < 2) ? 4 + (j >> 2) : (j == 2 ? 6 : -1)); };
+    auto input_of = [](int j) { return (j & 3) == 0 ? (j >> 2) : (((j & 3) == 1 && (j >> 2) < L) ? 4 + (j >> 2) : (j == 2 ? NX : -1)); };
     if (tile < MS) {
       const int u = unit_of(16 * tile + col, HS), st = l2s_state_h(row);
       return (u >= 0 && st >= 0) ? ((row & 1) ? o.wd : o.wp) + st * HS + u : -1;
     }
     if (tile < 2 * MS) {
       const int u = unit_of(16 * (tile - MS) + row, HS), in = input_of(col);
-      return (u >= 0 && in >= 0 && in < 6) ? o.wh + u * o.nin_s + in : -1;
+      return (u >= 0 && in >= 0 && in < NX) ? o.wh + u * o.nin_s + in : -1;
     }
     if (tile < 2 * MS + MP) {
       const int u = unit_of(16 * (tile - 2 * MS) + col, HP), ou = (row & 3) < 2 ? (row >> 2) : -1;
       return (u >= 0 && ou >= 0) ? ((row & 1) ? o.vd : o.vp) + ou * HP + u : -1;
     }
     const int u = unit_of(16 * (tile - 2 * MS - MP) + row, HP), in = input_of(col);
-    return (u >= 0 && in >= 0) ? o.vh + u * o.nin_p + (in == 6 ? 0 : 1 + in) : -1;
+    return (u >= 0 && in >= 0) ? o.vh + u * o.nin_p + (in == NX ? 0 : 1 + in) : -1;
   }
-  __host__ __device__ static int l2s_state_h(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < 2 ? 4 + qq : -1); }
+  __host__ __device__ static int l2s_state_h(int i) { const int qq = i >> 2, r = i & 3; return r < 2 ? qq : (qq < L ? 4 + qq : -1); }
   // floats of aux ahead of the tail when the Gram tiles are accumulated on chip
   __host__ __device__ static size_t gram_floats(int n) { return (size_t)gram_groups(n) * NG * 256; }
 };
 
 // ---- the ICML sizes (specs/dr_blackbox_icml.yaml:17-31) with the one-wavefront-per-group formulation on top -------------
-struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 25, 20, 12> {
+struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
   struct State {  // one lane's share of a trajectory: state q, latent state 4+q (q < 2), precision q
     float a, b, v;
   };

@@ -100,10 +100,10 @@ struct BbSplitT {
     return dy;
   }
 
-  struct SA {  // wave A's share of a trajectory: state q, latent state 4+q (q < 2)
+  struct SA {  // wave A's share of a trajectory: state q, latent state 4+q (q < L)
     float a, b;
   };
-  __device__ __forceinline__ static float in1(const SA& y, float t, int q) { return q < 2 ? y.b : (q == 2 ? t : 0.f); }
+  __device__ __forceinline__ static float in1(const SA& y, float t, int q) { return q < K::L ? y.b : (q == K::L ? t : 0.f); }
   __device__ __forceinline__ static SA axpyA(const SA& y, float h, const SA& k) { return {y.a + h * k.a, y.b + h * k.b}; }
 
   // ======================================================================================================================
@@ -124,7 +124,7 @@ struct BbSplitT {
       const f32x4 z = net_eval<0>(b0, b1, W, hc, h);
       SA d;
       d.a = bb_sigmoid(z[0]) - bb_sigmoid(z[1]) * y.a;
-      d.b = q < 2 ? bb_sigmoid(z[2]) - bb_sigmoid(z[3]) * y.b : 0.f;
+      d.b = q < K::L ? bb_sigmoid(z[2]) - bb_sigmoid(z[3]) * y.b : 0.f;
       return d;
     }
   };
@@ -223,7 +223,7 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
     typename S::FwdA F = {W, hc, pub, lane, q, 0};
     typename S::SA y;
     y.a = a.theta[(size_t)a.slot_row[K::NLAT + q] * n + i];  // init_x, init_rfp, init_yfp, init_cfp
-    y.b = q < 2 ? a.init_latent : 0.f;
+    y.b = q < K::L ? a.init_latent : 0.f;
     float tA = a.times[0], tB = a.times[1];
     for (int k = 0; k < a.T; ++k) {
       const float tC = (k + 1 < a.T) ? a.times[k + 1] : tB;
@@ -233,8 +233,8 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
       }
       tB = tC;
       if (a.traj && live) {
-        a.traj[((size_t)k * 10 + q) * n + i] = y.a;
-        if (q < 2) a.traj[((size_t)k * 10 + 4 + q) * n + i] = y.b;
+        a.traj[((size_t)k * K::NST + q) * n + i] = y.a;
+        if (q < K::L) a.traj[((size_t)k * K::NST + 4 + q) * n + i] = y.b;
       }
       const float x0 = __shfl(y.a, jj, 64);  // OD lives in quarter 0 of the column
       if (a.xpred && live) a.xpred[((size_t)k * 4 + q) * n + i] = q == 0 ? x0 : x0 * y.a;
@@ -253,7 +253,7 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
       const float tC = (k + 2 < a.T) ? a.times[k + 2] : tB;
       const float ob_next = (a.logp && k + 1 < a.T) ? ob[k + 1] : 0.f;
       F.take();  // grid point k: y_a of this lane's state in b0
-      if (a.traj && live) a.traj[((size_t)k * 10 + 6 + q) * n + i] = v;
+      if (a.traj && live) a.traj[((size_t)k * K::NST + 4 + K::L + q) * n + i] = v;
       const float x0 = __shfl(F.b0, jj, 64);
       const float xp = q == 0 ? x0 : x0 * F.b0;
       const float e = xp - ob_cur;
@@ -360,9 +360,9 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   struct Y3 { float a, b, v; };
   auto load_state = [&](int k) {
     Y3 s;
-    s.a = a.traj_in[((size_t)k * 10 + q) * n + i];
-    s.b = q < 2 ? a.traj_in[((size_t)k * 10 + 4 + q) * n + i] : 0.f;
-    s.v = a.traj_in[((size_t)k * 10 + 6 + q) * n + i];
+    s.a = a.traj_in[((size_t)k * K::NST + q) * n + i];
+    s.b = q < K::L ? a.traj_in[((size_t)k * K::NST + 4 + q) * n + i] : 0.f;
+    s.v = a.traj_in[((size_t)k * K::NST + 4 + K::L + q) * n + i];
     return s;
   };
   Y3 ynext = load_state(a.T - 1);
@@ -394,23 +394,23 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     auto rate = [&](const ActA& A, const SA& y) {
       SA d;
       d.a = A.sa - A.sd * y.a;
-      d.b = q < 2 ? A.sa2 - A.sd2 * y.b : 0.f;
+      d.b = q < K::L ? A.sa2 - A.sd2 * y.b : 0.f;
       return d;
     };
     auto eval_vjp = [&](float t, const SA& y, const SA& v, const ActA& A) {
       f32x4 gs[K::MS];
       SA yb;
       yb.a = -v.a * A.sd;
-      yb.b = q < 2 ? -v.b * A.sd2 : 0.f;
+      yb.b = q < K::L ? -v.b * A.sd2 : 0.f;
       f32x4 dz;
       dz[0] = v.a * A.sa * (1.f - A.sa);
       dz[1] = -v.a * y.a * A.sd * (1.f - A.sd);
-      dz[2] = q < 2 ? v.b * A.sa2 * (1.f - A.sa2) : 0.f;
-      dz[3] = q < 2 ? -v.b * y.b * A.sd2 * (1.f - A.sd2) : 0.f;
+      dz[2] = q < K::L ? v.b * A.sa2 * (1.f - A.sa2) : 0.f;
+      dz[3] = q < K::L ? -v.b * y.b * A.sd2 * (1.f - A.sd2) : 0.f;
       const f32x4 dy = S::template net_vjp<0>(dz, A.h, WT, gs, delta);
       bs[0] += dz[0]; bs[1] += dz[1]; bs[2] += dz[2]; bs[3] += dz[3];
       float* buf = lds + (e_vjp & 1) * K::GT_WAVE;
-      const f32x4 xin = {y.a, q < 2 ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
+      const f32x4 xin = {y.a, q < K::L ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
       K::put_cols(buf + K::T_DZ * K::GT_TILE, dz * lm, lane);
       K::put_cols(buf + K::T_IN * K::GT_TILE, xin, lane);
 #pragma unroll
@@ -424,7 +424,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       const float2 dyp = *reinterpret_cast<const float2*>(pub_dy + ((e_vjp & 1) * 64 + lane) * 2);
       ++e_vjp;
       yb.a += dy[0] + dyp.x;
-      if (q < 2) yb.b += dy[1] + dyp.y;
+      if (q < K::L) yb.b += dy[1] + dyp.y;
       return yb;
     };
     auto add = [](SA& x, const SA& w, float s) { x.a += s * w.a; x.b += s * w.b; };
@@ -502,8 +502,8 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       if (q == 0) lam.a += to_od;
       else lam.a += xpb * x0;
       if (a.g_traj) {
-        lam.a += a.g_traj[((size_t)k * 10 + q) * n + i];
-        if (q < 2) lam.b += a.g_traj[((size_t)k * 10 + 4 + q) * n + i];
+        lam.a += a.g_traj[((size_t)k * K::NST + q) * n + i];
+        if (q < K::L) lam.b += a.g_traj[((size_t)k * K::NST + 4 + q) * n + i];
       }
     }
     // d loss / d latent theta through the hoisted inputs: (Wc^T)[const x slot] . Delta[slot x traj]; the precision
@@ -532,7 +532,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       // output-bias adjoint sums, VALU-kernel order: prod states (6), degr states (6), prod prec (4), degr prec (4)
       bbp[(size_t)q * n + i] = bs[0];
       bbp[(size_t)(K::NX + q) * n + i] = bs[1];
-      if (q < 2) { bbp[(size_t)(4 + q) * n + i] = bs[2]; bbp[(size_t)(K::NX + 4 + q) * n + i] = bs[3]; }
+      if (q < K::L) { bbp[(size_t)(4 + q) * n + i] = bs[2]; bbp[(size_t)(K::NX + 4 + q) * n + i] = bs[3]; }
     }
   } else {
     // ================================ wave B: NeuralPrecisions ========================================================
@@ -576,7 +576,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       return ybv;
     };
     auto step_vjp = [&](float t0, float t1, const Y3& y) {
-      const In in0 = {y.a, q < 2 ? y.b : (q == 2 ? t0 : 0.f)};
+      const In in0 = {y.a, q < K::L ? y.b : (q == K::L ? t0 : 0.f)};
       if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
         const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
         const ActB A0 = act(in0);
@@ -640,7 +640,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       const float xp = q == 0 ? x0 : x0 * y.a;
       const float e = xp - obk;
       lam += glp * (0.5f / y.v - 0.5f * e * e);
-      if (a.g_traj) lam += a.g_traj[((size_t)k * 10 + 6 + q) * n + i];
+      if (a.g_traj) lam += a.g_traj[((size_t)k * K::NST + 4 + K::L + q) * n + i];
     }
     const typename BB::Off o = BB::offsets(a.n_const);
     const float* w = a.weights;
