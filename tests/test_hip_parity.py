@@ -1882,21 +1882,25 @@ def _relay_problem(model, B, S, T, seed, dt=0.25):
             th[n] = torch.exp(3.0 + 0.3 * torch.randn(B, S, generator=torch.Generator().manual_seed(9)))
     theta = torch.stack([th[n] for n in slots]).to(DEV)
     g = torch.Generator().manual_seed(seed + 1)
-    cond = torch.log1p(torch.tensor([0.0, 5.0, 250.0, 5000.0, 25000.0])[torch.arange(B) % 5][:, None].repeat(1, 2) *
-                       torch.rand(B, 2, generator=g)).to(DEV)
+    C = 3 if model.startswith("degrader") else 2  # (degrader_constant also reads arabinose)
+    cond = torch.log1p(torch.tensor([0.0, 5.0, 250.0, 5000.0, 25000.0])[torch.arange(B) % 5][:, None].repeat(1, C) *
+                       torch.rand(B, C, generator=g)).to(DEV)
     # (an uneven grid: modeuler's fixed h and modeulerwhile's per-step h must differ)
     times = (torch.arange(T, dtype=torch.float32) * dt + 0.03 * torch.rand(T, generator=g).cumsum(0)).to(DEV)
     obs = torch.rand(B, 4, T, generator=g).to(DEV)
     wts = None
     if model.endswith("_precisions"):
-        wts = (torch.randn(2 * (4 * 13 + 4), generator=g) * 0.2).to(DEV)
+        n_in = 1 + {"relay": 12, "degrader": 11, "prpr": 6}[model.split("_")[0]]  # t and the species
+        wts = (torch.randn(2 * (4 * n_in + 4), generator=g) * 0.2).to(DEV)
     return slots, theta, cond, times, obs, wts
 
 
-@pytest.mark.parametrize("model", ["relay_constant", "relay_constant_precisions"])
+@pytest.mark.parametrize("model", ["relay_constant", "relay_constant_precisions", "degrader_constant",
+                                   "degrader_constant_precisions", "prpr_constant", "prpr_constant_precisions"])
 @pytest.mark.parametrize("solver", ["modeuler", "modeulerwhile", "euler", "midpoint", "rk4"])
 def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
-    """relay_constant(_precisions) with sixteen lanes per trajectory (csrc/vihds_relay_lanes.hpp: the automatic choice
+    """relay_constant / degrader_constant / prpr_constant (and their _precisions forms) with one lane per state, sixteen
+    lanes per trajectory (csrc/vihds_relay_lanes.hpp: the automatic choice
     below 16 384 trajectories) against the one-thread-per-trajectory kernels (kernel_variant 1, themselves checked against
     the restatement of the reference's equations): trajectories, predictions, log-likelihood, every theta gradient --
     with upstream gradients on all three outputs -- and the precision network's weight gradients (per-lane accumulators
@@ -1909,11 +1913,11 @@ def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
     row_of = {n: i for i, n in enumerate(slots)}
     outs = {}
     g = torch.Generator().manual_seed(2)
-    N = 16 if wts is not None else 12
+    N = {"relay": 12, "degrader": 11, "prpr": 6}[model.split("_")[0]] + (4 if wts is not None else 0)
     up = (torch.randn(T, N, B, S, generator=g).to(DEV) * 1e-3, torch.randn(T, 4, B, S, generator=g).to(DEV) * 1e-3,
           torch.randn(4, B, S, generator=g).to(DEV) * 1e-3)
     for variant in (1, 0):
-        spec = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=variant)
+        spec = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=cond.shape[1], kernel_variant=variant)
         th = theta.clone().requires_grad_(True)
         w = wts.clone().requires_grad_(True) if wts is not None else None
         traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, w)
@@ -1926,8 +1930,13 @@ def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
     assert rel_err(got[2], ref[2], dim=0) < 1e-5
     for i, n in enumerate(slots):
         scale = ref[3][i].abs().max()
+        # (degrader's arabinose Hill exponent nA: prepare_vjp -- the SAME code behind both kernels -- forms its gradient
+        # as numb + denb, two nearly cancelling fp32 terms of the PBAD adjoint, so the last-bit difference of that adjoint
+        # between the kernels' summation orders comes out amplified: 6e-4 to 4e-3 measured; the float64 restatement is
+        # what pins it, test_relay_degrader_match_own_restatement)
+        gtol = 1e-2 if (model.startswith("degrader") and n == "nA") else 2e-4
         if scale > 0:
-            assert float((got[3][i] - ref[3][i]).abs().max() / scale) < 2e-4, n
+            assert float((got[3][i] - ref[3][i]).abs().max() / scale) < gtol, n
         else:
             assert float(got[3][i].abs().max()) == 0.0, n
     if wts is not None:

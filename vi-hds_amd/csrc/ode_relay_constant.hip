@@ -10,7 +10,7 @@ int launch_relay_constant(bool backward, int solver, const OdeArgs& a, hipStream
   // network's weight gradients brings the small per-block buffer of vihds_ode_bwd_aux_floats in `aux`.)
   if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&
       !(backward && false && a.g_weights && !a.aux))
-    return relay_lanes_launch<false>(backward, solver, a, st);
+    return relay_lanes_launch<RlRelay, false>(backward, solver, a, st);
   return launch_ode<RelayConstant>(backward, solver, a, st);
 }
 int n_slots_relay_constant() { return RelayConstant::NSLOT; }

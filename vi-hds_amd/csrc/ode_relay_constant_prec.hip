@@ -10,7 +10,7 @@ int launch_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipS
   // network's weight gradients brings the small per-block buffer of vihds_ode_bwd_aux_floats in `aux`.)
   if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&
       !(backward && true && a.g_weights && !a.aux))
-    return relay_lanes_launch<true>(backward, solver, a, st);
+    return relay_lanes_launch<RlRelay, true>(backward, solver, a, st);
   return launch_ode<WithPrec<RelayConstant>>(backward, solver, a, st);
 }
 int n_slots_relay_constant_prec() { return WithPrec<RelayConstant>::NSLOT; }

@@ -339,9 +339,19 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
   return check_hip("vihds_theta_ode_logp_grad launch");
 }
 
+// *_precisions models whose adjoint can run one lane per state (vihds_relay_lanes.hpp) and then leaves the precision
+// network's weight gradients as one partial row per block: the number of species, 0 for any other model
+static int lane_model_species(int model) {
+  switch (model) {
+    case VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS: return RlRelay::NSP;
+    case VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS: return RlDegrader::NSP;
+    case VIHDS_MODEL_PRPR_CONSTANT_PRECISIONS: return RlPrpr::NSP;
+  }
+  return 0;
+}
 int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p) {
   if (!p) return 0;
-  return p->model == VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS &&
+  return lane_model_species(p->model) > 0 &&
          relay_lanes_applicable(p->B * p->S, p->solver, p->kernel_variant, p->n_hidden_prec) ? 1 : 0;
 }
 
@@ -356,7 +366,7 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
-  if (vihds_ode_bwd_reduces_weights(p)) return relay_lanes_aux_floats(p->B * p->S);  // one partial row per block
+  if (vihds_ode_bwd_reduces_weights(p)) return relay_lanes_aux_floats(p->B * p->S, lane_model_species(p->model));  // one partial row per block
   // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
   const long long stages = ode_stages(p->solver);
   const long long fields = 8 + e->n_states() - 4 + 1 + (p->n_hidden_prec > 0 ? 2 * p->n_hidden_prec : 0);

@@ -1,4 +1,5 @@
-// relay_constant / relay_constant_precisions with SIXTEEN LANES PER TRAJECTORY (reference models/relay_constant.py:13-134
+// relay_constant, degrader_constant, prpr_constant and their _precisions forms with SIXTEEN LANES PER TRAJECTORY -- one lane per
+// ODE state; the lane models RlRelay / RlDegrader / RlPrpr below say which (written for relay: reference models/relay_constant.py:13-134
 // RHS, :199-251 states, vihds/precisions.py:55-61,76-87 neural precisions without a hidden layer; BASELINE config 5).
 //
 // The thread-per-trajectory kernels (vihds_ode_kernels.hpp) put 7 200 trajectories on 113 wavefronts: each walks its
@@ -38,9 +39,9 @@ namespace vihds {
 constexpr int RL_G = 16;                 // lanes per trajectory
 constexpr int RL_T = 256;                // threads per block
 constexpr int RL_TR = RL_T / RL_G;       // trajectories per block
-constexpr int RL_NIN = 13;               // network inputs: t, 12 species
-constexpr int RL_NWROW = 2 * RL_NIN + 2; // weight-gradient numbers per precision lane
-constexpr int RL_NWG = 4 * RL_NWROW;     // per block partial row (112)
+constexpr int RL_NIN = 13;               // network inputs at most: t, 12 species (arrays; a model uses 1 + its species)
+__host__ __device__ constexpr int rl_nwrow(int nin) { return 2 * nin + 2; }  // weight-gradient numbers per precision lane
+__host__ __device__ constexpr int rl_nwg(int nin) { return 4 * rl_nwrow(nin); }  // per block partial row (relay: 112)
 constexpr int RL_PATCH = 48;             // LDS floats per trajectory: y [16] | h [16] | adjoint scratch [16]
 constexpr float RL_LOG2PI = 1.8378770664093453f;
 typedef float rl_v2 __attribute__((ext_vector_type(2)));  // (production, degradation) pairs: v_pk_fma_f32
@@ -49,8 +50,8 @@ __host__ __device__ inline bool relay_lanes_applicable(int n, int solver, int ke
   return kernel_variant != 1 && n <= 16384 && solver >= VIHDS_SOLVER_MODEULER && solver <= VIHDS_SOLVER_RK4 &&
          n_hidden_prec < 1;
 }
-__host__ __device__ inline long long relay_lanes_aux_floats(int n) {
-  return (long long)((n + RL_TR - 1) / RL_TR) * RL_NWG;
+__host__ __device__ inline long long relay_lanes_aux_floats(int n, int n_species = 12) {
+  return (long long)((n + RL_TR - 1) / RL_TR) * rl_nwg(1 + n_species);
 }
 
 // ---- tableaux -----------------------------------------------------------------------------------------------------
@@ -121,14 +122,15 @@ struct RlEval {  // what one RHS evaluation leaves behind for its VJP
 };
 
 // publish (Y_l, tanh) and evaluate dy_l.  `pt` = this trajectory's LDS patch.
-template <bool PREC>
+template <class LM, bool PREC>
 __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float* pt, RlEval& E, float* hv) {
+  constexpr int NSP = LM::NSP, NIN = 1 + NSP;
   const int l = c.l;
   pt[l] = Y;
   if (PREC) {
-    const float hl = ftanh(l == 12 ? t : Y);
+    const float hl = ftanh(l == NSP ? t : Y);
     E.hl = hl;
-    if (l <= 12) pt[16 + (l == 12 ? 0 : l + 1)] = hl;
+    if (l <= NSP) pt[16 + (l == NSP ? 0 : l + 1)] = hl;
   }
   rl_wave_fence();
   E.x = pt[0]; E.luxR = pt[6]; E.lasR = pt[7]; E.I = pt[c.isrc];
@@ -136,23 +138,32 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
   E.gr = c.r * E.sig;
   E.g = 1.f - E.x * c.iKx;
   E.gamma = E.gr * E.g;
-  E.a = c.aR * E.luxR * E.luxR + c.aS * E.lasR * E.lasR;
-  E.den = 1.f + E.a;
-  E.P = fdiv(c.e + E.a, E.den);
-  E.denq = 1.f + E.I * c.iK;
-  E.Q = fdiv(E.x * E.I, E.denq);
-  float dy = c.F0 + c.cP * E.P + c.cQ * E.Q;
+  E.a = 0.f; E.den = 1.f; E.P = 0.f; E.denq = 1.f; E.Q = 0.f;
+  float dy = c.F0;
+  if (LM::HAS_P) {
+    E.a = c.aR * E.luxR * E.luxR + c.aS * E.lasR * E.lasR;
+    E.den = 1.f + E.a;
+    E.P = fdiv(c.e + E.a, E.den);
+    dy += c.cP * E.P;
+  }
+  if (LM::HAS_Q) {
+    E.denq = 1.f + E.I * c.iK;
+    E.Q = fdiv(E.x * E.I, E.denq);
+    dy += c.cQ * E.Q;
+  }
   float D = c.gsgn * E.gamma + c.deg;
   E.sp = 0.f; E.sd = 0.f;
   if (PREC) {
     const float4* h4 = reinterpret_cast<const float4*>(pt + 16);
     const float4 ha = h4[0], hb = h4[1], hc = h4[2];
     hv[0] = ha.x; hv[1] = ha.y; hv[2] = ha.z; hv[3] = ha.w; hv[4] = hb.x; hv[5] = hb.y; hv[6] = hb.z; hv[7] = hb.w;
-    hv[8] = hc.x; hv[9] = hc.y; hv[10] = hc.z; hv[11] = hc.w; hv[12] = pt[28];
+    hv[8] = hc.x; hv[9] = hc.y; hv[10] = hc.z; hv[11] = hc.w; hv[12] = NIN > 12 ? pt[28] : 0.f;
+#pragma unroll
+    for (int j = NIN; j < RL_NIN; ++j) hv[j] = 0.f;  // (slots past the model's inputs were never written)
     rl_v2 z2 = c.b2, z2b = rl_v2{0.f, 0.f};  // (two chains: back-to-back dependent packed FMAs cost a wait state each)
 #pragma unroll
-    for (int j = 0; j + 1 < RL_NIN; j += 2) { z2 += c.w2[j] * hv[j]; z2b += c.w2[j + 1] * hv[j + 1]; }
-    z2 += c.w2[RL_NIN - 1] * hv[RL_NIN - 1];
+    for (int j = 0; j + 1 < NIN; j += 2) { z2 += c.w2[j] * hv[j]; z2b += c.w2[j + 1] * hv[j + 1]; }
+    if (NIN & 1) z2 += c.w2[NIN - 1] * hv[NIN - 1];
     z2 += z2b;
     E.sp = sigmoid_f(z2.x); E.sd = sigmoid_f(z2.y);
     dy += c.isP * E.sp;
@@ -171,9 +182,10 @@ struct RlAcc {
 
 // VJP of one evaluation whose forward quantities (E, hv) are at hand: v = adjoint of dy_l; returns the adjoint of Y_l;
 // accumulates parameter adjoints.  Uses only the scratch third of the patch.
-template <bool PREC>
+template <class LM, bool PREC>
 __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, const RlEval& E, const float* hv, float* pt,
                                              RlAcc& A) {
+  constexpr int NSP = LM::NSP, NIN = 1 + NSP;
   const int l = c.l;
   const float D = c.gsgn * E.gamma + c.deg + (PREC ? c.isP * E.sd : 0.f);
   float yb = -v * D;
@@ -183,98 +195,203 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
   A.degb -= v * Y;
   const float gammab = rl_sum16(-v * c.gsgn * Y);
   // promoter
-  const float Pb = v * c.cP;
-  const float nb = fdiv(Pb, E.den);
-  const float sP = nb * (1.f - E.P);
-  A.eb += nb;
-  A.aRb += sP * E.luxR * E.luxR;
-  A.aSb += sP * E.lasR * E.lasR;
-  const float bRt = rl_sum16(sP * c.aR), bSt = rl_sum16(sP * c.aS);
+  float bRt = 0.f, bSt = 0.f;
+  if (LM::HAS_P) {
+    const float Pb = v * c.cP;
+    const float nb = fdiv(Pb, E.den);
+    const float sP = nb * (1.f - E.P);
+    A.eb += nb;
+    A.aRb += sP * E.luxR * E.luxR;
+    A.aSb += sP * E.lasR * E.lasR;
+    bRt = rl_sum16(sP * c.aR);
+    bSt = rl_sum16(sP * c.aS);
+  }
   // quadrature Q = x I / (1 + I iK)
-  const float Qb = v * c.cQ;
-  const float iden = frcp(E.denq);
-  const float xq = Qb * E.I * iden, Iq = Qb * E.x * iden * iden;
-  A.iKb -= Qb * E.x * E.I * E.I * iden * iden;
+  float xq = 0.f, Iq = 0.f;
+  if (LM::HAS_Q) {
+    const float Qb = v * c.cQ;
+    const float iden = frcp(E.denq);
+    xq = Qb * E.I * iden;
+    Iq = Qb * E.x * iden * iden;
+    A.iKb -= Qb * E.x * E.I * E.I * iden * iden;
+  }
   // precision network
   if (PREC) {
     rl_v2 zb;
     zb.x = c.isP * v * E.sp * (1.f - E.sp);
     zb.y = -c.isP * v * Y * E.sd * (1.f - E.sd);
 #pragma unroll
-    for (int j = 0; j < RL_NIN; ++j) A.w2b[j] += zb * hv[j];
+    for (int j = 0; j < NIN; ++j) A.w2b[j] += zb * hv[j];
     A.b2b += zb;
-    if (l >= 12) { pt[32 + (l - 12)] = zb.x; pt[36 + (l - 12)] = zb.y; }
+    if (l >= NSP && l < NSP + 4) { pt[32 + (l - NSP)] = zb.x; pt[36 + (l - NSP)] = zb.y; }
   }
-  if (l == 10 || l == 11) { pt[40 + (l - 10)] = xq; pt[42 + (l - 10)] = Iq; }
+  if (LM::HAS_Q && (l == LM::Q0 || l == LM::Q0 + 1)) { pt[40 + (l - LM::Q0)] = xq; pt[42 + (l - LM::Q0)] = Iq; }
   rl_wave_fence();
   const float4 q4 = *reinterpret_cast<const float4*>(pt + 40);
   if (PREC) {
     const float4 za = *reinterpret_cast<const float4*>(pt + 32), zd4 = *reinterpret_cast<const float4*>(pt + 36);
     const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
                      c.cw[6] * zd4.z + c.cw[7] * zd4.w;
-    if (l < 12) yb += hb * (1.f - E.hl * E.hl);
+    if (l < NSP) yb += hb * (1.f - E.hl * E.hl);
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
   A.Kb += gb * E.x * c.iKx * c.iKx;
   A.rb += grb * E.sig;
   A.tlagb -= 4.f * grb * c.r * E.sig * (1.f - E.sig);
-  if (l == 0) yb += -gb * c.iKx + q4.x + q4.y;
-  if (l == 6) yb += 2.f * E.luxR * bRt;
-  if (l == 7) yb += 2.f * E.lasR * bSt;
-  if (l == 8) yb += q4.z;
-  if (l == 9) yb += q4.w;
+  if (l == 0) yb += -gb * c.iKx + (LM::HAS_Q ? q4.x + q4.y : 0.f);
+  if (LM::HAS_P && l == 6) yb += 2.f * E.luxR * bRt;
+  if (LM::HAS_P && l == 7) yb += 2.f * E.lasR * bSt;
+  if (LM::HAS_Q) yb += LM::source_adjoint(l, q4.z, q4.w);  // the quadratures' sources (relay: luxI, lasI; degrader: aiiA)
   rl_wave_fence();
   return yb;
 }
 // ... with the forward quantities recomputed first
-template <bool PREC>
+template <class LM, bool PREC>
 __device__ __forceinline__ float rl_rhs_vjp(const RlLane& c, float t, float Y, float v, float* pt, RlAcc& A) {
   RlEval E;
   float hv[RL_NIN];
-  (void)rl_rhs<PREC>(c, t, Y, pt, E, hv);
-  return rl_vjp_core<PREC>(c, Y, v, E, hv, pt, A);
+  (void)rl_rhs<LM, PREC>(c, t, Y, pt, E, hv);
+  return rl_vjp_core<LM, PREC>(c, Y, v, E, hv, pt, A);
 }
 
+// ---- the models: which lane owns which state, and how the adjoints of the lanes' constants map back --------------------
+// lane(): the constants of lane l from the prepared parameters p.  map(): pb += the adjoints of p from the lanes' accumulators
+// T(lane, field), fields: 0 F0, 1 cP, 2 e, 3 aR, 4 aS, 5 cQ, 6 iK, 7 deg.  Q0: first of the two quadrature lanes;
+// source_adjoint(): what the quadratures hand back to their source lanes (zI = adjoint of I in lane Q0, wI in lane Q0 + 1).
+struct RlRelay {  // reference models/relay_constant.py:91-134
+  using M = RelayConstant;
+  static constexpr int NSP = 12, Q0 = 10, NCOND = 2;
+  static constexpr bool HAS_P = true, HAS_Q = true;
+  __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI : (l == 9 ? wI : 0.f); }
+  __device__ static void lane(int l, const float* p, RlLane& c) {
+    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
+    switch (l) {
+      case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
+      case 2: c.deg = p[M::P_dyfp]; c.cP = rc * p[M::P_aYFP]; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
+      case 3: c.deg = p[M::P_dcfp]; c.cP = rc * p[M::P_aCFP]; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
+      case 4: c.F0 = rc * p[M::P_a530]; break;
+      case 5: c.F0 = rc * p[M::P_a480]; break;
+      case 6: c.deg = p[M::P_dR]; c.F0 = rc * p[M::P_aR]; break;
+      case 7: c.deg = p[M::P_dS]; c.F0 = rc * p[M::P_aS]; break;
+      case 8: c.deg = p[M::P_dluxI]; c.cP = rc; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
+      case 9: c.deg = p[M::P_dlasI]; c.cP = rc; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
+      case 10: c.cQ = p[M::P_KC6] * rc; c.iK = frcp(p[M::P_Klux]); c.isrc = 8; break;
+      case 11: c.cQ = p[M::P_KC12] * rc; c.iK = frcp(p[M::P_Klas]); c.isrc = 9; break;
+      default: break;
+    }
+    c.gsgn = l == 0 ? -1.f : (l <= 9 ? 1.f : 0.f);
+  }
+  template <class TF>
+  __device__ static void map(TF T_, const float* p, float* pb) {
+    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
+    pb[M::P_rc] = T_(1, 0) + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480] + T_(6, 0) * p[M::P_aR] + T_(7, 0) * p[M::P_aS] +
+                  T_(2, 1) * p[M::P_aYFP] + T_(3, 1) * p[M::P_aCFP] + T_(8, 1) + T_(9, 1) + T_(10, 5) * p[M::P_KC6] +
+                  T_(11, 5) * p[M::P_KC12];
+    pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7); pb[M::P_dR] = T_(6, 7); pb[M::P_dS] = T_(7, 7);
+    pb[M::P_dluxI] = T_(8, 7); pb[M::P_dlasI] = T_(9, 7);
+    pb[M::P_e81] = T_(2, 2) + T_(8, 2); pb[M::P_e76] = T_(3, 2) + T_(9, 2);
+    pb[M::P_KGR81] = (T_(2, 3) + T_(8, 3)) * fR; pb[M::P_KGS81] = (T_(2, 4) + T_(8, 4)) * fS;
+    pb[M::P_KGR76] = (T_(3, 3) + T_(9, 3)) * fR; pb[M::P_KGS76] = (T_(3, 4) + T_(9, 4)) * fS;
+    pb[M::P_fR] = (T_(2, 3) + T_(8, 3)) * p[M::P_KGR81] + (T_(3, 3) + T_(9, 3)) * p[M::P_KGR76];
+    pb[M::P_fS] = (T_(2, 4) + T_(8, 4)) * p[M::P_KGS81] + (T_(3, 4) + T_(9, 4)) * p[M::P_KGS76];
+    pb[M::P_aYFP] = T_(2, 1) * rc; pb[M::P_aCFP] = T_(3, 1) * rc;
+    pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc; pb[M::P_aR] = T_(6, 0) * rc; pb[M::P_aS] = T_(7, 0) * rc;
+    pb[M::P_KC6] = T_(10, 5) * rc; pb[M::P_KC12] = T_(11, 5) * rc;
+    const float iKl = frcp(p[M::P_Klux]), iKs = frcp(p[M::P_Klas]);
+    pb[M::P_Klux] = -T_(10, 6) * iKl * iKl; pb[M::P_Klas] = -T_(11, 6) * iKs * iKs;
+  }
+};
+struct RlDegrader {  // reference models/degrader_constant.py:103-143: aiiA in lane 8, c6 / c12 = x rC aiiA in lanes 9, 10
+  using M = DegraderConstant;
+  static constexpr int NSP = 11, Q0 = 9, NCOND = 3;
+  static constexpr bool HAS_P = true, HAS_Q = true;
+  __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI + wI : 0.f; }
+  __device__ static void lane(int l, const float* p, RlLane& c) {
+    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
+    switch (l) {
+      case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
+      case 2: c.deg = p[M::P_dyfp]; c.cP = rc * p[M::P_aYFP]; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
+      case 3: c.deg = p[M::P_dcfp]; c.cP = rc * p[M::P_aCFP]; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
+      case 4: c.F0 = rc * p[M::P_a530]; break;
+      case 5: c.F0 = rc * p[M::P_a480]; break;
+      case 6: c.deg = p[M::P_dR]; c.F0 = rc * p[M::P_aR]; break;
+      case 7: c.deg = p[M::P_dS]; c.F0 = rc * p[M::P_aS]; break;
+      case 8: c.F0 = rc * p[M::P_aI] * p[M::P_PBAD] - p[M::P_daiiA]; break;  // d aiiA = rc aI PBAD - (daiiA + gamma aiiA)
+      case 9: c.cQ = p[M::P_rC6]; c.isrc = 8; break;                          // (no saturation: iK = 0)
+      case 10: c.cQ = p[M::P_rC12]; c.isrc = 8; break;
+      default: break;
+    }
+    c.gsgn = l == 0 ? -1.f : (l <= 8 ? 1.f : 0.f);
+  }
+  template <class TF>
+  __device__ static void map(TF T_, const float* p, float* pb) {
+    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
+    pb[M::P_rc] = T_(1, 0) + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480] + T_(6, 0) * p[M::P_aR] + T_(7, 0) * p[M::P_aS] +
+                  T_(2, 1) * p[M::P_aYFP] + T_(3, 1) * p[M::P_aCFP] + T_(8, 0) * p[M::P_aI] * p[M::P_PBAD];
+    pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7); pb[M::P_dR] = T_(6, 7); pb[M::P_dS] = T_(7, 7);
+    pb[M::P_e81] = T_(2, 2); pb[M::P_e76] = T_(3, 2);
+    pb[M::P_KGR81] = T_(2, 3) * fR; pb[M::P_KGS81] = T_(2, 4) * fS;
+    pb[M::P_KGR76] = T_(3, 3) * fR; pb[M::P_KGS76] = T_(3, 4) * fS;
+    pb[M::P_fR] = T_(2, 3) * p[M::P_KGR81] + T_(3, 3) * p[M::P_KGR76];
+    pb[M::P_fS] = T_(2, 4) * p[M::P_KGS81] + T_(3, 4) * p[M::P_KGS76];
+    pb[M::P_aYFP] = T_(2, 1) * rc; pb[M::P_aCFP] = T_(3, 1) * rc;
+    pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc; pb[M::P_aR] = T_(6, 0) * rc; pb[M::P_aS] = T_(7, 0) * rc;
+    pb[M::P_aI] = T_(8, 0) * rc * p[M::P_PBAD]; pb[M::P_PBAD] = T_(8, 0) * rc * p[M::P_aI]; pb[M::P_daiiA] = -T_(8, 0);
+    pb[M::P_rC6] = T_(9, 5); pb[M::P_rC12] = T_(10, 5);
+  }
+};
+struct RlPrpr {  // reference models/prpr_constant.py:46-69: every species with a constant production
+  using M = PrprConstant;
+  static constexpr int NSP = 6, Q0 = 14, NCOND = 2;
+  static constexpr bool HAS_P = false, HAS_Q = false;
+  __device__ static float source_adjoint(int, float, float) { return 0.f; }
+  __device__ static void lane(int l, const float* p, RlLane& c) {
+    const float rc = p[M::P_rc];
+    switch (l) {
+      case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
+      case 2: c.deg = p[M::P_dyfp]; c.F0 = rc * p[M::P_aYFP]; break;
+      case 3: c.deg = p[M::P_dcfp]; c.F0 = rc * p[M::P_aCFP]; break;
+      case 4: c.F0 = rc * p[M::P_a530]; break;
+      case 5: c.F0 = rc * p[M::P_a480]; break;
+      default: break;
+    }
+    c.gsgn = l == 0 ? -1.f : (l <= 5 ? 1.f : 0.f);
+  }
+  template <class TF>
+  __device__ static void map(TF T_, const float* p, float* pb) {
+    const float rc = p[M::P_rc];
+    pb[M::P_rc] = T_(1, 0) + T_(2, 0) * p[M::P_aYFP] + T_(3, 0) * p[M::P_aCFP] + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480];
+    pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7);
+    pb[M::P_aYFP] = T_(2, 0) * rc; pb[M::P_aCFP] = T_(3, 0) * rc; pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc;
+  }
+};
+
 // per-lane constants from theta (every lane loads the slots: cached, once per kernel)
-template <bool PREC>
+template <class LM, bool PREC>
 __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, RlLane& c, float* th, float* cc, float* p,
                                          float& y0, float* prec_const) {
-  using M = RelayConstant;
+  using M = typename LM::M;
+  constexpr int NSP = LM::NSP, NIN = 1 + NSP;
 #pragma unroll
   for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
   float pinit[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) pinit[j] = a.theta[(size_t)a.slot_row[M::NSLOT + j] * a.n + i];  // init_prec_* or prec_*
 #pragma unroll
-  for (int q = 0; q < 2; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+  for (int q = 0; q < LM::NCOND; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
   M::prepare(th, cc, p);
-  float yi[12];
+  float yi[NSP];
   M::init(th, cc, yi);
-  const float rc = p[M::P_rc];
   c.l = l;
   c.r = p[M::P_r]; c.iKx = frcp(p[M::P_K]); c.tlag = p[M::P_tlag]; c.rKx = 0.f;
-  c.gsgn = l == 0 ? -1.f : (l <= 9 ? 1.f : 0.f);
+  c.gsgn = 0.f;
   c.deg = 0.f; c.F0 = 0.f; c.cP = 0.f; c.e = 0.f; c.aR = 0.f; c.aS = 0.f; c.cQ = 0.f; c.iK = 0.f; c.isrc = 0;
-  c.isP = (PREC && l >= 12) ? 1.f : 0.f;
+  c.isP = (PREC && l >= NSP && l < NSP + 4) ? 1.f : 0.f;
   y0 = 0.f;
 #pragma unroll
-  for (int j = 0; j < 12; ++j) if (l == j) y0 = yi[j];
-  const float fR = p[M::P_fR], fS = p[M::P_fS];
-  switch (l) {
-    case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
-    case 2: c.deg = p[M::P_dyfp]; c.cP = rc * p[M::P_aYFP]; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
-    case 3: c.deg = p[M::P_dcfp]; c.cP = rc * p[M::P_aCFP]; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
-    case 4: c.F0 = rc * p[M::P_a530]; break;
-    case 5: c.F0 = rc * p[M::P_a480]; break;
-    case 6: c.deg = p[M::P_dR]; c.F0 = rc * p[M::P_aR]; break;
-    case 7: c.deg = p[M::P_dS]; c.F0 = rc * p[M::P_aS]; break;
-    case 8: c.deg = p[M::P_dluxI]; c.cP = rc; c.e = p[M::P_e81]; c.aR = p[M::P_KGR81] * fR; c.aS = p[M::P_KGS81] * fS; break;
-    case 9: c.deg = p[M::P_dlasI]; c.cP = rc; c.e = p[M::P_e76]; c.aR = p[M::P_KGR76] * fR; c.aS = p[M::P_KGS76] * fS; break;
-    case 10: c.cQ = p[M::P_KC6] * rc; c.iK = frcp(p[M::P_Klux]); c.isrc = 8; break;
-    case 11: c.cQ = p[M::P_KC12] * rc; c.iK = frcp(p[M::P_Klas]); c.isrc = 9; break;
-    default: break;
-  }
+  for (int j = 0; j < NSP; ++j) if (l == j) y0 = yi[j];
+  LM::lane(l, p, c);
 #pragma unroll
   for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
   c.b2 = rl_v2{0.f, 0.f};
@@ -283,28 +400,28 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
 #pragma unroll
   for (int j = 0; j < 8; ++j) c.cw[j] = 0.f;
   if (PREC) {
-    // weights: Wp [4][13], bp [4], Wd [4][13], bd [4] (reference precisions.py:55-61)
+    // weights: Wp [4][NIN], bp [4], Wd [4][NIN], bd [4] (reference precisions.py:55-61)
     const float* w = a.weights;
-    if (l >= 12) {
-      const int o = l - 12;
+    if (l >= NSP && l < NSP + 4) {
+      const int o = l - NSP;
       y0 = pinit[o];
 #pragma unroll
-      for (int j = 0; j < RL_NIN; ++j) c.w2[j] = rl_v2{w[o * RL_NIN + j], w[4 * RL_NIN + 4 + o * RL_NIN + j]};
-      c.b2 = rl_v2{w[4 * RL_NIN + o], w[8 * RL_NIN + 4 + o]};
-    } else {
+      for (int j = 0; j < NIN; ++j) c.w2[j] = rl_v2{w[o * NIN + j], w[4 * NIN + 4 + o * NIN + j]};
+      c.b2 = rl_v2{w[4 * NIN + o], w[8 * NIN + 4 + o]};
+    } else if (l < NSP) {
 #pragma unroll
-      for (int o = 0; o < 4; ++o) { c.cw[o] = w[o * RL_NIN + l + 1]; c.cw[4 + o] = w[4 * RL_NIN + 4 + o * RL_NIN + l + 1]; }
+      for (int o = 0; o < 4; ++o) { c.cw[o] = w[o * NIN + l + 1]; c.cw[4 + o] = w[4 * NIN + 4 + o * NIN + l + 1]; }
     }
   }
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
 // dynamic LDS: times [T] | obs rows [nb][4][T]
-template <bool PREC, int SOLVER>
+template <class LM, bool PREC, int SOLVER>
 __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
-  using M = RelayConstant;
+  using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
-  constexpr int N = PREC ? 16 : 12;
+  constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP;
   __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
   extern __shared__ float in_lds[];
   const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
@@ -321,8 +438,8 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
     for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
   }
   RlLane c;
-  float th[M::NSLOT], cc[2], p[M::NP], y, pconst[4];
-  rl_setup<PREC>(a, i, b, l, c, th, cc, p, y, pconst);
+  float th[M::NSLOT], cc[LM::NCOND], p[M::NP], y, pconst[4];
+  rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y, pconst);
   __syncthreads();
   const float* tl = in_lds;
   const float* ob = in_lds + a.T + (b - b0) * 4 * a.T;
@@ -345,7 +462,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
           if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
         RlEval E;
         float hv[RL_NIN];
-        kk[s] = rl_rhs<PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+        kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
       }
       float acc = 0.f;
 #pragma unroll
@@ -365,7 +482,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
         if (a.logp) {
           const float e = xp - ob[j * a.T + k];
           if (PREC) {
-            const float pr = pt[12 + j];
+            const float pr = pt[NSP + j];
             lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
           } else {
             lp += -0.5f * (lc + pconst[j] * e * e);
@@ -379,14 +496,14 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
 }
 
 // ---- adjoint -------------------------------------------------------------------------------------------------------
-template <bool PREC, int SOLVER>
+template <class LM, bool PREC, int SOLVER>
 __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
-  using M = RelayConstant;
+  using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
-  constexpr int N = PREC ? 16 : 12;
+  constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP, NIN = 1 + NSP, NWROW = rl_nwrow(NIN), NWG = rl_nwg(NIN);
   __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
   __shared__ float tab[RL_TR][RL_G][10];   // epilogue: per-lane accumulators of a trajectory
-  __shared__ float wred[PREC ? RL_TR : 1][PREC ? RL_NWG : 1];
+  __shared__ float wred[PREC ? RL_TR : 1][PREC ? NWG : 1];
   extern __shared__ float in_lds[];
   const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
   const int i0 = blockIdx.x * RL_TR + g;
@@ -403,8 +520,8 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   RlLane c;
   float pconst[4];
   {  // (theta and the prepared parameters are not kept across the time loop: the epilogue's one lane fetches them again)
-    float th[M::NSLOT], cc[2], p[M::NP], y_unused;
-    rl_setup<PREC>(a, i, b, l, c, th, cc, p, y_unused, pconst);
+    float th[M::NSLOT], cc[LM::NCOND], p[M::NP], y_unused;
+    rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y_unused, pconst);
   }
   __syncthreads();
   const float* tl = in_lds;
@@ -433,18 +550,18 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
         // one or two stages: every stage is evaluated ONCE (its forward quantities kept for its own VJP)
         RlEval E0, E1;
         float hv0[RL_NIN], hv1[RL_NIN];
-        const float k0 = rl_rhs<PREC>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
+        const float k0 = rl_rhs<LM, PREC>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
         float Y1 = y;
         if constexpr (Tab::S == 2) {
           Y1 = y + (Tab::A(1, 0) * h) * k0;
-          (void)rl_rhs<PREC>(c, Tab::ts(1, t0, t1), Y1, pt, E1, hv1);
+          (void)rl_rhs<LM, PREC>(c, Tab::ts(1, t0, t1), Y1, pt, E1, hv1);
           float kb0 = (Tab::B(0) * h) * lam;
-          const float Yb1 = rl_vjp_core<PREC>(c, Y1, (Tab::B(1) * h) * lam, E1, hv1, pt, A);
+          const float Yb1 = rl_vjp_core<LM, PREC>(c, Y1, (Tab::B(1) * h) * lam, E1, hv1, pt, A);
           lam += Yb1;
           kb0 += (Tab::A(1, 0) * h) * Yb1;
-          lam += rl_vjp_core<PREC>(c, y, kb0, E0, hv0, pt, A);
+          lam += rl_vjp_core<LM, PREC>(c, y, kb0, E0, hv0, pt, A);
         } else {
-          lam += rl_vjp_core<PREC>(c, y, (Tab::B(0) * h) * lam, E0, hv0, pt, A);
+          lam += rl_vjp_core<LM, PREC>(c, y, (Tab::B(0) * h) * lam, E0, hv0, pt, A);
         }
       } else {
         float Ys[Tab::S], kk[Tab::S], kb[Tab::S];
@@ -458,14 +575,14 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
           if (s + 1 < Tab::S) {  // (the last stage's derivative is not needed to rebuild the states)
             RlEval E;
             float hv[RL_NIN];
-            kk[s] = rl_rhs<PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+            kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
           }
         }
 #pragma unroll
         for (int s = 0; s < Tab::S; ++s) kb[s] = (Tab::B(s) * h) * lam;
 #pragma unroll
         for (int s = Tab::S - 1; s >= 0; --s) {
-          const float Yb = rl_rhs_vjp<PREC>(c, Tab::ts(s, t0, t1), Ys[s], kb[s], pt, A);
+          const float Yb = rl_rhs_vjp<LM, PREC>(c, Tab::ts(s, t0, t1), Ys[s], kb[s], pt, A);
           lam += Yb;
 #pragma unroll
           for (int q = 0; q < s; ++q)
@@ -481,7 +598,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     if (l < 4) {
       const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
       const float e = x * inner - ob[j * a.T + k];
-      const float pr = PREC ? pt[12 + j] : pconst[j];
+      const float pr = PREC ? pt[NSP + j] : pconst[j];
       xpb = -glp * pr * e;
       prb = glp * (0.5f / pr - 0.5f * e * e);
       if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
@@ -497,7 +614,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     else if (l == 1) inj = xb4.y * x;
     else if (l == 2 || l == 4) inj = xb4.z * x;
     else if (l == 3 || l == 5) inj = xb4.w * x;
-    else if (PREC && l >= 12) inj = pt[36 + (l - 12)];
+    else if (PREC && l >= NSP && l < NSP + 4) inj = pt[36 + (l - NSP)];
     lam += inj;
     if (a.g_traj && l < N) lam += a.g_traj[((size_t)k * N + l) * n + i];
     rl_wave_fence();
@@ -511,61 +628,46 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   }
   rl_wave_fence();
   if (l == 0) {
-    float th[M::NSLOT], cc[2], p[M::NP], pb[M::NP], thb[M::NSLOT], lam0[12];
+    float th[M::NSLOT], cc[LM::NCOND], p[M::NP], pb[M::NP], thb[M::NSLOT], lam0[NSP];
 #pragma unroll
     for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
 #pragma unroll
-    for (int q = 0; q < 2; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
+    for (int q = 0; q < LM::NCOND; ++q) cc[q] = clampf(expf(a.cond[b * a.C + q]) - 1.f, 1e-12f, 1e6f);
     M::prepare(th, cc, p);
 #pragma unroll
     for (int q = 0; q < M::NP; ++q) pb[q] = 0.f;
     auto T_ = [&](int lane, int f) { return tab[g][lane][f]; };
-    const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
     pb[M::P_r] = A.rb; pb[M::P_K] = A.Kb; pb[M::P_tlag] = A.tlagb;
-    pb[M::P_rc] = T_(1, 0) + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480] + T_(6, 0) * p[M::P_aR] + T_(7, 0) * p[M::P_aS] +
-                  T_(2, 1) * p[M::P_aYFP] + T_(3, 1) * p[M::P_aCFP] + T_(8, 1) + T_(9, 1) + T_(10, 5) * p[M::P_KC6] +
-                  T_(11, 5) * p[M::P_KC12];
-    pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7); pb[M::P_dR] = T_(6, 7); pb[M::P_dS] = T_(7, 7);
-    pb[M::P_dluxI] = T_(8, 7); pb[M::P_dlasI] = T_(9, 7);
-    pb[M::P_e81] = T_(2, 2) + T_(8, 2); pb[M::P_e76] = T_(3, 2) + T_(9, 2);
-    pb[M::P_KGR81] = (T_(2, 3) + T_(8, 3)) * fR; pb[M::P_KGS81] = (T_(2, 4) + T_(8, 4)) * fS;
-    pb[M::P_KGR76] = (T_(3, 3) + T_(9, 3)) * fR; pb[M::P_KGS76] = (T_(3, 4) + T_(9, 4)) * fS;
-    pb[M::P_fR] = (T_(2, 3) + T_(8, 3)) * p[M::P_KGR81] + (T_(3, 3) + T_(9, 3)) * p[M::P_KGR76];
-    pb[M::P_fS] = (T_(2, 4) + T_(8, 4)) * p[M::P_KGS81] + (T_(3, 4) + T_(9, 4)) * p[M::P_KGS76];
-    pb[M::P_aYFP] = T_(2, 1) * rc; pb[M::P_aCFP] = T_(3, 1) * rc;
-    pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc; pb[M::P_aR] = T_(6, 0) * rc; pb[M::P_aS] = T_(7, 0) * rc;
-    pb[M::P_KC6] = T_(10, 5) * rc; pb[M::P_KC12] = T_(11, 5) * rc;
-    const float iKl = frcp(p[M::P_Klux]), iKs = frcp(p[M::P_Klas]);
-    pb[M::P_Klux] = -T_(10, 6) * iKl * iKl; pb[M::P_Klas] = -T_(11, 6) * iKs * iKs;
+    LM::map(T_, p, pb);
 #pragma unroll
     for (int q = 0; q < M::NSLOT; ++q) thb[q] = 0.f;
     M::prepare_vjp(th, cc, p, pb, thb);
 #pragma unroll
-    for (int q = 0; q < 12; ++q) lam0[q] = T_(q, 8);
+    for (int q = 0; q < NSP; ++q) lam0[q] = T_(q, 8);
     M::init_vjp(lam0, thb);
     if (live) {
 #pragma unroll
       for (int q = 0; q < M::NSLOT; ++q) a.g_theta[(size_t)a.slot_row[q] * n + i] = thb[q];
 #pragma unroll
       for (int q = 0; q < 4; ++q)  // init_prec_* (neural: the adjoint of the initial precision state) or prec_*
-        a.g_theta[(size_t)a.slot_row[M::NSLOT + q] * n + i] = PREC ? T_(12 + q, 8) : T_(q, 9);
+        a.g_theta[(size_t)a.slot_row[M::NSLOT + q] * n + i] = PREC ? T_(NSP + q, 8) : T_(q, 9);
     }
   }
   if (PREC) {
     // weight gradients: rows of the precision lanes, summed over the block's trajectories in trajectory order
-    if (l >= 12) {
-      float* w = wred[g] + (l - 12) * RL_NWROW;
+    if (l >= NSP && l < NSP + 4) {
+      float* w = wred[g] + (l - NSP) * NWROW;
 #pragma unroll
-      for (int q = 0; q < RL_NIN; ++q) { w[q] = live ? A.w2b[q].x : 0.f; w[RL_NIN + q] = live ? A.w2b[q].y : 0.f; }
-      w[2 * RL_NIN] = live ? A.b2b.x : 0.f;
-      w[2 * RL_NIN + 1] = live ? A.b2b.y : 0.f;
+      for (int q = 0; q < NIN; ++q) { w[q] = live ? A.w2b[q].x : 0.f; w[NIN + q] = live ? A.w2b[q].y : 0.f; }
+      w[2 * NIN] = live ? A.b2b.x : 0.f;
+      w[2 * NIN + 1] = live ? A.b2b.y : 0.f;
     }
     __syncthreads();
-    if (tid < RL_NWG && a.aux) {
+    if (tid < NWG && a.aux) {
       float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < RL_TR; ++q) acc += wred[q][tid];
-      a.aux[(size_t)blockIdx.x * RL_NWG + tid] = acc;
+      a.aux[(size_t)blockIdx.x * NWG + tid] = acc;
     }
   }
 }
@@ -575,14 +677,15 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
 // One wavefront per element: lane q adds rows q, q + 64, ... (all requested together), then the lanes' sums are added by a
 // DPP scan -- a fixed order.
 static __global__ void __launch_bounds__(256) relay_lane_wreduce_kernel(const float* __restrict__ partial, int nblocks,
-                                                                        float* __restrict__ g_weights) {
+                                                                        float* __restrict__ g_weights, int NIN) {
+  const int NWROW = rl_nwrow(NIN), NWG = rl_nwg(NIN);
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-  if (e >= RL_NWG) return;
+  if (e >= NWG) return;
   float acc = 0.f;
   for (int b0 = 0; b0 < nblocks; b0 += 64 * 8) {
     float v[8];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) v[q] = partial[(size_t)min(b0 + lane + 64 * q, nblocks - 1) * RL_NWG + e];
+    for (int q = 0; q < 8; ++q) v[q] = partial[(size_t)min(b0 + lane + 64 * q, nblocks - 1) * NWG + e];
 #pragma unroll
     for (int q = 0; q < 8; ++q)
       if (b0 + lane + 64 * q < nblocks) acc += v[q];
@@ -592,37 +695,38 @@ static __global__ void __launch_bounds__(256) relay_lane_wreduce_kernel(const fl
   RL_SCAN(0x111, 0xf); RL_SCAN(0x112, 0xf); RL_SCAN(0x114, 0xf); RL_SCAN(0x118, 0xf); RL_SCAN(0x142, 0xa); RL_SCAN(0x143, 0xc);
 #undef RL_SCAN
   if (lane != 63) return;
-  const int o = e / RL_NWROW, q = e - o * RL_NWROW;
+  const int o = e / NWROW, q = e - o * NWROW;
   int dst;
-  if (q < RL_NIN) dst = o * RL_NIN + q;                                       // Wp[o][q]
-  else if (q < 2 * RL_NIN) dst = 4 * RL_NIN + 4 + o * RL_NIN + (q - RL_NIN);  // Wd[o][.]
-  else if (q == 2 * RL_NIN) dst = 4 * RL_NIN + o;                             // bp[o]
-  else dst = 8 * RL_NIN + 4 + o;                                              // bd[o]
+  if (q < NIN) dst = o * NIN + q;                                 // Wp[o][q]
+  else if (q < 2 * NIN) dst = 4 * NIN + 4 + o * NIN + (q - NIN);  // Wd[o][.]
+  else if (q == 2 * NIN) dst = 4 * NIN + o;                       // bp[o]
+  else dst = 8 * NIN + 4 + o;                                     // bd[o]
   g_weights[dst] += acc;
 }
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
-template <bool PREC, int SOLVER>
+template <class LM, bool PREC, int SOLVER>
 inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st) {
   const int nblk = (a.n + RL_TR - 1) / RL_TR;
   const int nb_max = min(a.B, (RL_TR - 1) / a.S + 2);
   const size_t lds = sizeof(float) * ((size_t)a.T + (size_t)nb_max * 4 * a.T);
+  constexpr int NIN = 1 + LM::NSP;
   if (!backward) {
-    hipLaunchKernelGGL((relay_lane_fwd_kernel<PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+    hipLaunchKernelGGL((relay_lane_fwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
   } else {
-    hipLaunchKernelGGL((relay_lane_bwd_kernel<PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+    hipLaunchKernelGGL((relay_lane_bwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
     if (PREC && a.g_weights && a.aux)
-      hipLaunchKernelGGL(relay_lane_wreduce_kernel, dim3((RL_NWG + 3) / 4), dim3(256), 0, st, a.aux, nblk, a.g_weights);
+      hipLaunchKernelGGL(relay_lane_wreduce_kernel, dim3((rl_nwg(NIN) + 3) / 4), dim3(256), 0, st, a.aux, nblk, a.g_weights, NIN);
   }
 }
-template <bool PREC>
+template <class LM, bool PREC>
 inline int relay_lanes_launch(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   switch (solver) {
-    case VIHDS_SOLVER_MODEULER: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MODEULER>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_MODEULERWHILE: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_EULER: relay_lanes_launch_s<PREC, VIHDS_SOLVER_EULER>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_MIDPOINT: relay_lanes_launch_s<PREC, VIHDS_SOLVER_MIDPOINT>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_RK4: relay_lanes_launch_s<PREC, VIHDS_SOLVER_RK4>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MODEULER: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULER>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MODEULERWHILE: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_EULER: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_EULER>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MIDPOINT: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MIDPOINT>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_RK4: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_RK4>(backward, a, st); return VIHDS_OK;
   }
   return VIHDS_E_BADARG;
 }
