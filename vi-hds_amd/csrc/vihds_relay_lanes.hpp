@@ -122,7 +122,8 @@ struct RlEval {  // what one RHS evaluation leaves behind for its VJP
 };
 
 // publish (Y_l, tanh) and evaluate dy_l.  `pt` = this trajectory's LDS patch.
-template <class LM, bool PREC>
+// (TAIL_FENCE = false: the caller still reads the published states and places the fence itself)
+template <class LM, bool PREC, bool TAIL_FENCE = true>
 __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float* pt, RlEval& E, float* hv) {
   constexpr int NSP = LM::NSP, NIN = 1 + NSP;
   const int l = c.l;
@@ -169,7 +170,7 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
     dy += c.isP * E.sp;
     D += c.isP * E.sd;
   }
-  rl_wave_fence();  // (the patch is rewritten by the next evaluation: reads first)
+  if (TAIL_FENCE) rl_wave_fence();  // (the patch is rewritten by the next evaluation: reads first)
   return dy - D * Y;
 }
 
@@ -449,48 +450,59 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   float lp = 0.f;
   const int j = l & 3;  // observed signal of lanes 0..3
   const float lc = PREC ? 0.f : RL_LOG2PI - logf(pconst[j]);
-  for (int k = 0; k < a.T; ++k) {
-    if (k > 0) {
-      const float t0 = tl[k - 1], t1 = tl[k];
-      const float h = Tab::h(t0, t1, h0);
-      float kk[Tab::S];
-#pragma unroll
-      for (int s = 0; s < Tab::S; ++s) {
-        float Y = y;
-#pragma unroll
-        for (int q = 0; q < s; ++q)
-          if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
-        RlEval E;
-        float hv[RL_NIN];
-        kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
-      }
-      float acc = 0.f;
-#pragma unroll
-      for (int s = 0; s < Tab::S; ++s)
-        if (Tab::B(s) != 0.f) acc += Tab::B(s) * kk[s];
-      y += h * acc;
-    }
-    if (a.traj && live && l < N) a.traj[((size_t)k * N + l) * n + i] = y;
-    if (a.xpred || a.logp) {
-      pt[l] = y;
-      rl_wave_fence();
-      if (l < 4) {
-        const float x = pt[0];
-        const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
-        const float xp = x * inner;
-        if (a.xpred && live) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
-        if (a.logp) {
-          const float e = xp - ob[j * a.T + k];
-          if (PREC) {
-            const float pr = pt[NSP + j];
-            lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
-          } else {
-            lp += -0.5f * (lc + pconst[j] * e * e);
-          }
+  // observation of grid point k from the states as published in the patch (x_predict, log-likelihood: lanes 0..3)
+  auto observe = [&](int k) {
+    if (l < 4) {
+      const float x = pt[0];
+      const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
+      const float xp = x * inner;
+      if (a.xpred && live) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
+      if (a.logp) {
+        const float e = xp - ob[j * a.T + k];
+        if (PREC) {
+          const float pr = pt[NSP + j];
+          lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
+        } else {
+          lp += -0.5f * (lc + pconst[j] * e * e);
         }
       }
-      rl_wave_fence();
     }
+  };
+  const bool obs_on = a.xpred || a.logp;
+  if (a.traj && live && l < N) a.traj[(size_t)l * n + i] = y;
+  for (int k = 1; k < a.T; ++k) {
+    const float t0 = tl[k - 1], t1 = tl[k];
+    const float h = Tab::h(t0, t1, h0);
+    float kk[Tab::S];
+#pragma unroll
+    for (int s = 0; s < Tab::S; ++s) {
+      float Y = y;
+#pragma unroll
+      for (int q = 0; q < s; ++q)
+        if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
+      RlEval E;
+      float hv[RL_NIN];
+      if (s == 0) {
+        // the step's first evaluation publishes the grid point k - 1 itself: its observation rides on that exchange
+        // instead of a publish / fence / read round of its own
+        kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+        if (obs_on) observe(k - 1);
+        rl_wave_fence();
+      } else {
+        kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+      }
+    }
+    float acc = 0.f;
+#pragma unroll
+    for (int s = 0; s < Tab::S; ++s)
+      if (Tab::B(s) != 0.f) acc += Tab::B(s) * kk[s];
+    y += h * acc;
+    if (a.traj && live && l < N) a.traj[((size_t)k * N + l) * n + i] = y;
+  }
+  if (obs_on) {  // the last grid point
+    pt[l] = y;
+    rl_wave_fence();
+    observe(a.T - 1);
   }
   if (a.logp && live && l < 4) a.logp[(size_t)j * n + i] = lp;
 }
