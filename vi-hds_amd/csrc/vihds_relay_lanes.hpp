@@ -114,6 +114,10 @@ struct RlLane {
   // this lane
   float gsgn, deg, F0, cP, e, aR, aS, cQ, iK, isP;
   int isrc, l;
+  // which-lane-am-I as 0 / 1 factors: `x += m * v` is one FMA where `if (l == ...) x += v` is an exec-mask branch that also
+  // cuts the basic block (the adjoint's loop body had 30 of them)
+  float m0, m6, m7, sz, sw;              // OD lane, luxR, lasR; weights of the two quadratures' source adjoints
+  float i0, i1, i2, i3;                  // observation injections: OD; rfp; yfp and f530; cfp and f480
   rl_v2 w2[RL_NIN], b2;                  // rows (production, degradation) of the precision network (precision lanes; zeros elsewhere)
   float cw[8];                           // column of both matrices that multiplies this lane's tanh (species lanes)
 };
@@ -233,17 +237,16 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     const float4 za = *reinterpret_cast<const float4*>(pt + 32), zd4 = *reinterpret_cast<const float4*>(pt + 36);
     const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
                      c.cw[6] * zd4.z + c.cw[7] * zd4.w;
-    if (l < NSP) yb += hb * (1.f - E.hl * E.hl);
+    yb += hb * (1.f - E.hl * E.hl);  // (the columns cw are zero outside the species lanes)
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
   A.Kb += gb * E.x * c.iKx * c.iKx;
   A.rb += grb * E.sig;
   A.tlagb -= 4.f * grb * c.r * E.sig * (1.f - E.sig);
-  if (l == 0) yb += -gb * c.iKx + (LM::HAS_Q ? q4.x + q4.y : 0.f);
-  if (LM::HAS_P && l == 6) yb += 2.f * E.luxR * bRt;
-  if (LM::HAS_P && l == 7) yb += 2.f * E.lasR * bSt;
-  if (LM::HAS_Q) yb += LM::source_adjoint(l, q4.z, q4.w);  // the quadratures' sources (relay: luxI, lasI; degrader: aiiA)
+  yb = fmaf(c.m0, -gb * c.iKx + (LM::HAS_Q ? q4.x + q4.y : 0.f), yb);
+  if (LM::HAS_P) yb = fmaf(c.m6, 2.f * E.luxR * bRt, fmaf(c.m7, 2.f * E.lasR * bSt, yb));
+  if (LM::HAS_Q) yb = fmaf(c.sz, q4.z, fmaf(c.sw, q4.w, yb));  // the quadratures' sources (relay: luxI, lasI; degrader: aiiA)
   rl_wave_fence();
   return yb;
 }
@@ -393,6 +396,9 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
 #pragma unroll
   for (int j = 0; j < NSP; ++j) if (l == j) y0 = yi[j];
   LM::lane(l, p, c);
+  c.m0 = l == 0 ? 1.f : 0.f; c.m6 = l == 6 ? 1.f : 0.f; c.m7 = l == 7 ? 1.f : 0.f;
+  c.sz = LM::source_adjoint(l, 1.f, 0.f); c.sw = LM::source_adjoint(l, 0.f, 1.f);
+  c.i0 = c.m0; c.i1 = l == 1 ? 1.f : 0.f; c.i2 = (l == 2 || l == 4) ? 1.f : 0.f; c.i3 = (l == 3 || l == 5) ? 1.f : 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
   c.b2 = rl_v2{0.f, 0.f};
@@ -551,6 +557,11 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   const float glp = (a.g_logp && l < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
   const int lr = l < N ? l : 0;  // row this lane reads from the stored trajectory
   float yn = a.traj_in[((size_t)(a.T - 1) * N + lr) * n + i];
+  float ox = 0.f, oy1 = 0.f, oy2 = 0.f, oy3 = 0.f, oy4 = 0.f, oy5 = 0.f, opr = 1.f;  // the grid point's observed states
+  auto grab = [&]() {
+    ox = pt[0]; oy1 = pt[1]; oy2 = pt[2]; oy3 = pt[3]; oy4 = pt[4]; oy5 = pt[5];
+    if (PREC) opr = pt[NSP + j];
+  };
   for (int k = a.T - 1; k >= 0; --k) {
     const float y = yn;
     if (k > 0) yn = a.traj_in[((size_t)(k - 1) * N + lr) * n + i];  // (one step ahead of its use)
@@ -562,7 +573,10 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
         // one or two stages: every stage is evaluated ONCE (its forward quantities kept for its own VJP)
         RlEval E0, E1;
         float hv0[RL_NIN], hv1[RL_NIN];
-        const float k0 = rl_rhs<LM, PREC>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
+        // (the step's first evaluation publishes the grid point k itself: the injection below takes what it needs of it here)
+        const float k0 = rl_rhs<LM, PREC, false>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
+        grab();
+        rl_wave_fence();
         float Y1 = y;
         if constexpr (Tab::S == 2) {
           Y1 = y + (Tab::A(1, 0) * h) * k0;
@@ -587,7 +601,13 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
           if (s + 1 < Tab::S) {  // (the last stage's derivative is not needed to rebuild the states)
             RlEval E;
             float hv[RL_NIN];
-            kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+            if (s == 0) {
+              kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+              grab();
+              rl_wave_fence();
+            } else {
+              kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+            }
           }
         }
 #pragma unroll
@@ -602,15 +622,20 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
         }
       }
     }
-    // gradient injected at time k: log-likelihood, x_predict and trajectory upstream gradients
-    pt[l] = y;
-    rl_wave_fence();
-    const float x = pt[0];
+    // gradient injected at time k: log-likelihood, x_predict and trajectory upstream gradients (the states of the grid
+    // point were taken from the step's first exchange; the last grid point has no step: publish it here)
+    if (k == a.T - 1) {
+      pt[l] = y;
+      rl_wave_fence();
+      grab();
+      rl_wave_fence();
+    }
+    const float x = ox;
     float xpb = 0.f, prb = 0.f;
     if (l < 4) {
-      const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
+      const float inner = j == 0 ? 1.f : (j == 1 ? oy1 : (j == 2 ? oy2 + oy4 : oy3 + oy5));
       const float e = x * inner - ob[j * a.T + k];
-      const float pr = PREC ? pt[NSP + j] : pconst[j];
+      const float pr = PREC ? opr : pconst[j];
       xpb = -glp * pr * e;
       prb = glp * (0.5f / pr - 0.5f * e * e);
       if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
@@ -618,15 +643,11 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
       pt[36 + j] = prb;
       if (!PREC) precb += prb;
     }
-    const float y1 = pt[1], y2 = pt[2], y3 = pt[3], y4 = pt[4], y5 = pt[5];
+    const float y1 = oy1, y2 = oy2, y3 = oy3, y4 = oy4, y5 = oy5;
     rl_wave_fence();
     const float4 xb4 = *reinterpret_cast<const float4*>(pt + 32);
-    float inj = 0.f;
-    if (l == 0) inj = xb4.x + xb4.y * y1 + xb4.z * (y2 + y4) + xb4.w * (y3 + y5);
-    else if (l == 1) inj = xb4.y * x;
-    else if (l == 2 || l == 4) inj = xb4.z * x;
-    else if (l == 3 || l == 5) inj = xb4.w * x;
-    else if (PREC && l >= NSP && l < NSP + 4) inj = pt[36 + (l - NSP)];
+    float inj = c.i0 * (xb4.x + xb4.y * y1 + xb4.z * (y2 + y4) + xb4.w * (y3 + y5)) + x * (c.i1 * xb4.y + c.i2 * xb4.z + c.i3 * xb4.w);
+    if (PREC) inj = fmaf(c.isP, pt[36 + ((l - NSP) & 3)], inj);
     lam += inj;
     if (a.g_traj && l < N) lam += a.g_traj[((size_t)k * N + l) * n + i];
     rl_wave_fence();
