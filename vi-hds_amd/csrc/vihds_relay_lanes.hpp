@@ -118,6 +118,7 @@ struct RlLane {
   // cuts the basic block (the adjoint's loop body had 30 of them)
   float m0, m6, m7, sz, sw;              // OD lane, luxR, lasR; weights of the two quadratures' source adjoints
   float i0, i1, i2, i3;                  // observation injections: OD; rfp; yfp and f530; cfp and f480
+  float n0, n1, n2, n3;                  // observed signal j = l & 3: x * (n0 + n1 rfp + n2 (yfp + f530) + n3 (cfp + f480))
   rl_v2 w2[RL_NIN], b2;                  // rows (production, degradation) of the precision network (precision lanes; zeros elsewhere)
   float cw[8];                           // column of both matrices that multiplies this lane's tanh (species lanes)
 };
@@ -398,6 +399,7 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
   LM::lane(l, p, c);
   c.m0 = l == 0 ? 1.f : 0.f; c.m6 = l == 6 ? 1.f : 0.f; c.m7 = l == 7 ? 1.f : 0.f;
   c.sz = LM::source_adjoint(l, 1.f, 0.f); c.sw = LM::source_adjoint(l, 0.f, 1.f);
+  c.n0 = (l & 3) == 0 ? 1.f : 0.f; c.n1 = (l & 3) == 1 ? 1.f : 0.f; c.n2 = (l & 3) == 2 ? 1.f : 0.f; c.n3 = (l & 3) == 3 ? 1.f : 0.f;
   c.i0 = c.m0; c.i1 = l == 1 ? 1.f : 0.f; c.i2 = (l == 2 || l == 4) ? 1.f : 0.f; c.i3 = (l == 3 || l == 5) ? 1.f : 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
@@ -460,7 +462,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   auto observe = [&](int k) {
     if (l < 4) {
       const float x = pt[0];
-      const float inner = j == 0 ? 1.f : (j == 1 ? pt[1] : (j == 2 ? pt[2] + pt[4] : pt[3] + pt[5]));
+      const float inner = c.n0 + c.n1 * pt[1] + c.n2 * (pt[2] + pt[4]) + c.n3 * (pt[3] + pt[5]);
       const float xp = x * inner;
       if (a.xpred && live) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
       if (a.logp) {
@@ -631,18 +633,18 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
       rl_wave_fence();
     }
     const float x = ox;
-    float xpb = 0.f, prb = 0.f;
+    // (straight-line for all lanes -- glp is zero outside lanes 0..3 --, only the two stores are the four lanes')
+    const float inner = c.n0 + c.n1 * oy1 + c.n2 * (oy2 + oy4) + c.n3 * (oy3 + oy5);
+    const float e = x * inner - ob[j * a.T + k];
+    const float pr = PREC ? opr : pconst[j];
+    float xpb = -glp * pr * e;
+    const float prb = glp * (0.5f * frcp(pr) - 0.5f * e * e);
+    if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
     if (l < 4) {
-      const float inner = j == 0 ? 1.f : (j == 1 ? oy1 : (j == 2 ? oy2 + oy4 : oy3 + oy5));
-      const float e = x * inner - ob[j * a.T + k];
-      const float pr = PREC ? opr : pconst[j];
-      xpb = -glp * pr * e;
-      prb = glp * (0.5f / pr - 0.5f * e * e);
-      if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
       pt[32 + j] = xpb;
       pt[36 + j] = prb;
-      if (!PREC) precb += prb;
     }
+    if (!PREC) precb += prb;
     const float y1 = oy1, y2 = oy2, y3 = oy3, y4 = oy4, y5 = oy5;
     rl_wave_fence();
     const float4 xb4 = *reinterpret_cast<const float4*>(pt + 32);
