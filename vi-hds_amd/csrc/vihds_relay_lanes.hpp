@@ -118,6 +118,8 @@ struct RlLane {
   // cuts the basic block (the adjoint's loop body had 30 of them)
   float m0, m6, m7, sz, sw;              // OD lane, luxR, lasR; weights of the two quadratures' source adjoints
   float i0, i1, i2, i3;                  // observation injections: OD; rfp; yfp and f530; cfp and f480
+  // where this lane's hand-overs go in the patch; a lane that has none writes a spare slot (44..47) instead of branching
+  int a_h, a_zx, a_zy, a_q1, a_q2, a_ix, a_ip;
   float n0, n1, n2, n3;                  // observed signal j = l & 3: x * (n0 + n1 rfp + n2 (yfp + f530) + n3 (cfp + f480))
   rl_v2 w2[RL_NIN], b2;                  // rows (production, degradation) of the precision network (precision lanes; zeros elsewhere)
   float cw[8];                           // column of both matrices that multiplies this lane's tanh (species lanes)
@@ -136,7 +138,7 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
   if (PREC) {
     const float hl = ftanh(l == NSP ? t : Y);
     E.hl = hl;
-    if (l <= NSP) pt[16 + (l == NSP ? 0 : l + 1)] = hl;
+    pt[c.a_h] = hl;
   }
   rl_wave_fence();
   E.x = pt[0]; E.luxR = pt[6]; E.lasR = pt[7]; E.I = pt[c.isrc];
@@ -229,9 +231,10 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
 #pragma unroll
     for (int j = 0; j < NIN; ++j) A.w2b[j] += zb * hv[j];
     A.b2b += zb;
-    if (l >= NSP && l < NSP + 4) { pt[32 + (l - NSP)] = zb.x; pt[36 + (l - NSP)] = zb.y; }
+    pt[c.a_zx] = zb.x;
+    pt[c.a_zy] = zb.y;
   }
-  if (LM::HAS_Q && (l == LM::Q0 || l == LM::Q0 + 1)) { pt[40 + (l - LM::Q0)] = xq; pt[42 + (l - LM::Q0)] = Iq; }
+  if (LM::HAS_Q) { pt[c.a_q1] = xq; pt[c.a_q2] = Iq; }
   rl_wave_fence();
   const float4 q4 = *reinterpret_cast<const float4*>(pt + 40);
   if (PREC) {
@@ -399,6 +402,16 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
   LM::lane(l, p, c);
   c.m0 = l == 0 ? 1.f : 0.f; c.m6 = l == 6 ? 1.f : 0.f; c.m7 = l == 7 ? 1.f : 0.f;
   c.sz = LM::source_adjoint(l, 1.f, 0.f); c.sw = LM::source_adjoint(l, 0.f, 1.f);
+  {
+    const bool pl = l >= NSP && l < NSP + 4, ql = LM::HAS_Q && (l == LM::Q0 || l == LM::Q0 + 1);
+    c.a_h = l <= NSP ? 16 + (l == NSP ? 0 : l + 1) : 44 + (l & 3);
+    c.a_zx = pl ? 32 + (l - NSP) : 44 + (l & 1);
+    c.a_zy = pl ? 36 + (l - NSP) : 46 + (l & 1);
+    c.a_q1 = ql ? 40 + (l - LM::Q0) : 44 + (l & 1);
+    c.a_q2 = ql ? 42 + (l - LM::Q0) : 46 + (l & 1);
+    c.a_ix = l < 4 ? 32 + l : 44 + (l & 1);
+    c.a_ip = l < 4 ? 36 + l : 46 + (l & 1);
+  }
   c.n0 = (l & 3) == 0 ? 1.f : 0.f; c.n1 = (l & 3) == 1 ? 1.f : 0.f; c.n2 = (l & 3) == 2 ? 1.f : 0.f; c.n3 = (l & 3) == 3 ? 1.f : 0.f;
   c.i0 = c.m0; c.i1 = l == 1 ? 1.f : 0.f; c.i2 = (l == 2 || l == 4) ? 1.f : 0.f; c.i3 = (l == 3 || l == 5) ? 1.f : 0.f;
 #pragma unroll
@@ -640,10 +653,8 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     float xpb = -glp * pr * e;
     const float prb = glp * (0.5f * frcp(pr) - 0.5f * e * e);
     if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + j) * n + i];
-    if (l < 4) {
-      pt[32 + j] = xpb;
-      pt[36 + j] = prb;
-    }
+    pt[c.a_ix] = xpb;
+    pt[c.a_ip] = prb;
     if (!PREC) precb += prb;
     const float y1 = oy1, y2 = oy2, y3 = oy3, y4 = oy4, y5 = oy5;
     rl_wave_fence();
