@@ -185,7 +185,10 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
 struct RlAcc {
   float F0b, cPb, eb, aRb, aSb, cQb, iKb, degb;  // adjoints of the lane's own constants
   float rb, Kb, tlagb;                            // growth parameters (the same numbers in every lane of the trajectory)
-  rl_v2 w2b[RL_NIN], b2b;                         // precision lanes: rows of the weight gradients (production, degradation)
+  // weight gradients of the precision network: lane l <= NSP owns COLUMN j(l) (the input it publishes: t or its own species)
+  // of both matrices -- its own tanh times the eight pre-activation adjoints every lane reads anyway: 4 packed FMAs per
+  // evaluation where a row per precision lane cost 13 in all sixteen lanes; the precision lanes keep the bias sums
+  rl_v2 wc[4], b2b;
 };
 
 // VJP of one evaluation whose forward quantities (E, hv) are at hand: v = adjoint of dy_l; returns the adjoint of Y_l;
@@ -228,8 +231,6 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     rl_v2 zb;
     zb.x = c.isP * v * E.sp * (1.f - E.sp);
     zb.y = -c.isP * v * Y * E.sd * (1.f - E.sd);
-#pragma unroll
-    for (int j = 0; j < NIN; ++j) A.w2b[j] += zb * hv[j];
     A.b2b += zb;
     pt[c.a_zx] = zb.x;
     pt[c.a_zy] = zb.y;
@@ -242,6 +243,8 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
                      c.cw[6] * zd4.z + c.cw[7] * zd4.w;
     yb += hb * (1.f - E.hl * E.hl);  // (the columns cw are zero outside the species lanes)
+    A.wc[0] += rl_v2{za.x, zd4.x} * E.hl; A.wc[1] += rl_v2{za.y, zd4.y} * E.hl;
+    A.wc[2] += rl_v2{za.z, zd4.z} * E.hl; A.wc[3] += rl_v2{za.w, zd4.w} * E.hl;
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
@@ -567,7 +570,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   A.F0b = A.cPb = A.eb = A.aRb = A.aSb = A.cQb = A.iKb = A.degb = A.rb = A.Kb = A.tlagb = 0.f;
   A.b2b = rl_v2{0.f, 0.f};
 #pragma unroll
-  for (int q = 0; q < RL_NIN; ++q) A.w2b[q] = rl_v2{0.f, 0.f};
+  for (int q = 0; q < 4; ++q) A.wc[q] = rl_v2{0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const float glp = (a.g_logp && l < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
   const int lr = l < N ? l : 0;  // row this lane reads from the stored trajectory
@@ -701,10 +704,16 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   }
   if (PREC) {
     // weight gradients: rows of the precision lanes, summed over the block's trajectories in trajectory order
+    if (l <= NSP) {  // column j of both matrices, rows o = 0..3
+      const int jc = l == NSP ? 0 : l + 1;
+#pragma unroll
+      for (int o = 0; o < 4; ++o) {
+        wred[g][o * NWROW + jc] = live ? A.wc[o].x : 0.f;
+        wred[g][o * NWROW + NIN + jc] = live ? A.wc[o].y : 0.f;
+      }
+    }
     if (l >= NSP && l < NSP + 4) {
       float* w = wred[g] + (l - NSP) * NWROW;
-#pragma unroll
-      for (int q = 0; q < NIN; ++q) { w[q] = live ? A.w2b[q].x : 0.f; w[NIN + q] = live ? A.w2b[q].y : 0.f; }
       w[2 * NIN] = live ? A.b2b.x : 0.f;
       w[2 * NIN + 1] = live ? A.b2b.y : 0.f;
     }
