@@ -511,8 +511,10 @@ def issue_bound(kernel_name, mean_us):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    # (defaults: a timed window of ~0.35 s at the headline -- a 200-step window is 17 ms, in which one 4 ms hiccup of the
+    # host or the clocks is a 20 % error: measured, profiles/r03_h_bench.json's first version)
+    ap.add_argument("--steps", type=int, default=4000)
+    ap.add_argument("--warmup", type=int, default=200)
     ap.add_argument("--solver", default=None)
     ap.add_argument("--workload", choices=sorted(WORKLOAD_TABLE) + ["run_loop"], default="config2",
                     help="which BASELINE.json configuration: config2 (headline, default), config3_train / config3_eval "

@@ -34,6 +34,6 @@ print(json.dumps(out, indent=1)[:1500])
 PY
 cp profiles/config4_mfma_busy.json $O/
 for W in config3_train config3_eval config4 config5; do
-  python bench.py --workload $W --steps 200 --warmup 20 > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
+  python bench.py --workload $W > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
   tail -1 $O/${TAG}_${W}_bench.json | cut -c1-160
 done
