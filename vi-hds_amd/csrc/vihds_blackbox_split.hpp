@@ -71,7 +71,7 @@ struct BbSplitT {
 #pragma unroll
     for (int m = 0; m < M; ++m)
 #pragma unroll
-      for (int r = 0; r < 4; ++r) h[m][r] = fmaxf(h[m][r], 0.f);
+      for (int r = 0; r < 4; ++r) h[m][r] = __builtin_amdgcn_fmed3f(h[m][r], 0.f, __builtin_inff());  // ReLU as ONE v_med3 (fmaxf adds a canonicalising v_max)
     f32x4 z = NET == 0 ? W.b2s : W.b2p;
 #pragma unroll
     for (int s = 0; s < KN; ++s) z = K::mfma(NET == 0 ? W.w2s[s < K::KS ? s : 0] : W.w2p[s < K::KP ? s : 0], h[K::step_m(s)][K::step_r(s)], z);
