@@ -627,9 +627,28 @@ def main():
         return out
 
     if use_graph:
-        step(batch)  # setup, not a measured or warm-up step: allocator warm-up + hipGraph capture happen on first use
-        if G > 1:
-            training.graph_step(batch, repeat=G)  # (same for the G-step graph: G untimed steps)
+        capture_error = None
+        try:
+            step(batch)  # setup, not a measured or warm-up step: allocator warm-up + hipGraph capture happen on first use
+            if G > 1:
+                training.graph_step(batch, repeat=G)  # (same for the G-step graph: G untimed steps)
+        except Exception as exc:  # noqa: BLE001 -- (reported in the line; the run goes on with eager launches)
+            if not multi:
+                raise
+            capture_error = repr(exc)[:300]
+        if multi:
+            # a multi-rank step is captured as hipGraph segments around its collectives; should that fail on ANY rank (it
+            # has only ever run over gloo and over RCCL with one rank: no multi-GPU node was available), every rank
+            # falls back to eager launches rather than losing the scaling line
+            flag = torch.tensor([0.0 if capture_error is None else 1.0], device=dev)
+            torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+            if float(flag) > 0:
+                torch.cuda.synchronize()
+                training.use_graph = False
+                use_graph, G = False, 1
+                step = training.step
+                launch_mode = "eager (hipGraph capture of the multi-rank step failed on a rank: %s)" % (capture_error or "another rank")
+                step(batch)
     loss = run_steps(a.warmup)
     barrier()
     t0 = time.perf_counter()
