@@ -475,20 +475,19 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   const int j = l & 3;  // observed signal of lanes 0..3
   const float lc = PREC ? 0.f : RL_LOG2PI - logf(pconst[j]);
   // observation of grid point k from the states as published in the patch (x_predict, log-likelihood: lanes 0..3)
+  // (straight-line for all sixteen lanes -- signal j = l & 3 --; only lanes 0..3 store)
   auto observe = [&](int k) {
-    if (l < 4) {
-      const float x = pt[0];
-      const float inner = c.n0 + c.n1 * pt[1] + c.n2 * (pt[2] + pt[4]) + c.n3 * (pt[3] + pt[5]);
-      const float xp = x * inner;
-      if (a.xpred && live) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
-      if (a.logp) {
-        const float e = xp - ob[j * a.T + k];
-        if (PREC) {
-          const float pr = pt[NSP + j];
-          lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
-        } else {
-          lp += -0.5f * (lc + pconst[j] * e * e);
-        }
+    const float x = pt[0];
+    const float inner = c.n0 + c.n1 * pt[1] + c.n2 * (pt[2] + pt[4]) + c.n3 * (pt[3] + pt[5]);
+    const float xp = x * inner;
+    if (a.xpred && live && l < 4) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
+    if (a.logp) {
+      const float e = xp - ob[j * a.T + k];
+      if (PREC) {
+        const float pr = pt[NSP + j];
+        lp += -0.5f * (RL_LOG2PI - logf(pr) + pr * e * e);
+      } else {
+        lp += -0.5f * (lc + pconst[j] * e * e);
       }
     }
   };
