@@ -19,8 +19,9 @@
 //
 // Per RHS evaluation: 20 MFMAs forward (8 first-layer, 12 second-layer); the adjoint adds 24 transposed ones.  The
 // 21 time-invariant inputs are folded into the first layers' accumulator initial values by 24 MFMAs in the prologue.
-// Weight gradients use the same per-evaluation dump as the VALU kernels (vihds_blackbox.hpp), contracted on the host
-// by batched GEMMs.
+// Weight gradients: accumulated on chip as Gram tiles by the cooperating-wavefront kernels (vihds_blackbox_split.hpp,
+// the default); the one-wavefront adjoint below (kernel_variant 4) writes the same per-evaluation dump as the VALU
+// kernels (vihds_blackbox.hpp) for vihds_gram_blocks.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -177,8 +178,9 @@ struct BbMfmaT {
   // tile of pre-activation adjoints and Y a tile of layer inputs, both already in registers in the C/D layout (lane =
   // (trajectory, quarter)).  The contraction index of an MFMA is K, so the tiles are turned into "row" layout -- lane
   // (row i, k-slot kq), register s = T[i][trajectory 4s + kq], which is the A layout and the B layout at once -- through
-  // a per-wavefront LDS buffer (one 16-byte store and four loads per tile), and 32 MFMAs per evaluation accumulate the
-  // eight 16x16 output tiles in registers:
+  // an LDS buffer (one 16-byte store and four loads per tile; since round 3 the stores are the main wavefronts', the loads and
+  // the MFMAs the helper wavefronts': vihds_blackbox_split.hpp), and 32 MFMAs per evaluation accumulate the eight 16x16
+  // output tiles (at the ICML sizes) in registers:
   //   tiles 0,1: d z (states' 2nd layer, 16 rows) x h[m]     -> Wp / Wd        tiles 2,3: gs[m] x inputs -> Wh
   //   tiles 4,5: d zp (precisions' 2nd layer)     x g[m]     -> Vp / Vd        tiles 6,7: gp[m] x inputs -> Vh
   // The 573 MB per-evaluation dump and its contraction pass (vihds_gram_blocks) disappear; a wavefront leaves 8 KB of
@@ -186,11 +188,6 @@ struct BbMfmaT {
   static constexpr int GT_LD = 20, GT_TILE = 16 * GT_LD, GT_NT = 3 + 2 * MS + 2 * MP, GT_WAVE = GT_NT * GT_TILE;  // floats
   // LDS tile slots of one hand-over: dz, dzp, inputs, then h[m], gs[m] (states), g[m], gp[m] (precisions)
   static constexpr int T_DZ = 0, T_DZP = 1, T_IN = 2, T_H = 3, T_GS = T_H + MS, T_G = T_GS + MS, T_GP = T_G + MP;
-  __device__ __forceinline__ static void lds_fence() {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-  }
   __device__ __forceinline__ static void put_cols(float* buf, const f32x4& t, int lane) {
     *reinterpret_cast<f32x4*>(buf + (lane & 15) * GT_LD + 4 * (lane >> 4)) = t;
   }
@@ -316,10 +313,9 @@ struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
     float bs[6];     // running sums of dz[0..3], dzp[0..1] (-> output-bias gradients)
   };
   // (d eval / d y)^T v, accumulating Delta (hidden pre-activation adjoint sums) and dumping the evaluation's fields
-  template <bool GRAM>
   __device__ __forceinline__ static State eval_vjp(float t, const State& y, const State& v, int q, bool live,
                                                    const Weights& W, const WeightsT& WT, const f32x4 hc[2][2],
-                                                   f32x4 delta[2][2], Dump& D, f32x4* G, float* gbuf, int lane) {
+                                                   f32x4 delta[2][2], Dump& D, int lane) {
     Act A;
     eval(t, y, q, W, hc, A);
     State yb;
@@ -386,11 +382,10 @@ struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
     return yb;
   }
 
-  template <int SOLVER, bool GRAM>
+  template <int SOLVER>
   __device__ __forceinline__ static State step_vjp(float t0, float t1, float h0, const State& y, const State& lam_in,
                                                    int q, bool live, const Weights& W, const WeightsT& WT,
-                                                   const f32x4 hc[2][2], f32x4 delta[2][2], Dump& D, f32x4* G,
-                                                   float* gbuf, int lane) {
+                                                   const f32x4 hc[2][2], f32x4 delta[2][2], Dump& D, int lane) {
     Act A;
     State lam = lam_in;
     auto add = [](State& x, const State& w, float s) { x.a += s * w.a; x.b += s * w.b; x.v += s * w.v; };
@@ -400,21 +395,21 @@ struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
       const State k1 = eval(t0, y, q, W, hc, A);
       const State ya = axpy(y, h, k1);
       State vv = scaled(lam, 0.5f * h);
-      const State w = eval_vjp<GRAM>(t1, ya, vv, q, live, W, WT, hc, delta, D, G, gbuf, lane);
+      const State w = eval_vjp(t1, ya, vv, q, live, W, WT, hc, delta, D, lane);
       add(lam, w, 1.f);
       add(vv, w, h);
-      add(lam, eval_vjp<GRAM>(t0, y, vv, q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
+      add(lam, eval_vjp(t0, y, vv, q, live, W, WT, hc, delta, D, lane), 1.f);
       return lam;
     } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      add(lam, eval_vjp<GRAM>(t0, y, scaled(lam, t1 - t0), q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
+      add(lam, eval_vjp(t0, y, scaled(lam, t1 - t0), q, live, W, WT, hc, delta, D, lane), 1.f);
       return lam;
     } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
       const float dt = t1 - t0;
       const State k1 = eval(t0, y, q, W, hc, A);
       const State ym = axpy(y, dt * 0.5f, k1);
-      const State w = eval_vjp<GRAM>(t0 + dt * 0.5f, ym, scaled(lam, dt), q, live, W, WT, hc, delta, D, G, gbuf, lane);
+      const State w = eval_vjp(t0 + dt * 0.5f, ym, scaled(lam, dt), q, live, W, WT, hc, delta, D, lane);
       add(lam, w, 1.f);
-      add(lam, eval_vjp<GRAM>(t0, y, scaled(w, 0.5f * dt), q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
+      add(lam, eval_vjp(t0, y, scaled(w, 0.5f * dt), q, live, W, WT, hc, delta, D, lane), 1.f);
       return lam;
     } else {
       const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
@@ -426,13 +421,13 @@ struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
       const State y4 = {y.a + dt * (k1.a - k2.a + k3.a), y.b + dt * (k1.b - k2.b + k3.b), y.v + dt * (k1.v - k2.v + k3.v)};
       const State k4b = scaled(lam, d8);
       State k1b = k4b, k2b = scaled(k4b, 3.f), k3b = scaled(k4b, 3.f);
-      State w = eval_vjp<GRAM>(t0 + dt, y4, k4b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
+      State w = eval_vjp(t0 + dt, y4, k4b, q, live, W, WT, hc, delta, D, lane);
       add(lam, w, 1.f); add(k1b, w, dt); add(k2b, w, -dt); add(k3b, w, dt);
-      w = eval_vjp<GRAM>(t0 + 2.f * d3, y3, k3b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
+      w = eval_vjp(t0 + 2.f * d3, y3, k3b, q, live, W, WT, hc, delta, D, lane);
       add(lam, w, 1.f); add(k1b, w, -d3); add(k2b, w, dt);
-      w = eval_vjp<GRAM>(t0 + d3, y2, k2b, q, live, W, WT, hc, delta, D, G, gbuf, lane);
+      w = eval_vjp(t0 + d3, y2, k2b, q, live, W, WT, hc, delta, D, lane);
       add(lam, w, 1.f); add(k1b, w, d3);
-      add(lam, eval_vjp<GRAM>(t0, y, k1b, q, live, W, WT, hc, delta, D, G, gbuf, lane), 1.f);
+      add(lam, eval_vjp(t0, y, k1b, q, live, W, WT, hc, delta, D, lane), 1.f);
       return lam;
     }
   }
@@ -491,14 +486,11 @@ __host__ __device__ inline size_t bb_mfma_head_floats(int n, int T, int solver, 
   return (size_t)(T - 1) * BB::stages(solver) * BB::NF * n;
 }
 
-template <int SOLVER, bool GRAM>
+template <int SOLVER>
 __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   using K = BbMfma;
   using BB = K::BB;
-  static_assert(!GRAM, "on-chip weight gradients: bb_split_bwd_kernel (vihds_blackbox_split.hpp)");
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  f32x4* G = nullptr;
-  float* gbuf = nullptr;
   const int jj = lane & 15, q = lane >> 4;
   const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
   const bool live = i0 < a.n;
@@ -536,7 +528,7 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
       ob_next = ob[k - 1];
       tLo = a.times[k - 1];
     }
-    if (k < a.T - 1) lam = K::template step_vjp<SOLVER, GRAM>(tK, tHi, h0, y, lam, q, live, W, WT, hc, delta, D, G, gbuf, lane);
+    if (k < a.T - 1) lam = K::template step_vjp<SOLVER>(tK, tHi, h0, y, lam, q, live, W, WT, hc, delta, D, lane);
     tHi = tK;
     // injection at time k: signal q = OD (q = 0) or OD * state q; precision q is an ODE state
     const float x0 = __shfl(y.a, jj, 64);
@@ -580,7 +572,7 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
       }
       a.g_theta[(size_t)a.slot_row[K::NLAT + q] * n + i] = lam.a;  // init_x .. init_cfp
       // Delta [HS+HP][n] behind the evaluation dump (or behind the Gram partial sums)
-      float* dd = a.aux + bb_mfma_head_floats(a.n, a.T, a.solver, GRAM);
+      float* dd = a.aux + bb_mfma_head_floats(a.n, a.T, a.solver, false);
       _Pragma("unroll") for (int m = 0; m < 2; ++m)
         _Pragma("unroll") for (int r = 0; r < 4; ++r) {
           const int us = K::unit_of(16 * m + 4 * q + r, K::HS), up = K::unit_of(16 * m + 4 * q + r, K::HP);
@@ -642,7 +634,7 @@ inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream
   const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
 #define VIHDS_BCASE(SV)                                                                                  \
   case SV:                                                                                               \
-    if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV, false>), grid, block, 0, st, a);            \
+    if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV>), grid, block, 0, st, a);            \
     else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);                            \
     return VIHDS_OK;
   switch (solver) {
