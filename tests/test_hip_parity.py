@@ -1890,16 +1890,17 @@ def _relay_problem(model, B, S, T, seed, dt=0.25):
     obs = torch.rand(B, 4, T, generator=g).to(DEV)
     wts = None
     if model.endswith("_precisions"):
-        n_in = 1 + {"relay": 12, "degrader": 11, "prpr": 6}[model.split("_")[0]]  # t and the species
+        n_in = 1 + {"relay": 12, "degrader": 11, "prpr": 6, "auto": 4}[model.split("_")[0]]  # t and the species
         wts = (torch.randn(2 * (4 * n_in + 4), generator=g) * 0.2).to(DEV)
     return slots, theta, cond, times, obs, wts
 
 
 @pytest.mark.parametrize("model", ["relay_constant", "relay_constant_precisions", "degrader_constant",
-                                   "degrader_constant_precisions", "prpr_constant", "prpr_constant_precisions"])
+                                   "degrader_constant_precisions", "prpr_constant", "prpr_constant_precisions",
+                                   "auto_constant", "auto_constant_precisions"])
 @pytest.mark.parametrize("solver", ["modeuler", "modeulerwhile", "euler", "midpoint", "rk4"])
 def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
-    """relay_constant / degrader_constant / prpr_constant (and their _precisions forms) with one lane per state, sixteen
+    """relay_constant / degrader_constant / prpr_constant / auto_constant (and their _precisions forms) with one lane per state, sixteen
     lanes per trajectory (csrc/vihds_relay_lanes.hpp: the automatic choice
     below 16 384 trajectories) against the one-thread-per-trajectory kernels (kernel_variant 1, themselves checked against
     the restatement of the reference's equations): trajectories, predictions, log-likelihood, every theta gradient --
@@ -1913,7 +1914,7 @@ def test_relay_lane_kernels_match_thread_per_trajectory(model, solver):
     row_of = {n: i for i, n in enumerate(slots)}
     outs = {}
     g = torch.Generator().manual_seed(2)
-    N = {"relay": 12, "degrader": 11, "prpr": 6}[model.split("_")[0]] + (4 if wts is not None else 0)
+    N = {"relay": 12, "degrader": 11, "prpr": 6, "auto": 4}[model.split("_")[0]] + (4 if wts is not None else 0)
     up = (torch.randn(T, N, B, S, generator=g).to(DEV) * 1e-3, torch.randn(T, 4, B, S, generator=g).to(DEV) * 1e-3,
           torch.randn(4, B, S, generator=g).to(DEV) * 1e-3)
     for variant in (1, 0):

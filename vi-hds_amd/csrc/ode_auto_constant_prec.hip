@@ -1,9 +1,15 @@
 // Instantiates the fused forward / adjoint ODE kernels for one model (one translation unit per model so the
 // library builds in parallel).  Model definition: vihds_models.hpp.
 #include "vihds_ode_kernels.hpp"
+#include "vihds_relay_lanes.hpp"
 
 namespace vihds {
 int launch_auto_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  // below 16 384 trajectories: one lane per state, sixteen lanes per trajectory (vihds_relay_lanes.hpp, RlAuto); the adaptive
+  // controller, a hidden layer in the precision network and kernel_variant 1 keep one thread per trajectory
+  if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&
+      !(backward && true && a.g_weights && !a.aux))
+    return relay_lanes_launch<RlAuto, true>(backward, solver, a, st);
   return launch_ode<WithPrec<AutoConstant>>(backward, solver, a, st);
 }
 int n_slots_auto_constant_prec() { return WithPrec<AutoConstant>::NSLOT; }

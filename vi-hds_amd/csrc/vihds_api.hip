@@ -346,6 +346,7 @@ static int lane_model_species(int model) {
     case VIHDS_MODEL_RELAY_CONSTANT_PRECISIONS: return RlRelay::NSP;
     case VIHDS_MODEL_DEGRADER_CONSTANT_PRECISIONS: return RlDegrader::NSP;
     case VIHDS_MODEL_PRPR_CONSTANT_PRECISIONS: return RlPrpr::NSP;
+    case VIHDS_MODEL_AUTO_CONSTANT_PRECISIONS: return RlAuto::NSP;
   }
   return 0;
 }

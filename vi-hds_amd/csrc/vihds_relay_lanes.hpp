@@ -273,7 +273,7 @@ __device__ __forceinline__ float rl_rhs_vjp(const RlLane& c, float t, float Y, f
 struct RlRelay {  // reference models/relay_constant.py:91-134
   using M = RelayConstant;
   static constexpr int NSP = 12, Q0 = 10, NCOND = 2;
-  static constexpr bool HAS_P = true, HAS_Q = true;
+  static constexpr bool HAS_P = true, HAS_Q = true, OBS_SUM = true;
   __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI : (l == 9 ? wI : 0.f); }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
@@ -316,7 +316,7 @@ struct RlRelay {  // reference models/relay_constant.py:91-134
 struct RlDegrader {  // reference models/degrader_constant.py:103-143: aiiA in lane 8, c6 / c12 = x rC aiiA in lanes 9, 10
   using M = DegraderConstant;
   static constexpr int NSP = 11, Q0 = 9, NCOND = 3;
-  static constexpr bool HAS_P = true, HAS_Q = true;
+  static constexpr bool HAS_P = true, HAS_Q = true, OBS_SUM = true;
   __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI + wI : 0.f; }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
@@ -354,8 +354,8 @@ struct RlDegrader {  // reference models/degrader_constant.py:103-143: aiiA in l
 };
 struct RlPrpr {  // reference models/prpr_constant.py:46-69: every species with a constant production
   using M = PrprConstant;
-  static constexpr int NSP = 6, Q0 = 14, NCOND = 2;
-  static constexpr bool HAS_P = false, HAS_Q = false;
+  static constexpr int NSP = 6, Q0 = 14, NCOND = 0;  // (prpr_constant reads no treatment: a.cond may be empty)
+  static constexpr bool HAS_P = false, HAS_Q = false, OBS_SUM = true;
   __device__ static float source_adjoint(int, float, float) { return 0.f; }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc];
@@ -375,6 +375,30 @@ struct RlPrpr {  // reference models/prpr_constant.py:46-69: every species with 
     pb[M::P_rc] = T_(1, 0) + T_(2, 0) * p[M::P_aYFP] + T_(3, 0) * p[M::P_aCFP] + T_(4, 0) * p[M::P_a530] + T_(5, 0) * p[M::P_a480];
     pb[M::P_drfp] = T_(1, 7); pb[M::P_dyfp] = T_(2, 7); pb[M::P_dcfp] = T_(3, 7);
     pb[M::P_aYFP] = T_(2, 0) * rc; pb[M::P_aCFP] = T_(3, 0) * rc; pb[M::P_a530] = T_(4, 0) * rc; pb[M::P_a480] = T_(5, 0) * rc;
+  }
+};
+
+struct RlAuto {  // reference models/auto_constant.py:42-63 (observation: x, x rfp, x f530, x f480 -- :89-97)
+  using M = AutoConstant;
+  static constexpr int NSP = 4, Q0 = 14, NCOND = 0;
+  static constexpr bool HAS_P = false, HAS_Q = false, OBS_SUM = false;
+  __device__ static float source_adjoint(int, float, float) { return 0.f; }
+  __device__ static void lane(int l, const float* p, RlLane& c) {
+    const float rc = p[M::P_rc];
+    switch (l) {
+      case 1: c.deg = p[M::P_drfp]; c.F0 = rc; break;
+      case 2: c.F0 = rc * p[M::P_a530]; break;
+      case 3: c.F0 = rc * p[M::P_a480]; break;
+      default: break;
+    }
+    c.gsgn = l == 0 ? -1.f : (l <= 3 ? 1.f : 0.f);
+  }
+  template <class TF>
+  __device__ static void map(TF T_, const float* p, float* pb) {
+    const float rc = p[M::P_rc];
+    pb[M::P_rc] = T_(1, 0) + T_(2, 0) * p[M::P_a530] + T_(3, 0) * p[M::P_a480];
+    pb[M::P_drfp] = T_(1, 7);
+    pb[M::P_a530] = T_(2, 0) * rc; pb[M::P_a480] = T_(3, 0) * rc;
   }
 };
 
@@ -416,7 +440,8 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
     c.a_ip = l < 4 ? 36 + l : 46 + (l & 1);
   }
   c.n0 = (l & 3) == 0 ? 1.f : 0.f; c.n1 = (l & 3) == 1 ? 1.f : 0.f; c.n2 = (l & 3) == 2 ? 1.f : 0.f; c.n3 = (l & 3) == 3 ? 1.f : 0.f;
-  c.i0 = c.m0; c.i1 = l == 1 ? 1.f : 0.f; c.i2 = (l == 2 || l == 4) ? 1.f : 0.f; c.i3 = (l == 3 || l == 5) ? 1.f : 0.f;
+  c.i0 = c.m0; c.i1 = l == 1 ? 1.f : 0.f; c.i2 = (l == 2 || (LM::OBS_SUM && l == 4)) ? 1.f : 0.f;
+  c.i3 = (l == 3 || (LM::OBS_SUM && l == 5)) ? 1.f : 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
   c.b2 = rl_v2{0.f, 0.f};
@@ -447,6 +472,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
   constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP;
+  constexpr float OS = LM::OBS_SUM ? 1.f : 0.f;  // observed signals 2, 3: x (yfp + f530), x (cfp + f480) -- or x y2, x y3 (auto_constant)
   __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
   extern __shared__ float in_lds[];
   const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
@@ -463,7 +489,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
     for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
   }
   RlLane c;
-  float th[M::NSLOT], cc[LM::NCOND], p[M::NP], y, pconst[4];
+  float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], y, pconst[4];
   rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y, pconst);
   __syncthreads();
   const float* tl = in_lds;
@@ -478,7 +504,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   // (straight-line for all sixteen lanes -- signal j = l & 3 --; only lanes 0..3 store)
   auto observe = [&](int k) {
     const float x = pt[0];
-    const float inner = c.n0 + c.n1 * pt[1] + c.n2 * (pt[2] + pt[4]) + c.n3 * (pt[3] + pt[5]);
+    const float inner = c.n0 + c.n1 * pt[1] + c.n2 * (pt[2] + OS * pt[4]) + c.n3 * (pt[3] + OS * pt[5]);
     const float xp = x * inner;
     if (a.xpred && live && l < 4) a.xpred[((size_t)k * 4 + j) * n + i] = xp;
     if (a.logp) {
@@ -536,6 +562,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
   constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP, NIN = 1 + NSP, NWROW = rl_nwrow(NIN), NWG = rl_nwg(NIN);
+  constexpr float OS = LM::OBS_SUM ? 1.f : 0.f;
   __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
   __shared__ float tab[RL_TR][RL_G][10];   // epilogue: per-lane accumulators of a trajectory
   __shared__ float wred[PREC ? RL_TR : 1][PREC ? NWG : 1];
@@ -555,7 +582,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   RlLane c;
   float pconst[4];
   {  // (theta and the prepared parameters are not kept across the time loop: the epilogue's one lane fetches them again)
-    float th[M::NSLOT], cc[LM::NCOND], p[M::NP], y_unused;
+    float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], y_unused;
     rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y_unused, pconst);
   }
   __syncthreads();
@@ -649,7 +676,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     }
     const float x = ox;
     // (straight-line for all lanes -- glp is zero outside lanes 0..3 --, only the two stores are the four lanes')
-    const float inner = c.n0 + c.n1 * oy1 + c.n2 * (oy2 + oy4) + c.n3 * (oy3 + oy5);
+    const float inner = c.n0 + c.n1 * oy1 + c.n2 * (oy2 + OS * oy4) + c.n3 * (oy3 + OS * oy5);
     const float e = x * inner - ob[j * a.T + k];
     const float pr = PREC ? opr : pconst[j];
     float xpb = -glp * pr * e;
@@ -661,7 +688,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     const float y1 = oy1, y2 = oy2, y3 = oy3, y4 = oy4, y5 = oy5;
     rl_wave_fence();
     const float4 xb4 = *reinterpret_cast<const float4*>(pt + 32);
-    float inj = c.i0 * (xb4.x + xb4.y * y1 + xb4.z * (y2 + y4) + xb4.w * (y3 + y5)) + x * (c.i1 * xb4.y + c.i2 * xb4.z + c.i3 * xb4.w);
+    float inj = c.i0 * (xb4.x + xb4.y * y1 + xb4.z * (y2 + OS * y4) + xb4.w * (y3 + OS * y5)) + x * (c.i1 * xb4.y + c.i2 * xb4.z + c.i3 * xb4.w);
     if (PREC) inj = fmaf(c.isP, pt[36 + ((l - NSP) & 3)], inj);
     lam += inj;
     if (a.g_traj && l < N) lam += a.g_traj[((size_t)k * N + l) * n + i];
@@ -676,7 +703,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   }
   rl_wave_fence();
   if (l == 0) {
-    float th[M::NSLOT], cc[LM::NCOND], p[M::NP], pb[M::NP], thb[M::NSLOT], lam0[NSP];
+    float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], pb[M::NP], thb[M::NSLOT], lam0[NSP];
 #pragma unroll
     for (int q = 0; q < M::NSLOT; ++q) th[q] = a.theta[(size_t)a.slot_row[q] * a.n + i];
 #pragma unroll
