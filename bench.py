@@ -305,7 +305,9 @@ def run_workload(a, name):
     P = len(model.encoder.names)
     N = int(hip.lib().vihds_model_n_states(hip.MODELS[ode.model_key]))
     s_local = S // world if strong else S
-    fwd_b = 4 * (P * B * s_local + B * s_local * N * T + B * s_local * 4 * T)
+    # (evaluation passes with params.lazy_x_predict: vihds_ode_fwd is handed xpred == NULL, so x_predict leaves the numerator)
+    stores_xpred = not (mode == "eval" and bool(settings.params.get("lazy_x_predict", True)))
+    fwd_b = 4 * (P * B * s_local + B * s_local * N * T + (B * s_local * 4 * T if stores_xpred else 0))
     bwd_b = 4 * (B * s_local * N * T + P * B * s_local)
     theta_b = 4 * (2 * P * B * s_local + 2 * B * s_local)
     n_eval = (T - 1) * {"euler": 1, "rk4": 4}.get(solver, 2)
@@ -351,7 +353,10 @@ def run_workload(a, name):
                               "launch stream",
                     "numerator_note": ("SURVEY 8d: %d flop per RHS evaluation and trajectory x %d evaluations x %d "
                                        "trajectories forward, backward counted as 2x forward" % (BLACKBOX_FLOP_PER_EVAL, n_eval, B * s_local))
-                    if bound == "mfma" else "SURVEY 8d fixed numerator: fwd = theta + trajectory + x_predict, bwd = trajectory + d theta",
+                    if bound == "mfma" else ("SURVEY 8d fixed numerator: fwd = theta + trajectory + x_predict, bwd = trajectory + d theta"
+                                                            if stores_xpred else
+                                                            "SURVEY 8d numerator without the x_predict term (fwd = theta + trajectory): "
+                                                            "the evaluation pass does not store x_predict (params.lazy_x_predict)"),
                     "other_kernels": [entry(k) for k in timed if k != dom]}
         mf = os.path.join(ROOT, "profiles", "%s_mfma_busy.json" % name)
         if bound == "mfma" and os.path.exists(mf):

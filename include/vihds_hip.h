@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 10
+#define VIHDS_ABI_VERSION 11
 
 /* error codes */
 #define VIHDS_OK 0
@@ -342,6 +342,18 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
                        const float* traj, const float* xpred, const float* theta, const int* prec_rows,
                        float* iw_predict_mu /*[B][4][T]*/, float* iw_predict_std /*[B][4][T]*/,
                        float* iw_states /*[B][n_species][T]*/, float* iw_variance /*[B][4][T]*/, void* stream);
+
+/* The same summaries without a stored x_predict: the four observed signals are formed from the states the kernel reads
+ * anyway, by the model's observation map (OdeModel.observe, vihds/ode.py:84-93; overridden by the inducer and the
+ * direct-read models) -- the forward launch can then be called with xpred == NULL and the evaluation pass neither
+ * writes nor re-reads the [T][4][B][S] array.  observe_kind: */
+#define VIHDS_OBS_DEFAULT 0 /* x, x*y1, x*(y2+y4), x*(y3+y5)   (needs n_species >= 6) */
+#define VIHDS_OBS_DIRECT 1  /* x, x*y1, x*y2, x*y3             (needs n_species >= 4) */
+#define VIHDS_OBS_INDUCER 2 /* x, x*y1, x*(y2+y3), x*y4        (needs n_species >= 5) */
+int vihds_iw_summaries_states(int B, int S, int T, int N_total, int n_species, int observe_kind, const float* log_w,
+                              const float* lse, const float* traj, const float* theta, const int* prec_rows,
+                              float* iw_predict_mu, float* iw_predict_std, float* iw_states, float* iw_variance,
+                              void* stream);
 
 /* q(theta | data) encoder (vihds/encoders.py): ConditionalEncoder.forward :49-55 (Conv1d -> AvgPool1d(stride 1) ->
  * Linear -> tanh), the per-parameter Linear(n,1) heads of Q_Local :143-169 and Q_Global_Cond :187-213, Q_Global's free

@@ -138,6 +138,39 @@ def test_evaluation_results_and_graph_step():
     assert np.isfinite(eager)
 
 
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "auto_constant_tiny_modeuler",
+                                  "dr_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler"])
+def test_evaluation_without_a_stored_x_predict_gives_the_same_results(name):
+    """params.lazy_x_predict (evaluation passes leave x_predict to the summaries kernel) against the pass that stores it:
+    the same Results, and the (x_states, x_predict, precisions) tuple a plugin reads from the decoder is the stored one."""
+    import e2e_util as E
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    fx = Fixture(name)
+    outs, tuples = [], []
+    for lazy in (False, True):
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, lazy_x_predict=lazy)
+        model = build_model(args, settings, data, parameters)
+        training = Training(args, settings, data, parameters, model)
+        batch = E.batch_from_fixture(fx, settings.device)
+        model.eval()
+        np.random.seed(11)
+        torch.manual_seed(11)
+        with torch.no_grad():
+            results, theta, q, p = model(batch, args.train_samples)
+            assert results.solution.has_x_predict == (not lazy)
+            outs.append(training.cost(batch, results, theta, q, p, full_output=True))
+            assert results.solution.has_x_predict == (not lazy)  # (the summaries did not materialise it)
+            tuples.append(tuple(results))
+    a, b = outs
+    assert a.elbo == b.elbo
+    for k in ("iw_predict_mu", "iw_predict_std", "iw_states", "iw_variance"):
+        assert np.array_equal(getattr(a, k), getattr(b, k)), k
+    for x, y in zip(tuples[0], tuples[1]):
+        assert x.shape == y.shape and torch.equal(x, y)
+
+
 class _TraceDataset(torch.utils.data.Dataset):
     def __init__(self, z):
         self.times = torch.tensor(z["times"])

@@ -569,6 +569,48 @@ def test_iw_summaries_shapes_against_float64(n_species, S, from_theta):
     assert rel_err(sd.cpu().double(), (r_sq - r_mu ** 2).sqrt()) < 1e-3
 
 
+@pytest.mark.parametrize("kind,n_species,from_theta", [("default", 8, True), ("default", 6, False), ("default", 17, True),
+                                                       ("direct", 4, True), ("direct", 12, False), ("direct", 20, True),
+                                                       ("inducer", 5, True), ("inducer", 18, False)])
+def test_iw_summaries_form_x_predict_from_the_states(kind, n_species, from_theta):
+    """vihds_iw_summaries_states (no stored x_predict) against vihds_iw_summaries on the x_predict the observation map
+    gives (reference ode.py:84-93, inducer_constant.py:106-114, the direct-read models): the same four outputs, for the three maps,
+    both kernels (up to 16 species / more) and both sources of the precisions."""
+    from vihds import ops
+
+    B, T, S = 3, 9, 333
+    g = torch.Generator().manual_seed(7 + n_species)
+    N = n_species + (0 if from_theta else 4)
+    traj = (torch.rand(T, N, B, S, generator=g) + 0.5).to(DEV)
+    x0 = traj[:, 0]
+    if kind == "default":
+        xp = [x0, x0 * traj[:, 1], x0 * (traj[:, 2] + traj[:, 4]), x0 * (traj[:, 3] + traj[:, 5])]
+    elif kind == "inducer":
+        xp = [x0, x0 * traj[:, 1], x0 * (traj[:, 2] + traj[:, 3]), x0 * traj[:, 4]]
+    else:
+        xp = [x0, x0 * traj[:, 1], x0 * traj[:, 2], x0 * traj[:, 3]]
+    xpred = torch.stack(xp, 1).contiguous()
+    log_w = (torch.randn(B, S, generator=g) * 2.0).to(DEV)
+    lse = torch.logsumexp(log_w, 1)
+    theta = (torch.rand(9, B, S, generator=g) + 0.5).to(DEV) if from_theta else None
+    prow = [7, 2, 5, 3] if from_theta else None
+    stored = ops.iw_summaries(log_w, lse, traj, xpred, n_species, theta=theta, prec_rows=prow)
+    formed = ops.iw_summaries(log_w, lse, traj, None, n_species, theta=theta, prec_rows=prow, observe_kind=kind)
+    for a, b in zip(stored, formed):
+        assert torch.equal(a, b)
+
+
+def test_iw_summaries_states_refuse_a_map_wider_than_the_model():
+    from vihds import ops
+
+    traj = torch.ones(3, 5, 2, 4, device=DEV)
+    log_w = torch.zeros(2, 4, device=DEV)
+    theta = torch.ones(4, 2, 4, device=DEV)
+    with pytest.raises(RuntimeError):
+        ops.iw_summaries(log_w, torch.logsumexp(log_w, 1), traj, None, 5, theta=theta, prec_rows=[0, 1, 2, 3],
+                         observe_kind="default")
+
+
 def test_iw_summaries_full_evaluation_size_properties():
     """BASELINE config 3's evaluation shape (B=234, n_iwae=1000, T=86, 8 species: 644 MB of trajectories + 322 MB of
     predictions through vihds_iw_summaries), checked through properties that do not need a CPU pass of that size:

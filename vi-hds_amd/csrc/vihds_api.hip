@@ -93,8 +93,8 @@ bool step_tail_supported(const vihds_encoder_shape&, int, int);
 void launch_step_tail(const vihds_encoder_shape&, const vihds_step_tail_args&, hipStream_t);
 void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, float, const float*,
                  hipStream_t);
-void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, const float*,
-                         const int*, float*, float*, float*, float*, hipStream_t);
+void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, int,
+                         const float*, const int*, float*, float*, float*, float*, hipStream_t);
 
 struct ModelEntry {
   int (*launch)(bool, int, const OdeArgs&, hipStream_t);
@@ -649,9 +649,25 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
     return fail(VIHDS_E_BADARG, "bad argument");
   if (theta && !prec_rows) return fail(VIHDS_E_BADARG, "theta given without prec_rows");
   if (!theta && N_total < n_species + 4) return fail(VIHDS_E_BADARG, "neural precisions need N_total >= n_species+4");
-  launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, theta, prec_rows, iw_predict_mu,
-                      iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
+  launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, VIHDS_OBS_DEFAULT, theta, prec_rows,
+                      iw_predict_mu, iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
   return check_hip("vihds_iw_summaries launch");
+}
+int vihds_iw_summaries_states(int B, int S, int T, int N_total, int n_species, int observe_kind, const float* log_w,
+                              const float* lse, const float* traj, const float* theta, const int* prec_rows,
+                              float* iw_predict_mu, float* iw_predict_std, float* iw_states, float* iw_variance,
+                              void* stream) {
+  if (B <= 0 || S <= 0 || T <= 0 || !log_w || !lse || !traj || !iw_predict_mu || !iw_predict_std || !iw_states ||
+      !iw_variance)
+    return fail(VIHDS_E_BADARG, "bad argument");
+  if (theta && !prec_rows) return fail(VIHDS_E_BADARG, "theta given without prec_rows");
+  if (!theta && N_total < n_species + 4) return fail(VIHDS_E_BADARG, "neural precisions need N_total >= n_species+4");
+  const int need = observe_kind == VIHDS_OBS_DEFAULT ? 6 : (observe_kind == VIHDS_OBS_INDUCER ? 5 : 4);
+  if (observe_kind < VIHDS_OBS_DEFAULT || observe_kind > VIHDS_OBS_INDUCER || n_species < need)
+    return fail(VIHDS_E_BADARG, "observe_kind / n_species: the observation map reads more species than the model has");
+  launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, nullptr, observe_kind, theta, prec_rows,
+                      iw_predict_mu, iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
+  return check_hip("vihds_iw_summaries_states launch");
 }
 
 static int check_encoder_shape(const vihds_encoder_shape* s) {

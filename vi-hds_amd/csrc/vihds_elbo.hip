@@ -669,8 +669,9 @@ template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
                     const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
-                    const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3, float* __restrict__ mu_out,
-                    float* __restrict__ std_out, float* __restrict__ states_out, float* __restrict__ var_out) {
+                    int obs_kind, const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3,
+                    float* __restrict__ mu_out, float* __restrict__ std_out, float* __restrict__ states_out,
+                    float* __restrict__ var_out) {
   constexpr int NW = BLOCK / 64, NV = 12 + IWS_MAXSP;
   __shared__ float sm[NW][NV];
   const int b = blockIdx.x, t = blockIdx.y;
@@ -684,12 +685,22 @@ iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float
     const size_t i = (size_t)b * S + s;
     float xp[4], pc[4], st[IWS_MAXSP];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      xp[j] = xpred[((size_t)t * 4 + j) * n + i];
+    for (int j = 0; j < 4; ++j)
       pc[j] = theta ? theta[(size_t)prow[j] * n + i] : traj[((size_t)t * N_total + n_species + j) * n + i];
-    }
 #pragma unroll
     for (int j = 0; j < IWS_MAXSP; ++j) st[j] = j < n_species ? traj[((size_t)t * N_total + j) * n + i] : 0.f;
+    if (xpred) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xp[j] = xpred[((size_t)t * 4 + j) * n + i];
+    } else {
+      // the observed signals from the states this block reads anyway (OdeModel.observe, reference ode.py:84-93 and the
+      // models' overrides): x_predict then never has to be written by the forward kernel nor read back here
+      xp[0] = st[0];
+      xp[1] = st[0] * st[1];
+      if (obs_kind == VIHDS_OBS_DEFAULT) { xp[2] = st[0] * (st[2] + st[4]); xp[3] = st[0] * (st[3] + st[5]); }
+      else if (obs_kind == VIHDS_OBS_INDUCER) { xp[2] = st[0] * (st[2] + st[3]); xp[3] = st[0] * st[4]; }
+      else { xp[2] = st[0] * st[2]; xp[3] = st[0] * st[3]; }
+    }
     const float w = expf(log_w[i] - l);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -737,8 +748,9 @@ template <int BLOCK>
 __global__ void __launch_bounds__(BLOCK)
 iw_summaries_rows_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
                     const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
-                    const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3, float* __restrict__ mu_out,
-                    float* __restrict__ std_out, float* __restrict__ states_out, float* __restrict__ var_out) {
+                    int obs_kind, const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3,
+                    float* __restrict__ mu_out, float* __restrict__ std_out, float* __restrict__ states_out,
+                    float* __restrict__ var_out) {
   __shared__ float sm[BLOCK / 64];
   const int b = blockIdx.x, t = blockIdx.y;
   const size_t n = (size_t)B * S;
@@ -749,7 +761,18 @@ iw_summaries_rows_kernel(int B, int S, int T, int N_total, int n_species, const 
     for (int s = threadIdx.x; s < S; s += BLOCK) {
       const size_t i = (size_t)b * S + s;
       const float w = expf(log_w[i] - l);
-      const float xp = xpred[((size_t)t * 4 + j) * n + i];
+      float xp;
+      if (xpred) {
+        xp = xpred[((size_t)t * 4 + j) * n + i];
+      } else {
+        auto y = [&](int q) { return traj[((size_t)t * N_total + q) * n + i]; };
+        const float x0 = y(0);
+        if (j == 0) xp = x0;
+        else if (j == 1) xp = x0 * y(1);
+        else if (obs_kind == VIHDS_OBS_DEFAULT) xp = j == 2 ? x0 * (y(2) + y(4)) : x0 * (y(3) + y(5));
+        else if (obs_kind == VIHDS_OBS_INDUCER) xp = j == 2 ? x0 * (y(2) + y(3)) : x0 * y(4);
+        else xp = x0 * y(j);
+      }
       const float prec = theta ? theta[(size_t)prow[j] * n + i] : traj[((size_t)t * N_total + n_species + j) * n + i];
       const float iv = 1.f / prec;
       a_mu += w * xp;
@@ -912,16 +935,16 @@ void launch_adam(const vihds_adam_tensors& t, float* m, float* v, float* state, 
                      grad_scale, gate);
 }
 void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
-                         const float* traj, const float* xpred, const float* theta, const int* prec_rows, float* mu,
-                         float* sd, float* states, float* var, hipStream_t st) {
+                         const float* traj, const float* xpred, int obs_kind, const float* theta, const int* prec_rows,
+                         float* mu, float* sd, float* states, float* var, hipStream_t st) {
   int r[4] = {0, 0, 0, 0};
   if (theta && prec_rows) for (int j = 0; j < 4; ++j) r[j] = prec_rows[j];
   if (n_species <= IWS_MAXSP)
     hipLaunchKernelGGL((iw_summaries_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species, log_w,
-                       lse, traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+                       lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
   else
     hipLaunchKernelGGL((iw_summaries_rows_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species,
-                       log_w, lse, traj, xpred, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+                       log_w, lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
 }
 
 }  // namespace vihds

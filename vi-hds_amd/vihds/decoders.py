@@ -69,12 +69,20 @@ class Decoder(nn.Module):
             self.config, data.times, theta_conditioned, data.inputs, data.dev_1hot,
             condition_on_device=self.condition_on_device, observations=data.get("observations", None),
         )
-        x_states, precisions = self.ode_model.expand_precisions(theta_conditioned, data.times, solution)
-        x_predict = self.ode_model.observe(solution, theta_conditioned)
+        last = self.ode_model._last
         if writer is not None:
             self.ode_model.summaries(writer, epoch)
-        result = DecoderResult((x_states, x_predict, precisions))
-        last = self.ode_model._last
+        if not getattr(last, "has_x_predict", True):  # params.lazy_x_predict under no_grad: the tuple on demand
+
+            def build_eval():
+                xs, prec = self.ode_model.expand_precisions(theta_conditioned, data.times, solution)
+                return xs, self.ode_model.observe(solution, theta_conditioned), prec
+
+            result = LazyDecoderResult(build_eval)
+        else:
+            x_states, precisions = self.ode_model.expand_precisions(theta_conditioned, data.times, solution)
+            x_predict = self.ode_model.observe(solution, theta_conditioned)
+            result = DecoderResult((x_states, x_predict, precisions))
         result.solution = last
         result.log_p_by_species = last.log_p_by_species if getattr(last, "has_logp", False) else None
         return result, theta_conditioned

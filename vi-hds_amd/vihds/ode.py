@@ -17,11 +17,25 @@ from vihds.utils import default_get_value
 class DecodedSolution(object):
     """What one fused kernel launch produced for a batch: views in the reference's layouts."""
 
-    def __init__(self, traj, xpred, logp):
-        self.traj_buffer, self.xpred_buffer, self.logp_buffer = traj, xpred, logp  # [T,N,B,S], [T,4,B,S], [4,B,S]
+    def __init__(self, traj, xpred, logp, observe=None):
+        self.traj_buffer, self._xpred, self.logp_buffer = traj, xpred, logp  # [T,N,B,S], [T,4,B,S], [4,B,S]
         self.sol = traj.permute(2, 3, 1, 0)          # [B,S,N,T]  (reference ode.py:82)
-        self.x_predict = xpred.permute(2, 3, 1, 0)   # [B,S,4,T]  (reference ode.py:84-93)
         self.log_p_by_species = logp.permute(1, 2, 0)  # [B,S,4] (reference training.py:24-33)
+        self._observe = observe  # xpred None (params.lazy_x_predict): the map that forms it from `sol` if somebody asks
+
+    @property
+    def has_x_predict(self):
+        return self._xpred is not None
+
+    @property
+    def xpred_buffer(self):
+        if self._xpred is None:
+            self._xpred = self._observe(self.sol).permute(3, 2, 0, 1).contiguous()
+        return self._xpred
+
+    @property
+    def x_predict(self):
+        return self.xpred_buffer.permute(2, 3, 1, 0)   # [B,S,4,T]  (reference ode.py:84-93)
 
 
 class LazySolution(object):
@@ -210,10 +224,13 @@ class OdeModel(nn.Module):
         if obs is None:  # likelihood not requested: feed zeros (logp output is then meaningless and unused)
             obs = torch.zeros((packed.shape[1], 4, times.shape[0]), device=dev)
         row_offset, row_offset_map = getattr(theta, "_row_offset", None) or (None, None)
+        # evaluation passes (no graph to differentiate) leave x_predict to whoever asks for it: Training.cost's summaries
+        # form it inside their kernel, plugin code reading DecoderResult gets it from the map below
+        lazy = not torch.is_grad_enabled() and bool(default_get_value(config.params, "lazy_x_predict", True))
         traj, xpred, logp = ops.OdeSolveObserve.apply(spec, packed, conditions.to(dev), times, obs.to(dev),
                                                       dev_1hot.to(dev) if dev_1hot is not None else None,
-                                                      self.neural_weights(), row_offset, row_offset_map)
-        self._last = DecodedSolution(traj, xpred, logp)
+                                                      self.neural_weights(), row_offset, row_offset_map, not lazy)
+        self._last = DecodedSolution(traj, xpred, logp, observe=lambda sol: self._observe_map(sol))
         self._last.has_logp = observations is not None
         return self._last
 
@@ -311,6 +328,9 @@ class OdeModel(nn.Module):
         last = self._last
         if last is not None and x_sample.data_ptr() == last.sol.data_ptr() and x_sample.shape[3] == last.sol.shape[3]:
             return last.x_predict
+        return self._observe_map(x_sample)
+
+    def _observe_map(self, x_sample):
         x0 = x_sample[:, :, 0, :]
         if self.observe_kind == "default":
             xp = [x0, x0 * x_sample[:, :, 1, :], x0 * (x_sample[:, :, 2, :] + x_sample[:, :, 4, :]),

@@ -168,7 +168,8 @@ class OdeSolveObserve(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, spec, theta, cond, times, obs, dev1hot, weights, row_offset=None, row_offset_map=None):
+    def forward(ctx, spec, theta, cond, times, obs, dev1hot, weights, row_offset=None, row_offset_map=None,
+                want_xpred=True):
         _require_cuda(theta, cond, times, obs)
         theta, cond, times, obs = _c(theta), _c(cond), _c(times), _c(obs)
         R, B, S = theta.shape
@@ -178,7 +179,9 @@ class OdeSolveObserve(torch.autograd.Function):
         prob = spec.bind(B, S, T)
         N = spec.n_states
         traj = torch.empty((T, N, B, S), device=theta.device, dtype=torch.float32)
-        xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32)
+        # (want_xpred False: the observed signals are not written -- they are a pointwise map of the trajectory and the
+        # evaluation summaries form them in registers, vihds_iw_summaries_states; the second output is then None)
+        xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32) if want_xpred else None
         logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
         rc = _launch("ode_fwd", lambda: hip.lib().vihds_ode_fwd(
             ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
@@ -244,7 +247,7 @@ class OdeSolveObserve(torch.autograd.Function):
                 if ctx.needs_input_grad[7]:
                     g_off = g_theta[dst:dst + n].sum(2).t()
                 g_theta[src:src + n] += g_theta[dst:dst + n]
-            grads = grads + (g_off, None)[:len(ctx.needs_input_grad) - 7]
+            grads = grads + (g_off, None, None)[:len(ctx.needs_input_grad) - 7]
         return grads
 
 
@@ -1153,9 +1156,13 @@ def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None, defer=False):
     return IwaeLossSharded.apply(logp, log_p, log_q, S, group)
 
 
-def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None):
-    """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99)."""
-    _require_cuda(log_w, lse, traj, xpred)
+OBSERVE_KINDS = {"default": 0, "direct": 1, "inducer": 2}  # VIHDS_OBS_* of include/vihds_hip.h
+
+
+def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None, observe_kind="default"):
+    """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99).  xpred None: the observed signals
+    are formed from the trajectory by the model's observation map (observe_kind) inside the kernel."""
+    _require_cuda(log_w, lse, traj)
     T, N, B, S = traj.shape
     dev = traj.device
     mu = torch.empty((B, 4, T), device=dev)
@@ -1163,6 +1170,13 @@ def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None)
     st = torch.empty((B, n_species, T), device=dev)
     var = torch.empty((B, 4, T), device=dev)
     rows = (ctypes.c_int * 4)(*prec_rows) if prec_rows is not None else None
+    if xpred is None:
+        rc = hip.lib().vihds_iw_summaries_states(B, S, T, N, n_species, OBSERVE_KINDS[observe_kind], hip.ptr(_c(log_w)),
+                                                 hip.ptr(_c(lse)), hip.ptr(traj), hip.ptr(theta), rows, hip.ptr(mu),
+                                                 hip.ptr(sd), hip.ptr(st), hip.ptr(var), hip.current_stream())
+        hip.check(rc, "vihds_iw_summaries_states")
+        return mu, sd, st, var
+    _require_cuda(xpred)
     rc = hip.lib().vihds_iw_summaries(B, S, T, N, n_species, hip.ptr(_c(log_w)), hip.ptr(_c(lse)), hip.ptr(traj),
                                       hip.ptr(xpred), hip.ptr(theta), rows, hip.ptr(mu), hip.ptr(sd), hip.ptr(st),
                                       hip.ptr(var), hip.current_stream())

@@ -153,7 +153,8 @@ class Training:
     def cost(self, batch_data, batch_results, theta, q, p, full_output=False, writer=None, epoch=None):
         """reference training.py:127-174.  Returns {"elbo": -ELBO} (sic) or a Results object."""
         fused = getattr(batch_results, "log_p_by_species", None)
-        if fused is None or full_output:  # (the training fast path never materialises these)
+        sol = getattr(batch_results, "solution", None)
+        if fused is None or (full_output and sol is None):  # (the kernel paths never materialise these)
             x_states, x_predict, precisions = batch_results
         if fused is not None:
             logp = batch_results.solution.logp_buffer  # [4,B,S] straight from the ODE kernel
@@ -182,19 +183,20 @@ class Training:
             normalized_iws = (log_unnormalized_iws - lse[:, None]).exp()
             self._update_summaries(writer, epoch, q, log_unnormalized_iws, normalized_iws, logp.sum(0),
                                    log_p_by_species, elbo, log_p_theta, log_q_theta)
-        sol = getattr(batch_results, "solution", None)
         output = Results()
         ode_model = self.model.decoder.ode_model
         if sol is not None:
-            if ode_model.precisions.dynamic:
-                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
-                                        sol.xpred_buffer.detach(), x_states.shape[2])
+            traj = sol.traj_buffer.detach()
+            # (a solution without a stored x_predict -- params.lazy_x_predict -- has the kernel form it from the states)
+            xpred = sol.xpred_buffer.detach() if getattr(sol, "has_x_predict", True) else None
+            if ode_model.precisions.dynamic:  # the last four states are the precisions (reference precisions.py:89-94)
+                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), traj, xpred, traj.shape[1] - 4,
+                                        observe_kind=ode_model.observe_kind)
             else:
                 packed, row_of = theta.pack(ode_model.precisions.precision_vars)
                 rows = [row_of[v] for v in ode_model.precisions.precision_vars]
-                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), sol.traj_buffer.detach(),
-                                        sol.xpred_buffer.detach(), x_states.shape[2], theta=packed.detach(),
-                                        prec_rows=rows)
+                summ = ops.iw_summaries(log_unnormalized_iws.detach(), lse.detach(), traj, xpred, traj.shape[1],
+                                        theta=packed.detach(), prec_rows=rows, observe_kind=ode_model.observe_kind)
         else:
             w = (log_unnormalized_iws - lse[:, None]).exp()[:, :, None, None]
             mu = (w * x_predict).sum(1)
