@@ -350,6 +350,10 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
 #define VIHDS_OBS_DEFAULT 0 /* x, x*y1, x*(y2+y4), x*(y3+y5)   (needs n_species >= 6) */
 #define VIHDS_OBS_DIRECT 1  /* x, x*y1, x*y2, x*y3             (needs n_species >= 4) */
 #define VIHDS_OBS_INDUCER 2 /* x, x*y1, x*(y2+y3), x*y4        (needs n_species >= 5) */
+/* Tuning knob of both summaries entry points (process-wide, read at launch): how many consecutive time points one block
+ * of the pipelined kernel walks (S a multiple of 4 in 512..1024, <= 16 species).  0 = automatic (as many as leave >= 2048
+ * blocks, 2 to 8), > 0 = exactly that many, < 0 = the one-block-per-time-point kernel.  Returns the previous value. */
+int vihds_iw_summaries_plan(int time_points_per_block);
 int vihds_iw_summaries_states(int B, int S, int T, int N_total, int n_species, int observe_kind, const float* log_w,
                               const float* lse, const float* traj, const float* theta, const int* prec_rows,
                               float* iw_predict_mu, float* iw_predict_std, float* iw_states, float* iw_variance,

@@ -600,6 +600,38 @@ def test_iw_summaries_form_x_predict_from_the_states(kind, n_species, from_theta
         assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("n_species,S,from_theta,stored", [(8, 1000, True, False), (8, 1024, True, True),
+                                                           (6, 512, False, False), (12, 1000, False, True),
+                                                           (16, 772, True, False), (4, 1000, True, False)])
+def test_iw_summaries_pipelined_kernel_matches_one_block_per_time_point(n_species, S, from_theta, stored):
+    """The pipelined summaries kernel (a block walks several time points of a row, weights formed once, next rows in flight
+    during the sums) against the one-block-per-time-point kernel it replaces at these sizes: the same arithmetic in the same
+    order, so the four outputs are identical -- for every number of time points per block, T not a multiple of it."""
+    from vihds import hip, ops
+
+    B, T = 3, 11
+    g = torch.Generator().manual_seed(31 + n_species + S)
+    N = n_species + (0 if from_theta else 4)
+    traj = (torch.rand(T, N, B, S, generator=g) + 0.5).to(DEV)
+    xpred = (torch.rand(T, 4, B, S, generator=g) * 3.0).to(DEV) if stored else None
+    log_w = (torch.randn(B, S, generator=g) * 2.0).to(DEV)
+    lse = torch.logsumexp(log_w, 1)
+    theta = (torch.rand(9, B, S, generator=g) + 0.5).to(DEV) if from_theta else None
+    prow = [7, 2, 5, 3] if from_theta else None
+    kind = "default" if n_species >= 6 else "direct"
+    L = hip.lib()
+    before = L.vihds_iw_summaries_plan(-1)
+    try:
+        ref = ops.iw_summaries(log_w, lse, traj, xpred, n_species, theta=theta, prec_rows=prow, observe_kind=kind)
+        for tpb in (0, 1, 2, 3, 4, 8, 16):
+            L.vihds_iw_summaries_plan(tpb)
+            out = ops.iw_summaries(log_w, lse, traj, xpred, n_species, theta=theta, prec_rows=prow, observe_kind=kind)
+            for a, b in zip(ref, out):
+                assert torch.equal(a, b), tpb
+    finally:
+        L.vihds_iw_summaries_plan(before)
+
+
 def test_iw_summaries_states_refuse_a_map_wider_than_the_model():
     from vihds import ops
 

@@ -93,6 +93,7 @@ bool step_tail_supported(const vihds_encoder_shape&, int, int);
 void launch_step_tail(const vihds_encoder_shape&, const vihds_step_tail_args&, hipStream_t);
 void launch_adam(const vihds_adam_tensors&, float*, float*, float*, const float*, float, float, float, float, float, const float*,
                  hipStream_t);
+extern int iw_summaries_tpb_override;
 void launch_iw_summaries(int, int, int, int, int, const float*, const float*, const float*, const float*, int,
                          const float*, const int*, float*, float*, float*, float*, hipStream_t);
 
@@ -652,6 +653,11 @@ int vihds_iw_summaries(int B, int S, int T, int N_total, int n_species, const fl
   launch_iw_summaries(B, S, T, N_total, n_species, log_w, lse, traj, xpred, VIHDS_OBS_DEFAULT, theta, prec_rows,
                       iw_predict_mu, iw_predict_std, iw_states, iw_variance, (hipStream_t)stream);
   return check_hip("vihds_iw_summaries launch");
+}
+int vihds_iw_summaries_plan(int time_points_per_block) {
+  const int before = iw_summaries_tpb_override;
+  iw_summaries_tpb_override = time_points_per_block;
+  return before;
 }
 int vihds_iw_summaries_states(int B, int S, int T, int N_total, int n_species, int observe_kind, const float* log_w,
                               const float* lse, const float* traj, const float* theta, const int* prec_rows,

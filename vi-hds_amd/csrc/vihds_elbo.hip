@@ -7,6 +7,7 @@
 
 #include "../../include/vihds_hip.h"
 #include "vihds_rng.hpp"
+#include "vihds_wave.hpp"
 
 namespace vihds {
 
@@ -662,17 +663,38 @@ __global__ void device_condition_kernel(int E, int B, int S, int S_total, int s_
 // Results.init (vihds/utils.py:79-99): one block per (b, t); rows of the [T][*][B][S] buffers are contiguous in s.
 // ONE pass over the block's samples: a thread forms the importance weight of a sample once and feeds the 12 + n_species
 // accumulators from 4 + 4 + n_species independent row loads (all in flight together); one barrier for all the block
-// sums.  Every sum is taken in the order iw_summaries_rows_kernel takes it (thread-serial over s, wavefront tree,
-// wavefronts in order), so the two kernels agree bit for bit.
+// sums (thread-serial over s, a DPP scan over the wavefront, wavefronts in order; iw_summaries_rows_kernel, the fallback
+// for more species, sums over the wavefront with a shuffle tree: the two agree to rounding).
 constexpr int IWS_MAXSP = 16;
-template <int BLOCK>
+// VEC = 4 (S a multiple of 4, so every row of the [.][B][S] buffers starts on 16 bytes): a thread takes four CONSECUTIVE
+// samples per round with one global_load_dwordx4 per row -- 16 B per lane is what a streaming read needs to approach the
+// HBM rate on this chip (/opt/skills/guides/MI355X_MICROARCH.md: dwordx4 ~10 B/cycle/CU); the thread-serial part of the
+// sum then runs over s = 4 tid .. 4 tid + 3 (+ 4 BLOCK per round) instead of tid (+ BLOCK per round).  VEC = 1: any S.
+template <int VEC>
+struct IwsVec {
+  float v[VEC];
+};
+template <int VEC>
+__device__ __forceinline__ IwsVec<VEC> iws_load(const float* __restrict__ p) {
+  IwsVec<VEC> r;
+  if constexpr (VEC == 4) {
+    const float4 q = *reinterpret_cast<const float4*>(p);
+    r.v[0] = q.x; r.v[1] = q.y; r.v[2] = q.z; r.v[3] = q.w;
+  } else {
+    r.v[0] = *p;
+  }
+  return r;
+}
+// NSPV: the species rows the loop is unrolled for (n_species <= NSPV; the rows past n_species re-read row n_species - 1, a
+// cache hit, so that no load sits behind a branch).
+template <int BLOCK, int VEC, int NSPV>
 __global__ void __launch_bounds__(BLOCK)
 iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float* __restrict__ log_w,
                     const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
                     int obs_kind, const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3,
                     float* __restrict__ mu_out, float* __restrict__ std_out, float* __restrict__ states_out,
                     float* __restrict__ var_out) {
-  constexpr int NW = BLOCK / 64, NV = 12 + IWS_MAXSP;
+  constexpr int NW = BLOCK / 64, NV = 12 + NSPV;
   __shared__ float sm[NW][NV];
   const int b = blockIdx.x, t = blockIdx.y;
   const size_t n = (size_t)B * S;
@@ -681,42 +703,54 @@ iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float
   float acc[NV];
 #pragma unroll
   for (int k = 0; k < NV; ++k) acc[k] = 0.f;
-  for (int s = threadIdx.x; s < S; s += BLOCK) {
+  for (int s = threadIdx.x * VEC; s < S; s += BLOCK * VEC) {
     const size_t i = (size_t)b * S + s;
-    float xp[4], pc[4], st[IWS_MAXSP];
+    IwsVec<VEC> xpv[4], pcv[4], stv[NSPV];
 #pragma unroll
     for (int j = 0; j < 4; ++j)
-      pc[j] = theta ? theta[(size_t)prow[j] * n + i] : traj[((size_t)t * N_total + n_species + j) * n + i];
+      pcv[j] = iws_load<VEC>(theta ? theta + (size_t)prow[j] * n + i : traj + ((size_t)t * N_total + n_species + j) * n + i);
 #pragma unroll
-    for (int j = 0; j < IWS_MAXSP; ++j) st[j] = j < n_species ? traj[((size_t)t * N_total + j) * n + i] : 0.f;
+    for (int j = 0; j < NSPV; ++j)
+      stv[j] = iws_load<VEC>(traj + ((size_t)t * N_total + (j < n_species ? j : n_species - 1)) * n + i);
     if (xpred) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) xp[j] = xpred[((size_t)t * 4 + j) * n + i];
-    } else {
-      // the observed signals from the states this block reads anyway (OdeModel.observe, reference ode.py:84-93 and the
-      // models' overrides): x_predict then never has to be written by the forward kernel nor read back here
-      xp[0] = st[0];
-      xp[1] = st[0] * st[1];
-      if (obs_kind == VIHDS_OBS_DEFAULT) { xp[2] = st[0] * (st[2] + st[4]); xp[3] = st[0] * (st[3] + st[5]); }
-      else if (obs_kind == VIHDS_OBS_INDUCER) { xp[2] = st[0] * (st[2] + st[3]); xp[3] = st[0] * st[4]; }
-      else { xp[2] = st[0] * st[2]; xp[3] = st[0] * st[3]; }
+      for (int j = 0; j < 4; ++j) xpv[j] = iws_load<VEC>(xpred + ((size_t)t * 4 + j) * n + i);
     }
-    const float w = expf(log_w[i] - l);
+    const IwsVec<VEC> lw = iws_load<VEC>(log_w + i);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float iv = 1.f / pc[j];
-      acc[3 * j] += w * xp[j];
-      acc[3 * j + 1] += w * (xp[j] * xp[j] + iv);
-      acc[3 * j + 2] += w * iv;
+    for (int e = 0; e < VEC; ++e) {
+      float xp[4], st[NSPV > 6 ? NSPV : 6];
+#pragma unroll
+      for (int j = 0; j < (NSPV > 6 ? NSPV : 6); ++j) st[j] = j < NSPV && j < n_species ? stv[j < NSPV ? j : 0].v[e] : 0.f;
+      if (xpred) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = xpv[j].v[e];
+      } else {
+        // the observed signals from the states this block reads anyway (OdeModel.observe, reference ode.py:84-93 and the
+        // models' overrides): x_predict then never has to be written by the forward kernel nor read back here
+        xp[0] = st[0];
+        xp[1] = st[0] * st[1];
+        if (obs_kind == VIHDS_OBS_DEFAULT) { xp[2] = st[0] * (st[2] + st[4]); xp[3] = st[0] * (st[3] + st[5]); }
+        else if (obs_kind == VIHDS_OBS_INDUCER) { xp[2] = st[0] * (st[2] + st[3]); xp[3] = st[0] * st[4]; }
+        else { xp[2] = st[0] * st[2]; xp[3] = st[0] * st[3]; }
+      }
+      const float w = expf(lw.v[e] - l);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float iv = 1.f / pcv[j].v[e];
+        acc[3 * j] += w * xp[j];
+        acc[3 * j + 1] += w * (xp[j] * xp[j] + iv);
+        acc[3 * j + 2] += w * iv;
+      }
+#pragma unroll
+      for (int j = 0; j < NSPV; ++j) acc[12 + j] += w * st[j];
     }
-#pragma unroll
-    for (int j = 0; j < IWS_MAXSP; ++j) acc[12 + j] += w * st[j];
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < NV; ++k) {
     if (k < 12 + n_species) {
-      const float v = wave_sum(acc[k]);
+      const float v = wave_total(acc[k]);  // (DPP: twenty-odd sums per wavefront would otherwise queue on the LDS pipe)
       if (lane == 0) sm[wid][k] = v;
     }
   }
@@ -740,6 +774,134 @@ iw_summaries_kernel(int B, int S, int T, int N_total, int n_species, const float
 #pragma unroll
     for (int w = 0; w < NW; ++w) r += sm[w][12 + j];
     states_out[((size_t)b * n_species + j) * T + t] = r;
+  }
+}
+
+// The kernel above for S <= 4 BLOCK (one round of float4 loads covers a row), as a loop over `tpb` consecutive time points
+// of ONE data row per block: the importance weights (and, with constant precisions, the four 1/precision) are formed once
+// per block instead of once per time point -- 5 of the 13 row loads of a time point disappear -- and the 8 (+4) row
+// loads of time point t+1 are in flight while the sums of time point t are taken, so a CU's blocks no longer alternate
+// between a load phase and a reduction phase with nothing in flight.  The barrier between the wavefront sums and the
+// block sums waits for LDS only (a plain __syncthreads() would drain the prefetch); the LDS slots alternate by parity of
+// t, which spares the second barrier.  Same per-sample arithmetic and the same summation order as the VEC = 4 kernel above
+// (bit-identical results: test_iw_summaries_pipelined_kernel_matches_one_block_per_time_point).
+template <int BLOCK, int NSPV, bool CONST_PREC>
+__global__ void __launch_bounds__(BLOCK)
+iw_summaries_pipe_kernel(int B, int S, int T, int tpb, int N_total, int n_species, const float* __restrict__ log_w,
+                         const float* __restrict__ lse, const float* __restrict__ traj, const float* __restrict__ xpred,
+                         int obs_kind, const float* __restrict__ theta, int pr0, int pr1, int pr2, int pr3,
+                         float* __restrict__ mu_out, float* __restrict__ std_out, float* __restrict__ states_out,
+                         float* __restrict__ var_out) {
+  constexpr int NW = BLOCK / 64, NV = 12 + NSPV, NST = NSPV > 6 ? NSPV : 6;
+  __shared__ float sm[2][NW][NV];
+  const int b = blockIdx.x, t0 = blockIdx.y * tpb, t1 = min(T, t0 + tpb);
+  const size_t n = (size_t)B * S;
+  const bool live = (int)threadIdx.x * 4 < S;
+  const size_t i = (size_t)b * S + (live ? threadIdx.x * 4 : 0);  // (idle threads re-read the row's first samples at weight 0)
+  const int prow[4] = {pr0, pr1, pr2, pr3};
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const bool has_xp = xpred != nullptr;
+
+  auto rows = [&](int t, IwsVec<4> (&stv)[NSPV], IwsVec<4> (&xpv)[4], IwsVec<4> (&pcv)[4]) {
+#pragma unroll
+    for (int j = 0; j < NSPV; ++j)
+      stv[j] = iws_load<4>(traj + ((size_t)t * N_total + (j < n_species ? j : n_species - 1)) * n + i);
+    if (!CONST_PREC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pcv[j] = iws_load<4>(traj + ((size_t)t * N_total + n_species + j) * n + i);
+    }
+    if (has_xp) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) xpv[j] = iws_load<4>(xpred + ((size_t)t * 4 + j) * n + i);
+    }
+  };
+
+  IwsVec<4> cur_st[NSPV], cur_xp[4], cur_pc[4], nxt_st[NSPV], nxt_xp[4], nxt_pc[4];
+  rows(t0, cur_st, cur_xp, cur_pc);
+  float w[4], ivc[4][4];
+  {
+    const IwsVec<4> lw = iws_load<4>(log_w + i);
+    const float l = lse[b];
+    IwsVec<4> pc[4];
+    if (CONST_PREC) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) pc[j] = iws_load<4>(theta + (size_t)prow[j] * n + i);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      w[e] = live ? expf(lw.v[e] - l) : 0.f;
+      if (CONST_PREC) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ivc[j][e] = 1.f / pc[j].v[e];
+      }
+    }
+  }
+  for (int t = t0; t < t1; ++t) {
+    rows(t + 1 < t1 ? t + 1 : t, nxt_st, nxt_xp, nxt_pc);  // (the last round re-reads its own rows: cache hits, no branch)
+    float acc[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) acc[k] = 0.f;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float xp[4], st[NST];
+#pragma unroll
+      for (int j = 0; j < NST; ++j) st[j] = j < NSPV && j < n_species ? cur_st[j < NSPV ? j : 0].v[e] : 0.f;
+      if (has_xp) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xp[j] = cur_xp[j].v[e];
+      } else {
+        xp[0] = st[0];
+        xp[1] = st[0] * st[1];
+        if (obs_kind == VIHDS_OBS_DEFAULT) { xp[2] = st[0] * (st[2] + st[4]); xp[3] = st[0] * (st[3] + st[5]); }
+        else if (obs_kind == VIHDS_OBS_INDUCER) { xp[2] = st[0] * (st[2] + st[3]); xp[3] = st[0] * st[4]; }
+        else { xp[2] = st[0] * st[2]; xp[3] = st[0] * st[3]; }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float iv = CONST_PREC ? ivc[j][e] : 1.f / cur_pc[j].v[e];
+        acc[3 * j] += w[e] * xp[j];
+        acc[3 * j + 1] += w[e] * (xp[j] * xp[j] + iv);
+        acc[3 * j + 2] += w[e] * iv;
+      }
+#pragma unroll
+      for (int j = 0; j < NSPV; ++j) acc[12 + j] += w[e] * st[j];
+    }
+    float(&slot)[NW][NV] = sm[(t - t0) & 1];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      if (k < 12 + n_species) {
+        const float v = wave_total(acc[k]);
+        if (lane == 0) slot[wid][k] = v;
+      }
+    }
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS writes above; the prefetched rows stay in flight
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    const int k = threadIdx.x;
+    if (k < 4) {
+      float r[3];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) {
+        r[q] = 0.f;
+#pragma unroll
+        for (int wv = 0; wv < NW; ++wv) r[q] += slot[wv][3 * k + q];
+      }
+      const size_t o = ((size_t)b * 4 + k) * T + t;
+      mu_out[o] = r[0];
+      std_out[o] = sqrtf(r[1] - r[0] * r[0]);
+      var_out[o] = r[2];
+    } else if (k >= 64 && k < 64 + n_species) {
+      const int j = k - 64;
+      float r = 0.f;
+#pragma unroll
+      for (int wv = 0; wv < NW; ++wv) r += slot[wv][12 + j];
+      states_out[((size_t)b * n_species + j) * T + t] = r;
+    }
+#pragma unroll
+    for (int j = 0; j < NSPV; ++j) cur_st[j] = nxt_st[j];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { cur_xp[j] = nxt_xp[j]; cur_pc[j] = nxt_pc[j]; }
   }
 }
 
@@ -934,14 +1096,47 @@ void launch_adam(const vihds_adam_tensors& t, float* m, float* v, float* state, 
   hipLaunchKernelGGL(adam_kernel, dim3(blocks), dim3(256), 0, st, t, m, v, state, lr_dev, lr, beta1, beta2, eps,
                      grad_scale, gate);
 }
+// tests: > 0 fixes the time points per block of the pipelined kernel, < 0 takes the one-block-per-time-point kernel
+int iw_summaries_tpb_override = 0;
 void launch_iw_summaries(int B, int S, int T, int N_total, int n_species, const float* log_w, const float* lse,
                          const float* traj, const float* xpred, int obs_kind, const float* theta, const int* prec_rows,
                          float* mu, float* sd, float* states, float* var, hipStream_t st) {
+  const int tpb_override = iw_summaries_tpb_override;
   int r[4] = {0, 0, 0, 0};
   if (theta && prec_rows) for (int j = 0; j < 4; ++j) r[j] = prec_rows[j];
-  if (n_species <= IWS_MAXSP)
-    hipLaunchKernelGGL((iw_summaries_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species, log_w,
-                       lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);
+#define VIHDS_IWS(VEC, NSPV)                                                                                          \
+  hipLaunchKernelGGL((iw_summaries_kernel<256, VEC, NSPV>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species,  \
+                     log_w, lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], mu, sd, states, var)
+#define VIHDS_IWS_SPECIES(VEC)                                                                                        \
+  do {                                                                                                                \
+    if (n_species <= 4) VIHDS_IWS(VEC, 4);                                                                            \
+    else if (n_species <= 8) VIHDS_IWS(VEC, 8);                                                                       \
+    else if (n_species <= 12) VIHDS_IWS(VEC, 12);                                                                     \
+    else VIHDS_IWS(VEC, 16);                                                                                          \
+  } while (0)
+#define VIHDS_IWS_PIPE(NSPV)                                                                                        \
+  do {                                                                                                              \
+    if (theta)                                                                                                      \
+      hipLaunchKernelGGL((iw_summaries_pipe_kernel<256, NSPV, true>), dim3(B, (T + tpb - 1) / tpb), dim3(256), 0, st, B, \
+                         S, T, tpb, N_total, n_species, log_w, lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], \
+                         mu, sd, states, var);                                                                      \
+    else                                                                                                            \
+      hipLaunchKernelGGL((iw_summaries_pipe_kernel<256, NSPV, false>), dim3(B, (T + tpb - 1) / tpb), dim3(256), 0, st, B, \
+                         S, T, tpb, N_total, n_species, log_w, lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], \
+                         mu, sd, states, var);                                                                      \
+  } while (0)
+  // time points per block of the pipelined kernel: as many as leave >= 2048 blocks (8 per CU), between 2 and 8
+  // (tests/probe/summaries_time.py at B=234, S=1000, T=86, N=8: 1 -> 217 us, 2 -> 159, 4 -> 130, 8 -> 129; one block per time
+  // point: 162)
+  const long long cells = (long long)B * T;
+  const int tpb = tpb_override > 0 ? tpb_override : (int)(cells / 2048 < 2 ? 2 : (cells / 2048 > 8 ? 8 : cells / 2048));
+  if (n_species >= 1 && n_species <= IWS_MAXSP && S % 4 == 0 && S >= 512 && S <= 1024 && tpb_override >= 0) {
+    if (n_species <= 4) VIHDS_IWS_PIPE(4);
+    else if (n_species <= 8) VIHDS_IWS_PIPE(8);
+    else if (n_species <= 12) VIHDS_IWS_PIPE(12);
+    else VIHDS_IWS_PIPE(16);
+  } else if (n_species >= 1 && n_species <= IWS_MAXSP && S % 4 == 0 && S >= 512) VIHDS_IWS_SPECIES(4);
+  else if (n_species >= 1 && n_species <= IWS_MAXSP) VIHDS_IWS_SPECIES(1);
   else
     hipLaunchKernelGGL((iw_summaries_rows_kernel<256>), dim3(B, T), dim3(256), 0, st, B, S, T, N_total, n_species,
                        log_w, lse, traj, xpred, obs_kind, theta, r[0], r[1], r[2], r[3], mu, sd, states, var);

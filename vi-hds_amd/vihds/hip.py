@@ -176,6 +176,7 @@ _PROTOTYPES = {
     "vihds_step_tail": (_I, [ctypes.POINTER(EncoderShape), ctypes.POINTER(StepTailArgs), _P]),
     "vihds_step_tail_supported": (_I, [ctypes.POINTER(EncoderShape), _I, _I]),
     "vihds_iw_summaries": (_I, [_I] * 5 + [_P] * 5 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
+    "vihds_iw_summaries_plan": (_I, [_I]),
     "vihds_iw_summaries_states": (_I, [_I] * 6 + [_P] * 4 + [ctypes.POINTER(ctypes.c_int)] + [_P] * 5),
 }
 
