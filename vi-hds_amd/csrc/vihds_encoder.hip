@@ -90,6 +90,9 @@ __device__ __forceinline__ float gcond_input(const vihds_encoder_shape& s, const
 // LDS: x [C_in*L] | conv weights [F*C_in*K] | conv bias [F] | conv out [F*Lc] | pooled [F*Lp] | hidden [H]
 constexpr int ENC_T = 1024;  // threads per block: these kernels are pure latency, so every phase is spread as wide as
                              // its output count allows (760 conv outputs, 720 pooled values, 16 waves for the Linear)
+// LIN_C: 64-wide column chunks of a Linear row a lane holds in registers (pooled vector <= 64 LIN_C: 12 covers the
+// reference's 86-point grids at 720, 16 the relay plate's 99-point grid at 850).
+template <int LIN_C>
 __global__ void __launch_bounds__(ENC_T)
 encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, const float* __restrict__ inputs,
                    const float* __restrict__ dev1hot, const float* __restrict__ conv_w,
@@ -113,7 +116,7 @@ encoder_fwd_kernel(vihds_encoder_shape s, const float* __restrict__ delta_obs, c
   // Every global read the later phases need is issued NOW, so that the kernel pays one memory round trip instead of
   // one per phase: this wave's Linear rows (4 output units x up to 12 x 64 inputs = 48 registers per lane) and its
   // head rows.  Shapes beyond those bounds take the plain loops further down.
-  constexpr int LIN_U = 4, LIN_C = 12, HEAD_R = 4;
+  constexpr int LIN_U = 4, HEAD_R = 4;
   const bool fast_lin = s.H <= LIN_U * NW && d.NPOOL <= LIN_C * 64;
   const int n_dot = 2 * (s.nl + s.ng);
   const bool fast_heads = d.NX <= 64 && d.NG <= 64 && n_dot <= HEAD_R * NW;
@@ -558,7 +561,12 @@ void launch_encoder_fwd(const vihds_encoder_shape& s, const float* delta_obs, co
                         const float* conv_w, const float* conv_b, const float* lin_w, const float* lin_b,
                         const float* local_w, const float* local_b, const float* gcond_w, const float* global_free,
                         const float* const_values, float* q_all, float* pooled, float* hidden, hipStream_t st) {
-  hipLaunchKernelGGL(encoder_fwd_kernel, dim3(s.B), dim3(ENC_T), encoder_fwd_lds_bytes(s), st, s, delta_obs, inputs,
+  if (enc_dims(s).NPOOL <= 12 * 64)
+    hipLaunchKernelGGL(encoder_fwd_kernel<12>, dim3(s.B), dim3(ENC_T), encoder_fwd_lds_bytes(s), st, s, delta_obs, inputs,
+                     dev1hot, conv_w, conv_b, lin_w, lin_b, local_w, local_b, gcond_w, global_free, const_values, q_all,
+                     pooled, hidden);
+  else
+    hipLaunchKernelGGL(encoder_fwd_kernel<16>, dim3(s.B), dim3(ENC_T), encoder_fwd_lds_bytes(s), st, s, delta_obs, inputs,
                      dev1hot, conv_w, conv_b, lin_w, lin_b, local_w, local_b, gcond_w, global_free, const_values, q_all,
                      pooled, hidden);
 }
