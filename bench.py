@@ -246,7 +246,7 @@ def run_workload(a, name):
     local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
-    use_graph = not a.eager and mode == "train"
+    use_graph = not a.eager
     extra = {}
     if wl == "dr_constant_icml":
         extra["fused_ode_training"] = not a.two_kernel_ode
@@ -263,10 +263,7 @@ def run_workload(a, name):
         model.eval()
 
         def step(bt):  # training.py:183-215 (_evaluate_elbo_and_plot): forward without grad + Results.init summaries
-            with torch.no_grad():
-                results, theta, q, p = model(bt, S)
-                out = training.cost(bt, results, theta, q, p, full_output=True)
-            return out.elbo
+            return training.evaluate(bt, S).elbo  # (Results on the host, every pass; replayed from a hipGraph unless --eager)
 
     def barrier():
         torch.cuda.synchronize()
@@ -298,7 +295,7 @@ def run_workload(a, name):
     if mode == "train":
         training.step(batch)
     else:
-        step(batch)
+        training._evaluation_device_side(batch, S)  # (the pass's own launches, eager: a graph replay records none)
     ops.TIMER = None
     ode = model.decoder.ode_model
     T = int(batch.times.shape[0])

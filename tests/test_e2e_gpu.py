@@ -171,6 +171,49 @@ def test_evaluation_without_a_stored_x_predict_gives_the_same_results(name):
         assert x.shape == y.shape and torch.equal(x, y)
 
 
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "dr_constant_precisions_tiny_modeuler",
+                                  "dr_blackbox_icml_tiny_modeuler"])
+def test_evaluation_replayed_from_a_graph_gives_the_eager_results(name):
+    """Training.evaluate with params.eval_graph (the device side of the pass captured once, replayed per evaluation) against
+    the eager pass from the same generator states: three consecutive evaluations each, every member of Results identical,
+    a Results kept from an earlier replay not disturbed by later ones, and parameters changed in between picked up."""
+    import e2e_util as E
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    fx = Fixture(name)
+    runs = []
+    for graph in (False, True):
+        # (draws inside the kernels: their generator states are rolled back after the capture's warm-up passes, so both
+        # runs see the same sequence; torch's device generator, "device", is consumed by the warm-up)
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, u_rng="kernel", conditioner_rng="kernel",
+                                                                hip_graph=True, eval_graph=graph)
+        model = build_model(args, settings, data, parameters)
+        training = Training(args, settings, data, parameters, model)
+        batch = E.batch_from_fixture(fx, settings.device)
+        model.eval()
+        outs = []
+        for k in range(3):
+            if k == 2:
+                with torch.no_grad():
+                    for p_ in model.parameters():
+                        p_.mul_(1.01)
+            outs.append(training.evaluate(batch, args.train_samples))
+        assert (len(training._eval_graphs) == 1) == graph
+        runs.append([(float(o.elbo), o.iw_predict_mu.copy(), o.iw_predict_std.copy(), o.iw_states.copy(),
+                      o.iw_variance.copy(), [np.asarray(v).copy() for v in o.q_values], o) for o in outs])
+    for a, b in zip(*runs):
+        assert a[0] == b[0]
+        for x, y in zip(a[1:5], b[1:5]):
+            assert np.array_equal(x, y)
+        for x, y in zip(a[5], b[5]):
+            assert np.array_equal(x, y)
+    # theta is read last: the first replay's samples must have survived the two replays behind it
+    for a, b in zip(*runs):
+        assert np.array_equal(a[6].theta, b[6].theta)
+    assert runs[1][0][0] != runs[1][1][0]  # (fresh draws per replay)
+
+
 class _TraceDataset(torch.utils.data.Dataset):
     def __init__(self, z):
         self.times = torch.tensor(z["times"])

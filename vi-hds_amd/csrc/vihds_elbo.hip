@@ -151,8 +151,8 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
                      const float* __restrict__ q_prec, const int* __restrict__ q_rows, int prec_is_log,
                      const float* __restrict__ p_mu, const float* __restrict__ p_prec,
                      const float* __restrict__ clip_lo, const float* __restrict__ clip_hi, float* __restrict__ u,
-                     unsigned int* rng, int S_total, int s_off, float* __restrict__ theta, float* __restrict__ log_q,
-                     float* __restrict__ log_p) {
+                     unsigned int* rng, int advance, int S_total, int s_off, float* __restrict__ theta,
+                     float* __restrict__ log_q, float* __restrict__ log_p) {
   extern __shared__ float tab[];  // [field][nb_max * P]
   const int n = B * S;
   const int first = blockIdx.x * 64, last = min(first + 64, n) - 1;
@@ -192,7 +192,9 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
   if (rng) { k0 = rng[0]; k1 = rng[1]; step = rng[2]; }
   __syncthreads();
   unsigned int ticket = 0u;
-  if (rng && threadIdx.x == 0) ticket = atomicAdd(&rng[3], 1u);
+  // (advance == 0: a launch of rng_advance_kernel behind this one moves the step -- thousands of blocks taking tickets from
+  // ONE address queue up behind each other: at 3 656 blocks the returning atomics were most of this kernel's 72 us)
+  if (rng && advance && threadIdx.x == 0) ticket = atomicAdd(&rng[3], 1u);
   const int t = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = t >> 2, q = t & 3;
   const bool live = i0 < n;
@@ -241,11 +243,21 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
     if (log_q) log_q[i] = lq;
     if (log_p) log_p[i] = lp;
   }
-  if (rng && threadIdx.x == 0 && ticket == gridDim.x - 1) {
+  if (rng && advance && threadIdx.x == 0 && ticket == gridDim.x - 1) {
     rng[2] = step + 1u;
     rng[3] = 0u;
   }
 }
+// the step of a generator state {seed lo, seed hi, step, ticket}, moved by a launch of its own behind a grid too large
+// to take tickets
+__global__ void rng_advance_kernel(unsigned int* rng) {
+  rng[2] = rng[2] + 1u;
+  rng[3] = 0u;
+}
+// grids up to this many blocks take tickets (one returning atomic per block on one address costs ~18 ns each once they
+// queue: 915 blocks of device_condition_kernel = 16 us, 3 656 of theta_fwd_lds_kernel = 72 us, both the whole launch);
+// beyond, the one-thread launch above (~2 us) moves the step
+constexpr int RNG_TICKET_BLOCKS = 256;
 
 // one block per (data row b, chunk of THETA_BWD_PCHUNK parameters), ONE WAVE PER PARAMETER: the chunk's parameters run
 // side by side instead of one after the other (each used to cost a round of loads plus two block reductions with
@@ -626,7 +638,7 @@ __global__ void iwae_loss_bwd_kernel(int B, int S, const float* __restrict__ log
 // rng (optional, {seed lo, seed hi, step, ticket} as in vihds_theta_opts): z is drawn here instead of read
 // (counter = (e*D + d, 0xC04D, step, 0): a stream disjoint from theta's, whose second word is a parameter block < 2^16).
 __global__ void device_condition_kernel(int E, int B, int S, int S_total, int s_off, int D, float w_mean, float w_std,
-                                        const float* __restrict__ z, unsigned int* rng,
+                                        const float* __restrict__ z, unsigned int* rng, int advance,
                                         const float* __restrict__ dev1hot, const float* __restrict__ rel,
                                         const int* __restrict__ is_default, float* __restrict__ out) {
   const int n = B * S;
@@ -651,7 +663,7 @@ __global__ void device_condition_kernel(int E, int B, int S, int S_total, int s_
     c = fmaxf(c, 0.f);
     if (live) out[(size_t)e * n + i] = (is_default[e] ? 1.f : 0.f) + c;
   }
-  if (rng) {
+  if (rng && advance) {  // (advance == 0: rng_advance_kernel follows, see theta_fwd_lds_kernel)
     __syncthreads();
     if (threadIdx.x == 0) {
       const unsigned int ticket = atomicAdd(&rng[3], 1u);
@@ -970,9 +982,12 @@ void launch_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, c
   const int nb_max = min(B, 63 / S + 2);
   const size_t lds = (size_t)THETA_LDS_FIELDS * nb_max * P * sizeof(float);
   if (lds <= 48 * 1024) {  // per-(row, parameter) constants staged in LDS
-    hipLaunchKernelGGL(theta_fwd_lds_kernel, dim3((n + 63) / 64), dim3(256), lds, st, P, B, S, nb_max, kind, q_mu,
-                       q_prec, o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, o.rng, o.rng ? o.S_total : S,
+    const int blocks = (n + 63) / 64;
+    const int advance = blocks <= RNG_TICKET_BLOCKS;
+    hipLaunchKernelGGL(theta_fwd_lds_kernel, dim3(blocks), dim3(256), lds, st, P, B, S, nb_max, kind, q_mu, q_prec,
+                       o.q_rows, o.q_prec_is_log, p_mu, p_prec, lo, hi, u, o.rng, advance, o.rng ? o.S_total : S,
                        o.rng ? o.s_offset : 0, theta, log_q, log_p);
+    if (o.rng && !advance) hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, st, o.rng);
     return;
   }
   hipLaunchKernelGGL(theta_fwd_kernel, dim3((4 * n + blk - 1) / blk), dim3(blk), 0, st, P, B, S, kind, q_mu, q_prec,
@@ -1032,8 +1047,11 @@ void launch_device_condition(int E, int B, int S, int S_total, int s_off, int D,
                              const float* dev1hot, const float* rel, const int* is_default, float* out,
                              hipStream_t st) {
   const int n = B * S, blk = 256;
-  hipLaunchKernelGGL(device_condition_kernel, dim3((n + blk - 1) / blk), dim3(blk), 0, st, E, B, S, S_total, s_off, D,
-                     w_mean, w_std, z, rng, dev1hot, rel, is_default, out);
+  const int blocks = (n + blk - 1) / blk;
+  const int advance = blocks <= RNG_TICKET_BLOCKS;
+  hipLaunchKernelGGL(device_condition_kernel, dim3(blocks), dim3(blk), 0, st, E, B, S, S_total, s_off, D, w_mean, w_std, z,
+                     rng, advance, dev1hot, rel, is_default, out);
+  if (rng && !advance) hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, st, rng);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -34,6 +34,7 @@ PARAM_DEFAULTS = {
     "hip_graph": False,        # capture the whole training step in a hipGraph
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
     "lazy_cache_dump": False,  # True: the best evaluation's Results are written to .vihds_cache once, when run() ends
+    "eval_graph": True,        # with hip_graph: Training.evaluate replays the device side of an evaluation pass from a hipGraph
     "lazy_x_predict": True,    # evaluation passes (no_grad): x_predict is not stored; the summaries kernel forms it from the
                                # trajectory, DecoderResult / OdeModel.observe compute it if somebody reads it
     "epoch_graph": True,       # with hip_graph and nan_check_every = 0 or >= the batches of an epoch: one graph launch per epoch

@@ -147,6 +147,46 @@ class Results:
         (self.elbo, self.iw_predict_mu, self.iw_predict_std, self.iw_states,
          self.iw_variance) = _to_host([elbo, mu, sd, st, var])
 
+    def init_from_staged(self, species_names, staged):
+        """The same members from the outputs of a captured evaluation pass (Training.evaluate): `flat` holds the q tables,
+        the ELBO and the four summaries back to back (one transfer); the theta rows live in the graph's memory pool, which
+        the next replay overwrites, so they are copied (on the device) now and to the host only if somebody reads them."""
+        import torch
+
+        self.species_names = species_names
+        self.q_names = staged["q_names"]
+        flat = staged["flat"]
+        host = _pinned(flat.numel(), flat.dtype)
+        host.copy_(flat, non_blocking=True)
+        rows = staged["theta_rows"]
+        if rows:
+            t0 = rows[0]
+            step = t0.numel() * t0.element_size()
+            if all(t.shape == t0.shape and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + k * step
+                   for k, t in enumerate(rows)):
+                block = torch.as_strided(t0, (len(rows),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride())).clone()
+            else:
+                block = torch.stack(rows)
+            self._theta_dev, self._theta_host = list(block.unbind(0)), None
+        else:
+            self._theta_dev, self._theta_host = [], None
+        torch.cuda.current_stream().synchronize()
+        arr = host.numpy().copy()
+        o, qv = 0, []
+        for shp in staged["q_shapes"]:
+            n = int(np.prod(shp)) if len(shp) else 1
+            qv.append(arr[o:o + n].reshape(shp))
+            o += n
+        self.q_values = np.array(qv, dtype=object)
+        self.elbo = arr[o:o + 1].reshape(())
+        o += 1
+        out = []
+        for shp in staged["summary_shapes"]:
+            n = int(np.prod(shp))
+            out.append(arr[o:o + n].reshape(shp))
+            o += n
+        self.iw_predict_mu, self.iw_predict_std, self.iw_states, self.iw_variance = out
+
     @property
     def theta(self):
         """numpy [P,B,S] as in the reference's Results (utils.py:83); copied from the device on first use."""
