@@ -8,6 +8,7 @@ import functools
 import math
 import os
 import time
+import weakref
 
 import numpy as np
 import torch
@@ -244,9 +245,26 @@ class Training:
         if key not in self._eval_graphs:
             self._eval_graphs[key] = self._capture_evaluation(data, int(n_samples))
         g, staged = self._eval_graphs[key]
+        # the theta samples of the previous pass live in the graph's memory pool: if its Results is still around and nobody
+        # has read them yet, they are copied (on the device) before this replay overwrites them -- a Results that was
+        # dropped, the usual case, costs nothing
+        last = staged["last_results"]() if staged.get("last_results") is not None else None
+        if last is not None:
+            last.detach_theta()
+        # what Results holds on the host arrives in one of a few pinned buffers, used in turn, and the numpy members are views
+        # of it: the Results that had this buffer before, if it is still alive, takes copies first
+        ring = staged["host_ring"]
+        k = staged["ring_pos"]
+        staged["ring_pos"] = (k + 1) % len(ring)
+        holder = staged["ring_refs"][k]() if staged["ring_refs"][k] is not None else None
+        if holder is not None:
+            holder.detach_host()
         g.replay()
+        ring[k].copy_(staged["flat"], non_blocking=True)
         out = Results()
-        out.init_from_staged(self.model.decoder.state_names, staged)
+        out.init_from_staged(self.model.decoder.state_names, staged, ring[k])
+        staged["last_results"] = weakref.ref(out)
+        staged["ring_refs"][k] = weakref.ref(out)
         return out
 
     def _evaluation_device_side(self, data, n_samples):
@@ -258,7 +276,8 @@ class Training:
         flat = torch.cat([t.reshape(-1).float() for t in parts])  # ONE device->host transfer per pass
         rows = [t.detach() for t in theta.get_tensors()]
         return {"q_names": q.get_tensor_names(), "q_shapes": [tuple(t.shape) for t in q_tensors],
-                "summary_shapes": [tuple(x.shape) for x in summ], "flat": flat, "theta_rows": rows}
+                "summary_shapes": [tuple(x.shape) for x in summ], "flat": flat, "theta_rows": rows,
+                "last_results": None}
 
     def _capture_evaluation(self, data, n_samples):
         """Warm up on a side stream (generator states rolled back afterwards: the warm-up passes must not consume draws),
@@ -274,6 +293,9 @@ class Training:
         g = torch.cuda.CUDAGraph()
         with torch.cuda.graph(g):
             staged = self._evaluation_device_side(data, n_samples)
+        n = staged["flat"].numel()
+        staged["host_ring"] = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(4)]
+        staged["ring_refs"], staged["ring_pos"] = [None] * 4, 0
         return g, staged
 
     def _evaluate_elbo_and_plot(self, epoch, log_data, train_writer, valid_writer):

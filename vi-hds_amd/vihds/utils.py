@@ -147,31 +147,19 @@ class Results:
         (self.elbo, self.iw_predict_mu, self.iw_predict_std, self.iw_states,
          self.iw_variance) = _to_host([elbo, mu, sd, st, var])
 
-    def init_from_staged(self, species_names, staged):
-        """The same members from the outputs of a captured evaluation pass (Training.evaluate): `flat` holds the q tables,
-        the ELBO and the four summaries back to back (one transfer); the theta rows live in the graph's memory pool, which
-        the next replay overwrites, so they are copied (on the device) now and to the host only if somebody reads them."""
+    def init_from_staged(self, species_names, staged, host):
+        """The same members from the outputs of a captured evaluation pass (Training.evaluate).  `host` is the pinned buffer
+        the pass's `flat` -- the q tables, the ELBO and the four summaries back to back -- is on its way into; the numpy
+        members are VIEWS of it (no second copy on the host) until Training.evaluate hands the buffer to a later pass
+        (detach_host).  The theta rows stay in the graph's memory pool until somebody reads them or the next replay is about
+        to overwrite them (detach_theta)."""
         import torch
 
         self.species_names = species_names
         self.q_names = staged["q_names"]
-        flat = staged["flat"]
-        host = _pinned(flat.numel(), flat.dtype)
-        host.copy_(flat, non_blocking=True)
-        rows = staged["theta_rows"]
-        if rows:
-            t0 = rows[0]
-            step = t0.numel() * t0.element_size()
-            if all(t.shape == t0.shape and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + k * step
-                   for k, t in enumerate(rows)):
-                block = torch.as_strided(t0, (len(rows),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride())).clone()
-            else:
-                block = torch.stack(rows)
-            self._theta_dev, self._theta_host = list(block.unbind(0)), None
-        else:
-            self._theta_dev, self._theta_host = [], None
+        self._theta_dev, self._theta_host = list(staged["theta_rows"]), None
         torch.cuda.current_stream().synchronize()
-        arr = host.numpy().copy()
+        arr = host.numpy()
         o, qv = 0, []
         for shp in staged["q_shapes"]:
             n = int(np.prod(shp)) if len(shp) else 1
@@ -186,6 +174,35 @@ class Results:
             out.append(arr[o:o + n].reshape(shp))
             o += n
         self.iw_predict_mu, self.iw_predict_std, self.iw_states, self.iw_variance = out
+        self._host_views = True
+
+    def detach_host(self):
+        """Give the numpy members storage of their own (they were views of a staging buffer that is about to be reused)."""
+        if not getattr(self, "_host_views", False):
+            return
+        self._host_views = False
+        qv = [np.array(v, copy=True) for v in self.q_values]
+        self.q_values = np.array(qv, dtype=object)
+        self.elbo = np.array(self.elbo, copy=True)
+        self.iw_predict_mu, self.iw_predict_std = self.iw_predict_mu.copy(), self.iw_predict_std.copy()
+        self.iw_states, self.iw_variance = self.iw_states.copy(), self.iw_variance.copy()
+
+    def detach_theta(self):
+        """Give the theta samples storage of their own (a device copy) if they are still views of somebody else's buffer
+        that is about to be rewritten."""
+        import torch
+
+        rows = self._theta_dev
+        if self._theta_host is not None or not rows:
+            return
+        t0 = rows[0]
+        step = t0.numel() * t0.element_size()
+        if all(t.shape == t0.shape and t.is_contiguous() and t.data_ptr() == t0.data_ptr() + k * step
+               for k, t in enumerate(rows)):
+            block = torch.as_strided(t0, (len(rows),) + tuple(t0.shape), (t0.numel(),) + tuple(t0.stride())).clone()
+        else:
+            block = torch.stack(rows)
+        self._theta_dev = list(block.unbind(0))
 
     @property
     def theta(self):
