@@ -16,6 +16,7 @@
 #include <hip/hip_runtime.h>
 
 #include "../../include/vihds_hip.h"
+#include "vihds_wave.hpp"
 
 namespace vihds {
 
@@ -424,28 +425,41 @@ bb_tail_kernel(BbTailArgs a, const float* __restrict__ theta, const float* __res
   float acc[TAIL_ACC];
 #pragma unroll
   for (int k = 0; k < TAIL_ACC; ++k) acc[k] = 0.f;
-  for (int col = threadIdx.x; col < a.n; col += TAIL_THREADS) {
-    const float v = row[col];
-    acc[TAIL_ACC - 1] += v;
-    if (dot) {
-      const int b = col / a.S;
-      float c[TAIL_ACC - 1];
+  // (a thread's columns are walked two at a time with every load of the pair requested before the first FMA: at 7 200
+  // trajectories the seven rounds of a thread were seven memory round trips in a row; columns past the end read a valid
+  // address at weight 0)
+  for (int col0 = threadIdx.x; col0 < a.n; col0 += 2 * TAIL_THREADS) {
+    float v[2], c[2][TAIL_ACC - 1];
 #pragma unroll
-      for (int k = 0; k < TAIL_LAT; ++k) c[k] = theta[(size_t)a.lat_row[k] * a.n + col];
+    for (int u = 0; u < 2; ++u) {
+      const int cu = col0 + u * TAIL_THREADS;
+      const int col = cu < a.n ? cu : col0;
+      v[u] = row[col];
+      if (dot) {
+        const int b = col / a.S;
 #pragma unroll
-      for (int k = 0; k < TAIL_C; ++k) c[TAIL_LAT + k] = cond[b * a.C + min(k, a.C - 1)];
+        for (int k = 0; k < TAIL_LAT; ++k) c[u][k] = theta[(size_t)a.lat_row[k] * a.n + col];
 #pragma unroll
-      for (int k = 0; k < TAIL_D; ++k) c[TAIL_LAT + TAIL_C + k] = dev1hot[b * a.D + min(k, a.D - 1)];
+        for (int k = 0; k < TAIL_C; ++k) c[u][TAIL_LAT + k] = cond[b * a.C + min(k, a.C - 1)];
 #pragma unroll
-      for (int k = 0; k < TAIL_ACC - 1; ++k) acc[k] = fmaf(v, c[k], acc[k]);
+        for (int k = 0; k < TAIL_D; ++k) c[u][TAIL_LAT + TAIL_C + k] = dev1hot[b * a.D + min(k, a.D - 1)];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const float vv = col0 + u * TAIL_THREADS < a.n ? v[u] : 0.f;
+      acc[TAIL_ACC - 1] += vv;
+      if (dot) {
+#pragma unroll
+        for (int k = 0; k < TAIL_ACC - 1; ++k) acc[k] = fmaf(vv, c[u][k], acc[k]);
+      }
     }
   }
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int k = 0; k < TAIL_ACC; ++k) {
-    float t = acc[k];
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) t += __shfl_xor(t, off, 64);
+    // (DPP scan: 33 shuffle trees per wavefront, 16 wavefronts, were ~3 000 ds_bpermute through the CU's one LDS pipe)
+    const float t = wave_total(acc[k]);
     if (lane == 0) sm[wid][k] = t;
   }
   __syncthreads();
