@@ -29,6 +29,39 @@ offset_rows_bwd_kernel(int B, int S, int D, int n, int src, int dst, int accumul
                        const float* __restrict__ dev1hot, float* __restrict__ g_theta, float* __restrict__ g_wb) {
   extern __shared__ float rs[];  // [B]
   const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6, n_waves = blockDim.x >> 6;
+  // Up to 3 rows per wavefront x 4 chunks of 64 samples (B <= 48, S <= 256: the ICML plate) -- every load of the wavefront
+  // is requested before the first one is used (as nested loops these were up to twelve memory round trips in a row);
+  // the sums are taken in the loops' order: per row, a lane over its samples in increasing s, then the shuffle tree.
+  constexpr int RB = 3, SC = 4;
+  if (B <= RB * (OFFSET_BWD_THREADS / 64) && S <= SC * 64 && n_waves == OFFSET_BWD_THREADS / 64) {
+    float g[RB][SC], old[RB][SC];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int b = min(wave + rb * n_waves, B - 1);
+#pragma unroll
+      for (int sc = 0; sc < SC; ++sc) {
+        const int sidx = min(lane + 64 * sc, S - 1);
+        g[rb][sc] = g_theta[((size_t)(dst + i) * B + b) * S + sidx];
+        old[rb][sc] = accumulate ? g_theta[((size_t)(src + i) * B + b) * S + sidx] : 0.f;
+      }
+    }
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+      const int b = wave + rb * n_waves;
+      float acc = 0.f;
+#pragma unroll
+      for (int sc = 0; sc < SC; ++sc) {
+        const int sidx = lane + 64 * sc;
+        if (b < B && sidx < S) {
+          acc += g[rb][sc];
+          g_theta[((size_t)(src + i) * B + b) * S + sidx] = old[rb][sc] + g[rb][sc];
+        }
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o, 64);
+      if (lane == 0 && b < B) rs[b] = acc;
+    }
+  } else
   for (int b = wave; b < B; b += n_waves) {
     const float* gd = g_theta + ((size_t)(dst + i) * B + b) * S;
     float* gs = g_theta + ((size_t)(src + i) * B + b) * S;
