@@ -379,7 +379,23 @@ encoder_bwd_row_kernel(vihds_encoder_shape s, const float* __restrict__ g_all, c
   // hidden adjoint through the local heads, then tanh'
   for (int j = tid; j < s.H; j += ENC_T) {
     float acc = 0.f;
-    for (int r = 0; r < 2 * s.nl; ++r) acc += local_w[(size_t)r * d.NX + j] * g_all[(size_t)r * B + b];
+    // (sixteen head rows at a time, every load of the chunk requested before the first product: as a plain loop the 2 nl
+    // rows were 2 nl dependent round trips, most of this launch; rows past the end re-read the last one at weight 0;
+    // the products are added in row order as before)
+    constexpr int RC = 16;
+    const int nr = 2 * s.nl;
+    for (int r0 = 0; r0 < nr; r0 += RC) {
+      float w[RC], g[RC];
+#pragma unroll
+      for (int u = 0; u < RC; ++u) {
+        const int r = min(r0 + u, nr - 1);
+        w[u] = local_w[(size_t)r * d.NX + j];
+        g[u] = g_all[(size_t)r * B + b];
+      }
+#pragma unroll
+      for (int u = 0; u < RC; ++u)
+        if (r0 + u < nr) acc += w[u] * g[u];
+    }
     const float h = hidden[(size_t)b * s.H + j];
     const float g = acc * (1.f - h * h);
     gpre[j] = g;
