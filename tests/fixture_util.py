@@ -25,6 +25,17 @@ ALL_FIXTURES = [
     "prpr_constant_tiny_modeuler",
 ]
 
+# Produced by `make_fixtures.py --patched`: the reference with its two CONSTRUCTION defects repaired in memory
+# (OdeFunc.__init__'s arity, the non-existent init_with_params) -- "MODIFIED REFERENCE" in their provenance.
+# The equations are the reference's own forward(); the only relay / degrader / inducer specs it ships are these.
+PATCHED_FIXTURES = [
+    "relay_constant_precisions_tiny_modeuler",
+    "relay_constant_precisions_tiny_modeulerwhile",
+    "degrader_constant_precisions_tiny_modeuler",
+    "inducer_constant_precisions_tiny_modeuler",
+    "prpr_constant_precisions_tiny_modeuler",
+]
+
 
 class Fixture:
     def __init__(self, name):

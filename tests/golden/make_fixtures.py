@@ -21,7 +21,17 @@ Provenance of every fixture (also stored inside each .npz under the key ``proven
   ``midpoint`` lives in torchdiffeq==0.1 which is absent (no network).  midpoint/rk4 parity is
   therefore *unpinned* (see oracle/vihds_oracle.py header and DESIGN.md).
 
+* ``--patched`` (PATCHED_CASES): the relay / degrader / inducer / prpr ``*_precisions`` specs.  The reference raises at
+  construction for them: ``OdeFunc.__init__`` takes four arguments and the RHS classes call it with five
+  (vihds/ode.py:21 vs models/relay_constant.py:17, degrader_constant.py:17, ...), and the ``*_Precisions`` model classes
+  call a method that does not exist (``init_with_params``, relay_constant.py:201, ...).  ``install_reference_patches``
+  repairs exactly those two defects IN MEMORY (the extra argument is dropped; ``init_with_params`` = ``OdeModel.__init__``)
+  -- no equation, constant or default is touched -- and every fixture of that leg says "MODIFIED REFERENCE" in its
+  provenance.  They also hold the first evaluation of the RHS class's own ``forward`` (``rhs_t``, ``rhs_state``,
+  ``rhs_out``), taken by a forward hook.
+
 Usage:  python tests/golden/make_fixtures.py            (writes tests/golden/*.npz)
+        python tests/golden/make_fixtures.py --patched  (writes only the MODIFIED-REFERENCE fixtures)
 """
 import argparse
 import json
@@ -101,6 +111,31 @@ def patch_merge_observations():
     D.merge_observations = merge_observations
 
 
+RHS_RECORD = {}
+
+
+def install_reference_patches():
+    """The two construction defects of SURVEY 2.1, repaired in memory (see the module docstring); plus a forward hook on
+    every OdeFunc that records the FIRST evaluation of the model's own RHS ``forward`` after RHS_RECORD was cleared."""
+    import vihds.ode as ode
+
+    orig_init = ode.OdeFunc.__init__
+
+    def init(self, config, theta, conditions, dev_1hot, *dropped):  # ode.py:21 takes four; the models pass five
+        orig_init(self, config, theta, conditions, dev_1hot)
+
+        def hook(_module, args, out):
+            if "rhs_out" not in RHS_RECORD:
+                RHS_RECORD["rhs_t"] = to_np(args[0])
+                RHS_RECORD["rhs_state"] = to_np(args[1])
+                RHS_RECORD["rhs_out"] = to_np(out)
+
+        self.register_forward_hook(hook)
+
+    ode.OdeFunc.__init__ = init
+    ode.OdeModel.init_with_params = ode.OdeModel.__init__  # relay_constant.py:201 and its siblings
+
+
 def to_np(x):
     import torch
 
@@ -165,6 +200,7 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
             t = getattr(dist, pname, None)
             if isinstance(t, torch.Tensor) and t.requires_grad and not t.is_leaf:
                 t.retain_grad()
+    RHS_RECORD.clear()
     result, cond_theta = model.decoder(clipped, batch, None, None)
     x_states, x_predict, precisions = result
     p = model.encoder.p
@@ -294,6 +330,7 @@ def run_case(spec, solver, n_iwae, rows, seed, sample_stride, with_training_step
     spec_dict["params"].update(params_override or {})
     fx["spec_json"] = np.array(json.dumps(spec_dict))
     fx["devices"] = np.asarray(batch.devices)
+    fx.update(RHS_RECORD)  # only with install_reference_patches(): first evaluation of the RHS class's forward
     return fx
 
 
@@ -396,9 +433,27 @@ CASES = [
 ]
 
 
+PATCHED_PROVENANCE = (
+    "MODIFIED REFERENCE: vihds.ode.OdeFunc.__init__ wrapped to drop the fifth positional argument the model RHS classes "
+    "pass (ode.py:21 vs relay_constant.py:17 / degrader_constant.py:17 / inducer_constant.py / prpr_constant.py), and "
+    "OdeModel.init_with_params bound to OdeModel.__init__ (called by the *_Precisions classes, e.g. relay_constant.py:201); "
+    "nothing else changed. rhs_t/rhs_state/rhs_out: first evaluation of the RHS class's forward (forward hook). "
+)
+
+# the only relay / degrader / inducer specs the reference ships are the *_precisions ones
+PATCHED_CASES = [
+    ("relay_constant_precisions_tiny_modeuler", "relay_constant_precisions", "modeuler", 8, 4, 1),
+    ("relay_constant_precisions_tiny_modeulerwhile", "relay_constant_precisions", "modeulerwhile", 5, 3, 1),
+    ("degrader_constant_precisions_tiny_modeuler", "degrader_constant_precisions", "modeuler", 8, 4, 1),
+    ("inducer_constant_precisions_tiny_modeuler", "inducer_constant_precisions", "modeuler", 8, 4, 1),
+    ("prpr_constant_precisions_tiny_modeuler", "prpr_constant_precisions", "modeuler", 8, 4, 1),
+]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default=None)
+    ap.add_argument("--patched", action="store_true", help="the MODIFIED-REFERENCE leg (PATCHED_CASES) instead of CASES")
     ap.add_argument("--out", default=HERE, help="directory the .npz files are written to (default: next to this script; "
                     "a scratch directory lets a regeneration be compared with the committed files)")
     a = ap.parse_args()
@@ -411,6 +466,18 @@ def main():
     patch_merge_observations()
     import torch
 
+    if a.patched:
+        install_reference_patches()
+        for name, spec, solver, S, rows, stride in PATCHED_CASES:
+            if a.only and a.only not in name:
+                continue
+            fx = run_case(spec, solver, S, rows, 0, stride)
+            fx["provenance"] = np.array(PATCHED_PROVENANCE + PROVENANCE + "torch %s numpy %s python %s"
+                                        % (torch.__version__, np.__version__, sys.version.split()[0]))
+            out = os.path.join(out_dir, name + ".npz")
+            np.savez_compressed(out, **fx)
+            print("wrote %s  loss=%s  (%.1f kB)" % (out, fx["loss"], os.path.getsize(out) / 1e3))
+        return
     if not a.only or "trace" in a.only:
         for name, spec, solver, S, epochs in [("trace_dr_constant_icml_modeuler", "dr_constant_icml", "modeuler", 20, 4),
                                               ("trace_auto_constant_modeuler", "auto_constant", "modeuler", 20, 6)]:

@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 import torch
 
-from fixture_util import Fixture, rel_err
+from fixture_util import PATCHED_FIXTURES, Fixture, rel_err
 
 pytestmark = pytest.mark.gpu
 
@@ -16,6 +16,9 @@ CASES = ["dr_constant_one_modeuler", "dr_constant_one_s5_modeulerwhile", "dr_con
          "auto_constant_tiny_modeuler", "prpr_constant_tiny_modeuler", "dr_constant_precisions_tiny_modeuler",
          "auto_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
          "dr_constant_precisions_hidden20_tiny_modeuler", "dr_blackbox_sized_tiny_modeuler"]
+# + the MODIFIED reference (construction defects repaired, fixture_util.PATCHED_FIXTURES): the relay / degrader / inducer /
+# prpr *_precisions plugins end to end, BASELINE config 5's model among them
+CASES = CASES + PATCHED_FIXTURES
 
 
 def _ref_encoder_grads(fx, enc):
@@ -213,6 +216,33 @@ def test_evaluation_replayed_from_a_graph_gives_the_eager_results(name):
     for a, b in zip(*runs):
         assert np.array_equal(a[6].theta, b[6].theta)
     assert runs[1][0][0] != runs[1][1][0]  # (fresh draws per replay)
+
+
+def test_kept_elbo_scalars_survive_later_graph_evaluations():
+    """_evaluate_elbo_and_plot keeps bare `out.elbo` values (max_val_elbo, the elbo lists) while the Results they
+    came from die; with the captured evaluation pass those used to be views of a pinned ring slot a later pass rewrites.
+    More passes than ring slots, keeping ONLY the scalars: every kept value must still be the value of its own pass."""
+    import gc
+    import e2e_util as E
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, u_rng="kernel", conditioner_rng="kernel",
+                                                            hip_graph=True, eval_graph=True)
+    model = build_model(args, settings, data, parameters)
+    training = Training(args, settings, data, parameters, model)
+    batch = E.batch_from_fixture(fx, settings.device)
+    model.eval()
+    kept, at_the_time = [], []
+    for k in range(11):
+        out = training.evaluate(batch, args.train_samples)
+        kept.append(out.elbo)  # the bare member, as the reference's loop keeps it
+        at_the_time.append(float(out.elbo))
+        del out
+        gc.collect()
+    assert len(set(at_the_time)) == 11  # (fresh draws per pass)
+    assert [float(v) for v in kept] == at_the_time
 
 
 class _TraceDataset(torch.utils.data.Dataset):

@@ -6,8 +6,10 @@ fp32 op sequence, so forward values agree to rounding of BLAS/reduction order on
 import pytest
 import torch
 
-from fixture_util import ALL_FIXTURES, Fixture, rel_err
+from fixture_util import ALL_FIXTURES as _PINNED, PATCHED_FIXTURES, Fixture, rel_err
 from oracle import vihds_oracle as O
+
+ALL_FIXTURES = _PINNED + PATCHED_FIXTURES  # the second list: the MODIFIED reference (fixture_util.PATCHED_FIXTURES)
 
 
 def _blackbox_kwargs(fx, th, prec_w, states_w):
@@ -296,3 +298,29 @@ def test_dependency_algorithm_steps_past_output_times_and_interpolates(solver):
     coef = O._interp_fit(y0, y1, 0.5 * (y0 + y1), f0, f1, 0.3)
     assert torch.allclose(O._interp_evaluate(coef, 1.0, 1.3, 1.0), y0, atol=1e-6)
     assert torch.allclose(O._interp_evaluate(coef, 1.0, 1.3, 1.3), y1, atol=1e-5)
+
+
+@pytest.mark.parametrize("name", PATCHED_FIXTURES)
+def test_rhs_forward_matches_the_modified_references_own_forward(name):
+    """The first evaluation of Relay_Constant_RHS.forward / Degrader_Constant_RHS.forward / ... themselves (recorded by a
+    forward hook in `make_fixtures.py --patched`: MODIFIED REFERENCE, construction defects repaired, equations untouched;
+    models/relay_constant.py:91-134, degrader_constant.py:103-143, inducer_constant.py, prpr_constant.py) against the
+    oracle's RHS closure on the recorded (t, state), and the initial state against initialize_state."""
+    fx = Fixture(name)
+    prec_w, _, _ = fx.decoder_weights()
+    maker, _, neural = O.MODEL_TABLE[fx.model]
+    assert neural
+    rhs, x0 = maker(fx.theta_dict(), fx.t("inputs"), prec_w=prec_w)
+    state = fx.t("rhs_state")
+    assert torch.equal(x0, state)  # the integrators' first call is f(times[0], x0)
+    assert float(fx.t("rhs_t")) == float(fx.t("times")[0])
+    with torch.no_grad():
+        out = rhs(fx.t("rhs_t"), state)
+    assert rel_err(out, fx.t("rhs_out"), dim=2) < 1e-6
+
+
+def test_patched_fixtures_say_so():
+    for name in PATCHED_FIXTURES:
+        assert str(Fixture(name).z["provenance"]).startswith("MODIFIED REFERENCE")
+    for name in _PINNED:
+        assert "MODIFIED REFERENCE" not in str(Fixture(name).z["provenance"])

@@ -247,7 +247,7 @@ class OdeModel(nn.Module):
         rtol = float(default_get_value(config.params, "solver_rtol", 1e-7))  # torchdiffeq.odeint defaults
         atol = float(default_get_value(config.params, "solver_atol", 1e-9))
         # The accepted grid lives in a caller-sized buffer: params.solver_max_grid (default 4096 points); when the controller
-        # runs out of it the buffer is doubled up to 2^17 points before giving up with a message that names the cause --
+        # runs out of it the buffer is quadrupled up to 2^17 points before giving up with a message that names the cause --
         # all arithmetic is fp32, so tolerances near its epsilon (torchdiffeq's defaults 1e-7 / 1e-9 with a low-order pair
         # such as adaptive_heun) ask for step sizes the state cannot resolve
         max_grid = int(default_get_value(config.params, "solver_max_grid", 4096))
@@ -256,7 +256,9 @@ class OdeModel(nn.Module):
                 grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol, max_grid=max_grid)
                 break
             except RuntimeError as e:
-                if "max_grid" not in str(e) and "grid" not in str(e):
+                # only the controller running out of its buffer is worth a larger one (the C ABI's message for that exact
+                # condition); step-size underflow, a non-finite error estimate or bad arguments are re-raised as they are
+                if "does not fit max_grid" not in str(e):
                     raise
                 if max_grid >= (1 << 17):
                     raise RuntimeError(

@@ -241,10 +241,18 @@ class Training:
             with torch.no_grad():
                 results, theta, q, p = self.model(data, n_samples, writer=writer, epoch=epoch)
                 return self.cost(data, results, theta, q, p, full_output=True, writer=writer, epoch=epoch)
+        # keyed by the data object's identity; the entry HOLDS the object, so its id cannot be reused by another batch of
+        # another shape while the graph that captured its tensors is cached; a caller that evaluates many
+        # throw-away batches keeps at most eight captured passes alive
         key = (id(data), int(n_samples))
         if key not in self._eval_graphs:
-            self._eval_graphs[key] = self._capture_evaluation(data, int(n_samples))
+            while len(self._eval_graphs) >= 8:
+                self._eval_graphs.pop(next(iter(self._eval_graphs)))
+            g, staged = self._capture_evaluation(data, int(n_samples))
+            staged["data"] = data
+            self._eval_graphs[key] = (g, staged)
         g, staged = self._eval_graphs[key]
+        assert staged["data"] is data
         # the theta samples of the previous pass live in the graph's memory pool: if its Results is still around and nobody
         # has read them yet, they are copied (on the device) before this replay overwrites them -- a Results that was
         # dropped, the usual case, costs nothing
@@ -314,15 +322,16 @@ class Training:
         log_data.total_test_time += time.time() - test_start
         print(" | val (iwae-elbo = %0.4f, time = %0.2f, total = %0.2f)"
               % (valid_output.elbo, log_data.total_test_time / log_data.n_test, log_data.total_test_time))
-        if valid_output.elbo > log_data.max_val_elbo:
-            log_data.max_val_elbo = valid_output.elbo
+        # plain floats: a Results' numpy members may be views of a staging buffer a later pass rewrites (utils.Results)
+        if float(valid_output.elbo) > log_data.max_val_elbo:
+            log_data.max_val_elbo = float(valid_output.elbo)
             if self.lazy_cache_dump:
                 self._best_output = valid_output  # written once, when run() leaves its loop (nine files per improvement otherwise)
             else:
                 valid_output.dump()
             self.empty_cache = False
-        log_data.training_elbo_list.append(train_output.elbo)
-        log_data.validation_elbo_list.append(valid_output.elbo)
+        log_data.training_elbo_list.append(float(train_output.elbo))
+        log_data.validation_elbo_list.append(float(valid_output.elbo))
         return valid_output
 
     # ------------------------------------------------------------------------------------------------
@@ -360,7 +369,10 @@ class Training:
         if elbo.is_cuda:
             # a non-finite loss makes the update a no-op on the device, step count included (the reference stops before
             # optimizer.step on a NaN ELBO, training.py:331-334; here the host reads the loss after the launches)
-            self.optimizer.gate = elbo.detach()
+            # Row replicas each have their OWN loss: gating on it would let one rank skip an update its peers apply.  There
+            # the all-reduced gradients -- identical on every rank, non-finite wherever any rank's were -- decide, element
+            # by element, inside the Adam kernel: the replicas stay in step
+            self.optimizer.gate = elbo.detach() if self.replica is None else None
         self.optimizer.step()
         if zero_grad:
             self.optimizer.zero_grad(set_to_none=True)
@@ -554,6 +566,28 @@ class Training:
         hip.check(rc, "vihds_gather_batch")
         return out
 
+    class _IndexStaging:
+        """Pinned staging slots for a captured step's row indices.  The host->device copy of step k is asynchronous and
+        sits behind step k-1 on the stream, so the slot it reads must not be rewritten until it has run: a slot is reused
+        only after the event recorded behind its copy has completed (one pinned buffer, rewritten per step,
+        let step k+1's indices overtake copy k whenever nothing else synchronised in between)."""
+
+        def __init__(self, n, slots=4):
+            self.bufs = [torch.empty(n, dtype=torch.int64).pin_memory() for _ in range(slots)]
+            self.events = [None] * slots
+            self.pos = 0
+
+        def upload(self, dst, fill):
+            k = self.pos
+            self.pos = (k + 1) % len(self.bufs)
+            if self.events[k] is not None:
+                self.events[k].synchronize()
+            fill(self.bufs[k])
+            dst.copy_(self.bufs[k], non_blocking=True)
+            if self.events[k] is None:
+                self.events[k] = torch.cuda.Event()
+            self.events[k].record()
+
     def step_rows(self, rows_host):
         """One training step on the rows `rows_host` (host int64 tensor) of the resident training set: eager, or -- with
         params.hip_graph -- one hipGraph per batch size holding the gather and the step; per step the host then only
@@ -566,11 +600,10 @@ class Training:
         if key not in self._graphs:
             idx = rows_host.to(dev).clone()
             static = self.gather_rows(idx)
-            pinned = torch.empty(n, dtype=torch.int64).pin_memory()
-            self._graphs[key] = self._capture(static, 1, prologue=lambda: self.gather_rows(idx, out=static)) + (idx, pinned)
-        g, static, loss, idx, pinned = self._graphs[key]
-        pinned.copy_(rows_host)
-        idx.copy_(pinned, non_blocking=True)
+            self._graphs[key] = (self._capture(static, 1, prologue=lambda: self.gather_rows(idx, out=static))
+                                 + (idx, self._IndexStaging(n)))
+        g, static, loss, idx, staging = self._graphs[key]
+        staging.upload(idx, lambda buf: buf.copy_(rows_host))
         g.replay()
         return loss
 
@@ -584,7 +617,6 @@ class Training:
         key = ("epoch",) + sizes
         if key not in self._graphs:
             idx = torch.cat(list(batches)).to(dev).clone()
-            pinned = torch.empty(int(idx.shape[0]), dtype=torch.int64).pin_memory()
             statics, segments, o = {}, [], 0
             for n in sizes:
                 view = idx[o: o + n]
@@ -592,10 +624,9 @@ class Training:
                     statics[n] = self.gather_rows(view)
                 segments.append((statics[n], (lambda v=view, st=statics[n]: self.gather_rows(v, out=st))))
                 o += n
-            self._graphs[key] = self._capture_segments(segments) + (idx, pinned)
-        g, losses, idx, pinned = self._graphs[key]
-        torch.cat(list(batches), out=pinned)
-        idx.copy_(pinned, non_blocking=True)
+            self._graphs[key] = self._capture_segments(segments) + (idx, self._IndexStaging(int(idx.shape[0])))
+        g, losses, idx, staging = self._graphs[key]
+        staging.upload(idx, lambda buf: torch.cat(list(batches), out=buf))
         g.replay()
         return losses
 
@@ -609,7 +640,7 @@ class Training:
         else:
             elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
         self._steps += 1
-        if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and torch.isnan(elbo):
+        if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and self._loss_is_nan(elbo):
             # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced the
             # NaN has already been launched -- the Adam launch is gated on the loss on the device (vihds_adam_step's
             # `gate`, vihds_step_tail's row check), so parameters, moments and the step count are those of the last
@@ -618,6 +649,18 @@ class Training:
             return False
         log_data.batch_train_time += time.time() - train_start
         return True
+
+    def _loss_is_nan(self, elbo):
+        """The reference's per-step check (training.py:331).  Row replicas must all leave the loop together -- a rank that
+        stopped alone would leave its peers blocked in the next gradient all-reduce -- so they agree on the flag first."""
+        bad = torch.isnan(elbo)
+        if self.replica is not None:
+            import torch.distributed as dist
+
+            flag = bad.to(torch.float32).reshape(1)
+            dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.replica.group)
+            bad = flag[0] > 0
+        return bool(bad)
 
     def run(self):
         """reference training.py:342-383"""

@@ -166,7 +166,9 @@ class Results:
             qv.append(arr[o:o + n].reshape(shp))
             o += n
         self.q_values = np.array(qv, dtype=object)
-        self.elbo = arr[o:o + 1].reshape(())
+        # the ELBO is a scalar callers KEEP (log_data.max_val_elbo, the elbo lists of _evaluate_elbo_and_plot): it gets
+        # storage of its own at once, never a view of a staging slot a later pass rewrites
+        self.elbo = np.array(arr[o], dtype=arr.dtype)
         o += 1
         out = []
         for shp in staged["summary_shapes"]:
@@ -183,7 +185,6 @@ class Results:
         self._host_views = False
         qv = [np.array(v, copy=True) for v in self.q_values]
         self.q_values = np.array(qv, dtype=object)
-        self.elbo = np.array(self.elbo, copy=True)
         self.iw_predict_mu, self.iw_predict_std = self.iw_predict_mu.copy(), self.iw_predict_std.copy()
         self.iw_states, self.iw_variance = self.iw_states.copy(), self.iw_variance.copy()
 
