@@ -97,27 +97,41 @@ def ode_kernel_times(model, settings, batch, n_iwae, n_launch):
     return out
 
 
-def make_oracle_step(solver, observations=None, n_iwae=N_IWAE, workload="dr_constant_icml"):
-    """One full training step of the oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python time loop, autograd,
-    Adam) on the bench workload, as a closure returning its wall time.  Shared by `cpu_baseline` below and by
-    oracle/time_vs_reference.py (which times the imported reference beside it in the build container)."""
+def make_oracle_step(solver, observations=None, n_iwae=N_IWAE, workload="dr_constant_icml", mode="train", rows=B_ROWS):
+    """One full training step -- or, mode="eval", one evaluation pass (forward without grad + Results.init's summaries,
+    reference training.py:283-307, utils.py:79-99) -- of the oracle (oracle/vihds_oracle.py: per-op [B,S] tensors, python
+    time loop, autograd, Adam) on the bench workload, as a closure returning its wall time.  Shared by `cpu_baseline`
+    below and by oracle/time_vs_reference.py (which times the imported reference beside it in the build container)."""
     from oracle import vihds_oracle as O
     from vihds import synthetic
 
     args, settings, data, parameters, model, training = synthetic.build(
-        workload, B_ROWS, n_iwae, solver=solver, device="cpu", seed=0, observations=observations)
-    N_IWAE_ = n_iwae
+        workload, rows, n_iwae, solver=solver, device="cpu", seed=0, observations=observations)
+    N_IWAE_, B_ = n_iwae, rows
     enc = model.encoder
     model_key = settings.model
+    ode = model.decoder.ode_model
     # relay_constant_precisions (config 5): aR / aS are sampled parameters (no device conditioner) and the precision network's
     # two Linear layers train with the encoder
-    conditioned = [k for k in ("aR", "aS") if k not in enc.names]
-    prec = getattr(model.decoder.ode_model, "precisions", None)
+    conditioned = [k for k in ("aR", "aS") if k not in enc.names and model_key != "dr_blackbox"]
+    prec = getattr(ode, "precisions", None)
     prec_w = None
     if getattr(prec, "dynamic", False):
         prec_w = {"prod_w": prec.prec_production.weight, "prod_b": prec.prec_production.bias,
                   "degr_w": prec.prec_degradation.weight, "degr_b": prec.prec_degradation.bias}
-    opt = torch.optim.Adam(list(enc.parameters()) + (list(prec.parameters()) if prec_w is not None else []), lr=0.01)
+        if getattr(prec, "n_hidden", 0) >= 1:
+            prec_w.update({"hid_w": prec.prec_hidden.weight, "hid_b": prec.prec_hidden.bias})
+    blackbox_kw, decoder_params = None, (list(prec.parameters()) if prec_w is not None else [])
+    if model_key == "dr_blackbox":  # config 4: NeuralStates + NeuralPrecisions + the y offset layer (models/dr_blackbox.py)
+        ns = ode.neural_states
+        states_w = {"hid_w": ns.states_hidden.weight, "hid_b": ns.states_hidden.bias,
+                    "prod_w": ns.states_production.weight, "prod_b": ns.states_production.bias,
+                    "degr_w": ns.states_degradation.weight, "degr_b": ns.states_degradation.bias}
+        blackbox_kw = dict(states_w=states_w, prec_w=prec_w, n_x=ode.n_x, n_y=ode.n_y, n_z=ode.n_z,
+                           n_latent_species=ode.n_latent_species, init_latent_species=ode.init_latent_species,
+                           init_prec=ode.init_prec)
+        decoder_params = list(ode.parameters())
+    opt = torch.optim.Adam(list(enc.parameters()) + decoder_params, lr=0.01)
     batch = training.train_data
     names = enc.names
     kinds = [d.kind for d in enc.descs]
@@ -125,41 +139,60 @@ def make_oracle_step(solver, observations=None, n_iwae=N_IWAE, workload="dr_cons
     p_mu, p_prec = [pm[i, 0] for i in range(len(names))], [pp[i, 0] for i in range(len(names))]
     rel = {k: torch.tensor(v) for k, v in settings.data.relevance_vectors.items()}
 
-    def one_step():
-        t0 = time.perf_counter()
-        u = torch.tensor(np.random.randn(B_ROWS, N_IWAE_, len(names)).astype(np.float32))
+    def forward():
+        u = torch.tensor(np.random.randn(B_, N_IWAE_, len(names)).astype(np.float32))
         q = enc(batch)
-        _, q_mu, q_prec = q.image("cpu", B_ROWS)
+        _, q_mu, q_prec = q.image("cpu", B_)
         qm = [q_mu[i][:, None] for i in range(len(names))]
         qp = [q_prec[i][:, None] for i in range(len(names))]
         th = O.sample_clip_theta(names, kinds, qm, qp, p_mu, p_prec, u)
-        ones = torch.ones(B_ROWS, N_IWAE_)
+        ones = torch.ones(B_, N_IWAE_)
         for k in conditioned:
             w = 2.0 + 1.5 * torch.randn(1, batch.dev_1hot.shape[1])
             th[k] = O.device_conditioner(w, ones, rel[k], batch.dev_1hot, True)
-        out = O.elbo_from_theta(model_key, names, kinds, th, qm, qp, p_mu, p_prec, batch.inputs, batch.times,
-                                batch.observations, solver, prec_w=prec_w)
-        out["loss"].backward()
-        opt.step()
-        opt.zero_grad()
+        th_sim, bb = th, None
+        if blackbox_kw is not None:  # condition_theta: the ODE sees y + offset_layer(dev_1hot), log q / log p the sampled y
+            th_sim = dict(th)
+            off = ode.offset_layer(batch.dev_1hot.unsqueeze(1).repeat([1, N_IWAE_, 1]))
+            for i in range(ode.n_y):
+                th_sim["y%d" % (i + 1)] = th["y%d" % (i + 1)] + off[:, :, i]
+            bb = dict(blackbox_kw, dev_1hot=batch.dev_1hot)
+        xs, xp, prc = O.decode(model_key, th_sim, batch.inputs, batch.times, solver, prec_w=prec_w, blackbox=bb)
+        lpo = O.log_prob_observations(xp, batch.observations, prc)
+        vals = [th[n] for n in names]
+        loss, log_w = O.iwae_loss(lpo, O.chained_log_prob(kinds, p_mu, p_prec, vals), O.chained_log_prob(kinds, qm, qp, vals))
+        return loss, log_w, xs, xp, prc
+
+    def one_step():
+        t0 = time.perf_counter()
+        if mode == "eval":
+            with torch.no_grad():
+                loss, log_w, xs, xp, prc = forward()
+                O.importance_weighted_summaries(log_w, xp, xs, prc)
+        else:
+            loss = forward()[0]
+            loss.backward()
+            opt.step()
+            opt.zero_grad()
         return time.perf_counter() - t0
 
     return one_step
 
 
 def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=N_IWAE, workload="dr_constant_icml",
-                 n_times=None):
+                 n_times=None, mode="train", rows=B_ROWS, probe_threads=None):
     """The oracle timed on this box's host cores on the same workload.  Checker code used as a *reported baseline*
     only.  Rows for 1 thread, 8 threads and all host threads; `value` is the best of them.  `fidelity` echoes
     oracle/cpu_fidelity.json: the same oracle step timed against the imported reference in the build container."""
     all_threads = torch.get_num_threads()
-    one_step = make_oracle_step(solver, observations, n_iwae, workload)
+    one_step = make_oracle_step(solver, observations, n_iwae, workload, mode, rows)
     # the tensors are tiny (7 200 elements), so more threads is not faster: probe 1 / 8 / all host threads and time
-    # the baseline with whichever is quickest on this box
+    # the baseline with whichever is quickest on this box (probe_threads: a fixed list, for the bounded legs)
     probe = {}
-    for n in sorted({1, min(8, all_threads), all_threads}):
+    for n in sorted(set(probe_threads) if probe_threads else {1, min(8, all_threads), all_threads}):
         torch.set_num_threads(n)
-        one_step()
+        if not probe_threads:
+            one_step()
         probe[n] = one_step()
     threads = min(probe, key=probe.get)
     torch.set_num_threads(threads)
@@ -170,20 +203,22 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=
     steps = len(times_s)
     torch.set_num_threads(all_threads)
     med = float(np.median(times_s))
-    out = {"value": 1.0 / med, "unit": "steps/s", "cores": threads, "kind": "port",
-           "sample": "%d full training steps of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
+    out = {"value": 1.0 / med, "unit": "steps/s" if mode == "train" else "passes/s", "cores": threads, "kind": "port",
+           "sample": "%d %s of the same workload (B=%d, n_iwae=%d, T=%d, %s), median; eager PyTorch "
                      "CPU restatement of the reference path (oracle/); %d threads chosen from a probe of %s "
                      "(s/step); box has %d host threads"
-                     % (steps, B_ROWS, n_iwae, n_times or N_TIMES, solver, threads,
+                     % (steps, "full training steps" if mode == "train" else "evaluation passes (forward without grad + "
+                        "Results.init summaries)", rows, n_iwae, n_times or N_TIMES, solver, threads,
                         {k: round(v, 2) for k, v in probe.items()}, all_threads),
            "ms_per_step": 1e3 * med,
            "rows_steps_per_s": {("%d thread%s" % (k, "" if k == 1 else "s")): round(1.0 / v, 3) for k, v in probe.items()}}
     fid = os.path.join(ROOT, "oracle", "cpu_fidelity.json")
     if os.path.exists(fid) and workload == "dr_constant_icml":
         out["fidelity"] = json.load(open(fid))
-    if workload != "dr_constant_icml":
-        out["note"] = ("no reference timing can exist beside this one: the reference's classes for this model raise at "
-                       "construction (relay_constant.py:17,201); the oracle restates its equations")
+    if workload == "relay_constant_precisions":
+        out["note"] = ("no reference timing exists beside this one: the reference's classes for this model raise at "
+                       "construction (relay_constant.py:17,201); the oracle restates its equations and is pinned on the "
+                       "MODIFIED reference's outputs (tests/golden/make_fixtures.py --patched)")
     return out
 
 
@@ -220,8 +255,11 @@ def time_launch(fn, n):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def run_workload(a, name):
-    """One of BASELINE.json's other configurations through the same host path: timed loop (barrier + synchronize on
+def run_workload(a, name, min_seconds=None, bounded_cpu=False):
+    """Returns the JSON object of one of BASELINE.json's other configurations (None on ranks other than 0).  min_seconds:
+    the timed window is sized from a short trial instead of --steps (the legs of the default line: >= that many seconds
+    each).  bounded_cpu: the cpu_baseline leg runs at 8 threads without the thread probe, two samples.
+    One of BASELINE.json's other configurations through the same host path: timed loop (barrier + synchronize on
     both sides, max over ranks), then the step's own ODE launches re-issued back to back between one HIP event pair for
     the roofline object.  N > 1: --shard samples splits the ONE batch's IWAE-sample axis over the ranks (strong
     scaling, the partitioning BASELINE config 3 names); --shard rows replicates the batch per rank (weak)."""
@@ -273,11 +311,22 @@ def run_workload(a, name):
 
     if use_graph:
         step(batch)
-    for _ in range(a.warmup):
+    n_steps, n_warm = a.steps, a.warmup
+    if min_seconds is not None:
+        for _ in range(5):
+            step(batch)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            step(batch)
+        barrier()
+        per = (time.perf_counter() - t0) / 20
+        n_steps, n_warm = max(50, int(math.ceil(min_seconds / per))), 20
+    for _ in range(n_warm):
         loss = step(batch)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(a.steps):
+    for _ in range(n_steps):
         loss = step(batch)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -337,7 +386,7 @@ def run_workload(a, name):
                 "traffic": tr}
 
     if rank != 0:
-        return
+        return None
     roofline = None
     if timed:
         dom = max(timed, key=timed.get)
@@ -361,9 +410,9 @@ def run_workload(a, name):
     what = "training steps" if mode == "train" else "evaluation passes"
     scale = 1 if (strong or not multi) else world
     out = {
-        "metric": "ELBO %s/sec (%s, n_iwae=%d)" % (what, wl, S), "value": scale * a.steps / elapsed,
-        "unit": "steps/s" if mode == "train" else "passes/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-        "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True,
+        "metric": "ELBO %s/sec (%s, n_iwae=%d)" % (what, wl, S), "value": scale * n_steps / elapsed,
+        "unit": "steps/s" if mode == "train" else "passes/s", "n_gpus": world, "steps": n_steps, "warmup": n_warm,
+        "ms_per_step": 1e3 * elapsed / n_steps, "higher_is_better": True,
         "scaling": "strong" if strong else "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": "%s (BASELINE.json %s): B=%d rows x n_iwae=%d, N=%d states, T=%d, P=%d, %s, %s"
                                % (wl, cfg_note, B, S, N, T, P, solver,
@@ -380,14 +429,24 @@ def run_workload(a, name):
                                    "data parallel over rows x%d (one gradient all-reduce per step)" % world)},
         "final_objective": final, "roofline": roofline,
     }
-    if world == 1 and not a.no_cpu_baseline and wl in ("dr_constant_icml", "relay_constant_precisions") and mode == "train":
-        out["cpu_baseline"] = cpu_baseline(solver, batch.observations.detach().cpu(), n_iwae=S, max_steps=4, workload=wl,
-                                           n_times=T)
-        out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
+    if world == 1 and not a.no_cpu_baseline:
+        # the oracle on this box's host cores: a training step (white-box models and, since round 4, dr_blackbox) or an
+        # evaluation pass; the evaluation shape's sample is 36 of its 234 rows (the pass is row-wise independent; 234 rows
+        # x 1000 samples of eager [B,S] tensors would be minutes), scaled to passes of the full shape
+        cpu_rows = B if mode == "train" else min(B, 36)
+        obs_cpu = batch.observations.detach().cpu()[:cpu_rows].contiguous()
+        cb = cpu_baseline(solver, obs_cpu, n_iwae=S, max_steps=2 if bounded_cpu else 4, workload=wl, n_times=T, mode=mode,
+                          rows=cpu_rows, probe_threads=[min(8, torch.get_num_threads())] if bounded_cpu else None,
+                          seconds_budget=15.0 if bounded_cpu else 20.0)
+        if cpu_rows != B:
+            cb["value"] *= cpu_rows / B
+            cb["ms_per_step"] *= B / cpu_rows
+            cb["sample"] += "; timed on %d of the %d rows (row-wise independent work), value scaled by %d/%d" % (cpu_rows, B, cpu_rows, B)
+        out["cpu_baseline"] = cb
+        out["speedup_vs_cpu_restatement"] = out["value"] / cb["value"]
     else:
         out["cpu_baseline"] = None
-        out["cpu_baseline_note"] = "the oracle's timed training step exists for the white-box training workloads only"
-    print(json.dumps(out))
+    return out
 
 
 def run_loop_workload(a):
@@ -490,6 +549,74 @@ def strong_scaling_leg(a, dev, world, rank):
         return {"error": "%s: %s" % (type(e).__name__, e)}
 
 
+def unchanged_spec_leg(a, dev, min_seconds):
+    """The headline workload with NONE of this implementation's opt-in keys: what `run_xval.py --gpu 0 <spec>.yaml` runs
+    when the YAML is the reference's own -- u drawn by host numpy (vae.py:22-24) and uploaded, the conditioner's weights
+    drawn by torch on the CPU, eager launches, autograd's backward + the Adam launch, and the reference's NaN check (a
+    device synchronisation) after every step (training.py:331-334).  rk4 like the headline (the spec's own default solver is
+    midpoint)."""
+    from vihds import synthetic
+
+    args, settings, data, parameters, model, training = synthetic.build(
+        "dr_constant_icml", B_ROWS, N_IWAE, solver=a.solver, device=dev, seed=a.seed, learning_rate=a.lr)
+    model.train()
+    batch = training.train_data
+
+    def step():
+        elbo = training.step(batch)
+        if bool(torch.isnan(elbo)):
+            raise SystemExit("NaN objective in the unchanged-spec leg")
+        return elbo
+
+    for _ in range(5):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        step()
+    torch.cuda.synchronize()
+    n = max(20, int(math.ceil(min_seconds / ((time.perf_counter() - t0) / 10))))
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        loss = step()
+    torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    p = settings.params
+    return {"metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200), reference-default keys", "value": n / el,
+            "unit": "steps/s", "steps": n, "ms_per_step": 1e3 * el / n, "final_loss": float(loss),
+            "config": {"workload": "the headline workload with no opt-in key set (params.fast off)", "solver": a.solver,
+                       "u_rng": p.u_rng, "conditioner_rng": p.conditioner_rng, "hip_graph": bool(p.hip_graph),
+                       "nan_check_every": int(p.nan_check_every), "learning_rate": a.lr,
+                       "launch": "eager, host-drawn normals uploaded per step, loss read on the host after every step"}}
+
+
+def other_config_legs(a, dev):
+    """The other single-GPU BASELINE configurations and the unchanged-spec path, each timed for >= --leg-seconds inside the
+    driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
+    error; it never takes the headline line with it."""
+    legs = {}
+    for name in ("config3_train", "config3_eval", "config4", "config5"):
+        t0 = time.perf_counter()
+        try:
+            out = run_workload(a, name, min_seconds=a.leg_seconds, bounded_cpu=True)
+            keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "final_objective", "roofline",
+                    "cpu_baseline", "speedup_vs_cpu_restatement")
+            legs[name] = {k: out[k] for k in keep if k in out}
+        except BaseException as exc:  # noqa: BLE001 (SystemExit included: a leg must not end the run)
+            legs[name] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        legs[name]["leg_wall_s"] = time.perf_counter() - t0
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    t0 = time.perf_counter()
+    try:
+        legs["unchanged_spec"] = unchanged_spec_leg(a, dev, a.leg_seconds)
+    except BaseException as exc:  # noqa: BLE001
+        legs["unchanged_spec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    legs["unchanged_spec"]["leg_wall_s"] = time.perf_counter() - t0
+    return legs
+
+
 def issue_bound(kernel_name, mean_us):
     """HBM is demonstrably not what bounds the headline launch (measured traffic is ~10x below the algorithmic bytes: the
     trajectory stays in LDS), VALU issue is the nearer ceiling: instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, a pass
@@ -545,6 +672,10 @@ def main():
                     help="N > 1: skip the extra strong-scaling measurement (config 3's one batch, n_iwae=1000, sample-sharded) "
                          "that is otherwise added to the line as `strong_scaling_config3`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
+                    help="N = 1: skip the legs of the other single-GPU BASELINE configurations (config3_train, config3_eval, "
+                         "config4, config5) and of the unchanged-spec path that the default line nests under `other_configs`")
+    ap.add_argument("--leg-seconds", type=float, default=0.6, help="timed window of each `other_configs` leg")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
     ap.add_argument("--seed", type=int, default=1)
@@ -574,7 +705,10 @@ def main():
             raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
         if a.workload == "run_loop":
             return run_loop_workload(a)
-        return run_workload(a, a.workload)
+        out = run_workload(a, a.workload)
+        if out is not None:
+            print(json.dumps(out))
+        return
     a.solver = a.solver or "rk4"
 
     from vihds import ops, parallel, synthetic
@@ -814,6 +948,11 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.solver, batch.observations.detach().cpu())
         out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
+    if world == 1 and a.other_configs and not (a.eager or a.host_rng or a.two_kernel_ode):
+        del model, training, step
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+        out["other_configs"] = other_config_legs(a, dev)
     print(json.dumps(out))
 
 

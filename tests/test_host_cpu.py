@@ -8,7 +8,9 @@ import numpy as np
 import pytest
 import torch
 
-from fixture_util import ALL_FIXTURES, Fixture, rel_err
+from fixture_util import ALL_FIXTURES as _PINNED, PATCHED_FIXTURES, Fixture, rel_err
+
+ALL_FIXTURES = _PINNED + PATCHED_FIXTURES
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -181,3 +183,22 @@ def test_run_batch_with_nan_check_disabled_and_graph_needs_device_rng():
         from vihds.training import Training
 
         Training(args, settings, data, parameters, model)
+
+
+def test_fast_switch_sets_the_eight_keys_coherently(monkeypatch):
+    """`params: {fast: true}` / VIHDS_FAST=1 (INTEGRATION.md section 6): one switch instead of eight keys; explicit keys win;
+    without it every addition of this implementation keeps the reference's behaviour."""
+    from vihds import config as C
+
+    monkeypatch.delenv("VIHDS_FAST", raising=False)
+    base = C.apply_defaults_params({"learning_rate": 0.01})
+    assert (base.u_rng, base.conditioner_rng, base.hip_graph, base.nan_check_every) == ("numpy", "cpu", False, 1)
+    assert not base.fused_ode_training and not base.fused_iwae_backward and not base.get("fused_step_tail", False)
+    fast = C.apply_defaults_params({"fast": True, "nan_check_every": 7})
+    for k, v in C.FAST_PARAMS.items():
+        assert fast[k] == (7 if k == "nan_check_every" else v), k
+    monkeypatch.setenv("VIHDS_FAST", "1")
+    env = C.apply_defaults_params({"learning_rate": 0.01})
+    assert all(env[k] == v for k, v in C.FAST_PARAMS.items())
+    monkeypatch.setenv("VIHDS_FAST", "0")
+    assert C.apply_defaults_params({"fast": True}).hip_graph is False
