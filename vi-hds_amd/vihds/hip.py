@@ -148,6 +148,7 @@ _PROTOTYPES = {
                                   + [_P] * 10),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_bwd_reduces_weights": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_traj_layout": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_blackbox_dump_fields": (_I, []),
     "vihds_problem_n_states": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_problem_n_slots": (_I, [ctypes.POINTER(OdeProblem)]),
@@ -203,7 +204,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 11:
+        if handle.vihds_abi_version() != 12:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

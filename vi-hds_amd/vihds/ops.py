@@ -178,19 +178,25 @@ class OdeSolveObserve(torch.autograd.Function):
             raise RuntimeError("theta has %d rows, problem expects %d" % (R, spec.n_rows))
         prob = spec.bind(B, S, T)
         N = spec.n_states
-        traj = torch.empty((T, N, B, S), device=theta.device, dtype=torch.float32)
+        # kernel_variant 5 (time-parallel kernels): the buffers are [B][S][N][T] / [B][S][4][T], time fastest -- the reference's
+        # own logical layout (ode.py:82); what this function returns keeps the shape [T,N,B,S] / [T,4,B,S] as a permuted view
+        time_fastest = bool(hip.lib().vihds_ode_traj_layout(ctypes.byref(prob)))
+        traj = torch.empty((B, S, N, T) if time_fastest else (T, N, B, S), device=theta.device, dtype=torch.float32)
         # (want_xpred False: the observed signals are not written -- they are a pointwise map of the trajectory and the
         # evaluation summaries form them in registers, vihds_iw_summaries_states; the second output is then None)
-        xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32) if want_xpred else None
+        xpred = (torch.empty((B, S, 4, T) if time_fastest else (T, 4, B, S), device=theta.device, dtype=torch.float32)
+                 if (want_xpred or time_fastest) else None)
         logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
         rc = _launch("ode_fwd", lambda: hip.lib().vihds_ode_fwd(
             ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
             hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred), hip.ptr(logp), hip.current_stream()))
         hip.check(rc, "vihds_ode_fwd")
-        ctx.spec, ctx.prob = spec, prob
+        ctx.spec, ctx.prob, ctx.time_fastest = spec, prob, time_fastest
         ctx.row_offset_map = row_offset_map if row_offset is not None else None
         ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
         ctx.set_materialize_grads(False)
+        if time_fastest:
+            return traj.permute(3, 2, 0, 1), xpred.permute(3, 2, 0, 1), logp
         return traj, xpred, logp
 
     @staticmethod
@@ -215,7 +221,11 @@ class OdeSolveObserve(torch.autograd.Function):
         else:
             prob.logp_grad_broadcast = 0
             g_logp = _c(g_logp)
-        g_traj, g_xpred = _c(g_traj), _c(g_xpred)
+        if ctx.time_fastest:  # upstream gradients arrive shaped [T,.,B,S]: the kernels read them as [B][S][.][T]
+            g_traj = None if g_traj is None else g_traj.permute(2, 3, 1, 0).contiguous()
+            g_xpred = None if g_xpred is None else g_xpred.permute(2, 3, 1, 0).contiguous()
+        else:
+            g_traj, g_xpred = _c(g_traj), _c(g_xpred)
         aux = torch.empty(n_aux, device=theta.device, dtype=torch.float32) if n_aux > 0 else None
         rc = _launch("ode_bwd", lambda: hip.lib().vihds_ode_bwd(
             ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
