@@ -394,7 +394,7 @@ __host__ __device__ inline size_t relay_scan_bwd_lds_floats(int T) {
 }
 
 template <class LM, bool PREC, int SOLVER>
-__global__ void __launch_bounds__(RS_T) relay_scan_bwd_kernel(OdeArgs a) {
+__global__ void __launch_bounds__(RS_T, 2) relay_scan_bwd_kernel(OdeArgs a) {
   using S_ = Rs<LM, PREC, SOLVER>;
   using M = typename LM::M;
   using R = Rk<SOLVER>;
@@ -716,7 +716,7 @@ __global__ void __launch_bounds__(RS_T) relay_scan_bwd_kernel(OdeArgs a) {
 
 // ---- weight gradients of the precision network -------------------------------------------------------------------------
 template <class LM, int SOLVER>
-__global__ void __launch_bounds__(RS_T) relay_scan_wgrad_kernel(OdeArgs a) {
+__global__ void __launch_bounds__(RS_T, 2) relay_scan_wgrad_kernel(OdeArgs a) {
   using S_ = Rs<LM, true, SOLVER>;
   using R = Rk<SOLVER>;
   constexpr int NSP = S_::NSP, N = S_::N, NS = S_::NS, NIN = S_::NIN, NWROW = rl_nwrow(NIN), NWG = rl_nwg(NIN);
