@@ -591,6 +591,33 @@ def unchanged_spec_leg(a, dev, min_seconds):
                        "launch": "eager, host-drawn normals uploaded per step, loss read on the host after every step"}}
 
 
+def distributed_path_leg(a, plain_ms):
+    """The headline workload as a ONE-rank job through the distributed path (torch.distributed over RCCL, RowReplica: the
+    gradient all-reduce, the captured step with the collective inside the graph or cut at it) next to the plain one-process
+    number: what the multi-GPU machinery costs per step before any wire latency.  A child process (its own communicator)."""
+    import socket
+    import subprocess
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+               VIHDS_FORCE_DIST="1")
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2000", "--warmup", "200", "--no-cpu-baseline",
+           "--no-other-configs", "--no-strong-leg", "--roofline-steps", "0", "--seed", str(a.seed), "--lr", str(a.lr)]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    if out.returncode != 0 or not line:
+        return {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
+    d = json.loads(line[-1])
+    keep = {k: d.get(k) for k in ("value", "ms_per_step", "steps", "launch", "world_size", "dist_backend",
+                                  "collectives_in_graph", "steps_per_graph_launch")}
+    keep["overhead_us_per_step_vs_plain"] = 1e3 * (d["ms_per_step"] - plain_ms)
+    keep["ratio_to_plain"] = plain_ms / d["ms_per_step"]
+    return keep
+
+
 def other_config_legs(a, dev):
     """The other single-GPU BASELINE configurations and the unchanged-spec path, each timed for >= --leg-seconds inside the
     driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
@@ -615,6 +642,16 @@ def other_config_legs(a, dev):
         legs["unchanged_spec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     legs["unchanged_spec"]["leg_wall_s"] = time.perf_counter() - t0
     return legs
+
+
+def distributed_leg_guarded(a, plain_ms):
+    t0 = time.perf_counter()
+    try:
+        leg = distributed_path_leg(a, plain_ms)
+    except BaseException as exc:  # noqa: BLE001
+        leg = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    leg["leg_wall_s"] = time.perf_counter() - t0
+    return leg
 
 
 def issue_bound(kernel_name, mean_us):
@@ -752,7 +789,11 @@ def main():
     # steps per graph launch: between two graph launches the GPU idles 6-8 us (measured: rocprofv3 kernel trace), so the
     # resident-batch replay captures G consecutive steps per graph; K timed steps = K // G launches of that graph plus
     # K % G launches of the one-step graph -- exactly K optimizer steps either way
-    G = max(1, a.steps_per_graph) if (use_graph and not multi) else 1
+    # (several ranks: only data-parallel replicas, and only when the communicator records into the capture -- the gradient
+    # all-reduce then sits inside the graph between the step's kernels; the sample-sharded step keeps one step per graph)
+    G = 1
+    if use_graph and (not multi or (replica is not None and parallel.collectives_capturable(replica.group))):
+        G = max(1, a.steps_per_graph)
 
     def run_steps(k):
         out = None
@@ -830,7 +871,9 @@ def main():
                               "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "launch": launch_mode,
                               "final_loss": final_loss, "world_size": world, "rank_devices": rank_devices,
                               "value_long": long_run["value"] if long_run else None,
-                              "strong_scaling_config3": strong, "scaling": "weak",
+                              "strong_scaling_config3": strong, "scaling": "weak", "steps_per_graph_launch": G,
+                              "dist_backend": torch.distributed.get_backend() if multi else None,
+                              "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None,
                               "note": "roofline leg skipped (--roofline-steps 0)"}))
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
@@ -936,6 +979,8 @@ def main():
                    "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "steps_per_graph_launch": G, "learning_rate": a.lr,
                    "world_size": torch.distributed.get_world_size() if multi else 1, "rank_devices": rank_devices,
+                   "dist_backend": torch.distributed.get_backend() if multi else None,
+                   "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None,
                    "batch_staging": "the batch is resident in HBM; its staging copies and delta_obs (reference "
                                     "encoders.py:385) are outside the replayed step",
                    "ode": "vihds_ode_fwd + vihds_ode_bwd" if a.two_kernel_ode else "vihds_theta_ode_logp_grad (sampling + conditioning + ODE + adjoint in one launch)", "tail": "loss + backward + Adam: five launches" if (a.no_step_tail or multi) else "vihds_step_tail (IWAE loss + theta adjoint + encoder adjoint + Adam in two launches)", "u_rng": "host numpy" if a.host_rng else ("in-kernel philox" if a.device_rng == "kernel" else "torch device philox"),
@@ -953,6 +998,7 @@ def main():
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
         out["other_configs"] = other_config_legs(a, dev)
+        out["other_configs"]["distributed_path_world1"] = distributed_leg_guarded(a, out["ms_per_step"])
     print(json.dumps(out))
 
 

@@ -457,6 +457,56 @@ def test_two_replicas_row_data_parallel_plumbing():
     assert all(np.isfinite(diff)) and min(diff[-5:]) < diff[0]
 
 
+def test_one_rank_rccl_job_with_the_collective_inside_the_graph():
+    """The multi-GPU path on the one GPU of the test box: a ONE-rank job over RCCL (VIHDS_FORCE_DIST=1: communicator,
+    RowReplica, gradient all-reduce) must walk the single-process loss trajectory -- eagerly, with one step per captured
+    graph and with four steps per graph launch, which needs the all-reduce recorded INSIDE the hipGraph
+    (parallel.collectives_capturable: probed in a child process; where the stack cannot, the step is cut at the collective
+    and `graph4` is refused -- then this test checks the refusal instead)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    worker = os.path.join(os.path.dirname(os.path.abspath(__file__)), "two_rank_worker.py")
+
+    def run(mode, steps, dist):
+        env = dict(os.environ)
+        for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "VIHDS_DIST_BACKEND"):
+            env.pop(k, None)
+        if dist:
+            s = socket.socket()
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+            s.close()
+            env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                       VIHDS_FORCE_DIST="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+        out = subprocess.run([sys.executable, worker, mode, str(steps), "16"], env=env, capture_output=True, text=True, timeout=900)
+        return out
+
+    def losses(out):
+        assert out.returncode == 0, out.stderr[-3000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("LOSSES ")][-1]
+        cap = [ln for ln in out.stdout.splitlines() if ln.startswith("CAPTURED ")][-1]
+        return json.loads(line[len("LOSSES "):]), int(cap.split()[1])
+
+    single, _ = losses(run("eager", 8, False))
+    eager, _ = losses(run("dp-same-eager", 8, True))
+    graph, captured = losses(run("dp-same-graph", 8, True))
+    for a, b in zip(single, eager):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (single, eager)
+    for a, b in zip(eager, graph):
+        assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (eager, graph)
+    out4 = run("dp-same-graph4", 8, True)
+    if captured:
+        g4, cap4 = losses(out4)
+        assert cap4 == 1
+        for a, b in zip(eager, g4):
+            assert abs(a - b) <= 2e-4 * max(1.0, abs(a)), (eager, g4)
+    else:
+        assert out4.returncode != 0 and "collectives inside the graph" in out4.stderr
+
+
 @pytest.mark.parametrize("tail", [False, True])
 @pytest.mark.parametrize("solver", ["rk4", "modeuler"])
 def test_headline_decoder_launch_matches_oracle_at_bench_shape(solver, tail):

@@ -26,12 +26,20 @@ def main():
     args, settings, data, parameters, model, training = synthetic.build(
         "dr_constant_icml", 12, s_total, solver="midpoint", device=dev, seed=5, shard=shard, replica=replica,
         replica_same_data=same, u_rng="kernel",
-        conditioner_rng="kernel", hip_graph=(mode == "graph"), nan_check_every=0, fused_ode_training=True)
+        conditioner_rng="kernel", hip_graph=(mode in ("graph", "graph4")), nan_check_every=0, fused_ode_training=True)
     model.train()
     batch = training.train_data
-    step = training.graph_step if mode == "graph" else training.step
-    losses = [float(step(batch)) for _ in range(steps)]
+    if mode == "graph4":  # four consecutive steps per graph launch (multi-rank: needs the collectives inside the graph)
+        training.use_graph = True
+        losses = []
+        for _ in range(steps // 4):
+            training.graph_step(batch, repeat=4)
+            losses += [float(x) for x in training.last_losses]
+    else:
+        step = training.graph_step if mode == "graph" else training.step
+        losses = [float(step(batch)) for _ in range(steps)]
     if rank == 0:
+        print("CAPTURED %d" % int(bool(getattr(training, "collectives_captured", False))), flush=True)
         print("LOSSES " + json.dumps(losses), flush=True)
     if shard is not None or replica is not None:
         torch.distributed.barrier()

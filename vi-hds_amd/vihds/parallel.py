@@ -83,9 +83,81 @@ class SegmentedGraph(object):
         return self.result
 
 
+# ---- collectives INSIDE the captured step ------------------------------------------------------------------------
+# RCCL (torch's "nccl" backend on ROCm) can record its kernels into a stream capture; whether THIS software stack does is
+# found out once, in a throw-away child process (a capture that fails cannot be undone in the process it failed in): a
+# one-rank communicator on this GPU, one all_reduce and one all_gather_into_tensor captured into a hipGraph, replayed and
+# checked.  VIHDS_CAPTURE_COLLECTIVES=0 / 1 overrides the probe; gloo (the CPU-side test backend) is never captured.
+_CAPTURABLE = None
+_PROBE = r"""
+import os, sys, torch, torch.distributed as dist
+dev = int(sys.argv[1]); port = sys.argv[2]
+torch.cuda.set_device(dev)
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, rank=0, world_size=1)
+x = torch.ones(4096, device="cuda"); y = torch.empty(4096, device="cuda"); z = torch.arange(8, device="cuda", dtype=torch.float32)
+dist.all_reduce(x); dist.all_gather_into_tensor(y[:8], z)   # communicator set-up outside the capture
+torch.cuda.synchronize()
+g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
+with torch.cuda.stream(s):
+    g.capture_begin(capture_error_mode="thread_local")
+    x.mul_(2.0); dist.all_reduce(x); dist.all_gather_into_tensor(y[:8], z); x.add_(1.0)
+    g.capture_end()
+torch.cuda.current_stream().wait_stream(s)
+x.fill_(1.0); g.replay(); g.replay(); torch.cuda.synchronize()
+ok = bool((x == 7.0).all()) and bool((y[:8] == z).all())
+dist.destroy_process_group()
+print("VIHDS_CAPTURE_PROBE", "ok" if ok else "wrong")
+"""
+
+
+def collectives_capturable(group=None):
+    """True when the step's collectives may be recorded inside ONE hipGraph with the kernels around them (then a
+    multi-rank step is one graph launch, several steps per launch included); False: the step is cut at its collectives
+    (SegmentedGraph).  Every rank asks rank 0's answer, so all of them capture the same way."""
+    global _CAPTURABLE
+    if _CAPTURABLE is not None:
+        return _CAPTURABLE
+    env = os.environ.get("VIHDS_CAPTURE_COLLECTIVES", "").strip()
+    ans = None
+    if env in ("0", "1"):
+        ans = env == "1"
+    elif not dist.is_initialized() or dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
+        ans = False
+    if ans is None:
+        flag = torch.zeros(1, device="cuda")
+        if dist.get_rank(group) == 0:
+            flag[0] = 1.0 if _probe_capture() else 0.0
+        dist.broadcast(flag, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        ans = bool(flag.item() > 0)
+    _CAPTURABLE = ans
+    return ans
+
+
+def _probe_capture(timeout=180):
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
+              "TORCHELASTIC_RUN_ID"):
+        env.pop(k, None)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    try:
+        out = subprocess.run([sys.executable, "-c", _PROBE, str(torch.cuda.current_device()), str(port)], env=env,
+                             capture_output=True, text=True, timeout=timeout)
+    except Exception:  # noqa: BLE001 (a probe that hangs or cannot start means: do not capture)
+        return False
+    return out.returncode == 0 and "VIHDS_CAPTURE_PROBE ok" in out.stdout
+
+
 def graph_break(op):
     """Run `op` -- a collective over tensors whose addresses do not change between steps -- now; if a SegmentedGraph
-    is being captured, close the current segment before it and open the next one after it."""
+    is being captured, close the current segment before it and open the next one after it.  (Inside a plain hipGraph
+    capture -- collectives_capturable() -- the call is simply recorded with the rest.)"""
     seg = _ACTIVE_CAPTURE
     if seg is None:
         op()
@@ -121,8 +193,8 @@ def combine_row_lse(row_max, row_sumexp, group):
 def init_from_env(backend=None):
     """One process per GPU, launched by torch.distributed.run (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world == 1:
-        return None
+    if world == 1 and os.environ.get("VIHDS_FORCE_DIST") != "1":
+        return None  # (VIHDS_FORCE_DIST=1: a one-rank job through the distributed path -- communicator, collectives and all)
     if not dist.is_initialized():
         if backend is None:  # VIHDS_DIST_BACKEND=gloo lets the plumbing be exercised with several ranks on one GPU
             backend = os.environ.get("VIHDS_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")

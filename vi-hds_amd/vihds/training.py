@@ -145,6 +145,7 @@ class Training:
         if on_gpu:
             self.optimizer.gate = None
         self._graphs = {}
+        self.collectives_captured = False  # multi-rank captured steps: were the collectives recorded inside the graph?
         self._eval_graphs = {}
         # evaluation passes replayed from a hipGraph (with hip_graph; Training.evaluate)
         self.eval_graph = bool(default_get_value(p, "eval_graph", True))
@@ -484,9 +485,12 @@ class Training:
         if _warn is not None:
             _warn(False)
         try:
-            if self.shard is not None or self.replica is not None:  # cut the captured step at its collectives
+            sync = self.shard if self.shard is not None else self.replica
+            self.collectives_captured = sync is not None and parallel.collectives_capturable(sync.group)
+            if sync is not None and not self.collectives_captured:  # cut the captured step at its collectives
                 if len(segments) != 1:
-                    raise ValueError("several steps per graph are for single-process steps")
+                    raise ValueError("several steps per graph need the collectives inside the graph "
+                                     "(parallel.collectives_capturable())")
                 static, prologue = segments[0]
                 g = parallel.SegmentedGraph()
 
@@ -497,8 +501,10 @@ class Training:
 
                 loss = [g.capture(fn)]
             else:
+                # single process -- or several ranks whose communicator records into the capture: the collectives sit in
+                # the graph between the kernels they separate, one graph launch per `len(segments)` steps
                 g = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(g):
+                with torch.cuda.graph(g, **({"capture_error_mode": "thread_local"} if sync is not None else {})):
                     loss = []
                     for k, (static, prologue) in enumerate(segments):
                         if prologue is not None:
@@ -522,7 +528,10 @@ class Training:
         anyway.  Returns the loss of the last step; all of them are in self.last_losses."""
         repeat = int(repeat)
         if repeat > 1 and (self.shard is not None or self.replica is not None):
-            raise ValueError("graph_step(repeat > 1) is for single-process steps (the multi-rank step is cut at its collectives)")
+            sync = self.shard if self.shard is not None else self.replica
+            if not parallel.collectives_capturable(sync.group):
+                raise ValueError("graph_step(repeat > 1) with several ranks needs the collectives inside the graph "
+                                 "(parallel.collectives_capturable()); the segmented step is one step per replay")
         key = tuple(batch.observations.shape) + ((repeat,) if repeat > 1 else ())
         if key not in self._graphs:
             static = attrify({k: (v.clone(memory_format=torch.contiguous_format) if isinstance(v, torch.Tensor) else v)
