@@ -157,6 +157,26 @@ int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p);
  * [4][B][S]. */
 int vihds_ode_traj_layout(const vihds_ode_problem* p);
 
+/* torchdiffeq==0.1's adaptive algorithm ITSELF, resident on the device (round 4; reference call site vihds/ode.py:79-81,
+ * `odeint(func, y0, t, method="dopri5" | "bosh3" | "adaptive_heun")`; csrc/vihds_rk_adaptive_device.hpp): one persistent launch
+ * holds the step size and the accept / reject decisions in device memory (one grid barrier per trial step, no host round trip:
+ * asynchronous on `stream` and hipGraph-capturable), steps are NOT shortened to hit output times -- every output time is
+ * evaluated from the quartic interpolant (interp._interp_fit) of the accepted step that contains it -- and the accepted steps
+ * (start time, size, state) are logged in `workspace` for vihds_ode_adaptive_bwd, the discrete adjoint of exactly that
+ * computation with the step sizes held constant.  Models without shared neural weights, at most 65 536 trajectories;
+ * VIHDS_E_UNSUPPORTED otherwise (then: vihds_ode_adaptive_grid below).
+ *   times: [T] on the DEVICE.  traj: [T][N][B][S], the solution at the output times.  g_traj: its upstream gradient.
+ *   workspace: vihds_ode_adaptive_tape_floats(p, max_steps) floats; its first 32-bit words after the launch:
+ *   [1] error (0 ok, 1 barrier time-out, 2 more than max_steps accepted steps, 3 step-size underflow, 4 non-finite error
+ *   estimate), [2] accepted steps, [3] rejected steps. */
+long long vihds_ode_adaptive_tape_floats(const vihds_ode_problem* p, int max_steps);
+int vihds_ode_adaptive_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                           const float* times, float rtol, float atol, int max_steps, float* workspace, float* traj,
+                           void* stream);
+int vihds_ode_adaptive_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                           const float* times, int max_steps, const float* workspace, const float* g_traj, float* g_theta,
+                           void* stream);
+
 /* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN / DOPRI8; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
  * odeint / odeint_adjoint, absent from the tree: restated, parity unpinned).  Step-size controller, SYNCHRONOUS on
  * `stream` (one device round trip per trial step): walks the whole batch from times_host[0] to times_host[T-1] with ONE

@@ -20,6 +20,7 @@
 
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
+thread_local AdaptiveDevCtl* g_adaptive_dev = nullptr;
 // per-model translation units (ode_<model>.hip)
 #define VIHDS_DECL(name)                                                        \
   int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
@@ -516,6 +517,53 @@ int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, cons
   if (rc) return fail(rc, "adaptive step controller failed");
   if (int h = check_hip("vihds_ode_adaptive_grid")) return h;
   return ctl.result;
+}
+
+// ---- torchdiffeq's adaptive algorithm on the device (csrc/vihds_rk_adaptive_device.hpp) -------------------------------------
+static bool adaptive_device_model(const vihds_ode_problem* p, const ModelEntry* e) {
+  return e && !e->neural_prec && p->solver >= VIHDS_SOLVER_DOPRI5 && p->solver <= VIHDS_SOLVER_ADAPTIVE_HEUN &&
+         (long long)p->B * p->S <= (long long)ADP_MAX_BLOCKS * ADP_BLOCK;
+}
+long long vihds_ode_adaptive_tape_floats(const vihds_ode_problem* p, int max_steps) {
+  if (!p || max_steps < 1) return VIHDS_E_BADARG;
+  const ModelEntry* e = entry(p->model);
+  if (!adaptive_device_model(p, e)) return VIHDS_E_UNSUPPORTED;
+  const int n = p->B * p->S, nblk = (n + ADP_BLOCK - 1) / ADP_BLOCK;
+  return (long long)AdaptiveLayout(nblk, max_steps, p->T, e->n_states(), (size_t)n).total;
+}
+static int adaptive_device_call(int mode, const vihds_ode_problem* p, const float* theta, const float* cond,
+                                const float* dev1hot, const float* times, float rtol, float atol, int max_steps,
+                                float* workspace, float* traj, const float* g_traj, float* g_theta, void* stream) {
+  if (!p || !theta || !times || !workspace || max_steps < 1) return fail(VIHDS_E_BADARG, "null problem/theta/times/workspace");
+  const ModelEntry* e = entry(p->model);
+  if (!adaptive_device_model(p, e))
+    return fail(VIHDS_E_UNSUPPORTED, "device-resident adaptive solver: dopri5 / bosh3 / adaptive_heun on a model without shared "
+                                     "neural weights, at most 65 536 trajectories (use vihds_ode_adaptive_grid otherwise)");
+  OdeArgs a;
+  int rc = build_args(p, e, a, nullptr);
+  if (rc) return rc;
+  if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times;
+  a.traj = traj; a.g_traj = g_traj; a.g_theta = g_theta;
+  AdaptiveDevCtl ctl = {mode, {workspace, rtol, atol, max_steps}, 0};
+  g_adaptive_dev = &ctl;
+  rc = e->launch(mode == 2, p->solver, a, (hipStream_t)stream);
+  g_adaptive_dev = nullptr;
+  if (rc) return fail(rc, "device-resident adaptive solver: not available for this model / solver");
+  return check_hip(mode == 1 ? "vihds_ode_adaptive_fwd launch" : "vihds_ode_adaptive_bwd launch");
+}
+int vihds_ode_adaptive_fwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                           const float* times, float rtol, float atol, int max_steps, float* workspace, float* traj,
+                           void* stream) {
+  if (!traj) return fail(VIHDS_E_BADARG, "null traj");
+  return adaptive_device_call(1, p, theta, cond, dev1hot, times, rtol, atol, max_steps, workspace, traj, nullptr, nullptr, stream);
+}
+int vihds_ode_adaptive_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                           const float* times, int max_steps, const float* workspace, const float* g_traj, float* g_theta,
+                           void* stream) {
+  if (!g_theta) return fail(VIHDS_E_BADARG, "null g_theta");
+  return adaptive_device_call(2, p, theta, cond, dev1hot, times, 0.f, 0.f, max_steps, const_cast<float*>(workspace), nullptr,
+                              g_traj, g_theta, stream);
 }
 
 int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,

@@ -528,8 +528,16 @@ constexpr int kOnlySolver = -1;
 template <int ONLY>
 constexpr bool solver_built_in(int sv) { return ONLY < 0 || sv == ONLY; }
 
+}  // namespace vihds
+#include "vihds_rk_adaptive_device.hpp"
+namespace vihds {
+
 template <class M, int ONLY = kOnlySolver>
 inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  if (AdaptiveDevCtl* dc = g_adaptive_dev) {  // vihds_ode_adaptive_fwd / _bwd: the device-resident controller and its adjoint
+    dc->result = adaptive_device<M, ONLY>(solver, a, *dc, st);
+    return dc->result;
+  }
   if (AdaptiveCtl* ctl = g_adaptive_ctl) {
     ctl->result = adaptive_grid<M, ONLY>(solver, a, ctl->times_host, ctl->rtol, ctl->atol, ctl->workspace, ctl->grid_host,
                                    ctl->max_grid, ctl->index_host, st);

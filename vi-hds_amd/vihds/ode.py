@@ -251,6 +251,13 @@ class OdeModel(nn.Module):
         # all arithmetic is fp32, so tolerances near its epsilon (torchdiffeq's defaults 1e-7 / 1e-9 with a low-order pair
         # such as adaptive_heun) ask for step sizes the state cannot resolve
         max_grid = int(default_get_value(config.params, "solver_max_grid", 4096))
+        # torchdiffeq's own algorithm, resident on the device (round 4): steps run past the output times, outputs come from
+        # the accepted step's quartic interpolant, the adjoint walks the logged accepted steps -- models without shared
+        # neural weights; params.adaptive_device: false keeps the clipped-grid controller below for them too
+        B, S = packed.shape[1], packed.shape[2]
+        if (weights is None and bool(default_get_value(config.params, "adaptive_device", True))
+                and ops.adaptive_device_supported(spec, B, S, int(times.shape[0]), max_grid) is not None):
+            return self._solve_adaptive_device(config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_grid)
         while True:
             try:
                 grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol, max_grid=max_grid)
@@ -283,6 +290,38 @@ class OdeModel(nn.Module):
         else:
             logp = torch.zeros((4,) + tuple(packed.shape[1:]), device=dev)
         self._last = DecodedSolution(traj, xpred, logp)
+        self._last.has_logp = observations is not None
+        return self._last
+
+    def _solve_adaptive_device(self, config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_steps):
+        """ops.AdaptiveOdeSolve + the observation map and the Gaussian log-likelihood with torch ops on the solution at the
+        output times (autograd hands the adjoint kernel the upstream gradient of the trajectory)."""
+        check = bool(default_get_value(config.params, "adaptive_check", True))  # False: no synchronisation (capturable)
+        stats = [0, 0, 0]
+        while True:
+            try:
+                traj = ops.AdaptiveOdeSolve.apply(spec, packed, cond, times, d1, rtol, atol, max_steps, check, stats)
+                break
+            except ops.GridOverflow as e:
+                if max_steps >= (1 << 17):
+                    raise RuntimeError(
+                        "solver %r with rtol=%g, atol=%g needs more than %d accepted steps on this batch: in fp32 a relative "
+                        "tolerance below ~1e-6 is at rounding level for a low-order pair -- raise params.solver_rtol / "
+                        "solver_atol (or params.solver_max_grid)" % (config.params.solver, rtol, atol, max_steps)) from e
+                max_steps *= 4
+        self.last_adaptive_stats = {"accepted": stats[1], "rejected": stats[2]}
+        self.last_adaptive_grid = None
+        sol = traj.permute(2, 3, 1, 0)                               # [B,S,N,T]
+        xpred = self._observe_map(sol).permute(3, 2, 0, 1)           # [T,4,B,S]
+        dev = packed.device
+        if observations is not None:
+            rows = [row_of[n] for n in spec.slots[-4:]]              # constant precisions (reference precisions.py:31-35)
+            prec = packed[rows][None]
+            err = xpred - observations.to(dev).permute(2, 1, 0)[:, :, :, None]
+            logp = (-0.5 * (math.log(2 * math.pi) - torch.log(prec) + prec * err * err)).sum(0)  # training.py:24-44
+        else:
+            logp = torch.zeros((4,) + tuple(packed.shape[1:]), device=dev)
+        self._last = DecodedSolution(traj, xpred.contiguous(), logp)
         self._last.has_logp = observations is not None
         return self._last
 

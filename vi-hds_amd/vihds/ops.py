@@ -150,6 +150,71 @@ def adaptive_grid(spec, theta, cond, times, dev1hot, weights, rtol=1e-7, atol=1e
     return grid[:rc].to(theta.device), index.to(theta.device, torch.int64)
 
 
+class GridOverflow(RuntimeError):
+    """The adaptive controller accepted more steps than its buffer holds (raise solver_max_grid or the tolerances)."""
+
+
+ADAPTIVE_DEVICE_ERRORS = {1: "the grid barrier timed out", 2: "more accepted steps than params.solver_max_grid",
+                          3: "step-size underflow", 4: "non-finite error estimate"}
+
+
+def adaptive_device_supported(spec, B, S, T, max_steps):
+    """Floats of the tape vihds_ode_adaptive_fwd needs, or None when the device-resident solver does not serve this
+    problem (shared neural weights, dopri8, more than 65 536 trajectories)."""
+    n = hip.lib().vihds_ode_adaptive_tape_floats(ctypes.byref(spec.bind(B, S, T)), int(max_steps))
+    return int(n) if n > 0 else None
+
+
+class AdaptiveOdeSolve(torch.autograd.Function):
+    """torchdiffeq 0.1's adaptive-step algorithm on the device (vihds_ode_adaptive_fwd / _bwd): one persistent launch
+    forward, one launch for the discrete adjoint over the logged accepted steps.  forward(theta [R,B,S], cond, times [T]) ->
+    traj [T,N,B,S] (the solution at the output times; steps run past them, outputs come from the accepted step's quartic
+    interpolant).  `stats` (host ints [error, accepted, rejected]) is filled when check=True, which synchronises; with
+    check=False nothing waits and the pair of launches can be captured in a hipGraph."""
+
+    @staticmethod
+    def forward(ctx, spec, theta, cond, times, dev1hot, rtol, atol, max_steps, check, stats):
+        _require_cuda(theta, cond, times)
+        theta, cond, times = _c(theta), _c(cond), _c(times.to(torch.float32))
+        R, B, S = theta.shape
+        T = times.shape[0]
+        prob = spec.bind(B, S, T)
+        n_ws = hip.lib().vihds_ode_adaptive_tape_floats(ctypes.byref(prob), int(max_steps))
+        if n_ws <= 0:
+            hip.check(int(n_ws), "vihds_ode_adaptive_tape_floats")
+        ws = torch.empty(int(n_ws), device=theta.device, dtype=torch.float32)
+        traj = torch.empty((T, spec.n_states, B, S), device=theta.device, dtype=torch.float32)
+        rc = _launch("ode_adaptive_fwd", lambda: hip.lib().vihds_ode_adaptive_fwd(
+            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), float(rtol), float(atol),
+            int(max_steps), hip.ptr(ws), hip.ptr(traj), hip.current_stream()))
+        hip.check(rc, "vihds_ode_adaptive_fwd")
+        if check:
+            err, acc, rej = (int(v) for v in ws[:4].view(torch.int32)[1:4].tolist())
+            if stats is not None:
+                stats[:] = [err, acc, rej]
+            if err == 2:
+                raise GridOverflow("adaptive solver '%s': more than %d accepted steps" % (spec.solver, max_steps))
+            if err != 0:
+                raise RuntimeError("adaptive solver '%s' failed on the device: %s" % (spec.solver, ADAPTIVE_DEVICE_ERRORS.get(err, err)))
+        ctx.spec, ctx.prob, ctx.max_steps = spec, prob, int(max_steps)
+        ctx.save_for_backward(theta, cond, times, dev1hot, ws)
+        ctx.set_materialize_grads(False)
+        return traj
+
+    @staticmethod
+    def backward(ctx, g_traj):
+        theta, cond, times, dev1hot, ws = ctx.saved_tensors
+        g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
+        if g_traj is None:
+            return (None, torch.zeros_like(theta)) + (None,) * 8
+        g_traj = _c(g_traj)
+        rc = _launch("ode_adaptive_bwd", lambda: hip.lib().vihds_ode_adaptive_bwd(
+            ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), ctx.max_steps,
+            hip.ptr(ws), hip.ptr(g_traj), hip.ptr(g_theta), hip.current_stream()))
+        hip.check(rc, "vihds_ode_adaptive_bwd")
+        return (None, g_theta) + (None,) * 8
+
+
 class OdeSolveObserve(torch.autograd.Function):
     """simulate + observe + Gaussian log-likelihood in one kernel; adjoint in one kernel.
 
