@@ -296,15 +296,23 @@ def test_training_run_tracks_reference_trace(name, tmp_path, monkeypatch):
     model = build_model(args, settings, data, parameters)
     training = Training(args, settings, data, parameters, model)
     losses = []
-    orig = training.cost
+    orig = training.step_rows
 
-    def recording_cost(*a, **k):
-        out = orig(*a, **k)
-        if not k.get("full_output", False):
-            losses.append(float(out.elbo))
+    def recording_step(rows):  # (run() replays its steps from hipGraphs by default: the loss is what a step hands back)
+        out = orig(rows)
+        losses.append(float(out))
         return out
 
-    training.cost = recording_cost
+    training.step_rows = recording_step
+    orig_epoch = training.epoch_rows
+
+    def recording_epoch(batches):  # (an epoch of a single batch is one graph launch even with the per-step NaN check)
+        out = orig_epoch(batches)
+        losses.extend(float(v) for v in out)
+        return out
+
+    training.epoch_rows = recording_epoch
+    assert training.use_graph and settings.params.u_rng == "numpy" and settings.params.conditioner_rng == "cpu"
     monkeypatch.chdir(tmp_path)
     result = training.run()
     ref = z["step_losses"]

@@ -27,11 +27,17 @@ PARAM_DEFAULTS = {
     "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48):
                                # "cpu" (reference stream) | "device" (torch on the GPU) | "kernel" (in the kernel)
     "encoder_kernel": True,    # q(theta|data) encoder as fused HIP kernels on the GPU (False: nn.Conv1d / nn.Linear)
-    "fused_ode_training": False,  # training: log-likelihood + unit-weight adjoint in one launch, no trajectory written
-                               # (dr_constant family, lane-split regime; x_states / x_predict then exist on demand only)
+    "fused_ode_training": True,   # training: log-likelihood + unit-weight adjoint in one launch, no trajectory written
+                               # (dr_constant family; x_states / x_predict then exist on demand: whoever unpacks the decoder's
+                               # result gets them from the ordinary forward kernel).  Round 4: on by default -- it changes
+                               # no value a caller can observe, and with the two keys below it is most of the difference
+                               # between an unchanged reference spec and the fast path
     "fused_decoder_step": True,   # with fused_ode_training: sampling + device conditioning + ODE + adjoint in ONE launch
-    "fused_iwae_backward": False,  # with the two above: the IWAE loss is formed inside the theta-adjoint launch (its value exists after backward())
-    "hip_graph": False,        # capture the whole training step in a hipGraph
+    "fused_iwae_backward": True,   # with the two above, INSIDE Training.step only (which runs backward() itself): the IWAE loss is
+                               # formed inside the theta-adjoint launch; a caller of Training.cost gets the value at once
+    "fused_step_tail": True,   # Training.step: loss + backward + Adam as vihds_step_tail's two launches where it applies
+    "hip_graph": None,         # replay the training step / evaluation pass from a hipGraph: true | false | None = automatic (on the
+                               # GPU unless the solver is adaptive); host-side random streams are staged (vihds/hostdraws.py)
     "nan_check_every": 1,      # training.py:331 checks every step (a host sync); >1 defers the check
     "lazy_cache_dump": False,  # True: the best evaluation's Results are written to .vihds_cache once, when run() ends
     "eval_graph": True,        # with hip_graph: Training.evaluate replays the device side of an evaluation pass from a hipGraph

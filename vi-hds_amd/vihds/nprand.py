@@ -1,0 +1,58 @@
+"""numpy's legacy standard-normal stream from native code (csrc/host/vihds_nprand.cpp, libvihds_host.so): the SAME numbers
+`np.random.randn(...).astype(np.float32)` returns -- and the same global RandomState afterwards -- several times faster
+(MT19937 regenerated in vectorised runs, the polar method's attempts evaluated by a small thread pool).  The reference draws
+u ~ N(0,1)[B,S,P] on the host every step (vihds/vae.py:22-24); with `u_rng: numpy` (the default: the reference's stream)
+that draw was 25x the GPU's work for the step.
+
+This is host-side plumbing, not the hot path: when the library is missing the call falls back to numpy itself."""
+import ctypes
+import os
+
+import numpy as np
+
+_LIB = None
+_THREADS = int(os.environ.get("VIHDS_NPRAND_THREADS", str(min(8, os.cpu_count() or 1))))
+
+
+def _lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "lib", "libvihds_host.so")
+        try:
+            lib = ctypes.CDLL(path)
+            lib.vihds_np_randn_f32.restype = ctypes.c_int
+            lib.vihds_np_randn_f32.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
+                                               ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+            _LIB = lib
+        except OSError:
+            _LIB = False
+    return _LIB
+
+
+def available():
+    return bool(_lib())
+
+
+def randn_f32(shape, out=None):
+    """float32 array of `shape` drawn from numpy's GLOBAL RandomState exactly as np.random.randn(*shape).astype(np.float32)
+    draws it; `out`: a writable C-contiguous float32 buffer of that many elements (e.g. the numpy view of a pinned tensor)."""
+    shape = tuple(int(v) for v in shape)
+    n = int(np.prod(shape)) if shape else 1
+    lib = _lib()
+    if out is None:
+        out = np.empty(n, np.float32)
+    flat = out.reshape(-1)
+    if flat.dtype != np.float32 or flat.size != n or not flat.flags.c_contiguous:
+        raise ValueError("out must be a C-contiguous float32 buffer of %d elements" % n)
+    if not lib or n == 0:
+        flat[:] = np.random.randn(n).astype(np.float32) if n else 0
+        return out.reshape(shape)
+    name, key, pos, has_gauss, gauss = np.random.get_state()
+    key = np.ascontiguousarray(key, dtype=np.uint32).copy()
+    cpos, chg, cg = ctypes.c_int(int(pos)), ctypes.c_int(int(has_gauss)), ctypes.c_double(float(gauss))
+    rc = lib.vihds_np_randn_f32(key.ctypes.data, ctypes.byref(cpos), ctypes.byref(chg), ctypes.byref(cg), flat.ctypes.data, n,
+                                _THREADS)
+    if rc != 0:
+        raise RuntimeError("vihds_np_randn_f32 failed (%d)" % rc)
+    np.random.set_state((name, key, cpos.value, chg.value, cg.value))
+    return out.reshape(shape)

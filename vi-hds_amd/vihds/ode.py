@@ -154,7 +154,19 @@ class OdeModel(nn.Module):
         elif self.conditioner_rng == "device":
             z, mean, std = torch.randn((len(names), D), device=dev), 2.0, 1.5
         else:  # the reference's stream: a fresh DeviceConditioner per name, drawn on the host
-            z = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in names], 0).to(dev)
+            from vihds import hostdraws
+
+            def draw(host=None, k=len(names)):
+                w = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in range(k)], 0)
+                if host is None:
+                    return w
+                host[:] = w.reshape(-1).numpy()
+
+            if hostdraws.capturing():  # a captured step: drawn before every replay (vihds/hostdraws.py)
+                z = hostdraws.ACTIVE.add((len(names), D), dev, draw)
+            else:
+                hostdraws.note((len(names), D))
+                z = draw().to(dev)
             mean, std = 0.0, 1.0
         return rel, dflt, z, mean, std, rng_state
 
@@ -333,7 +345,7 @@ class OdeModel(nn.Module):
         import vihds.hip as hip
 
         if (observations is None or self.model_key not in self.fused_training_keys or not torch.is_grad_enabled()
-                or not default_get_value(config.params, "fused_ode_training", False)
+                or not default_get_value(config.params, "fused_ode_training", True)
                 or config.params.solver in hip.ADAPTIVE_SOLVERS):
             return None
         slots = self.kernel_slots()

@@ -14,7 +14,7 @@ import numpy as np
 import torch
 from torch.utils.data import DataLoader
 
-from vihds import ops, parallel
+from vihds import hostdraws, ops, parallel
 from vihds.encoders import LocalAndGlobal
 from vihds.utils import Results, TrainingLogData, attrify, default_get_value, variable_summaries
 
@@ -80,19 +80,22 @@ class Training:
         self.replica = getattr(model, "replica", None)  # parallel.RowReplica: gradients averaged over ranks
         p = settings.params
         on_gpu = settings.device.type == "cuda"
-        self.use_graph = bool(default_get_value(p, "hip_graph", False)) and on_gpu
+        # hip_graph: true / false, or (the default, None) automatic: on the GPU whenever the step holds no host round trip --
+        # i.e. not with an adaptive solver, whose controller reports back to the host.  Replaying the step changes no number;
+        # host-side random streams are fed through vihds/hostdraws.py
+        want_graph = default_get_value(p, "hip_graph", None)
+        if want_graph is None:
+            from vihds import hip as _hip
+
+            want_graph = p.solver not in _hip.ADAPTIVE_SOLVERS and os.environ.get("VIHDS_AUTO_GRAPH", "1") != "0"
+        self.use_graph = bool(want_graph) and on_gpu
+        self._pending_elbo = None
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
         # run(): with hip_graph, a single process and a NaN check at most once per epoch, an epoch is ONE graph launch
         self.epoch_graph = (self.use_graph and bool(default_get_value(p, "epoch_graph", True)) and self.shard is None
                             and self.replica is None)
-        if self.use_graph:
-            # a captured step replays whatever the capture recorded: host-side draws (numpy u, CPU conditioner
-            # weights) would be frozen into the graph or leave a stale host pointer behind
-            u_rng = default_get_value(p, "u_rng", "numpy")
-            c_rng = default_get_value(p, "conditioner_rng", "cpu")
-            if u_rng not in ("device", "kernel") or c_rng not in ("device", "kernel"):
-                raise ValueError("hip_graph: true needs device-side random numbers (u_rng and conditioner_rng in "
-                                 "{'device', 'kernel'}); got u_rng=%r, conditioner_rng=%r" % (u_rng, c_rng))
+        # (a captured step that keeps the reference's host-side streams -- u_rng: numpy, conditioner_rng: cpu, the defaults --
+        # reads the draws from static device buffers that are refreshed before every replay: vihds/hostdraws.py)
         # capturable Adam keeps step counts on the device => the whole step can live in one hipGraph
         self.lr = torch.tensor(float(p.learning_rate), device=settings.device) if self.use_graph else p.learning_rate
         # one launch for the whole update, step counter on the device (vihds/optim.py)
@@ -140,7 +143,7 @@ class Training:
         self.lazy_cache_dump = bool(default_get_value(p, "lazy_cache_dump", False))
         self._best_output = None
         # the step's tail (loss, backward, Adam) as two launches: vihds_step_tail (off by default: reference call sequence)
-        self.fused_tail = bool(default_get_value(p, "fused_step_tail", False)) and on_gpu
+        self.fused_tail = bool(default_get_value(p, "fused_step_tail", True)) and on_gpu
         self._tail, self._tail_ok, self._tail_shapes = None, False, {}
         if on_gpu:
             self.optimizer.gate = None
@@ -268,7 +271,7 @@ class Training:
         holder = staged["ring_refs"][k]() if staged["ring_refs"][k] is not None else None
         if holder is not None:
             holder.detach_host()
-        g.replay()
+        hostdraws.replay(g)
         ring[k].copy_(staged["flat"], non_blocking=True)
         out = Results()
         out.init_from_staged(self.model.decoder.state_names, staged, ring[k])
@@ -294,14 +297,27 @@ class Training:
         side = torch.cuda.Stream()
         snap = self._snapshot_training_state()
         side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(2):
-                self._evaluation_device_side(data, n_samples)
+        draws = hostdraws.HostDraws()
+        hostdraws.ACTIVE = draws  # (measuring what one pass draws on the host)
+        try:
+            with torch.cuda.stream(side):
+                for _ in range(2):
+                    draws.noted = 0
+                    self._evaluation_device_side(data, n_samples)
+        finally:
+            hostdraws.ACTIVE = None
         torch.cuda.current_stream().wait_stream(side)
         self._restore_training_state(snap)
+        if draws.noted:
+            draws.reserve(draws.noted, data.observations.device)
         g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            staged = self._evaluation_device_side(data, n_samples)
+        hostdraws.ACTIVE = draws
+        try:
+            with torch.cuda.graph(g):
+                staged = self._evaluation_device_side(data, n_samples)
+        finally:
+            hostdraws.ACTIVE = None
+        g.host_draws = draws
         n = staged["flat"].numel()
         staged["host_ring"] = [torch.empty(n, dtype=torch.float32, pin_memory=True) for _ in range(4)]
         staged["ring_refs"], staged["ring_pos"] = [None] * 4, 0
@@ -417,6 +433,10 @@ class Training:
         if flat:
             opt = {gi: {k: st[k].clone() for k in ("m", "v", "state")} for gi, st in flat.items()}
         rng = {id(t): t.clone() for t in self._rng_states()}
+        # the host-side streams too (numpy's global RandomState: u; torch's CPU generator: the conditioner's weights and the
+        # loader's shuffles): the warm-up steps of a capture must not consume draws the training run is entitled to
+        rng["__numpy__"] = np.random.get_state()
+        rng["__torch_cpu__"] = torch.get_rng_state()
         return params, opt, rng
 
     def _rng_states(self):
@@ -445,6 +465,9 @@ class Training:
                     else:  # the optimizer state was created by the warm-up: back to its initial value
                         for k in ("m", "v", "state"):
                             st[k].zero_()
+            if "__numpy__" in rng:
+                np.random.set_state(rng["__numpy__"])
+                torch.set_rng_state(rng["__torch_cpu__"])
             for t in self._rng_states():
                 if id(t) in rng:
                     t.copy_(rng[id(t)])
@@ -465,17 +488,28 @@ class Training:
         # it, so the warm-up steps (which run Adam and advance the generator states) are ordered after the copies
         snap = self._snapshot_training_state()
         s.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(s):
-            seen = set()
-            for static, prologue in segments:  # allocator warm-up, lazy initialisations, Adam state: once per batch shape
-                if id(static) in seen and prologue is None:
-                    continue
-                seen.add(id(static))
-                for _ in range(3):
-                    if prologue is not None:
-                        prologue()
-                    self.step(static)
+        draws = hostdraws.HostDraws()
+        per_static = {}
+        hostdraws.ACTIVE = draws  # (measuring: how many host-drawn numbers a step on each buffer set consumes)
+        try:
+            with torch.cuda.stream(s):
+                seen = set()
+                for static, prologue in segments:  # allocator warm-up, lazy initialisations, Adam state: once per batch shape
+                    if id(static) in seen and prologue is None:
+                        continue
+                    seen.add(id(static))
+                    for _ in range(3):
+                        if prologue is not None:
+                            prologue()
+                        draws.noted = 0
+                        self.step(static)
+                        per_static[id(static)] = draws.noted
+        finally:
+            hostdraws.ACTIVE = None
         torch.cuda.current_stream().wait_stream(s)
+        need = sum(per_static.get(id(static), 0) for static, _ in segments)
+        if need:
+            draws.reserve(need, self.train_data.observations.device)
         self._restore_training_state(snap)  # the warm-up steps must not count as training steps
         self.optimizer.zero_grad(set_to_none=True)
         # The parameters' AccumulateGrad nodes were created during the warm-up steps, on the side stream; the capture
@@ -484,6 +518,7 @@ class Training:
         _warn = getattr(torch.autograd.graph, "set_warn_on_accumulate_grad_stream_mismatch", None)
         if _warn is not None:
             _warn(False)
+        hostdraws.ACTIVE = draws
         try:
             sync = self.shard if self.shard is not None else self.replica
             self.collectives_captured = sync is not None and parallel.collectives_capturable(sync.group)
@@ -512,8 +547,10 @@ class Training:
                         # (every step but the last drops its gradients: left standing, autograd would ADD the next step's)
                         loss.append(self.step(static, zero_grad=k < len(segments) - 1))
         finally:
+            hostdraws.ACTIVE = None
             if _warn is not None:
                 _warn(True)  # only the capture itself is exempt, not the rest of the process
+        g.host_draws = draws
         return g, loss
 
     def graph_step(self, batch, repeat=1):
@@ -546,7 +583,7 @@ class Training:
                 static[k].copy_(batch[k], non_blocking=True)
             static["delta_obs"].copy_(_delta_obs(static.observations))
             self._staged[key] = batch
-        g.replay()
+        hostdraws.replay(g)
         if repeat > 1:
             self.last_losses = loss
             return loss[-1]
@@ -613,7 +650,7 @@ class Training:
                                  + (idx, self._IndexStaging(n)))
         g, static, loss, idx, staging = self._graphs[key]
         staging.upload(idx, lambda buf: buf.copy_(rows_host))
-        g.replay()
+        hostdraws.replay(g)
         return loss
 
     def epoch_rows(self, batches):
@@ -636,7 +673,7 @@ class Training:
             self._graphs[key] = self._capture_segments(segments) + (idx, self._IndexStaging(int(idx.shape[0])))
         g, losses, idx, staging = self._graphs[key]
         staging.upload(idx, lambda buf: torch.cat(list(batches), out=buf))
-        g.replay()
+        hostdraws.replay(g)
         return losses
 
     def _run_batch(self, epoch_start, batch, log_data):
@@ -649,7 +686,17 @@ class Training:
         else:
             elbo = self.graph_step(batch) if self.use_graph else self.step(batch)
         self._steps += 1
-        if self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and self._loss_is_nan(elbo):
+        if self.use_graph and self.nan_check_every == 1 and self.replica is None and self.shard is None:
+            # The reference looks at every step's ELBO (training.py:331), a device synchronisation per step.  With the step
+            # replayed from a graph the look is one step late: step k is queued -- its host-side draws included -- before the
+            # ELBO of step k-1 is read, so the host's work for the next step overlaps the GPU's for this one.  Every update
+            # is gated on its own loss on the device, so the parameters are those of the last finite step either way.
+            prev, self._pending_elbo = self._pending_elbo, elbo
+            if prev is not None and self._loss_is_nan(prev):
+                self._pending_elbo = None
+                print("Cannot proceed with ELBO = nan. Exiting.")
+                return False
+        elif self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and self._loss_is_nan(elbo):
             # (the reference aborts before backward / optimizer.step, training.py:331-334; here the step that produced the
             # NaN has already been launched -- the Adam launch is gated on the loss on the device (vihds_adam_step's
             # `gate`, vihds_step_tail's row check), so parameters, moments and the step count are those of the last
@@ -698,6 +745,11 @@ class Training:
             ELBOs, before anything else is launched -- every update is gated on its own loss on the device either way)."""
             nonlocal pending
             ok = True
+            if self._pending_elbo is not None:  # (the per-step check that runs one step late: _run_batch)
+                last, self._pending_elbo = self._pending_elbo, None
+                if self._loss_is_nan(last):
+                    print("Cannot proceed with ELBO = nan. Exiting.")
+                    ok = False
             if pending is not None and self.nan_check_every > 0:
                 if bool(torch.isnan(torch.stack([l.detach().reshape(()) for l in pending])).any()):
                     print("Cannot proceed with ELBO = nan. Exiting.")

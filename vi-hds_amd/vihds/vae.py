@@ -19,6 +19,7 @@ class BaseVAE(nn.Module):
         self.u_rng = u_rng
         self.shard = shard  # vihds.parallel.SampleShard or None
         self._rng_state = None
+        self._u_staging = {}
         self._fused_declined = {}
 
     def sample_u(self, n_batch, n_samples, device=None):
@@ -35,10 +36,33 @@ class BaseVAE(nn.Module):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
                 self._rng_state = ops.KernelNormal.new_state(seed, self.device)
             return ops.KernelNormal((n_batch, n_samples, self.n_theta), self._rng_state)
-        # (from_numpy: no host-side copy -- torch.tensor() of a 1 MB array goes through the intra-op thread pool, which
-        # costs ~25 ms per call on a 128-thread host)
-        u = torch.from_numpy(np.random.randn(n_batch, n_samples, self.n_theta).astype(np.float32))
-        return u.to(self.device, non_blocking=True)
+        # The reference's stream (np.random.randn of the global RandomState), bit for bit, from native code (vihds/nprand.py:
+        # 2.3 ms of numpy per draw at B=36, S=200 otherwise), straight into one of a few pinned staging buffers -- used in
+        # turn, each reused only after the copy that read it has run -- and on to the device without waiting.
+        from vihds import hostdraws, nprand
+
+        shape = (int(n_batch), int(n_samples), int(self.n_theta))
+        if hostdraws.capturing():  # a captured step: the draw happens before every replay (vihds/hostdraws.py)
+            return hostdraws.ACTIVE.add(shape, self.device, lambda host, sh=shape: nprand.randn_f32(sh, out=host))
+        hostdraws.note(shape)
+        if not (torch.cuda.is_available() and torch.device(self.device).type == "cuda"):
+            return torch.from_numpy(nprand.randn_f32(shape)).to(self.device)
+        n = shape[0] * shape[1] * shape[2]
+        ring = self._u_staging.get(n)
+        if ring is None:
+            ring = self._u_staging[n] = {"bufs": [torch.empty(n, dtype=torch.float32).pin_memory() for _ in range(4)],
+                                         "events": [None] * 4, "pos": 0}
+        k = ring["pos"]
+        ring["pos"] = (k + 1) % 4
+        if ring["events"][k] is not None:
+            ring["events"][k].synchronize()
+        host = ring["bufs"][k]
+        nprand.randn_f32(shape, out=host.numpy())
+        u = host.view(shape).to(self.device, non_blocking=True)
+        if ring["events"][k] is None:
+            ring["events"][k] = torch.cuda.Event()
+        ring["events"][k].record()
+        return u
 
     def forward(self, data, samples, writer=None, epoch=None):
         u = self.sample_u(len(data.inputs), samples)
@@ -71,7 +95,7 @@ def _bind_fused(BaseVAE):
         ode = dec.ode_model
         cfg = dec.config
         obs = data.get("observations", None) if hasattr(data, "get") else None
-        if (not torch.is_grad_enabled() or obs is None or not default_get_value(cfg.params, "fused_ode_training", False)
+        if (not torch.is_grad_enabled() or obs is None or not default_get_value(cfg.params, "fused_ode_training", True)
                 or not default_get_value(cfg.params, "fused_decoder_step", True) or ode.model_key not in ode.fused_training_keys or getattr(q, "_packed_q", None) is None
                 or not obs.is_cuda or (n_extra and not dec.condition_on_device)
                 or cfg.params.solver in hip.ADAPTIVE_SOLVERS):
@@ -112,7 +136,7 @@ def _bind_fused(BaseVAE):
             ode.aR, ode.aS = getattr(theta, "aR", None), getattr(theta, "aS", None)
         sol = LazySolution(logp, lambda: ode.solve(cfg, data.times, theta, data.inputs, data.dev_1hot, obs))
         # params.fused_iwae_backward: Training.cost may leave the IWAE loss to this step's theta-adjoint launch
-        sol.defer_iwae = bool(default_get_value(cfg.params, "fused_iwae_backward", False)) and self.shard is None
+        sol.defer_iwae = bool(default_get_value(cfg.params, "fused_iwae_backward", True)) and self.shard is None
         ode._last = sol
 
         def build():
