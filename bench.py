@@ -223,6 +223,7 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=
 
 
 # ---- the other BASELINE configurations: same JSON contract, `--workload NAME` ------------------------
+ISSUE_CYCLES_FULL_SIMD, ISSUE_CYCLES_TWO_WAVES = 3.0, 3.6  # measured: profiles/r04_issue_rate.log (see issue_bound)
 MFMA_F32_PEAK_TFLOPS = 157.3  # /opt/skills/guides/MI355X_MICROARCH.md: dense fp32 MFMA peak (no TF32 on gfx950)
 BLACKBOX_FLOP_PER_EVAL = 3390  # 2 (27 25 + 2 25 6) + 2 (28 20 + 2 20 4) per RHS evaluation and trajectory
 WORKLOAD_TABLE = {
@@ -567,7 +568,7 @@ def unchanged_spec_leg(a, dev, min_seconds):
     log = TrainingLogData()
 
     def step():  # the body of Training.run()'s loop for one resident batch: the step and the reference's per-step NaN check
-        if not training._run_batch(time.time(), batch, log):
+        if not training._run_batch(time.time(), batch, log, next_batch=batch):  # (the same resident batch follows)
             raise SystemExit("NaN objective in the unchanged-spec leg")
 
     for _ in range(5):
@@ -663,18 +664,24 @@ def distributed_leg_guarded(a, plain_ms):
 def issue_bound(kernel_name, mean_us):
     """HBM is demonstrably not what bounds the headline launch (measured traffic is ~10x below the algorithmic bytes: the
     trajectory stays in LDS), VALU issue is the nearer ceiling: instructions per launch (rocprofv3 --pmc SQ_INSTS_VALU, a pass
-    of its own; newest profiles/r*_pmc_valu.json holding this kernel) / 1024 SIMDs x the measured issue interval of a busy
-    SIMD (tests/micro/issue_rate.hip: one wavefront instruction per ~2.7 cycles with >= 4 wavefronts resident, 2.4 GHz)."""
+    of its own; newest profiles/r*_pmc_valu.json holding this kernel) / 1024 SIMDs x the measured issue interval of a SIMD.
+    ONE constant, measured (tests/micro/issue_rate.hip, output committed as profiles/r04_issue_rate.log; independent FMAs at
+    2.4 GHz): a SIMD retires one wavefront-instruction per 3.0 cycles with 4 wavefronts resident, per 3.6 cycles with 2, per
+    5.9 cycles with 1 (9.8 when each depends on the last).  `frac` uses the full-SIMD figure (3.0: the kernel's ceiling);
+    `frac_at_residency` the figure at the kernel's own two wavefronts per SIMD (3.6)."""
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")), reverse=True):
         ks = json.load(open(f))["kernels"]
         if kernel_name in ks:
             insts = ks[kernel_name]["SQ_INSTS_VALU"]
-            cyc, clk, simds = 2.7, 2.4e9, 1024
+            cyc, cyc2, clk, simds = ISSUE_CYCLES_FULL_SIMD, ISSUE_CYCLES_TWO_WAVES, 2.4e9, 1024
             t_us = insts / simds * cyc / clk * 1e6
             return {"valu_insts_per_launch": insts, "simds": simds, "cycles_per_inst": cyc, "clock_hz": clk,
-                    "issue_time_us": t_us, "frac": t_us / mean_us, "source": "profiles/" + os.path.basename(f),
+                    "issue_time_us": t_us, "frac": t_us / mean_us, "cycles_per_inst_at_two_waves_per_simd": cyc2,
+                    "frac_at_residency": insts / simds * cyc2 / clk * 1e6 / mean_us,
+                    "constants_source": "profiles/r04_issue_rate.log (tests/micro/issue_rate.hip)",
+                    "source": "profiles/" + os.path.basename(f),
                     "note": "fraction of the launch that pure VALU issue on all 1024 SIMDs would take: the kernel's distance "
                             "from its own (instruction-count) ceiling; the rest is serial phases and idle SIMDs"}
     return None

@@ -9,8 +9,8 @@
 TAG=$1; shift
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --no-cpu-baseline "$@" > $O/bench_stats.log 2>&1
-SHORT="--steps 20 --warmup 5 --eager --no-cpu-baseline --roofline-steps 2"
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats -o $TAG -- python $R/bench.py --no-cpu-baseline --no-other-configs "$@" > $O/bench_stats.log 2>&1
+SHORT="--steps 20 --warmup 5 --eager --no-cpu-baseline --no-other-configs --roofline-steps 2"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/fetch -o fetch -- python $R/bench.py $SHORT "$@" > $O/fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/write -o write -- python $R/bench.py $SHORT "$@" > $O/write.log 2>&1
 rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d $O/valu -o valu -- python $R/bench.py $SHORT "$@" > $O/valu.log 2>&1

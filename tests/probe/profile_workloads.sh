@@ -9,6 +9,15 @@ for W in config3_train config3_eval config4 config5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -o $W -- python $R/bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline > $O/stats_$W.log 2>&1
   cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
   rm -rf $O/stats_$W
+  # HBM traffic of the workload's kernels: FETCH_SIZE and WRITE_SIZE in two separate passes (round 4)
+  for C in FETCH_SIZE WRITE_SIZE; do
+    rocprofv3 --pmc $C --kernel-trace --output-format csv -d $O/pmc_${W}_$C -o pmc -- python $R/bench.py --workload $W --steps 10 --warmup 3 --eager --no-cpu-baseline --roofline-steps 4 > $O/pmc_${W}_$C.log 2>&1
+  done
+  F=$(find $O/pmc_${W}_FETCH_SIZE -name "*counter_collection.csv" | head -1); WR=$(find $O/pmc_${W}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+  head -1 $F > $O/${TAG}_${W}_pmc_fetch_counter_collection.csv; grep vihds $F >> $O/${TAG}_${W}_pmc_fetch_counter_collection.csv
+  head -1 $WR > $O/${TAG}_${W}_pmc_write_counter_collection.csv; grep vihds $WR >> $O/${TAG}_${W}_pmc_write_counter_collection.csv
+  (cd $R && python profiles/make_pmc_traffic.py $F $WR profiles/${TAG}_${W}_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload $W --steps 10 --warmup 3 --eager --no-cpu-baseline --roofline-steps 4" > $O/traffic_$W.log 2>&1; cp profiles/${TAG}_${W}_pmc_hbm_traffic.json $O/)
+  rm -rf $O/pmc_${W}_FETCH_SIZE $O/pmc_${W}_WRITE_SIZE
 done
 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o mfma -- python $R/bench.py --workload config4 --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4 > $O/mfma.log 2>&1
 F=$(find $O/mfma -name "*counter_collection.csv" | head -1)

@@ -221,3 +221,20 @@ def test_native_numpy_normal_stream_is_bit_identical():
         assert all(np.array_equal(a, b) and a.shape == b.shape for a, b in zip(ref, got))
         assert np.array_equal(mid_ref, mid) and np.array_equal(ref2, got2)
         assert np.array_equal(st_ref[1], st[1]) and st_ref[2:] == st[2:]
+    # consecutive even-sized draws take the in-place path (numpy's state read and advanced where it lives); a foreign draw
+    # in between, a re-seed and an odd size fall back to get_state / set_state -- the numbers must not care
+    np.random.seed(3)
+    ref = [np.random.randn(252).astype(np.float32), np.random.randn(1000).astype(np.float32), np.random.randn(3),
+           np.random.randn(64).astype(np.float32), np.random.randn(7).astype(np.float32), np.random.randn(8).astype(np.float32),
+           np.random.randn(8).astype(np.float32)]
+    st_ref = np.random.get_state()
+    np.random.seed(3)
+    got = [nprand.randn_f32((252,)), nprand.randn_f32((1000,)), np.random.randn(3), nprand.randn_f32((64,)),
+           nprand.randn_f32((7,)), nprand.randn_f32((8,)), nprand.randn_f32((8,))]
+    st = np.random.get_state()
+    assert all(np.array_equal(a, b) for a, b in zip(ref, got))
+    assert np.array_equal(st_ref[1], st[1]) and st_ref[2:] == st[2:]
+    np.random.seed(4)
+    a = np.random.randn(10).astype(np.float32)
+    np.random.seed(4)
+    assert np.array_equal(a, nprand.randn_f32((10,)))

@@ -114,15 +114,37 @@ class Pool {
   bool stop_ = false;
 };
 
+constexpr long long CH = 2048;  // attempts per chunk
+
 struct Buffers {  // kept between calls: fresh allocations of this size cost more in page faults than the arithmetic
-  std::vector<uint32_t> raw;
-  std::vector<long long> count;
-  std::vector<double> x1, x2, r2;  // per attempt (written by the vectorised first pass, read by the second)
+  std::vector<uint32_t> raw;       // raw generator states, block after block; block 0 = the caller's key
+  std::vector<long long> count;    // accepted attempts per chunk
+  std::vector<float> vals;         // per chunk: its accepted attempts' outputs in order (f x2, f x1), 2 CH floats
 };
 
 std::mutex g_lock;           // one call at a time (the pool and the buffers are shared)
 Pool* g_pool = nullptr;
 Buffers g_buf;
+
+inline void cpu_relax() {
+#if defined(__x86_64__)
+  __builtin_ia32_pause();
+#endif
+}
+
+// the attempts a0 .. a0 + CH of the stream whose word w is temper(raw[pos0 + w]): r2, x1, x2 (no branch, no call: vectorised)
+inline void chunk_attempts(const uint32_t* raw, long long pos0, long long a0, double* X1, double* X2, double* R2) {
+  const uint32_t* w = raw + pos0 + 4 * a0;
+  for (long long a = 0; a < CH; ++a) {
+    const uint32_t w0 = temper(w[4 * a]), w1 = temper(w[4 * a + 1]), w2 = temper(w[4 * a + 2]), w3 = temper(w[4 * a + 3]);
+    const double d1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
+    const double d2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
+    const double x1 = 2.0 * d1 - 1.0, x2 = 2.0 * d2 - 1.0;
+    X1[a] = x1;
+    X2[a] = x2;
+    R2[a] = x1 * x1 + x2 * x2;
+  }
+}
 
 }  // namespace
 
@@ -130,6 +152,11 @@ extern "C" {
 
 // out[0..n) <- what np.random.standard_normal(n).astype(np.float32) would return from the RandomState (key, pos, has_gauss,
 // gauss); the four are updated to the state numpy would be left in.  Returns 0, or -1 on bad arguments.
+//
+// One thread regenerates the generator's blocks in order and publishes how far it is; the others (and then that one too)
+// take chunks of 2048 attempts as soon as the blocks under them exist, evaluate them (a vectorised pass for x1, x2, r2, then
+// the accepted ones' sqrt(-2 log r2 / r2)) into the chunk's own buffer; a last pass copies the chunks' outputs to their
+// places (prefix sum over the chunks' counts).
 int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, float* out, long long n, int n_threads) {
   if (!key || !pos || !has_gauss || !gauss || !out || n < 0 || *pos < 0 || *pos > N) return -1;
   std::lock_guard<std::mutex> guard(g_lock);
@@ -148,104 +175,104 @@ int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, f
     g_pool = new Pool(n_threads - 1);
   }
   const int K = need_pairs < 4096 ? 1 : n_threads;
-  std::vector<uint32_t>& raw = g_buf.raw;  // raw states, block after block; block 0 = the caller's key
-  const int pos0 = *pos;
-  // word w of the stream (w = 0: the first unread word) is temper(raw[pos0 + w])
-  auto word = [&](long long w) { return temper(raw[(size_t)(pos0 + w)]); };
-  auto attempt = [&](long long a, double& x1, double& x2, double& r2) {
-    const uint32_t w0 = word(4 * a), w1 = word(4 * a + 1), w2 = word(4 * a + 2), w3 = word(4 * a + 3);
-    const double d1 = ((double)(w0 >> 5) * 67108864.0 + (double)(w1 >> 6)) / 9007199254740992.0;
-    const double d2 = ((double)(w2 >> 5) * 67108864.0 + (double)(w3 >> 6)) / 9007199254740992.0;
-    x1 = 2.0 * d1 - 1.0;
-    x2 = 2.0 * d2 - 1.0;
-    r2 = x1 * x1 + x2 * x2;
-    return !(r2 >= 1.0 || r2 == 0.0);
-  };
+  std::vector<uint32_t>& raw = g_buf.raw;
+  std::vector<long long>& count = g_buf.count;
+  std::vector<float>& vals = g_buf.vals;
+  const long long pos0 = *pos;
   raw.resize(N);
   std::memcpy(raw.data(), key, N * sizeof(uint32_t));
-  long long attempts_ready = 0, pairs_found = 0;
-  // chunks of attempts, each with its count of accepted ones; chunk boundaries fixed so that extensions append chunks
-  constexpr long long CH = 2048;
-  std::vector<long long>& count = g_buf.count;
   count.clear();
+  long long pairs_found = 0, chunks_done = 0, blocks_done = 1;
   while (pairs_found < need_pairs) {
-    const long long want_attempts = attempts_ready + (long long)((need_pairs - pairs_found) * 1.2732395447 * 1.02) + 64;
+    const long long want_attempts = chunks_done * CH + (long long)((need_pairs - pairs_found) * 1.2732395447 * 1.02) + 64;
     const long long want_chunks = (want_attempts + CH - 1) / CH;
-    const long long want_words = (long long)pos0 + 4 * want_chunks * CH;
-    const long long have_blocks = (long long)raw.size() / N, need_blocks = (want_words + N - 1) / N;
-    if (need_blocks > have_blocks) {
-      raw.resize((size_t)need_blocks * N);
-      for (long long b = have_blocks; b < need_blocks; ++b) regenerate(&raw[(size_t)(b - 1) * N], &raw[(size_t)b * N]);
-    }
-    const long long c0 = (long long)count.size();
+    const long long need_blocks = ((long long)pos0 + 4 * want_chunks * CH + N - 1) / N;
+    raw.resize((size_t)std::max<long long>(need_blocks, blocks_done) * N);
     count.resize((size_t)want_chunks);
-    g_buf.x1.resize((size_t)(want_chunks * CH));
-    g_buf.x2.resize((size_t)(want_chunks * CH));
-    g_buf.r2.resize((size_t)(want_chunks * CH));
-    double* X1 = g_buf.x1.data();
-    double* X2 = g_buf.x2.data();
-    double* R2 = g_buf.r2.data();
-    const long long nch = want_chunks - c0;
+    vals.resize((size_t)want_chunks * 2 * CH);
+    std::atomic<long long> blocks_ready(blocks_done), next_chunk(chunks_done);
+    uint32_t* R = raw.data();
+    long long* C = count.data();
+    float* V = vals.data();
     g_pool->run([&](int t) {
-      for (long long c = c0 + t; c < want_chunks; c += K) {
-        long long acc = 0;
-        for (long long a = c * CH; a < (c + 1) * CH; ++a) {  // (no branch, no call: vectorised)
-          double x1, x2, r2;
-          acc += attempt(a, x1, x2, r2);
-          X1[a] = x1;
-          X2[a] = x2;
-          R2[a] = r2;
+      if (t == 0) {
+        for (long long b = blocks_done; b < need_blocks; ++b) {
+          regenerate(R + (size_t)(b - 1) * N, R + (size_t)b * N);
+          blocks_ready.store(b + 1, std::memory_order_release);
         }
-        count[(size_t)c] = acc;
       }
-    }, (int)std::min<long long>(K, nch));
-    for (long long c = c0; c < want_chunks; ++c) pairs_found += count[(size_t)c];
-    attempts_ready = want_chunks * CH;
-  }
-  // the chunk in which the last needed pair falls, and the attempt index behind it
-  long long before = 0, last_chunk = 0;
-  for (long long c = 0; c < (long long)count.size(); ++c) {
-    if (before + count[(size_t)c] >= need_pairs) { last_chunk = c; break; }
-    before += count[(size_t)c];
-  }
-  // outputs: accepted attempt m (in order) -> out[done + 2m] = f x2, out[done + 2m + 1] = f x1 (numpy's cached deviate)
-  std::vector<long long> start((size_t)last_chunk + 2, 0);
-  for (long long c = 0; c <= last_chunk; ++c) start[(size_t)c + 1] = start[(size_t)c] + count[(size_t)c];
-  long long last_attempt = -1;
-  double last_f = 0.0, last_x1 = 0.0;
-  std::mutex lm;
-  g_pool->run([&](int t) {
-    for (long long c = t; c <= last_chunk; c += K) {
-      long long m = start[(size_t)c];
-      const double* X1 = g_buf.x1.data();
-      const double* X2 = g_buf.x2.data();
-      const double* R2 = g_buf.r2.data();
-      for (long long a = c * CH; a < (c + 1) * CH && m < need_pairs; ++a) {
-        const double r2 = R2[a];
-        if (r2 >= 1.0 || r2 == 0.0) continue;
-        const double x1 = X1[a], x2 = X2[a];
-        const double f = std::sqrt(-2.0 * std::log(r2) / r2);
-        const long long o = done + 2 * m;
-        out[o] = (float)(f * x2);
-        if (o + 1 < n) out[o + 1] = (float)(f * x1);
-        if (m == need_pairs - 1) {
-          std::lock_guard<std::mutex> lk(lm);
-          last_attempt = a;
-          last_f = f;
-          last_x1 = x1;
+      double X1[CH], X2[CH], R2[CH];
+      for (;;) {
+        const long long c = next_chunk.fetch_add(1, std::memory_order_relaxed);
+        if (c >= want_chunks) break;
+        const long long blk = (pos0 + 4 * (c + 1) * CH + N - 1) / N;
+        for (int spins = 0; blocks_ready.load(std::memory_order_acquire) < blk; ++spins) {
+          if (spins < 256) cpu_relax();
+          else std::this_thread::yield();  // (an oversubscribed host: let the regenerating thread run)
         }
-        ++m;
+        chunk_attempts(R, pos0, c * CH, X1, X2, R2);
+        float* v = V + (size_t)c * 2 * CH;
+        long long m = 0;
+        for (long long a = 0; a < CH; ++a) {
+          const double r2 = R2[a];
+          if (r2 >= 1.0 || r2 == 0.0) continue;
+          const double f = std::sqrt(-2.0 * std::log(r2) / r2);
+          v[2 * m] = (float)(f * X2[a]);
+          v[2 * m + 1] = (float)(f * X1[a]);
+          ++m;
+        }
+        C[c] = m;
+      }
+    }, K);
+    for (long long c = chunks_done; c < want_chunks; ++c) pairs_found += count[(size_t)c];
+    chunks_done = want_chunks;
+    blocks_done = std::max<long long>(need_blocks, blocks_done);
+  }
+  // where every chunk's outputs go; the chunk in which the last needed pair falls
+  std::vector<long long> start((size_t)chunks_done + 1, 0);
+  long long last_chunk = 0;
+  for (long long c = 0; c < chunks_done; ++c) {
+    start[(size_t)c + 1] = start[(size_t)c] + count[(size_t)c];
+    if (start[(size_t)c] < need_pairs) last_chunk = c;
+  }
+  {
+    const float* V = vals.data();
+    g_pool->run([&](int t) {
+      for (long long c = t; c <= last_chunk; c += K) {
+        const long long m0 = start[(size_t)c], m1 = std::min<long long>(start[(size_t)c + 1], need_pairs);
+        const long long o = done + 2 * m0;
+        long long cnt = 2 * (m1 - m0);
+        if (o + cnt > n) cnt = n - o;  // (an odd request: the last pair's second deviate stays cached)
+        if (cnt > 0) std::memcpy(out + o, V + (size_t)c * 2 * CH, (size_t)cnt * sizeof(float));
+      }
+    }, (int)std::min<long long>(K, last_chunk + 1));
+  }
+  // the attempt that yielded the last needed pair: the (need_pairs - start[last_chunk])-th accepted one of its chunk
+  long long last_attempt = -1;
+  double last_gauss = 0.0;
+  {
+    double X1[CH], X2[CH], R2[CH];
+    chunk_attempts(raw.data(), pos0, last_chunk * CH, X1, X2, R2);
+    long long m = start[(size_t)last_chunk];
+    for (long long a = 0; a < CH; ++a) {
+      const double r2 = R2[a];
+      if (r2 >= 1.0 || r2 == 0.0) continue;
+      if (++m == need_pairs) {
+        last_attempt = last_chunk * CH + a;
+        last_gauss = std::sqrt(-2.0 * std::log(r2) / r2) * X1[a];
+        break;
       }
     }
-  }, (int)std::min<long long>(K, last_chunk + 1));
+  }
   // the state numpy is left in: words consumed = 4 (last_attempt + 1); an odd request caches the last pair's first deviate
   if ((n - done) & 1) {
-    *gauss = last_f * last_x1;
+    *gauss = last_gauss;
     *has_gauss = 1;
   }
   const long long abs_pos = (long long)pos0 + 4 * (last_attempt + 1);
   long long blk = abs_pos / N, p = abs_pos % N;
   if (p == 0 && blk > 0) { blk -= 1; p = N; }  // numpy leaves pos = 624 at a block's end (regeneration on the next read)
+  // (key may BE numpy's own state array: block 0 of `raw` is a copy, so the source and the target never overlap)
   std::memcpy(key, &raw[(size_t)blk * N], N * sizeof(uint32_t));
   *pos = (int)p;
   return 0;

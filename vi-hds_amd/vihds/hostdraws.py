@@ -7,9 +7,12 @@ defaults) reads the numbers from STATIC device buffers: while a step is captured
 (what to draw, where it goes) instead of drawing; before every replay the slots are refreshed in registration order -- the
 same draws, in the same order, from the same generators as the eager step -- through pinned staging buffers (used in turn,
 each reused only after the copy that read it has run) and asynchronous copies that the replay queues behind."""
+from concurrent.futures import ThreadPoolExecutor
+
 import torch
 
-ACTIVE = None  # the HostDraws being recorded (set by Training while it captures)
+ACTIVE = None
+_WORKER = None  # one helper thread: the next step's numpy draw (native code, GIL released) while this step is being queued  # the HostDraws being recorded (set by Training while it captures)
 
 
 class HostDraws(object):
@@ -35,8 +38,9 @@ class HostDraws(object):
         self.arena = torch.empty(max(int(floats), self.ALIGN), device=device, dtype=torch.float32)
         self.used = 0
 
-    def add(self, shape, device, fill):
-        """Register a draw of `shape` float32 numbers; returns the static device buffer the captured kernels read."""
+    def add(self, shape, device, fill, prefetchable=False):
+        """Register a draw of `shape` float32 numbers; returns the static device buffer the captured kernels read.
+        prefetchable: the draw may run on the helper thread ahead of its replay (numpy's stream, drawn by native code)."""
         n = 1
         for v in shape:
             n *= int(v)
@@ -48,18 +52,42 @@ class HostDraws(object):
         self.used += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         # (the pinned staging buffers are made at the first refresh: page-locked allocations are not permitted while a
         # stream is capturing)
-        self.slots.append([buf, fill, None, [None, None, None], 0])
+        self.slots.append([buf, fill, None, [None, None, None], 0, prefetchable, None])
         return buf
+
+    def _stage(self, slot):
+        """The slot's next pinned buffer, free to be written (the copy that last read it has run)."""
+        buf, _fill, pinned, events, k = slot[:5]
+        if pinned is None:
+            pinned = slot[2] = [torch.empty(buf.numel(), dtype=torch.float32).pin_memory() for _ in range(3)]
+        slot[4] = (k + 1) % len(pinned)
+        if events[k] is not None:
+            events[k].synchronize()
+        return k
+
+    def prefetch(self):
+        """Start the prefetchable slots' NEXT draws on the helper thread.  Only the caller knows that the next consumer of
+        that random stream is this graph's next replay (Training.run: the next batch of the epoch); a prefetched draw that
+        is never replayed has advanced the stream by one unused draw."""
+        global _WORKER
+        for slot in self.slots:
+            if slot[5] and slot[6] is None:
+                if _WORKER is None:
+                    _WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vihds-hostdraws")
+                k = self._stage(slot)
+                slot[6] = (k, _WORKER.submit(slot[1], slot[2][k].numpy()))
 
     def refresh(self):
         for slot in self.slots:
-            buf, fill, pinned, events, k = slot
-            if pinned is None:
-                pinned = slot[2] = [torch.empty(buf.numel(), dtype=torch.float32).pin_memory() for _ in range(3)]
-            slot[4] = (k + 1) % len(pinned)
-            if events[k] is not None:
-                events[k].synchronize()
-            fill(pinned[k].numpy())
+            buf, fill, events = slot[0], slot[1], slot[3]
+            if slot[6] is not None:  # drawn ahead by prefetch()
+                k, fut = slot[6]
+                slot[6] = None
+                fut.result()
+            else:
+                k = self._stage(slot)
+                fill(slot[2][k].numpy())
+            pinned = slot[2]
             buf.copy_(pinned[k].view(buf.shape), non_blocking=True)
             if events[k] is None:
                 events[k] = torch.cuda.Event()
@@ -79,10 +107,14 @@ def note(shape):
         ACTIVE.note(shape)
 
 
-def replay(graph):
+def replay(graph, next_graph=None):
     """graph.replay() behind the refresh of the host draws it was captured with (Training attaches them as
-    graph.host_draws)."""
+    graph.host_draws).  next_graph: the graph whose replay is KNOWN to be the next consumer of the host streams (often the
+    same one): its prefetchable draws start on the helper thread as soon as this replay is queued."""
     draws = getattr(graph, "host_draws", None)
     if draws:
         draws.refresh()
     graph.replay()
+    nxt = getattr(next_graph, "host_draws", None) if next_graph is not None else None
+    if nxt:
+        nxt.prefetch()
