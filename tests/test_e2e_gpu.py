@@ -218,6 +218,59 @@ def test_evaluation_replayed_from_a_graph_gives_the_eager_results(name):
     assert runs[1][0][0] != runs[1][1][0]  # (fresh draws per replay)
 
 
+@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "dr_constant_precisions_tiny_modeuler",
+                                  "dr_blackbox_icml_tiny_modeuler", "relay_constant_precisions_tiny_modeuler",
+                                  "auto_constant_tiny_modeuler"])
+def test_default_graph_replay_with_the_reference_streams_equals_eager(name):
+    """An UNCHANGED spec on the GPU (round 4): hip_graph is automatic and the reference's host-side streams (numpy u, CPU-drawn
+    conditioner weights) are staged into the replayed step and the replayed evaluation (vihds/hostdraws.py).  Against
+    hip_graph: false from the same seeds: five training steps through Training._run_batch (the second half with the next
+    step's numpy draw prefetched), then an evaluation, a step, an evaluation -- every loss and ELBO equal, both generators left
+    in the same state."""
+    import e2e_util as E
+    from vihds.training import Training
+    from vihds.utils import TrainingLogData
+    from vihds.vae import build_model
+
+    fx = Fixture(name)
+    runs = {}
+    for graph in (False, None):
+        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, hip_graph=graph)
+        model = build_model(args, settings, data, parameters)
+        training = Training(args, settings, data, parameters, model)
+        assert training.use_graph == (graph is None)
+        batch = E.batch_from_fixture(fx, settings.device)
+        log = TrainingLogData()
+        np.random.seed(21)
+        torch.manual_seed(21)
+        out = []
+
+        def step(nxt):
+            model.train()
+            assert training._run_batch(0.0, batch, log, next_batch=nxt)
+            out.append(float(training._pending_elbo) if training._pending_elbo is not None else float(training.last_elbo))
+
+        orig_step = training.step
+
+        def keeping(b, *a, **k):  # (the eager path hands the loss back through _run_batch's local only)
+            training.last_elbo = orig_step(b, *a, **k)
+            return training.last_elbo
+
+        training.step = keeping
+        for k in range(5):
+            step(batch if k >= 2 and k < 4 else None)
+        model.eval()
+        out.append(float(training.evaluate(batch, fx.S).elbo))
+        step(None)
+        model.eval()
+        out.append(float(training.evaluate(batch, fx.S).elbo))
+        runs[graph] = (out, np.random.rand(), float(torch.rand(1)))
+    a, b = runs[False], runs[None]
+    assert a[1] == b[1] and a[2] == b[2], "the host generators were consumed differently"
+    for x, y in zip(a[0], b[0]):
+        assert abs(x - y) <= 2e-5 * max(1.0, abs(x)), (a[0], b[0])
+
+
 def test_kept_elbo_scalars_survive_later_graph_evaluations():
     """_evaluate_elbo_and_plot keeps bare `out.elbo` values (max_val_elbo, the elbo lists) while the Results they
     came from die; with the captured evaluation pass those used to be views of a pinned ring slot a later pass rewrites.

@@ -88,6 +88,7 @@ class Training:
             from vihds import hip as _hip
 
             want_graph = p.solver not in _hip.ADAPTIVE_SOLVERS and os.environ.get("VIHDS_AUTO_GRAPH", "1") != "0"
+        self._graph_auto = default_get_value(p, "hip_graph", None) is None  # (automatic: a capture that fails falls back to eager launches)
         self.use_graph = bool(want_graph) and on_gpu
         self._pending_elbo = None
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
@@ -252,7 +253,14 @@ class Training:
         if key not in self._eval_graphs:
             while len(self._eval_graphs) >= 8:
                 self._eval_graphs.pop(next(iter(self._eval_graphs)))
-            g, staged = self._capture_evaluation(data, int(n_samples))
+            try:
+                g, staged = self._capture_evaluation(data, int(n_samples))
+            except Exception as exc:  # noqa: BLE001
+                self._graphs_off(exc)
+                self.eval_graph = False
+                with torch.no_grad():
+                    results, theta, q, p = self.model(data, n_samples, writer=writer, epoch=epoch)
+                    return self.cost(data, results, theta, q, p, full_output=True, writer=writer, epoch=epoch)
             staged["data"] = data
             self._eval_graphs[key] = (g, staged)
         g, staged = self._eval_graphs[key]
@@ -480,6 +488,17 @@ class Training:
         g, losses = self._capture_segments([(static, prologue if k == 0 else None) for k in range(repeat)])
         return g, static, (losses[0] if repeat == 1 else losses)
 
+    def _graphs_off(self, exc):
+        """hip_graph was chosen automatically and a capture failed (a step that synchronises, an allocation the capture does
+        not permit, ...): say so once and run eagerly from here on -- the numbers are the same.  An explicit hip_graph: true
+        re-raises."""
+        if not self._graph_auto:
+            raise exc
+        print("- hipGraph capture failed (%s: %s): continuing with eager launches" % (type(exc).__name__, str(exc)[:200]))
+        torch.cuda.synchronize()
+        self.use_graph = self.epoch_graph = False
+        self.optimizer.zero_grad(set_to_none=True)
+
     def _capture_segments(self, segments):
         """One hipGraph holding len(segments) consecutive training steps: segment k = `prologue_k()` (or nothing), then the
         step on the buffers `static_k`.  Returns (graph, [loss_k])."""
@@ -576,7 +595,14 @@ class Training:
             # input-only preprocessing of the encoder (reference encoders.py:385) is done when a batch is staged, not
             # inside every replay
             static["delta_obs"] = _delta_obs(static.observations)
-            self._graphs[key] = self._capture(static, repeat)
+            try:
+                self._graphs[key] = self._capture(static, repeat)
+            except Exception as exc:  # noqa: BLE001
+                self._graphs_off(exc)
+                out = None
+                for _ in range(repeat):
+                    out = self.step(batch)
+                return out
         g, static, loss = self._graphs[key]
         if self._staged.get(key) is not batch:  # a batch that is already resident in the graph's inputs is not re-copied
             for k in ("dev_1hot", "inputs", "observations", "times"):
@@ -648,8 +674,12 @@ class Training:
         if key not in self._graphs:
             idx = rows_host.to(dev).clone()
             static = self.gather_rows(idx)
-            self._graphs[key] = (self._capture(static, 1, prologue=lambda: self.gather_rows(idx, out=static))
-                                 + (idx, self._IndexStaging(n)))
+            try:
+                self._graphs[key] = (self._capture(static, 1, prologue=lambda: self.gather_rows(idx, out=static))
+                                     + (idx, self._IndexStaging(n)))
+            except Exception as exc:  # noqa: BLE001
+                self._graphs_off(exc)
+                return self.step(self.gather_rows(rows_host.to(dev, non_blocking=True)))
         g, static, loss, idx, staging = self._graphs[key]
         staging.upload(idx, lambda buf: buf.copy_(rows_host))
         nxt = self._graphs.get(("rows", int(next_rows.shape[0]))) if next_rows is not None else None
