@@ -1097,7 +1097,9 @@ class StepTail(object):
         mine = [t for t in self.tensors if t is not None]
         return len(group) == len(mine) and {id(p) for p in group} == {id(t) for t in mine} and all(t.is_cuda for t in mine)
 
-    def launch(self, dec_node, enc_node, job):
+    def launch(self, dec_node, enc_node, job, apply_adam=True):
+        """apply_adam False (row replicas): the second launch only forms the gradient sums into the arena -- the caller
+        all-reduces them and runs the Adam launch on the result."""
         (q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, g_unit, _theta, _cond, _times, _obs,
          _dev1hot) = dec_node.saved_tensors
         delta_obs, inputs, dev_1hot, _cw, lin_w, local_w, _lb, _gw, _gf, pooled, hidden = enc_node.saved_tensors
@@ -1149,7 +1151,7 @@ class StepTail(object):
             a.param[k], a.grad[k], a.mv_offset[k] = t.data_ptr(), views[-1].data_ptr(), offsets[id(t)]
             o += sizes[k]
         lr = group["lr"]
-        a.m, a.v, a.state = st["m"].data_ptr(), st["v"].data_ptr(), st["state"].data_ptr()
+        a.m, a.v, a.state = st["m"].data_ptr(), st["v"].data_ptr(), (st["state"].data_ptr() if apply_adam else None)
         a.lr_dev = hip.ptr(lr) if isinstance(lr, torch.Tensor) else None
         a.lr = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
         a.beta1, a.beta2 = group["betas"]

@@ -372,6 +372,12 @@ class Training:
             self._in_step = False
         if self._step_tail(batch_results, q) is not None:
             # params.fused_step_tail: loss, backward and Adam ran as vihds_step_tail's two launches
+            if self.replica is not None:
+                # row replicas: the tail formed this rank's gradients (no Adam); ONE in-place all-reduce over the arena they
+                # sit in, then the Adam launch on the sums -- three launches and a collective where the autograd path has five
+                self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.replica.group, self._grad_buffer)
+                self.optimizer.gate = None
+                self.optimizer.step()
             if zero_grad:
                 self.optimizer.zero_grad(set_to_none=True)
             return elbo.detach()
@@ -407,7 +413,7 @@ class Training:
         """params.fused_step_tail (single process, fused decoder step with a deferred IWAE loss, all trainable parameters
         in the encoder): hand the rest of the step to ops.StepTail.  Returns the loss tensor, or None when it does not
         apply (the caller then runs autograd's backward and optimizer.step())."""
-        if not self.fused_tail or self.shard is not None or self.replica is not None or len(ops._PENDING_IWAE) != 1:
+        if not self.fused_tail or self.shard is not None or len(ops._PENDING_IWAE) != 1:
             return None
         sol = getattr(batch_results, "solution", None)
         dec_node = getattr(getattr(sol, "logp_buffer", None), "grad_fn", None)
@@ -430,7 +436,7 @@ class Training:
             return None
         (job,) = ops._PENDING_IWAE.values()
         ops._PENDING_IWAE.clear()
-        return self._tail.launch(dec_node, enc_node, job)
+        return self._tail.launch(dec_node, enc_node, job, apply_adam=self.replica is None)
 
     def _snapshot_training_state(self):
         """Parameters + optimizer state before a capture's warm-up steps (a new batch shape, e.g. an epoch's last partial
