@@ -574,7 +574,7 @@ def unchanged_spec_leg(a, dev, min_seconds):
         if not training._run_batch(time.time(), batch, log, next_batch=batch):  # (the same resident batch follows)
             raise SystemExit("NaN objective in the unchanged-spec leg")
 
-    for _ in range(5):
+    for _ in range(20):  # (the capture and its warm-up steps happen in here)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -652,6 +652,17 @@ def other_config_legs(a, dev):
         legs["unchanged_spec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     legs["unchanged_spec"]["leg_wall_s"] = time.perf_counter() - t0
     return legs
+
+
+def run_plain_ms(a):
+    """ms per step of the plain one-process headline run, from a child process with the distributed leg's own arguments."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2000", "--warmup", "200", "--no-cpu-baseline",
+           "--no-other-configs", "--no-strong-leg", "--roofline-steps", "0", "--seed", str(a.seed), "--lr", str(a.lr)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return json.loads(line[-1])["ms_per_step"]
 
 
 def distributed_leg_guarded(a, plain_ms):
@@ -737,7 +748,19 @@ def main():
                          "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
                          "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
+    ap.add_argument("--legs-only", action="store_true",
+                    help="development aid: time only the two host-bound legs (unchanged spec; one rank through the "
+                         "distributed path) and print them; not the driver's line")
     a = ap.parse_args()
+    if a.legs_only:
+        a.solver = a.solver or "rk4"
+        torch.cuda.set_device(0)
+        legs = {"unchanged_spec": unchanged_spec_leg(a, "cuda:0", a.leg_seconds)}
+        plain = run_plain_ms(a)
+        legs["plain_ms_per_step"] = plain
+        legs["distributed_path_world1"] = distributed_leg_guarded(a, plain)
+        print(json.dumps(legs))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
         # hand the same arguments on; rank 0 of that job prints the line

@@ -24,3 +24,14 @@ for k, s in enumerate(slots):
     buf = torch.empty(s[0].numel(), dtype=torch.float32).pin_memory().numpy()
     print("  fill slot %d %s       %.3f ms" % (k, tuple(s[0].shape), t(lambda: s[1](buf))))
 print("replay only              %.3f ms" % t(lambda: g.replay()))
+
+from vihds import nprand
+import numpy as np
+out = np.empty(36 * 200 * 35, np.float32)
+for th in (1, 2, 4, 8):
+    nprand._THREADS = th
+    nprand.randn_f32((36, 200, 35), out)
+    ts = []
+    for _ in range(60):
+        t0 = time.perf_counter(); nprand.randn_f32((36, 200, 35), out); ts.append(time.perf_counter() - t0)
+    print("nprand %d threads: median %.3f ms  min %.3f ms" % (th, np.median(ts) * 1e3, min(ts) * 1e3))

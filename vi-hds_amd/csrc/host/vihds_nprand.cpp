@@ -11,7 +11,12 @@
 //     whatever its outcome, so attempt a reads words 4a .. 4a+3 and all attempts are independent -- evaluated by a small
 //     persistent pool of threads, accepted ones compacted in order (prefix sum over per-chunk counts); accepted attempt m
 //     yields outputs 2m (= f x2) and 2m + 1 (= f x1), f = sqrt(-2 log(r2) / r2) with libm's log, as numpy calls it;
-//   * the state handed back is numpy's state after the same call (key, pos, has_gauss, cached deviate).
+//   * the state handed back is numpy's state after the same call (key, pos, has_gauss, cached deviate);
+//   * the OUTPUT is float32: the double f x is formed with a four-wide table-driven log (|error| of f x below 1e-15
+//     relative) and rounded to float32; wherever that double lies within 4096 ulps of a float32 rounding boundary -- where a
+//     last-bit difference from libm's log could change the rounded result, about 1.5e-5 of the values -- the value is
+//     recomputed with libm's log as numpy calls it.  The float32 numbers are therefore the ones numpy's float64 stream
+//     rounds to, bit for bit; the cached deviate (a double) always comes from libm.
 //
 // C ABI (ctypes: vi-hds_amd/vihds/nprand.py).  Host code only; not part of the HIP library.
 #include <atomic>
@@ -20,6 +25,7 @@
 #include <cstdint>
 #include <cstring>
 #include <functional>
+#include <immintrin.h>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -117,8 +123,8 @@ class Pool {
 constexpr long long CH = 2048;  // attempts per chunk
 
 struct Buffers {  // kept between calls: fresh allocations of this size cost more in page faults than the arithmetic
-  std::vector<uint32_t> raw;       // raw generator states, block after block; block 0 = the caller's key
   std::vector<long long> count;    // accepted attempts per chunk
+  std::vector<long long> start;    // prefix sums of `count`
   std::vector<float> vals;         // per chunk: its accepted attempts' outputs in order (f x2, f x1), 2 CH floats
 };
 
@@ -146,6 +152,128 @@ inline void chunk_attempts(const uint32_t* raw, long long pos0, long long a0, do
   }
 }
 
+// the accepted attempts moved to the front, in order (no branch); returns how many
+inline long long compact_accepted(double* X1, double* X2, double* R2) {
+  long long m = 0;
+  for (long long a = 0; a < CH; ++a) {
+    const double r2 = R2[a], x1 = X1[a], x2 = X2[a];
+    X1[m] = x1;
+    X2[m] = x2;
+    R2[m] = r2;
+    m += (r2 < 1.0) & (r2 != 0.0);
+  }
+  return m;
+}
+
+// log(z) = k ln2 + log(c_i) + log1p(z'/c_i - 1) over 128 sub-intervals of z' in [0.6875, 1.375) (the interval below 1 is
+// centred ON 1, so that arguments near 1 keep their relative accuracy); a few 1e-16 relative -- only the float32 rounding
+// of what is built on it has to agree with libm's log (see `finish_chunk`)
+struct LogTable {
+  alignas(16) double t[128][2];  // (1 / c_i, log c_i)
+  LogTable() {
+    for (int i = 0; i < 128; ++i) {
+      const uint64_t lo = 0x3fe6000000000000ULL + ((uint64_t)i << 45), hi = lo + (1ULL << 45);
+      double a, b;
+      std::memcpy(&a, &lo, 8);
+      std::memcpy(&b, &hi, 8);
+      const double c = i == 79 ? 1.0 : 0.5 * (a + b);
+      t[i][0] = i == 79 ? 1.0 : 1.0 / c;
+      t[i][1] = i == 79 ? 0.0 : (double)-std::log((long double)t[i][0]);  // log of the c that 1/c stands for exactly
+    }
+  }
+};
+const LogTable g_log;
+
+__attribute__((target("avx2,fma"))) inline __m256d log4(__m256d x) {
+  const __m256i ix = _mm256_castpd_si256(x);
+  const __m256i tmp = _mm256_sub_epi64(ix, _mm256_set1_epi64x(0x3fe6000000000000LL));
+  const __m256i idx = _mm256_and_si256(_mm256_srli_epi64(tmp, 45), _mm256_set1_epi64x(127));
+  const __m256i kbits = _mm256_and_si256(tmp, _mm256_set1_epi64x((long long)(0xfffULL << 52)));
+  const __m256d z = _mm256_castsi256_pd(_mm256_sub_epi64(ix, kbits));
+  // k = (int64) tmp >> 52: twelve bits, sign-extended, as doubles
+  __m256i k12 = _mm256_srli_epi64(tmp, 52);
+  k12 = _mm256_sub_epi64(_mm256_xor_si256(k12, _mm256_set1_epi64x(0x800)), _mm256_set1_epi64x(0x800));
+  const __m128i k32 = _mm256_castsi256_si128(_mm256_permutevar8x32_epi32(k12, _mm256_setr_epi32(0, 2, 4, 6, 0, 0, 0, 0)));
+  const __m256d k = _mm256_cvtepi32_pd(k32);
+  // the four table rows by index: plain 16-byte loads and two unpacks (a vgatherqpd here was slower than libm's scalar log
+  // on an EPYC 9575F, and on Intel it chained the loop's iterations through its merge destination)
+  alignas(32) long long ii[4];
+  _mm256_store_si256((__m256i*)ii, idx);
+  const __m256d t02 = _mm256_set_m128d(_mm_load_pd(g_log.t[ii[2]]), _mm_load_pd(g_log.t[ii[0]]));
+  const __m256d t13 = _mm256_set_m128d(_mm_load_pd(g_log.t[ii[3]]), _mm_load_pd(g_log.t[ii[1]]));
+  const __m256d invc = _mm256_unpacklo_pd(t02, t13), logc = _mm256_unpackhi_pd(t02, t13);
+  const __m256d r = _mm256_fmadd_pd(z, invc, _mm256_set1_pd(-1.0));
+  __m256d p = _mm256_set1_pd(1.0 / 7.0);
+  p = _mm256_fmadd_pd(p, r, _mm256_set1_pd(-1.0 / 6.0));
+  p = _mm256_fmadd_pd(p, r, _mm256_set1_pd(1.0 / 5.0));
+  p = _mm256_fmadd_pd(p, r, _mm256_set1_pd(-1.0 / 4.0));
+  p = _mm256_fmadd_pd(p, r, _mm256_set1_pd(1.0 / 3.0));
+  p = _mm256_fmadd_pd(p, r, _mm256_set1_pd(-0.5));
+  const __m256d hi = _mm256_fmadd_pd(k, _mm256_set1_pd(0.693147180559945309417232121458), logc);
+  const __m256d lo = _mm256_fmadd_pd(_mm256_mul_pd(r, r), p, r);
+  return _mm256_add_pd(hi, lo);
+}
+
+// does any of the eight doubles have a doubtful float32 rounding -- the 29 bits below float32's mantissa within 4096 of the
+// half-way pattern?  (Their magnitudes are always inside float32's normal range: |f x| <= sqrt(-2 log r2) <= 12 since
+// |x| <= sqrt(r2) and r2 >= 2^-104, and |f x| >= sqrt(2 * 2^-53) * 2^-52 since r2 <= 1 - 2^-53 and |x| >= 2^-52.)
+__attribute__((target("avx2,fma"))) inline bool doubtful8(__m256d a, __m256d b) {
+  const __m256i lo = _mm256_castps_si256(_mm256_shuffle_ps(_mm256_castpd_ps(a), _mm256_castpd_ps(b), 0x88));  // low words
+  const __m256i near = _mm256_add_epi32(_mm256_and_si256(lo, _mm256_set1_epi32(0x1fffffff)),
+                                        _mm256_set1_epi32(4096 - 0x10000000));  // in [0, 8192) when doubtful
+  return _mm256_movemask_epi8(_mm256_cmpeq_epi32(_mm256_srli_epi32(near, 13), _mm256_setzero_si256())) != 0;
+}
+
+// v[2j], v[2j+1] <- float32 of f x2, f x1 for the m accepted attempts (X1, X2, R2 compacted), f = sqrt(-2 log(r2) / r2)
+__attribute__((target("avx2,fma"))) inline void finish_chunk(const double* X1, const double* X2, const double* R2,
+                                                             long long m, float* v) {
+  long long j = 0;
+  for (; j + 4 <= m; j += 4) {
+    const __m256d r2 = _mm256_loadu_pd(R2 + j);
+    const __m256d f = _mm256_sqrt_pd(_mm256_div_pd(_mm256_mul_pd(_mm256_set1_pd(-2.0), log4(r2)), r2));
+    const __m256d d2 = _mm256_mul_pd(f, _mm256_loadu_pd(X2 + j)), d1 = _mm256_mul_pd(f, _mm256_loadu_pd(X1 + j));
+    // interleave (d2[0], d1[0], d2[1], d1[1]) | (d2[2], d1[2], d2[3], d1[3])
+    const __m256d ul = _mm256_unpacklo_pd(d2, d1), uh = _mm256_unpackhi_pd(d2, d1);  // (a0 b0 a2 b2), (a1 b1 a3 b3)
+    const __m256d first = _mm256_permute2f128_pd(ul, uh, 0x20), second = _mm256_permute2f128_pd(ul, uh, 0x31);
+    _mm_storeu_ps(v + 2 * j, _mm256_cvtpd_ps(first));
+    _mm_storeu_ps(v + 2 * j + 4, _mm256_cvtpd_ps(second));
+    if (doubtful8(d2, d1)) {
+      for (long long q = j; q < j + 4; ++q) {
+        const double fe = std::sqrt(-2.0 * std::log(R2[q]) / R2[q]);
+        v[2 * q] = (float)(fe * X2[q]);
+        v[2 * q + 1] = (float)(fe * X1[q]);
+      }
+    }
+  }
+  for (; j < m; ++j) {
+    const double fe = std::sqrt(-2.0 * std::log(R2[j]) / R2[j]);
+    v[2 * j] = (float)(fe * X2[j]);
+    v[2 * j + 1] = (float)(fe * X1[j]);
+  }
+}
+
+// bound[0..K]: contiguous chunk ranges of equal COST for K threads, where a thread pays `RHO` per chunk before its range's end
+// (regenerating the generator up to there) on top of 1 per chunk of its own (RHO: 73 ns per block x 13.1 blocks per chunk
+// against 6.4 us per evaluated chunk on an EPYC 9575F; 0.15 on a Xeon as well)
+inline void split_chunks(long long chunks, int K, long long* bound) {
+  constexpr double RHO = 0.15;
+  double lo = 0.0, hi = (double)chunks * (1.0 + RHO);
+  for (int it = 0; it < 60; ++it) {
+    const double T = 0.5 * (lo + hi);
+    double e = 0.0;
+    for (int t = 0; t < K; ++t) e = (T + e) / (1.0 + RHO);
+    if (e < (double)chunks) lo = T;
+    else hi = T;
+  }
+  double e = 0.0;
+  bound[0] = 0;
+  for (int t = 0; t < K; ++t) {
+    e = (hi + e) / (1.0 + RHO);
+    bound[t + 1] = std::min<long long>(chunks, std::max<long long>(bound[t], (long long)(e + 0.5)));
+  }
+  bound[K] = chunks;
+}
+
 }  // namespace
 
 extern "C" {
@@ -153,10 +281,13 @@ extern "C" {
 // out[0..n) <- what np.random.standard_normal(n).astype(np.float32) would return from the RandomState (key, pos, has_gauss,
 // gauss); the four are updated to the state numpy would be left in.  Returns 0, or -1 on bad arguments.
 //
-// One thread regenerates the generator's blocks in order and publishes how far it is; the others (and then that one too)
-// take chunks of 2048 attempts as soon as the blocks under them exist, evaluate them (a vectorised pass for x1, x2, r2, then
-// the accepted ones' sqrt(-2 log r2 / r2)) into the chunk's own buffer; a last pass copies the chunks' outputs to their
-// places (prefix sum over the chunks' counts).
+// The attempts are cut into chunks of 2048 and the chunks into one contiguous range per thread.  Nothing is shared while the
+// threads work: each regenerates the generator's blocks from the caller's key up to the end of its own range (that costs
+// 1/7 of evaluating the same stretch, so later threads get shorter ranges: `split_chunks`) and keeps only the blocks under its
+// range, evaluates its chunks (a vectorised pass for x1, x2, r2, then the accepted ones' sqrt(-2 log r2 / r2)) into the
+// chunks' own buffers; then one thread places the chunks (prefix sum over their counts), every thread copies its chunks'
+// outputs to their places, and the thread that owns the last needed attempt leaves the generator state behind it.  (A first
+// version had one thread regenerate for all: on a 64-core EPYC the others then pulled 2.5 MB of state across the chip.)
 int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, float* out, long long n, int n_threads) {
   if (!key || !pos || !has_gauss || !gauss || !out || n < 0 || *pos < 0 || *pos > N) return -1;
   std::lock_guard<std::mutex> guard(g_lock);
@@ -174,110 +305,184 @@ int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, f
     delete g_pool;
     g_pool = new Pool(n_threads - 1);
   }
-  const int K = need_pairs < 4096 ? 1 : n_threads;
-  std::vector<uint32_t>& raw = g_buf.raw;
-  std::vector<long long>& count = g_buf.count;
-  std::vector<float>& vals = g_buf.vals;
   const long long pos0 = *pos;
-  raw.resize(N);
-  std::memcpy(raw.data(), key, N * sizeof(uint32_t));
-  count.clear();
-  long long pairs_found = 0, chunks_done = 0, blocks_done = 1;
-  while (pairs_found < need_pairs) {
-    const long long want_attempts = chunks_done * CH + (long long)((need_pairs - pairs_found) * 1.2732395447 * 1.02) + 64;
+  std::vector<long long>& count = g_buf.count;
+  std::vector<long long>& start = g_buf.start;
+  std::vector<float>& vals = g_buf.vals;
+  const bool odd = (n - done) & 1;
+  for (double margin = 1.02;; margin = 1.0 + 2.0 * (margin - 1.0)) {  // (a second round: never seen; the margin doubles)
+    const long long want_attempts = (long long)(need_pairs * 1.2732395447 * margin) + 64;
     const long long want_chunks = (want_attempts + CH - 1) / CH;
-    const long long need_blocks = ((long long)pos0 + 4 * want_chunks * CH + N - 1) / N;
-    raw.resize((size_t)std::max<long long>(need_blocks, blocks_done) * N);
+    const int K = (int)std::min<long long>(need_pairs < 4096 ? 1 : n_threads, want_chunks);
     count.resize((size_t)want_chunks);
-    vals.resize((size_t)want_chunks * 2 * CH);
-    std::atomic<long long> blocks_ready(blocks_done), next_chunk(chunks_done);
-    uint32_t* R = raw.data();
+    start.resize((size_t)want_chunks + 1);
+    if (vals.size() < (size_t)want_chunks * 2 * CH) vals.resize((size_t)want_chunks * 2 * CH);
+    long long bound[65];
+    split_chunks(want_chunks, K, bound);
+    std::atomic<int> finished(0), verdict(0);  // verdict: 1 = enough pairs, copy out; 2 = another round is needed
+    long long last_chunk = 0;
     long long* C = count.data();
+    long long* S = start.data();
     float* V = vals.data();
     g_pool->run([&](int t) {
-      if (t == 0) {
-        for (long long b = blocks_done; b < need_blocks; ++b) {
-          regenerate(R + (size_t)(b - 1) * N, R + (size_t)b * N);
-          blocks_ready.store(b + 1, std::memory_order_release);
+      static thread_local std::vector<uint32_t> local;  // the blocks first .. last of this thread's range
+      const long long c0 = bound[t], c1 = bound[t + 1];
+      // words of the range: [pos0 + 4 c0 CH, pos0 + 4 c1 CH); the block before is kept as well (the state handed back
+      // when the last attempt ends exactly at a block's end)
+      const long long first = std::max<long long>((pos0 + 4 * c0 * CH) / N - 1, 0), last = (pos0 + 4 * c1 * CH + N - 1) / N;
+      if (local.size() < (size_t)(last - first + 1) * N) local.resize((size_t)(last - first + 1) * N);
+      uint32_t* L = local.data();
+      {
+        uint32_t roll[2][N];
+        const uint32_t* prev = key;
+        for (long long b = 1; b <= first; ++b) {  // up to the range: nothing kept
+          regenerate(prev, roll[b & 1]);
+          prev = roll[b & 1];
         }
+        std::memcpy(L, prev, N * sizeof(uint32_t));
+        for (long long b = first + 1; b <= last; ++b) regenerate(L + (size_t)(b - first - 1) * N, L + (size_t)(b - first) * N);
       }
+      const uint32_t* R = L - (size_t)first * N;  // R[w] = raw word w of the stream, for the words of this range
       double X1[CH], X2[CH], R2[CH];
-      for (;;) {
-        const long long c = next_chunk.fetch_add(1, std::memory_order_relaxed);
-        if (c >= want_chunks) break;
-        const long long blk = (pos0 + 4 * (c + 1) * CH + N - 1) / N;
-        for (int spins = 0; blocks_ready.load(std::memory_order_acquire) < blk; ++spins) {
-          if (spins < 256) cpu_relax();
-          else std::this_thread::yield();  // (an oversubscribed host: let the regenerating thread run)
-        }
+      for (long long c = c0; c < c1; ++c) {
         chunk_attempts(R, pos0, c * CH, X1, X2, R2);
-        float* v = V + (size_t)c * 2 * CH;
-        long long m = 0;
-        for (long long a = 0; a < CH; ++a) {
-          const double r2 = R2[a];
-          if (r2 >= 1.0 || r2 == 0.0) continue;
-          const double f = std::sqrt(-2.0 * std::log(r2) / r2);
-          v[2 * m] = (float)(f * X2[a]);
-          v[2 * m + 1] = (float)(f * X1[a]);
-          ++m;
-        }
+        const long long m = compact_accepted(X1, X2, R2);
+        finish_chunk(X1, X2, R2, m, V + (size_t)c * 2 * CH);
         C[c] = m;
       }
-    }, K);
-    for (long long c = chunks_done; c < want_chunks; ++c) pairs_found += count[(size_t)c];
-    chunks_done = want_chunks;
-    blocks_done = std::max<long long>(need_blocks, blocks_done);
-  }
-  // where every chunk's outputs go; the chunk in which the last needed pair falls
-  std::vector<long long> start((size_t)chunks_done + 1, 0);
-  long long last_chunk = 0;
-  for (long long c = 0; c < chunks_done; ++c) {
-    start[(size_t)c + 1] = start[(size_t)c] + count[(size_t)c];
-    if (start[(size_t)c] < need_pairs) last_chunk = c;
-  }
-  {
-    const float* V = vals.data();
-    g_pool->run([&](int t) {
-      for (long long c = t; c <= last_chunk; c += K) {
-        const long long m0 = start[(size_t)c], m1 = std::min<long long>(start[(size_t)c + 1], need_pairs);
+      finished.fetch_add(1, std::memory_order_acq_rel);
+      if (t == 0) {
+        for (int spins = 0; finished.load(std::memory_order_acquire) < K; ++spins) {
+          if (spins < 4096) cpu_relax();
+          else std::this_thread::yield();
+        }
+        S[0] = 0;
+        for (long long c = 0; c < want_chunks; ++c) {
+          S[c + 1] = S[c] + C[c];
+          if (S[c] < need_pairs) last_chunk = c;
+        }
+        verdict.store(S[want_chunks] >= need_pairs ? 1 : 2, std::memory_order_release);
+      } else {
+        for (int spins = 0; verdict.load(std::memory_order_acquire) == 0; ++spins) {
+          if (spins < 4096) cpu_relax();
+          else std::this_thread::yield();
+        }
+      }
+      if (verdict.load(std::memory_order_acquire) != 1) return;
+      for (long long c = c0; c < c1 && c <= last_chunk; ++c) {
+        const long long m0 = S[c], m1 = std::min<long long>(S[c + 1], need_pairs);
         const long long o = done + 2 * m0;
         long long cnt = 2 * (m1 - m0);
         if (o + cnt > n) cnt = n - o;  // (an odd request: the last pair's second deviate stays cached)
         if (cnt > 0) std::memcpy(out + o, V + (size_t)c * 2 * CH, (size_t)cnt * sizeof(float));
       }
-    }, (int)std::min<long long>(K, last_chunk + 1));
-  }
-  // the attempt that yielded the last needed pair: the (need_pairs - start[last_chunk])-th accepted one of its chunk
-  long long last_attempt = -1;
-  double last_gauss = 0.0;
-  {
-    double X1[CH], X2[CH], R2[CH];
-    chunk_attempts(raw.data(), pos0, last_chunk * CH, X1, X2, R2);
-    long long m = start[(size_t)last_chunk];
-    for (long long a = 0; a < CH; ++a) {
-      const double r2 = R2[a];
-      if (r2 >= 1.0 || r2 == 0.0) continue;
-      if (++m == need_pairs) {
-        last_attempt = last_chunk * CH + a;
-        last_gauss = std::sqrt(-2.0 * std::log(r2) / r2) * X1[a];
-        break;
+      if (c0 <= last_chunk && last_chunk < c1) {
+        // the attempt that yielded the last needed pair: the (need_pairs - S[last_chunk])-th accepted one of its chunk
+        long long last_attempt = -1;
+        double last_gauss = 0.0;
+        chunk_attempts(R, pos0, last_chunk * CH, X1, X2, R2);
+        long long m = S[last_chunk];
+        for (long long a = 0; a < CH; ++a) {
+          const double r2 = R2[a];
+          if (r2 >= 1.0 || r2 == 0.0) continue;
+          if (++m == need_pairs) {
+            last_attempt = last_chunk * CH + a;
+            last_gauss = std::sqrt(-2.0 * std::log(r2) / r2) * X1[a];
+            break;
+          }
+        }
+        // the state numpy is left in: words consumed = 4 (last_attempt + 1); an odd request caches the last pair's first
+        // deviate
+        if (odd) {
+          *gauss = last_gauss;
+          *has_gauss = 1;
+        }
+        const long long abs_pos = pos0 + 4 * (last_attempt + 1);
+        long long blk = abs_pos / N, p = abs_pos % N;
+        if (p == 0 && blk > 0) { blk -= 1; p = N; }  // numpy leaves pos = 624 at a block's end (regeneration on the next read)
+        if (blk > 0) std::memcpy(key, R + (size_t)blk * N, N * sizeof(uint32_t));  // (block 0 IS the caller's key)
+        *pos = (int)p;
       }
+    }, K);
+    if (verdict.load() == 1) return 0;
+  }
+}
+
+// The same draw on a native helper thread: `start` returns at once, `wait` blocks until the numbers are in `out` and numpy's
+// state (key, pos: read and advanced IN PLACE) is the state after the draw.  For an even n on a state without a cached
+// deviate only (the training loop's draws).  A Python helper thread cannot do this job: it needs the interpreter lock to
+// start, which the main thread holds while it queues the step -- measured, the "overlapped" draw ran after the main thread's
+// work, not beside it.  One draw in flight at a time; the caller must leave numpy's generator alone until `wait` returns.
+struct AsyncDraw {
+  std::thread worker;
+  std::mutex m;
+  std::condition_variable cv;
+  int state = 0;  // 0 idle, 1 submitted, 2 running, 3 done (result not collected yet)
+  uint32_t* key = nullptr;
+  int* pos = nullptr;
+  float* out = nullptr;
+  long long n = 0;
+  int threads = 1, rc = 0;
+  bool stop = false;
+  void loop() {
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(m);
+        cv.wait(lk, [&] { return state == 1 || stop; });
+        if (stop) return;
+        state = 2;
+      }
+      int has_gauss = 0;
+      double gauss = 0.0;
+      const int r = vihds_np_randn_f32(key, pos, &has_gauss, &gauss, out, n, threads);
+      {
+        std::lock_guard<std::mutex> lk(m);
+        rc = r;
+        state = 3;
+      }
+      cv.notify_all();
     }
   }
-  // the state numpy is left in: words consumed = 4 (last_attempt + 1); an odd request caches the last pair's first deviate
-  if ((n - done) & 1) {
-    *gauss = last_gauss;
-    *has_gauss = 1;
+};
+static AsyncDraw* g_async = nullptr;
+static std::mutex g_async_create;
+
+int vihds_np_randn_f32_start(uint32_t* key, int* pos, float* out, long long n, int n_threads) {
+  if (!key || !pos || !out || n <= 0 || (n & 1)) return -1;
+  {
+    std::lock_guard<std::mutex> lk(g_async_create);
+    if (!g_async) {
+      g_async = new AsyncDraw();
+      g_async->worker = std::thread([] { g_async->loop(); });
+      g_async->worker.detach();
+    }
   }
-  const long long abs_pos = (long long)pos0 + 4 * (last_attempt + 1);
-  long long blk = abs_pos / N, p = abs_pos % N;
-  if (p == 0 && blk > 0) { blk -= 1; p = N; }  // numpy leaves pos = 624 at a block's end (regeneration on the next read)
-  // (key may BE numpy's own state array: block 0 of `raw` is a copy, so the source and the target never overlap)
-  std::memcpy(key, &raw[(size_t)blk * N], N * sizeof(uint32_t));
-  *pos = (int)p;
+  AsyncDraw& a = *g_async;
+  {
+    std::lock_guard<std::mutex> lk(a.m);
+    if (a.state != 0) return -2;  // a draw is in flight (or its result has not been collected)
+    a.key = key;
+    a.pos = pos;
+    a.out = out;
+    a.n = n;
+    a.threads = n_threads;
+    a.state = 1;
+  }
+  a.cv.notify_all();
   return 0;
 }
 
-int vihds_host_abi_version(void) { return 1; }
+// result of the draw started last (0 = done); -3: none was started
+int vihds_np_randn_f32_wait(void) {
+  if (!g_async) return -3;
+  AsyncDraw& a = *g_async;
+  std::unique_lock<std::mutex> lk(a.m);
+  if (a.state == 0) return -3;
+  a.cv.wait(lk, [&] { return a.state == 3; });
+  a.state = 0;
+  return a.rc;
+}
+
+int vihds_host_abi_version(void) { return 2; }
 
 }  // extern "C"

@@ -7,12 +7,9 @@ defaults) reads the numbers from STATIC device buffers: while a step is captured
 (what to draw, where it goes) instead of drawing; before every replay the slots are refreshed in registration order -- the
 same draws, in the same order, from the same generators as the eager step -- through pinned staging buffers (used in turn,
 each reused only after the copy that read it has run) and asynchronous copies that the replay queues behind."""
-from concurrent.futures import ThreadPoolExecutor
-
 import torch
 
-ACTIVE = None
-_WORKER = None  # one helper thread: the next step's numpy draw (native code, GIL released) while this step is being queued  # the HostDraws being recorded (set by Training while it captures)
+ACTIVE = None  # the HostDraws being recorded (set by Training while it captures)
 
 
 class HostDraws(object):
@@ -66,24 +63,23 @@ class HostDraws(object):
         return k
 
     def prefetch(self):
-        """Start the prefetchable slots' NEXT draws on the helper thread.  Only the caller knows that the next consumer of
-        that random stream is this graph's next replay (Training.run: the next batch of the epoch); a prefetched draw that
-        is never replayed has advanced the stream by one unused draw."""
-        global _WORKER
+        """Start the prefetchable slots' NEXT draws on the native helper thread (fill.start / fill.finish: vihds/nprand.py).
+        Only the caller knows that the next consumer of that random stream is this graph's next replay (Training.run: the
+        next batch of the epoch); a prefetched draw that is never replayed has advanced the stream by one unused draw."""
         for slot in self.slots:
-            if slot[5] and slot[6] is None:
-                if _WORKER is None:
-                    _WORKER = ThreadPoolExecutor(max_workers=1, thread_name_prefix="vihds-hostdraws")
+            if slot[5] and slot[6] is None and hasattr(slot[1], "start"):
                 k = self._stage(slot)
-                slot[6] = (k, _WORKER.submit(slot[1], slot[2][k].numpy()))
+                if slot[1].start(slot[2][k].numpy()):
+                    slot[6] = k
+                else:  # not startable now: drawn at the refresh, into the buffer that was just staged
+                    slot[4] = k
 
     def refresh(self):
         for slot in self.slots:
             buf, fill, events = slot[0], slot[1], slot[3]
             if slot[6] is not None:  # drawn ahead by prefetch()
-                k, fut = slot[6]
-                slot[6] = None
-                fut.result()
+                k, slot[6] = slot[6], None
+                fill.finish()
             else:
                 k = self._stage(slot)
                 fill(slot[2][k].numpy())

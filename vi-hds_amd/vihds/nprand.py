@@ -23,6 +23,11 @@ def _lib():
             lib.vihds_np_randn_f32.restype = ctypes.c_int
             lib.vihds_np_randn_f32.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int),
                                                ctypes.POINTER(ctypes.c_double), ctypes.c_void_p, ctypes.c_longlong, ctypes.c_int]
+            lib.vihds_np_randn_f32_start.restype = ctypes.c_int
+            lib.vihds_np_randn_f32_start.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_longlong,
+                                                     ctypes.c_int]
+            lib.vihds_np_randn_f32_wait.restype = ctypes.c_int
+            lib.vihds_np_randn_f32_wait.argtypes = []
             _LIB = lib
         except OSError:
             _LIB = False
@@ -49,12 +54,26 @@ def _fingerprint():
     return (_POS.value, _KEY[0], _KEY[1], _KEY[396], _KEY[623])
 
 
+_IN_FLIGHT = False  # a Draw.start() whose finish() has not run yet
+
+
+def _collect_stray():
+    """A started draw that nobody finished (its consumer never came: the stream has advanced by that unused draw, as
+    hostdraws documents): wait for it, so that numpy's state is at rest before anybody reads or writes it."""
+    global _IN_FLIGHT, _LEFT
+    if _IN_FLIGHT:
+        _IN_FLIGHT = False
+        _lib().vihds_np_randn_f32_wait()
+        _LEFT = _fingerprint()
+
+
 def randn_f32(shape, out=None):
     """float32 array of `shape` drawn from numpy's GLOBAL RandomState exactly as np.random.randn(*shape).astype(np.float32)
     draws it; `out`: a writable C-contiguous float32 buffer of that many elements (e.g. the numpy view of a pinned tensor)."""
     shape = tuple(int(v) for v in shape)
     n = int(np.prod(shape)) if shape else 1
     lib = _lib()
+    _collect_stray()
     if out is None:
         out = np.empty(n, np.float32)
     flat = out.reshape(-1)
@@ -83,3 +102,43 @@ def randn_f32(shape, out=None):
     np.random.set_state((name, key, cpos.value, chg.value, cg.value))
     _LEFT = _fingerprint() if chg.value == 0 else None
     return out.reshape(shape)
+
+
+class Draw(object):
+    """A draw of `shape` normals from numpy's global stream into a host buffer: called, it draws now (`randn_f32`); `start`
+    / `finish` run the same draw on the library's native helper thread -- beside the Python that queues the current step, which
+    a Python helper thread cannot do (it needs the interpreter lock to start).  Between `start` and `finish` numpy's global
+    generator belongs to the draw: nobody else may use it (vihds/hostdraws.py starts a draw only when its consumer is
+    known to be the next user of the stream)."""
+
+    def __init__(self, shape):
+        self.shape = tuple(int(v) for v in shape)
+        self.n = int(np.prod(self.shape)) if self.shape else 1
+
+    def __call__(self, host):
+        randn_f32(self.shape, out=host)
+
+    def start(self, host):
+        """True: the draw is running natively (call `finish` before reading `host`).  False: not started (no library, an odd
+        count, or numpy's state is not the one our last draw left in place) -- the caller draws synchronously instead."""
+        global _LEFT, _IN_FLIGHT
+        lib = _lib()
+        _collect_stray()
+        flat = host.reshape(-1)
+        if (not lib or self.n == 0 or self.n % 2 or _LEFT is None or _fingerprint() != _LEFT or flat.dtype != np.float32
+                or flat.size != self.n or not flat.flags.c_contiguous):
+            return False
+        rc = lib.vihds_np_randn_f32_start(_ADDR, _ADDR + 624 * 4, flat.ctypes.data, self.n, _THREADS)
+        if rc != 0:
+            return False
+        _LEFT = None  # (the state is in motion until finish())
+        _IN_FLIGHT = True
+        return True
+
+    def finish(self):
+        global _LEFT, _IN_FLIGHT
+        _IN_FLIGHT = False
+        rc = _lib().vihds_np_randn_f32_wait()
+        if rc != 0:
+            raise RuntimeError("vihds_np_randn_f32_wait failed (%d)" % rc)
+        _LEFT = _fingerprint()

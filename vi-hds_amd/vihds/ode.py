@@ -157,10 +157,16 @@ class OdeModel(nn.Module):
             from vihds import hostdraws
 
             def draw(host=None, k=len(names)):
-                w = torch.cat([DeviceConditioner(D).cond.weight.detach() for _ in range(k)], 0)
-                if host is None:
-                    return w
-                host[:] = w.reshape(-1).numpy()
+                # what constructing k DeviceConditioner(D) modules draws from torch's CPU generator, without the modules:
+                # nn.Linear's own initialisation and xavier_uniform_ (a uniform_ of the weight each: the stream advances by
+                # the same amount whatever the bounds), then the N(2, 1.5) weights that are kept
+                w = torch.empty((k, D)) if host is None else torch.from_numpy(host).view(k, D)
+                for row in w:
+                    row = row.view(1, D)
+                    row.uniform_()
+                    row.uniform_()
+                    row.normal_(mean=2.0, std=1.5)
+                return w
 
             if hostdraws.capturing():  # a captured step: drawn before every replay (vihds/hostdraws.py)
                 z = hostdraws.ACTIVE.add((len(names), D), dev, draw)

@@ -68,6 +68,29 @@ class _RowIndices(torch.utils.data.Dataset):
         return int(i)
 
 
+class _ElboLook(object):
+    """The per-step look at the ELBO (reference training.py:331), one step late and without draining the stream: `push`
+    queues a copy of the step's ELBO into one of two pinned slots and an event behind it, `take` waits for that event only."""
+
+    def __init__(self):
+        self.host = torch.empty(2, dtype=torch.float32).pin_memory()
+        self.slots = [self.host[0:1], self.host[1:2]]
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.pos, self.pending = 0, None
+
+    def push(self, elbo):
+        """Queue the copy of `elbo` (a device scalar); returns the slot pushed before, not looked at yet (or None)."""
+        i, self.pos = self.pos, self.pos ^ 1
+        self.slots[i].copy_(elbo.detach().reshape(1), non_blocking=True)
+        self.events[i].record()
+        prev, self.pending = self.pending, i
+        return prev
+
+    def take(self, i):
+        self.events[i].synchronize()
+        return float(self.host[i])
+
+
 class Training:
     """Orchestrates IWAE training of the VAE (reference training.py:71-383)."""
 
@@ -91,6 +114,7 @@ class Training:
         self._graph_auto = default_get_value(p, "hip_graph", None) is None  # (automatic: a capture that fails falls back to eager launches)
         self.use_graph = bool(want_graph) and on_gpu
         self._pending_elbo = None
+        self._elbo_look = None
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
         # run(): with hip_graph, a single process and a NaN check at most once per epoch, an epoch is ONE graph launch
         self.epoch_graph = (self.use_graph and bool(default_get_value(p, "epoch_graph", True)) and self.shard is None
@@ -730,9 +754,15 @@ class Training:
             # replayed from a graph the look is one step late: step k is queued -- its host-side draws included -- before the
             # ELBO of step k-1 is read, so the host's work for the next step overlaps the GPU's for this one.  Every update
             # is gated on its own loss on the device, so the parameters are those of the last finite step either way.
-            prev, self._pending_elbo = self._pending_elbo, elbo
-            if prev is not None and self._loss_is_nan(prev):
+            # The look itself waits for nothing queued since: step k's ELBO is copied to a pinned slot behind step k, with an
+            # event behind the copy; one step later the host waits for THAT event and reads the slot.
+            if self._elbo_look is None:
+                self._elbo_look = _ElboLook()
+            self._pending_elbo = elbo
+            prev = self._elbo_look.push(elbo)
+            if prev is not None and math.isnan(self._elbo_look.take(prev)):
                 self._pending_elbo = None
+                self._elbo_look.pending = None
                 print("Cannot proceed with ELBO = nan. Exiting.")
                 return False
         elif self.nan_check_every > 0 and self._steps % self.nan_check_every == 0 and self._loss_is_nan(elbo):
@@ -787,8 +817,9 @@ class Training:
             nonlocal pending
             ok = True
             if self._pending_elbo is not None:  # (the per-step check that runs one step late: _run_batch)
-                last, self._pending_elbo = self._pending_elbo, None
-                if self._loss_is_nan(last):
+                self._pending_elbo = None
+                last, self._elbo_look.pending = self._elbo_look.pending, None
+                if last is not None and math.isnan(self._elbo_look.take(last)):
                     print("Cannot proceed with ELBO = nan. Exiting.")
                     ok = False
             if pending is not None and self.nan_check_every > 0:

@@ -43,8 +43,7 @@ class BaseVAE(nn.Module):
 
         shape = (int(n_batch), int(n_samples), int(self.n_theta))
         if hostdraws.capturing():  # a captured step: the draw happens before every replay (vihds/hostdraws.py)
-            return hostdraws.ACTIVE.add(shape, self.device, lambda host, sh=shape: nprand.randn_f32(sh, out=host),
-                                        prefetchable=True)
+            return hostdraws.ACTIVE.add(shape, self.device, nprand.Draw(shape), prefetchable=True)
         hostdraws.note(shape)
         if not (torch.cuda.is_available() and torch.device(self.device).type == "cuda"):
             return torch.from_numpy(nprand.randn_f32(shape)).to(self.device)
