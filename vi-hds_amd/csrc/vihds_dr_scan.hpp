@@ -242,6 +242,29 @@ struct RkChainTab : RkChain<SOLVER> {
     });
     return acc[NS];
   }
+  // the same step with its derivative: returns u' = Phi(u), d = dPhi/du
+  __device__ __forceinline__ static float step_d(const float* E, float u, float* us, float& d) {
+    float acc[NS + 1], dac[NS + 1];
+    VIHDS_UNROLL for (int s = 0; s <= NS; ++s) { acc[s] = u; dac[s] = 1.f; }
+    static_for<0, NS>([&](auto S) {
+      constexpr int sidx = decltype(S)::value;
+      const float v = acc[sidx], dv = dac[sidx];
+      us[sidx] = v;
+      const float p = fmaf(-v, v, v);
+      const float dp = fmaf(-2.f * v, dv, dv);
+      static_for<sidx + 1, NS + 1>([&](auto S1) {
+        constexpr int s1 = decltype(S1)::value;
+        if constexpr (C::wgt(s1, sidx) != 0.f) {
+          constexpr int e = C::index(s1, sidx);
+          constexpr bool pos = C::wgt(s1, sidx) > 0.f;
+          acc[s1] = pos ? fmaf(E[e], p, acc[s1]) : fmaf(-E[e], p, acc[s1]);
+          dac[s1] = pos ? fmaf(E[e], dp, dac[s1]) : fmaf(-E[e], dp, dac[s1]);
+        }
+      });
+    });
+    d = dac[NS];
+    return acc[NS];
+  }
 };
 
 // ---- affine maps and their scans over the 32 lanes of a trajectory -------------------------------------------------
@@ -310,8 +333,7 @@ __device__ __forceinline__ void wave_sync() {
 #endif
 constexpr int DR_SCAN_TPB = VIHDS_SCAN_TPB;  // trajectories per block: 2 per wavefront, 32 lanes each
 constexpr int DR_SCAN_THREADS = 32 * DR_SCAN_TPB;
-static_assert(DR_SCAN_THREADS % 64 == 0 && DR_SCAN_THREADS >= 128, "the x chains run in wavefront 0 beside at least one other wavefront");
-constexpr int DR_SCAN_CHAIN_LANES = 64 / DR_SCAN_TPB;  // lanes of wavefront 0 that walk one trajectory's x chain
+static_assert(DR_SCAN_THREADS % 64 == 0 && DR_SCAN_THREADS >= 128, "two trajectories per wavefront, at least two wavefronts");
 // Block barrier for data exchanged through LDS: waits for this wavefront's LDS operations only.  (__syncthreads() also
 // waits for every outstanding global store and returning atomic -- a full memory round trip on the critical path of the
 // block at each of its barriers; nothing in this kernel passes data between wavefronts through global memory.)
@@ -382,7 +404,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   constexpr int O_G = 0, O_U = O_G + NS * ITEMS * NT, O_B = O_U + NS * ITEMS * NT, O_Q = O_B + NS * ITEMS * NT,
                 O_Y = O_Q + 4 * ITEMS * NT, O_Z = O_Y + 4 * ITEMS * NT, O_A = O_Z + 2 * ITEMS * NT,
                 O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64,
-                O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4;
+                O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4, O_C = O_UK + DR_SCAN_TPB;
   auto VG = [&](int m) { return lds + O_G + (m * NT + tid) * NS; };
   // (the stage values of x are written by the chain wavefront, for all trajectories of the block at once: a trajectory's
   // 32 lane slots are rotated by its index, so that those eight stores fall into different LDS banks)
@@ -435,13 +457,12 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) o_in[m][j] = ob[j * a.T + kc];
   }
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) obK[j] = ob[j * a.T + K];
-  // the treatments of this lane's trajectory and of the one two places down (wavefront 1 evaluates the Hill terms of
-  // wavefront 0's trajectories), and the conditioner generator's state: fetched here, used after the first barrier
-  float cond_raw[2][2];
-  VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
-    const int bb = min(blockIdx.x * DR_SCAN_TPB + max(tib - 2 * q, 0), a.n - 1) / a.S;
-    cond_raw[q][0] = a.cond[bb * a.C + 0];
-    cond_raw[q][1] = a.cond[bb * a.C + 1];
+  // the treatments of this lane's trajectory and the conditioner generator's state: fetched here, used after the first barrier
+  float cond_raw[1][2];
+  {
+    const int bb = min(blockIdx.x * DR_SCAN_TPB + tib, a.n - 1) / a.S;
+    cond_raw[0][0] = a.cond[bb * a.C + 0];
+    cond_raw[0][1] = a.cond[bb * a.C + 1];
   }
   // the theta rows this lane writes the gradients of in the epilogue (slots l and l + 32)
   int out_row[2];
@@ -454,9 +475,6 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_ROLLED for (int k = tid + NT; k < a.T; k += NT) tT[k] = a.times[k];
     VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
       stv<4>(VQ(m), o_in[m]);
-      float half_[NS];
-      VIHDS_UNROLL for (int s = 0; s < NS; ++s) half_[s] = 0.5f;
-      stv<NS>(VU(m), half_);  // (padding steps beyond T-1 keep this harmless value; the chain fills the real ones)
     }
   };
   if (!THETA) {
@@ -493,7 +511,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     // the conditioner's inputs for this block (relevance masks, default flags, the device one-hot rows its tiling
     // selects: row (b S_total + s) mod B for sample (b, s)) -> LDS, for the wavefront that evaluates it later
-    float* t_rel = lds + O_G;                      // [E][D]   (the VG area is free until the gamma pass)
+    float* t_rel = lds + O_C;                      // [E][D]   (an area of its own behind the block's other fields:
+                                                   //  read by every wavefront, at its own pace, after barrier A)
     float* t_dev = t_rel + t.E * a.D;              // [TPB][D]
     float* t_dfl = t_dev + DR_SCAN_TPB * a.D;      // [E]
     const bool cnd = t.E > 0;
@@ -606,123 +625,102 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     return it;
   };
   auto stage_sigmoid = [&](const Item& it, int s) { return sigmoid_f(4.f * (fmaf(R::c(s), it.dt, it.t0) - tlag)); };
-  // ---- 1. the x chain's coefficient table for this lane's steps (RkChainTab: |w| h_k r sigmoid(4 (t_{k,s} - tlag)), state
-  //         independent).  The tables of the block's 8 trajectories sit where the gamma adjoints (VB) and the yfp / cfp
-  //         maps (VA) will go later. --------------------------------------------------------------------------------------
+  // ---- 1. the x chain's coefficients for this lane's steps (RkChainTab: |w| h_k r sigmoid(4 (t_{k,s} - tlag)), state
+  //         independent), in registers. ---------------------------------------------------------------------------------
   using CT = RkChainTab<SOLVER>;
-  // (step-major: the chain wavefront reads one step of all trajectories at a time -- consecutive addresses)
-  constexpr int HIW = CT::HI > 0 ? CT::HI : 1;
-  float* tC = lds + O_B + tib * CT::LO;   // [32 ITEMS][TPB][LO]: row k of this trajectory at tC + k * TPB * LO
-  float* tC2 = lds + O_A + tib * HIW;     // [32 ITEMS][TPB][HI]
-  constexpr int TS = DR_SCAN_TPB * CT::LO, TS2 = DR_SCAN_TPB * HIW;
-  VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+  float Eown[ITEMS][CT::NCW];
+  VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
     const Item it = item(m);
-    float hgr[NS], E[CT::NCW];
+    float hgr[NS];
     VIHDS_UNROLL for (int s = 0; s < NS; ++s) hgr[s] = (it.h * r) * stage_sigmoid(it, s);
-    CT::fill(hgr, E);
-    stv<CT::LO>(tC + (k0 + m) * TS, E);
-    if (CT::HI > 0) stv<HIW>(tC2 + (k0 + m) * TS2, E + CT::LO);
+    CT::fill(hgr, Eown[m]);
   }
-  block_sync_lds();  // every trajectory's parameters and coefficient table are in place
+  block_sync_lds();  // every trajectory's parameters and the conditioner's staged inputs are in place; VZ's draws are consumed
   VIHDS_SCAN_STOP(1)
 
-  // ---- 2. the x chains of the block's 8 trajectories, in wavefront 0, 8 lanes per trajectory (u = x / K, two dependent
-  //         instructions per stage, the table read one step ahead).  Stage values go to the owning lane's VU.  The other
-  //         wavefronts go through their parameter stage meanwhile. ---------------------------------------------------------
-  // gamma_s = gr_s (1 - u_s) at this lane's stages -> VG (after the chains; the last reader of the table)
-  auto gamma_pass = [&]() {
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+  // ---- 2. the x chain u_{k+1} = Phi_k(u_k) (u = x / K), IN PARALLEL over the trajectory's 32 lanes.  The chain is the one
+  //         nonlinear recurrence of the model; walked step by step (85 steps of 20 dependent instructions in one wavefront,
+  //         the other three waiting) it was 6 us of a block's 30.  Here it is solved as what it is, a system of equations in
+  //         the values g_l at the lanes' first steps:  g_{l+1} = F_l(g_l),  F_l = this lane's ITEMS steps, g_0 given.
+  //         Newton on that system: every lane walks its own steps from its current g_l, with the derivative (F_l, F_l');
+  //         the linearised recurrence  g_{l+1} = F_l + F_l' (g_l^new - g_l)  is a scan of affine maps over the lanes.  The
+  //         first guess is the closed form of the continuous equation du/dt = gr(t) u (1 - u), gr = r sigmoid(4 (t -
+  //         tlag)):  1/u - 1 = (1/u0 - 1) exp(-(G(t) - G(t0))),  G = r/4 softplus(4 (t - tlag)), off by the scheme's own
+  //         truncation error; convergence is quadratic, and since g_0 is exact, iteration i leaves the first i lanes exact
+  //         whatever the guess: 32 iterations always suffice (typically two).  The loop ends when an update moved nothing
+  //         by more than 1e-6 of its value; the stage values kept are those of the walk that preceded that update, so
+  //         every lane's steps are exact steps of the scheme and the values where two lanes meet agree to that 1e-6 --
+  //         the rounding level of the sequential walk itself.
+  float us_own[ITEMS][NS];
+  VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m)
+    VIHDS_UNROLL for (int s = 0; s < NS; ++s) us_own[m][s] = 0.5f;  // (padding steps beyond T-1 keep this harmless value)
+  {
+    const float u0 = th(M::SI + 0) * frcp(clampf(th(M::S_K), 0.f, 4.f));
+    auto softplus = [](float z) { return fmaxf(z, 0.f) + __logf(1.f + __expf(-fabsf(z))); };
+    const float tl = tT[min(k0, K)];
+    const float dG = 0.25f * r * (softplus(4.f * (tl - tlag)) - softplus(4.f * (tT[0] - tlag)));
+    float g = l == 0 ? u0 : frcp(fmaf(frcp(u0) - 1.f, __expf(-dG), 1.f));
+    float uend = g;
+    for (int iter = 0; iter < 32; ++iter) {
+      float u = g, da = 1.f;
+      VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
+        if (k0 + m < K) {
+          float d;
+          u = CT::step_d(Eown[m], u, us_own[m], d);
+          da *= d;
+        }
+      }
+      uend = u;
+      Aff mp;
+      mp.a = da;
+      mp.b = fmaf(-da, g, u);
+      const Aff inc = scan_up32(mp, lane);               // lane l: this lane's map after those of the lanes below it
+      const float end_new = fmaf(inc.a, u0, inc.b);      // the new value at the first step of lane l + 1
+      float gn = lane_read(end_new, (lane & 32) + ((l + 31) & 31));
+      gn = l == 0 ? u0 : gn;
+      // (NaN-safe: a trajectory whose parameters are not finite leaves the loop at once, as non-finite as the walk would be)
+      const bool moved = fabsf(gn - g) > 1e-6f * fabsf(gn);
+      if (__builtin_amdgcn_ballot_w64(moved) == 0ull) break;
+      g = gn;
+    }
+    if (l == 31) uK[tib] = uend;  // (lanes beyond the last step hold the identity: the last lane's value is x(T-1) / K)
+    VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
-      float E[CT::NCW], g[NS], us[NS];
-      ldv<CT::LO>(tC + it.kc * TS, E);
-      if (CT::HI > 0) ldv<HIW>(tC2 + it.kc * TS2, E + CT::LO);
-      ldv<NS>(VU(m), us);
+      float gm[NS];
       const float invh = frcp(it.h);
       static_for<0, NS>([&](auto S) {
         constexpr int sidx = decltype(S)::value;
-        const float gr = CT::template hgr<sidx>(E) * invh;
-        g[sidx] = fmaf(-gr, us[sidx], gr);
+        const float gr = CT::template hgr<sidx>(Eown[m]) * invh;
+        gm[sidx] = fmaf(-gr, us_own[m][sidx], gr);  // gamma_s = gr_s (1 - u_s)
       });
-      stv<NS>(VG(m), g);
+      stv<NS>(VU(m), us_own[m]);
+      stv<NS>(VG(m), gm);
     }
-  };
-  // (Wavefront 0 meets the others at the two barriers below from its own branch: a workgroup barrier counts arrivals,
-  // it does not care which instruction a wavefront arrives from.)
-  if (wave == 0) {
-    const int t = lane / DR_SCAN_CHAIN_LANES;
-    const float* part = par_of(t);
-    float u = part[a.slot_row[M::SI + 0]] * frcp(clampf(part[a.slot_row[M::S_K]], 0.f, 4.f));
-    const float* Ct = lds + O_B + t * CT::LO;
-    const float* Ct2 = lds + O_A + t * HIW;
-    auto row = [&](int k, float* E) {
-      ldv<CT::LO>(Ct + k * TS, E);
-      if (CT::HI > 0) ldv<HIW>(Ct2 + k * TS2, E + CT::LO);
-    };
-    // One group = the ITEMS steps that belong to one lane slot L of the trajectory (their stage values go to that slot:
-    // one address computation per group).  Two groups per trip, the table rows of the next one in flight; a lone
-    // wavefront issues an instruction every 5-9 cycles whatever it is, so the loop is kept to the tableau's FMAs, the
-    // table loads and the stores.  (The lanes of a chain hold the same values and store them to the same address.)
-    auto rows = [&](int L, float (*E)[CT::NCW]) {
-      VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) row(min(L * ITEMS + m, K - 1), E[m]);
-    };
-    auto group = [&](int L, float (*E)[CT::NCW], int n_valid) {
-      float* dst = lds + O_U + (t * 32 + ((L + t) & 31)) * NS;
-      VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m)
-        if (m < n_valid) {
-          float us[NS];
-          u = CT::step(E[m], u, us);
-          stv<NS>(dst + m * NT * NS, us);
-        }
-    };
-    const int NL = K / ITEMS;  // complete groups
-    float Ea[ITEMS][CT::NCW], Eb[ITEMS][CT::NCW];
-    rows(0, Ea);
-    int L = 0;
-    for (; L + 2 <= NL; L += 2) {
-      rows(L + 1, Eb);
-      group(L, Ea, ITEMS);
-      rows(L + 2, Ea);
-      group(L + 1, Eb, ITEMS);
-    }
-    for (; L * ITEMS < K; ++L) {  // at most one complete group and a partial one
-      group(L, Ea, min(ITEMS, K - L * ITEMS));
-      rows(L + 1, Ea);
-    }
-    uK[t] = u;
-#ifdef VIHDS_SCAN_STAMPS
-    VIHDS_SCAN_STOP(11)
-#endif
-    block_sync_lds();  // the chains' stage values are in place
-#ifdef VIHDS_SCAN_STAMPS
-    VIHDS_SCAN_STOP(12)
-#endif
-    gamma_pass();
-    block_sync_lds();  // the table is dead from here on: VB may be written
   }
+#ifdef VIHDS_SCAN_STAMPS
+  VIHDS_SCAN_STOP(11)
+#endif
 
-  // ---- Hill fractions (dr_constant.py:58-73) of the block's trajectories, while the chains run: wavefronts 1-3 for their
-  //      own two trajectories, wavefront 1 also for wavefront 0's.  Lanes 0..7 of a half-wave hold the power terms
-  //      (v1: (K6 c6)^n, (K12 c12)^n, (1 + K6 c6 + K12 c12)^n for LuxR and LasR; v2: four terms), as in DrLanes::hill.
-  auto treatments = [&](int q, float* c) {  // q = 0: this lane's trajectory; 1: the one two places down
-    c[0] = clampf(expf(cond_raw[q][0]) - 1.f, 1e-12f, 1e6f);
-    c[1] = clampf(expf(cond_raw[q][1]) - 1.f, 1e-12f, 1e6f);
+  // ---- Hill fractions (dr_constant.py:58-73) of this wavefront's two trajectories.  Lanes 0..7 of a half-wave hold the
+  //      power terms (v1: (K6 c6)^n, (K12 c12)^n, (1 + K6 c6 + K12 c12)^n for LuxR and LasR; v2: four terms), as in
+  //      DrLanes::hill.
+  auto treatments = [&](float* c) {
+    c[0] = clampf(expf(cond_raw[0][0]) - 1.f, 1e-12f, 1e6f);
+    c[1] = clampf(expf(cond_raw[0][1]) - 1.f, 1e-12f, 1e6f);
   };
-  if (wave != 0) {
+  {
     // Every thread of the block read the generators' step counters before the barrier above (scalar loads, complete at its
-    // lgkmcnt(0)), so the block may take its tickets: the wavefront with the least to do until the chains are through
-    // does, and the atomics' round trips (the compiler waits for a returning atomic at the end of the branch) fall
-    // into its wait for barrier B.  The holder of the last ticket advances the step at the very end of the kernel
-    // (rng_advance; see dr_lane_theta_stage).
+    // lgkmcnt(0)), so the block may take its tickets.  The holder of the last ticket advances the step at the very end of
+    // the kernel (rng_advance; see dr_lane_theta_stage).
     if (THETA && tid == TW * 64) {
       if (t.rng) tk.u = atomicAdd(&t.rng[3], 1u);
       if (t.crng) tk.c = atomicAdd(&t.crng[3], 1u);
     }
-    VIHDS_ROLLED for (int pass = 0; pass < (wave == 1 ? 2 : 1); ++pass) {
-      const int tp = pass == 0 ? tib : tib - 2;
-      float* pp = par_of(tp);
+    {
+      float* pp = par;
       auto tht = [&](int slot) { return pp[a.slot_row[slot]]; };
       float cc[2];
-      if (pass == 0) treatments(0, cc); else treatments(1, cc);
+      treatments(cc);
       const int j = l & 7;
       const float nR = clampf(tht(M::S_nR), 0.5f, 3.f), nS = clampf(tht(M::S_nS), 0.5f, 3.f);
       float base, ex, fR_, fS_;
@@ -739,7 +737,9 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         base = j == 0 ? cc[0] : (j == 1 ? eR12 * cc[1] : (j == 2 ? eS6 * cc[0] : (j == 3 ? cc[1] : 1.f)));
         ex = j < 2 ? nR : (j < 4 ? nS : 1.f);
       }
-      const float pw = powf(base, ex);
+      // base^ex as 2^(ex log2 base) on v_log_f32 / v_exp_f32 (base > 0 by its clamps; the terms that matter have a base
+      // near 1, where the product's rounding is below 1e-6; libm's powf was ~200 instructions on every wavefront's path)
+      const float pw = __builtin_amdgcn_exp2f(ex * __builtin_amdgcn_logf(base));
       if (VERSION == 1) {
         fR_ = (bcast8<0>(pw) + bcast8<1>(pw)) / bcast8<2>(pw);
         fS_ = (bcast8<3>(pw) + bcast8<4>(pw)) / bcast8<5>(pw);
@@ -757,11 +757,13 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         pp[65] = fS_;
       }
     }
-    if (THETA && t.E > 0 && wave == DR_SCAN_THREADS / 64 - 1) {
-      // device conditioner (ode.py:43-58, with its .repeat tiling) for the block's trajectories, off the critical path:
-      // the rows it produces (aR, aS) are first read after the chains.  One generator call for the E x D weights.
-      float* t_cw = lds + O_Z;  // [E][D] (the VZ area again: the draws it held were consumed before the last barrier)
-      const float* t_rel = lds + O_G;
+    if (THETA && t.E > 0) {
+      // device conditioner (ode.py:43-58, with its .repeat tiling) for THIS wavefront's two trajectories.  Every wavefront
+      // generates the E x D weights itself (one generator call per weight, the same counters: the same numbers) into its
+      // own corner of LDS -- its trajectories' draw slots, which it has consumed itself -- and writes the rows (aR, aS) of
+      // its own trajectories only: nothing in this stage crosses wavefronts, so no workgroup barrier follows it.
+      float* t_cw = lds + O_Z + wave * 128;  // [E][D], E D <= 128 (checked by the launcher)
+      const float* t_rel = lds + O_C;
       const float* t_dev = t_rel + t.E * a.D;
       const float* t_dfl = t_dev + DR_SCAN_TPB * a.D;
       const int ed = t.E * a.D;
@@ -772,8 +774,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         t_cw[e] = t.w_mean + t.w_std * zz;
       }
       wave_sync();
-      for (int w = lane; w < DR_SCAN_TPB * t.E; w += 64) {
-        const int tt = w / t.E, e = w - tt * t.E;
+      if (lane < 2 * t.E) {  // (E <= 32)
+        const int tl = lane >= t.E ? 1 : 0, e = lane - tl * t.E, tt = 2 * wave + tl;
         const int it0 = blockIdx.x * DR_SCAN_TPB + tt;
         const bool lv = it0 < a.n;
         const int it = lv ? it0 : a.n - 1;
@@ -785,21 +787,16 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         par_of(tt)[t.cond_row0 + e] = val;
       }
     }
-#ifdef VIHDS_SCAN_STAMPS
-    VIHDS_SCAN_STOP(11)
-#endif
-    block_sync_lds();  // the chains' stage values are in place
+    wave_sync();  // this wavefront's Hill terms and conditioner rows are in its trajectories' parameters
 #ifdef VIHDS_SCAN_STAMPS
     VIHDS_SCAN_STOP(12)
 #endif
-    gamma_pass();
-    block_sync_lds();
   }
   VIHDS_SCAN_STOP(2)
 
   // ---- parameters of this trajectory (every lane of its 32 holds them) -----------------------------------------
   float c[2];
-  treatments(0, c);
+  treatments(c);
   const float Kc = clampf(th(M::S_K), 0.f, 4.f), invK = frcp(Kc);
   const float rc = th(M::S_rc);
   typename D::HillTerm H;
@@ -1302,7 +1299,7 @@ inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st, co
   const int nb_max = min(a.B, (DR_SCAN_TPB - 1) / a.S + 2);
   if (ts) {
     if (ts->P > 64 || ts->n_rows > 64 || ts->E > 32) return VIHDS_E_UNSUPPORTED;
-    if (dr_scan_theta_floats(ts->E, a.D) > (size_t)items * DR_SCAN_THREADS) return VIHDS_E_UNSUPPORTED;
+    if (ts->E * a.D > 128) return VIHDS_E_UNSUPPORTED;  // (every wavefront keeps the conditioner's weights in 128 floats)
     if (a.B >= (1 << 24) || a.D >= (1 << 24)) return VIHDS_E_UNSUPPORTED;
   }
   for (int q = 0; q < DrConstant<VERSION>::NSLOT + 4; ++q)
@@ -1310,7 +1307,7 @@ inline int launch_dr_scan_train(int solver, const OdeArgs& a, hipStream_t st, co
   const dim3 grid((a.n + DR_SCAN_TPB - 1) / DR_SCAN_TPB), block(DR_SCAN_THREADS);
 #define VIHDS_SCASE2(SV, IT)                                                                                \
   case IT: {                                                                                                \
-    const size_t lds = dr_scan_lds_floats<SV>(IT) * sizeof(float);                                          \
+    const size_t lds = (dr_scan_lds_floats<SV>(IT) + (ts ? dr_scan_theta_floats(ts->E, a.D) : 0)) * sizeof(float); \
     auto kern = dr_scan_train_kernel<VERSION, SV, IT>;                                                      \
     auto kern_t = dr_scan_train_theta_kernel<VERSION, SV, IT>;                                              \
     static bool opted = false, opted_t = false;                                                             \
