@@ -103,8 +103,11 @@ struct DrLanes {
     const float nR = clampf(th(a, M::S_nR, i), 0.5f, 3.f), nS = clampf(th(a, M::S_nS, i), 0.5f, 3.f);
     if (VERSION == 1) {
       const bool isR = j < 3;
-      const float K6 = clampf(th(a, isR ? M::S_H0 : M::S_H2, i), 1e-12f, 1.f);
-      const float K12 = clampf(th(a, isR ? M::S_H1 : M::S_H3, i), 1e-12f, 1.f);
+      // (both rows read, then chosen: a lane-dependent slot index turns a.slot_row[] into a per-lane global load from the
+      // kernel-argument segment, a memory round trip ahead of the row's own load)
+      const float h0 = th(a, M::S_H0, i), h1 = th(a, M::S_H1, i), h2 = th(a, M::S_H2, i), h3 = th(a, M::S_H3, i);
+      const float K6 = clampf(isR ? h0 : h2, 1e-12f, 1.f);
+      const float K12 = clampf(isR ? h1 : h3, 1e-12f, 1.f);
       const float ta = K6 * c[0], tb = K12 * c[1];
       const int k = isR ? j : j - 3;
       H.base = j >= 6 ? 1.f : (k == 0 ? ta : (k == 1 ? tb : 1.f + ta + tb));

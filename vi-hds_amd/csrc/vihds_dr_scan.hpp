@@ -356,6 +356,40 @@ __host__ __device__ inline size_t dr_scan_lds_floats(int items) {
   return (steps > red ? steps : red) + (size_t)(32 * items + 4) + DR_SCAN_TPB;
 }
 #define VIHDS_ROLLED _Pragma("clang loop unroll(disable)")
+// the loops over a lane's ITEMS steps: rolled unless VIHDS_ITEMBIT_<n> is 1 (three independent
+// iterations side by side hide each other's latencies, at the price of registers: the mask is what fits 256 of them)
+#ifndef VIHDS_ITEMBIT_0
+#define VIHDS_ITEMBIT_0 1
+#endif
+#ifndef VIHDS_ITEMBIT_1
+#define VIHDS_ITEMBIT_1 1
+#endif
+#ifndef VIHDS_ITEMBIT_2
+#define VIHDS_ITEMBIT_2 1
+#endif
+#ifndef VIHDS_ITEMBIT_3
+#define VIHDS_ITEMBIT_3 1
+#endif
+#ifndef VIHDS_ITEMBIT_4
+#define VIHDS_ITEMBIT_4 0
+#endif
+#ifndef VIHDS_ITEMBIT_5
+#define VIHDS_ITEMBIT_5 1
+#endif
+#ifndef VIHDS_ITEMBIT_6
+#define VIHDS_ITEMBIT_6 0
+#endif
+#ifndef VIHDS_ITEMBIT_7
+#define VIHDS_ITEMBIT_7 1
+#endif
+#ifndef VIHDS_ITEMBIT_8
+#define VIHDS_ITEMBIT_8 1
+#endif
+#define VIHDS_ITEMLOOP_0 _Pragma("clang loop unroll(disable)")
+#define VIHDS_ITEMLOOP_1 _Pragma("clang loop unroll(full)")
+#define VIHDS_ITEMLOOP_SEL(B) VIHDS_ITEMLOOP_##B
+#define VIHDS_ITEMLOOP_PICK(B) VIHDS_ITEMLOOP_SEL(B)
+#define VIHDS_ITEMLOOP(N) VIHDS_ITEMLOOP_PICK(VIHDS_ITEMBIT_##N)
 // profiling aid: kernel_variant = 3 | (phase << 8) makes the kernel return after that phase (tests/probe/scan_phases.py)
 #ifdef VIHDS_SCAN_STAMPS
 // profiling build (tests/probe/scan_stamps.py): every wavefront writes the 100 MHz wall clock at each phase boundary
@@ -726,8 +760,11 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       float base, ex, fR_, fS_;
       if (VERSION == 1) {
         const bool isR = j < 3;
-        const float K6 = clampf(tht(isR ? M::S_H0 : M::S_H2), 1e-12f, 1.f);
-        const float K12 = clampf(tht(isR ? M::S_H1 : M::S_H3), 1e-12f, 1.f);
+        // (both rows read, then chosen: `tht(isR ? a : b)` made the lane-dependent slot index a per-lane GLOBAL load from
+        // the kernel-argument segment -- a memory round trip of ~1 us in every wavefront's path)
+        const float h0 = tht(M::S_H0), h1 = tht(M::S_H1), h2 = tht(M::S_H2), h3 = tht(M::S_H3);
+        const float K6 = clampf(isR ? h0 : h2, 1e-12f, 1.f);
+        const float K12 = clampf(isR ? h1 : h3, 1e-12f, 1.f);
         const float ta = K6 * cc[0], tb = K12 * cc[1];
         const int k = isR ? j : j - 3;
         base = j >= 6 ? 1.f : (k == 0 ? ta : (k == 1 ? tb : 1.f + ta + tb));
@@ -846,7 +883,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   float ys[NSP];  // state at this lane's first grid point
   {
     v2f la[2] = {{1.f, 1.f}, {1.f, 1.f}}, lb[2] = {{0.f, 0.f}, {0.f, 0.f}};  // composed maps of the two pairs
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+    VIHDS_ITEMLOOP(0) for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
       float gam[NS];
       ldv<NS>(VG(m), gam);
@@ -874,7 +911,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   {
     v2f cur2[2] = {{ys[RFP], ys[WW]}, {ys[LUXR], ys[LASR]}};
     v2f la = {1.f, 1.f}, lb = {0.f, 0.f};
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+    VIHDS_ITEMLOOP(1) for (int m = 0; m < ITEMS; ++m) {
       const Item it = item(m);
       float gam[NS];
       ldv<NS>(VG(m), gam);
@@ -935,7 +972,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       a480b += qo[3] * x * w;
     };
     float cz[2] = {ys[YFP], ys[CFP]};
-    VIHDS_ROLLED for (int m = 0; m < ITEMS; ++m) {
+    VIHDS_ITEMLOOP(2) for (int m = 0; m < ITEMS; ++m) {
       const bool valid = k0 + m < K;
       float qo[4], obk[4], y4[4], ab[4], us[NS];
       ldv<4>(VQ(m), obk);
@@ -987,7 +1024,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     const float gK2[2] = {ginj(YFP, qK, xK), ginj(CFP, qK, xK)};
     {
       Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
-      VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+      VIHDS_ITEMLOOP(3) for (int m = ITEMS - 1; m >= 0; --m) {
         float qq[4], ab[4], us[NS];
         ldv<4>(VQ(m), qq);
         ldv<4>(VA(m), ab);
@@ -998,7 +1035,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     v2f dz2 = {0.f, 0.f}, sz2 = {0.f, 0.f}, drs2 = {0.f, 0.f}, srs2 = {0.f, 0.f};
     v2f svt2 = {0.f, 0.f}, svr2 = {0.f, 0.f}, c1b2 = {0.f, 0.f}, c2b2 = {0.f, 0.f};
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+    VIHDS_ITEMLOOP(4) for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
       float gam[NS], us[NS], qq[4], y4[4], z2[2], ab[4];
@@ -1083,7 +1120,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     constexpr int jp = inj ? 1 : 0;   // the pair's constants (delta2 / F12)
     const float gK[2] = {ginj(jA, qK, xK), ginj(jB, qK, xK)};
     Aff lm[2] = {{1.f, 0.f}, {1.f, 0.f}};
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+    VIHDS_ITEMLOOP(5) for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       float gam[NS], us[NS], qq[4], ab[4];
       ldv<NS>(VG(m), gam);
@@ -1103,7 +1140,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     v2f lam = {lane_entry(lm[0]), lane_entry(lm[1])};
     v2f d2 = {degb[jA], degb[jB]}, s2 = {sv[jA], sv[jB]};
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+    VIHDS_ITEMLOOP(6) for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
       float gam[NS], y4[4], tag[4], gb[NS];
@@ -1149,7 +1186,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     };
     const float gK = qK[0] + qK[1] * yend[RFP] + qK[2] * fmaf(a530, yend[WW], yend[YFP]) + qK[3] * fmaf(a480, yend[WW], yend[CFP]);
     Aff lm = {1.f, 0.f};
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+    VIHDS_ITEMLOOP(7) for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], Fz[NS], kv[NS], qq[4], y4[4], z2[2], tag[4], A, dB;
       x_stage(m, it, sg, us, ax, gbo, Jx);
@@ -1166,7 +1203,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       lane_step(lm, m, tag[0], tag[1], gK);
     }
     float lam = lane_entry(lm);
-    VIHDS_ROLLED for (int m = ITEMS - 1; m >= 0; --m) {
+    VIHDS_ITEMLOOP(8) for (int m = ITEMS - 1; m >= 0; --m) {
       const Item it = item(m);
       const bool last = k0 + m == K - 1;
       float sg[NS], us[NS], ax[NS], gbo[NS], Jx[NS], kbar[NS], tag[4];
