@@ -562,9 +562,24 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     const float* relp = cnd ? t.rel : a.times;
     const float* devp = cnd ? a.dev1hot : a.times;
     const int* dflp = cnd ? t.is_default : t.kind;
-    const float pre_rel = relp[cnd ? min(tid, ed - 1) : 0];
-    const float pre_dev = devp[cnd ? dev_row(min(tid, td - 1)) : 0];
-    int pre_dfl = dflp[cnd ? min(tid, t.E - 1) : 0];
+    // Fast path (E rows x D devices fit a trajectory's 32 lanes, D padded to a power of two -- every shipped model): lane
+    // (e, d) of the trajectory holds ITS OWN operands of row e's dot product, loaded here with everything else; the weights
+    // are generated by the lanes that use them, the sum over d is four DPP adds, and nothing of the conditioner goes
+    // through LDS (the general path below stages the inputs for a loop per row).
+    int clog = 0;
+    while ((1 << clog) < Dd) ++clog;
+    const bool cfast = cnd && (t.E << clog) <= 32;
+    const int ce = l >> clog, cd = l & ((1 << clog) - 1);
+    const bool cmine = cfast && ce < t.E && cd < a.D;
+    const unsigned int rr_own = ((unsigned int)b * (unsigned int)t.S_total + (unsigned int)(t.s_off + (i - b * a.S))) % (unsigned int)B;
+    const float cf_rel = relp[cmine ? ce * a.D + cd : 0];
+    const float cf_dev = devp[cmine ? (int)(__umul24(rr_own, (unsigned int)Dd) + (unsigned int)cd) : 0];
+    const int cf_dfl = dflp[cmine ? ce : 0];
+    const float cf_z = (cmine && !t.crng) ? t.z[ce * a.D + cd] : 0.f;
+    const bool cslow = cnd && !cfast;
+    const float pre_rel = relp[cslow ? min(tid, ed - 1) : 0];
+    const float pre_dev = devp[cslow ? dev_row(min(tid, td - 1)) : 0];
+    int pre_dfl = dflp[cslow ? min(tid, t.E - 1) : 0];
     // (the dependent pair: the rows of mu_p / log-precision_p in the encoder's table)
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const int rm = t.q_rows ? q_raw[q][0] : pqc[q], rp = t.q_rows ? q_raw[q][1] : pqc[q];
@@ -588,7 +603,23 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_SCAN_STOP(14)
 #endif
     stage_grid_and_observations();
-    if (cnd) {
+    float cf_val = 0.f;
+    if (cfast) {
+      // device conditioner (ode.py:43-58, with its .repeat tiling), row e of this trajectory: relu(sum_d w[e,d] dev[d]
+      // rel[e,d]) on top of the default flag; w = mean + std z, z from the conditioner's generator (one call per weight,
+      // counter e D + d: the numbers of the general path) or from the caller's draw
+      float zz = cf_z;
+      if (t.crng) zz = philox_normal((unsigned int)(ce * a.D + cd), 0xC04Du, cstep, 0u, ck0, ck1, 0);
+      float sm = cmine ? (t.w_mean + t.w_std * zz) * (cf_dev * cf_rel) : 0.f;
+      if (clog >= 1) sm += dpp_all<0xB1>(sm);   // quad_perm [1,0,3,2]
+      if (clog >= 2) sm += dpp_all<0x4E>(sm);   // quad_perm [2,3,0,1]
+      if (clog >= 3) sm += dpp_all<0x141>(sm);  // row_half_mirror
+      if (clog >= 4) sm += dpp_all<0x140>(sm);  // row_mirror
+      if (clog >= 5) sm += lane_read(sm, lane ^ 16);
+      cf_val = (cf_dfl ? 1.f : 0.f) + fmaxf(sm, 0.f);
+      if (cmine && cd == 0) par[t.cond_row0 + ce] = cf_val;  // (its copy in theta: with the stage's other stores, below)
+    }
+    if (cslow) {
       asm volatile("" : "+v"(pre_dfl));  // (keeps the flag's comparison here, behind the requests above)
       if (tid < ed) t_rel[tid] = pre_rel;
       if (tid < td) t_dev[tid] = pre_dev;
@@ -636,6 +667,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       if (t.log_q) t.log_q[i] = lq;
       if (t.log_p) t.log_p[i] = lp;
     }
+    if (live && cmine && cd == 0) t.theta[(size_t)(t.cond_row0 + ce) * n + i] = cf_val;
     wave_sync();  // this trajectory's theta rows are in `par` (its own lanes wrote them)
 #ifdef VIHDS_SCAN_STAMPS
     VIHDS_SCAN_STOP(15)
@@ -794,8 +826,9 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         pp[65] = fS_;
       }
     }
-    if (THETA && t.E > 0) {
-      // device conditioner (ode.py:43-58, with its .repeat tiling) for THIS wavefront's two trajectories.  Every wavefront
+    if (THETA && t.E > 0 && (t.E << [&] { int c = 0; while ((1 << c) < max(a.D, 1)) ++c; return c; }()) > 32) {
+      // device conditioner, general path (the rows did not fit the trajectory's lanes: see the sampling stage) for THIS
+      // wavefront's two trajectories.  Every wavefront
       // generates the E x D weights itself (one generator call per weight, the same counters: the same numbers) into its
       // own corner of LDS -- its trajectories' draw slots, which it has consumed itself -- and writes the rows (aR, aS) of
       // its own trajectories only: nothing in this stage crosses wavefronts, so no workgroup barrier follows it.
