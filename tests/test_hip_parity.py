@@ -1458,6 +1458,61 @@ def test_time_parallel_training_kernel_matches_forward_plus_adjoint(model, solve
                                  obs.data_ptr(), lp.data_ptr(), g3.data_ptr(), st) == hip.E_UNSUPPORTED
 
 
+@pytest.mark.parametrize("solver", ["rk4", "midpoint", "modeuler", "euler"])
+def test_time_parallel_x_chain_at_extreme_growth_parameters(solver):
+    """The time-parallel kernel solves the one nonlinear recurrence of the model, the OD chain, by Newton's method over the
+    lanes' first values from a closed-form first guess (csrc/vihds_dr_scan.hpp, stage 2) -- two iterations at ordinary
+    parameters.  Here the parameters are not ordinary: growth rates at and beyond both clamps (0 and 4 per hour, with steps
+    of 0.3 h: r h = 1.2, where the scheme's own truncation error makes the continuous guess poor), lags before the first
+    and after the last time point, capacities at both clamps and initial densities above the capacity (u0 > 1: decay).  The
+    chain must still be the one the step-by-step kernels walk: log-likelihoods and gradients against the lane kernels'
+    forward + adjoint pair."""
+    import ctypes
+    from vihds import hip, ops
+
+    L = hip.lib()
+    model = "dr_constant"
+    slots = hip.model_slots(model)
+    row_of = {n: i for i, n in enumerate(slots)}
+    st = torch.cuda.current_stream().cuda_stream
+    B, S, T = 6, 64, 86
+    th = _synthetic_theta(slots, B, S, 31)
+    g = torch.Generator().manual_seed(17)
+    pick = lambda vals: torch.tensor(vals)[torch.randint(0, len(vals), (B, S), generator=g)]
+    th["r"] = pick([-1.0, 0.0, 0.01, 0.5, 2.0, 4.0, 9.0])
+    th["tlag"] = pick([-10.0, 0.0, 1.0, 8.0, 24.9, 60.0])
+    th["K"] = pick([0.0011, 0.05, 1.0, 4.0, 7.0])
+    th["init_x"] = pick([1e-6, 0.002, 0.05, 0.5])
+    theta = torch.stack([th[n] for n in slots]).to(DEV)
+    cond = torch.log1p(torch.rand(B, 2, generator=g) * 1000.0).to(DEV)
+    times = (torch.arange(T, dtype=torch.float32) * 0.3).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+    prob = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=2).bind(B, S, T)
+    prob.logp_grad_broadcast = 1
+    prob3 = ops.OdeProblemSpec(model, solver, row_of, len(slots), C=2, kernel_variant=3).bind(B, S, T)
+    traj = torch.empty(T, 8, B, S, device=DEV); xpred = torch.empty(T, 4, B, S, device=DEV)
+    logp = torch.empty(4, B, S, device=DEV); ones = torch.ones(B, S, device=DEV)
+    g_ref = torch.empty_like(theta)
+    args = (theta.data_ptr(), cond.data_ptr(), None, times.data_ptr(), obs.data_ptr())
+    assert L.vihds_ode_fwd(ctypes.byref(prob), *args, None, traj.data_ptr(), xpred.data_ptr(), logp.data_ptr(), st) == 0
+    assert L.vihds_ode_bwd(ctypes.byref(prob), *args, None, traj.data_ptr(), None, None, ones.data_ptr(),
+                           g_ref.data_ptr(), None, None, st) == 0
+    logp3 = torch.full_like(logp, float("nan")); g3 = torch.full_like(theta, float("nan"))
+    assert L.vihds_ode_logp_grad(ctypes.byref(prob3), *args, logp3.data_ptr(), g3.data_ptr(), st) == 0, L.vihds_last_error()
+    torch.cuda.synchronize()
+    # (a density 450 x the capacity with r h = 1.2 makes the explicit scheme itself overflow: those trajectories are
+    # non-finite in the step-by-step kernels too, and must be so here -- the Newton loop leaves at the first NaN)
+    ok = torch.isfinite(logp).all(0) & torch.isfinite(g_ref).all(0) & (logp.abs().amax(0) < 1e30)
+    assert float(ok.float().mean()) > 0.75
+    ok3 = torch.isfinite(logp3).all(0) & torch.isfinite(g3).all(0) & (logp3.abs().amax(0) < 1e30)
+    assert bool(ok3[ok].all())  # (finite wherever the step-by-step pair is; its adjoint also loses some r = 0 samples)
+    # per trajectory: a sample whose OD decays from several times its capacity has log-likelihoods of 1e6 next to ones of 1e2
+    scale = logp.abs().amax(0, keepdim=True).clamp_min(1.0)
+    assert float(((logp3 - logp).abs() / scale)[:, ok].max()) < 2e-5
+    gscale = g_ref.abs().amax(0, keepdim=True).clamp_min(1e-3)
+    assert float(((g3 - g_ref).abs() / gscale)[:, ok].max()) < 1e-3
+
+
 @pytest.mark.parametrize("B,S", [(36, 1000), (234, 1000)])
 def test_time_parallel_training_kernel_at_the_config3_sizes(B, S):
     """BASELINE config 3's shapes (36 000 and 234 000 trajectories, T = 86, rk4) through the time-parallel training kernel:

@@ -713,7 +713,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   //         first guess is the closed form of the continuous equation du/dt = gr(t) u (1 - u), gr = r sigmoid(4 (t -
   //         tlag)):  1/u - 1 = (1/u0 - 1) exp(-(G(t) - G(t0))),  G = r/4 softplus(4 (t - tlag)), off by the scheme's own
   //         truncation error; convergence is quadratic, and since g_0 is exact, iteration i leaves the first i lanes exact
-  //         whatever the guess: 32 iterations always suffice (typically two).  The loop ends when an update moved nothing
+  //         whatever the guess (even one that overflows the lanes above): 32 iterations always suffice (typically two;
+  //         tests/test_hip_parity.py::test_time_parallel_x_chain_at_extreme_growth_parameters).  The loop ends when an update moved nothing
   //         by more than 1e-6 of its value; the stage values kept are those of the walk that preceded that update, so
   //         every lane's steps are exact steps of the scheme and the values where two lanes meet agree to that 1e-6 --
   //         the rounding level of the sequential walk itself.
@@ -744,9 +745,12 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       const float end_new = fmaf(inc.a, u0, inc.b);      // the new value at the first step of lane l + 1
       float gn = lane_read(end_new, (lane & 32) + ((l + 31) & 31));
       gn = l == 0 ? u0 : gn;
-      // (NaN-safe: a trajectory whose parameters are not finite leaves the loop at once, as non-finite as the walk would be)
-      const bool moved = fabsf(gn - g) > 1e-6f * fabsf(gn);
-      if (__builtin_amdgcn_ballot_w64(moved) == 0ull) break;
+      // A lane whose values are not finite has NOT settled: a poor guess far above the capacity can overflow a lane's walk
+      // while the lanes below it are still converging -- maps only act upwards, so those keep converging, and each
+      // iteration hands at least one more lane an exact first value.  (A chain that is non-finite itself, as the
+      // step-by-step walk would find it, costs the full 32 iterations; non-finite parameters leave at once.)
+      const bool settled = fabsf(gn - g) <= 1e-6f * fabsf(gn);
+      if (__builtin_amdgcn_ballot_w64(!settled && (u0 - u0 == 0.f)) == 0ull) break;
       g = gn;
     }
     if (l == 31) uK[tib] = uend;  // (lanes beyond the last step hold the identity: the last lane's value is x(T-1) / K)
