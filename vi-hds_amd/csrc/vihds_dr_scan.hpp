@@ -996,7 +996,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   const bool owner_last = (K - 1) / ITEMS == l;
   {
     float lc[4], lp[4] = {0.f, 0.f, 0.f, 0.f};
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) lc[j] = LOG2PI_F - logf(prec[j]);
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) lc[j] = LOG2PI_F - __logf(prec[j]);  // (v_log_f32: 1 ulp of log2; libm's was ~30 instructions each)
     auto point = [&](const float* obs_k, bool on, float x, float rfp, float yf, float cf, float w, float* qo) {
       const float xp[4] = {x, x * rfp, x * fmaf(a530, w, yf), x * fmaf(a480, w, cf)};
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
