@@ -577,9 +577,13 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     const int cf_dfl = dflp[cmine ? ce : 0];
     const float cf_z = (cmine && !t.crng) ? t.z[ce * a.D + cd] : 0.f;
     const bool cslow = cnd && !cfast;
-    const float pre_rel = relp[cslow ? min(tid, ed - 1) : 0];
-    const float pre_dev = devp[cslow ? dev_row(min(tid, td - 1)) : 0];
-    int pre_dfl = dflp[cslow ? min(tid, t.E - 1) : 0];
+    float pre_rel = 0.f, pre_dev = 0.f;
+    int pre_dfl = 0;
+    if (cslow) {  // (uniform: the block-wide staging of the general path, with its index arithmetic -- two divisions and a modulo)
+      pre_rel = relp[min(tid, ed - 1)];
+      pre_dev = devp[dev_row(min(tid, td - 1))];
+      pre_dfl = dflp[min(tid, t.E - 1)];
+    }
     // (the dependent pair: the rows of mu_p / log-precision_p in the encoder's table)
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const int rm = t.q_rows ? q_raw[q][0] : pqc[q], rp = t.q_rows ? q_raw[q][1] : pqc[q];
@@ -635,12 +639,12 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       // stage every wavefront of the block goes through before the x chains can start)
       const float prc = cst ? 1.f : (t.prec_is_log ? __expf(c_pr[q]) : c_pr[q]);
       const float sigma = __builtin_amdgcn_rsqf(prc);
-      const float cq = -LOG2PI + 0.5f * __logf(prc + 1e-12f), cp = -LOG2PI + 0.5f * __logf(c_pp[q] + 1e-12f);
+      const float cq = -LOG2PI + 0.34657359027997264f * __builtin_amdgcn_logf(prc + 1e-12f), cp = -LOG2PI + 0.34657359027997264f * __builtin_amdgcn_logf(c_pp[q] + 1e-12f);
       const float mu = c_mu[q];
       const float zz = mu + sigma * uu[q];
       float x = ln ? __expf(zz) : zz;
       x = x < c_lo[q] ? c_lo[q] : (x > c_hi[q] ? c_hi[q] : x);
-      const float v = ln ? __logf(x + 1e-12f) : x;
+      const float v = ln ? 0.6931471805599453f * __builtin_amdgcn_logf(x + 1e-12f) : x;
       const float jac = ln ? v : 0.f;
       const float dq = mu - v, dp = c_pmu[q] - v;
       const float tq = cq - 0.5f * prc * dq * dq - jac;
@@ -723,7 +727,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_UNROLL for (int s = 0; s < NS; ++s) us_own[m][s] = 0.5f;  // (padding steps beyond T-1 keep this harmless value)
   {
     const float u0 = th(M::SI + 0) * frcp(clampf(th(M::S_K), 0.f, 4.f));
-    auto softplus = [](float z) { return fmaxf(z, 0.f) + __logf(1.f + __expf(-fabsf(z))); };
+    auto softplus = [](float z) { return fmaxf(z, 0.f) + 0.6931471805599453f * __builtin_amdgcn_logf(1.f + __expf(-fabsf(z))); };
     const float tl = tT[min(k0, K)];
     const float dG = 0.25f * r * (softplus(4.f * (tl - tlag)) - softplus(4.f * (tT[0] - tlag)));
     float g = l == 0 ? u0 : frcp(fmaf(frcp(u0) - 1.f, __expf(-dG), 1.f));
@@ -996,14 +1000,19 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   const bool owner_last = (K - 1) / ITEMS == l;
   {
     float lc[4], lp[4] = {0.f, 0.f, 0.f, 0.f};
-    VIHDS_UNROLL for (int j = 0; j < 4; ++j) lc[j] = LOG2PI_F - __logf(prec[j]);  // (v_log_f32: 1 ulp of log2; libm's was ~30 instructions each)
+    // (v_log_f32 x ln 2: 1 ulp of log2; libm's logf was ~30 instructions each.  0.5 / prec once, not per grid point.)
+    float hp[4];
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+      lc[j] = LOG2PI_F - 0.6931471805599453f * __builtin_amdgcn_logf(prec[j]);
+      hp[j] = 0.5f / prec[j];
+    }
     auto point = [&](const float* obs_k, bool on, float x, float rfp, float yf, float cf, float w, float* qo) {
       const float xp[4] = {x, x * rfp, x * fmaf(a530, w, yf), x * fmaf(a480, w, cf)};
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
         const float e = xp[j] - obs_k[j];
         lp[j] += on ? -0.5f * fmaf(prec[j] * e, e, lc[j]) : 0.f;
         qo[j] = on ? -prec[j] * e : 0.f;
-        precb[j] += on ? (0.5f / prec[j] - 0.5f * e * e) : 0.f;
+        precb[j] += on ? fmaf(-0.5f * e, e, hp[j]) : 0.f;
       }
       a530b += qo[2] * x * w;  // f530 = a530 W, f480 = a480 W: their amplitudes only enter here
       a480b += qo[3] * x * w;
