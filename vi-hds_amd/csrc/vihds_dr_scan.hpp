@@ -590,6 +590,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       c_mu[q] = t.q_mu[rm * B + b];
       c_pr[q] = t.q_prec[rp * B + b];
     }
+    const bool one_call = t.rng && t.crng && cfast && (t.E << clog) + ((P + 3) >> 2) <= 32;
+    float cw_z = 0.f;
     if (t.rng) {
       // one generator call per wavefront: lane l < ceil(P / 4) draws the four normals of parameter block l (counter =
       // global sample index, block, step: vihds_rng.hpp), the trajectory's lanes pick theirs up from LDS
@@ -597,8 +599,15 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       const unsigned int gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * a.S));
       float* zb = lds + O_Z + tib * 64;  // (the VZ area: 64 floats per trajectory, unused until the log-likelihood)
       float z4[4];
-      philox_normal4(gidx, (unsigned int)l, step, 0u, rk0, rk1, z4);
-      if (4 * l < P) stv<4>(zb + 4 * l, z4);
+      // (one call for both generators where the lanes allow it: the conditioner's weights are drawn by lanes (e, d) at the
+      // bottom of the trajectory's 32, the parameter blocks by lanes 31, 30, ... -- a second call would cost every lane of
+      // the wavefront its ~170 instructions again)
+      const bool cw_lane = one_call && cmine;
+      const int ub = one_call ? 31 - l : l;
+      philox_normal4(cw_lane ? (unsigned int)(ce * a.D + cd) : gidx, cw_lane ? 0xC04Du : (unsigned int)ub,
+                     cw_lane ? cstep : step, 0u, cw_lane ? ck0 : rk0, cw_lane ? ck1 : rk1, z4);
+      cw_z = z4[0];
+      if (4 * ub < P && !cw_lane) stv<4>(zb + 4 * ub, z4);
       wave_sync();
       VIHDS_UNROLL for (int q = 0; q < 2; ++q)
         if (l + 32 * q < P) uu[q] = zb[l + 32 * q];
@@ -613,7 +622,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       // rel[e,d]) on top of the default flag; w = mean + std z, z from the conditioner's generator (one call per weight,
       // counter e D + d: the numbers of the general path) or from the caller's draw
       float zz = cf_z;
-      if (t.crng) zz = philox_normal((unsigned int)(ce * a.D + cd), 0xC04Du, cstep, 0u, ck0, ck1, 0);
+      if (one_call) zz = cw_z;
+      else if (t.crng) zz = philox_normal((unsigned int)(ce * a.D + cd), 0xC04Du, cstep, 0u, ck0, ck1, 0);
       float sm = cmine ? (t.w_mean + t.w_std * zz) * (cf_dev * cf_rel) : 0.f;
       if (clog >= 1) sm += dpp_all<0xB1>(sm);   // quad_perm [1,0,3,2]
       if (clog >= 2) sm += dpp_all<0x4E>(sm);   // quad_perm [2,3,0,1]
@@ -1004,7 +1014,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     float hp[4];
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       lc[j] = LOG2PI_F - 0.6931471805599453f * __builtin_amdgcn_logf(prec[j]);
-      hp[j] = 0.5f / prec[j];
+      hp[j] = 0.5f * frcp(prec[j]);
     }
     auto point = [&](const float* obs_k, bool on, float x, float rfp, float yf, float cf, float w, float* qo) {
       const float xp[4] = {x, x * rfp, x * fmaf(a530, w, yf), x * fmaf(a480, w, cf)};
