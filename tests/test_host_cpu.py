@@ -275,3 +275,21 @@ def test_native_numpy_normal_stream_is_bit_identical():
     st = np.random.get_state()
     assert np.array_equal(a, b)
     assert np.array_equal(st_ref[1], st[1]) and st_ref[2:] == st[2:]
+
+
+def test_host_library_exports_what_its_header_declares():
+    """include/vihds_host.h: every declared entry point is exported by libvihds_host.so, and the ABI number matches."""
+    import ctypes
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    lib_path = os.path.join(root, "vi-hds_amd", "lib", "libvihds_host.so")
+    if not os.path.exists(lib_path):
+        pytest.skip("libvihds_host.so not built")
+    header = open(os.path.join(root, "include", "vihds_host.h")).read()
+    names = sorted(set(re.findall(r"\b(vihds_[a-z0-9_]+)\s*\(", header)))
+    assert names == ["vihds_host_abi_version", "vihds_np_randn_f32", "vihds_np_randn_f32_start", "vihds_np_randn_f32_wait"]
+    lib = ctypes.CDLL(lib_path)
+    for n in names:
+        assert hasattr(lib, n), n
+    assert lib.vihds_host_abi_version() == int(re.search(r"#define VIHDS_HOST_ABI_VERSION (\d+)", header).group(1))
