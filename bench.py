@@ -729,7 +729,7 @@ def main():
     ap.add_argument("--no-step-tail", action="store_true",
                     help="keep IWAE loss + theta adjoint, the encoder adjoint (two launches) and Adam as the five launches of "
                          "round 2 instead of vihds_step_tail's two")
-    ap.add_argument("--steps-per-graph", type=int, default=8,
+    ap.add_argument("--steps-per-graph", type=int, default=32,
                     help="consecutive training steps captured into one hipGraph (single process, resident batch); 1 = one "
                          "graph launch per step as in round 2")
     ap.add_argument("--no-strong-leg", dest="strong_leg", action="store_false",
@@ -827,7 +827,7 @@ def main():
 
     # steps per graph launch: between two graph launches the GPU idles 6-8 us (measured: rocprofv3 kernel trace), so the
     # resident-batch replay captures G consecutive steps per graph; K timed steps = K // G launches of that graph plus
-    # K % G launches of the one-step graph -- exactly K optimizer steps either way
+    # one launch of a graph holding the K % G remaining steps -- exactly K optimizer steps either way
     # (several ranks: only data-parallel replicas, and only when the communicator records into the capture -- the gradient
     # all-reduce then sits inside the graph between the step's kernels; the sample-sharded step keeps one step per graph)
     G = 1
@@ -838,7 +838,10 @@ def main():
         out = None
         for _ in range(k // G):
             out = training.graph_step(batch, repeat=G) if G > 1 else step(batch)
-        for _ in range(k % G if G > 1 else 0):
+        rest = k % G if G > 1 else 0
+        if rest > 1:
+            out = training.graph_step(batch, repeat=rest)  # (the remainder as ONE graph of its own, captured during setup)
+        elif rest == 1:
             out = step(batch)
         return out
 
@@ -848,6 +851,9 @@ def main():
             step(batch)  # setup, not a measured or warm-up step: allocator warm-up + hipGraph capture happen on first use
             if G > 1:
                 training.graph_step(batch, repeat=G)  # (same for the G-step graph: G untimed steps)
+                for k in sorted({a.warmup % G, a.steps % G}):  # (and for the graphs that hold the remainders)
+                    if k > 1:
+                        training.graph_step(batch, repeat=k)
         except Exception as exc:  # noqa: BLE001 -- (reported in the line; the run goes on with eager launches)
             if not multi:
                 raise
