@@ -9,6 +9,7 @@ model.train()
 batch = training.train_data
 log = TrainingLogData()
 for _ in range(10): training._run_batch(time.time(), batch, log)
+for _ in range(100): training._run_batch(time.time(), batch, log, next_batch=batch)  # (the helper thread and its pool warm)
 torch.cuda.synchronize()
 g = list(training._graphs.values())[0][0]
 slots = g.host_draws.slots
@@ -17,7 +18,7 @@ def t(fn, n=200):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(n): fn()
     torch.cuda.synchronize(); return (time.perf_counter() - t0) / n * 1e3
-print("whole _run_batch        %.3f ms" % t(lambda: training._run_batch(time.time(), batch, log, next_batch=batch)))
+print("whole _run_batch        %.3f ms" % t(lambda: training._run_batch(time.time(), batch, log, next_batch=batch), 1000))
 print("graph_step (no nan look) %.3f ms" % t(lambda: training.graph_step(batch)))
 print("refresh all slots        %.3f ms" % t(lambda: g.host_draws.refresh()))
 for k, s in enumerate(slots):

@@ -16,14 +16,18 @@ class HostDraws(object):
     """The static buffers live in ONE arena that is allocated before the capture begins (`reserve`), sized from the warm-up
     steps that every capture runs first (`note` counts what a step draws): a buffer allocated from the graph's own memory
     pool while it captures was handed out again later in the same capture (measured: the conditioner's 56-byte weight
-    buffer came back holding the evaluation's variance summaries)."""
+    buffer came back holding the evaluation's variance summaries).  The pinned side mirrors the arena -- three page-locked
+    copies of it, used in turn: a refresh fills every slot's slice of one of them and uploads the whole with ONE copy."""
 
     ALIGN = 64  # floats
+    RING = 3
 
     def __init__(self):
-        self.slots = []  # (device buffer, fill(host numpy view), [pinned buffers], [events], position)
+        self.slots = []  # [device buffer, fill(host numpy view), offset in the arena, floats, prefetchable, started ahead]
         self.arena, self.used = None, 0
         self.noted = 0   # floats one step asked for (measuring mode: warm-up steps)
+        self.pinned, self.views, self.events = None, None, [None] * self.RING
+        self.pos, self.staged = 0, None  # next ring entry; the entry prefetch() has already started filling
 
     def note(self, shape):
         n = 1
@@ -46,48 +50,52 @@ class HostDraws(object):
                                "(%d floats reserved, %d in use, %d more wanted)"
                                % (0 if self.arena is None else self.arena.numel(), self.used, n))
         buf = self.arena[self.used: self.used + n].view(shape)
+        self.slots.append([buf, fill, self.used, n, prefetchable, False])
         self.used += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
-        # (the pinned staging buffers are made at the first refresh: page-locked allocations are not permitted while a
-        # stream is capturing)
-        self.slots.append([buf, fill, None, [None, None, None], 0, prefetchable, None])
         return buf
 
-    def _stage(self, slot):
-        """The slot's next pinned buffer, free to be written (the copy that last read it has run)."""
-        buf, _fill, pinned, events, k = slot[:5]
-        if pinned is None:
-            pinned = slot[2] = [torch.empty(buf.numel(), dtype=torch.float32).pin_memory() for _ in range(3)]
-        slot[4] = (k + 1) % len(pinned)
-        if events[k] is not None:
-            events[k].synchronize()
+    def _stage(self):
+        """The next pinned copy of the arena, free to be written (the upload that last read it has run).  (Made at the first
+        use: page-locked allocations are not permitted while a stream is capturing.)"""
+        if self.pinned is None:
+            self.pinned = [torch.empty(self.used, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
+            self.views = [[p[off: off + n].numpy() for (_b, _f, off, n, _p, _s) in self.slots] for p in self.pinned]
+        k = self.pos
+        self.pos = (k + 1) % self.RING
+        if self.events[k] is not None:
+            self.events[k].synchronize()
         return k
 
     def prefetch(self):
         """Start the prefetchable slots' NEXT draws on the native helper thread (fill.start / fill.finish: vihds/nprand.py).
         Only the caller knows that the next consumer of that random stream is this graph's next replay (Training.run: the
         next batch of the epoch); a prefetched draw that is never replayed has advanced the stream by one unused draw."""
-        for slot in self.slots:
-            if slot[5] and slot[6] is None and hasattr(slot[1], "start"):
-                k = self._stage(slot)
-                if slot[1].start(slot[2][k].numpy()):
-                    slot[6] = k
-                else:  # not startable now: drawn at the refresh, into the buffer that was just staged
-                    slot[4] = k
+        if self.staged is not None:
+            return
+        k, any_started = None, False
+        for j, slot in enumerate(self.slots):
+            if slot[4] and hasattr(slot[1], "start"):
+                if k is None:
+                    k = self._stage()
+                slot[5] = bool(slot[1].start(self.views[k][j]))
+                any_started = any_started or slot[5]
+        if any_started:
+            self.staged = k
+        elif k is not None:
+            self.pos = k  # (nothing could be started now: the refresh takes this entry itself)
 
     def refresh(self):
-        for slot in self.slots:
-            buf, fill, events = slot[0], slot[1], slot[3]
-            if slot[6] is not None:  # drawn ahead by prefetch()
-                k, slot[6] = slot[6], None
-                fill.finish()
+        k, self.staged = (self.staged if self.staged is not None else self._stage()), None
+        for j, slot in enumerate(self.slots):
+            if slot[5]:  # drawn ahead by prefetch()
+                slot[5] = False
+                slot[1].finish()
             else:
-                k = self._stage(slot)
-                fill(slot[2][k].numpy())
-            pinned = slot[2]
-            buf.copy_(pinned[k].view(buf.shape), non_blocking=True)
-            if events[k] is None:
-                events[k] = torch.cuda.Event()
-            events[k].record()
+                slot[1](self.views[k][j])
+        self.arena[: self.used].copy_(self.pinned[k], non_blocking=True)
+        if self.events[k] is None:
+            self.events[k] = torch.cuda.Event()
+        self.events[k].record()
 
     def __bool__(self):
         return bool(self.slots)

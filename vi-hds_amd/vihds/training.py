@@ -77,11 +77,14 @@ class _ElboLook(object):
         self.slots = [self.host[0:1], self.host[1:2]]
         self.events = [torch.cuda.Event(), torch.cuda.Event()]
         self.pos, self.pending = 0, None
+        self._src, self._view = None, None
 
     def push(self, elbo):
         """Queue the copy of `elbo` (a device scalar); returns the slot pushed before, not looked at yet (or None)."""
         i, self.pos = self.pos, self.pos ^ 1
-        self.slots[i].copy_(elbo.detach().reshape(1), non_blocking=True)
+        if elbo is not self._src:  # (a replayed graph hands back the same static tensor every step: one view, kept)
+            self._src, self._view = elbo, elbo.detach().reshape(1)
+        self.slots[i].copy_(self._view, non_blocking=True)
         self.events[i].record()
         prev, self.pending = self.pending, i
         return prev
