@@ -344,6 +344,10 @@ __device__ __forceinline__ void block_sync_lds() {
   asm volatile("" ::: "memory");
 }
 constexpr int DR_SCAN_NACC = 32;       // accumulators summed over the time axis in the epilogue (29 used)
+// row stride of the epilogue's reduction buffer [NACC][threads]: lane l reads row l, sixteen bytes at a time -- at a stride of
+// exactly `threads` floats (1 KB) all of a wavefront's lanes met in the same four banks (PMC: 3.3 M conflict cycles per
+// launch, most of them here); four floats of padding move every lane to the next four banks
+constexpr int DR_SCAN_RED_STRIDE = DR_SCAN_THREADS + 4;
 
 // LDS per block (floats).  Per lane and step, as vectors: VG[NS] (sigmoid, then gamma), VU[NS] (x / K at the stages),
 // VB[NS] (gamma adjoints), VQ[4] (observations, then log-likelihood injections), VY[4] + VZ[2] (states at the step's grid
@@ -352,7 +356,7 @@ constexpr int DR_SCAN_NACC = 32;       // accumulators summed over the time axis
 template <int SOLVER>
 __host__ __device__ inline size_t dr_scan_lds_floats(int items) {
   const size_t steps = (size_t)(3 * Rk<SOLVER>::NS + 14) * items * DR_SCAN_THREADS;
-  const size_t red = (size_t)DR_SCAN_NACC * DR_SCAN_THREADS + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64;
+  const size_t red = (size_t)DR_SCAN_NACC * DR_SCAN_RED_STRIDE + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64;
   return (steps > red ? steps : red) + (size_t)(32 * items + 4) + DR_SCAN_TPB;
 }
 #define VIHDS_ROLLED _Pragma("clang loop unroll(disable)")
@@ -437,7 +441,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   // per-lane vector fields: field of width W, step m of thread t at base + (m * NT + t) * W
   constexpr int O_G = 0, O_U = O_G + NS * ITEMS * NT, O_B = O_U + NS * ITEMS * NT, O_Q = O_B + NS * ITEMS * NT,
                 O_Y = O_Q + 4 * ITEMS * NT, O_Z = O_Y + 4 * ITEMS * NT, O_A = O_Z + 2 * ITEMS * NT,
-                O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64,
+                O_STEPS = O_A + 4 * ITEMS * NT, O_RED = DR_SCAN_NACC * DR_SCAN_RED_STRIDE + DR_SCAN_TPB * DR_SCAN_NACC + DR_SCAN_TPB * 64,
                 O_T = O_STEPS > O_RED ? O_STEPS : O_RED, O_UK = O_T + 32 * ITEMS + 4, O_C = O_UK + DR_SCAN_TPB;
   auto VG = [&](int m) { return lds + O_G + (m * NT + tid) * NS; };
   // (the stage values of x are written by the chain wavefront, for all trajectories of the block at once: a trajectory's
@@ -1287,7 +1291,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     // The gradients leave through LDS: lane 0 of the trajectory lays them out in slot order (constant offsets), then lane
     // l stores slots l and l + 32 -- two store instructions per wavefront instead of one per slot with two lanes at work.
     unsigned long long put_mask = 0ull;
-    float* gout = lds + DR_SCAN_NACC * NT + DR_SCAN_TPB * DR_SCAN_NACC + tib * 64;  // [TPB][64], behind `tot`
+    float* gout = lds + DR_SCAN_NACC * DR_SCAN_RED_STRIDE + DR_SCAN_TPB * DR_SCAN_NACC + tib * 64;  // [TPB][64], behind `tot`
     auto put = [&](int slot, float v) {
       gout[slot] = v;
       put_mask |= 1ull << slot;
@@ -1302,12 +1306,12 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_SCAN_STOP(13)
 #endif
     float* red = lds;                       // [NACC][NT]
-    float* tot = lds + DR_SCAN_NACC * NT;   // [TPB][NACC]
-    VIHDS_UNROLL for (int q = 0; q < 29; ++q) red[q * NT + tid] = acc[q];
+    float* tot = lds + DR_SCAN_NACC * DR_SCAN_RED_STRIDE;   // [TPB][NACC]
+    VIHDS_UNROLL for (int q = 0; q < 29; ++q) red[q * DR_SCAN_RED_STRIDE + tid] = acc[q];
     wave_sync();
     {
       float s4[4] = {0.f, 0.f, 0.f, 0.f};
-      const float* row = red + l * NT + tib * 32;  // accumulator l of this trajectory, its 32 lanes' partial sums
+      const float* row = red + l * DR_SCAN_RED_STRIDE + tib * 32;  // accumulator l of this trajectory, its 32 lanes' partial sums
       VIHDS_UNROLL for (int q = 0; q < 8; ++q) {
         float v[4];
         ldv<4>(row + 4 * q, v);
