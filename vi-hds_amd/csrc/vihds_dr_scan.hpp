@@ -458,8 +458,10 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   // theta rows of this trajectory in LDS (written once, by its 32 lanes; every lane then picks what it needs from
   // there).  Lives in the VY area of this trajectory's first lanes, which nobody writes before the parameter stage is over.
   // [0,64): theta rows; [64,66): fR, fS; [66,90): the Hill power terms (base, exponent, power) of lanes 0..7.
-  // (128 floats per trajectory: the two trajectories of a wavefront stay inside that wavefront's own slots.)
-  auto par_of = [&](int t) { return lds + O_Y + t * 128; };
+  // (90 floats per trajectory in use: the two trajectories of a wavefront stay inside that wavefront's own 256-float slot.)
+  // (the second trajectory of a wavefront 100 floats behind the first, not 128: both halves of the wavefront read the same
+  // slot at the same time, and at a distance of 512 bytes the two addresses fell into one bank -- every th() two passes)
+  auto par_of = [&](int t) { return lds + O_Y + (t >> 1) * 256 + (t & 1) * 100; };
   float* par = par_of(tib);
   auto th = [&](int slot) { return par[a.slot_row[slot]]; };
 
