@@ -293,3 +293,22 @@ def test_host_library_exports_what_its_header_declares():
     for n in names:
         assert hasattr(lib, n), n
     assert lib.vihds_host_abi_version() == int(re.search(r"#define VIHDS_HOST_ABI_VERSION (\d+)", header).group(1))
+
+
+def test_sized_blackbox_libraries_load_on_their_own():
+    """The dr_blackbox size-set libraries (lib/libvihds_bb_<L>_<HS>_<HP>_<NLAT>.so, csrc/sized/) are opened by libvihds_hip.so
+    with RTLD_LOCAL and do not link against it: every symbol they use must be their own.  (A header once grew an `extern`
+    that only the main library defined; the size sets then failed to load after their next rebuild.)"""
+    import glob
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libs = sorted(glob.glob(os.path.join(root, "vi-hds_amd", "lib", "libvihds_bb_*.so")))
+    if not libs:
+        pytest.skip("no size-set library built")
+    for path in libs:
+        code = ("import ctypes, os; h = ctypes.CDLL(%r, mode=os.RTLD_NOW | os.RTLD_LOCAL); "
+                "assert h.vihds_bb_variant_v2" % path)
+        out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, (path, out.stderr[-400:])

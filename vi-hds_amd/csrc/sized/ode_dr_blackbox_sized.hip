@@ -49,6 +49,9 @@ VIHDS_BB_DECL(7) VIHDS_BB_DECL(8)
 static_assert(VIHDS_SOLVER_COUNT == 9, "one object per solver: extend the table and the Makefile");
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own (it does not link against libvihds_hip.so)
+// (never set here: the device-resident adaptive solver does not serve models with shared neural weights, but launch_ode
+// looks at it -- without this definition the library did not load: an undefined symbol only libvihds_hip.so has)
+thread_local AdaptiveDevCtl* g_adaptive_dev = nullptr;
 static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
 static long long gram_floats_sized(int n) { return BBV_MFMA ? (long long)KV::gram_floats(n) : -1; }
 static void gram_reduce_sized(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
