@@ -130,7 +130,7 @@ struct Buffers {  // kept between calls: fresh allocations of this size cost mor
 
 std::mutex g_lock;           // one call at a time (the pool and the buffers are shared)
 Pool* g_pool = nullptr;
-Buffers g_buf;
+Buffers& g_buf = *new Buffers;  // (never destroyed: the helper thread may still be drawing when the process's statics are torn down)
 
 inline void cpu_relax() {
 #if defined(__x86_64__)

@@ -5,6 +5,7 @@ u ~ N(0,1)[B,S,P] on the host every step (vihds/vae.py:22-24); with `u_rng: nump
 that draw was 25x the GPU's work for the step.
 
 This is host-side plumbing, not the hot path: when the library is missing the call falls back to numpy itself."""
+import atexit
 import ctypes
 import os
 
@@ -65,6 +66,9 @@ def _collect_stray():
         _IN_FLIGHT = False
         _lib().vihds_np_randn_f32_wait()
         _LEFT = _fingerprint()
+
+
+atexit.register(lambda: _collect_stray() if _IN_FLIGHT else None)  # (numpy's state must outlive a draw that is still running)
 
 
 def randn_f32(shape, out=None):
