@@ -2001,6 +2001,55 @@ def test_time_parallel_kernel_matches_reference_fixture(name):
     assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL
 
 
+@pytest.mark.parametrize("D", [1, 7, 16, 20, 40])
+def test_decoder_step_conditioner_rows_at_other_device_counts(D):
+    """The decoder launch evaluates the device conditioner itself (ode.py:43-58 with its .repeat tiling: sample (b, s) reads
+    device row (b S + s) mod B).  Its fast path keeps row e's operands in the lanes (e, d) of the trajectory -- E rows x D
+    devices, D padded to a power of two, must fit 32 lanes: D = 1, 7, 16 with the two rows of dr_constant --, the general path
+    stages them and loops (D = 20: 2 x 32 lanes do not fit; D = 40).  Both against the formula, on the reference fixture's
+    other inputs with a random device matrix, weights given (no generator) and w = 0.3 + 1.7 z."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture("dr_constant_icml_tiny_modeuler")
+    P, B, S = len(fx.names), fx.B, fx.S
+    E = len(fx.extra_names)
+    assert E == 2
+    th, row_of = H.pack_theta(fx, DEV)
+    spec3 = ops.OdeProblemSpec(fx.model, fx.solver, row_of, th.shape[0], C=fx.z["inputs"].shape[1], D=D, kernel_variant=3)
+    kind, q_mu, q_prec, p_mu, p_prec, lo, hi = H.theta_inputs(fx, DEV)
+    q_all = torch.cat([q_mu, q_prec.log()], 0).contiguous()
+    rows = torch.arange(2 * P, dtype=torch.int32, device=DEV)
+    g = torch.Generator().manual_seed(40 + D)
+    dev = torch.rand(B, D, generator=g)
+    dev[torch.rand(B, D, generator=g) < 0.5] = 0.0
+    rel = (torch.rand(E, D, generator=g) < 0.7).float()
+    dflt = torch.tensor([1, 0], dtype=torch.int32)
+    z = torch.randn(E, D, generator=g)
+    cond_job = (E, P, 0.3, 1.7, z.to(DEV), None, rel.to(DEV), dflt.to(DEV))
+    with torch.no_grad():
+        theta, _lq, _lp, _u, logp = ops.DecoderStepFused.apply(
+            q_all, kind, p_mu, p_prec, lo, hi, fx.t("u", DEV), P + E, rows, spec3, fx.t("inputs", DEV), fx.t("times", DEV),
+            fx.t("observations", DEV), dev.to(DEV), cond_job)
+    w = 0.3 + 1.7 * z
+    bs = torch.arange(B)[:, None] * S + torch.arange(S)[None, :]
+    drow = dev[bs % B]                                                   # [B, S, D]
+    want = dflt.float()[:, None, None] + torch.relu(torch.einsum("ed,bsd->ebs", w * rel, drow))
+    assert rel_err(theta[P:].cpu(), want, dim=0) < 1e-6
+    assert rel_err(theta[:P], fx.t("theta"), dim=0) < 1e-5 and bool(torch.isfinite(logp).all())
+    # the weights drawn in the launch (the conditioner's own generator; with u given there is one generator call for them
+    # alone): the same numbers as the stand-alone conditioner kernel draws from an equal generator state
+    st_a, st_b = ops.KernelNormal.new_state(77, DEV), ops.KernelNormal.new_state(77, DEV)
+    cond_job = (E, P, 2.0, 1.5, None, st_a, rel.to(DEV), dflt.to(DEV))
+    with torch.no_grad():
+        theta2, *_ = ops.DecoderStepFused.apply(
+            q_all, kind, p_mu, p_prec, lo, hi, fx.t("u", DEV), P + E, rows, spec3, fx.t("inputs", DEV), fx.t("times", DEV),
+            fx.t("observations", DEV), dev.to(DEV), cond_job)
+        alone = ops.device_condition(None, dev.to(DEV), rel.to(DEV), dflt.to(DEV), torch.empty(E, B, S, device=DEV), 2.0, 1.5, st_b)
+    assert rel_err(theta2[P:], alone, dim=0) < 1e-6
+    assert torch.equal(st_a.cpu(), st_b.cpu())  # (both advanced their step once)
+
+
 def _relay_problem(model, B, S, T, seed, dt=0.25):
     from vihds import hip
 
