@@ -45,7 +45,6 @@ __host__ __device__ constexpr int rl_nwg(int nin) { return 4 * rl_nwrow(nin); } 
 constexpr int RL_PATCH = 48;             // LDS floats per trajectory: y [16] | h [16] | adjoint scratch [16]
 constexpr float RL_LOG2PI = 1.8378770664093453f;
 typedef float rl_v2 __attribute__((ext_vector_type(2)));  // (production, degradation) pairs: v_pk_fma_f32
-__device__ __forceinline__ rl_v2 fm2(rl_v2 a, float b, rl_v2 c) { return __builtin_elementwise_fma(a, rl_v2{b, b}, c); }
 
 __host__ __device__ inline bool relay_lanes_applicable(int n, int solver, int kernel_variant, int n_hidden_prec) {
   return kernel_variant != 1 && n <= 16384 && solver >= VIHDS_SOLVER_MODEULER && solver <= VIHDS_SOLVER_RK4 &&
@@ -244,11 +243,8 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
                      c.cw[6] * zd4.z + c.cw[7] * zd4.w;
     yb += hb * (1.f - E.hl * E.hl);  // (the columns cw are zero outside the species lanes)
-    // (accumulated in the layout the two float4s arrive in -- wc[0..1] the activation rows' (x, y), (z, w), wc[2..3] the
-    // degradation rows' -- so that each is ONE v_pk_fma on adjacent registers; paired as (a_k, d_k) every pair cost two
-    // register moves to assemble: 12 of this line's 20 instructions)
-    A.wc[0] = fm2(rl_v2{za.x, za.y}, E.hl, A.wc[0]); A.wc[1] = fm2(rl_v2{za.z, za.w}, E.hl, A.wc[1]);
-    A.wc[2] = fm2(rl_v2{zd4.x, zd4.y}, E.hl, A.wc[2]); A.wc[3] = fm2(rl_v2{zd4.z, zd4.w}, E.hl, A.wc[3]);
+    A.wc[0] += rl_v2{za.x, zd4.x} * E.hl; A.wc[1] += rl_v2{za.y, zd4.y} * E.hl;
+    A.wc[2] += rl_v2{za.z, zd4.z} * E.hl; A.wc[3] += rl_v2{za.w, zd4.w} * E.hl;
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
@@ -752,10 +748,8 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
       const int jc = l == NSP ? 0 : l + 1;
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        // (A.wc: [0..1] = activation rows 0..3 as (x, y), (z, w); [2..3] = degradation rows 0..3)
-        const rl_v2 wa = A.wc[o >> 1], wd = A.wc[2 + (o >> 1)];
-        wred[g][o * NWROW + jc] = live ? ((o & 1) ? wa.y : wa.x) : 0.f;
-        wred[g][o * NWROW + NIN + jc] = live ? ((o & 1) ? wd.y : wd.x) : 0.f;
+        wred[g][o * NWROW + jc] = live ? A.wc[o].x : 0.f;
+        wred[g][o * NWROW + NIN + jc] = live ? A.wc[o].y : 0.f;
       }
     }
     if (l >= NSP && l < NSP + 4) {
