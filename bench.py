@@ -571,7 +571,7 @@ def unchanged_spec_leg(a, dev, min_seconds):
     log = TrainingLogData()
 
     def step():  # the body of Training.run()'s loop for one resident batch: the step and the reference's per-step NaN check
-        if not training._run_batch(time.time(), batch, log, next_batch=batch):  # (the same resident batch follows)
+        if not training._run_batch(time.time(), batch, log, next_batch=batch, ahead=2):  # (the same resident batch follows, twice)
             raise SystemExit("NaN objective in the unchanged-spec leg")
 
     for _ in range(20):  # (the capture and its warm-up steps happen in here)

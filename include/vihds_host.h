@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_HOST_ABI_VERSION 2
+#define VIHDS_HOST_ABI_VERSION 3
 int vihds_host_abi_version(void);
 
 /* out[0..n) <- np.random.standard_normal(n).astype(np.float32) of the RandomState (key[624], pos, has_gauss, gauss) -- numpy's
@@ -27,9 +27,10 @@ int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, f
 
 /* The same draw on the library's helper thread.  start: even n, a state without a cached deviate; key / pos are read and
  * advanced IN PLACE (numpy's own state array: np.random.mtrand._rand._bit_generator.ctypes.state_address) -- nobody else may
- * use that generator until wait returns.  Returns 0, -1 on bad arguments, -2 when a draw is already in flight or its result has
- * not been collected.  wait: blocks until the draw started last is complete; returns its result (0), or -3 when none was
- * started. */
+ * use that generator until every started draw has been waited for.  Up to TWO draws may be started before the first is
+ * waited for; the helper works through them in order.  Returns 0, -1 on bad arguments, -2 when two draws are already queued.
+ * wait: blocks until the OLDEST draw started and not yet waited for is complete; returns its result (0), or -3 when there
+ * is none. */
 int vihds_np_randn_f32_start(uint32_t* key, int* pos, float* out, long long n, int n_threads);
 int vihds_np_randn_f32_wait(void);
 

@@ -351,8 +351,8 @@ def test_training_run_tracks_reference_trace(name, tmp_path, monkeypatch):
     losses = []
     orig = training.step_rows
 
-    def recording_step(rows, next_rows=None):  # (run() replays its steps from hipGraphs by default: the loss is what a step hands back)
-        out = orig(rows, next_rows)
+    def recording_step(rows, next_rows=None, ahead=1):  # (run() replays its steps from hipGraphs by default: the loss is what a step hands back)
+        out = orig(rows, next_rows, ahead)
         losses.append(float(out))
         return out
 

@@ -412,33 +412,38 @@ int vihds_np_randn_f32(uint32_t* key, int* pos, int* has_gauss, double* gauss, f
 // state (key, pos: read and advanced IN PLACE) is the state after the draw.  For an even n on a state without a cached
 // deviate only (the training loop's draws).  A Python helper thread cannot do this job: it needs the interpreter lock to
 // start, which the main thread holds while it queues the step -- measured, the "overlapped" draw ran after the main thread's
-// work, not beside it.  One draw in flight at a time; the caller must leave numpy's generator alone until `wait` returns.
+// work, not beside it.  Up to two draws may be queued: the helper then goes from one straight into the next instead of
+// waiting for the main thread to hand it the next job (its wake-ups were a third of the step).  The caller must leave numpy's
+// generator alone until every started draw has been waited for.
 struct AsyncDraw {
+  struct Job {
+    uint32_t* key;
+    int* pos;
+    float* out;
+    long long n;
+    int threads, rc;
+  };
+  static constexpr int DEPTH = 2;  // draws that may be queued or running at once (the helper works through them in order)
   std::thread worker;
   std::mutex m;
   std::condition_variable cv;
-  int state = 0;  // 0 idle, 1 submitted, 2 running, 3 done (result not collected yet)
-  uint32_t* key = nullptr;
-  int* pos = nullptr;
-  float* out = nullptr;
-  long long n = 0;
-  int threads = 1, rc = 0;
-  bool stop = false;
+  Job ring[DEPTH];
+  unsigned long submitted = 0, completed = 0, collected = 0;  // job j lives in ring[j % DEPTH]
   void loop() {
     for (;;) {
+      Job* j;
       {
         std::unique_lock<std::mutex> lk(m);
-        cv.wait(lk, [&] { return state == 1 || stop; });
-        if (stop) return;
-        state = 2;
+        cv.wait(lk, [&] { return completed < submitted; });
+        j = &ring[completed % DEPTH];
       }
       int has_gauss = 0;
       double gauss = 0.0;
-      const int r = vihds_np_randn_f32(key, pos, &has_gauss, &gauss, out, n, threads);
+      const int r = vihds_np_randn_f32(j->key, j->pos, &has_gauss, &gauss, j->out, j->n, j->threads);
       {
         std::lock_guard<std::mutex> lk(m);
-        rc = r;
-        state = 3;
+        j->rc = r;
+        ++completed;
       }
       cv.notify_all();
     }
@@ -460,29 +465,26 @@ int vihds_np_randn_f32_start(uint32_t* key, int* pos, float* out, long long n, i
   AsyncDraw& a = *g_async;
   {
     std::lock_guard<std::mutex> lk(a.m);
-    if (a.state != 0) return -2;  // a draw is in flight (or its result has not been collected)
-    a.key = key;
-    a.pos = pos;
-    a.out = out;
-    a.n = n;
-    a.threads = n_threads;
-    a.state = 1;
+    if (a.submitted - a.collected >= (unsigned long)AsyncDraw::DEPTH) return -2;  // the queue is full
+    a.ring[a.submitted % AsyncDraw::DEPTH] = AsyncDraw::Job{key, pos, out, n, n_threads, 0};
+    ++a.submitted;
   }
   a.cv.notify_all();
   return 0;
 }
 
-// result of the draw started last (0 = done); -3: none was started
+// result of the OLDEST draw started and not collected yet (0 = done); -3: there is none
 int vihds_np_randn_f32_wait(void) {
   if (!g_async) return -3;
   AsyncDraw& a = *g_async;
   std::unique_lock<std::mutex> lk(a.m);
-  if (a.state == 0) return -3;
-  a.cv.wait(lk, [&] { return a.state == 3; });
-  a.state = 0;
-  return a.rc;
+  if (a.collected == a.submitted) return -3;
+  a.cv.wait(lk, [&] { return a.completed > a.collected; });
+  const int rc = a.ring[a.collected % AsyncDraw::DEPTH].rc;
+  ++a.collected;
+  return rc;
 }
 
-int vihds_host_abi_version(void) { return 2; }
+int vihds_host_abi_version(void) { return 3; }
 
 }  // extern "C"

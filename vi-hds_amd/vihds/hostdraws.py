@@ -20,14 +20,16 @@ class HostDraws(object):
     copies of it, used in turn: a refresh fills every slot's slice of one of them and uploads the whole with ONE copy."""
 
     ALIGN = 64  # floats
-    RING = 3
+    RING = 5    # pinned copies: one being uploaded, one being filled now, up to AHEAD started ahead, one spare
+    AHEAD = 2   # draws the native helper may have queued (vihds_np_randn_f32_start takes two)
 
     def __init__(self):
-        self.slots = []  # [device buffer, fill(host numpy view), offset in the arena, floats, prefetchable, started ahead]
+        self.slots = []  # [device buffer, fill(host numpy view), offset in the arena, floats, prefetchable]
         self.arena, self.used = None, 0
         self.noted = 0   # floats one step asked for (measuring mode: warm-up steps)
         self.pinned, self.views, self.events = None, None, [None] * self.RING
-        self.pos, self.staged = 0, None  # next ring entry; the entry prefetch() has already started filling
+        self.pos = 0       # next ring entry
+        self.staged = []   # ring entries whose prefetchable draws were started ahead, oldest first
 
     def note(self, shape):
         n = 1
@@ -50,7 +52,7 @@ class HostDraws(object):
                                "(%d floats reserved, %d in use, %d more wanted)"
                                % (0 if self.arena is None else self.arena.numel(), self.used, n))
         buf = self.arena[self.used: self.used + n].view(shape)
-        self.slots.append([buf, fill, self.used, n, prefetchable, False])
+        self.slots.append([buf, fill, self.used, n, prefetchable and hasattr(fill, "start")])
         self.used += (n + self.ALIGN - 1) // self.ALIGN * self.ALIGN
         return buf
 
@@ -59,40 +61,39 @@ class HostDraws(object):
         use: page-locked allocations are not permitted while a stream is capturing.)"""
         if self.pinned is None:
             self.pinned = [torch.empty(self.used, dtype=torch.float32).pin_memory() for _ in range(self.RING)]
-            self.views = [[p[off: off + n].numpy() for (_b, _f, off, n, _p, _s) in self.slots] for p in self.pinned]
+            self.views = [[p[off: off + n].numpy() for (_b, _f, off, n, _p) in self.slots] for p in self.pinned]
+            self.upload = self.arena[: self.used]
         k = self.pos
         self.pos = (k + 1) % self.RING
         if self.events[k] is not None:
             self.events[k].synchronize()
         return k
 
-    def prefetch(self):
-        """Start the prefetchable slots' NEXT draws on the native helper thread (fill.start / fill.finish: vihds/nprand.py).
-        Only the caller knows that the next consumer of that random stream is this graph's next replay (Training.run: the
-        next batch of the epoch); a prefetched draw that is never replayed has advanced the stream by one unused draw."""
-        if self.staged is not None:
+    def prefetch(self, ahead=1):
+        """Start the prefetchable slots' draws for the next `ahead` replays (at most AHEAD) on the native helper thread
+        (fill.start / fill.finish: vihds/nprand.py), which goes from one straight into the next.  Only the caller knows that
+        the next consumers of that random stream are this graph's next replays (Training.run: the epoch's next batches); a
+        prefetched draw that is never replayed has advanced the stream by one unused draw."""
+        n_pre = sum(1 for slot in self.slots if slot[4])
+        if n_pre != 1:  # (none to start -- or several streams to interleave, which the one queue cannot order)
             return
-        k, any_started = None, False
-        for j, slot in enumerate(self.slots):
-            if slot[4] and hasattr(slot[1], "start"):
-                if k is None:
-                    k = self._stage()
-                slot[5] = bool(slot[1].start(self.views[k][j]))
-                any_started = any_started or slot[5]
-        if any_started:
-            self.staged = k
-        elif k is not None:
-            self.pos = k  # (nothing could be started now: the refresh takes this entry itself)
+        j = next(i for i, slot in enumerate(self.slots) if slot[4])
+        while len(self.staged) < min(int(ahead), self.AHEAD):
+            k = self._stage()
+            if not self.slots[j][1].start(self.views[k][j]):
+                self.pos = k  # (not startable now: the refresh takes this entry itself)
+                break
+            self.staged.append(k)
 
     def refresh(self):
-        k, self.staged = (self.staged if self.staged is not None else self._stage()), None
+        ahead = bool(self.staged)
+        k = self.staged.pop(0) if ahead else self._stage()
         for j, slot in enumerate(self.slots):
-            if slot[5]:  # drawn ahead by prefetch()
-                slot[5] = False
+            if ahead and slot[4]:  # drawn ahead by prefetch()
                 slot[1].finish()
             else:
                 slot[1](self.views[k][j])
-        self.arena[: self.used].copy_(self.pinned[k], non_blocking=True)
+        self.upload.copy_(self.pinned[k], non_blocking=True)
         if self.events[k] is None:
             self.events[k] = torch.cuda.Event()
         self.events[k].record()
@@ -111,14 +112,14 @@ def note(shape):
         ACTIVE.note(shape)
 
 
-def replay(graph, next_graph=None):
+def replay(graph, next_graph=None, ahead=1):
     """graph.replay() behind the refresh of the host draws it was captured with (Training attaches them as
-    graph.host_draws).  next_graph: the graph whose replay is KNOWN to be the next consumer of the host streams (often the
-    same one): its prefetchable draws start on the helper thread as soon as this replay is queued."""
+    graph.host_draws).  next_graph: the graph whose replays are KNOWN to be the next `ahead` consumers of the host streams
+    (often the same one): its prefetchable draws start on the helper thread as soon as this replay is queued."""
     draws = getattr(graph, "host_draws", None)
     if draws:
         draws.refresh()
     graph.replay()
     nxt = getattr(next_graph, "host_draws", None) if next_graph is not None else None
-    if nxt:
-        nxt.prefetch()
+    if nxt and (nxt is draws or not (draws and draws.staged)):
+        nxt.prefetch(ahead)

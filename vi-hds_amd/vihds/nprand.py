@@ -57,7 +57,7 @@ def _fingerprint():
     return (_POS.value, _KEY[0], _KEY[1], _KEY[396], _KEY[623])
 
 
-_IN_FLIGHT = False  # a Draw.start() whose finish() has not run yet
+_IN_FLIGHT = 0  # Draw.start()s whose finish() has not run yet (the library queues up to two)
 
 
 def _collect_stray():
@@ -65,8 +65,9 @@ def _collect_stray():
     hostdraws documents): wait for it, so that numpy's state is at rest before anybody reads or writes it."""
     global _IN_FLIGHT, _LEFT
     if _IN_FLIGHT:
-        _IN_FLIGHT = False
-        _lib().vihds_np_randn_f32_wait()
+        while _IN_FLIGHT:
+            _IN_FLIGHT -= 1
+            _lib().vihds_np_randn_f32_wait()
         _LEFT = _fingerprint()
 
 
@@ -129,22 +130,26 @@ class Draw(object):
         count, or numpy's state is not the one our last draw left in place) -- the caller draws synchronously instead."""
         global _LEFT, _IN_FLIGHT
         lib = _lib()
-        _collect_stray()
         flat = host.reshape(-1)
-        if (not lib or self.n == 0 or self.n % 2 or _LEFT is None or _fingerprint() != _LEFT or flat.dtype != np.float32
-                or flat.size != self.n or not flat.flags.c_contiguous):
+        if not lib or self.n == 0 or self.n % 2 or flat.dtype != np.float32 or flat.size != self.n or not flat.flags.c_contiguous:
+            return False
+        # (with a draw of ours in flight the generator is ours already and its state in motion: nothing to compare; else it
+        # must be the state our last draw left in place)
+        if not _IN_FLIGHT and (_LEFT is None or _fingerprint() != _LEFT):
             return False
         rc = lib.vihds_np_randn_f32_start(_ADDR, _ADDR + 624 * 4, flat.ctypes.data, self.n, _THREADS)
-        if rc != 0:
+        if rc != 0:  # (-2: two draws are queued already)
             return False
-        _LEFT = None  # (the state is in motion until finish())
-        _IN_FLIGHT = True
+        _LEFT = None  # (the state is in motion until the last finish())
+        _IN_FLIGHT += 1
         return True
 
     def finish(self):
+        """Wait for the OLDEST started draw."""
         global _LEFT, _IN_FLIGHT
-        _IN_FLIGHT = False
+        _IN_FLIGHT -= 1
         rc = _lib().vihds_np_randn_f32_wait()
         if rc != 0:
             raise RuntimeError("vihds_np_randn_f32_wait failed (%d)" % rc)
-        _LEFT = _fingerprint()
+        if not _IN_FLIGHT:
+            _LEFT = _fingerprint()

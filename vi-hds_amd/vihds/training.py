@@ -605,7 +605,7 @@ class Training:
         g.host_draws = draws
         return g, loss
 
-    def graph_step(self, batch, repeat=1, next_same=False):
+    def graph_step(self, batch, repeat=1, next_same=False, ahead=1):
         """The same step replayed from a hipGraph: the ~10^2 small launches of encoder + kernels + Adam become one
         graph launch.  Needs device-side RNG (u_rng=device, conditioner_rng=device) and a fixed batch shape.
         Capture follows PyTorch's whole-network recipe: warm up on a side stream, drop the .grad tensors, then
@@ -642,7 +642,7 @@ class Training:
                 static[k].copy_(batch[k], non_blocking=True)
             static["delta_obs"].copy_(_delta_obs(static.observations))
             self._staged[key] = batch
-        hostdraws.replay(g, g if next_same else None)
+        hostdraws.replay(g, g if next_same else None, ahead)
         if repeat > 1:
             self.last_losses = loss
             return loss[-1]
@@ -693,12 +693,13 @@ class Training:
                 self.events[k] = torch.cuda.Event()
             self.events[k].record()
 
-    def step_rows(self, rows_host, next_rows=None):
+    def step_rows(self, rows_host, next_rows=None, ahead=1):
         """One training step on the rows `rows_host` (host int64 tensor) of the resident training set: eager, or -- with
         params.hip_graph -- one hipGraph per batch size holding the gather and the step; per step the host then only
         refreshes the graph's index buffer (one small copy) and launches it.  next_rows: the rows of the step that is KNOWN to
         follow (Training.run: the epoch's next batch) -- its host-side numpy draw then starts on a helper thread as soon as
-        this step is queued (vihds/hostdraws.py)."""
+        this step is queued (vihds/hostdraws.py); ahead: how many of the steps that follow are known to be of next_rows' size
+        (the helper may then draw for two of them in a row)."""
         n = int(rows_host.shape[0])
         dev = self.train_data.observations.device
         if not self.use_graph:
@@ -716,7 +717,7 @@ class Training:
         g, static, loss, idx, staging = self._graphs[key]
         staging.upload(idx, lambda buf: buf.copy_(rows_host))
         nxt = self._graphs.get(("rows", int(next_rows.shape[0]))) if next_rows is not None else None
-        hostdraws.replay(g, nxt[0] if nxt is not None else None)
+        hostdraws.replay(g, nxt[0] if nxt is not None else None, ahead)
         return loss
 
     def epoch_rows(self, batches):
@@ -742,15 +743,15 @@ class Training:
         hostdraws.replay(g)
         return losses
 
-    def _run_batch(self, epoch_start, batch, log_data, next_batch=None):
+    def _run_batch(self, epoch_start, batch, log_data, next_batch=None, ahead=1):
         """reference training.py:324-340.  `batch`: a batch of the reference's form, or the row indices of one (host int64
         tensor: what self.train_loader yields).  next_batch: the batch that is known to follow (see step_rows)."""
         log_data.batch_feed_time += time.time() - epoch_start
         train_start = time.time()
         if isinstance(batch, torch.Tensor):
-            elbo = self.step_rows(batch, next_batch if isinstance(next_batch, torch.Tensor) else None)
+            elbo = self.step_rows(batch, next_batch if isinstance(next_batch, torch.Tensor) else None, ahead)
         else:
-            elbo = (self.graph_step(batch, next_same=next_batch is batch) if self.use_graph else self.step(batch))
+            elbo = (self.graph_step(batch, next_same=next_batch is batch, ahead=ahead) if self.use_graph else self.step(batch))
         self._steps += 1
         if self.use_graph and self.nan_check_every == 1 and self.replica is None and self.shard is None:
             # The reference looks at every step's ELBO (training.py:331), a device synchronisation per step.  With the step
@@ -855,10 +856,14 @@ class Training:
                     log_data.batch_train_time += time.time() - train_start
                 else:
                     todo = batches if batches is not None else list(self.train_loader)
+                    def n_rows(b):
+                        return int(b.shape[0]) if isinstance(b, torch.Tensor) else len(b.observations)
+
                     for j, batch in enumerate(todo):
-                        if iterating:  # (the batch that follows inside the epoch is known: its numpy draw runs ahead)
-                            iterating = self._run_batch(epoch_start, batch, log_data,
-                                                        next_batch=todo[j + 1] if j + 1 < len(todo) else None)
+                        if iterating:  # (the batches that follow inside the epoch are known: their numpy draws run ahead)
+                            nxt = todo[j + 1] if j + 1 < len(todo) else None
+                            two = nxt is not None and j + 2 < len(todo) and n_rows(todo[j + 2]) == n_rows(nxt)
+                            iterating = self._run_batch(epoch_start, batch, log_data, next_batch=nxt, ahead=2 if two else 1)
                 log_data.total_train_time += time.time() - epoch_start
                 if iterating and (np.mod(epoch, self.args.test_epoch) == 0):
                     iterating = settle()
