@@ -574,14 +574,14 @@ def unchanged_spec_leg(a, dev, min_seconds):
         if not training._run_batch(time.time(), batch, log, next_batch=batch, ahead=2):  # (the same resident batch follows, twice)
             raise SystemExit("NaN objective in the unchanged-spec leg")
 
-    for _ in range(20):  # (the capture and its warm-up steps happen in here)
+    for _ in range(50):  # (the capture and its warm-up steps happen in here; the helper thread and its pool come up)
         step()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(10):
+    for _ in range(100):
         step()
     torch.cuda.synchronize()
-    n = max(20, int(math.ceil(min_seconds / ((time.perf_counter() - t0) / 10))))
+    n = max(500, int(math.ceil(min_seconds / ((time.perf_counter() - t0) / 100))))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(n):
