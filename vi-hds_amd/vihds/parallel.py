@@ -84,27 +84,32 @@ class SegmentedGraph(object):
 
 
 # ---- collectives INSIDE the captured step ------------------------------------------------------------------------
-# RCCL (torch's "nccl" backend on ROCm) can record its kernels into a stream capture; whether THIS software stack does is
-# found out once, in a throw-away child process (a capture that fails cannot be undone in the process it failed in): a
-# one-rank communicator on this GPU, one all_reduce and one all_gather_into_tensor captured into a hipGraph, replayed and
-# checked.  VIHDS_CAPTURE_COLLECTIVES=0 / 1 overrides the probe; gloo (the CPU-side test backend) is never captured.
+# RCCL (torch's "nccl" backend on ROCm) can record its kernels into a stream capture; whether THIS software stack does -- at
+# THIS world size -- is found out once, in throw-away child processes (a capture that fails cannot be undone in the process it
+# failed in, and one that hangs would take the job with it): every rank starts a child on its own GPU, the children form a
+# communicator of the job's size among themselves, capture one all_reduce and one all_gather_into_tensor into a hipGraph,
+# replay it twice and check the numbers; a child that fails, or is not done within the time limit, means "do not capture"
+# for every rank.  VIHDS_CAPTURE_COLLECTIVES=0 / 1 overrides the probe; gloo (the CPU-side test backend) is never captured.
 _CAPTURABLE = None
 _PROBE = r"""
 import os, sys, torch, torch.distributed as dist
-dev = int(sys.argv[1]); port = sys.argv[2]
+dev, port, rank, world = int(sys.argv[1]), sys.argv[2], int(sys.argv[3]), int(sys.argv[4])
 torch.cuda.set_device(dev)
-dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, rank=0, world_size=1)
-x = torch.ones(4096, device="cuda"); y = torch.empty(4096, device="cuda"); z = torch.arange(8, device="cuda", dtype=torch.float32)
-dist.all_reduce(x); dist.all_gather_into_tensor(y[:8], z)   # communicator set-up outside the capture
+dist.init_process_group("nccl", init_method="tcp://127.0.0.1:" + port, rank=rank, world_size=world)
+x = torch.ones(4096, device="cuda"); y = torch.empty(8 * world, device="cuda"); z = torch.arange(8, device="cuda", dtype=torch.float32)
+dist.all_reduce(x); dist.all_gather_into_tensor(y, z)   # communicator set-up outside the capture
 torch.cuda.synchronize()
 g = torch.cuda.CUDAGraph(); s = torch.cuda.Stream(); s.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(s):
     g.capture_begin(capture_error_mode="thread_local")
-    x.mul_(2.0); dist.all_reduce(x); dist.all_gather_into_tensor(y[:8], z); x.add_(1.0)
+    x.mul_(2.0); dist.all_reduce(x); dist.all_gather_into_tensor(y, z); x.add_(1.0)
     g.capture_end()
 torch.cuda.current_stream().wait_stream(s)
-x.fill_(1.0); g.replay(); g.replay(); torch.cuda.synchronize()
-ok = bool((x == 7.0).all()) and bool((y[:8] == z).all())
+x.fill_(1.0); y.zero_(); g.replay(); g.replay(); torch.cuda.synchronize()
+want = 1.0
+for _ in range(2):
+    want = want * 2.0 * world + 1.0
+ok = bool((x == want).all()) and bool((y.view(world, 8) == z).all())
 dist.destroy_process_group()
 print("VIHDS_CAPTURE_PROBE", "ok" if ok else "wrong")
 """
@@ -113,7 +118,7 @@ print("VIHDS_CAPTURE_PROBE", "ok" if ok else "wrong")
 def collectives_capturable(group=None):
     """True when the step's collectives may be recorded inside ONE hipGraph with the kernels around them (then a
     multi-rank step is one graph launch, several steps per launch included); False: the step is cut at its collectives
-    (SegmentedGraph).  Every rank asks rank 0's answer, so all of them capture the same way."""
+    (SegmentedGraph).  All ranks take part in the probe and agree on the answer, so all of them capture the same way."""
     global _CAPTURABLE
     if _CAPTURABLE is not None:
         return _CAPTURABLE
@@ -124,31 +129,40 @@ def collectives_capturable(group=None):
     elif not dist.is_initialized() or dist.get_backend(group) != "nccl" or not torch.cuda.is_available():
         ans = False
     if ans is None:
-        flag = torch.zeros(1, device="cuda")
-        if dist.get_rank(group) == 0:
-            flag[0] = 1.0 if _probe_capture() else 0.0
-        dist.broadcast(flag, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        import socket
+
+        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        src = dist.get_global_rank(group, 0) if group is not None else 0
+        port = torch.zeros(1, device="cuda", dtype=torch.int64)
+        if rank == 0:
+            with socket.socket() as sock:
+                sock.bind(("127.0.0.1", 0))
+                port[0] = sock.getsockname()[1]
+        dist.broadcast(port, src=src, group=group)
+        flag = torch.tensor([1.0 if _probe_capture(rank, world, int(port.item())) else 0.0], device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
         ans = bool(flag.item() > 0)
     _CAPTURABLE = ans
     return ans
 
 
-def _probe_capture(timeout=180):
+def _probe_capture(rank=0, world=1, port=None, timeout=180):
     import socket
     import subprocess
     import sys
 
-    with socket.socket() as sock:
-        sock.bind(("127.0.0.1", 0))
-        port = sock.getsockname()[1]
+    if port is None:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
     env = dict(os.environ)
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT", "GROUP_RANK", "LOCAL_WORLD_SIZE",
               "TORCHELASTIC_RUN_ID"):
         env.pop(k, None)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     try:
-        out = subprocess.run([sys.executable, "-c", _PROBE, str(torch.cuda.current_device()), str(port)], env=env,
-                             capture_output=True, text=True, timeout=timeout)
+        out = subprocess.run([sys.executable, "-c", _PROBE, str(torch.cuda.current_device()), str(port), str(rank), str(world)],
+                             env=env, capture_output=True, text=True, timeout=timeout)
     except Exception:  # noqa: BLE001 (a probe that hangs or cannot start means: do not capture)
         return False
     return out.returncode == 0 and "VIHDS_CAPTURE_PROBE ok" in out.stdout
