@@ -801,6 +801,12 @@ def main():
     if shard is not None and a.shard == "rows":  # data parallel over rows: replicas + one gradient all-reduce
         replica, shard = parallel.RowReplica(shard.rank, shard.world, shard.group), None
     multi = shard is not None or replica is not None
+    if multi:
+        # (a multi-rank run that stops making progress -- a collective one rank never joins, a capture that hangs -- says where
+        # it stands and ends after twenty minutes instead of sitting there: this path has only ever run with one rank)
+        import faulthandler
+
+        faulthandler.dump_traceback_later(1200, exit=True)
     local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
