@@ -42,8 +42,8 @@ t0 = st[:, :, 0].min()
 us = (st - t0) / 100.0  # 100 MHz
 us[st == 0] = np.nan
 order = [0, 14, 15, 1, 11, 12, 2, 3, 4, 5, 6, 7, 8, 9, 13, 10]
-names = {0: "start", 14: "requests, row indirection, draws", 15: "sampling arithmetic, stores", 11: "own work: chain (wave 0) / hill, conditioner", 12: "barrier B", 1: "(sampling stage,) sigmoid table, barrier",
-         2: "gamma pass, barrier C", 3: "parameters", 4: "level-1 maps + scan", 5: "level-1 steps, level-2 maps + scan",
+names = {0: "start", 14: "requests, row indirection, draws", 15: "sampling arithmetic, conditioner rows, stores", 11: "x chain (Newton over the lanes), gamma", 12: "Hill terms", 1: "coefficients, barrier A",
+         2: "(nothing: the old barrier slot)", 3: "parameters", 4: "level-1 maps + scan", 5: "level-1 steps, level-2 maps + scan",
          6: "log-likelihood", 7: "adjoint level 2", 8: "adjoint level 1", 9: "adjoint x", 13: "epilogue barrier", 10: "epilogue (end)"}
 print("launch: first start 0, last end %.1f us; %d blocks x %d waves" % (np.nanmax(us[:, :, 10]), nblk, nw))
 start = us[:, 0, 0]
@@ -62,6 +62,6 @@ for ph in order[1:]:
              np.nanmedian(d[~first]) if (~first).any() else float("nan")))
     if ph == 11:
         for w in range(nw):
-            print("      wave %d own work: median %5.2f  max %5.2f" % (w, np.nanmedian(d[:, w]), np.nanmax(d[:, w])))
+            print("      wave %d: median %5.2f  max %5.2f" % (w, np.nanmedian(d[:, w]), np.nanmax(d[:, w])))
     prev = ph
 

@@ -464,7 +464,10 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   // slot at the same time, and at a distance of 512 bytes the two addresses fell into one bank -- every th() two passes)
   auto par_of = [&](int t) { return lds + O_Y + (t >> 1) * 256 + (t & 1) * 100; };
   float* par = par_of(tib);
-  auto th = [&](int slot) { return par[a.slot_row[slot]]; };
+  // (from the end of the first stage on `par` is in SLOT order -- see the permutation there: par[slot] is a constant
+  // offset, neighbouring slots are read together, and no later phase waits for a scalar load of a.slot_row from the
+  // kernel-argument segment: those misses were ~0.5 us each, two or three in a row ahead of the Hill stage)
+  auto th = [&](int slot) { return par[slot]; };
 
 #ifdef VIHDS_SCAN_STAMPS
   VIHDS_SCAN_STOP(0)
@@ -522,10 +525,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     stage_grid_and_observations();
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const int slot = l + 32 * q;
-      if (slot < M::NSLOT + 4) {
-        const int row = a.slot_row[slot];
-        par[row] = a.theta[(size_t)row * n + i];
-      }
+      if (slot < M::NSLOT + 4) par[slot] = a.theta[(size_t)out_row[q] * n + i];  // (slot order; out_row: this lane's slots' rows)
     }
     block_sync_lds();
   } else {
@@ -690,6 +690,16 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     if (live && cmine && cd == 0) t.theta[(size_t)(t.cond_row0 + ce) * n + i] = cf_val;
     wave_sync();  // this trajectory's theta rows are in `par` (its own lanes wrote them)
+    {
+      // rows -> slots, in place: lane l picks up the rows of its slots l and l + 32 (out_row, fetched per lane at kernel
+      // entry with everything else), then all write.  Rows no slot names are not needed again.
+      float pv[2];
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q) pv[q] = par[out_row[q]];
+      wave_sync();
+      VIHDS_UNROLL for (int q = 0; q < 2; ++q)
+        if (l + 32 * q < M::NSLOT + 4) par[l + 32 * q] = pv[q];
+      wave_sync();
+    }
 #ifdef VIHDS_SCAN_STAMPS
     VIHDS_SCAN_STOP(15)
 #endif
@@ -825,7 +835,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     }
     {
       float* pp = par;
-      auto tht = [&](int slot) { return pp[a.slot_row[slot]]; };
+      auto tht = [&](int slot) { return pp[slot]; };
       float cc[2];
       treatments(cc);
       const int j = l & 7;
@@ -895,7 +905,8 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         cc = fmaxf(cc, 0.f);
         const float val = t_dfl[e] + cc;
         if (lv) t.theta[(size_t)(t.cond_row0 + e) * n + it] = val;
-        par_of(tt)[t.cond_row0 + e] = val;
+        for (int sl = 0; sl < M::NSLOT + 4; ++sl)  // (`par` is in slot order by now: the slots that name this row)
+          if (a.slot_row[sl] == t.cond_row0 + e) par_of(tt)[sl] = val;
       }
     }
     wave_sync();  // this wavefront's Hill terms and conditioner rows are in its trajectories' parameters
