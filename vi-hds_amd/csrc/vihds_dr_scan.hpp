@@ -12,11 +12,14 @@
 // oracle's autograd in float64 by tests/probe/scan_proto.py for all five solvers).
 //
 // Mapping: 32 lanes per trajectory, lane l owns the steps k = l*ITEMS .. l*ITEMS+ITEMS-1 (ITEMS = ceil((T-1)/32) <= 4),
-// two trajectories per wavefront, all 8 species of a step in one lane's registers.  A wavefront never waits for
-// another one (no block barrier): its tables sit in its own slice of LDS.
-//   1. sigmoid table  sig[k][s]          every lane its own steps                           (state independent)
-//   2. x chain                           serial over k, all lanes of the half-wave in step  (u = x / K: 2 dependent
-//                                        instructions per stage), stage values u[k][s] -> LDS
+// two trajectories per wavefront, all 8 species of a step in one lane's registers.  Between the barrier behind the first
+// stage (the block's shared time grid) and the epilogue's, a wavefront never waits for another one: its records sit in its
+// own slice of LDS.
+//   0. (decoder step) sampling stage: theta = clip(sample(q, u)), log q, log p, the device conditioner's rows
+//   1. coefficients  |w| h r sigmoid(4 (t_s - tlag)) of this lane's steps                   (state independent, registers)
+//   2. x chain       u_{k+1} = Phi_k(u_k), the one nonlinear recurrence, solved over the lanes by Newton's method: every
+//                    lane walks its own steps from its current first value with the derivative, the linearised recurrence
+//                    is an affine scan (round 4; before: 85 steps walked by one wavefront); stage values u[k][s] -> LDS
 //   3. rfp, W (f530 = a530 W, f480 = a480 W), luxR, lasR: per-step affine maps, composed per lane, DPP scan over lanes
 //   4. promoters at the stage values of luxR / lasR -> yfp, cfp the same way
 //   5. log-likelihood at the grid points, segment sum
