@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 12
+#define VIHDS_ABI_VERSION 13
 
 /* error codes */
 #define VIHDS_OK 0
@@ -501,6 +501,16 @@ int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* stat
  *   state: FOUR device floats {step count, (unused), 1/(1-beta1^t), sqrt(1-beta2^t)}: the first launch counts the
  *     step and writes the two bias corrections for the second.  state = NULL: gradients and loss only, no update.
  * VIHDS_E_UNSUPPORTED when the row working set (S importance weights + the encoder's row buffers) exceeds 60 KB of LDS. */
+#define VIHDS_TAIL_MAX_EXTRA 4
+typedef struct vihds_tail_tensor { /* one decoder-side parameter tensor of vihds_step_tail (see extra[] below) */
+  float* param;
+  float* grad;
+  const float* grad_src;
+  const int* map;
+  int size, nparts;
+  long long part_stride;
+  int mv_offset;
+} vihds_tail_tensor;
 typedef struct vihds_step_tail_args {
   int P, S;
   const int* kind;
@@ -519,6 +529,30 @@ typedef struct vihds_step_tail_args {
   float *m, *v, *state;
   const float* lr_dev;
   float lr, beta1, beta2, eps;
+  /* ---- ABI 13: any model, not only the ones whose trainable parameters are all in the encoder (all zero / NULL: the
+   * form above, fed by vihds_theta_ode_logp_grad's unit-weight gradient) -------------------------------------------
+   * g_theta_weighted = 1: g_theta_unit already carries the importance weight d loss / d log_w (it is vihds_ode_bwd's
+   *   output for the g_logp that vihds_iwae_loss_fwd / vihds_ode_bwd_elbo formed), so the theta adjoint does not
+   *   multiply by it again.
+   * g_shift_lo / g_shift_n / g_shift: parameters p in [g_shift_lo, g_shift_lo + g_shift_n) take their gradient from row
+   *   p + g_shift of g_theta_unit instead of row p (dr_blackbox: the sampled y receive the gradient of the
+   *   device-conditioned rows the integrator read, models/dr_blackbox.py:86-96).
+   * extra[k], k < n_extra: decoder-side parameter tensors (NeuralPrecisions / NeuralStates weights, reference
+   *   precisions.py:44-87, ode.py:119-146), updated by the same Adam launch: the gradient of element e is the sum over
+   *   `nparts` partial rows, grad_src[part * part_stride + (map ? map[e] : e)], parts in ascending order (nparts = 1: an
+   *   already reduced flat gradient; nparts > 1: one partial row per block of the lane-split adjoint, vihds_ode_bwd's
+   *   aux).  grad[e] receives the sum, param / m / v are updated in place (mv_offset as above).
+   * offset layer (dr_blackbox's Linear(D, n_y) of condition_theta): off_n rows starting at g_theta row off_row0;
+   *   g_W[i][d] = sum_b dev1hot[b][d] rs[i][b], g_b[i] = sum_b rs[i][b], rs[i][b] = sum_s g_theta[off_row0+i][b][s]
+   *   (x the importance weight unless g_theta_weighted); off_rowsum [off_n][B] is a work buffer. */
+  int g_theta_weighted;
+  int g_shift_lo, g_shift_n, g_shift;
+  int n_extra;
+  vihds_tail_tensor extra[VIHDS_TAIL_MAX_EXTRA];
+  int off_n, off_row0;
+  float *off_w, *off_b, *off_gw, *off_gb;
+  int off_mv_w, off_mv_b;
+  float* off_rowsum;
 } vihds_step_tail_args;
 int vihds_step_tail(const vihds_encoder_shape* s, const vihds_step_tail_args* a, void* stream);
 int vihds_step_tail_supported(const vihds_encoder_shape* s, int P, int S); /* 1 / 0: shapes vihds_step_tail takes (LDS budget,

@@ -883,6 +883,21 @@ int vihds_step_tail(const vihds_encoder_shape* s, const vihds_step_tail_args* a,
     if (a->param[k] && (!a->grad[k] || a->mv_offset[k] < 0)) return fail(VIHDS_E_BADARG, "bad tensor table entry");
   }
   if (a->state && (!a->m || !a->v)) return fail(VIHDS_E_BADARG, "state without moment buffers");
+  // ABI 13: decoder-side tensors, the offset layer, shifted gradient rows
+  if (a->n_extra < 0 || a->n_extra > VIHDS_TAIL_MAX_EXTRA) return fail(VIHDS_E_BADARG, "n_extra out of range");
+  for (int k = 0; k < a->n_extra; ++k) {
+    const vihds_tail_tensor& t = a->extra[k];
+    if (!t.param || !t.grad || !t.grad_src || t.size <= 0 || t.nparts <= 0 || t.mv_offset < 0 ||
+        (t.nparts > 1 && t.part_stride <= 0))
+      return fail(VIHDS_E_BADARG, "bad decoder-side tensor entry");
+  }
+  if (a->off_n < 0 || (a->off_n > 0 && (!a->off_w || !a->off_b || !a->off_gw || !a->off_gb || !a->off_rowsum ||
+                                        !a->dev1hot || s->D <= 0 || a->off_row0 < 0 || a->off_mv_w < 0 || a->off_mv_b < 0)))
+    return fail(VIHDS_E_BADARG, "bad offset-layer entry");
+  if (a->off_n * (s->D + 1) > 256) return fail(VIHDS_E_UNSUPPORTED, "offset layer larger than one block of the update launch");
+  if (a->g_shift_n < 0 || (a->g_shift_n > 0 && (a->g_shift_lo < 0 || a->g_shift_lo + a->g_shift_n > a->P ||
+                                                a->g_shift_lo + a->g_shift < 0)))
+    return fail(VIHDS_E_BADARG, "bad gradient-row shift");
   if (!step_tail_supported(*s, a->P, a->S))
     return fail(VIHDS_E_UNSUPPORTED, "vihds_step_tail: working set exceeds the 60 KB LDS budget (or more than 10 filter taps)");
   launch_step_tail(*s, *a, (hipStream_t)stream);

@@ -103,9 +103,17 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
   float* red = lw_l + pad4(2 * s.nl * s.H);
   float* ctab = red + 2 * ROWS_NW;
   const vihds_iwae_job& iw = a.iwae;
-  // this block's parameters: [p_lo, p_hi), wavefront w takes p_lo + w, p_lo + w + 16, ...
+  // this block's tasks: [p_lo, p_hi), wavefront w takes p_lo + w, p_lo + w + 16, ...  Tasks 0..P-1 are the parameters;
+  // tasks P..P+off_n-1 (ABI 13: dr_blackbox's offset layer) are plain row sums over the samples of g_theta rows off_row0..
+  const int P_tasks = P + a.off_n;
   const int p_lo = chain ? 0 : s.nl + ROWS_NW * (part - 1);
-  const int p_hi = chain ? s.nl : min(P, p_lo + ROWS_NW);
+  const int p_hi = chain ? s.nl : min(P_tasks, p_lo + ROWS_NW);
+  // the row of g_theta_unit a task reads (ABI 13: a shifted range of parameters; the offset layer's rows)
+  auto g_row = [&](int p) {
+    if (p >= P) return a.off_row0 + (p - P);
+    return p + ((p >= a.g_shift_lo && p < a.g_shift_lo + a.g_shift_n) ? a.g_shift : 0);
+  };
+  const float unit_g = a.g_theta_weighted ? 0.f : 1.f;  // 1: g_theta_unit is the unit-weight gradient (x the weight here)
   VIHDS_TAIL_STOP(0, 0)
 
   // ---- every global read of the block is requested here, into registers: one memory round trip for the whole kernel --
@@ -160,7 +168,7 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
   float gx[RC];
 #pragma unroll
   for (int c = 0; c < RC; ++c)
-    gx[c] = a.g_theta_unit[(size_t)min(p_w, P - 1) * n + b * S + min(lane + 64 * c, S - 1)];
+    gx[c] = a.g_theta_unit[(size_t)g_row(min(p_w, P_tasks - 1)) * n + b * S + min(lane + 64 * c, S - 1)];
   VIHDS_TAIL_STOP(0, 1)
   // ---- registers -> LDS for what other threads read
   if (U_LDS) {
@@ -191,8 +199,8 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
       gall[rmp] = 0.f; gall[rpp] = 0.f;
     }
   };
-  if (cp < p_hi) fill_ctab(cp, c_kd, c_rm, c_rp, c_mu, c_pr, c_pm, c_pp, c_lo, c_hi);
-  for (int p = cp + ROWS_T; p < p_hi; p += ROWS_T) {  // (more than 1024 local parameters: not a case that exists; kept correct)
+  if (cp < min(p_hi, P)) fill_ctab(cp, c_kd, c_rm, c_rp, c_mu, c_pr, c_pm, c_pp, c_lo, c_hi);
+  for (int p = cp + ROWS_T; p < min(p_hi, P); p += ROWS_T) {  // (more than 1024 local parameters: not a case that exists; kept correct)
     const int rmp = a.q_rows[p], rpp = a.q_rows[P + p];
     fill_ctab(p, a.kind[p], rmp, rpp, a.q_all[(size_t)rmp * B + b], a.q_all[(size_t)rpp * B + b], a.p_mu[p], a.p_prec[p],
               a.clip_lo[p], a.clip_hi[p]);
@@ -281,7 +289,7 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
       // d lq/dv = prec*(mu - v) - jac ; d lp/dv = pp*(pm - v) - jac
       const float dd = muk - v;
       const float gv = glq * (prec * dd - jac) + glp * (ppk * (pmk - v) - jac);
-      float gz = (g * gw + gv * dv_dx) * pass;  // back through clip ...
+      float gz = (g * (unit_g != 0.f ? gw : 1.f) + gv * dv_dx) * pass;  // back through clip ...
       if (ln) gz *= xr;                         // ... and exp
       am += gz;                                 // z = mu + u / sqrt(prec)
       ap += gz * uu * c_ap;
@@ -295,7 +303,7 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
       if (sidx < S) body(sidx, U_LDS ? u_l[sidx * P + p] : ug[(size_t)sidx * P + p], first_rounds_g(cc, sidx));
     }
     for (int sidx = lane + 64 * RC; sidx < S; sidx += 64)
-      body(sidx, U_LDS ? u_l[sidx * P + p] : ug[(size_t)sidx * P + p], a.g_theta_unit[(size_t)p * n + b * S + sidx]);
+      body(sidx, U_LDS ? u_l[sidx * P + p] : ug[(size_t)sidx * P + p], a.g_theta_unit[(size_t)g_row(p) * n + b * S + sidx]);
     am = wave_total(am);
     ap = wave_total(ap);
     if (lane == 0) {
@@ -304,9 +312,28 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
       gall[rmk] = am; gall[rpk] = gp;
     }
   };
-  if (p_w < p_hi) run_param(p_w, [&](int cc, int) { return gx[cc]; });
-  for (int p = p_w + ROWS_NW; p < p_hi; p += ROWS_NW)
-    run_param(p, [&](int, int sidx) { return a.g_theta_unit[(size_t)p * n + b * S + sidx]; });
+  // (ABI 13) a row-sum task: rs[b] = sum_s g_theta[row][b][s] (x the importance weight when the gradient is unit-weight)
+  auto run_rowsum = [&](int p, auto first_rounds_g) {
+    float acc = 0.f;
+#pragma unroll
+    for (int cc = 0; cc < RC; ++cc) {
+      const int sidx = lane + 64 * cc;
+      if (sidx < S) acc += first_rounds_g(cc, sidx) * (unit_g != 0.f ? wsm[sidx] : 1.f);
+    }
+    for (int sidx = lane + 64 * RC; sidx < S; sidx += 64)
+      acc += a.g_theta_unit[(size_t)g_row(p) * n + b * S + sidx] * (unit_g != 0.f ? wsm[sidx] : 1.f);
+    acc = wave_total(acc);
+    if (lane == 0) a.off_rowsum[(size_t)(p - P) * B + b] = acc;
+  };
+  if (p_w < p_hi) {
+    if (p_w < P) run_param(p_w, [&](int cc, int) { return gx[cc]; });
+    else run_rowsum(p_w, [&](int cc, int) { return gx[cc]; });
+  }
+  for (int p = p_w + ROWS_NW; p < p_hi; p += ROWS_NW) {
+    auto ld = [&](int, int sidx) { return a.g_theta_unit[(size_t)g_row(p) * n + b * S + sidx]; };
+    if (p < P) run_param(p, ld);
+    else run_rowsum(p, ld);
+  }
   VIHDS_TAIL_STOP(0, 4)
   if (!chain) return;
   sync_lds();
@@ -385,6 +412,8 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
 // in a row is the whole launch.
 struct TailTasks {
   int nb_lin, nb_conv, nb_localw, nb_gcondw;
+  int nb_off;                          // ABI 13: the offset layer's block (0 / 1)
+  int nb_extra[VIHDS_TAIL_MAX_EXTRA];  // ABI 13: blocks of each decoder-side tensor
 };
 struct AdamScalars {
   float step_size, bc2_sqrt, one_m_b1, beta2, one_m_b2, eps;
@@ -630,6 +659,80 @@ step_tail_update_kernel(vihds_encoder_shape s, TailTasks tk, vihds_step_tail_arg
     if (live) adam_elem(a, k, 7, e, acc, pe, me, ve);
     return;
   }
+  blk -= tk.nb_gcondw;
+  if (blk < tk.nb_off) {
+    // ---- (ABI 13) dr_blackbox's offset layer: weight [off_n][D] = rowsum x dev1hot over the rows, bias [off_n] = row sums
+    const int nW = a.off_n * s.D, e = tid;
+    const bool isw = e < nW, live = e < nW + a.off_n;
+    const int ec = live ? e : 0;
+    const int i = isw ? ec / s.D : (live ? ec - nW : 0), dd = isw ? ec - i * s.D : 0;
+    float* pp_ = isw ? a.off_w + ec : a.off_b + i;
+    const int mvo = isw ? a.off_mv_w + ec : a.off_mv_b + i;
+    const float pe = *pp_, me = a.m[mvo], ve = a.v[mvo];
+    const float acc = dot_rows(a.off_rowsum + (size_t)i * B, 1, isw ? a.dev1hot + dd : nullptr, s.D, B);
+    const AdamScalars k = scalars();
+    if (live) {
+      (isw ? a.off_gw + ec : a.off_gb + i)[0] = acc;
+      if (k.apply && finite_f(acc)) {  // (adam_elem's arithmetic)
+        const float m1 = me + (acc - me) * k.one_m_b1, v1 = ve * k.beta2 + k.one_m_b2 * acc * acc;
+        a.m[mvo] = m1; a.v[mvo] = v1;
+        *pp_ = pe - k.step_size * (m1 / (sqrtf(v1) / k.bc2_sqrt + k.eps));
+      }
+    }
+    return;
+  }
+  blk -= tk.nb_off;
+#pragma unroll
+  for (int x = 0; x < VIHDS_TAIL_MAX_EXTRA; ++x) {
+    if (blk < tk.nb_extra[x]) {
+      // ---- (ABI 13) decoder-side tensor x: gradient = fixed-order sum over its partial rows, Adam on the element
+      const vihds_tail_tensor& t = a.extra[x];
+      if (t.nparts == 1) {  // one thread per element
+        const int e = blk * UPD_T + tid;
+        const bool live = e < t.size;
+        const int ec = live ? e : 0;
+        const int src = t.map ? t.map[ec] : ec;
+        const float pe = t.param[ec], me = a.m[t.mv_offset + ec], ve = a.v[t.mv_offset + ec];
+        const float ge = t.grad_src[src];
+        const AdamScalars k = scalars();
+        if (live) {
+          t.grad[e] = ge;
+          if (k.apply && finite_f(ge)) {
+            const float m1 = me + (ge - me) * k.one_m_b1, v1 = ve * k.beta2 + k.one_m_b2 * ge * ge;
+            a.m[t.mv_offset + e] = m1; a.v[t.mv_offset + e] = v1;
+            t.param[e] = pe - k.step_size * (m1 / (sqrtf(v1) / k.bc2_sqrt + k.eps));
+          }
+        }
+      } else {  // one wavefront per element: lane q adds parts q, q + 64, ... (8 requested together), then the lanes in order
+        const int e = blk * UPD_NW + wid;
+        const bool live = e < t.size;
+        const int ec = live ? e : 0;
+        const int src = t.map ? t.map[ec] : ec;
+        const float pe = t.param[ec], me = a.m[t.mv_offset + ec], ve = a.v[t.mv_offset + ec];
+        float acc = 0.f;
+        for (int q0 = 0; q0 < t.nparts; q0 += 64 * 8) {
+          float vq[8];
+#pragma unroll
+          for (int q = 0; q < 8; ++q) vq[q] = t.grad_src[(size_t)min(q0 + lane + 64 * q, t.nparts - 1) * t.part_stride + src];
+#pragma unroll
+          for (int q = 0; q < 8; ++q)
+            if (q0 + lane + 64 * q < t.nparts) acc += vq[q];
+        }
+        const float ge = wave_total(acc);
+        const AdamScalars k = scalars();
+        if (live && lane == 0) {
+          t.grad[e] = ge;
+          if (k.apply && finite_f(ge)) {
+            const float m1 = me + (ge - me) * k.one_m_b1, v1 = ve * k.beta2 + k.one_m_b2 * ge * ge;
+            a.m[t.mv_offset + e] = m1; a.v[t.mv_offset + e] = v1;
+            t.param[e] = pe - k.step_size * (m1 / (sqrtf(v1) / k.bc2_sqrt + k.eps));
+          }
+        }
+      }
+      return;
+    }
+    blk -= tk.nb_extra[x];
+  }
   // ---- the last block: bias / free-scalar sums (B-term sums of strided columns), then -ELBO
   const int n_lb = a.param[6] ? 2 * s.nl : 0;
   const int n_items = s.H + n_lb + 2 * s.ngl;
@@ -711,7 +814,7 @@ void launch_step_tail(const vihds_encoder_shape& s, const vihds_step_tail_args& 
   const TailDims d = tail_dims(s);
   const bool u_lds = step_tail_rows_lds_bytes(s, a.P, a.S, true) <= 60 * 1024;
   const size_t lds = step_tail_rows_lds_bytes(s, a.P, a.S, u_lds);
-  const int rest = a.P - s.nl;  // parameters without a path into the encoder's hidden layer: one wavefront each
+  const int rest = a.P + a.off_n - s.nl;  // tasks without a path into the encoder's hidden layer: one wavefront each
   const dim3 grid(s.B, 1 + (rest > 0 ? (rest + ROWS_NW - 1) / ROWS_NW : 0));
 #define VIHDS_TAIL_ROWS(UL, HM) hipLaunchKernelGGL((step_tail_rows_kernel<UL, HM>), grid, dim3(ROWS_T), lds, st, s, a)
   if (u_lds) {
@@ -729,7 +832,14 @@ void launch_step_tail(const vihds_encoder_shape& s, const vihds_step_tail_args& 
   tk.nb_conv = s.F * s.C_in;
   tk.nb_localw = (2 * s.nl * d.NX + UPD_T - 1) / UPD_T;
   tk.nb_gcondw = (2 * s.ng * d.NG + UPD_T - 1) / UPD_T;
-  const int nblocks = tk.nb_lin + tk.nb_conv + tk.nb_localw + tk.nb_gcondw + 1;
+  tk.nb_off = a.off_n > 0 ? 1 : 0;
+  int nb_x = 0;
+  for (int x = 0; x < VIHDS_TAIL_MAX_EXTRA; ++x) {
+    const vihds_tail_tensor& t = a.extra[x];
+    tk.nb_extra[x] = x < a.n_extra ? (t.nparts == 1 ? (t.size + UPD_T - 1) / UPD_T : (t.size + UPD_NW - 1) / UPD_NW) : 0;
+    nb_x += tk.nb_extra[x];
+  }
+  const int nblocks = tk.nb_lin + tk.nb_conv + tk.nb_localw + tk.nb_gcondw + tk.nb_off + nb_x + 1;
   hipLaunchKernelGGL(step_tail_update_kernel, dim3(nblocks), dim3(UPD_T), step_tail_update_lds_bytes(s), st, s, tk, a);
 }
 

@@ -92,6 +92,9 @@ class DR_Blackbox(OdeModel):
     def neural_weights(self):
         return self._flat(self.neural_states.weight_tensors() + self.precisions.weight_tensors())
 
+    def flat_weight_tensors(self):
+        return self.neural_states.weight_tensors() + self.precisions.weight_tensors()
+
     def kernel_slots(self):
         """reference dr_blackbox.py:34-52: latents z (locals), x (globals), then the device-conditioned y."""
         return (["z%d" % (i + 1) for i in range(self.n_z)] + ["x%d" % (i + 1) for i in range(self.n_x)]

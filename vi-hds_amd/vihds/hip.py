@@ -114,6 +114,17 @@ class AdamTensors(ctypes.Structure):
                 ("param", ctypes.c_void_p * ADAM_MAX_TENSORS), ("grad", ctypes.c_void_p * ADAM_MAX_TENSORS)]
 
 
+TAIL_MAX_EXTRA = 4
+
+
+class TailTensor(ctypes.Structure):
+    """struct vihds_tail_tensor (include/vihds_hip.h)"""
+
+    _fields_ = [("param", ctypes.c_void_p), ("grad", ctypes.c_void_p), ("grad_src", ctypes.c_void_p),
+                ("map", ctypes.c_void_p), ("size", ctypes.c_int), ("nparts", ctypes.c_int),
+                ("part_stride", ctypes.c_longlong), ("mv_offset", ctypes.c_int)]
+
+
 class StepTailArgs(ctypes.Structure):
     """struct vihds_step_tail_args (include/vihds_hip.h)"""
 
@@ -126,7 +137,13 @@ class StepTailArgs(ctypes.Structure):
                 ("hidden", ctypes.c_void_p), ("g_pre", ctypes.c_void_p), ("g_conv", ctypes.c_void_p),
                 ("param", ctypes.c_void_p * 8), ("grad", ctypes.c_void_p * 8), ("mv_offset", ctypes.c_int * 8),
                 ("m", ctypes.c_void_p), ("v", ctypes.c_void_p), ("state", ctypes.c_void_p), ("lr_dev", ctypes.c_void_p),
-                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float)]
+                ("lr", ctypes.c_float), ("beta1", ctypes.c_float), ("beta2", ctypes.c_float), ("eps", ctypes.c_float),
+                # ABI 13: pre-weighted gradients, shifted gradient rows, decoder-side tensors, dr_blackbox's offset layer
+                ("g_theta_weighted", ctypes.c_int), ("g_shift_lo", ctypes.c_int), ("g_shift_n", ctypes.c_int),
+                ("g_shift", ctypes.c_int), ("n_extra", ctypes.c_int), ("extra", TailTensor * TAIL_MAX_EXTRA),
+                ("off_n", ctypes.c_int), ("off_row0", ctypes.c_int), ("off_w", ctypes.c_void_p), ("off_b", ctypes.c_void_p),
+                ("off_gw", ctypes.c_void_p), ("off_gb", ctypes.c_void_p), ("off_mv_w", ctypes.c_int),
+                ("off_mv_b", ctypes.c_int), ("off_rowsum", ctypes.c_void_p)]
 
 
 _PROTOTYPES = {
@@ -207,7 +224,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 12:
+        if handle.vihds_abi_version() != 13:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

@@ -203,6 +203,12 @@ class OdeModel(nn.Module):
         """Flat weight buffer for models with neural blocks (None for white-box models)."""
         return None
 
+    def flat_weight_tensors(self):
+        """The nn.Parameters behind neural_weights(), in the flat buffer's order ([] for white-box models): what
+        ops.GeneralTail updates in the step's last launch."""
+        prec = self.precisions
+        return list(prec.weight_tensors()) if getattr(prec, "dynamic", False) else []
+
     def problem_kwargs(self, config):
         return {}
 
@@ -244,7 +250,9 @@ class OdeModel(nn.Module):
         row_offset, row_offset_map = getattr(theta, "_row_offset", None) or (None, None)
         # evaluation passes (no graph to differentiate) leave x_predict to whoever asks for it: Training.cost's summaries
         # form it inside their kernel, plugin code reading DecoderResult gets it from the map below
-        lazy = not torch.is_grad_enabled() and bool(default_get_value(config.params, "lazy_x_predict", True))
+        # (... and so do training steps whose backward is ops.GeneralTail: nobody reads x_predict there)
+        lazy = ((not torch.is_grad_enabled() or getattr(self, "_train_without_x_predict", False))
+                and bool(default_get_value(config.params, "lazy_x_predict", True)))
         traj, xpred, logp = ops.OdeSolveObserve.apply(spec, packed, conditions.to(dev), times, obs.to(dev),
                                                       dev_1hot.to(dev) if dev_1hot is not None else None,
                                                       self.neural_weights(), row_offset, row_offset_map, not lazy)

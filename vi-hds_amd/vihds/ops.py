@@ -258,6 +258,7 @@ class OdeSolveObserve(torch.autograd.Function):
         hip.check(rc, "vihds_ode_fwd")
         ctx.spec, ctx.prob, ctx.time_fastest = spec, prob, time_fastest
         ctx.row_offset_map = row_offset_map if row_offset is not None else None
+        ctx.logp_out = logp.detach()  # (GeneralTail reads the step's forward state off this node)
         ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
         ctx.set_materialize_grads(False)
         if time_fastest:
@@ -1162,6 +1163,244 @@ class StepTail(object):
             if t is not None:
                 t.grad = v
         return job["loss"]
+
+
+class GeneralTail(StepTail):
+    """vihds_step_tail for ANY model (ABI 13; reference training.py:324-340 is model-agnostic): the step's forward ran as
+    the ordinary autograd-tracked launches (encoder -> theta kernel -> [conditioning] -> vihds_ode_fwd); this object runs
+    everything behind them WITHOUT autograd: the IWAE launch (loss, importance weights), vihds_ode_bwd fed those weights
+    as its log-likelihood gradient, the decoder networks' weight-gradient contraction where the model has one, and the two
+    tail launches -- whose second now also applies Adam to the decoder-side tensors (NeuralPrecisions / NeuralStates
+    weights, dr_blackbox's offset layer) and whose first forms the offset layer's row sums.  What used to be ten to thirteen
+    launches (theta adjoint, offset adjoint, weight reduce, encoder adjoint x 2, Adam, several aten fills / adds) is two."""
+
+    def __init__(self, encoder, optimizer, ode_model):
+        super(GeneralTail, self).__init__(encoder, optimizer)
+        self.ode = ode_model
+        self.flat_tensors = ode_model.flat_weight_tensors()  # [] for white-box models; the kernels' weight buffer order
+        off = getattr(ode_model, "offset_layer", None)
+        self.offset = off if (off is not None and getattr(ode_model, "n_y", 0) > 0) else None
+        self._bufs = {}
+        self._maps = {}
+
+    def applicable(self):
+        """HipAdam, one parameter group = the encoder's tensors + every decoder-side parameter, each of which this path
+        updates (the flat weight buffer's tensors, the offset layer)."""
+        from vihds.optim import HipAdam
+
+        opt = self.optimizer
+        if not isinstance(opt, HipAdam) or len(opt.param_groups) != 1:
+            return False
+        group = [p for p in opt.param_groups[0]["params"] if p.requires_grad]
+        mine = [t for t in self.tensors if t is not None] + list(self.flat_tensors)
+        if self.offset is not None:
+            mine += [self.offset.weight, self.offset.bias]
+        decoder = [p for p in self.ode.parameters() if p.requires_grad]
+        covered = {id(t) for t in mine}
+        if any(id(p) not in covered for p in decoder):
+            return False
+        return (len(group) == len(mine) and {id(p) for p in group} == covered and all(t.is_cuda for t in mine)
+                and len(self._chunks_static()) <= hip.TAIL_MAX_EXTRA)
+
+    def _chunks_static(self):
+        """Runs of the flat weight buffer's tensors that are also back to back in Adam's flat m / v (= consecutive in
+        model.parameters() order): [(first tensor index, n tensors, flat offset, size)]."""
+        opt = self.optimizer
+        order = {id(p): k for k, p in enumerate(p for p in opt.param_groups[0]["params"] if p.requires_grad)}
+        chunks, o = [], 0
+        for k, t in enumerate(self.flat_tensors):
+            if chunks and order.get(id(t), -9) == order.get(id(self.flat_tensors[k - 1]), -9) + 1:
+                first, cnt, fo, size = chunks[-1]
+                chunks[-1] = (first, cnt + 1, fo, size + t.numel())
+            else:
+                chunks.append((k, 1, o, t.numel()))
+            o += t.numel()
+        return chunks
+
+    def _lane_map(self, NIN, dev):
+        """flat element (Wp [4][NIN], bp [4], Wd [4][NIN], bd [4]) -> its place in a lane-split adjoint's partial row
+        (vihds_relay_lanes.hpp: [4][2 NIN + 2] = rows (Wp row, Wd row, bp, bd) of output o)."""
+        key = (NIN, str(dev))
+        if key not in self._maps:
+            nwrow = 2 * NIN + 2
+            m = []
+            for o in range(4):
+                m += [o * nwrow + j for j in range(NIN)]
+            m += [o * nwrow + 2 * NIN for o in range(4)]
+            for o in range(4):
+                m += [o * nwrow + NIN + j for j in range(NIN)]
+            m += [o * nwrow + 2 * NIN + 1 for o in range(4)]
+            self._maps[key] = torch.tensor(m, dtype=torch.int32, device=dev)
+        return self._maps[key]
+
+    def launch(self, theta_node, ode_node, enc_node, log_q, log_p, n_total, apply_adam=True):
+        """theta_node: ThetaSampleLogProbPacked's backward node, ode_node: OdeSolveObserve's, enc_node: EncoderQTables'
+        (their saved tensors are the step's forward state).  Returns the loss tensor (-ELBO), or None when the step is
+        outside this path's regime (time-fastest trajectory layout, an offset that is not the one-launch linear form)."""
+        q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows = theta_node.saved_tensors
+        theta, cond, times, obs, traj, dev1hot, weights = ode_node.saved_tensors
+        delta_obs, inputs, dev_1hot_e, _cw, lin_w, local_w, _lb, _gw, _gf, pooled, hidden = enc_node.saved_tensors
+        spec, prob, rom = ode_node.spec, ode_node.prob, ode_node.row_offset_map
+        if ode_node.time_fastest:
+            return None
+        s = enc_node.shape
+        P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
+        dev = q_all.device
+        R = theta.shape[0]
+        blackbox = spec.model == "dr_blackbox"
+        shift = (0, 0, 0)
+        off_n = off_row0 = 0
+        if rom is not None:
+            # (the sampled rows must not be rows the adjoint writes: their gradient is then exactly the conditioned rows'.
+            # Other rows the adjoint leaves alone stay zero in the persistent buffer below)
+            if (len(rom) != 4 or self.offset is None
+                    or any(r not in spec.unwritten_rows for r in range(rom[0], rom[0] + rom[2]))):
+                return None
+            src, dst, n_off, _ = rom
+            shift, off_n, off_row0 = (src, n_off, dst - src), n_off, dst
+        elif self.offset is not None:
+            return None
+        L = hip.lib()
+        logp = ode_node.logp_out
+        # ---- work buffers: allocated once per shape OUTSIDE any capture (the warm-up steps come first) and reused
+        key = (B, S, R, str(dev))
+        capturing = torch.cuda.is_current_stream_capturing()
+        if key not in self._bufs:
+            n_aux = int(L.vihds_ode_bwd_aux_floats(ctypes.byref(prob)))
+            lanes_reduce = (weights is not None and not blackbox and bool(L.vihds_ode_bwd_reduces_weights(ctypes.byref(prob))))
+            if not blackbox and weights is None:
+                n_aux = 0
+            n_flat = sum(t.numel() for t in self.flat_tensors)
+            n_all = sum(p.numel() for p in self.optimizer.param_groups[0]["params"] if p.requires_grad)
+            Lc = s.L - s.K + 1
+            bufs = {
+                # every gradient, laid out like Adam's flat m / v (= model.parameters() order): a replica's all-reduce
+                # takes the arena in place (parallel.allreduce_gradients)
+                "arena": torch.empty(n_all, device=dev),
+                "g_all": torch.empty((2 * P, B), device=dev), "g_pre": torch.empty((B, s.H), device=dev),
+                "g_conv": torch.empty((B, s.F, Lc), device=dev),
+                # rows the adjoint never writes (parameters the integrator does not read) stay zero for good
+                "g_theta": torch.zeros((R, B, S), device=dev),
+                "aux": torch.empty(max(n_aux, 1), device=dev), "n_aux": n_aux, "lanes_reduce": lanes_reduce,
+                "log_w": torch.empty((B, S), device=dev), "rows": torch.empty((3, B), device=dev),
+                "loss": torch.empty((), device=dev), "ug": torch.empty((B, S), device=dev),
+                "g_w": torch.zeros(max(n_flat, 1), device=dev),
+                "rowsum": torch.empty((max(off_n, 1), B), device=dev),
+            }
+            if capturing:
+                raise RuntimeError("GeneralTail: first use of a shape inside a graph capture (the warm-up steps allocate)")
+            self._bufs[key] = bufs
+        bf = self._bufs[key]
+        # ---- IWAE: loss, log_w, lse and the unit-upstream gradient d loss / d log_w (training.py:135-149)
+        ticket = _iwae_ticket(dev)
+        logp_c, log_p_c, log_q_c = _c(logp.detach()), _c(log_p.detach()), _c(log_q.detach())
+        rows = bf["rows"]
+        rc = L.vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp_c), hip.ptr(log_p_c), hip.ptr(log_q_c),
+                                   hip.ptr(bf["log_w"]), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
+                                   hip.ptr(bf["loss"]), hip.ptr(bf["ug"]), None, hip.ptr(ticket), hip.current_stream())
+        hip.check(rc, "vihds_iwae_loss_fwd")
+        # ---- the ODE adjoint, its log-likelihood gradient = the importance weights broadcast over the four signals
+        prob.logp_grad_broadcast = 1
+        g_theta = bf["g_theta"]
+        aux = bf["aux"] if bf["n_aux"] > 0 else None
+        g_w = bf["g_w"] if (weights is not None and not blackbox and not bf["lanes_reduce"]) else None
+        if g_w is not None:
+            g_w.zero_()  # (thread-per-trajectory kernels ADD the bias gradients; the contraction below adds the matrices)
+        rc = _launch("ode_bwd", lambda: L.vihds_ode_bwd(
+            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+            hip.ptr(weights), hip.ptr(traj), None, None, hip.ptr(bf["ug"]), hip.ptr(g_theta), hip.ptr(g_w), hip.ptr(aux),
+            hip.current_stream()))
+        hip.check(rc, "vihds_ode_bwd")
+        extras = []  # (flat offset, size, grad_src tensor, src offset, map, nparts, stride)
+        chunks = self._chunks_static()
+        if weights is not None:
+            if bf["lanes_reduce"]:
+                NIN = spec.n_species + 1
+                nwg = 4 * (2 * NIN + 2)
+                nblk = bf["n_aux"] // nwg
+                assert len(chunks) == 1
+                extras = [(0, chunks[0][3], aux, 0, self._lane_map(NIN, dev), nblk, nwg)]
+            else:
+                if blackbox:
+                    gw = blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot)
+                else:
+                    gw = neural_precision_weight_grads(spec, prob, aux, g_w)
+                extras = [(fo, size, gw, fo, None, 1, 0) for (_f, _c2, fo, size) in chunks]
+        # ---- the tail
+        opt = self.optimizer
+        group = opt.param_groups[0]
+        st = opt._group_state(0, group)
+        offsets, off = {}, 0
+        for prm in st["params"]:
+            offsets[id(prm)] = off
+            off += prm.numel()
+        arena = bf["arena"]
+
+        def gview(t):
+            return arena[offsets[id(t)]:offsets[id(t)] + t.numel()].view(t.shape)
+
+        a = hip.StepTailArgs()
+        a.P, a.S = P, S
+        a.kind, a.q_all, a.q_rows = hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_rows)
+        a.p_mu, a.p_prec, a.clip_lo, a.clip_hi = hip.ptr(p_mu), hip.ptr(p_prec), hip.ptr(clip_lo), hip.ptr(clip_hi)
+        a.u, a.g_theta_unit = hip.ptr(u), hip.ptr(g_theta)
+        a.iwae.logp, a.iwae.log_p, a.iwae.log_q = hip.ptr(logp_c), hip.ptr(log_p_c), hip.ptr(log_q_c)
+        a.iwae.n_iwae_total = int(n_total)
+        a.iwae.log_w, a.iwae.lse, a.iwae.loss = hip.ptr(bf["log_w"]), hip.ptr(rows[2]), hip.ptr(bf["loss"])
+        a.g_all = hip.ptr(bf["g_all"])
+        a.delta_obs, a.inputs, a.dev1hot = hip.ptr(delta_obs), hip.ptr(inputs), hip.ptr(dev_1hot_e if dev_1hot_e is not None else dev1hot)
+        a.lin_w, a.local_w, a.pooled, a.hidden = hip.ptr(lin_w), hip.ptr(local_w), hip.ptr(pooled), hip.ptr(hidden)
+        a.g_pre, a.g_conv = hip.ptr(bf["g_pre"]), hip.ptr(bf["g_conv"])
+        grads = []
+        for k, t in enumerate(self.tensors):
+            if t is None:
+                continue
+            if not t.is_contiguous():
+                raise RuntimeError("vihds_step_tail needs contiguous parameters")
+            view = gview(t)
+            grads.append((t, view))
+            a.param[k], a.grad[k], a.mv_offset[k] = t.data_ptr(), view.data_ptr(), offsets[id(t)]
+        a.g_theta_weighted = 1
+        a.g_shift_lo, a.g_shift_n, a.g_shift = shift
+        flat0 = weights.data_ptr() if weights is not None else 0
+        a.n_extra = len(extras)
+        keep = []
+        for x, (fo, size, src, so, mp, nparts, stride) in enumerate(extras):
+            first = chunks[x][0]
+            e = a.extra[x]
+            e.param = flat0 + 4 * fo
+            e.grad = arena.data_ptr() + 4 * offsets[id(self.flat_tensors[first])]
+            e.grad_src = src.data_ptr() + 4 * so
+            e.map = hip.ptr(mp)
+            e.size, e.nparts, e.part_stride = size, nparts, stride
+            e.mv_offset = offsets[id(self.flat_tensors[first])]
+            keep.append(src)
+        fo = 0
+        for t in self.flat_tensors:
+            if t.data_ptr() != flat0 + 4 * fo:
+                raise RuntimeError("GeneralTail: the decoder's parameters are not views of its flat weight buffer")
+            grads.append((t, gview(t)))
+            fo += t.numel()
+        if off_n > 0:
+            W, bvec = self.offset.weight, self.offset.bias
+            a.off_n, a.off_row0 = off_n, off_row0
+            a.off_w, a.off_b = W.data_ptr(), bvec.data_ptr()
+            gW, gb = gview(W), gview(bvec)
+            a.off_gw, a.off_gb = gW.data_ptr(), gb.data_ptr()
+            a.off_mv_w, a.off_mv_b = offsets[id(W)], offsets[id(bvec)]
+            a.off_rowsum = hip.ptr(bf["rowsum"])
+            grads += [(W, gW), (bvec, gb)]
+        lr = group["lr"]
+        a.m, a.v, a.state = st["m"].data_ptr(), st["v"].data_ptr(), (st["state"].data_ptr() if apply_adam else None)
+        a.lr_dev = hip.ptr(lr) if isinstance(lr, torch.Tensor) else None
+        a.lr = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
+        a.beta1, a.beta2 = group["betas"]
+        a.eps = group["eps"]
+        rc = _launch("step_tail", lambda: L.vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream()))
+        hip.check(rc, "vihds_step_tail")
+        for t, v in grads:
+            t.grad = v
+        return bf["loss"]
 
 
 class IwaeLossSharded(torch.autograd.Function):

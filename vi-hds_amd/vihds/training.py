@@ -170,9 +170,10 @@ class Training:
         # the reference does, or -- lazy_cache_dump -- once, when run() leaves its loop (also on an exception): same final cache
         self.lazy_cache_dump = bool(default_get_value(p, "lazy_cache_dump", False))
         self._best_output = None
-        # the step's tail (loss, backward, Adam) as two launches: vihds_step_tail (off by default: reference call sequence)
+        # the step's tail (loss, backward, Adam) as two launches: vihds_step_tail (params.fused_step_tail, default on)
         self.fused_tail = bool(default_get_value(p, "fused_step_tail", True)) and on_gpu
         self._tail, self._tail_ok, self._tail_shapes = None, False, {}
+        self._gtail, self._gtail_ok = None, None  # ops.GeneralTail (any model); None: not decided yet
         if on_gpu:
             self.optimizer.gate = None
         self._graphs = {}
@@ -390,7 +391,24 @@ class Training:
     def step(self, batch, zero_grad=True):
         """One ELBO training step on a device batch: forward, cost, backward, (gradient all-reduce), Adam.
         Returns the loss tensor (-ELBO) without synchronising."""
-        batch_results, theta, q, p = self.model(batch, self.args.train_samples)
+        ode = self.model.decoder.ode_model
+        # (a step whose backward is ops.GeneralTail reads neither trajectory views nor x_predict: the forward skips the latter)
+        ode._train_without_x_predict = bool(self._gtail_ok)
+        try:
+            batch_results, theta, q, p = self.model(batch, self.args.train_samples)
+        finally:
+            ode._train_without_x_predict = False
+        loss = self._general_tail(batch_results, theta, q, p)
+        if loss is not None:
+            # params.fused_step_tail, any model: IWAE loss, ODE adjoint, weight gradients, theta / encoder adjoints and Adam
+            # ran as GeneralTail's launches; autograd's backward and optimizer.step() do not run for this step
+            if self.replica is not None:
+                self._grad_buffer = parallel.allreduce_gradients(self.model.parameters(), self.replica.group, self._grad_buffer)
+                self.optimizer.gate = None
+                self.optimizer.step()
+            if zero_grad:
+                self.optimizer.zero_grad(set_to_none=True)
+            return loss.detach()
         self._in_step = True
         ops._PENDING_IWAE.clear()  # (a deferred loss whose backward never ran must not be mistaken for this step's)
         try:
@@ -464,6 +482,43 @@ class Training:
         (job,) = ops._PENDING_IWAE.values()
         ops._PENDING_IWAE.clear()
         return self._tail.launch(dec_node, enc_node, job, apply_adam=self.replica is None)
+
+    def _general_tail(self, batch_results, theta, q, p):
+        """params.fused_step_tail for the models WITHOUT a fused decoder step (anything but dr_constant: relay / degrader /
+        prpr / auto and their _precisions forms, dr_blackbox, dr_constant_precisions; reference training.py:324-340 is
+        model-agnostic): the forward ran as encoder -> theta kernel -> [conditioning] -> vihds_ode_fwd; hand everything
+        behind it to ops.GeneralTail.  Returns the loss tensor, or None when it does not apply (the caller then runs cost(),
+        autograd's backward and optimizer.step())."""
+        if not self.fused_tail or self.shard is not None or self._gtail_ok is False:
+            return None
+        sol = getattr(batch_results, "solution", None)
+        logp = getattr(sol, "logp_buffer", None)
+        ode_node = getattr(logp, "grad_fn", None)
+        packed = getattr(theta, "_packed", None)
+        theta_node = getattr(packed, "grad_fn", None)
+        pq = getattr(q, "_packed_q", None)
+        enc_node = getattr(pq[1], "grad_fn", None) if pq is not None else None
+        if (type(ode_node).__name__ != "OdeSolveObserveBackward" or type(theta_node).__name__ != "ThetaSampleLogProbPackedBackward"
+                or type(enc_node).__name__ != "EncoderQTablesBackward" or not getattr(sol, "has_logp", False)):
+            return None
+        if self._gtail is None:
+            self._gtail = ops.GeneralTail(self.model.encoder, self.optimizer, self.model.decoder.ode_model)
+            self._gtail_ok = self._gtail.applicable()
+            if not self._gtail_ok:
+                return None
+        # the integrator must have read the sampling kernel's own buffer (nothing re-bound into a copy on the way)
+        if ode_node.saved_tensors[0].data_ptr() != packed.data_ptr():
+            return None
+        q_all, u = theta_node.saved_tensors[0], theta_node.saved_tensors[6]
+        key = (q_all.shape, u.shape[1])
+        if key not in self._tail_shapes:
+            from vihds import hip
+
+            self._tail_shapes[key] = bool(hip.lib().vihds_step_tail_supported(enc_node.shape, q_all.shape[0] // 2, u.shape[1]))
+        if not self._tail_shapes[key]:
+            return None
+        return self._gtail.launch(theta_node, ode_node, enc_node, q.log_prob(theta), p.log_prob(theta), logp.shape[2],
+                                  apply_adam=self.replica is None)
 
     def _snapshot_training_state(self):
         """Parameters + optimizer state before a capture's warm-up steps (a new batch shape, e.g. an epoch's last partial
