@@ -144,6 +144,16 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
                   const float* times, const float* obs, const float* weights, const float* traj,
                   const float* g_traj, const float* g_xpred, const float* g_logp, float* g_theta,
                   float* g_weights, float* aux, void* stream);
+
+/* vihds_ode_bwd for the ELBO's own upstream gradient (ABI 13): the log-likelihood gradient of every (signal, row, sample) is
+ * the importance weight d loss / d log_w[b][s] = -(1/B) softmax_s(log_w[b][.]), log_w = sum_j logp[j] + log_p - log_q
+ * (reference training.py:135-149), and the kernel forms it itself from logp [4][B][S], log_p, log_q [B][S] (either may be
+ * NULL) -- every wavefront the row-wise logsumexp of its trajectories' data rows -- so a training step needs no IWAE launch
+ * between the forward and the adjoint.  Everything else as vihds_ode_bwd (no g_traj / g_xpred); fixed-grid solvers. */
+int vihds_ode_bwd_elbo(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                       const float* times, const float* obs, const float* weights, const float* traj, const float* logp,
+                       const float* log_p, const float* log_q, float* g_theta, float* g_weights, float* aux,
+                       void* stream);
 long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
 /* 1: vihds_ode_bwd itself completes g_weights for this problem (relay_constant_precisions below 16 384 trajectories on a
  * fixed-grid solver: sixteen lanes per trajectory, the precision network's weight gradients accumulated per lane, one

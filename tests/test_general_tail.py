@@ -130,3 +130,20 @@ def test_general_tail_at_config5_shape_trains_and_counts_launches():
     w1 = model.decoder.ode_model.precisions.flat_weights().detach()
     assert (w1 != w0).any() and torch.isfinite(w1).all()
     assert training.optimizer.step_count() == 3
+
+
+@pytest.mark.parametrize("name", ["relay_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
+                                  "dr_constant_precisions_tiny_modeuler", "auto_constant_tiny_modeuler",
+                                  "dr_blackbox_sized_tiny_modeuler"])
+def test_importance_weights_formed_inside_the_adjoint_launch(name):
+    """vihds_ode_bwd_elbo (params.inkernel_iwae, default): every wavefront of the adjoint forms the row-wise logsumexp of its
+    trajectories' data rows itself -- lane-split, thread-per-trajectory and both dr_blackbox kernel families -- against the
+    same step with the IWAE launch (vihds_iwae_loss_fwd) in front of vihds_ode_bwd: loss, every gradient."""
+    fx = Fixture(name)
+    ref = _one_step(fx, True, inkernel_iwae=False)
+    got = _one_step(fx, True, inkernel_iwae=True)
+    assert ref[3]._gtail.inkernel_iwae is False and got[3]._gtail.inkernel_iwae is True
+    assert abs(ref[0][0] - got[0][0]) <= 1e-6 * max(1.0, abs(ref[0][0]))
+    assert set(ref[1]) == set(got[1])
+    for k, g in ref[1].items():
+        assert rel_err(got[1][k], g) < 1e-5, k

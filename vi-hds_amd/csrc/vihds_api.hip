@@ -598,6 +598,43 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   return check_hip("vihds_ode_bwd launch");
 }
 
+/* vihds_ode_bwd with the log-likelihood gradient formed in the kernel: g_logp[j][b][s] = -(1/B) softmax_s(log_w[b][.]) for the
+ * four signals j, log_w = sum_j logp[j] + log_p - log_q (reference training.py:135-149) -- the training step's adjoint without
+ * an IWAE launch in front of it (csrc/vihds_iwae_inline.hpp). */
+int vihds_ode_bwd_elbo(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                       const float* times, const float* obs, const float* weights, const float* traj, const float* logp,
+                       const float* log_p, const float* log_q, float* g_theta, float* g_weights, float* aux,
+                       void* stream) {
+  if (!p || !theta || !times || !traj || !g_theta || !logp) return fail(VIHDS_E_BADARG, "null problem/theta/times/traj/g_theta/logp");
+  const BbVariant* sized = nullptr;
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  if (!obs) return fail(VIHDS_E_BADARG, "null obs");
+  if (solver_is_adaptive(p->solver)) return fail(VIHDS_E_UNSUPPORTED, "vihds_ode_bwd_elbo: fixed-grid solvers");
+  if (e->neural_prec) {
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+    if (p->model == VIHDS_MODEL_DR_BLACKBOX) {
+      // (side libraries were built against the same headers: their kernels form the weights too)
+      if (!bb_builtin(p) && !(sized = bb_sized(p))) return VIHDS_E_UNSUPPORTED;
+      if (!dev1hot || (p->C > 0 && !cond)) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
+    } else if (p->n_hidden_prec > 256) {
+      return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
+    }
+  }
+  OdeArgs a;
+  int rc = build_args(p, e, a, sized);
+  if (rc) return rc;
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
+  a.g_weights = g_weights; a.aux = aux;
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && !aux) return fail(VIHDS_E_BADARG, "dr_blackbox backward needs the aux buffer");
+  a.traj_in = traj; a.g_theta = g_theta;
+  a.iw_logp = logp; a.iw_log_p = log_p; a.iw_log_q = log_q;
+  a.logp_grad_broadcast = 1;
+  rc = sized ? sized->launch(true, p->solver, a, (hipStream_t)stream, nullptr) : e->launch(true, p->solver, a, (hipStream_t)stream);
+  if (rc) return fail(rc, "unknown solver");
+  return check_hip("vihds_ode_bwd_elbo launch");
+}
+
 int vihds_theta_fwd(int P, int B, int S, const int* kind, const float* q_mu, const float* q_prec, const float* p_mu,
                     const float* p_prec, const float* clip_lo, const float* clip_hi, float* u, float* theta,
                     float* log_q, float* log_p, const vihds_theta_opts* opts, void* stream) {

@@ -29,6 +29,11 @@ struct OdeArgs {
   float* aux;            // backward scratch (dr_blackbox: per-evaluation dump for the weight-gradient GEMMs)
   float init_latent, init_prec;
   int n_hidden_prec;     // white-box models with neural precisions: hidden units of the precision network (0: none)
+  // backward, vihds_ode_bwd_elbo: the log-likelihood gradient is the importance weight, formed in the kernel from these
+  // (vihds_iwae_inline.hpp); iw_logp NULL: g_logp as given
+  const float* iw_logp;   // [4][B][S]
+  const float* iw_log_p;  // [B][S] or NULL
+  const float* iw_log_q;  // [B][S] or NULL
 };
 
 // Everything the sampling stage needs when it runs inside the decoder-step kernel (vihds_theta_ode_logp_grad):

@@ -28,6 +28,7 @@
 #include "vihds_args.hpp"
 #include "vihds_blackbox.hpp"
 #include "vihds_models.hpp"
+#include "vihds_iwae_inline.hpp"
 
 namespace vihds {
 
@@ -507,7 +508,8 @@ __global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
   K::Dump D = {a.aux + i, (size_t)a.n, (size_t)(a.T - 1) * BB::stages(a.solver) * a.n, 0, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
   K::State lam = {0.f, 0.f, 0.f};
   const size_t n = a.n;
-  const float glp = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)q * n) + i] : 0.f;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
+  const float glp = ode_logp_grad(a, w_iw, i, q);
   const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
   const float h0 = a.times[1] - a.times[0];
   auto load_state = [&](int k) {

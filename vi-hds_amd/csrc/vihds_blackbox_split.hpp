@@ -350,7 +350,8 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   f32x4 delta[K::MT];
 #pragma unroll
   for (int m = 0; m < K::MT; ++m) delta[m] = zero;
-  const float glp = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)q * n) + i] : 0.f;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
+  const float glp = ode_logp_grad(a, w_iw, i, q);
   const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
   const float h0 = a.times[1] - a.times[0];
   float* pub_in = lds + S::O_IN;

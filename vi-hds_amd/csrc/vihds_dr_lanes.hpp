@@ -19,6 +19,7 @@
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
 #include "vihds_rng.hpp"
+#include "vihds_iwae_inline.hpp"
 
 namespace vihds {
 
@@ -529,7 +530,8 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
   typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   float lam = 0.f, precb = 0.f;
   const size_t n = a.n;
-  const float glp = (a.g_logp && j < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
+  const float glp = j < 4 ? ode_logp_grad(a, w_iw, i, j) : 0.f;
   const float* ob = a.obs + ((size_t)b * 4 + (j & 3)) * a.T;
   auto time_at = [&](int k) { return LDS_IN ? lds[k] : a.times[k]; };
   auto obs_at = [&](int k) { return LDS_IN ? lds[ob_off + k] : ob[k]; };

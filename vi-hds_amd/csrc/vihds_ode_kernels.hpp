@@ -20,6 +20,7 @@
 #include "vihds_models.hpp"
 #include "vihds_rk_adaptive.hpp"
 #include "vihds_blackbox.hpp"
+#include "vihds_iwae_inline.hpp"
 
 namespace vihds {
 
@@ -398,9 +399,10 @@ __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
   typename CtxImpl::type wtsb;
   CtxImpl::init(wtsb, a, i);
   const size_t n = a.n;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
   VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
     precb[j] = 0.f;
-    glp[j] = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
+    glp[j] = ode_logp_grad(a, w_iw, i, j);
   }
   const float* ob = a.obs + (size_t)b * 4 * a.T;
   const float h0 = a.times[1] - a.times[0];

@@ -33,6 +33,7 @@
 #include "../../include/vihds_hip.h"
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
+#include "vihds_iwae_inline.hpp"
 
 namespace vihds {
 
@@ -121,18 +122,35 @@ struct RlLane {
   // where this lane's hand-overs go in the patch; a lane that has none writes a spare slot (44..47) instead of branching
   int a_h, a_zx, a_zy, a_q1, a_q2, a_ix, a_ip;
   float n0, n1, n2, n3;                  // observed signal j = l & 3: x * (n0 + n1 rfp + n2 (yfp + f530) + n3 (cfp + f480))
-  rl_v2 w2[RL_NIN], b2;                  // rows (production, degradation) of the precision network (precision lanes; zeros elsewhere)
+  // The precision network's eight pre-activations (production rows 0..3, degradation rows 4..7) are formed by lane PAIRS:
+  // lane l works on output o(l) = (l - NSP + 4) & 7 over half h(l) = ((l - NSP + 4) & 15) >> 3 of the sixteen input slots
+  // (eight FMAs), the two halves meet through one row_ror:8 DPP add, one sigmoid per lane; the precision lane NSP + o'
+  // then holds sigma(zd_o') itself and takes sigma(zp_o') from lane l - 4 (row_shr:4).  (Round 3-4: every lane ran both of
+  // "its" rows over all thirteen inputs -- 13 packed FMAs + two sigmoids in sixteen lanes for the four that used them.)
+  float wq[8], bq;                       // this lane's half row and (first half only) its bias
+  int a_hr;                              // where the half's eight input slots start in the patch (16 or 24)
   float cw[8];                           // column of both matrices that multiplies this lane's tanh (species lanes)
 };
 struct RlEval {  // what one RHS evaluation leaves behind for its VJP
   float x, luxR, lasR, I, sig, gr, g, gamma, a, den, P, denq, Q, sp, sd, hl;
 };
+// sigma(4 (t - tlag)) of every (step, stage) of the grid depends on the trajectory's lag only: tabulated once per kernel
+// in LDS ([trajectory][(T - 1) stages]), sixteen entries at a time by the trajectory's lanes; an evaluation reads its entry
+// (one broadcast LDS read) where it used to spend six VALU instructions in all sixteen lanes
+template <class Tab>
+__device__ __forceinline__ void rl_sigma_table(float* sg, const float* tl, int T, float tlag, int l) {
+  const int n = (T - 1) * Tab::S;
+  for (int q = l; q < n; q += RL_G) {
+    const int k = q / Tab::S, s = q - k * Tab::S;
+    sg[q] = sigmoid_f(4.f * (Tab::ts(s, tl[k], tl[k + 1]) - tlag));
+  }
+}
 
 // publish (Y_l, tanh) and evaluate dy_l.  `pt` = this trajectory's LDS patch.
 // (TAIL_FENCE = false: the caller still reads the published states and places the fence itself)
 template <class LM, bool PREC, bool TAIL_FENCE = true>
-__device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float* pt, RlEval& E, float* hv) {
-  constexpr int NSP = LM::NSP, NIN = 1 + NSP;
+__device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float sig, float Y, float* pt, RlEval& E) {
+  constexpr int NSP = LM::NSP;
   const int l = c.l;
   pt[l] = Y;
   if (PREC) {
@@ -142,7 +160,7 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
   }
   rl_wave_fence();
   E.x = pt[0]; E.luxR = pt[6]; E.lasR = pt[7]; E.I = pt[c.isrc];
-  E.sig = sigmoid_f(4.f * (t - c.tlag));
+  E.sig = sig;
   E.gr = c.r * E.sig;
   E.g = 1.f - E.x * c.iKx;
   E.gamma = E.gr * E.g;
@@ -162,18 +180,18 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float Y, float
   float D = c.gsgn * E.gamma + c.deg;
   E.sp = 0.f; E.sd = 0.f;
   if (PREC) {
-    const float4* h4 = reinterpret_cast<const float4*>(pt + 16);
-    const float4 ha = h4[0], hb = h4[1], hc = h4[2];
-    hv[0] = ha.x; hv[1] = ha.y; hv[2] = ha.z; hv[3] = ha.w; hv[4] = hb.x; hv[5] = hb.y; hv[6] = hb.z; hv[7] = hb.w;
-    hv[8] = hc.x; hv[9] = hc.y; hv[10] = hc.z; hv[11] = hc.w; hv[12] = NIN > 12 ? pt[28] : 0.f;
-#pragma unroll
-    for (int j = NIN; j < RL_NIN; ++j) hv[j] = 0.f;  // (slots past the model's inputs were never written)
-    rl_v2 z2 = c.b2, z2b = rl_v2{0.f, 0.f};  // (two chains: back-to-back dependent packed FMAs cost a wait state each)
-#pragma unroll
-    for (int j = 0; j + 1 < NIN; j += 2) { z2 += c.w2[j] * hv[j]; z2b += c.w2[j + 1] * hv[j + 1]; }
-    if (NIN & 1) z2 += c.w2[NIN - 1] * hv[NIN - 1];
-    z2 += z2b;
-    E.sp = sigmoid_f(z2.x); E.sd = sigmoid_f(z2.y);
+    // this lane's half of its output row (input slots past the model's 1 + NSP were zeroed at kernel entry and are never
+    // written; their weights are zero as well)
+    const float4 ha = *reinterpret_cast<const float4*>(pt + c.a_hr), hb = *reinterpret_cast<const float4*>(pt + c.a_hr + 4);
+    float z = fmaf(c.wq[0], ha.x, c.bq), zb = c.wq[1] * ha.y;  // (two chains)
+    z = fmaf(c.wq[2], ha.z, z); zb = fmaf(c.wq[3], ha.w, zb);
+    z = fmaf(c.wq[4], hb.x, z); zb = fmaf(c.wq[5], hb.y, zb);
+    z = fmaf(c.wq[6], hb.z, z); zb = fmaf(c.wq[7], hb.w, zb);
+    z += zb;
+    z += rl_dpp<0x128>(z);  // row_ror:8: the other half of the same output
+    const float sg_ = sigmoid_f(z);
+    E.sd = sg_;                   // precision lane NSP + o': sigma(zd_o') is its own output ...
+    E.sp = rl_dpp<0x114>(sg_);    // ... and sigma(zp_o') sits four lanes below (row_shr:4)
     dy += c.isP * E.sp;
     D += c.isP * E.sd;
   }
@@ -194,10 +212,7 @@ struct RlAcc {
 // VJP of one evaluation whose forward quantities (E, hv) are at hand: v = adjoint of dy_l; returns the adjoint of Y_l;
 // accumulates parameter adjoints.  Uses only the scratch third of the patch.
 template <class LM, bool PREC>
-__device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, const RlEval& E, const float* hv, float* pt,
-                                             RlAcc& A) {
-  constexpr int NSP = LM::NSP, NIN = 1 + NSP;
-  const int l = c.l;
+__device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, const RlEval& E, float* pt, RlAcc& A) {
   const float D = c.gsgn * E.gamma + c.deg + (PREC ? c.isP * E.sd : 0.f);
   float yb = -v * D;
   A.F0b += v;
@@ -259,11 +274,10 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
 }
 // ... with the forward quantities recomputed first
 template <class LM, bool PREC>
-__device__ __forceinline__ float rl_rhs_vjp(const RlLane& c, float t, float Y, float v, float* pt, RlAcc& A) {
+__device__ __forceinline__ float rl_rhs_vjp(const RlLane& c, float t, float sig, float Y, float v, float* pt, RlAcc& A) {
   RlEval E;
-  float hv[RL_NIN];
-  (void)rl_rhs<LM, PREC>(c, t, Y, pt, E, hv);
-  return rl_vjp_core<LM, PREC>(c, Y, v, E, hv, pt, A);
+  (void)rl_rhs<LM, PREC>(c, t, sig, Y, pt, E);
+  return rl_vjp_core<LM, PREC>(c, Y, v, E, pt, A);
 }
 
 // ---- the models: which lane owns which state, and how the adjoints of the lanes' constants map back --------------------
@@ -458,20 +472,28 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
   c.i3 = (l == 3 || (LM::OBS_SUM && l == 5)) ? 1.f : 0.f;
 #pragma unroll
   for (int j = 0; j < 4; ++j) prec_const[j] = pinit[j];
-  c.b2 = rl_v2{0.f, 0.f};
+  c.bq = 0.f;
+  c.a_hr = 16;
 #pragma unroll
-  for (int j = 0; j < RL_NIN; ++j) c.w2[j] = rl_v2{0.f, 0.f};
-#pragma unroll
-  for (int j = 0; j < 8; ++j) c.cw[j] = 0.f;
+  for (int j = 0; j < 8; ++j) { c.wq[j] = 0.f; c.cw[j] = 0.f; }
   if (PREC) {
     // weights: Wp [4][NIN], bp [4], Wd [4][NIN], bd [4] (reference precisions.py:55-61)
     const float* w = a.weights;
-    if (l >= NSP && l < NSP + 4) {
-      const int o = l - NSP;
-      y0 = pinit[o];
+    {
+      const int o = (l - NSP + 4) & 7, half = ((l - NSP + 4) & 15) >> 3;  // see RlLane
+      const int row0 = (o < 4 ? 0 : 4 * NIN + 4) + (o & 3) * NIN;        // first weight of output o's row
+      c.a_hr = 16 + 8 * half;
 #pragma unroll
-      for (int j = 0; j < NIN; ++j) c.w2[j] = rl_v2{w[o * NIN + j], w[4 * NIN + 4 + o * NIN + j]};
-      c.b2 = rl_v2{w[4 * NIN + o], w[8 * NIN + 4 + o]};
+      for (int jj = 0; jj < 8; ++jj) {
+        const int j = 8 * half + jj;
+        const float wv = w[row0 + (j < NIN ? j : 0)];  // (unconditional load, value selected)
+        c.wq[jj] = j < NIN ? wv : 0.f;
+      }
+      const float bv = w[(o < 4 ? 4 * NIN : 8 * NIN + 4) + (o & 3)];
+      c.bq = half == 0 ? bv : 0.f;
+    }
+    if (l >= NSP && l < NSP + 4) {
+      y0 = pinit[l - NSP];
     } else if (l < NSP) {
 #pragma unroll
       for (int o = 0; o < 4; ++o) { c.cw[o] = w[o * NIN + l + 1]; c.cw[4 + o] = w[4 * NIN + 4 + o * NIN + l + 1]; }
@@ -480,9 +502,9 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
-// dynamic LDS: times [T] | obs rows [nb][4][T]
+// dynamic LDS: times [T] | sigma table [RL_TR][(T - 1) stages] | obs rows [nb][4][T]
 template <class LM, bool PREC, int SOLVER>
-__global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
+__global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a, int sig_tab) {
   using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
   constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP;
@@ -497,18 +519,24 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
   // time grid and the observation rows of the block's data rows -> LDS (no vector loads inside the time loop)
   const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
   const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  const int n_sg = sig_tab ? (a.T - 1) * Tab::S : 0, o_obs = a.T + RL_TR * n_sg;  // (sig_tab 0: a grid too long for the table)
   for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
   if (a.obs) {
     const float* src = a.obs + (size_t)b0 * 4 * a.T;
-    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
+    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[o_obs + q] = src[q];
   }
   RlLane c;
   float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], y, pconst[4];
   rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y, pconst);
+  float* pt = patch[g];
+  pt[16 + l] = 0.f;  // the network's input slots (those past the model's inputs stay zero: see rl_rhs)
   __syncthreads();
   const float* tl = in_lds;
-  const float* ob = in_lds + a.T + (b - b0) * 4 * a.T;
-  float* pt = patch[g];
+  const float* ob = in_lds + o_obs + (b - b0) * 4 * a.T;
+  float* sg = in_lds + a.T + g * n_sg;
+  if (sig_tab) rl_sigma_table<Tab>(sg, tl, a.T, c.tlag, l);
+  rl_wave_fence();
+  auto sigma = [&](int q, float t) { return sig_tab ? sg[q] : sigmoid_f(4.f * (t - c.tlag)); };
   const float h0 = tl[1] - tl[0];
   const size_t n = a.n;
   float lp = 0.f;
@@ -544,15 +572,15 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
       for (int q = 0; q < s; ++q)
         if (Tab::A(s, q) != 0.f) Y += (Tab::A(s, q) * h) * kk[q];
       RlEval E;
-      float hv[RL_NIN];
+      const float sig = sigma((k - 1) * Tab::S + s, Tab::ts(s, t0, t1));
       if (s == 0) {
         // the step's first evaluation publishes the grid point k - 1 itself: its observation rides on that exchange
         // instead of a publish / fence / read round of its own
-        kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+        kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), sig, Y, pt, E);
         if (obs_on) observe(k - 1);
         rl_wave_fence();
       } else {
-        kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+        kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), sig, Y, pt, E);
       }
     }
     float acc = 0.f;
@@ -572,7 +600,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a) {
 
 // ---- adjoint -------------------------------------------------------------------------------------------------------
 template <class LM, bool PREC, int SOLVER>
-__global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
+__global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig_tab) {
   using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
   constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP, NIN = 1 + NSP, NWROW = rl_nwrow(NIN), NWG = rl_nwg(NIN);
@@ -588,10 +616,11 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
   const int b = i / a.S;
   const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
   const int b0 = first / a.S, nb = last / a.S - b0 + 1;
+  const int n_sg = sig_tab ? (a.T - 1) * Tab::S : 0, o_obs = a.T + RL_TR * n_sg;  // (sig_tab 0: a grid too long for the table)
   for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
   {
     const float* src = a.obs + (size_t)b0 * 4 * a.T;
-    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[a.T + q] = src[q];
+    for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[o_obs + q] = src[q];
   }
   RlLane c;
   float pconst[4];
@@ -599,10 +628,15 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
     float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], y_unused;
     rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y_unused, pconst);
   }
+  float* pt = patch[g];
+  pt[16 + l] = 0.f;  // the network's input slots (those past the model's inputs stay zero: see rl_rhs)
   __syncthreads();
   const float* tl = in_lds;
-  const float* ob = in_lds + a.T + (b - b0) * 4 * a.T;
-  float* pt = patch[g];
+  const float* ob = in_lds + o_obs + (b - b0) * 4 * a.T;
+  float* sg = in_lds + a.T + g * n_sg;
+  if (sig_tab) rl_sigma_table<Tab>(sg, tl, a.T, c.tlag, l);
+  rl_wave_fence();
+  auto sigma = [&](int q, float t) { return sig_tab ? sg[q] : sigmoid_f(4.f * (t - c.tlag)); };
   const float h0 = tl[1] - tl[0];
   const size_t n = a.n;
   const int j = l & 3;
@@ -612,7 +646,8 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) A.wc[q] = rl_v2{0.f, 0.f};
   float lam = 0.f, precb = 0.f;
-  const float glp = (a.g_logp && l < 4) ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
+  const float glp = l < 4 ? ode_logp_grad(a, w_iw, i, j) : 0.f;
   const int lr = l < N ? l : 0;  // row this lane reads from the stored trajectory
   float yn = a.traj_in[((size_t)(a.T - 1) * N + lr) * n + i];
   float ox = 0.f, oy1 = 0.f, oy2 = 0.f, oy3 = 0.f, oy4 = 0.f, oy5 = 0.f, opr = 1.f;  // the grid point's observed states
@@ -630,22 +665,21 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
       if constexpr (Tab::S <= 2) {
         // one or two stages: every stage is evaluated ONCE (its forward quantities kept for its own VJP)
         RlEval E0, E1;
-        float hv0[RL_NIN], hv1[RL_NIN];
         // (the step's first evaluation publishes the grid point k itself: the injection below takes what it needs of it here)
-        const float k0 = rl_rhs<LM, PREC, false>(c, Tab::ts(0, t0, t1), y, pt, E0, hv0);
+        const float k0 = rl_rhs<LM, PREC, false>(c, Tab::ts(0, t0, t1), sigma(k * Tab::S, Tab::ts(0, t0, t1)), y, pt, E0);
         grab();
         rl_wave_fence();
         float Y1 = y;
         if constexpr (Tab::S == 2) {
           Y1 = y + (Tab::A(1, 0) * h) * k0;
-          (void)rl_rhs<LM, PREC>(c, Tab::ts(1, t0, t1), Y1, pt, E1, hv1);
+          (void)rl_rhs<LM, PREC>(c, Tab::ts(1, t0, t1), sigma(k * Tab::S + 1, Tab::ts(1, t0, t1)), Y1, pt, E1);
           float kb0 = (Tab::B(0) * h) * lam;
-          const float Yb1 = rl_vjp_core<LM, PREC>(c, Y1, (Tab::B(1) * h) * lam, E1, hv1, pt, A);
+          const float Yb1 = rl_vjp_core<LM, PREC>(c, Y1, (Tab::B(1) * h) * lam, E1, pt, A);
           lam += Yb1;
           kb0 += (Tab::A(1, 0) * h) * Yb1;
-          lam += rl_vjp_core<LM, PREC>(c, y, kb0, E0, hv0, pt, A);
+          lam += rl_vjp_core<LM, PREC>(c, y, kb0, E0, pt, A);
         } else {
-          lam += rl_vjp_core<LM, PREC>(c, y, (Tab::B(0) * h) * lam, E0, hv0, pt, A);
+          lam += rl_vjp_core<LM, PREC>(c, y, (Tab::B(0) * h) * lam, E0, pt, A);
         }
       } else {
         float Ys[Tab::S], kk[Tab::S], kb[Tab::S];
@@ -658,13 +692,12 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
           Ys[s] = Y;
           if (s + 1 < Tab::S) {  // (the last stage's derivative is not needed to rebuild the states)
             RlEval E;
-            float hv[RL_NIN];
             if (s == 0) {
-              kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+              kk[s] = rl_rhs<LM, PREC, false>(c, Tab::ts(s, t0, t1), sigma(k * Tab::S + s, Tab::ts(s, t0, t1)), Y, pt, E);
               grab();
               rl_wave_fence();
             } else {
-              kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), Y, pt, E, hv);
+              kk[s] = rl_rhs<LM, PREC>(c, Tab::ts(s, t0, t1), sigma(k * Tab::S + s, Tab::ts(s, t0, t1)), Y, pt, E);
             }
           }
         }
@@ -672,7 +705,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a) {
         for (int s = 0; s < Tab::S; ++s) kb[s] = (Tab::B(s) * h) * lam;
 #pragma unroll
         for (int s = Tab::S - 1; s >= 0; --s) {
-          const float Yb = rl_rhs_vjp<LM, PREC>(c, Tab::ts(s, t0, t1), Ys[s], kb[s], pt, A);
+          const float Yb = rl_rhs_vjp<LM, PREC>(c, Tab::ts(s, t0, t1), sigma(k * Tab::S + s, Tab::ts(s, t0, t1)), Ys[s], kb[s], pt, A);
           lam += Yb;
 #pragma unroll
           for (int q = 0; q < s; ++q)
@@ -804,12 +837,15 @@ template <class LM, bool PREC, int SOLVER>
 inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st) {
   const int nblk = (a.n + RL_TR - 1) / RL_TR;
   const int nb_max = min(a.B, (RL_TR - 1) / a.S + 2);
-  const size_t lds = sizeof(float) * ((size_t)a.T + (size_t)nb_max * 4 * a.T);
+  const size_t lds_in = sizeof(float) * ((size_t)a.T + (size_t)nb_max * 4 * a.T);
+  const size_t lds_sg = sizeof(float) * (size_t)RL_TR * (a.T - 1) * RlTab<SOLVER>::S;
+  const int sig_tab = lds_in + lds_sg <= 48 * 1024 ? 1 : 0;  // (beyond that the stage sigmoids are evaluated in place)
+  const size_t lds = lds_in + (sig_tab ? lds_sg : 0);
   constexpr int NIN = 1 + LM::NSP;
   if (!backward) {
-    hipLaunchKernelGGL((relay_lane_fwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+    hipLaunchKernelGGL((relay_lane_fwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a, sig_tab);
   } else {
-    hipLaunchKernelGGL((relay_lane_bwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a);
+    hipLaunchKernelGGL((relay_lane_bwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a, sig_tab);
     if (PREC && a.g_weights && a.aux)
       hipLaunchKernelGGL(relay_lane_wreduce_kernel, dim3((rl_nwg(NIN) + 3) / 4), dim3(256), 0, st, a.aux, nblk, a.g_weights, NIN);
   }

@@ -429,7 +429,8 @@ __global__ void __launch_bounds__(RS_T, 2) relay_scan_bwd_kernel(OdeArgs a) {
   const bool owner_last = (K - 1) / ITEMS == l;
   const float* ob = a.obs + (size_t)b * 4 * T;
   float glp[4];
-  VIHDS_UNROLL for (int j = 0; j < 4; ++j) glp[j] = a.g_logp ? a.g_logp[(a.logp_grad_broadcast ? 0 : (size_t)j * n) + i] : 0.f;
+  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) glp[j] = ode_logp_grad(a, w_iw, i, j);
 
   // parameter-adjoint accumulators: per state the adjoints of its own constants (RlAcc's fields; the entries an
   // instantiation never writes stay compile-time zeros), the growth parameters, the constant precisions

@@ -156,6 +156,7 @@ _PROTOTYPES = {
     "vihds_model_n_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_fwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 10),
     "vihds_ode_bwd": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
+    "vihds_ode_bwd_elbo": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 14),
     "vihds_ode_adaptive_workspace_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_adaptive_grid": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 5 + [ctypes.c_float, ctypes.c_float] + [_P] * 2
                                 + [_I, _P, _P]),

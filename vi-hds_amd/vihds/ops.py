@@ -1182,6 +1182,7 @@ class GeneralTail(StepTail):
         self.offset = off if (off is not None and getattr(ode_model, "n_y", 0) > 0) else None
         self._bufs = {}
         self._maps = {}
+        self.inkernel_iwae = True  # (False: vihds_iwae_loss_fwd + vihds_ode_bwd -- the same numbers, one launch more)
 
     def applicable(self):
         """HipAdam, one parameter group = the encoder's tensors + every decoder-side parameter, each of which this path
@@ -1291,14 +1292,8 @@ class GeneralTail(StepTail):
                 raise RuntimeError("GeneralTail: first use of a shape inside a graph capture (the warm-up steps allocate)")
             self._bufs[key] = bufs
         bf = self._bufs[key]
-        # ---- IWAE: loss, log_w, lse and the unit-upstream gradient d loss / d log_w (training.py:135-149)
-        ticket = _iwae_ticket(dev)
         logp_c, log_p_c, log_q_c = _c(logp.detach()), _c(log_p.detach()), _c(log_q.detach())
         rows = bf["rows"]
-        rc = L.vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp_c), hip.ptr(log_p_c), hip.ptr(log_q_c),
-                                   hip.ptr(bf["log_w"]), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
-                                   hip.ptr(bf["loss"]), hip.ptr(bf["ug"]), None, hip.ptr(ticket), hip.current_stream())
-        hip.check(rc, "vihds_iwae_loss_fwd")
         # ---- the ODE adjoint, its log-likelihood gradient = the importance weights broadcast over the four signals
         prob.logp_grad_broadcast = 1
         g_theta = bf["g_theta"]
@@ -1306,11 +1301,26 @@ class GeneralTail(StepTail):
         g_w = bf["g_w"] if (weights is not None and not blackbox and not bf["lanes_reduce"]) else None
         if g_w is not None:
             g_w.zero_()  # (thread-per-trajectory kernels ADD the bias gradients; the contraction below adds the matrices)
-        rc = _launch("ode_bwd", lambda: L.vihds_ode_bwd(
-            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
-            hip.ptr(weights), hip.ptr(traj), None, None, hip.ptr(bf["ug"]), hip.ptr(g_theta), hip.ptr(g_w), hip.ptr(aux),
-            hip.current_stream()))
-        hip.check(rc, "vihds_ode_bwd")
+        if self.inkernel_iwae:
+            # the weights are formed inside the adjoint launch (vihds_ode_bwd_elbo): no IWAE launch in this step; the tail's
+            # rows kernel recomputes them for the theta adjoint and leaves log_w, lse and -ELBO
+            rc = _launch("ode_bwd", lambda: L.vihds_ode_bwd_elbo(
+                ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+                hip.ptr(weights), hip.ptr(traj), hip.ptr(logp_c), hip.ptr(log_p_c), hip.ptr(log_q_c), hip.ptr(g_theta),
+                hip.ptr(g_w), hip.ptr(aux), hip.current_stream()))
+            hip.check(rc, "vihds_ode_bwd_elbo")
+        else:
+            # IWAE launch: loss, log_w, lse and the unit-upstream gradient d loss / d log_w (training.py:135-149)
+            ticket = _iwae_ticket(dev)
+            rc = L.vihds_iwae_loss_fwd(B, S, int(n_total), hip.ptr(logp_c), hip.ptr(log_p_c), hip.ptr(log_q_c),
+                                       hip.ptr(bf["log_w"]), hip.ptr(rows[0]), hip.ptr(rows[1]), hip.ptr(rows[2]),
+                                       hip.ptr(bf["loss"]), hip.ptr(bf["ug"]), None, hip.ptr(ticket), hip.current_stream())
+            hip.check(rc, "vihds_iwae_loss_fwd")
+            rc = _launch("ode_bwd", lambda: L.vihds_ode_bwd(
+                ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+                hip.ptr(weights), hip.ptr(traj), None, None, hip.ptr(bf["ug"]), hip.ptr(g_theta), hip.ptr(g_w), hip.ptr(aux),
+                hip.current_stream()))
+            hip.check(rc, "vihds_ode_bwd")
         extras = []  # (flat offset, size, grad_src tensor, src offset, map, nparts, stride)
         chunks = self._chunks_static()
         if weights is not None:

@@ -503,6 +503,7 @@ class Training:
             return None
         if self._gtail is None:
             self._gtail = ops.GeneralTail(self.model.encoder, self.optimizer, self.model.decoder.ode_model)
+            self._gtail.inkernel_iwae = bool(default_get_value(self.settings.params, "inkernel_iwae", True))
             self._gtail_ok = self._gtail.applicable()
             if not self._gtail_ok:
                 return None
