@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 B_ROWS, N_IWAE, N_TIMES, N_STATES, N_PARAMS = 36, 200, 86, 8, 35
+MULTI_RANK_WATCHDOG_S = 300  # a multi-rank graph path that has not finished by then gives way to the eager line taken before it
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
@@ -256,7 +257,7 @@ def time_launch(fn, n):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def run_workload(a, name, min_seconds=None, bounded_cpu=False):
+def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, light=False):
     """Returns the JSON object of one of BASELINE.json's other configurations (None on ranks other than 0).  min_seconds:
     the timed window is sized from a short trial instead of --steps (the legs of the default line: >= that many seconds
     each).  bounded_cpu: the cpu_baseline leg runs at 8 threads without the thread probe, two samples.
@@ -267,6 +268,8 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False):
     from vihds import hip, ops, parallel, synthetic
 
     wl, B, S, solver, mode, bound, cfg_note = WORKLOAD_TABLE[name]
+    if s_override is not None:  # (--emulate-shards: the per-rank share of the configuration's IWAE-sample axis)
+        S = int(s_override)
     if a.solver_given:
         solver = a.solver
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -336,8 +339,15 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False):
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(tt)
     final = float(torch.as_tensor(loss).float().mean())
+    if mode == "train" and (not np.isfinite(final) or final < -1e6):  # (the headline's own guard, on every training leg)
+        raise SystemExit("degenerate objective %r after the timed steps (training ran away): not a valid bench run" % final)
     if not np.isfinite(final):
-        raise SystemExit("non-finite objective %r after the timed steps: not a valid bench run" % final)
+        raise SystemExit("non-finite objective %r after the timed passes: not a valid bench run" % final)
+
+    if light:  # (--emulate-shards: the timing only)
+        return {"value": n_steps / elapsed, "ms_per_step": 1e3 * elapsed / n_steps, "steps": n_steps, "final_objective": final,
+                "n_iwae": S, "launch": "hipGraph replay" if use_graph else "eager",
+                "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None}
 
     # ---- roofline: the step's own ODE launches, re-issued back to back ---------------------------------------------
     rec = ops.LaunchRecorder()
@@ -453,58 +463,112 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False):
     return out
 
 
-def run_loop_workload(a):
-    """`Training.run()` itself -- the loop a user of run_xval.py runs (reference training.py:342-383) -- on a synthetic
-    dr_constant_icml plate of the reference's size: 234 training rows in batches of 36 (six full batches and a ragged one of
-    18 per epoch, shuffled by the reference's own DataLoader sampler), n_iwae = 200, evaluation of the training and the
-    validation rows at 1000 samples every `test_epoch` epochs (the reference's default, 20), with the fast keys of the
-    headline bench.  `value` = optimizer steps / wall time of run(), evaluations and host work included.  Three legs: one graph
-    launch per epoch (run()'s default with hip_graph when the NaN check is at most once per epoch: nan_check_every = 7), one
-    per step with the same check, and one per step with the check after every step as the reference has it (a device
-    synchronisation per step)."""
+def newton_summary(hist):
+    """{mean, p99, max, ...} of the time-parallel decoder kernel's Newton walks per wavefront (vihds_debug_newton_hist)."""
+    h = [int(v) for v in hist[:33]]
+    n = sum(h)
+    if n == 0:
+        return None
+    cum, p99 = 0, 0
+    for w, c in enumerate(h):
+        cum += c
+        if cum >= 0.99 * n:
+            p99 = w
+            break
+    return {"wavefront_launches": n, "mean": sum(w * c for w, c in enumerate(h)) / n, "p99": p99,
+            "max": max(w for w, c in enumerate(h) if c), "hist": {str(w): c for w, c in enumerate(h) if c},
+            "first_order_exit_frac": int(hist[33]) / n,
+            "note": "walks of the OD chain per wavefront (two trajectories) of dr_scan_train_theta_kernel's Newton iteration; "
+                    "1 = the closed-form guess was already settled, 2 = the usual case"}
+
+
+REAL_PLATE_NPZ = os.path.join(ROOT, "tests", "golden", "trace_dr_constant_icml_modeuler.npz")
+
+
+def run_loop_legs(a, plate="synthetic", leg_names=None, epochs=None, telemetry=True):
+    """`Training.run()` itself -- the loop a user of run_xval.py runs (reference training.py:342-383) -- on a dr_constant_icml
+    plate of the reference's size: 234 training rows in batches of 36 (six full batches and a ragged one of 18 per epoch,
+    shuffled by the reference's own DataLoader sampler), n_iwae = 200, evaluation of the training and the validation rows at
+    1000 samples every `test_epoch` epochs (the reference's default, 20), with the fast keys of the headline bench.
+    plate = "synthetic": the seeded synthetic plate at --lr; "real": the reference's processed plate (the 312 wells recorded in
+    tests/golden/trace_dr_constant_icml_modeuler.npz, its own 234 / 78 split) with the spec's learning_rate 0.01 and MultiStepLR
+    [250, 1000] unchanged.  value = optimizer steps / wall time of run(), evaluations and host work included.  Legs: one graph
+    launch per epoch (run()'s default with hip_graph when the NaN check is at most once per epoch), one per step with the same
+    check, one per step with the check after every step as the reference has it.  telemetry: the decoder kernel's Newton walks."""
     import contextlib
     import io
 
-    from vihds import synthetic
+    from vihds import hip, synthetic
 
-    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or a.gpus != 1:
-        raise SystemExit("--workload run_loop is a single-process measurement")
     torch.cuda.set_device(0)
     solver = a.solver or "rk4"
     n_rows, n_batch, S, S_eval = 234, 36, 200, 1000
-    epochs, test_epoch = max(100, a.steps // 7), 20
+    epochs = epochs or max(100, a.steps // 7)
+    test_epoch = 20
+    all_legs = (("epoch_graph_nan_check_per_epoch", 7, True), ("step_graphs_nan_check_per_epoch", 7, False),
+                ("step_graphs_nan_check_every_step", 1, False))
     legs = {}
-    for name, check, epoch_graph in (("epoch_graph_nan_check_per_epoch", 7, True), ("step_graphs_nan_check_per_epoch", 7, False),
-                                     ("step_graphs_nan_check_every_step", 1, False)):
-        args, settings, data, parameters, model, training = synthetic.build(
-            "dr_constant_icml", n_rows, S, solver=solver, device="cuda:0", seed=a.seed, n_batch=n_batch, u_rng=a.device_rng,
-            conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=check, learning_rate=a.lr,
-            epoch_graph=epoch_graph, lazy_cache_dump=epoch_graph, fused_ode_training=True, fused_iwae_backward=True, fused_step_tail=not a.no_step_tail)
-        args.epochs, args.test_epoch, args.test_samples = 2, 1, S_eval
-        with contextlib.redirect_stdout(io.StringIO()):
-            training.run()  # captures, allocator warm-up, one evaluation: not timed
-        args.epochs, args.test_epoch = epochs, test_epoch
-        steps_per_epoch = (n_rows + n_batch - 1) // n_batch
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        buf = io.StringIO()
-        with contextlib.redirect_stdout(buf):
-            out = training.run()
-        torch.cuda.synchronize()
-        el = time.perf_counter() - t0
+    for name, check, epoch_graph in all_legs:
+        if leg_names is not None and name not in leg_names:
+            continue
+        keys = dict(u_rng=a.device_rng, conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=check,
+                    epoch_graph=epoch_graph, lazy_cache_dump=epoch_graph, fused_ode_training=True, fused_iwae_backward=True,
+                    fused_step_tail=not a.no_step_tail)
+        hist = torch.zeros(34, dtype=torch.int32, device="cuda:0") if telemetry else None
+        hip.lib().vihds_debug_newton_hist(hip.ptr(hist))  # (before the captures: a captured launch keeps its pointer)
+        try:
+            if plate == "real":
+                args, settings, data, parameters, model, training = synthetic.build_recorded_plate(
+                    REAL_PLATE_NPZ, S, solver=solver, device="cuda:0", seed=0, **keys)
+            else:
+                args, settings, data, parameters, model, training = synthetic.build(
+                    "dr_constant_icml", n_rows, S, solver=solver, device="cuda:0", seed=a.seed, n_batch=n_batch,
+                    learning_rate=a.lr, **keys)
+            args.epochs, args.test_epoch, args.test_samples = 2, 1, S_eval
+            with contextlib.redirect_stdout(io.StringIO()):
+                training.run()  # captures, allocator warm-up, one evaluation: not timed
+            if hist is not None:
+                torch.cuda.synchronize()
+                hist.zero_()
+            args.epochs, args.test_epoch = epochs, test_epoch
+            steps_per_epoch = (len(data.train) + n_batch - 1) // n_batch
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                out = training.run()
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+        finally:
+            hip.lib().vihds_debug_newton_hist(None)
         n_steps, n_eval = epochs * steps_per_epoch, epochs // test_epoch
+        stopped = "Cannot proceed" in buf.getvalue()
         legs[name] = {"value": n_steps / el, "ms_per_step": 1e3 * el / n_steps, "wall_s": el, "epochs": epochs, "steps": n_steps,
-                      "evaluations": n_eval, "final_validation_elbo": float(out.elbo) if out is not None else None}
+                      "evaluations": n_eval, "final_validation_elbo": float(out.elbo) if out is not None else None,
+                      "stopped_on_nan": stopped, "learning_rate": float(settings.params.learning_rate),
+                      "learning_boundaries": list(settings.params.learning_boundaries),
+                      "newton_iters": newton_summary(hist.cpu().tolist()) if hist is not None else None}
+        del training, model
+        torch.cuda.synchronize()
+        torch.cuda.empty_cache()
+    return legs
+
+
+def run_loop_workload(a):
+    """--workload run_loop: the three legs of run_loop_legs on the synthetic plate, as a line of its own."""
+    if int(os.environ.get("WORLD_SIZE", "1")) != 1 or a.gpus != 1:
+        raise SystemExit("--workload run_loop is a single-process measurement")
+    legs = run_loop_legs(a, "synthetic")
     best = legs["epoch_graph_nan_check_per_epoch"]
     print(json.dumps({
         "metric": "ELBO training steps/sec through Training.run() (dr_constant_icml, n_iwae=200)", "value": best["value"],
         "unit": "steps/s", "n_gpus": 1, "steps": best["steps"], "warmup": 2 * 7, "ms_per_step": best["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "Training.run(): %d rows in batches of %d (ragged last batch of %d), n_iwae=%d, T=86, %s, "
-                               "evaluation of train + validation rows at n_iwae=%d every %d epochs; rows resident in HBM, "
+        "config": {"workload": "Training.run(): 234 rows in batches of 36 (ragged last batch of 18), n_iwae=200, T=86, %s, "
+                               "evaluation of train + validation rows at n_iwae=1000 every 20 epochs; rows resident in HBM, "
                                "batches gathered on the device by row index (vihds_gather_batch), one hipGraph per EPOCH "
                                "holding its seven gather + step pairs, fed by one copy of the epoch's row indices"
-                               % (n_rows, n_batch, n_rows % n_batch, S, solver, S_eval, test_epoch),
+                               % (a.solver or "rk4"),
                    "name": "run_loop", "launch": "eager" if a.eager else "hipGraph replay (one epoch = 7 steps per launch)",
                    "learning_rate": a.lr},
         "legs": legs, "roofline": None, "cpu_baseline": None,
@@ -512,22 +576,44 @@ def run_loop_workload(a):
                 "per-step host work (sampler, index copy, graph launch), the ragged batch and the evaluations"}))
 
 
-def strong_scaling_leg(a, dev, world, rank):
+def loop_legs_for_default_line(a):
+    """`run_loop` (synthetic plate, --lr) and `real_plate` (the reference's processed plate at the spec's own learning rate and
+    schedule) for the default line: Training.run() end to end, one graph launch per epoch, with the decoder kernel's Newton
+    telemetry.  A failure is reported in the object, never raised."""
+    out = {}
+    for key, plate, epochs in (("run_loop", "synthetic", 200), ("real_plate", "real", 300)):
+        t0 = time.perf_counter()
+        try:
+            leg = run_loop_legs(a, plate, leg_names=("epoch_graph_nan_check_per_epoch",), epochs=epochs)
+            leg = leg["epoch_graph_nan_check_per_epoch"]
+            leg["unit"] = "steps/s"
+            leg["data"] = ("synthetic plate (vihds/synthetic.py), 234 rows" if plate == "synthetic" else
+                           "the reference's processed ICML plate: 312 wells from data/*.csv through datasets.py:173-224, recorded "
+                           "in tests/golden/trace_dr_constant_icml_modeuler.npz; 234 train / 78 validation rows (its own split)")
+            leg["workload"] = ("Training.run(): batches of 36 (ragged last 18), n_iwae=200, rk4, evaluation of train + validation "
+                               "rows at n_iwae=1000 every 20 epochs, one hipGraph launch per epoch, fast keys")
+            out[key] = leg
+        except BaseException as exc:  # noqa: BLE001
+            out[key] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+        out[key]["leg_wall_s"] = time.perf_counter() - t0
+    return out
+
+
+def strong_scaling_leg(a, dev, world, rank, workload="dr_constant_icml", S=1000, solver=None, label="config3_train"):
     """BASELINE config 3's partitioning next to the headline's weak-scaling line: ONE batch (36 rows, n_iwae = 1000) with its
     IWAE-sample axis sharded over the ranks (all-gather of the row statistics + one gradient all-reduce per step; same code
     as `--workload config3_train --shard samples`).  Returned as an object of the same JSON line; a failure is reported
     in it, never raised (the headline line must come out)."""
     from vihds import parallel, synthetic
 
-    S = 1000
     try:
         if S % world:
             return {"skipped": "n_iwae=%d does not split over %d ranks" % (S, world)}
         shard = parallel.SampleShard(rank, world)
+        extra = {"fused_ode_training": not a.two_kernel_ode} if workload == "dr_constant_icml" else {}
         args, settings, data, parameters, model, training = synthetic.build(
-            "dr_constant_icml", B_ROWS, S, solver=a.solver, device=dev, seed=a.seed, shard=shard, u_rng=a.device_rng,
-            conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=0, learning_rate=a.lr,
-            fused_ode_training=not a.two_kernel_ode)
+            workload, B_ROWS, S, solver=solver or a.solver, device=dev, seed=a.seed, shard=shard, u_rng=a.device_rng,
+            conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=0, learning_rate=a.lr, **extra)
         model.train()
         batch = training.train_data
         step = training.step if a.eager else training.graph_step
@@ -546,7 +632,7 @@ def strong_scaling_leg(a, dev, world, rank):
         el = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
         torch.distributed.all_reduce(el, op=torch.distributed.ReduceOp.MAX)
         el = float(el)
-        return {"workload": "config3_train: ONE batch of 36 rows, n_iwae=1000 sharded over the ranks (--shard samples)",
+        return {"workload": "%s: ONE batch of 36 rows, n_iwae=%d sharded over the ranks (--shard samples)" % (label, S),
                 "scaling": "strong", "value": n / el, "unit": "steps/s", "ms_per_step": 1e3 * el / n, "steps": n,
                 "n_iwae_per_gpu": S // world, "final_loss": float(loss)}
     except Exception as e:  # noqa: BLE001
@@ -626,6 +712,68 @@ def distributed_path_leg(a, plain_ms):
     keep["overhead_us_per_step_vs_plain"] = 1e3 * (d["ms_per_step"] - plain_ms)
     keep["ratio_to_plain"] = plain_ms / d["ms_per_step"]
     return keep
+
+
+def shard_emulation_child(a):
+    """`python bench.py --emulate-shards` (started by shard_emulation below with VIHDS_FORCE_DIST=1: a ONE-rank RCCL job): for
+    the configurations BASELINE.json shards over the IWAE-sample axis, the step time of the PER-RANK shape at N = 1, 2, 4, 8 --
+    n_iwae / N samples of the one batch -- through the whole distributed path (communicator, the all-gather of row statistics,
+    the gradient all-reduce; captured in the step's hipGraph when RCCL allows), on the one GPU there is.  What it measures:
+    whether the per-rank launch shrinks with its share of the samples, i.e. the speed-up sharding CAN give before any wire
+    latency: predicted_speedup(N) = t(N = 1) / t(per-rank shape at N).  What it cannot: the xGMI latency of the two
+    collectives at N > 1 (one-rank collectives are local copies)."""
+    a.shard, a.solver_given, a.no_cpu_baseline = "samples", False, True
+    table = {}
+    for name in ("config3_train", "config5", "config4"):
+        S_full = WORKLOAD_TABLE[name][2]
+        rows = {}
+        for N in (1, 2, 4, 8):
+            try:
+                out = run_workload(a, name, min_seconds=0.25, s_override=S_full // N, light=True)
+                rows[str(N)] = {"n_iwae_per_rank": S_full // N, "ms_per_step": out["ms_per_step"], "launch": out["launch"],
+                                "collectives_in_graph": out["collectives_in_graph"]}
+            except BaseException as exc:  # noqa: BLE001
+                rows[str(N)] = {"n_iwae_per_rank": S_full // N, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
+            torch.cuda.synchronize()
+            torch.cuda.empty_cache()
+        t1 = rows["1"].get("ms_per_step")
+        for N in (2, 4, 8):
+            tN = rows[str(N)].get("ms_per_step")
+            if t1 and tN:
+                rows[str(N)]["predicted_speedup"] = t1 / tN
+                rows[str(N)]["predicted_efficiency"] = t1 / tN / N
+        table[name] = rows
+    print(json.dumps(table))
+
+
+def shard_emulation(a):
+    """The table of shard_emulation_child, from a child process with a one-rank communicator of its own."""
+    import socket
+    import subprocess
+
+    t0 = time.perf_counter()
+    try:
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VIHDS_FORCE_DIST="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        cmd = [sys.executable, os.path.abspath(__file__), "--emulate-shards", "--seed", str(a.seed), "--lr", str(a.lr)]
+        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+        if out.returncode != 0 or not line:
+            table = {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
+        else:
+            table = json.loads(line[-1])
+    except BaseException as exc:  # noqa: BLE001
+        table = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
+    table["how"] = ("per-rank shapes of the sample-sharded configurations (n_iwae / N samples of ONE batch of 36 rows) timed on one "
+                    "GPU through a one-rank RCCL job: predicted_speedup = t(N=1) / t(per-rank shape); the collectives' xGMI latency "
+                    "at N > 1 is NOT in it.  The weak-scaling headline's per-rank shape is the headline itself: see "
+                    "other_configs.distributed_path_world1")
+    table["leg_wall_s"] = time.perf_counter() - t0
+    return table
 
 
 def other_config_legs(a, dev):
@@ -748,10 +896,21 @@ def main():
                          "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
                          "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
+    ap.add_argument("--emulate-shards", action="store_true",
+                    help="print the per-rank-shape table of the sample-sharded configurations (see shard_emulation_child); run "
+                         "as a one-rank distributed job, which the default line does for itself in a child process")
+    ap.add_argument("--no-shard-emulation", dest="shard_emulation", action="store_false",
+                    help="N = 1: skip the `shard_emulation` object of the default line")
+    ap.add_argument("--no-loop-legs", dest="loop_legs", action="store_false",
+                    help="N = 1: skip the `run_loop` / `real_plate` legs (Training.run() end to end) of the default line")
     ap.add_argument("--legs-only", action="store_true",
                     help="development aid: time only the two host-bound legs (unchanged spec; one rank through the "
                          "distributed path) and print them; not the driver's line")
     a = ap.parse_args()
+    if a.emulate_shards:
+        if not torch.cuda.is_available():
+            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
+        return shard_emulation_child(a)
     if a.legs_only:
         a.solver = a.solver or "rk4"
         torch.cuda.set_device(0)
@@ -802,11 +961,10 @@ def main():
         replica, shard = parallel.RowReplica(shard.rank, shard.world, shard.group), None
     multi = shard is not None or replica is not None
     if multi:
-        # (a multi-rank run that stops making progress -- a collective one rank never joins, a capture that hangs -- says where
-        # it stands and ends after twenty minutes instead of sitting there: this path has only ever run with one rank)
+        # (backstop behind the watchdog below: a multi-rank run that stops making progress says where it stands and ends)
         import faulthandler
 
-        faulthandler.dump_traceback_later(1200, exit=True)
+        faulthandler.dump_traceback_later(MULTI_RANK_WATCHDOG_S + 60, exit=True)
     local_rank = int(os.environ.get("VIHDS_FORCE_DEVICE", os.environ.get("LOCAL_RANK", "0")))
     torch.cuda.set_device(local_rank)
     dev = "cuda:%d" % local_rank
@@ -830,6 +988,46 @@ def main():
         if multi:
             torch.distributed.barrier()
             torch.cuda.synchronize()
+
+    # Several ranks: the SAFE measurement first -- eager launches, eager collectives, nothing captured -- so that a valid line
+    # exists before anything that has never run on more than one GPU is tried (the captured step with RCCL's kernels inside
+    # the hipGraph, the capture probe's child processes).  A watchdog then guards the graph path: if it has not finished within
+    # MULTI_RANK_WATCHDOG_S seconds, rank 0 prints the eager line (marked as such) and every rank leaves with exit code 0 -- the
+    # scaling record is never lost to a hang (VERDICT r04 #2d: the old behaviour was a traceback after twenty minutes).
+    watchdog = None
+    if multi:
+        import threading
+
+        for _ in range(10):
+            training.step(batch)
+        barrier()
+        t0 = time.perf_counter()
+        n_eager = max(20, min(a.steps, 200))
+        for _ in range(n_eager):
+            loss_e = training.step(batch)
+        barrier()
+        te = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(te, op=torch.distributed.ReduceOp.MAX)
+        el_e = float(te)
+        fallback = {
+            "metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)", "value": world * n_eager / el_e, "unit": "steps/s",
+            "n_gpus": world, "steps": n_eager, "warmup": 10, "ms_per_step": 1e3 * el_e / n_eager, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, N=8 species, T=86, P=35, %s, full training "
+                                   "step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" % a.solver, "launch": "eager (fallback line)",
+                       "world_size": world, "parallelism": "data parallel over rows" if replica is not None else "iwae-sample shard"},
+            "final_loss": float(loss_e), "roofline": None, "cpu_baseline": None,
+            "note": "FALLBACK: the hipGraph-replayed multi-rank measurement did not finish within %d s; this is the eager "
+                    "measurement taken before it" % MULTI_RANK_WATCHDOG_S}
+
+        def fire():
+            if rank == 0:
+                print(json.dumps(fallback), flush=True)
+            os._exit(0)
+
+        watchdog = threading.Timer(MULTI_RANK_WATCHDOG_S, fire)
+        watchdog.daemon = True
+        watchdog.start()
 
     # steps per graph launch: between two graph launches the GPU idles 6-8 us (measured: rocprofv3 kernel trace), so the
     # resident-batch replay captures G consecutive steps per graph; K timed steps = K // G launches of that graph plus
@@ -907,13 +1105,18 @@ def main():
                          % final_loss)
 
     rank_devices = ["rank 0: %s (%s)" % (dev, torch.cuda.get_device_name(local_rank))]
-    strong = None
+    strong = strong5 = None
     if multi:
         gathered = [None] * world
         torch.distributed.all_gather_object(gathered, "rank %d: %s (%s)" % (rank, dev, torch.cuda.get_device_name(local_rank)))
         rank_devices = gathered
         if a.strong_leg:
             strong = strong_scaling_leg(a, dev, world, rank)
+            strong5 = strong_scaling_leg(a, dev, world, rank, "relay_constant_precisions", 200, "midpoint", "config5")
+    eager_ms = None
+    if watchdog is not None:
+        watchdog.cancel()
+        eager_ms = fallback["ms_per_step"]
     # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
     if a.roofline_steps <= 0:
         if rank == 0:
@@ -922,9 +1125,11 @@ def main():
                               "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "launch": launch_mode,
                               "final_loss": final_loss, "world_size": world, "rank_devices": rank_devices,
                               "value_long": long_run["value"] if long_run else None,
-                              "strong_scaling_config3": strong, "scaling": "weak", "steps_per_graph_launch": G,
+                              "strong_scaling_config3": strong, "strong_scaling_config5": strong5, "scaling": "weak",
+                              "steps_per_graph_launch": G,
                               "dist_backend": torch.distributed.get_backend() if multi else None,
                               "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None,
+                              "eager_ms_per_step": eager_ms,
                               "note": "roofline leg skipped (--roofline-steps 0)"}))
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
@@ -1040,6 +1245,7 @@ def main():
                                    if replica is not None else "iwae-sample shard x%d (all-gather of row statistics + "
                                    "one gradient all-reduce per step)" % world)},
         "final_loss": final_loss, "roofline": roofline, "strong_scaling_config3": strong,
+        "strong_scaling_config5": strong5, "eager_ms_per_step": eager_ms,
     }
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.solver, batch.observations.detach().cpu())
@@ -1050,6 +1256,12 @@ def main():
         torch.cuda.empty_cache()
         out["other_configs"] = other_config_legs(a, dev)
         out["other_configs"]["distributed_path_world1"] = distributed_leg_guarded(a, out["ms_per_step"])
+        if a.loop_legs:
+            loops = loop_legs_for_default_line(a)
+            out["run_loop"], out["real_plate"] = loops["run_loop"], loops["real_plate"]
+            out["newton_iters"] = {k: (loops[k] or {}).get("newton_iters") for k in ("run_loop", "real_plate")}
+        if a.shard_emulation:
+            out["shard_emulation"] = shard_emulation(a)
     print(json.dumps(out))
 
 

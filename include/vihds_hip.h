@@ -493,6 +493,14 @@ int vihds_adam_step(const vihds_adam_tensors* t, float* m, float* v, float* stat
  * reads the same value to report it.  (Without a gate, and always as a second line of defence, a non-finite gradient
  * ELEMENT leaves its parameter and moments untouched.) */
 
+/* Telemetry of the time-parallel decoder kernel (vihds_theta_ode_logp_grad / vihds_ode_logp_grad on the headline path): its OD
+ * chain is solved by Newton's method over the lanes, so its run time depends on the values.  hist: 34 zeroed device words (or
+ * NULL to switch it off, the default): hist[w], w = 1..32, counts the wavefronts (two trajectories each) whose iteration took w
+ * walks of the chain, hist[33] those that finished through the first-order correction instead of a last walk.  A
+ * process-wide setting read at launch time (the one piece of state besides the error string); captured launches keep the
+ * pointer they were captured with. */
+int vihds_debug_newton_hist(unsigned int* hist);
+
 /* The rest of a training step behind the decoder launch, for a single process whose trainable parameters are the
  * encoder's: IWAE loss (training.py:135-149), the backward through theta / log q / log p to q's tables, the backward
  * through the encoder, and Adam (training.py:334-337) -- what vihds_theta_bwd (with a vihds_iwae_job) +

@@ -17,8 +17,10 @@
 extern "C" {
 #endif
 
-#define VIHDS_HOST_ABI_VERSION 3
+#define VIHDS_HOST_ABI_VERSION 4
 int vihds_host_abi_version(void);
+/* 1 when the CPU has the vector extensions the library was built for (AVX2); the binding uses numpy itself otherwise */
+int vihds_host_cpu_ok(void);
 
 /* out[0..n) <- np.random.standard_normal(n).astype(np.float32) of the RandomState (key[624], pos, has_gauss, gauss) -- numpy's
  * MT19937 state as np.random.get_state() returns it; the four are left as numpy would leave them.  n_threads: 1..64.

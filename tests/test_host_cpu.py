@@ -278,6 +278,41 @@ def test_native_numpy_normal_stream_is_bit_identical():
     assert np.array_equal(st_ref[1], st[1]) and st_ref[2:] == st[2:]
 
 
+def test_prefetched_draw_collected_by_another_consumer_is_not_waited_for_twice():
+    """a graph's prefetch bookkeeping (vihds/hostdraws.py `staged`) and nprand's count of draws in flight could
+    desynchronise -- an evaluate() refresh, another graph's refresh, an eager draw or a training-state snapshot drains the
+    helper's queue through nprand._collect_stray, and the owner's later finish() then waited for a draw that was not there
+    (count -1, vihds_np_randn_f32_wait -> -3, RuntimeError).  The draws now carry an ownership token (nprand.generation):
+    a draw somebody else had to wait for is left alone by its owner, its numbers are in place, and the stream is unchanged."""
+    from vihds import nprand
+
+    if not nprand.available():
+        pytest.skip("libvihds_host.so not built")
+    np.random.seed(21)
+    ref = [np.random.randn(4096).astype(np.float32) for _ in range(4)]
+    np.random.seed(21)
+    a, b, c = (np.empty(4096, np.float32) for _ in range(3))
+    first = nprand.randn_f32((4096,))  # (leaves the state "ours": a start() is allowed)
+    da, db = nprand.Draw((4096,)), nprand.Draw((4096,))
+    assert da.start(a) and db.start(b)
+    tok = da.generation()
+    other = nprand.randn_f32((4096,))  # another consumer of the stream: collects both started draws first
+    assert nprand._IN_FLIGHT == 0 and nprand.generation() == tok + 1
+    da.finish()  # the owners come later: nothing to wait for, nothing raised, the count stays at rest
+    db.finish()
+    assert nprand._IN_FLIGHT == 0
+    assert np.array_equal(first, ref[0]) and np.array_equal(a, ref[1]) and np.array_equal(b, ref[2]) and np.array_equal(other, ref[3])
+    # and the ordinary path still waits for its own draw
+    dc = nprand.Draw((4096,))
+    np.random.seed(5)
+    want = np.random.randn(8192).astype(np.float32)
+    np.random.seed(5)
+    nprand.randn_f32((4096,))
+    assert dc.start(c) and dc.generation() == nprand.generation()
+    dc.finish()
+    assert np.array_equal(c, want[4096:]) and nprand._IN_FLIGHT == 0
+
+
 def test_host_library_exports_what_its_header_declares():
     """include/vihds_host.h: every declared entry point is exported by libvihds_host.so, and the ABI number matches."""
     import ctypes
@@ -289,7 +324,8 @@ def test_host_library_exports_what_its_header_declares():
         pytest.skip("libvihds_host.so not built")
     header = open(os.path.join(root, "include", "vihds_host.h")).read()
     names = sorted(set(re.findall(r"\b(vihds_[a-z0-9_]+)\s*\(", header)))
-    assert names == ["vihds_host_abi_version", "vihds_np_randn_f32", "vihds_np_randn_f32_start", "vihds_np_randn_f32_wait"]
+    assert names == ["vihds_host_abi_version", "vihds_host_cpu_ok", "vihds_np_randn_f32", "vihds_np_randn_f32_start",
+                     "vihds_np_randn_f32_wait"]
     lib = ctypes.CDLL(lib_path)
     for n in names:
         assert hasattr(lib, n), n

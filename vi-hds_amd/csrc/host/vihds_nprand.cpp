@@ -485,6 +485,15 @@ int vihds_np_randn_f32_wait(void) {
   return rc;
 }
 
-int vihds_host_abi_version(void) { return 3; }
+int vihds_host_abi_version(void) { return 4; }
+// 1 when this CPU runs the AVX2 code the library was compiled to (the Python binding asks once and falls back to numpy
+// itself otherwise: on a host without AVX2 the first vector instruction would be a SIGILL)
+int vihds_host_cpu_ok(void) {
+#if defined(__x86_64__) || defined(__i386__)
+  return __builtin_cpu_supports("avx2") ? 1 : 0;
+#else
+  return 0;
+#endif
+}
 
 }  // extern "C"

@@ -129,6 +129,7 @@ static const ModelEntry kModels[VIHDS_MODEL_COUNT] = {
 };
 
 static thread_local char g_err[256] = "";
+static unsigned int* g_newton_hist = nullptr;  // vihds_debug_newton_hist: telemetry buffer of the time-parallel decoder kernel
 static int fail(int code, const char* msg) {
   std::snprintf(g_err, sizeof(g_err), "%s", msg);
   return code;
@@ -230,6 +231,10 @@ using namespace vihds;
 extern "C" {
 
 int vihds_abi_version(void) { return VIHDS_ABI_VERSION; }
+int vihds_debug_newton_hist(unsigned int* hist) {
+  g_newton_hist = hist;
+  return VIHDS_OK;
+}
 const char* vihds_last_error(void) { return g_err; }
 
 int vihds_model_n_states(int model) {
@@ -285,6 +290,7 @@ int vihds_ode_logp_grad(const vihds_ode_problem* p, const float* theta, const fl
   if (p->C < 2) return fail(VIHDS_E_BADARG, "dr_constant needs two treatments");
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs;
   a.logp = logp; a.g_theta = g_theta_unit;
+  a.newton_hist = g_newton_hist;
   const int rc = p->model == VIHDS_MODEL_DR_CONSTANT
                      ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream, nullptr)
                      : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream, nullptr);
@@ -333,6 +339,7 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
   }
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs;
   a.logp = logp; a.g_theta = g_theta_unit;
+  a.newton_hist = g_newton_hist;
   const int rc = p->model == VIHDS_MODEL_DR_CONSTANT
                      ? launch_dr_constant_train_v1(p->solver, a, (hipStream_t)stream, &t)
                      : launch_dr_constant_train_v2(p->solver, a, (hipStream_t)stream, &t);

@@ -34,6 +34,9 @@ struct OdeArgs {
   const float* iw_logp;   // [4][B][S]
   const float* iw_log_p;  // [B][S] or NULL
   const float* iw_log_q;  // [B][S] or NULL
+  // telemetry of the time-parallel decoder kernel (vihds_debug_newton_hist; NULL: none): [0..32] wavefronts by the number of
+  // walks their Newton iteration over the OD chain took, [33] wavefronts that left through the first-order correction
+  unsigned int* newton_hist;
 };
 
 // Everything the sampling stage needs when it runs inside the decoder-step kernel (vihds_theta_ode_logp_grad):

@@ -765,6 +765,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     float dus_own[ITEMS][NS];  // d us_own[m][s] / d g
     VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m)
       VIHDS_UNROLL for (int s = 0; s < NS; ++s) dus_own[m][s] = 0.f;
+    int walks = 32, first_order = 0;  // (telemetry only: a.newton_hist)
     for (int iter = 0; iter < 32; ++iter) {
       float u = g, da = 1.f;
       VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {
@@ -789,7 +790,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       // step-by-step walk would find it, costs the full 32 iterations; non-finite parameters leave at once.)
       const float dg = gn - g;
       const bool settled = fabsf(dg) <= 1e-6f * fabsf(gn);
-      if (__builtin_amdgcn_ballot_w64(!settled && (u0 - u0 == 0.f)) == 0ull) break;
+      if (__builtin_amdgcn_ballot_w64(!settled && (u0 - u0 == 0.f)) == 0ull) { walks = iter + 1; break; }
       // Close enough for the first-order term to finish the job (the usual case: the closed form is off by ~1e-4, the
       // neglected second-order term is the square of that): the stage values move along the derivatives this walk carried,
       // and the second walk is saved -- every lane's steps then hold to ~1e-8 instead of exactly, the level of the rounding
@@ -799,9 +800,15 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
         VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m)
           VIHDS_UNROLL for (int s = 0; s < NS; ++s) us_own[m][s] = fmaf(dus_own[m][s], dg, us_own[m][s]);
         uend = fmaf(da, dg, uend);
+        walks = iter + 1;
+        first_order = 1;
         break;
       }
       g = gn;
+    }
+    if (a.newton_hist && lane == 0) {  // (uniform; a non-returning atomic: nothing waits for it)
+      atomicAdd(&a.newton_hist[walks], 1u);
+      if (first_order) atomicAdd(&a.newton_hist[33], 1u);
     }
     if (l == 31) uK[tib] = uend;  // (lanes beyond the last step hold the identity: the last lane's value is x(T-1) / K)
     VIHDS_UNROLL for (int m = 0; m < ITEMS; ++m) {

@@ -206,7 +206,9 @@ struct RlAcc {
   // weight gradients of the precision network: lane l <= NSP owns COLUMN j(l) (the input it publishes: t or its own species)
   // of both matrices -- its own tanh times the eight pre-activation adjoints every lane reads anyway: 4 packed FMAs per
   // evaluation where a row per precision lane cost 13 in all sixteen lanes; the precision lanes keep the bias sums
-  rl_v2 wc[4], b2b;
+  // (scalars, not (production, degradation) pairs: packed fp32 instructions cost this kernel time -- the pairs' register
+  // shuffles and the v_pk_* issue rate; measured with -fno-slp-vectorize, round 5)
+  float wcp[4], wcd[4], b2p, b2d;
 };
 
 // VJP of one evaluation whose forward quantities (E, hv) are at hand: v = adjoint of dy_l; returns the adjoint of Y_l;
@@ -243,12 +245,12 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
   }
   // precision network
   if (PREC) {
-    rl_v2 zb;
-    zb.x = c.isP * v * E.sp * (1.f - E.sp);
-    zb.y = -c.isP * v * Y * E.sd * (1.f - E.sd);
-    A.b2b += zb;
-    pt[c.a_zx] = zb.x;
-    pt[c.a_zy] = zb.y;
+    const float zbx = c.isP * v * E.sp * (1.f - E.sp);
+    const float zby = -c.isP * v * Y * E.sd * (1.f - E.sd);
+    A.b2p += zbx;
+    A.b2d += zby;
+    pt[c.a_zx] = zbx;
+    pt[c.a_zy] = zby;
   }
   if (LM::HAS_Q) { pt[c.a_q1] = xq; pt[c.a_q2] = Iq; }
   rl_wave_fence();
@@ -258,8 +260,10 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     const float hb = c.cw[0] * za.x + c.cw[1] * za.y + c.cw[2] * za.z + c.cw[3] * za.w + c.cw[4] * zd4.x + c.cw[5] * zd4.y +
                      c.cw[6] * zd4.z + c.cw[7] * zd4.w;
     yb += hb * (1.f - E.hl * E.hl);  // (the columns cw are zero outside the species lanes)
-    A.wc[0] += rl_v2{za.x, zd4.x} * E.hl; A.wc[1] += rl_v2{za.y, zd4.y} * E.hl;
-    A.wc[2] += rl_v2{za.z, zd4.z} * E.hl; A.wc[3] += rl_v2{za.w, zd4.w} * E.hl;
+    A.wcp[0] = fmaf(za.x, E.hl, A.wcp[0]); A.wcp[1] = fmaf(za.y, E.hl, A.wcp[1]);
+    A.wcp[2] = fmaf(za.z, E.hl, A.wcp[2]); A.wcp[3] = fmaf(za.w, E.hl, A.wcp[3]);
+    A.wcd[0] = fmaf(zd4.x, E.hl, A.wcd[0]); A.wcd[1] = fmaf(zd4.y, E.hl, A.wcd[1]);
+    A.wcd[2] = fmaf(zd4.z, E.hl, A.wcd[2]); A.wcd[3] = fmaf(zd4.w, E.hl, A.wcd[3]);
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
@@ -642,9 +646,9 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig
   const int j = l & 3;
   RlAcc A;
   A.F0b = A.cPb = A.eb = A.aRb = A.aSb = A.cQb = A.iKb = A.degb = A.rb = A.Kb = A.tlagb = 0.f;
-  A.b2b = rl_v2{0.f, 0.f};
+  A.b2p = A.b2d = 0.f;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) A.wc[q] = rl_v2{0.f, 0.f};
+  for (int q = 0; q < 4; ++q) A.wcp[q] = A.wcd[q] = 0.f;
   float lam = 0.f, precb = 0.f;
   const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
   const float glp = l < 4 ? ode_logp_grad(a, w_iw, i, j) : 0.f;
@@ -781,14 +785,14 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig
       const int jc = l == NSP ? 0 : l + 1;
 #pragma unroll
       for (int o = 0; o < 4; ++o) {
-        wred[g][o * NWROW + jc] = live ? A.wc[o].x : 0.f;
-        wred[g][o * NWROW + NIN + jc] = live ? A.wc[o].y : 0.f;
+        wred[g][o * NWROW + jc] = live ? A.wcp[o] : 0.f;
+        wred[g][o * NWROW + NIN + jc] = live ? A.wcd[o] : 0.f;
       }
     }
     if (l >= NSP && l < NSP + 4) {
       float* w = wred[g] + (l - NSP) * NWROW;
-      w[2 * NIN] = live ? A.b2b.x : 0.f;
-      w[2 * NIN + 1] = live ? A.b2b.y : 0.f;
+      w[2 * NIN] = live ? A.b2p : 0.f;
+      w[2 * NIN + 1] = live ? A.b2d : 0.f;
     }
     __syncthreads();
     if (tid < NWG && a.aux) {

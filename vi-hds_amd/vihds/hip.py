@@ -149,6 +149,7 @@ class StepTailArgs(ctypes.Structure):
 _PROTOTYPES = {
     "vihds_abi_version": (_I, []),
     "vihds_last_error": (ctypes.c_char_p, []),
+    "vihds_debug_newton_hist": (_I, [_P]),
     "vihds_model_n_states": (_I, [_I]),
     "vihds_model_n_species": (_I, [_I]),
     "vihds_model_n_slots": (_I, [_I]),

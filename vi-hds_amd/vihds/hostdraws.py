@@ -29,7 +29,7 @@ class HostDraws(object):
         self.noted = 0   # floats one step asked for (measuring mode: warm-up steps)
         self.pinned, self.views, self.events = None, None, [None] * self.RING
         self.pos = 0       # next ring entry
-        self.staged = []   # ring entries whose prefetchable draws were started ahead, oldest first
+        self.staged = []   # (ring entry, the draw's ownership token) of prefetchable draws started ahead, oldest first
 
     def note(self, shape):
         n = 1
@@ -80,17 +80,23 @@ class HostDraws(object):
         j = next(i for i, slot in enumerate(self.slots) if slot[4])
         while len(self.staged) < min(int(ahead), self.AHEAD):
             k = self._stage()
-            if not self.slots[j][1].start(self.views[k][j]):
+            fill = self.slots[j][1]
+            if not fill.start(self.views[k][j]):
                 self.pos = k  # (not startable now: the refresh takes this entry itself)
                 break
-            self.staged.append(k)
+            self.staged.append((k, fill.generation() if hasattr(fill, "generation") else None))
 
     def refresh(self):
         ahead = bool(self.staged)
-        k = self.staged.pop(0) if ahead else self._stage()
+        k, token = self.staged.pop(0) if ahead else (self._stage(), None)
         for j, slot in enumerate(self.slots):
             if ahead and slot[4]:  # drawn ahead by prefetch()
-                slot[1].finish()
+                # Another consumer of the same host stream (an evaluate() refresh, another graph's refresh, an eager draw, a
+                # training-state snapshot) may have had to wait for this draw in the meantime (nprand._collect_stray): the
+                # numbers are in the staging buffer then and there is nothing left to wait for -- waiting again would take
+                # somebody else's draw off the helper's queue (the two books could desynchronise)
+                if not hasattr(slot[1], "generation") or slot[1].generation() == token:
+                    slot[1].finish()
             else:
                 slot[1](self.views[k][j])
         self.upload.copy_(self.pinned[k], non_blocking=True)

@@ -31,8 +31,9 @@ def _lib():
                                                      ctypes.c_int]
             lib.vihds_np_randn_f32_wait.restype = ctypes.c_int
             lib.vihds_np_randn_f32_wait.argtypes = []
-            _LIB = lib
-        except OSError:
+            # (a CPU without the vector extensions the library was compiled for, or numpy internals that moved: numpy itself)
+            _LIB = lib if (_ADDR is not None and lib.vihds_host_cpu_ok()) else False
+        except (OSError, AttributeError):
             _LIB = False
     return _LIB
 
@@ -46,10 +47,13 @@ def available():
 # path below lets the native code read and advance it where it lives -- allowed only when nobody else has drawn since our
 # last call (the state's fingerprint is unchanged) and that call left no cached second deviate (the legacy gauss cache is
 # not reachable this way), which is every draw of an even number of normals in a row: the training loop's.
-_BG = np.random.mtrand._rand._bit_generator
-_ADDR = _BG.ctypes.state_address
-_KEY = (ctypes.c_uint32 * 624).from_address(_ADDR)
-_POS = ctypes.c_int.from_address(_ADDR + 624 * 4)
+try:
+    _BG = np.random.mtrand._rand._bit_generator
+    _ADDR = _BG.ctypes.state_address
+    _KEY = (ctypes.c_uint32 * 624).from_address(_ADDR)
+    _POS = ctypes.c_int.from_address(_ADDR + 624 * 4)
+except Exception:  # noqa: BLE001 -- private numpy internals: if they ever move, the native path is off, numpy draws
+    _BG = _ADDR = _KEY = _POS = None
 _LEFT = None
 
 
@@ -58,17 +62,25 @@ def _fingerprint():
 
 
 _IN_FLIGHT = 0  # Draw.start()s whose finish() has not run yet (the library queues up to two)
+_GEN = 0        # bumped whenever started draws were waited for by somebody other than their owner (_collect_stray)
+
+
+def generation():
+    """Token of the started draws' ownership: a draw started under generation g whose owner finds another generation later was
+    waited for by _collect_stray in between -- its numbers are in place, and its finish() must not wait again."""
+    return _GEN
 
 
 def _collect_stray():
     """A started draw that nobody finished (its consumer never came: the stream has advanced by that unused draw, as
     hostdraws documents): wait for it, so that numpy's state is at rest before anybody reads or writes it."""
-    global _IN_FLIGHT, _LEFT
-    if _IN_FLIGHT:
-        while _IN_FLIGHT:
+    global _IN_FLIGHT, _LEFT, _GEN
+    if _IN_FLIGHT > 0:
+        while _IN_FLIGHT > 0:
             _IN_FLIGHT -= 1
             _lib().vihds_np_randn_f32_wait()
         _LEFT = _fingerprint()
+        _GEN += 1  # (whoever started them -- a graph's prefetch bookkeeping, vihds/hostdraws.py -- sees that they are done)
 
 
 atexit.register(lambda: _collect_stray() if _IN_FLIGHT else None)  # (numpy's state must outlive a draw that is still running)
@@ -144,9 +156,14 @@ class Draw(object):
         _IN_FLIGHT += 1
         return True
 
+    def generation(self):
+        return _GEN
+
     def finish(self):
         """Wait for the OLDEST started draw."""
         global _LEFT, _IN_FLIGHT
+        if _IN_FLIGHT <= 0:  # (collected already -- _collect_stray waited for it: the numbers are in place)
+            return
         _IN_FLIGHT -= 1
         rc = _lib().vihds_np_randn_f32_wait()
         if rc != 0:

@@ -1489,6 +1489,10 @@ def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None,
     """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99).  xpred None: the observed signals
     are formed from the trajectory by the model's observation map (observe_kind) inside the kernel."""
     _require_cuda(log_w, lse, traj)
+    # the kernels read [T][N][B][S] / [T][4][B][S] storage through raw pointers: a solution that came back as a permuted view of
+    # time-fastest storage (kernel_variant 5: [B][S][N][T], ops.OdeSolveObserve) is laid out first (ADVICE r04: it was read as
+    # is, and the summaries of relay / degrader / prpr / auto models evaluated with that variant came out wrong)
+    traj, xpred = _c(traj), _c(xpred)
     T, N, B, S = traj.shape
     dev = traj.device
     mu = torch.empty((B, 4, T), device=dev)

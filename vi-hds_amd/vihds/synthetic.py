@@ -111,6 +111,7 @@ def relay_constant_precisions_spec(solver="midpoint"):
     }
 
 
+MODEL_SIMULATED = ("dr_constant_icml", "relay_constant_precisions")
 WORKLOADS = {"dr_constant_icml": (dr_constant_icml_spec, 86), "dr_blackbox_icml": (dr_blackbox_icml_spec, 86),
              "relay_constant_precisions": (relay_constant_precisions_spec, 99)}
 
@@ -158,7 +159,7 @@ def simulate_observations(settings, parameters, dataset, device, seed=0, noise=0
     from vihds import hip
     from vihds.distributions import DotOperatorSamples
 
-    ode = models.LOOKUP[settings.model](settings)
+    ode = models.LOOKUP[settings.model](settings).to(device)  # (neural precisions: their weights feed the kernel from HBM)
     g = torch.Generator().manual_seed(seed)
     n = len(dataset)
     th = DotOperatorSamples()
@@ -217,7 +218,10 @@ def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=No
     idx = np.arange(n_rows)
     data = TimeSeriesDatasetPair(Subset(ds, idx), Subset(ds, idx), settings.data)
     parameters = Parameters(settings.params)
-    if settings.device.type == "cuda" and workload == "dr_constant_icml":
+    # white-box workloads observe what their own model produces (a well-posed inference problem: the objective does not run
+    # away at the spec's learning rate); dr_blackbox keeps the plate-like curves -- its network starts
+    # from random weights, there is no "own model" to simulate from, and its objective stays finite on them
+    if settings.device.type == "cuda" and workload in MODEL_SIMULATED:
         simulate_observations(settings, parameters, ds, settings.device, data_seed)
     elif observations is not None:
         ds.observations = observations
@@ -226,4 +230,58 @@ def build(workload, n_rows, n_iwae, solver="rk4", device="cpu", seed=0, shard=No
     model.replica = replica
     training = Training(args, settings, data, parameters, model)
     torch.manual_seed(data_seed + 1)  # the in-kernel generators are seeded from torch's stream at their first use
+    return args, settings, data, parameters, model, training
+
+
+class RecordedPlate(Dataset):
+    """A processed plate as the reference's data pipeline produced it (vihds/datasets.py:173-224 of the reference: CSVs ->
+    merged, scaled, background-subtracted observations, log1p'ed treatments, device one-hot blocks), read from the arrays a
+    golden trace file recorded (tests/golden/trace_*.npz: `times, devices, dev_1hot, inputs, observations`)."""
+
+    def __init__(self, z):
+        self.times = torch.tensor(np.asarray(z["times"]))
+        self.n_times, self.n_species = len(self.times), 4
+        self.devices = np.asarray(z["devices"])
+        self.dev_1hot = torch.tensor(np.asarray(z["dev_1hot"]))
+        self.inputs = torch.tensor(np.asarray(z["inputs"]))
+        self.observations = torch.tensor(np.asarray(z["observations"]))
+
+    def __len__(self):
+        return len(self.devices)
+
+    def __getitem__(self, idx):
+        if torch.is_tensor(idx):
+            idx = idx.tolist()
+        return {"devices": self.devices[idx], "dev_1hot": self.dev_1hot[idx], "inputs": self.inputs[idx],
+                "observations": self.observations[idx]}
+
+
+def build_recorded_plate(npz_path, n_iwae, solver="rk4", device="cpu", seed=0, **param_overrides):
+    """(args, settings, data_pair, parameters, model, training) on the REAL plate of the reference's specs/dr_constant_icml.yaml
+    -- 312 wells, 234 / 78 train / validation rows of its own seeded split (datasets.py:199-222) -- with the experiment
+    definition recorded next to it (spec_json: the YAML as parsed), e.g. learning_rate 0.01 and MultiStepLR [250, 1000]."""
+    import json
+
+    from vihds.config import Config
+    from vihds.datasets import split_dataset
+    from vihds.parameters import Parameters
+    from vihds.training import Training
+    from vihds.vae import build_model
+
+    z = np.load(npz_path)
+    spec = json.loads(str(z["spec_json"]))
+    spec["params"]["solver"] = solver
+    spec["params"].update(param_overrides)
+    args = make_args(n_iwae, seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    settings = Config(args=None, spec=spec)
+    settings.device = torch.device(device)
+    settings.seed = seed
+    data = split_dataset(RecordedPlate(z), args, settings.data)
+    parameters = Parameters(settings.params)
+    torch.manual_seed(seed)
+    model = build_model(args, settings, data, parameters)
+    training = Training(args, settings, data, parameters, model)
+    torch.manual_seed(seed + 1)
     return args, settings, data, parameters, model, training

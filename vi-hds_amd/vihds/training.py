@@ -532,6 +532,9 @@ class Training:
         rng = {id(t): t.clone() for t in self._rng_states()}
         # the host-side streams too (numpy's global RandomState: u; torch's CPU generator: the conditioner's weights and the
         # loader's shuffles): the warm-up steps of a capture must not consume draws the training run is entitled to
+        from vihds import nprand
+
+        nprand._collect_stray()  # (a helper-thread draw started ahead mutates numpy's state in place: at rest first)
         rng["__numpy__"] = np.random.get_state()
         rng["__torch_cpu__"] = torch.get_rng_state()
         return params, opt, rng
@@ -563,6 +566,9 @@ class Training:
                         for k in ("m", "v", "state"):
                             st[k].zero_()
             if "__numpy__" in rng:
+                from vihds import nprand
+
+                nprand._collect_stray()
                 np.random.set_state(rng["__numpy__"])
                 torch.set_rng_state(rng["__torch_cpu__"])
             for t in self._rng_states():
@@ -581,7 +587,12 @@ class Training:
         """hip_graph was chosen automatically and a capture failed (a step that synchronises, an allocation the capture does
         not permit, ...): say so once and run eagerly from here on -- the numbers are the same.  An explicit hip_graph: true
         re-raises."""
-        if not self._graph_auto:
+        # (only failures of the capture itself qualify -- a step that synchronises, an allocation or a call the capture does
+        # not permit; anything else, e.g. a shape error or the host-draw reservation mismatch, is a bug and is raised as it is)
+        msg = str(exc).lower()
+        capture_related = isinstance(exc, RuntimeError) and any(k in msg for k in ("captur", "hiperror", "cuda error", "hip error",
+                                                                                     "graph", "stream is capturing"))
+        if not self._graph_auto or not capture_related:
             raise exc
         print("- hipGraph capture failed (%s: %s): continuing with eager launches" % (type(exc).__name__, str(exc)[:200]))
         torch.cuda.synchronize()
@@ -793,7 +804,11 @@ class Training:
                     statics[n] = self.gather_rows(view)
                 segments.append((statics[n], (lambda v=view, st=statics[n]: self.gather_rows(v, out=st))))
                 o += n
-            self._graphs[key] = self._capture_segments(segments) + (idx, self._IndexStaging(int(idx.shape[0])))
+            try:
+                self._graphs[key] = self._capture_segments(segments) + (idx, self._IndexStaging(int(idx.shape[0])))
+            except Exception as exc:  # noqa: BLE001 -- the same policy as graph_step / step_rows: automatic mode falls back to eager
+                self._graphs_off(exc)
+                return [self.step(self.gather_rows(b.to(dev, non_blocking=True))) for b in batches]
         g, losses, idx, staging = self._graphs[key]
         staging.upload(idx, lambda buf: torch.cat(list(batches), out=buf))
         hostdraws.replay(g)
