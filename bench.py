@@ -234,6 +234,9 @@ WORKLOAD_TABLE = {
     "config3_eval": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm", "configs[2], evaluation shape (all 234 rows, n_iwae=1000)"),
     "config4": ("dr_blackbox_icml", 36, 200, "midpoint", "train", "mfma", "configs[3]"),
     "config5": ("relay_constant_precisions", 36, 200, "midpoint", "train", "hbm", "configs[4]"),
+    # the dr_blackbox kernels with the chip FULL (2 250 groups of 16 trajectories on 1 024 SIMDs; configs[3] itself is 450): what
+    # their matrix-core utilisation is when every SIMD has work
+    "config4_s1000": ("dr_blackbox_icml", 36, 1000, "midpoint", "train", "mfma", "configs[3] at n_iwae=1000"),
 }
 LAUNCH_KERNELS = {  # launch name (ops._launch) -> substrings of the kernels it can run, for the PMC lookup
     "decoder_step": ["dr_scan_train_theta_kernel", "dr_lane_train_theta_kernel"],
@@ -419,6 +422,9 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
                                                             "the evaluation pass does not store x_predict (params.lazy_x_predict)"),
                     "other_kernels": [entry(k) for k in timed if k != dom]}
         mf = os.path.join(ROOT, "profiles", "%s_mfma_busy.json" % name)
+        if not os.path.exists(mf):  # (per-round files: the newest r*_<name>_mfma_busy.json)
+            cand = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_mfma_busy.json" % name)), reverse=True)
+            mf = cand[0] if cand else mf
         if bound == "mfma" and os.path.exists(mf):
             roofline["mfma_busy"] = json.load(open(mf))
     what = "training steps" if mode == "train" else "evaluation passes"
@@ -485,7 +491,7 @@ def newton_summary(hist):
 REAL_PLATE_NPZ = os.path.join(ROOT, "tests", "golden", "trace_dr_constant_icml_modeuler.npz")
 
 
-def run_loop_legs(a, plate="synthetic", leg_names=None, epochs=None, telemetry=True):
+def run_loop_legs(a, plate="synthetic", leg_names=None, epochs=None, telemetry=True, stream_seed=None):
     """`Training.run()` itself -- the loop a user of run_xval.py runs (reference training.py:342-383) -- on a dr_constant_icml
     plate of the reference's size: 234 training rows in batches of 36 (six full batches and a ragged one of 18 per epoch,
     shuffled by the reference's own DataLoader sampler), n_iwae = 200, evaluation of the training and the validation rows at
@@ -524,6 +530,11 @@ def run_loop_legs(a, plate="synthetic", leg_names=None, epochs=None, telemetry=T
                 args, settings, data, parameters, model, training = synthetic.build(
                     "dr_constant_icml", n_rows, S, solver=solver, device="cuda:0", seed=a.seed, n_batch=n_batch,
                     learning_rate=a.lr, **keys)
+            if stream_seed is not None:
+                # the split and the initial weights stay the recorded ones (seed 0: the reference's); only the run's random
+                # streams -- the draws u, the conditioner's weights, the loader's shuffles -- start somewhere else
+                np.random.seed(1000 + stream_seed)
+                torch.manual_seed(1000 + stream_seed)
             args.epochs, args.test_epoch, args.test_samples = 2, 1, S_eval
             with contextlib.redirect_stdout(io.StringIO()):
                 training.run()  # captures, allocator warm-up, one evaluation: not timed
@@ -584,8 +595,24 @@ def loop_legs_for_default_line(a):
     for key, plate, epochs in (("run_loop", "synthetic", 200), ("real_plate", "real", 300)):
         t0 = time.perf_counter()
         try:
-            leg = run_loop_legs(a, plate, leg_names=("epoch_graph_nan_check_per_epoch",), epochs=epochs)
-            leg = leg["epoch_graph_nan_check_per_epoch"]
+            name = "epoch_graph_nan_check_per_epoch"
+            if plate == "real":
+                # The spec's learning rate (0.01) on this objective is not stable for every random stream: the reference's own
+                # clip-after-sample log q lets q collapse onto a clipped sample (-ELBO -> -1e19) for some draws -- with the
+                # reference's own keys (numpy stream, modeuler) as with these; tests/probe/runaway_seeds.py, DESIGN.md.  Four
+                # streams are run, every final validation ELBO is reported; `value` is the median throughput.
+                runs = [run_loop_legs(a, plate, leg_names=(name,), epochs=epochs, stream_seed=k)[name] for k in range(4)]
+                runs_sorted = sorted(runs, key=lambda r: r["value"])
+                leg = dict(runs_sorted[len(runs) // 2])
+                leg["final_validation_elbo_by_stream"] = [r["final_validation_elbo"] for r in runs]
+                leg["value_by_stream"] = [r["value"] for r in runs]
+                leg["runaway_streams"] = sum(1 for r in runs if r["final_validation_elbo"] is None
+                                             or not np.isfinite(r["final_validation_elbo"]) or abs(r["final_validation_elbo"]) > 1e6)
+                finite = [r for r in runs if r["final_validation_elbo"] is not None and abs(r["final_validation_elbo"]) <= 1e6]
+                if finite:  # (the telemetry and the ELBO quoted at top level come from a run that stayed finite)
+                    leg["final_validation_elbo"], leg["newton_iters"] = finite[0]["final_validation_elbo"], finite[0]["newton_iters"]
+            else:
+                leg = run_loop_legs(a, plate, leg_names=(name,), epochs=epochs)[name]
             leg["unit"] = "steps/s"
             leg["data"] = ("synthetic plate (vihds/synthetic.py), 234 rows" if plate == "synthetic" else
                            "the reference's processed ICML plate: 312 wells from data/*.csv through datasets.py:173-224, recorded "
@@ -781,10 +808,14 @@ def other_config_legs(a, dev):
     driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
     error; it never takes the headline line with it."""
     legs = {}
-    for name in ("config3_train", "config3_eval", "config4", "config5"):
+    for name in ("config3_train", "config3_eval", "config4", "config5", "config4_s1000"):
         t0 = time.perf_counter()
         try:
+            if name == "config4_s1000":  # (no CPU leg: 36 000 trajectories of eager [B,S] tensors would be a minute per step)
+                keep_cb, a.no_cpu_baseline = a.no_cpu_baseline, True
             out = run_workload(a, name, min_seconds=a.leg_seconds, bounded_cpu=True)
+            if name == "config4_s1000":
+                a.no_cpu_baseline = keep_cb
             keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "final_objective", "roofline",
                     "cpu_baseline", "speedup_vs_cpu_restatement")
             legs[name] = {k: out[k] for k in keep if k in out}

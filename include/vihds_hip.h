@@ -305,6 +305,28 @@ int vihds_theta_ode_logp_grad(const vihds_ode_problem* p, int P, const int* kind
                               const float* times, const float* obs, float* theta, float* log_q, float* log_p,
                               float* logp, float* g_theta_unit, void* stream);
 
+/* The sampling stage as a prologue of the ODE FORWARD launch (ABI 13), for every model whose forward kernels own a
+ * contiguous run of trajectories per block -- the lane-split kernels of relay / degrader / prpr / auto_constant and their
+ * _precisions forms, dr_blackbox's cooperating wavefronts: vihds_theta_fwd (+ dr_blackbox's condition_theta, the offset
+ * layer of models/dr_blackbox.py:86-96, as vihds_offset_rows_fwd) + vihds_ode_fwd in ONE launch, each block sampling its own
+ * trajectories' parameters.  Same outputs as the separate calls: theta [n_rows][B][S] (rows dst_row.. of the offset layer
+ * included), u (written when opts->rng draws it), log_q, log_p, traj, xpred (may be NULL), logp.
+ * The in-kernel generator's step counter (opts->rng[2]) is READ, not advanced: the launch that follows in a training step
+ * advances it (vihds_step_tail_args.rng_advance), or vihds_rng_advance.  VIHDS_E_UNSUPPORTED for any other model / kernel
+ * variant / shape: use the separate calls. */
+typedef struct vihds_offset_layer {
+  int n, src_row, dst_row; /* theta[dst_row + k] = theta[src_row + k] + W[k][.] . dev1hot[b][.] + bias[k], k < n */
+  const float* W;          /* [n][D] */
+  const float* bias;       /* [n] */
+} vihds_offset_layer;
+int vihds_theta_ode_fwd(const vihds_ode_problem* p, int P, const int* kind, const float* q_mu, const float* q_prec,
+                        const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi, float* u,
+                        const vihds_theta_opts* opts, const vihds_offset_layer* offset /* or NULL */, const float* cond,
+                        const float* dev1hot, const float* times, const float* obs, const float* weights, float* theta,
+                        float* log_q, float* log_p, float* traj, float* xpred, float* logp, void* stream);
+/* rng[2] += 1 (one thread): the step of an in-kernel generator state {seed lo, seed hi, step, ticket} */
+int vihds_rng_advance(unsigned int* rng, void* stream);
+
 /* IWAE reduction (vihds/training.py:135-149):  log_w = sum_j logp[j] + log_p - log_q;  per row b:
  * row_max[b] = max_s log_w, row_sumexp[b] = sum_s exp(log_w - row_max[b]).  The host finishes
  * lse = row_max + log(row_sumexp) (after the cross-rank combine when S is sharded) and the mean over B. */
@@ -571,6 +593,12 @@ typedef struct vihds_step_tail_args {
   float *off_w, *off_b, *off_gw, *off_gb;
   int off_mv_w, off_mv_b;
   float* off_rowsum;
+  /* phase: 0 = both launches (rows, then update); 1 = the rows launch only; 2 = the update launch only -- so that work the
+   * update depends on but the rows launch does not (dr_blackbox's weight-gradient reductions) can run beside the rows launch on
+   * another stream, and join before the update */
+  int phase;
+  /* NULL, or the in-kernel generator state whose step the rows launch advances (vihds_theta_ode_fwd left it to its successor) */
+  unsigned int* rng_advance;
 } vihds_step_tail_args;
 int vihds_step_tail(const vihds_encoder_shape* s, const vihds_step_tail_args* a, void* stream);
 int vihds_step_tail_supported(const vihds_encoder_shape* s, int P, int S); /* 1 / 0: shapes vihds_step_tail takes (LDS budget,

@@ -480,7 +480,10 @@ def main():
         return
     if not a.only or "trace" in a.only:
         for name, spec, solver, S, epochs in [("trace_dr_constant_icml_modeuler", "dr_constant_icml", "modeuler", 20, 4),
-                                              ("trace_auto_constant_modeuler", "auto_constant", "modeuler", 20, 6)]:
+                                              ("trace_auto_constant_modeuler", "auto_constant", "modeuler", 20, 6),
+                                              # the headline's sample count at the spec's own learning rate, long enough to show
+                                              # what the objective does past the first epochs (round 5: 15 epochs = 105 steps)
+                                              ("trace_dr_constant_icml_s200_modeuler", "dr_constant_icml", "modeuler", 200, 15)]:
             if a.only and a.only not in name:
                 continue
             fx = run_training_trace(spec, solver, S, epochs, 0)

@@ -317,7 +317,8 @@ class _TraceDataset(torch.utils.data.Dataset):
                 "observations": self.observations[idx]}
 
 
-@pytest.mark.parametrize("name", ["trace_dr_constant_icml_modeuler", "trace_auto_constant_modeuler"])
+@pytest.mark.parametrize("name", ["trace_dr_constant_icml_modeuler", "trace_auto_constant_modeuler",
+                                  "trace_dr_constant_icml_s200_modeuler"])
 def test_training_run_tracks_reference_trace(name, tmp_path, monkeypatch):
     """Drop-in check of the whole loop: Training.run() driven through the same seeds as the reference's
     run_on_split (same CV split, DataLoader shuffles, host-numpy u, CPU-drawn conditioner weights, Adam,

@@ -178,3 +178,55 @@ def test_evaluation_summaries_with_the_time_parallel_kernels(name, lazy):
     for k in ("iw_predict_mu", "iw_predict_std", "iw_states", "iw_variance"):
         x, y = torch.as_tensor(getattr(a, k)), torch.as_tensor(getattr(b, k))
         assert x.shape == y.shape and rel_err(y, x) < 1e-4, k
+
+
+@pytest.mark.parametrize("rng", ["numpy", "kernel"])
+@pytest.mark.parametrize("name", ["relay_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
+                                  "prpr_constant_tiny_modeuler", "degrader_constant_precisions_tiny_modeuler"])
+def test_sampling_stage_inside_the_forward_launch(name, rng):
+    """vihds_theta_ode_fwd (params.fused_theta_ode, default): theta = clip(sample(q, u)), log q, log p -- and dr_blackbox's
+    condition_theta -- as a prologue of the ODE forward launch, against the separate vihds_theta_fwd [+ vihds_offset_rows_fwd] +
+    vihds_ode_fwd launches: three steps each (the fused forward serves from the second step on), same draws -- the host's
+    numpy stream, or the in-kernel generator whose step the tail now advances: losses, gradients, parameters."""
+    fx = Fixture(name)
+    over = {} if rng == "numpy" else {"u_rng": "kernel", "conditioner_rng": "kernel"}
+    ref = _one_step(fx, True, 3, fused_theta_ode=False, **over)
+    got = _one_step(fx, True, 3, fused_theta_ode=True, **over)
+    assert "ode_fwd" in got[4] and got[3]._gtail_ok is True
+    node_names = []
+    for a, b in zip(ref[0], got[0]):
+        assert abs(a - b) <= 1e-5 * max(1.0, abs(a)), (ref[0], got[0])
+    if rng == "kernel":  # three different draws: the generator's step moved every step
+        assert len({round(v, 3) for v in got[0]}) == 3, got[0]
+    for k, g in ref[1].items():
+        assert rel_err(got[1][k], g) < 2e-4, k
+    for k, v in ref[2].items():
+        assert rel_err(got[2][k], v) < 1e-4, k
+
+
+def test_fused_forward_node_differentiates_through_autograd_too():
+    """ops.ThetaOdeFused's own backward (a caller that runs loss.backward() on the fused forward's outputs): replays the unfused
+    ops on the saved draws -- gradients of q's tables and the network weights against the unfused autograd path."""
+    from vihds import ops
+
+    fx = Fixture("relay_constant_precisions_tiny_modeuler")
+    args, settings, model, training, batch = _build(fx, False)
+    outs = []
+    for fused in (False, True):
+        np.random.seed(3)
+        torch.manual_seed(3)
+        model.zero_grad(set_to_none=True)
+        model._fuse_theta_ode = fused
+        try:
+            results, theta, q, p = model(batch, args.train_samples)
+        finally:
+            model._fuse_theta_ode = False
+        node = results.solution.logp_buffer.grad_fn
+        assert (type(node).__name__ == "ThetaOdeFusedBackward") == fused
+        loss = training.cost(batch, results, theta, q, p).elbo
+        loss.backward()
+        outs.append((float(loss), {k: v.grad.detach().clone() for k, v in model.named_parameters() if v.grad is not None}))
+    assert abs(outs[0][0] - outs[1][0]) <= 1e-6 * abs(outs[0][0])
+    assert set(outs[0][1]) == set(outs[1][1])
+    for k, g in outs[0][1].items():
+        assert rel_err(outs[1][1][k], g) < 1e-5, k

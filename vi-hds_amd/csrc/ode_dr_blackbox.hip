@@ -3,15 +3,29 @@
 #include "vihds_ode_kernels.hpp"
 #include "vihds_blackbox_split.hpp"
 
+// Compiled TWICE (csrc/Makefile): VIHDS_BB_PART 1 = the forward launch of the cooperating-wavefront kernels alone, built
+// with -fno-slp-vectorize (its VALU stream is faster unpacked: 99.0 -> 94.4 us at config 4); everything else -- the adjoint,
+// which is faster with LLVM's packed fp32 (213.8 vs 226.6 us), the other variants, the tables -- as part 2 without the flag.
 namespace vihds {
 using BB = Blackbox<2, 25, 20, 5, 5, 2>;
+#if defined(VIHDS_BB_PART) && VIHDS_BB_PART == 1
+int launch_dr_blackbox_split_fwd(int solver, const OdeArgs& a, hipStream_t st) {
+  return launch_bb_split_dir<BbMfma, false>(solver, a, st, g_theta_stage);
+}
+}  // namespace vihds
+#else
+int launch_dr_blackbox_split_fwd(int solver, const OdeArgs& a, hipStream_t st);
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   // kernel_variant 1 = VALU, one thread per trajectory (vihds_blackbox.hpp); otherwise the MFMA formulation
+  // (vihds_theta_ode_fwd: the sampling stage exists in the cooperating-wavefront forward only)
+  if (g_theta_stage && (backward || a.kernel_variant == 1 || a.kernel_variant == 4 || solver_is_adaptive(solver) || g_adaptive_ctl))
+    return VIHDS_E_UNSUPPORTED;
   if (a.kernel_variant == 1 || solver_is_adaptive(solver) || g_adaptive_ctl) return launch_ode<BB>(backward, solver, a, st);
   // kernel_variant 4: one wavefront per 16 trajectories, the adjoint dumping every evaluation (vihds_blackbox_mfma.hpp);
   // otherwise the two networks on two wavefronts and the Gram tiles on two more (vihds_blackbox_split.hpp)
   if (a.kernel_variant == 4) return launch_bb_mfma(backward, solver, a, st);
-  return launch_bb_split<BbMfma>(backward, solver, a, st);
+  if (!backward) return launch_dr_blackbox_split_fwd(solver, a, st);
+  return launch_bb_split_dir<BbMfma, true>(solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }
 int n_states_dr_blackbox() { return BB::N; }
@@ -37,6 +51,7 @@ int bb_check(int L, int HS, int HP, int n_const, int C, int D) {
 }
 int bb_dump_fields() { return BB::NF; }
 }  // namespace vihds
+#endif  // VIHDS_BB_PART
 #ifdef VIHDS_BB_STAMPS
 extern "C" int vihds_debug_bb_stamps(unsigned long long* buf) {
   return (int)hipMemcpyToSymbol(HIP_SYMBOL(vihds::vihds_bb_stamp_buf), &buf, sizeof(buf));

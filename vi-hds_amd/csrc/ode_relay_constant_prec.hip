@@ -8,6 +8,8 @@ namespace vihds {
 int launch_scan_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st);  // scan_relay_constant_prec.hip
 int launch_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   // kernel_variant 5: the time axis in parallel (vihds_relay_scan.hpp; trajectory / x_predict in the layout [B][S][N][T])
+  if (g_theta_stage && (g_adaptive_ctl || relay_scan_applicable(a.T, solver, a.kernel_variant, a.n_hidden_prec)))
+    return VIHDS_E_UNSUPPORTED;  // (vihds_theta_ode_fwd: the sampling stage exists in the lane-split kernels only)
   if (!g_adaptive_ctl && relay_scan_applicable(a.T, solver, a.kernel_variant, a.n_hidden_prec))
     return launch_scan_relay_constant_prec(backward, solver, a, st);
   // below 16 384 trajectories: sixteen lanes per trajectory (vihds_relay_lanes.hpp); the adaptive controller, a hidden
@@ -15,7 +17,8 @@ int launch_relay_constant_prec(bool backward, int solver, const OdeArgs& a, hipS
   // network's weight gradients brings the small per-block buffer of vihds_ode_bwd_aux_floats in `aux`.)
   if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&
       !(backward && true && a.g_weights && !a.aux))
-    return relay_lanes_launch<RlRelay, true>(backward, solver, a, st);
+    return relay_lanes_launch<RlRelay, true>(backward, solver, a, st, g_theta_stage);
+  if (g_theta_stage) return VIHDS_E_UNSUPPORTED;
   return launch_ode<WithPrec<RelayConstant>>(backward, solver, a, st);
 }
 int n_slots_relay_constant_prec() { return WithPrec<RelayConstant>::NSLOT; }

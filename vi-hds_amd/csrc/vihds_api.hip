@@ -21,6 +21,7 @@
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
 thread_local AdaptiveDevCtl* g_adaptive_dev = nullptr;
+thread_local const ThetaStageArgs* g_theta_stage = nullptr;
 // per-model translation units (ode_<model>.hip)
 #define VIHDS_DECL(name)                                                        \
   int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
@@ -72,6 +73,7 @@ void launch_iwae_combine(int, int, int, float, const float*, const float*, float
 void launch_iwae_loss_bwd(int, int, const float*, const float*, const float*, float*, float*, hipStream_t);
 void launch_device_condition(int, int, int, int, int, int, float, float, const float*, unsigned int*, const float*, const float*, const int*,
                              float*, hipStream_t);
+void launch_rng_advance(unsigned int* rng, hipStream_t st);
 // vihds_offset.hip
 void launch_gather_batch(int, int, int, int, int, int, const long long*, const float*, const float*, const float*, float*, float*,
                          float*, float*, hipStream_t);
@@ -603,6 +605,62 @@ int vihds_ode_bwd(const vihds_ode_problem* p, const float* theta, const float* c
   rc = sized ? sized->launch(true, p->solver, a, (hipStream_t)stream, nullptr) : e->launch(true, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_bwd launch");
+}
+
+int vihds_rng_advance(unsigned int* rng, void* stream) {
+  if (!rng) return fail(VIHDS_E_BADARG, "null rng");
+  launch_rng_advance(rng, (hipStream_t)stream);
+  return check_hip("vihds_rng_advance launch");
+}
+
+int vihds_theta_ode_fwd(const vihds_ode_problem* p, int P, const int* kind, const float* q_mu, const float* q_prec,
+                        const float* p_mu, const float* p_prec, const float* clip_lo, const float* clip_hi, float* u,
+                        const vihds_theta_opts* opts, const vihds_offset_layer* offset, const float* cond, const float* dev1hot,
+                        const float* times, const float* obs, const float* weights, float* theta, float* log_q, float* log_p,
+                        float* traj, float* xpred, float* logp, void* stream) {
+  if (!p || !kind || !q_mu || !q_prec || !p_mu || !p_prec || !clip_lo || !clip_hi || !u || !times || !theta)
+    return fail(VIHDS_E_BADARG, "null argument");
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  const bool lane_family = p->model == VIHDS_MODEL_AUTO_CONSTANT || p->model == VIHDS_MODEL_PRPR_CONSTANT ||
+                           p->model == VIHDS_MODEL_RELAY_CONSTANT || p->model == VIHDS_MODEL_DEGRADER_CONSTANT ||
+                           lane_model_species(p->model) > 0;
+  if (!lane_family && !(p->model == VIHDS_MODEL_DR_BLACKBOX && bb_builtin(p)))
+    return fail(VIHDS_E_UNSUPPORTED, "vihds_theta_ode_fwd: no sampling stage in this model's forward kernels");
+  if (logp && !obs) return fail(VIHDS_E_BADARG, "logp requested without obs");
+  if (P <= 0 || P > p->n_rows) return fail(VIHDS_E_BADARG, "P out of range");
+  if (e->neural_prec && !weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX && (!dev1hot || (p->C > 0 && !cond))) return fail(VIHDS_E_BADARG, "dr_blackbox needs cond and dev1hot");
+  OdeArgs a;
+  int rc = build_args(p, e, a, nullptr);
+  if (rc) return rc;
+  if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
+  const vihds_theta_opts o = theta_opts(opts);
+  ThetaStageArgs t;
+  std::memset(&t, 0, sizeof(t));
+  t.P = P; t.kind = kind; t.q_mu = q_mu; t.q_prec = q_prec; t.q_rows = o.q_rows; t.prec_is_log = o.q_prec_is_log;
+  t.p_mu = p_mu; t.p_prec = p_prec; t.clip_lo = clip_lo; t.clip_hi = clip_hi; t.u = u; t.rng = o.rng;
+  t.S_total = p->S; t.s_off = 0;
+  if (o.S_total > 0) {
+    if (o.s_offset < 0 || o.s_offset + p->S > o.S_total) return fail(VIHDS_E_BADARG, "bad sample window");
+    t.S_total = o.S_total; t.s_off = o.s_offset;
+  }
+  t.theta = theta; t.n_rows = p->n_rows; t.log_q = log_q; t.log_p = log_p;
+  if (offset && offset->n > 0) {
+    if (!offset->W || !offset->bias || !dev1hot || p->D <= 0 || offset->src_row < 0 || offset->src_row + offset->n > P ||
+        offset->dst_row < P || offset->dst_row + offset->n > p->n_rows)
+      return fail(VIHDS_E_BADARG, "bad offset layer");
+    t.off_n = offset->n; t.off_src = offset->src_row; t.off_dst = offset->dst_row; t.off_w = offset->W; t.off_b = offset->bias;
+  }
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = obs; a.weights = weights;
+  a.traj = traj; a.xpred = xpred; a.logp = logp;
+  g_theta_stage = &t;
+  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+  g_theta_stage = nullptr;
+  if (rc == VIHDS_E_UNSUPPORTED)
+    return fail(rc, "vihds_theta_ode_fwd: kernel variant / solver / shape outside the kernels that carry the sampling stage");
+  if (rc) return fail(rc, "unknown solver");
+  return check_hip("vihds_theta_ode_fwd launch");
 }
 
 /* vihds_ode_bwd with the log-likelihood gradient formed in the kernel: g_logp[j][b][s] = -(1/B) softmax_s(log_w[b][.]) for the

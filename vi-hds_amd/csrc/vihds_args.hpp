@@ -61,6 +61,10 @@ struct ThetaStageArgs {
   unsigned int* crng;
   const float* rel;
   const int* is_default;
+  // dr_blackbox's condition_theta inside the stage (vihds_theta_stage.hpp; off_n = 0: none):
+  // theta[off_dst + k] = theta[off_src + k] + off_w[k][.] . dev1hot[b][.] + off_b[k]
+  int off_n, off_src, off_dst;
+  const float *off_w, *off_b;
 };
 
 }  // namespace vihds

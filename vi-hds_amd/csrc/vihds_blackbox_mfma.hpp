@@ -29,6 +29,7 @@
 #include "vihds_blackbox.hpp"
 #include "vihds_models.hpp"
 #include "vihds_iwae_inline.hpp"
+#include "vihds_theta_stage.hpp"
 
 namespace vihds {
 

@@ -203,8 +203,13 @@ struct BbSplitT {
 };
 
 // grid: one block of two wavefronts per 16 trajectories
-template <class K, int SOLVER>
-__global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
+template <class K, int SOLVER, bool THETA>
+__device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaStageArgs* ts, int nb_max) {
+  // THETA: the sampling stage and condition_theta first, for the block's sixteen trajectories (vihds_theta_ode_fwd)
+  if constexpr (THETA) {
+    extern __shared__ float bb_theta_scratch[];
+    theta_stage_block<128>(a, *ts, blockIdx.x * K::TPW, K::TPW, nb_max, bb_theta_scratch);
+  }
   using S = BbSplitT<K>;
   __shared__ float pub[S::LDS_FWD];
   const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
@@ -265,6 +270,14 @@ __global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
     }
     if (a.logp && live) a.logp[(size_t)q * n + i] = lp;
   }
+}
+template <class K, int SOLVER>
+__global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
+  bb_split_fwd_body<K, SOLVER, false>(a, nullptr, 0);
+}
+template <class K, int SOLVER>
+__global__ void __launch_bounds__(128) bb_split_theta_fwd_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
+  bb_split_fwd_body<K, SOLVER, true>(a, &t, nb_max);
 }
 
 // ======================================================================================================================
@@ -672,6 +685,45 @@ inline int launch_bb_split_solver(bool backward, const OdeArgs& a, hipStream_t s
   if (backward) hipLaunchKernelGGL((bb_split_bwd_kernel<K, SV>), grid, dim3(256), 0, st, a);
   else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(128), 0, st, a);
   return VIHDS_OK;
+}
+// ... with the direction a compile-time choice: a translation unit that only launches forwards holds no adjoint kernel (the
+// built-in ICML sizes compile the two directions with different flags: csrc/Makefile, -fno-slp-vectorize)
+template <class K, bool BACKWARD>
+inline int launch_bb_split_dir(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
+  const dim3 grid(K::gram_groups(a.n));
+  if (ts) {  // forward with the sampling stage and condition_theta in front (vihds_theta_ode_fwd)
+    if constexpr (BACKWARD) return VIHDS_E_UNSUPPORTED;
+    else {
+      const int nb_max = min(a.B, (K::TPW - 1) / a.S + 2);
+      const size_t lds = sizeof(float) * theta_stage_lds_floats(nb_max, ts->P, K::TPW);
+      if (lds > 48 * 1024) return VIHDS_E_UNSUPPORTED;
+#define VIHDS_BB_TH(SV)                                                                                                  \
+  case SV: hipLaunchKernelGGL((bb_split_theta_fwd_kernel<K, SV>), grid, dim3(128), lds, st, a, nb_max, *ts); return VIHDS_OK;
+      switch (solver) {
+        VIHDS_BB_TH(VIHDS_SOLVER_MODEULER)
+        VIHDS_BB_TH(VIHDS_SOLVER_MODEULERWHILE)
+        VIHDS_BB_TH(VIHDS_SOLVER_EULER)
+        VIHDS_BB_TH(VIHDS_SOLVER_MIDPOINT)
+        VIHDS_BB_TH(VIHDS_SOLVER_RK4)
+      }
+#undef VIHDS_BB_TH
+      return VIHDS_E_BADARG;
+    }
+  }
+#define VIHDS_BB_DIR(SV)                                                                                   \
+  case SV:                                                                                                 \
+    if constexpr (BACKWARD) hipLaunchKernelGGL((bb_split_bwd_kernel<K, SV>), grid, dim3(256), 0, st, a);   \
+    else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(128), 0, st, a);                      \
+    return VIHDS_OK;
+  switch (solver) {
+    VIHDS_BB_DIR(VIHDS_SOLVER_MODEULER)
+    VIHDS_BB_DIR(VIHDS_SOLVER_MODEULERWHILE)
+    VIHDS_BB_DIR(VIHDS_SOLVER_EULER)
+    VIHDS_BB_DIR(VIHDS_SOLVER_MIDPOINT)
+    VIHDS_BB_DIR(VIHDS_SOLVER_RK4)
+  }
+#undef VIHDS_BB_DIR
+  return VIHDS_E_BADARG;
 }
 template <class K>
 inline int launch_bb_split(bool backward, int solver, const OdeArgs& a, hipStream_t st) {

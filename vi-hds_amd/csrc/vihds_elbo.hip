@@ -250,6 +250,8 @@ theta_fwd_lds_kernel(int P, int B, int S, int nb_max, const int* __restrict__ ki
 }
 // the step of a generator state {seed lo, seed hi, step, ticket}, moved by a launch of its own behind a grid too large
 // to take tickets
+__global__ void rng_advance_kernel(unsigned int* rng);
+void launch_rng_advance(unsigned int* rng, hipStream_t st) { hipLaunchKernelGGL(rng_advance_kernel, dim3(1), dim3(1), 0, st, rng); }
 __global__ void rng_advance_kernel(unsigned int* rng) {
   rng[2] = rng[2] + 1u;
   rng[3] = 0u;

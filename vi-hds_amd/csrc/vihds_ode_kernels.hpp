@@ -514,6 +514,9 @@ struct AdaptiveCtl {
   int result;
 };
 extern thread_local AdaptiveCtl* g_adaptive_ctl;
+// vihds_theta_ode_fwd: the sampling stage to run in front of the forward launch (NULL: none); a launch function whose kernels
+// have no such stage returns VIHDS_E_UNSUPPORTED when it is set
+extern thread_local const ThetaStageArgs* g_theta_stage;
 template <class M, int ONLY>
 inline int adaptive_grid(int solver, const OdeArgs& a, const float* times_host, float rtol, float atol, float* workspace,
                          float* grid_host, int max_grid, int* index_host, hipStream_t st);

@@ -34,6 +34,7 @@
 #include "vihds_args.hpp"
 #include "vihds_models.hpp"
 #include "vihds_iwae_inline.hpp"
+#include "vihds_theta_stage.hpp"
 
 namespace vihds {
 
@@ -506,9 +507,10 @@ __device__ __forceinline__ void rl_setup(const OdeArgs& a, int i, int b, int l, 
 }
 
 // ---- forward -------------------------------------------------------------------------------------------------------
-// dynamic LDS: times [T] | sigma table [RL_TR][(T - 1) stages] | obs rows [nb][4][T]
-template <class LM, bool PREC, int SOLVER>
-__global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a, int sig_tab) {
+// dynamic LDS: times [T] | sigma table [RL_TR][(T - 1) stages] | obs rows [nb][4][T] | (THETA) the sampling stage's scratch
+// THETA: the sampling stage (vihds_theta_stage.hpp) runs first, for the block's sixteen trajectories (vihds_theta_ode_fwd)
+template <class LM, bool PREC, int SOLVER, bool THETA>
+__device__ __forceinline__ void relay_lane_fwd_body(const OdeArgs& a, int sig_tab, const ThetaStageArgs* ts, int nb_max) {
   using M = typename LM::M;
   using Tab = RlTab<SOLVER>;
   constexpr int NSP = LM::NSP, N = PREC ? NSP + 4 : NSP;
@@ -529,6 +531,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a, int sig
     const float* src = a.obs + (size_t)b0 * 4 * a.T;
     for (int q = tid; q < nb * 4 * a.T; q += RL_T) in_lds[o_obs + q] = src[q];
   }
+  if constexpr (THETA) theta_stage_block<RL_T>(a, *ts, first, RL_TR, nb_max, in_lds + o_obs + nb_max * 4 * a.T);
   RlLane c;
   float th[M::NSLOT], cc[LM::NCOND > 0 ? LM::NCOND : 1], p[M::NP], y, pconst[4];
   rl_setup<LM, PREC>(a, i, b, l, c, th, cc, p, y, pconst);
@@ -600,6 +603,14 @@ __global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a, int sig
     observe(a.T - 1);
   }
   if (a.logp && live && l < 4) a.logp[(size_t)j * n + i] = lp;
+}
+template <class LM, bool PREC, int SOLVER>
+__global__ void __launch_bounds__(RL_T) relay_lane_fwd_kernel(OdeArgs a, int sig_tab) {
+  relay_lane_fwd_body<LM, PREC, SOLVER, false>(a, sig_tab, nullptr, 0);
+}
+template <class LM, bool PREC, int SOLVER>
+__global__ void __launch_bounds__(RL_T) relay_lane_theta_fwd_kernel(OdeArgs a, int sig_tab, int nb_max, ThetaStageArgs t) {
+  relay_lane_fwd_body<LM, PREC, SOLVER, true>(a, sig_tab, &t, nb_max);
 }
 
 // ---- adjoint -------------------------------------------------------------------------------------------------------
@@ -838,7 +849,7 @@ static __global__ void __launch_bounds__(256) relay_lane_wreduce_kernel(const fl
 
 // ---- launch ---------------------------------------------------------------------------------------------------------
 template <class LM, bool PREC, int SOLVER>
-inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st) {
+inline int relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
   const int nblk = (a.n + RL_TR - 1) / RL_TR;
   const int nb_max = min(a.B, (RL_TR - 1) / a.S + 2);
   const size_t lds_in = sizeof(float) * ((size_t)a.T + (size_t)nb_max * 4 * a.T);
@@ -846,6 +857,12 @@ inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st
   const int sig_tab = lds_in + lds_sg <= 48 * 1024 ? 1 : 0;  // (beyond that the stage sigmoids are evaluated in place)
   const size_t lds = lds_in + (sig_tab ? lds_sg : 0);
   constexpr int NIN = 1 + LM::NSP;
+  if (ts) {  // forward with the sampling stage in front (vihds_theta_ode_fwd)
+    const size_t lds_t = lds + sizeof(float) * theta_stage_lds_floats(nb_max, ts->P, RL_TR);
+    if (backward || lds_t > 60 * 1024) return VIHDS_E_UNSUPPORTED;
+    hipLaunchKernelGGL((relay_lane_theta_fwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds_t, st, a, sig_tab, nb_max, *ts);
+    return VIHDS_OK;
+  }
   if (!backward) {
     hipLaunchKernelGGL((relay_lane_fwd_kernel<LM, PREC, SOLVER>), dim3(nblk), dim3(RL_T), lds, st, a, sig_tab);
   } else {
@@ -853,15 +870,16 @@ inline void relay_lanes_launch_s(bool backward, const OdeArgs& a, hipStream_t st
     if (PREC && a.g_weights && a.aux)
       hipLaunchKernelGGL(relay_lane_wreduce_kernel, dim3((rl_nwg(NIN) + 3) / 4), dim3(256), 0, st, a.aux, nblk, a.g_weights, NIN);
   }
+  return VIHDS_OK;
 }
 template <class LM, bool PREC>
-inline int relay_lanes_launch(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+inline int relay_lanes_launch(bool backward, int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
   switch (solver) {
-    case VIHDS_SOLVER_MODEULER: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULER>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_MODEULERWHILE: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_EULER: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_EULER>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_MIDPOINT: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MIDPOINT>(backward, a, st); return VIHDS_OK;
-    case VIHDS_SOLVER_RK4: relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_RK4>(backward, a, st); return VIHDS_OK;
+    case VIHDS_SOLVER_MODEULER: return relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULER>(backward, a, st, ts);
+    case VIHDS_SOLVER_MODEULERWHILE: return relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MODEULERWHILE>(backward, a, st, ts);
+    case VIHDS_SOLVER_EULER: return relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_EULER>(backward, a, st, ts);
+    case VIHDS_SOLVER_MIDPOINT: return relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_MIDPOINT>(backward, a, st, ts);
+    case VIHDS_SOLVER_RK4: return relay_lanes_launch_s<LM, PREC, VIHDS_SOLVER_RK4>(backward, a, st, ts);
   }
   return VIHDS_E_BADARG;
 }

@@ -205,6 +205,7 @@ step_tail_rows_kernel(vihds_encoder_shape s, vihds_step_tail_args a) {
     fill_ctab(p, a.kind[p], rmp, rpp, a.q_all[(size_t)rmp * B + b], a.q_all[(size_t)rpp * B + b], a.p_mu[p], a.p_prec[p],
               a.clip_lo[p], a.clip_hi[p]);
   }
+  if (a.rng_advance && b == 0 && part == 0 && tid == ROWS_T - 2) a.rng_advance[2] = a.rng_advance[2] + 1u;
   if (adam_thread) {
     const float t = adam_t + 1.f;
     a.state[0] = t;
@@ -817,7 +818,8 @@ void launch_step_tail(const vihds_encoder_shape& s, const vihds_step_tail_args& 
   const int rest = a.P + a.off_n - s.nl;  // tasks without a path into the encoder's hidden layer: one wavefront each
   const dim3 grid(s.B, 1 + (rest > 0 ? (rest + ROWS_NW - 1) / ROWS_NW : 0));
 #define VIHDS_TAIL_ROWS(UL, HM) hipLaunchKernelGGL((step_tail_rows_kernel<UL, HM>), grid, dim3(ROWS_T), lds, st, s, a)
-  if (u_lds) {
+  if (a.phase == 2) {
+  } else if (u_lds) {
     if (s.H <= 32) VIHDS_TAIL_ROWS(true, 32);
     else if (s.H <= 52) VIHDS_TAIL_ROWS(true, 52);
     else VIHDS_TAIL_ROWS(true, 64);
@@ -827,6 +829,7 @@ void launch_step_tail(const vihds_encoder_shape& s, const vihds_step_tail_args& 
     else VIHDS_TAIL_ROWS(false, 64);
   }
 #undef VIHDS_TAIL_ROWS
+  if (a.phase == 1) return;
   TailTasks tk;
   tk.nb_lin = (s.H * d.NPOOL + UPD_T - 1) / UPD_T;
   tk.nb_conv = s.F * s.C_in;

@@ -1,17 +1,11 @@
 """Model registry: the same string keys as the reference's models/__init__.py:19-35, so `model:` in a spec
-YAML selects the same model.  Keys the HIP library does not implement raise at construction with a clear
-message.  debug_constant, inducer_*, relay_* and degrader_* cannot run in the reference itself (they raise at
-construction / call); they are restated from the reference's equations and labelled "parity unpinned"."""
+YAML selects the same model; every key maps to a kernel model.  debug_constant, inducer_*, relay_* and degrader_* cannot run
+in the reference itself (its classes raise at construction / call).  relay / degrader / inducer / prpr
+`_precisions` -- the only specs of those models the reference ships -- are pinned against the MODIFIED reference (the two
+construction defects repaired in memory, tests/golden/make_fixtures.py --patched; tests/test_config5_parity.py,
+tests/test_general_tail.py); their constant-precision forms share that RHS code; debug_constant is unpinned."""
 from models import (auto_constant, debug, degrader_constant, dr_blackbox, dr_constant, inducer_constant, prpr_constant,
                     relay_constant)
-
-
-class _Unsupported(object):
-    def __init__(self, key, why):
-        self.key, self.why = key, why
-
-    def __call__(self, config):
-        raise NotImplementedError("model '%s' is not implemented by the HIP path: %s" % (self.key, self.why))
 
 
 LOOKUP = {

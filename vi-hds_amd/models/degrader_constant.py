@@ -1,6 +1,7 @@
 """Degrader models: the equations of the reference's models/degrader_constant.py (kernel: struct
-DegraderConstant).  As for relay, the reference classes raise at construction (degrader_constant.py:17), so
-parity is against our own restatement of the equations."""
+DegraderConstant).  As for relay, the reference classes raise at construction (degrader_constant.py:17);
+degrader_constant_precisions is pinned against the MODIFIED reference (construction defects repaired in memory,
+tests/golden/make_fixtures.py --patched; tests/test_config5_parity.py) and the oracle, degrader_constant shares its RHS code."""
 from vihds.ode import OdeModel
 from vihds.precisions import ConstantPrecisions, NeuralPrecisions
 from vihds.utils import variable_summaries

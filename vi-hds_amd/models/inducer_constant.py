@@ -2,8 +2,10 @@
 InducerConstant in csrc/vihds_models.hpp.
 
 The reference classes raise at construction (`init_with_params` does not exist on OdeModel, inducer_constant.py:85,
-:119), so there is no runnable reference: the equations are restated from Inducer_Constant_RHS (:11-80) and parity is
-labelled unpinned (tests compare against oracle/vihds_oracle.py make_inducer_constant)."""
+:119), so there is no runnable reference as shipped: the equations are restated from Inducer_Constant_RHS (:11-80).
+inducer_constant_precisions is pinned against the MODIFIED reference (those construction defects repaired in memory,
+tests/golden/make_fixtures.py --patched: inducer_constant_precisions_tiny_modeuler.npz) and the oracle; inducer_constant
+(constant precisions) shares its RHS code."""
 from vihds.ode import OdeModel
 from vihds.precisions import ConstantPrecisions, NeuralPrecisions
 

@@ -1,8 +1,11 @@
 """Relay models: the equations of the reference's models/relay_constant.py (kernel: struct RelayConstant).
 
 The reference classes cannot be constructed at this commit (relay_constant.py:17 passes five arguments to
-OdeFunc.__init__, :201 calls a non-existent init_with_params -- SURVEY.md 2.1), so parity for these models is
-against our own restatement of the reference's equations, never against reference output."""
+OdeFunc.__init__, :201 calls a non-existent init_with_params -- SURVEY.md 2.1).  Parity of relay_constant_precisions (the
+one relay spec the reference ships) is against the MODIFIED reference -- exactly those two construction defects repaired
+in memory, its own forward() untouched (tests/golden/make_fixtures.py --patched; tests/test_config5_parity.py: trajectories,
+precision states, log-likelihood, loss, every theta and network-weight gradient) -- and against the oracle; relay_constant
+(constant precisions, no spec in the reference) shares the same RHS code."""
 from vihds.ode import OdeModel
 from vihds.precisions import ConstantPrecisions, NeuralPrecisions
 from vihds.utils import variable_summaries

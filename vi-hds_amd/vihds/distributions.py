@@ -381,6 +381,20 @@ class ChainedDistribution(object):
             obs, dev1hot, cond_job)
         return self._wrap_samples(names, theta, log_q, log_p, p, u_used), logp
 
+    def theta_ode_fused(self, list_of_u, p, stddevs, n_extra_rows, spec_of, cond, times, obs, dev1hot, weights, offset):
+        """sample_clip_log_prob with the sampling stage INSIDE the ODE forward launch (ops.ThetaOdeFused): returns (theta
+        samples, traj [T,N,B,S], logp [4,B,S]); offset = None or (weight, bias, (src row, dst row, n)) of dr_blackbox's
+        condition_theta.  Raises ops.FusedTrainingUnsupported when the library declines."""
+        if self._packed_q is None:
+            raise ops.FusedTrainingUnsupported("needs the encoder's packed q tables")
+        names, P, p_mu, p_prec, lo, hi = self._kernel_inputs(list_of_u, p, stddevs)
+        kind, q_all, _ = self._packed_q
+        off_w, off_b, off_rows = offset if offset is not None else (None, None, None)
+        theta, log_q, log_p, u_used, traj, logp = ops.ThetaOdeFused.apply(
+            q_all, kind, p_mu, p_prec, lo, hi, list_of_u, P + n_extra_rows, self._q_rows, spec_of(names), cond, times, obs,
+            dev1hot, weights, off_w, off_b, off_rows)
+        return self._wrap_samples(names, theta, log_q, log_p, p, u_used), traj, logp
+
     # ---- reference-compatible entry points -------------------------------------------------------------
     def sample(self, list_of_u, device, stop_grad=False):
         """reference distributions.py:119-142 (no clipping); same kernel with infinite bounds."""

@@ -91,6 +91,13 @@ class Conditioner(ctypes.Structure):
                 ("is_default", ctypes.c_void_p)]
 
 
+class OffsetLayer(ctypes.Structure):
+    """struct vihds_offset_layer (include/vihds_hip.h)"""
+
+    _fields_ = [("n", ctypes.c_int), ("src_row", ctypes.c_int), ("dst_row", ctypes.c_int), ("W", ctypes.c_void_p),
+                ("bias", ctypes.c_void_p)]
+
+
 class EncoderShape(ctypes.Structure):
     """struct vihds_encoder_shape (include/vihds_hip.h)"""
 
@@ -143,7 +150,8 @@ class StepTailArgs(ctypes.Structure):
                 ("g_shift", ctypes.c_int), ("n_extra", ctypes.c_int), ("extra", TailTensor * TAIL_MAX_EXTRA),
                 ("off_n", ctypes.c_int), ("off_row0", ctypes.c_int), ("off_w", ctypes.c_void_p), ("off_b", ctypes.c_void_p),
                 ("off_gw", ctypes.c_void_p), ("off_gb", ctypes.c_void_p), ("off_mv_w", ctypes.c_int),
-                ("off_mv_b", ctypes.c_int), ("off_rowsum", ctypes.c_void_p)]
+                ("off_mv_b", ctypes.c_int), ("off_rowsum", ctypes.c_void_p), ("phase", ctypes.c_int),
+                ("rng_advance", ctypes.c_void_p)]
 
 
 _PROTOTYPES = {
@@ -165,6 +173,9 @@ _PROTOTYPES = {
     "vihds_theta_ode_logp_grad": (_I, [ctypes.POINTER(OdeProblem), _I] + [_P] * 8 + [ctypes.POINTER(ThetaOpts),
                                                                                      ctypes.POINTER(Conditioner)]
                                   + [_P] * 10),
+    "vihds_theta_ode_fwd": (_I, [ctypes.POINTER(OdeProblem), _I] + [_P] * 8 + [ctypes.POINTER(ThetaOpts), ctypes.POINTER(OffsetLayer)]
+                            + [_P] * 12),
+    "vihds_rng_advance": (_I, [_P, _P]),
     "vihds_ode_bwd_aux_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_bwd_reduces_weights": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_ode_traj_layout": (_I, [ctypes.POINTER(OdeProblem)]),

@@ -546,6 +546,92 @@ class DecoderStepFused(torch.autograd.Function):
         return (g_all,) + (None,) * 14
 
 
+class ThetaOdeFused(torch.autograd.Function):
+    """The sampling stage inside the ODE FORWARD launch (vihds_theta_ode_fwd): theta = clip(sample(q, u)) with log q / log p,
+    dr_blackbox's condition_theta (offset layer) and the trajectory + log-likelihood, one launch where ThetaSampleLogProbPacked
+    [+ OffsetRows] + OdeSolveObserve are two or three.  Training fast path of the models WITHOUT a fused decoder step; the
+    step's backward is ops.GeneralTail (which reads this node's saved tensors).  Returns (theta, log_q, log_p, u, traj, logp).
+    backward (a caller that runs autograd after all): the unfused ops are replayed on the saved draws and differentiated."""
+
+    @staticmethod
+    def forward(ctx, q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, n_rows, q_rows, spec, cond, times, obs, dev1hot, weights,
+                off_w, off_b, off_rows):
+        _require_cuda(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, q_rows, cond, times, obs)
+        q_all, cond, times, obs, dev1hot = _c(q_all), _c(cond), _c(times), _c(obs), _c(dev1hot)
+        P, B = q_all.shape[0] // 2, q_all.shape[1]
+        opts = hip.ThetaOpts()
+        opts.q_rows, opts.q_prec_is_log = hip.ptr(q_rows), 1
+        rng_state = None
+        if isinstance(u, KernelNormal):
+            rng, u = u, torch.empty(u.shape, device=q_all.device, dtype=torch.float32)
+            opts.rng, opts.S_total, opts.s_offset = rng.state.data_ptr(), rng.S_total, rng.s_offset
+            rng_state = rng.state
+        else:
+            _require_cuda(u)
+            u = _c(u)
+        S, T = u.shape[1], times.shape[0]
+        if n_rows != spec.n_rows:
+            raise RuntimeError("theta has %d rows, problem expects %d" % (n_rows, spec.n_rows))
+        prob = spec.bind(B, S, T)
+        if hip.lib().vihds_ode_traj_layout(ctypes.byref(prob)):
+            raise FusedTrainingUnsupported("time-fastest trajectory layout")
+        dev = q_all.device
+        theta = torch.empty((n_rows, B, S), device=dev, dtype=torch.float32)
+        log_q = torch.empty((B, S), device=dev, dtype=torch.float32)
+        log_p = torch.empty((B, S), device=dev, dtype=torch.float32)
+        traj = torch.empty((T, spec.n_states, B, S), device=dev, dtype=torch.float32)
+        logp = torch.empty((4, B, S), device=dev, dtype=torch.float32)
+        off = None
+        if off_rows is not None:
+            off = hip.OffsetLayer()
+            off.src_row, off.dst_row, off.n = off_rows
+            off.W, off.bias = hip.ptr(_c(off_w)), hip.ptr(_c(off_b))
+        rc = _launch("ode_fwd", lambda: hip.lib().vihds_theta_ode_fwd(
+            ctypes.byref(prob), P, hip.ptr(kind), hip.ptr(q_all), hip.ptr(q_all), hip.ptr(p_mu), hip.ptr(p_prec),
+            hip.ptr(clip_lo), hip.ptr(clip_hi), hip.ptr(u), ctypes.byref(opts), ctypes.byref(off) if off is not None else None,
+            hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs), hip.ptr(weights), hip.ptr(theta), hip.ptr(log_q),
+            hip.ptr(log_p), hip.ptr(traj), None, hip.ptr(logp), hip.current_stream()))
+        if rc == hip.E_UNSUPPORTED:
+            raise FusedTrainingUnsupported(hip.lib().vihds_last_error().decode())
+        hip.check(rc, "vihds_theta_ode_fwd")
+        ctx.spec, ctx.prob, ctx.time_fastest = spec, prob, False
+        ctx.row_offset_map = None if off_rows is None else (off_rows[0], off_rows[1], off_rows[2], "linear")
+        ctx.logp_out = logp.detach()
+        ctx.rng_state = rng_state  # (its step is advanced by the launch that follows: GeneralTail, or vihds_rng_advance)
+        ctx.n_rows = n_rows
+        ctx.save_for_backward(q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, theta, cond, times, obs, traj, dev1hot,
+                              weights, off_w, off_b)
+        ctx.set_materialize_grads(False)
+        ctx.mark_non_differentiable(u)
+        return theta, log_q, log_p, u, traj, logp
+
+    @staticmethod
+    def backward(ctx, g_theta, g_log_q, g_log_p, _g_u, g_traj, g_logp):
+        (q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, _theta, cond, times, obs, _traj, dev1hot, weights, off_w,
+         off_b) = ctx.saved_tensors
+        with torch.enable_grad():
+            q = q_all.detach().requires_grad_(True)
+            w = weights.detach().requires_grad_(True) if weights is not None else None
+            W = off_w.detach().requires_grad_(True) if off_w is not None else None
+            bvec = off_b.detach().requires_grad_(True) if off_b is not None else None
+            th, lq, lp, _u = ThetaSampleLogProbPacked.apply(q, kind, p_mu, p_prec, clip_lo, clip_hi, u, ctx.n_rows, q_rows)
+            token, rom = None, None
+            if ctx.row_offset_map is not None:
+                src, dst, n, _ = ctx.row_offset_map
+                token = OffsetRows.apply(W, bvec, dev1hot, th.detach(), src, dst)
+                rom = ctx.row_offset_map
+            tr, _xp, lg = OdeSolveObserve.apply(ctx.spec, th, cond, times, obs, dev1hot, w, token, rom, False)
+            outs, gouts = [], []
+            for o, g in ((th, g_theta), (lq, g_log_q), (lp, g_log_p), (tr, g_traj), (lg, g_logp)):
+                if g is not None:
+                    outs.append(o)
+                    gouts.append(g)
+            ins = [t for t in (q, w, W, bvec) if t is not None]
+            grads = dict(zip([id(t) for t in ins], torch.autograd.grad(outs, ins, gouts, allow_unused=True))) if outs else {}
+        g = lambda t: None if t is None else grads.get(id(t))  # noqa: E731
+        return (g(q), None, None, None, None, None, None, None, None, None, None, None, None, None, g(w), g(W), g(bvec), None)
+
+
 def neural_precision_weight_grads(spec, prob, aux, g_w):
     """White-box model + neural precisions: the two weight matrices of NeuralPrecisions (reference precisions.py:55-61,
     76-87; buffer order Wp [4][NIN], bp [4], Wd [4][NIN], bd [4]) from the adjoint kernel's dump [8+NIN][E][n] --
@@ -1182,6 +1268,7 @@ class GeneralTail(StepTail):
         self.offset = off if (off is not None and getattr(ode_model, "n_y", 0) > 0) else None
         self._bufs = {}
         self._maps = {}
+        self._sides = {}
         self.inkernel_iwae = True  # (False: vihds_iwae_loss_fwd + vihds_ode_bwd -- the same numbers, one launch more)
 
     def applicable(self):
@@ -1234,15 +1321,34 @@ class GeneralTail(StepTail):
             self._maps[key] = torch.tensor(m, dtype=torch.int32, device=dev)
         return self._maps[key]
 
-    def launch(self, theta_node, ode_node, enc_node, log_q, log_p, n_total, apply_adam=True):
-        """theta_node: ThetaSampleLogProbPacked's backward node, ode_node: OdeSolveObserve's, enc_node: EncoderQTables'
-        (their saved tensors are the step's forward state).  Returns the loss tensor (-ELBO), or None when the step is
-        outside this path's regime (time-fastest trajectory layout, an offset that is not the one-launch linear form)."""
-        q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows = theta_node.saved_tensors
-        theta, cond, times, obs, traj, dev1hot, weights = ode_node.saved_tensors
+    @staticmethod
+    def forward_state(theta_node, ode_node):
+        """The step's forward state as GeneralTail.launch takes it, from ThetaSampleLogProbPacked's and OdeSolveObserve's
+        backward nodes -- or from the one node of ThetaOdeFused (pass it twice)."""
+        if type(ode_node).__name__ == "ThetaOdeFusedBackward":
+            (q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows, theta, cond, times, obs, traj, dev1hot, weights, _ow,
+             _ob) = ode_node.saved_tensors
+            rng = ode_node.rng_state
+        else:
+            q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows = theta_node.saved_tensors
+            theta, cond, times, obs, traj, dev1hot, weights = ode_node.saved_tensors
+            rng = None
+        return {"q_all": q_all, "kind": kind, "p_mu": p_mu, "p_prec": p_prec, "clip_lo": clip_lo, "clip_hi": clip_hi, "u": u,
+                "q_rows": q_rows, "theta": theta, "cond": cond, "times": times, "obs": obs, "traj": traj, "dev1hot": dev1hot,
+                "weights": weights, "spec": ode_node.spec, "prob": ode_node.prob, "rom": ode_node.row_offset_map,
+                "time_fastest": ode_node.time_fastest, "logp": ode_node.logp_out, "rng_advance": rng}
+
+    def launch(self, fwd, enc_node, log_q, log_p, n_total, apply_adam=True):
+        """fwd: forward_state(...) of the step; enc_node: EncoderQTables' backward node.  Returns the loss tensor (-ELBO), or
+        None when the step is outside this path's regime (time-fastest trajectory layout, an offset that is not the
+        one-launch linear form)."""
+        q_all, kind, p_mu, p_prec, clip_lo, clip_hi, u, q_rows = (fwd[k] for k in ("q_all", "kind", "p_mu", "p_prec", "clip_lo",
+                                                                                   "clip_hi", "u", "q_rows"))
+        theta, cond, times, obs, traj, dev1hot, weights = (fwd[k] for k in ("theta", "cond", "times", "obs", "traj", "dev1hot",
+                                                                            "weights"))
         delta_obs, inputs, dev_1hot_e, _cw, lin_w, local_w, _lb, _gw, _gf, pooled, hidden = enc_node.saved_tensors
-        spec, prob, rom = ode_node.spec, ode_node.prob, ode_node.row_offset_map
-        if ode_node.time_fastest:
+        spec, prob, rom = fwd["spec"], fwd["prob"], fwd["rom"]
+        if fwd["time_fastest"]:
             return None
         s = enc_node.shape
         P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
@@ -1262,7 +1368,7 @@ class GeneralTail(StepTail):
         elif self.offset is not None:
             return None
         L = hip.lib()
-        logp = ode_node.logp_out
+        logp = fwd["logp"]
         # ---- work buffers: allocated once per shape OUTSIDE any capture (the warm-up steps come first) and reused
         key = (B, S, R, str(dev))
         capturing = torch.cuda.is_current_stream_capturing()
@@ -1323,6 +1429,7 @@ class GeneralTail(StepTail):
             hip.check(rc, "vihds_ode_bwd")
         extras = []  # (flat offset, size, grad_src tensor, src offset, map, nparts, stride)
         chunks = self._chunks_static()
+        side = None
         if weights is not None:
             if bf["lanes_reduce"]:
                 NIN = spec.n_species + 1
@@ -1331,10 +1438,17 @@ class GeneralTail(StepTail):
                 assert len(chunks) == 1
                 extras = [(0, chunks[0][3], aux, 0, self._lane_map(NIN, dev), nblk, nwg)]
             else:
-                if blackbox:
-                    gw = blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot)
-                else:
-                    gw = neural_precision_weight_grads(spec, prob, aux, g_w)
+                # the weight-gradient contraction / reductions (dr_blackbox: Gram-tile sums + the tail launch, ~19 us) feed
+                # only the tail's UPDATE launch: they run on a second stream beside the rows launch and join before the update
+                # (in a captured step: a parallel branch of the hipGraph)
+                main = torch.cuda.current_stream()
+                side = self._side_stream(dev)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    if blackbox:
+                        gw = blackbox_weight_grads(spec, prob, aux, theta, cond, dev1hot)
+                    else:
+                        gw = neural_precision_weight_grads(spec, prob, aux, g_w)
                 extras = [(fo, size, gw, fo, None, 1, 0) for (_f, _c2, fo, size) in chunks]
         # ---- the tail
         opt = self.optimizer
@@ -1371,6 +1485,7 @@ class GeneralTail(StepTail):
             grads.append((t, view))
             a.param[k], a.grad[k], a.mv_offset[k] = t.data_ptr(), view.data_ptr(), offsets[id(t)]
         a.g_theta_weighted = 1
+        a.rng_advance = hip.ptr(fwd["rng_advance"])  # (ThetaOdeFused read the generator's step and left the increment to us)
         a.g_shift_lo, a.g_shift_n, a.g_shift = shift
         flat0 = weights.data_ptr() if weights is not None else 0
         a.n_extra = len(extras)
@@ -1406,11 +1521,29 @@ class GeneralTail(StepTail):
         a.lr = 0.0 if isinstance(lr, torch.Tensor) else float(lr)
         a.beta1, a.beta2 = group["betas"]
         a.eps = group["eps"]
-        rc = _launch("step_tail", lambda: L.vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream()))
-        hip.check(rc, "vihds_step_tail")
+        if side is None:
+            rc = _launch("step_tail", lambda: L.vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream()))
+            hip.check(rc, "vihds_step_tail")
+        else:
+            a.phase = 1
+            rc = _launch("step_tail", lambda: L.vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream()))
+            hip.check(rc, "vihds_step_tail (rows)")
+            torch.cuda.current_stream().wait_stream(side)
+            # (the gradient buffers were allocated on the side stream and are read on this one: they are kept until the next
+            # step's side-stream work -- which waits for this stream first -- could be handed their memory again)
+            self._keep_alive = keep
+            a.phase = 2
+            rc = L.vihds_step_tail(ctypes.byref(s), ctypes.byref(a), hip.current_stream())
+            hip.check(rc, "vihds_step_tail (update)")
         for t, v in grads:
             t.grad = v
         return bf["loss"]
+
+    def _side_stream(self, dev):
+        key = str(dev)
+        if key not in self._sides:
+            self._sides[key] = torch.cuda.Stream(device=dev)
+        return self._sides[key]
 
 
 class IwaeLossSharded(torch.autograd.Function):

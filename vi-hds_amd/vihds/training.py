@@ -394,10 +394,13 @@ class Training:
         ode = self.model.decoder.ode_model
         # (a step whose backward is ops.GeneralTail reads neither trajectory views nor x_predict: the forward skips the latter)
         ode._train_without_x_predict = bool(self._gtail_ok)
+        # (... and the sampling stage can run inside the forward launch: params.fused_theta_ode, vihds_theta_ode_fwd)
+        self.model._fuse_theta_ode = bool(self._gtail_ok) and bool(default_get_value(self.settings.params, "fused_theta_ode", True))
         try:
             batch_results, theta, q, p = self.model(batch, self.args.train_samples)
         finally:
             ode._train_without_x_predict = False
+            self.model._fuse_theta_ode = False
         loss = self._general_tail(batch_results, theta, q, p)
         if loss is not None:
             # params.fused_step_tail, any model: IWAE loss, ODE adjoint, weight gradients, theta / encoder adjoints and Adam
@@ -409,6 +412,12 @@ class Training:
             if zero_grad:
                 self.optimizer.zero_grad(set_to_none=True)
             return loss.detach()
+        node = getattr(getattr(getattr(batch_results, "solution", None), "logp_buffer", None), "grad_fn", None)
+        if type(node).__name__ == "ThetaOdeFusedBackward" and node.rng_state is not None:
+            # (the fused forward left the generator's step to the tail, which did not take this step after all)
+            from vihds import hip
+
+            hip.check(hip.lib().vihds_rng_advance(hip.ptr(node.rng_state), hip.current_stream()), "vihds_rng_advance")
         self._in_step = True
         ops._PENDING_IWAE.clear()  # (a deferred loss whose backward never ran must not be mistaken for this step's)
         try:
@@ -498,7 +507,9 @@ class Training:
         theta_node = getattr(packed, "grad_fn", None)
         pq = getattr(q, "_packed_q", None)
         enc_node = getattr(pq[1], "grad_fn", None) if pq is not None else None
-        if (type(ode_node).__name__ != "OdeSolveObserveBackward" or type(theta_node).__name__ != "ThetaSampleLogProbPackedBackward"
+        fused_fwd = type(ode_node).__name__ == "ThetaOdeFusedBackward" and type(theta_node).__name__ == "ThetaOdeFusedBackward"
+        if (not (fused_fwd or (type(ode_node).__name__ == "OdeSolveObserveBackward"
+                               and type(theta_node).__name__ == "ThetaSampleLogProbPackedBackward"))
                 or type(enc_node).__name__ != "EncoderQTablesBackward" or not getattr(sol, "has_logp", False)):
             return None
         if self._gtail is None:
@@ -507,10 +518,11 @@ class Training:
             self._gtail_ok = self._gtail.applicable()
             if not self._gtail_ok:
                 return None
+        fwd = ops.GeneralTail.forward_state(theta_node, ode_node)
         # the integrator must have read the sampling kernel's own buffer (nothing re-bound into a copy on the way)
-        if ode_node.saved_tensors[0].data_ptr() != packed.data_ptr():
+        if fwd["theta"].data_ptr() != packed.data_ptr():
             return None
-        q_all, u = theta_node.saved_tensors[0], theta_node.saved_tensors[6]
+        q_all, u = fwd["q_all"], fwd["u"]
         key = (q_all.shape, u.shape[1])
         if key not in self._tail_shapes:
             from vihds import hip
@@ -518,7 +530,7 @@ class Training:
             self._tail_shapes[key] = bool(hip.lib().vihds_step_tail_supported(enc_node.shape, q_all.shape[0] // 2, u.shape[1]))
         if not self._tail_shapes[key]:
             return None
-        return self._gtail.launch(theta_node, ode_node, enc_node, q.log_prob(theta), p.log_prob(theta), logp.shape[2],
+        return self._gtail.launch(fwd, enc_node, q.log_prob(theta), p.log_prob(theta), logp.shape[2],
                                   apply_adam=self.replica is None)
 
     def _snapshot_training_state(self):

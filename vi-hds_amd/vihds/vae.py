@@ -75,6 +75,9 @@ class BaseVAE(nn.Module):
         fused = self._decoder_step_fused(data, samples, u, q, p, n_extra)
         if fused is not None:
             return fused + (q, p)
+        fused = self._theta_ode_fused(data, samples, u, q, p, n_extra)
+        if fused is not None:
+            return fused + (q, p)
         clipped_theta = q.sample_clip_log_prob(u, p, stddevs=4, n_extra_rows=n_extra)
         if self.shard is not None:
             lo, _ = self.shard.bounds(samples)
@@ -150,6 +153,70 @@ def _bind_fused(BaseVAE):
         return result, theta
 
     BaseVAE._decoder_step_fused = _decoder_step_fused
+
+    def _theta_ode_fused(self, data, samples, u, q, p, n_extra):
+        """Training steps whose backward is ops.GeneralTail (Training.step sets `_fuse_theta_ode`): the sampling stage, for
+        dr_blackbox also condition_theta, runs inside the ODE forward launch (ops.ThetaOdeFused, vihds_theta_ode_fwd) -- the
+        models whose forward kernels carry it: relay / degrader / prpr / auto_constant (+ _precisions), dr_blackbox at the
+        built-in sizes.  None when it does not apply (then the separate launches)."""
+        from vihds import hip, ops
+        from vihds.decoders import LazyDecoderResult
+        from vihds.ode import DecodedSolution
+
+        dec = self.decoder
+        ode, cfg = dec.ode_model, dec.config
+        obs = data.get("observations", None) if hasattr(data, "get") else None
+        if (not getattr(self, "_fuse_theta_ode", False) or not torch.is_grad_enabled() or obs is None or not obs.is_cuda
+                or getattr(q, "_packed_q", None) is None or self.shard is not None or cfg.params.solver in hip.ADAPTIVE_SOLVERS):
+            return None
+        blackbox = ode.model_key == "dr_blackbox"
+        if not blackbox and (n_extra or getattr(ode, "extra_theta_names", ())):
+            return None  # (a device conditioner: not a stage of these kernels)
+        key = ("theta_ode", tuple(obs.shape), samples, cfg.params.solver)
+        if self._fused_declined.get(key):
+            return None
+        extra = list(ode.extra_theta_names) if (blackbox and n_extra) else []
+        n_q = len(q.names())
+        offset = None
+        if blackbox and getattr(ode, "n_y", 0) > 0:
+            if not extra:
+                return None
+            names = q.names()
+            rows = [names.index("y%d" % (i + 1)) if ("y%d" % (i + 1)) in names else -1 for i in range(ode.n_y)]
+            if rows != list(range(rows[0], rows[0] + ode.n_y)) or rows[0] < 0:
+                return None
+            offset = (ode.offset_layer.weight, ode.offset_layer.bias, (rows[0], n_q, ode.n_y))
+
+        def spec_of(names):
+            row_of = {n: k for k, n in enumerate(list(names) + extra)}
+            if blackbox:  # the integrator reads the device-conditioned rows (condition_theta re-binds y1.. to them)
+                for i in range(ode.n_y):
+                    row_of["y%d" % (i + 1)] = n_q + i
+            return ode._spec(cfg, row_of, len(names) + len(extra))
+
+        try:
+            theta, traj, logp = q.theta_ode_fused(u, p, 4, len(extra), spec_of, data.inputs, data.times.to(obs.device), obs,
+                                                  data.dev_1hot, ode.neural_weights(), offset)
+        except ops.FusedTrainingUnsupported:
+            self._fused_declined[key] = True
+            return None
+        if blackbox:
+            for i in range(ode.n_y):  # (what condition_theta does: the attribute now names the conditioned row)
+                theta.bind_reserved_row("y%d" % (i + 1), n_q + i)
+        sol = DecodedSolution(traj, None, logp, observe=lambda s_: ode._observe_map(s_))
+        sol.has_logp = True
+        ode._last = sol
+
+        def build():
+            xs, prec = ode.expand_precisions(theta, data.times, sol.sol)
+            return xs, ode.observe(sol.sol, theta), prec
+
+        result = LazyDecoderResult(build)
+        result.solution = sol
+        result.log_p_by_species = sol.log_p_by_species
+        return result, theta
+
+    BaseVAE._theta_ode_fused = _theta_ode_fused
 
 
 _bind_fused(BaseVAE)
