@@ -186,6 +186,16 @@ int vihds_ode_adaptive_fwd(const vihds_ode_problem* p, const float* theta, const
 int vihds_ode_adaptive_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                            const float* times, int max_steps, const float* workspace, const float* g_traj, float* g_theta,
                            void* stream);
+/* The same pair for the white-box models WITH neural precisions (*_precisions, no hidden layer: every such spec of the
+ * reference; ABI 13): weights as for vihds_ode_fwd; g_weights [n_weights] receives += the network's weight gradient
+ * (per-thread accumulators, one atomic per wavefront and entry: zero it first).  Models without a network: weights /
+ * g_weights NULL, identical to the calls above.  dr_blackbox and a hidden precision layer: VIHDS_E_UNSUPPORTED. */
+int vihds_ode_adaptive_fwd_w(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                             const float* weights, const float* times, float rtol, float atol, int max_steps, float* workspace,
+                             float* traj, void* stream);
+int vihds_ode_adaptive_bwd_w(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                             const float* weights, const float* times, int max_steps, const float* workspace,
+                             const float* g_traj, float* g_theta, float* g_weights, void* stream);
 
 /* Adaptive solvers (VIHDS_SOLVER_DOPRI5 / BOSH3 / ADAPTIVE_HEUN / DOPRI8; reference vihds/ode.py:79-81 -> torchdiffeq==0.1
  * odeint / odeint_adjoint, absent from the tree: restated, parity unpinned).  Step-size controller, SYNCHRONOUS on

@@ -2240,6 +2240,56 @@ def test_adaptive_device_solver_is_the_dependencys_algorithm(solver):
     assert e_sol < 1e-4 and e_grad < 1e-4
 
 
+@pytest.mark.parametrize("name", ["dr_constant_precisions_tiny_modeuler", "auto_constant_precisions_tiny_modeuler",
+                                  "relay_constant_precisions_tiny_modeuler"])
+@pytest.mark.parametrize("solver", ["dopri5", "bosh3"])
+def test_adaptive_device_solver_with_neural_precisions(name, solver):
+    """Round 5: the dependency's adaptive algorithm on the device for the white-box models WITH neural
+    precisions (*_precisions, no hidden layer: vihds_ode_adaptive_fwd_w / _bwd_w) -- they used to take the clipped-grid,
+    host-synchronised controller, tested to 200 x rtol.  Against `oracle.odeint_adaptive` (the restatement of torchdiffeq
+    0.1's driver; parity unpinned: the dependency is absent): identical accepted / rejected step counts, the solution at the
+    output times -- the four precision states included --, and the gradient of a weighted sum of all states w.r.t. every
+    theta row AND every weight of the precision network, within 1e-4 (solution) / 1e-3 (gradients, atomics in the sum)."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture(name)
+    rtol, atol = (1e-6, 1e-8) if solver == "dopri5" else (1e-5, 1e-7)
+    prec_w, _sw, _off = fx.decoder_weights()
+    flat = torch.cat([prec_w[k].reshape(-1) for k in ("prod_w", "prod_b", "degr_w", "degr_b")]).to(DEV).requires_grad_(True)
+    th, row_of = H.pack_theta(fx, DEV)
+    th.requires_grad_(True)
+    spec = H.spec_for(fx, row_of, th.shape[0], solver, 0)
+    assert ops.adaptive_device_supported(spec, fx.B, fx.S, len(fx.t("times")), 8192) is not None
+    stats = [0, 0, 0]
+    traj = ops.AdaptiveOdeSolve.apply(spec, th, fx.t("inputs", DEV), fx.t("times", DEV), None, rtol, atol, 8192, True, stats, flat)
+    sol = H.view_bsnt(traj)  # [B,S,N,T]
+    wgt = torch.linspace(0.5, 1.5, sol.shape[2] * sol.shape[3]).reshape(sol.shape[2], sol.shape[3])
+    (sol * wgt.to(DEV)).sum().backward()
+    thc = fx.theta_dict(requires_grad=True)
+    for n in fx.extra_names:
+        thc[n].requires_grad_(True)
+    pw = {k: v.clone().requires_grad_(True) for k, v in prec_w.items()}
+    rhs, x0 = O.MODEL_TABLE[fx.model][0](thc, fx.t("inputs"), prec_w=pw)
+    ref, n_acc, n_rej = O.odeint_adaptive(solver, rhs, x0, fx.t("times"), rtol, atol)
+    ref = ref.permute(1, 2, 3, 0)
+    (ref * wgt).sum().backward()
+    assert (stats[1], stats[2]) == (n_acc, n_rej), (stats, n_acc, n_rej)
+    e_sol = float(rel_err(sol, ref))
+    names = list(fx.names) + list(fx.extra_names)
+    e_grad = 0.0
+    for i, n in enumerate(names):
+        g_ref = thc[n].grad
+        if g_ref is None or float(g_ref.abs().max()) == 0.0:
+            continue
+        e_grad = max(e_grad, float((th.grad[i].cpu() - g_ref).abs().max() / g_ref.abs().max()))
+    g_ref_w = torch.cat([pw[k].grad.reshape(-1) for k in ("prod_w", "prod_b", "degr_w", "degr_b")])
+    e_w = float((flat.grad.cpu() - g_ref_w).abs().max() / g_ref_w.abs().max())
+    print("adaptive %s on %s: %d accepted + %d rejected; solution %.2e, theta gradient %.2e, weight gradient %.2e"
+          % (solver, fx.model, n_acc, n_rej, e_sol, e_grad, e_w))
+    assert e_sol < 1e-4 and e_grad < 1e-3 and e_w < 1e-3
+
+
 def test_adaptive_device_solver_through_the_plugin_and_in_a_graph():
     """The same solver through the plugin surface (`solver: dopri5` in the spec -> OdeModel.solve), a training step with
     finite gradients on every encoder parameter, and -- params.adaptive_check: false, nothing synchronises -- the forward

@@ -530,7 +530,9 @@ int vihds_ode_adaptive_grid(const vihds_ode_problem* p, const float* theta, cons
 
 // ---- torchdiffeq's adaptive algorithm on the device (csrc/vihds_rk_adaptive_device.hpp) -------------------------------------
 static bool adaptive_device_model(const vihds_ode_problem* p, const ModelEntry* e) {
-  return e && !e->neural_prec && p->solver >= VIHDS_SOLVER_DOPRI5 && p->solver <= VIHDS_SOLVER_ADAPTIVE_HEUN &&
+  // (round 5: the white-box models with neural precisions too, when their network has no hidden layer; not dr_blackbox)
+  const bool net_ok = e && (!e->neural_prec || (p->model != VIHDS_MODEL_DR_BLACKBOX && p->n_hidden_prec < 1));
+  return net_ok && p->solver >= VIHDS_SOLVER_DOPRI5 && p->solver <= VIHDS_SOLVER_ADAPTIVE_HEUN &&
          (long long)p->B * p->S <= (long long)ADP_MAX_BLOCKS * ADP_BLOCK;
 }
 long long vihds_ode_adaptive_tape_floats(const vihds_ode_problem* p, int max_steps) {
@@ -542,18 +544,21 @@ long long vihds_ode_adaptive_tape_floats(const vihds_ode_problem* p, int max_ste
 }
 static int adaptive_device_call(int mode, const vihds_ode_problem* p, const float* theta, const float* cond,
                                 const float* dev1hot, const float* times, float rtol, float atol, int max_steps,
-                                float* workspace, float* traj, const float* g_traj, float* g_theta, void* stream) {
+                                float* workspace, float* traj, const float* g_traj, float* g_theta, void* stream,
+                                const float* weights = nullptr, float* g_weights = nullptr) {
   if (!p || !theta || !times || !workspace || max_steps < 1) return fail(VIHDS_E_BADARG, "null problem/theta/times/workspace");
   const ModelEntry* e = entry(p->model);
   if (!adaptive_device_model(p, e))
-    return fail(VIHDS_E_UNSUPPORTED, "device-resident adaptive solver: dopri5 / bosh3 / adaptive_heun on a model without shared "
-                                     "neural weights, at most 65 536 trajectories (use vihds_ode_adaptive_grid otherwise)");
+    return fail(VIHDS_E_UNSUPPORTED, "device-resident adaptive solver: dopri5 / bosh3 / adaptive_heun on a white-box model (neural "
+                                     "precisions without a hidden layer included), at most 65 536 trajectories (use "
+                                     "vihds_ode_adaptive_grid otherwise)");
+  if (e->neural_prec && !weights) return fail(VIHDS_E_BADARG, "model has neural precisions: weights must not be NULL");
   OdeArgs a;
   int rc = build_args(p, e, a, nullptr);
   if (rc) return rc;
   if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
   a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times;
-  a.traj = traj; a.g_traj = g_traj; a.g_theta = g_theta;
+  a.traj = traj; a.g_traj = g_traj; a.g_theta = g_theta; a.weights = weights; a.g_weights = g_weights;
   AdaptiveDevCtl ctl = {mode, {workspace, rtol, atol, max_steps}, 0};
   g_adaptive_dev = &ctl;
   rc = e->launch(mode == 2, p->solver, a, (hipStream_t)stream);
@@ -566,6 +571,20 @@ int vihds_ode_adaptive_fwd(const vihds_ode_problem* p, const float* theta, const
                            void* stream) {
   if (!traj) return fail(VIHDS_E_BADARG, "null traj");
   return adaptive_device_call(1, p, theta, cond, dev1hot, times, rtol, atol, max_steps, workspace, traj, nullptr, nullptr, stream);
+}
+int vihds_ode_adaptive_fwd_w(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                             const float* weights, const float* times, float rtol, float atol, int max_steps, float* workspace,
+                             float* traj, void* stream) {
+  if (!traj) return fail(VIHDS_E_BADARG, "null traj");
+  return adaptive_device_call(1, p, theta, cond, dev1hot, times, rtol, atol, max_steps, workspace, traj, nullptr, nullptr, stream,
+                              weights, nullptr);
+}
+int vihds_ode_adaptive_bwd_w(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                             const float* weights, const float* times, int max_steps, const float* workspace,
+                             const float* g_traj, float* g_theta, float* g_weights, void* stream) {
+  if (!g_theta) return fail(VIHDS_E_BADARG, "null g_theta");
+  return adaptive_device_call(2, p, theta, cond, dev1hot, times, 0.f, 0.f, max_steps, const_cast<float*>(workspace), nullptr,
+                              g_traj, g_theta, stream, weights, g_weights);
 }
 int vihds_ode_adaptive_bwd(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
                            const float* times, int max_steps, const float* workspace, const float* g_traj, float* g_theta,

@@ -16,8 +16,11 @@
 //     constant: reverse walk over the tape; per step the adjoints of the interpolated outputs enter through y0, y1, y_mid,
 //     f0, f1, then the stages are pulled back with the model's rhs_vjp.
 //
-// No host round trip, no hipStreamSynchronize: the pair of launches is hipGraph-capturable.  Models with shared neural
-// weights (dr_blackbox, *_precisions) and `dopri8` keep the clipped-grid controller (vihds_ode_adaptive_grid).
+// No host round trip, no hipStreamSynchronize: the pair of launches is hipGraph-capturable.  Round 5: the white-box models
+// with neural precisions (*_precisions without a hidden layer: every spec the reference ships) run here too -- the network's
+// weights are read as scalars like in the fixed-grid kernels, and the adjoint accumulates their gradient per thread (2 (4 NIN +
+// 4) registers: WeightGradCtx), reduced per wavefront and added to g_weights.  dr_blackbox, a hidden precision layer and
+// `dopri8` keep the clipped-grid controller (vihds_ode_adaptive_grid).
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -170,7 +173,7 @@ __global__ void __launch_bounds__(ADP_BLOCK) ode_adaptive_fwd_kernel(OdeArgs a, 
   using TD = TabD<SOLVER>;
   using MW = MidWeights<SOLVER>;
   constexpr int N = M::N, NS = TB::NS;
-  static_assert(M::NW == 0, "the device-resident adaptive solver serves the models without shared neural weights");
+  static_assert(!is_blackbox<M>::value, "the device-resident adaptive solver does not serve dr_blackbox");
   const AdaptiveLayout L(gridDim.x, d.max_steps, a.T, N, a.n);
   unsigned int* ctrl = reinterpret_cast<unsigned int*>(d.ws);
   double* partial = reinterpret_cast<double*>(d.ws + L.partial);
@@ -188,8 +191,9 @@ __global__ void __launch_bounds__(ADP_BLOCK) ode_adaptive_fwd_kernel(OdeArgs a, 
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP], y[N];
   load_theta<M>(a, i, b, th, prec, c);
   M::prepare(th, c, p);
+  if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
   M::init(th, c, y);
-  const float* wts = nullptr;
+  const float* wts = a.weights;  // (NULL for the models without a network)
   unsigned int epoch = 0;
   const double cnt = (double)N * (double)n;
   const float rtol = d.rtol, atol = d.atol;
@@ -353,8 +357,11 @@ __global__ void __launch_bounds__(ADP_BLOCK) ode_adaptive_bwd_kernel(OdeArgs a, 
   float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP];
   load_theta<M>(a, i, b, th, prec, c);
   M::prepare(th, c, p);
-  const float* wts = nullptr;
-  NoCtx ctx;
+  if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
+  const float* wts = a.weights;
+  using CtxImpl = bwd_ctx<M>;  // NoCtx, or per-thread weight-gradient accumulators (white-box + neural precisions)
+  typename CtxImpl::type ctx;
+  CtxImpl::init(ctx, a, i);
   float lam[N], pb[M::NP];
   VIHDS_UNROLL for (int j = 0; j < N; ++j) lam[j] = 0.f;
   VIHDS_UNROLL for (int j = 0; j < M::NP; ++j) pb[j] = 0.f;
@@ -447,6 +454,15 @@ __global__ void __launch_bounds__(ADP_BLOCK) ode_adaptive_bwd_kernel(OdeArgs a, 
       VIHDS_UNROLL for (int j = 0; j < 4; ++j) a.g_theta[(size_t)a.slot_row[M::NSLOT + j] * n + i] = 0.f;
     }
   }
+  if constexpr (M::NW > 0) {  // the precision network's weight gradient: wavefront shuffle tree, one atomic per wavefront
+    if (a.g_weights) {
+      VIHDS_UNROLL for (int q = 0; q < M::NW; ++q) {
+        float v = live ? ctx.wb[q] : 0.f;
+        VIHDS_UNROLL for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o, 64);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&a.g_weights[q], v);
+      }
+    }
+  }
 }
 
 // request block for the model launchers (see AdaptiveCtl): mode 1 = forward, 2 = adjoint
@@ -459,9 +475,10 @@ extern thread_local AdaptiveDevCtl* g_adaptive_dev;
 
 template <class M, int SOLVER>
 inline int adaptive_device_s(const OdeArgs& a, const AdaptiveDevCtl& ctl, hipStream_t st) {
-  if constexpr (M::NW != 0) {
+  if constexpr (is_blackbox<M>::value) {
     return VIHDS_E_UNSUPPORTED;
   } else {
+    if (M::NW != 0 && a.n_hidden_prec >= 1) return VIHDS_E_UNSUPPORTED;  // (a hidden precision layer: the dump-mode adjoint only)
     const int nblk = (a.n + ADP_BLOCK - 1) / ADP_BLOCK;
     if (nblk > ADP_MAX_BLOCKS) return VIHDS_E_UNSUPPORTED;
     if (ctl.mode == 1) {

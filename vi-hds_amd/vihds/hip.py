@@ -182,6 +182,8 @@ _PROTOTYPES = {
     "vihds_ode_adaptive_tape_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem), _I]),
     "vihds_ode_adaptive_fwd": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
     "vihds_ode_adaptive_bwd": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "vihds_ode_adaptive_fwd_w": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
+    "vihds_ode_adaptive_bwd_w": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "vihds_blackbox_dump_fields": (_I, []),
     "vihds_problem_n_states": (_I, [ctypes.POINTER(OdeProblem)]),
     "vihds_problem_n_slots": (_I, [ctypes.POINTER(OdeProblem)]),

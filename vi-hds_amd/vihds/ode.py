@@ -281,9 +281,11 @@ class OdeModel(nn.Module):
         # the accepted step's quartic interpolant, the adjoint walks the logged accepted steps -- models without shared
         # neural weights; params.adaptive_device: false keeps the clipped-grid controller below for them too
         B, S = packed.shape[1], packed.shape[2]
-        if (weights is None and bool(default_get_value(config.params, "adaptive_device", True))
+        # (round 5: also the *_precisions models without a hidden layer -- the library says which problems it takes)
+        if (bool(default_get_value(config.params, "adaptive_device", True))
                 and ops.adaptive_device_supported(spec, B, S, int(times.shape[0]), max_grid) is not None):
-            return self._solve_adaptive_device(config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_grid)
+            return self._solve_adaptive_device(config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_grid,
+                                               weights)
         while True:
             try:
                 grid, index = ops.adaptive_grid(spec, packed, cond, times, d1, weights, rtol, atol, max_grid=max_grid)
@@ -319,14 +321,15 @@ class OdeModel(nn.Module):
         self._last.has_logp = observations is not None
         return self._last
 
-    def _solve_adaptive_device(self, config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_steps):
+    def _solve_adaptive_device(self, config, spec, packed, row_of, times, cond, d1, observations, rtol, atol, max_steps,
+                               weights=None):
         """ops.AdaptiveOdeSolve + the observation map and the Gaussian log-likelihood with torch ops on the solution at the
         output times (autograd hands the adjoint kernel the upstream gradient of the trajectory)."""
         check = bool(default_get_value(config.params, "adaptive_check", True))  # False: no synchronisation (capturable)
         stats = [0, 0, 0]
         while True:
             try:
-                traj = ops.AdaptiveOdeSolve.apply(spec, packed, cond, times, d1, rtol, atol, max_steps, check, stats)
+                traj = ops.AdaptiveOdeSolve.apply(spec, packed, cond, times, d1, rtol, atol, max_steps, check, stats, weights)
                 break
             except ops.GridOverflow as e:
                 if max_steps >= (1 << 17):
@@ -341,8 +344,11 @@ class OdeModel(nn.Module):
         xpred = self._observe_map(sol).permute(3, 2, 0, 1)           # [T,4,B,S]
         dev = packed.device
         if observations is not None:
-            rows = [row_of[n] for n in spec.slots[-4:]]              # constant precisions (reference precisions.py:31-35)
-            prec = packed[rows][None]
+            if spec.n_species < spec.n_states:  # neural precisions: the last four states (reference precisions.py:89-94)
+                prec = traj[:, spec.n_species:, :, :]
+            else:
+                rows = [row_of[n] for n in spec.slots[-4:]]          # constant precisions (reference precisions.py:31-35)
+                prec = packed[rows][None]
             err = xpred - observations.to(dev).permute(2, 1, 0)[:, :, :, None]
             logp = (-0.5 * (math.log(2 * math.pi) - torch.log(prec) + prec * err * err)).sum(0)  # training.py:24-44
         else:

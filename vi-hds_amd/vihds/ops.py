@@ -166,14 +166,15 @@ def adaptive_device_supported(spec, B, S, T, max_steps):
 
 
 class AdaptiveOdeSolve(torch.autograd.Function):
-    """torchdiffeq 0.1's adaptive-step algorithm on the device (vihds_ode_adaptive_fwd / _bwd): one persistent launch
-    forward, one launch for the discrete adjoint over the logged accepted steps.  forward(theta [R,B,S], cond, times [T]) ->
-    traj [T,N,B,S] (the solution at the output times; steps run past them, outputs come from the accepted step's quartic
-    interpolant).  `stats` (host ints [error, accepted, rejected]) is filled when check=True, which synchronises; with
-    check=False nothing waits and the pair of launches can be captured in a hipGraph."""
+    """torchdiffeq 0.1's adaptive-step algorithm on the device (vihds_ode_adaptive_fwd_w / _bwd_w): one persistent launch
+    forward, one launch for the discrete adjoint over the logged accepted steps.  forward(theta [R,B,S], cond, times [T],
+    weights or None) -> traj [T,N,B,S] (the solution at the output times; steps run past them, outputs come from the accepted
+    step's quartic interpolant).  `stats` (host ints [error, accepted, rejected]) is filled when check=True, which
+    synchronises; with check=False nothing waits and the pair of launches can be captured in a hipGraph.  weights: the
+    precision network of a *_precisions model (no hidden layer); its gradient comes back from the adjoint launch."""
 
     @staticmethod
-    def forward(ctx, spec, theta, cond, times, dev1hot, rtol, atol, max_steps, check, stats):
+    def forward(ctx, spec, theta, cond, times, dev1hot, rtol, atol, max_steps, check, stats, weights=None):
         _require_cuda(theta, cond, times)
         theta, cond, times = _c(theta), _c(cond), _c(times.to(torch.float32))
         R, B, S = theta.shape
@@ -184,9 +185,9 @@ class AdaptiveOdeSolve(torch.autograd.Function):
             hip.check(int(n_ws), "vihds_ode_adaptive_tape_floats")
         ws = torch.empty(int(n_ws), device=theta.device, dtype=torch.float32)
         traj = torch.empty((T, spec.n_states, B, S), device=theta.device, dtype=torch.float32)
-        rc = _launch("ode_adaptive_fwd", lambda: hip.lib().vihds_ode_adaptive_fwd(
-            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), float(rtol), float(atol),
-            int(max_steps), hip.ptr(ws), hip.ptr(traj), hip.current_stream()))
+        rc = _launch("ode_adaptive_fwd", lambda: hip.lib().vihds_ode_adaptive_fwd_w(
+            ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(weights), hip.ptr(times), float(rtol),
+            float(atol), int(max_steps), hip.ptr(ws), hip.ptr(traj), hip.current_stream()))
         hip.check(rc, "vihds_ode_adaptive_fwd")
         if check:
             err, acc, rej = (int(v) for v in ws[:4].view(torch.int32)[1:4].tolist())
@@ -197,22 +198,23 @@ class AdaptiveOdeSolve(torch.autograd.Function):
             if err != 0:
                 raise RuntimeError("adaptive solver '%s' failed on the device: %s" % (spec.solver, ADAPTIVE_DEVICE_ERRORS.get(err, err)))
         ctx.spec, ctx.prob, ctx.max_steps = spec, prob, int(max_steps)
-        ctx.save_for_backward(theta, cond, times, dev1hot, ws)
+        ctx.save_for_backward(theta, cond, times, dev1hot, ws, weights)
         ctx.set_materialize_grads(False)
         return traj
 
     @staticmethod
     def backward(ctx, g_traj):
-        theta, cond, times, dev1hot, ws = ctx.saved_tensors
+        theta, cond, times, dev1hot, ws, weights = ctx.saved_tensors
         g_theta = torch.empty_like(theta) if ctx.spec.covers_all_rows else torch.zeros_like(theta)
         if g_traj is None:
-            return (None, torch.zeros_like(theta)) + (None,) * 8
+            return (None, torch.zeros_like(theta)) + (None,) * 9
         g_traj = _c(g_traj)
-        rc = _launch("ode_adaptive_bwd", lambda: hip.lib().vihds_ode_adaptive_bwd(
-            ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), ctx.max_steps,
-            hip.ptr(ws), hip.ptr(g_traj), hip.ptr(g_theta), hip.current_stream()))
+        g_w = torch.zeros_like(weights) if weights is not None else None
+        rc = _launch("ode_adaptive_bwd", lambda: hip.lib().vihds_ode_adaptive_bwd_w(
+            ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(weights), hip.ptr(times),
+            ctx.max_steps, hip.ptr(ws), hip.ptr(g_traj), hip.ptr(g_theta), hip.ptr(g_w), hip.current_stream()))
         hip.check(rc, "vihds_ode_adaptive_bwd")
-        return (None, g_theta) + (None,) * 8
+        return (None, g_theta) + (None,) * 8 + (g_w,)
 
 
 class OdeSolveObserve(torch.autograd.Function):
