@@ -285,6 +285,9 @@ __device__ __forceinline__ const float* stage_weights(const OdeArgs& a, float* l
   }
 }
 
+#ifndef VIHDS_NT_TRAJ
+#define VIHDS_NT_TRAJ 1
+#endif
 // ---- forward -------------------------------------------------------------------------------------
 // LDS_IN: the time grid and the observation rows of the data rows this block spans are staged in LDS once, so the
 // time loop holds no vector-memory loads and its trajectory / x_predict stores are never waited on (see
@@ -331,6 +334,10 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   const float h0 = a.times[1] - a.times[0];
   const size_t n = a.n;
 
+  // A trajectory larger than the chip's caches (the evaluation shape: 644 MB at B=234, S=1000) is written with streaming
+  // (non-temporal) stores: its lines are not kept dirty in L2 / Infinity Cache, so the summaries launch that follows does not
+  // share HBM with their write-back.  Training shapes keep ordinary stores (the adjoint re-reads them from cache).
+  const bool nt_traj = VIHDS_NT_TRAJ && (size_t)a.n * N * a.T * sizeof(float) > ((size_t)256 << 20);
   // times / observations are fetched one step ahead so their latency is off the dependent chain
   float tA = time_at(0), tB = time_at(1);
   float obc[4], obn[4];
@@ -346,7 +353,11 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
     }
     tB = tC;
     if (a.traj) {
-      VIHDS_UNROLL for (int j = 0; j < N; ++j) a.traj[((size_t)k * N + j) * n + i] = y[j];
+      if (nt_traj) {  // (streaming stores at evaluation-sized launches: see nt_traj)
+        VIHDS_UNROLL for (int j = 0; j < N; ++j) __builtin_nontemporal_store(y[j], &a.traj[((size_t)k * N + j) * n + i]);
+      } else {
+        VIHDS_UNROLL for (int j = 0; j < N; ++j) a.traj[((size_t)k * N + j) * n + i] = y[j];
+      }
     }
     float xp[4];
     observe<M::OBS>(y, xp);

@@ -134,6 +134,7 @@ struct RlLane {
 };
 struct RlEval {  // what one RHS evaluation leaves behind for its VJP
   float x, luxR, lasR, I, sig, gr, g, gamma, a, den, P, denq, Q, sp, sd, hl;
+  float lux2, las2;  // luxR^2, lasR^2 (the promoter's forward forms them; its VJP reads them again)
 };
 // sigma(4 (t - tlag)) of every (step, stage) of the grid depends on the trajectory's lag only: tabulated once per kernel
 // in LDS ([trajectory][(T - 1) stages]), sixteen entries at a time by the trajectory's lanes; an evaluation reads its entry
@@ -165,10 +166,11 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float sig, flo
   E.gr = c.r * E.sig;
   E.g = 1.f - E.x * c.iKx;
   E.gamma = E.gr * E.g;
-  E.a = 0.f; E.den = 1.f; E.P = 0.f; E.denq = 1.f; E.Q = 0.f;
+  E.a = 0.f; E.den = 1.f; E.P = 0.f; E.denq = 1.f; E.Q = 0.f; E.lux2 = 0.f; E.las2 = 0.f;
   float dy = c.F0;
   if (LM::HAS_P) {
-    E.a = c.aR * E.luxR * E.luxR + c.aS * E.lasR * E.lasR;
+    E.lux2 = E.luxR * E.luxR; E.las2 = E.lasR * E.lasR;
+    E.a = c.aR * E.lux2 + c.aS * E.las2;
     E.den = 1.f + E.a;
     E.P = fdiv(c.e + E.a, E.den);
     dy += c.cP * E.P;
@@ -203,7 +205,9 @@ __device__ __forceinline__ float rl_rhs(const RlLane& c, float t, float sig, flo
 // per-lane adjoint accumulators
 struct RlAcc {
   float F0b, cPb, eb, aRb, aSb, cQb, iKb, degb;  // adjoints of the lane's own constants
-  float rb, Kb, tlagb;                            // growth parameters (the same numbers in every lane of the trajectory)
+  // growth parameters (the same numbers in every lane of the trajectory), kept as RAW sums over the evaluations and scaled
+  // once after the time loop (rl_acc_finish): rb = sum grb sig;  Kb = iKx^2 sum gb x;  tlagb = -4 r sum grb (sig - sig^2)
+  float rb, Kb, tlagb;
   // weight gradients of the precision network: lane l <= NSP owns COLUMN j(l) (the input it publishes: t or its own species)
   // of both matrices -- its own tanh times the eight pre-activation adjoints every lane reads anyway: 4 packed FMAs per
   // evaluation where a row per precision lane cost 13 in all sixteen lanes; the precision lanes keep the bias sums
@@ -230,24 +234,25 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
     const float nb = fdiv(Pb, E.den);
     const float sP = nb * (1.f - E.P);
     A.eb += nb;
-    A.aRb += sP * E.luxR * E.luxR;
-    A.aSb += sP * E.lasR * E.lasR;
+    A.aRb = fmaf(sP, E.lux2, A.aRb);
+    A.aSb = fmaf(sP, E.las2, A.aSb);
     bRt = rl_sum16(sP * c.aR);
     bSt = rl_sum16(sP * c.aS);
   }
   // quadrature Q = x I / (1 + I iK)
   float xq = 0.f, Iq = 0.f;
   if (LM::HAS_Q) {
-    const float Qb = v * c.cQ;
     const float iden = frcp(E.denq);
-    xq = Qb * E.I * iden;
-    Iq = Qb * E.x * iden * iden;
-    A.iKb -= Qb * E.x * E.I * E.I * iden * iden;
+    const float t1 = (v * c.cQ) * iden;   // Qb / denq
+    xq = t1 * E.I;
+    Iq = (t1 * E.x) * iden;
+    A.iKb = fmaf(-(Iq * E.I), E.I, A.iKb);
   }
   // precision network
   if (PREC) {
-    const float zbx = c.isP * v * E.sp * (1.f - E.sp);
-    const float zby = -c.isP * v * Y * E.sd * (1.f - E.sd);
+    const float vP = c.isP * v;
+    const float zbx = vP * fmaf(-E.sp, E.sp, E.sp);            // isP v sp (1 - sp)
+    const float zby = -(vP * Y) * fmaf(-E.sd, E.sd, E.sd);     // -isP v Y sd (1 - sd)
     A.b2p += zbx;
     A.b2d += zby;
     pt[c.a_zx] = zbx;
@@ -268,14 +273,19 @@ __device__ __forceinline__ float rl_vjp_core(const RlLane& c, float Y, float v, 
   }
   // growth: gamma = gr (1 - x / K)
   const float grb = gammab * E.g, gb = gammab * E.gr;
-  A.Kb += gb * E.x * c.iKx * c.iKx;
-  A.rb += grb * E.sig;
-  A.tlagb -= 4.f * grb * c.r * E.sig * (1.f - E.sig);
+  A.Kb = fmaf(gb, E.x, A.Kb);                                   // (raw sums: rl_acc_finish scales them)
+  A.rb = fmaf(grb, E.sig, A.rb);
+  A.tlagb = fmaf(grb, fmaf(-E.sig, E.sig, E.sig), A.tlagb);
   yb = fmaf(c.m0, -gb * c.iKx + (LM::HAS_Q ? q4.x + q4.y : 0.f), yb);
   if (LM::HAS_P) yb = fmaf(c.m6, 2.f * E.luxR * bRt, fmaf(c.m7, 2.f * E.lasR * bSt, yb));
   if (LM::HAS_Q) yb = fmaf(c.sz, q4.z, fmaf(c.sw, q4.w, yb));  // the quadratures' sources (relay: luxI, lasI; degrader: aiiA)
   rl_wave_fence();
   return yb;
+}
+// the growth adjoints from their raw sums (see RlAcc)
+__device__ __forceinline__ void rl_acc_finish(const RlLane& c, RlAcc& A) {
+  A.Kb *= c.iKx * c.iKx;
+  A.tlagb *= -4.f * c.r;
 }
 // ... with the forward quantities recomputed first
 template <class LM, bool PREC>
@@ -774,6 +784,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig
 #pragma unroll
     for (int q = 0; q < M::NP; ++q) pb[q] = 0.f;
     auto T_ = [&](int lane, int f) { return tab[g][lane][f]; };
+    rl_acc_finish(c, A);
     pb[M::P_r] = A.rb; pb[M::P_K] = A.Kb; pb[M::P_tlag] = A.tlagb;
     LM::map(T_, p, pb);
 #pragma unroll
