@@ -19,12 +19,16 @@ for W in config3_train config3_eval config4 config5; do
   (cd $R && python profiles/make_pmc_traffic.py $F $WR profiles/${TAG}_${W}_pmc_hbm_traffic.json "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python bench.py --workload $W --steps 10 --warmup 3 --eager --no-cpu-baseline --roofline-steps 4" > $O/traffic_$W.log 2>&1; cp profiles/${TAG}_${W}_pmc_hbm_traffic.json $O/)
   rm -rf $O/pmc_${W}_FETCH_SIZE $O/pmc_${W}_WRITE_SIZE
 done
-rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma -o mfma -- python $R/bench.py --workload config4 --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4 > $O/mfma.log 2>&1
-F=$(find $O/mfma -name "*counter_collection.csv" | head -1)
-head -1 $F > $O/${TAG}_config4_pmc_mfma_counter_collection.csv; grep "vihds" $F >> $O/${TAG}_config4_pmc_mfma_counter_collection.csv
-rm -rf $O/mfma
-cd $R
-python - $O/${TAG}_config4_pmc_mfma_counter_collection.csv profiles/config4_mfma_busy.json <<'PY'
+# matrix-core busy fraction of the dr_blackbox kernels: BASELINE config 4 itself (450 groups of 16 trajectories: fewer than the
+# chip's SIMDs) and the same kernels with the chip full (config4_s1000: 2 250 groups)
+for W in config4 config4_s1000; do
+  cd /tmp
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma_$W -o mfma -- python $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4 > $O/mfma_$W.log 2>&1
+  F=$(find $O/mfma_$W -name "*counter_collection.csv" | head -1)
+  head -1 $F > $O/${TAG}_${W}_pmc_mfma_counter_collection.csv; grep "vihds" $F >> $O/${TAG}_${W}_pmc_mfma_counter_collection.csv
+  rm -rf $O/mfma_$W
+  cd $R
+  python - $O/${TAG}_${W}_pmc_mfma_counter_collection.csv profiles/${TAG}_${W}_mfma_busy.json $W <<'PY'
 import csv, json, sys, collections
 busy, act = collections.defaultdict(list), collections.defaultdict(list)
 for r in csv.DictReader(open(sys.argv[1])):
@@ -36,13 +40,20 @@ for k in busy:
         b, a = sum(busy[k]) / len(busy[k]), sum(act[k]) / len(act[k])
         # GRBM_GUI_ACTIVE is summed over the 8 XCDs; 1024 SIMDs share the MFMA-busy cycles
         out[k] = {"SQ_VALU_MFMA_BUSY_CYCLES": b, "GRBM_GUI_ACTIVE": a, "mfma_busy_frac": b / (a / 8 * 1024), "dispatches": len(busy[k])}
-json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --workload config4 "
+json.dump({"note": "rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace -- python bench.py --workload %s "
                    "--steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4; mfma_busy_frac = MFMA-busy cycles / (GUI-active / 8 XCDs "
-                   "x 1024 SIMDs)", "kernels": out}, open(sys.argv[2], "w"), indent=1)
+                   "x 1024 SIMDs)" % sys.argv[3], "kernels": out}, open(sys.argv[2], "w"), indent=1)
 print(json.dumps(out, indent=1)[:1500])
 PY
-cp profiles/config4_mfma_busy.json $O/
-for W in config3_train config3_eval config4 config5; do
+  cp profiles/${TAG}_${W}_mfma_busy.json $O/
+done
+cp profiles/${TAG}_config4_mfma_busy.json profiles/config4_mfma_busy.json
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4s -o c4s -- python $R/bench.py --workload config4_s1000 --steps 50 --warmup 10 --no-cpu-baseline > $O/stats_c4s.log 2>&1
+cp $(find $O/stats_c4s -name "*kernel_stats.csv" | head -1) $O/${TAG}_config4_s1000_kernel_stats.csv
+rm -rf $O/stats_c4s
+cd $R
+for W in config3_train config3_eval config4 config5 config4_s1000; do
   python bench.py --workload $W > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
   tail -1 $O/${TAG}_${W}_bench.json | cut -c1-160
 done

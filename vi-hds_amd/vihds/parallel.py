@@ -146,7 +146,7 @@ def collectives_capturable(group=None):
     return ans
 
 
-def _probe_capture(rank=0, world=1, port=None, timeout=180):
+def _probe_capture(rank=0, world=1, port=None, timeout=90):
     import socket
     import subprocess
     import sys
