@@ -35,6 +35,16 @@ MULTI_RANK_WATCHDOG_S = 300  # a multi-rank graph path that has not finished by 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
 
+_OUT = None  # the process's real stdout once `__main__` has routed everything else to stderr
+
+
+def emit(obj):
+    """The bench line (and nothing else) on stdout."""
+    out = _OUT if _OUT is not None else sys.stdout
+    out.write(json.dumps(obj) + "\n")
+    out.flush()
+
+
 def algorithmic_bytes(B, S, T=N_TIMES, N=N_STATES, P=N_PARAMS):
     """fwd = read theta + write trajectory + write x_predict; bwd = read trajectory + write d theta."""
     fwd = 4 * (P * B * S + B * S * N * T + B * S * 4 * T)
@@ -571,7 +581,7 @@ def run_loop_workload(a):
         raise SystemExit("--workload run_loop is a single-process measurement")
     legs = run_loop_legs(a, "synthetic")
     best = legs["epoch_graph_nan_check_per_epoch"]
-    print(json.dumps({
+    emit(({
         "metric": "ELBO training steps/sec through Training.run() (dr_constant_icml, n_iwae=200)", "value": best["value"],
         "unit": "steps/s", "n_gpus": 1, "steps": best["steps"], "warmup": 2 * 7, "ms_per_step": best["ms_per_step"],
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
@@ -770,7 +780,7 @@ def shard_emulation_child(a):
                 rows[str(N)]["predicted_speedup"] = t1 / tN
                 rows[str(N)]["predicted_efficiency"] = t1 / tN / N
         table[name] = rows
-    print(json.dumps(table))
+    emit(table)
 
 
 def shard_emulation(a):
@@ -949,7 +959,7 @@ def main():
         plain = run_plain_ms(a)
         legs["plain_ms_per_step"] = plain
         legs["distributed_path_world1"] = distributed_leg_guarded(a, plain)
-        print(json.dumps(legs))
+        emit(legs)
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
@@ -964,7 +974,7 @@ def main():
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus),
                "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-        raise SystemExit(subprocess.call(cmd, env=env))
+        raise SystemExit(subprocess.call(cmd, env=env, stdout=_OUT))  # (the ranks inherit the REAL stdout for their one line)
     a.solver_given = a.solver is not None
     if a.workload != "config2":
         if not torch.cuda.is_available():
@@ -973,7 +983,7 @@ def main():
             return run_loop_workload(a)
         out = run_workload(a, a.workload)
         if out is not None:
-            print(json.dumps(out))
+            emit(out)
         return
     a.solver = a.solver or "rk4"
 
@@ -1053,7 +1063,7 @@ def main():
 
         def fire():
             if rank == 0:
-                print(json.dumps(fallback), flush=True)
+                emit(fallback)
             os._exit(0)
 
         watchdog = threading.Timer(MULTI_RANK_WATCHDOG_S, fire)
@@ -1151,7 +1161,7 @@ def main():
     # ---- roofline leg: the same step, eager, with HIP events around every ODE kernel launch -----------------
     if a.roofline_steps <= 0:
         if rank == 0:
-            print(json.dumps({"metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)",
+            emit(({"metric": "ELBO training steps/sec (dr_constant_icml, n_iwae=200)",
                               "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps,
                               "warmup": a.warmup, "ms_per_step": 1e3 * elapsed / a.steps, "launch": launch_mode,
                               "final_loss": final_loss, "world_size": world, "rank_devices": rank_devices,
@@ -1293,8 +1303,13 @@ def main():
             out["newton_iters"] = {k: (loops[k] or {}).get("newton_iters") for k in ("run_loop", "real_plate")}
         if a.shard_emulation:
             out["shard_emulation"] = shard_emulation(a)
-    print(json.dumps(out))
+    emit(out)
 
 
 if __name__ == "__main__":
+    # The contract is ONE line on stdout.  The package mirrors the reference's console messages ("Initialising encoder" ...) and
+    # libraries print what they like: everything but the line goes to stderr, from python and from native code alike.
+    _OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
+    sys.stdout = sys.stderr
     main()

@@ -827,6 +827,7 @@ def test_bench_gpus_2_self_launch_on_one_device():
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout[-3000:]
+    assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[-3000:]  # the line and nothing else on stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and np.isfinite(out["final_loss"])
 
