@@ -202,17 +202,36 @@ struct BbSplitT {
   }
 };
 
-// grid: one block of two wavefronts per 16 trajectories
+// Where the wavefronts land (tests/micro/wave_placement.hip, profiles/r05_wave_placement.log): the dispatcher deals a block's
+// wavefronts to the CU's SIMDs in a fixed cyclic order, and the next block of the same CU (block j + 256 at 450 blocks: 194
+// of the 256 CUs hold two) starts ONE position behind the first one's start.  With two wavefronts per block that is
+// [p, p+1] and [p+1, p+2]: the second group's state wavefront shares a SIMD with the first group's precision wavefront while
+// a fourth SIMD idles; with the adjoint's four in the order A, B, H1, H2 it pairs B with the other group's A.  So:
+//   * the forward launches FOUR wavefronts per group and uses wavefronts 0 and 2 (A, B); 1 and 3 help with the sampling
+//     stage and leave: [p, p+2] and [p+1, p+3], every chain on a SIMD of its own;
+//   * the adjoint's wavefronts take their roles in the order A, H1, B, H2, which pairs every chain wavefront of one group
+//     with a Gram helper of the other.
+#ifndef VIHDS_BB_FWD_WAVES
+#define VIHDS_BB_FWD_WAVES 4
+#endif
+#ifndef VIHDS_BB_BWD_ORDER
+#define VIHDS_BB_BWD_ORDER 0x3120  // role of wavefront w = nibble w: A(0), H1(2), B(1), H2(3)
+#endif
+constexpr int kBbFwdThreads = 64 * VIHDS_BB_FWD_WAVES;
+
+// grid: one block per 16 trajectories, two working wavefronts (see above)
 template <class K, int SOLVER, bool THETA>
 __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaStageArgs* ts, int nb_max) {
   // THETA: the sampling stage and condition_theta first, for the block's sixteen trajectories (vihds_theta_ode_fwd)
   if constexpr (THETA) {
     extern __shared__ float bb_theta_scratch[];
-    theta_stage_block<128>(a, *ts, blockIdx.x * K::TPW, K::TPW, nb_max, bb_theta_scratch);
+    theta_stage_block<kBbFwdThreads>(a, *ts, blockIdx.x * K::TPW, K::TPW, nb_max, bb_theta_scratch);
   }
   using S = BbSplitT<K>;
   __shared__ float pub[S::LDS_FWD];
-  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (VIHDS_BB_FWD_WAVES == 4 && (wave & 1)) return;  // (a finished wavefront no longer counts at the workgroup barrier)
+  const int role = VIHDS_BB_FWD_WAVES == 4 ? wave >> 1 : wave;
   const int jj = lane & 15, q = lane >> 4;
   const int i0 = blockIdx.x * K::TPW + jj;
   const bool live = i0 < a.n;
@@ -272,11 +291,11 @@ __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaS
   }
 }
 template <class K, int SOLVER>
-__global__ void __launch_bounds__(128) bb_split_fwd_kernel(OdeArgs a) {
+__global__ void __launch_bounds__(kBbFwdThreads) bb_split_fwd_kernel(OdeArgs a) {
   bb_split_fwd_body<K, SOLVER, false>(a, nullptr, 0);
 }
 template <class K, int SOLVER>
-__global__ void __launch_bounds__(128) bb_split_theta_fwd_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
+__global__ void __launch_bounds__(kBbFwdThreads) bb_split_theta_fwd_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
   bb_split_fwd_body<K, SOLVER, true>(a, &t, nb_max);
 }
 
@@ -290,7 +309,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   using S = BbSplitT<K>;
   using BB = typename K::BB;
   __shared__ __attribute__((aligned(16))) float lds[S::LDS_BWD];
-  const int lane = threadIdx.x & 63, role = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, role = (VIHDS_BB_BWD_ORDER >> (4 * (threadIdx.x >> 6))) & 3;
   const int jj = lane & 15, q = lane >> 4;
   const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
   constexpr int NIN = S::n_in(SOLVER), NVJP = S::n_vjp(SOLVER);
@@ -683,7 +702,7 @@ template <class K, int SV>
 inline int launch_bb_split_solver(bool backward, const OdeArgs& a, hipStream_t st) {
   const dim3 grid(K::gram_groups(a.n));
   if (backward) hipLaunchKernelGGL((bb_split_bwd_kernel<K, SV>), grid, dim3(256), 0, st, a);
-  else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(128), 0, st, a);
+  else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(kBbFwdThreads), 0, st, a);
   return VIHDS_OK;
 }
 // ... with the direction a compile-time choice: a translation unit that only launches forwards holds no adjoint kernel (the
@@ -698,7 +717,7 @@ inline int launch_bb_split_dir(int solver, const OdeArgs& a, hipStream_t st, con
       const size_t lds = sizeof(float) * theta_stage_lds_floats(nb_max, ts->P, K::TPW);
       if (lds > 48 * 1024) return VIHDS_E_UNSUPPORTED;
 #define VIHDS_BB_TH(SV)                                                                                                  \
-  case SV: hipLaunchKernelGGL((bb_split_theta_fwd_kernel<K, SV>), grid, dim3(128), lds, st, a, nb_max, *ts); return VIHDS_OK;
+  case SV: hipLaunchKernelGGL((bb_split_theta_fwd_kernel<K, SV>), grid, dim3(kBbFwdThreads), lds, st, a, nb_max, *ts); return VIHDS_OK;
       switch (solver) {
         VIHDS_BB_TH(VIHDS_SOLVER_MODEULER)
         VIHDS_BB_TH(VIHDS_SOLVER_MODEULERWHILE)
@@ -713,7 +732,7 @@ inline int launch_bb_split_dir(int solver, const OdeArgs& a, hipStream_t st, con
 #define VIHDS_BB_DIR(SV)                                                                                   \
   case SV:                                                                                                 \
     if constexpr (BACKWARD) hipLaunchKernelGGL((bb_split_bwd_kernel<K, SV>), grid, dim3(256), 0, st, a);   \
-    else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(128), 0, st, a);                      \
+    else hipLaunchKernelGGL((bb_split_fwd_kernel<K, SV>), grid, dim3(kBbFwdThreads), 0, st, a);                     \
     return VIHDS_OK;
   switch (solver) {
     VIHDS_BB_DIR(VIHDS_SOLVER_MODEULER)
