@@ -13,6 +13,11 @@ int launch_dr_blackbox_split_fwd(int solver, const OdeArgs& a, hipStream_t st) {
   return launch_bb_split_dir<BbMfma, false>(solver, a, st, g_theta_stage);
 }
 }  // namespace vihds
+#ifdef VIHDS_BB_STAMPS
+extern "C" int vihds_debug_bb_fwd_stamps(unsigned long long* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(vihds::vihds_bb_stamp_buf), &buf, sizeof(buf));
+}
+#endif
 #else
 int launch_dr_blackbox_split_fwd(int solver, const OdeArgs& a, hipStream_t st);
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
@@ -24,7 +29,11 @@ int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t 
   // kernel_variant 4: one wavefront per 16 trajectories, the adjoint dumping every evaluation (vihds_blackbox_mfma.hpp);
   // otherwise the two networks on two wavefronts and the Gram tiles on two more (vihds_blackbox_split.hpp)
   if (a.kernel_variant == 4) return launch_bb_mfma(backward, solver, a, st);
-  if (!backward) return launch_dr_blackbox_split_fwd(solver, a, st);
+  if (!backward) {
+    const int rc = launch_dr_blackbox_split_fwd(solver, a, st);
+    // (a time grid too long for the cooperating-wavefront forward's staged inputs: the one-wavefront forward, same arithmetic)
+    return (rc == VIHDS_E_UNSUPPORTED && !g_theta_stage) ? launch_bb_mfma(false, solver, a, st) : rc;
+  }
   return launch_bb_split_dir<BbMfma, true>(solver, a, st);
 }
 int n_slots_dr_blackbox() { return BB::NSLOT; }

@@ -34,7 +34,10 @@ extern "C" int VIHDS_BB_CAT(vihds_bb_launch_, VIHDS_ONLY_SOLVER)(bool backward, 
 #if VIHDS_ONLY_SOLVER <= 4
   static_assert(VIHDS_SOLVER_RK4 == 4 && VIHDS_SOLVER_MODEULER == 0, "fixed-grid schemes are solvers 0..4");
   if constexpr (BBV_MFMA)
-    if (bbv_takes_mfma(solver, a, ctl)) return launch_bb_split_solver<KV, VIHDS_ONLY_SOLVER>(backward, a, st);
+    if (bbv_takes_mfma(solver, a, ctl)) {
+      const int rc = launch_bb_split_solver<KV, VIHDS_ONLY_SOLVER>(backward, a, st);
+      if (rc != VIHDS_E_UNSUPPORTED) return rc;  // (forward with a time grid too long for its staged inputs: the VALU kernel)
+    }
 #endif
   g_adaptive_ctl = ctl;
   const int rc = launch_ode<BBV>(backward, solver, a, st);
