@@ -242,6 +242,8 @@ WORKLOAD_TABLE = {
     "config2": ("dr_constant_icml", 36, 200, "rk4", "train", "hbm", "configs[1]"),
     "config3_train": ("dr_constant_icml", 36, 1000, "rk4", "train", "hbm", "configs[2], training shape (one batch, n_iwae=1000)"),
     "config3_eval": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm", "configs[2], evaluation shape (all 234 rows, n_iwae=1000)"),
+    "config3_eval_online": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm",
+                            "configs[2], evaluation shape, params.online_summaries: no trajectory through HBM"),
     "config4": ("dr_blackbox_icml", 36, 200, "midpoint", "train", "mfma", "configs[3]"),
     "config5": ("relay_constant_precisions", 36, 200, "midpoint", "train", "hbm", "configs[4]"),
     # the dr_blackbox kernels with the chip FULL (2 250 groups of 16 trajectories on 1 024 SIMDs; configs[3] itself is 450): what
@@ -253,6 +255,7 @@ LAUNCH_KERNELS = {  # launch name (ops._launch) -> substrings of the kernels it 
     "ode_logp_grad": ["dr_scan_train_kernel", "dr_lane_train_kernel"],
     "ode_fwd": ["bb_split_fwd_kernel", "bb_mfma_fwd_kernel", "relay_lane_fwd_kernel", "dr_lane_fwd_kernel", "ode_fwd_kernel"],
     "ode_bwd": ["bb_split_bwd_kernel", "bb_mfma_bwd_kernel", "relay_lane_bwd_kernel", "dr_lane_bwd_kernel", "ode_bwd_kernel"],
+    "ode_fwd_summaries": ["ode_fwd_summ_kernel"],
 }
 
 
@@ -303,6 +306,8 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
     dev = "cuda:%d" % local_rank
     use_graph = not a.eager
     extra = {}
+    if a.online_summaries or name.endswith("_online"):
+        extra["online_summaries"] = True
     if wl == "dr_constant_icml":
         extra["fused_ode_training"] = not a.two_kernel_ode
         extra["fused_iwae_backward"] = not a.no_fused_iwae
@@ -383,7 +388,10 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
     n_eval = (T - 1) * {"euler": 1, "rk4": 4}.get(solver, 2)
     fwd_f = BLACKBOX_FLOP_PER_EVAL * n_eval * B * s_local
     work = {"decoder_step": (fwd_b + bwd_b + theta_b, 3 * fwd_f), "ode_logp_grad": (fwd_b + bwd_b, 3 * fwd_f),
-            "ode_fwd": (fwd_b, fwd_f), "ode_bwd": (bwd_b, 2 * fwd_f)}
+            "ode_fwd": (fwd_b, fwd_f), "ode_bwd": (bwd_b, 2 * fwd_f),
+            # (the evaluation's second forward pass: the same fixed numerator -- what the pair "forward with the trajectory
+            # through HBM" moves per pass -- although this kernel itself moves theta and 26 MB of partial sums: see traffic)
+            "ode_fwd_summaries": (fwd_b, fwd_f)}
     timed = {k: time_launch(fn, max(10, a.roofline_steps // 2)) for k, fn in rec.calls.items() if k in work}
     import glob
     pmc = {}
@@ -447,6 +455,8 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
         "config": {"workload": "%s (BASELINE.json %s): B=%d rows x n_iwae=%d, N=%d states, T=%d, P=%d, %s, %s"
                                % (wl, cfg_note, B, S, N, T, P, solver,
                                   "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" if mode == "train" else
+                                  "evaluation pass (forward without grad writing the log-likelihoods only, the importance-weighted summaries from a second forward launch that adds them up on the way: no trajectory through HBM; the [B,.,T] summaries, q and the ELBO are copied to the host, the theta samples [P,B,S] stay on the device until Results.theta / dump() reads them)"
+                                  if bool(settings.params.get("online_summaries", False)) else
                                   "evaluation pass (forward without grad, trajectories through HBM, IW summaries on device; the [B,.,T] summaries, q and the ELBO are copied to the host, the theta samples [P,B,S] stay on the device until Results.theta / dump() reads them)"),
                    "name": name, "solver": solver, "n_iwae_per_gpu": s_local, "n_iwae_global": S,
                    "rows_global": B * (world if replica is not None else 1),
@@ -818,13 +828,15 @@ def other_config_legs(a, dev):
     driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
     error; it never takes the headline line with it."""
     legs = {}
-    for name in ("config3_train", "config3_eval", "config4", "config5", "config4_s1000"):
+    for name in ("config3_train", "config3_eval", "config3_eval_online", "config4", "config5", "config4_s1000"):
         t0 = time.perf_counter()
         try:
-            if name == "config4_s1000":  # (no CPU leg: 36 000 trajectories of eager [B,S] tensors would be a minute per step)
+            # (no CPU leg: 36 000 trajectories of eager [B,S] tensors would be a minute per step; config3_eval has the pass's)
+            no_cpu = name in ("config4_s1000", "config3_eval_online")
+            if no_cpu:
                 keep_cb, a.no_cpu_baseline = a.no_cpu_baseline, True
             out = run_workload(a, name, min_seconds=a.leg_seconds, bounded_cpu=True)
-            if name == "config4_s1000":
+            if no_cpu:
                 a.no_cpu_baseline = keep_cb
             keep = ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "config", "final_objective", "roofline",
                     "cpu_baseline", "speedup_vs_cpu_restatement")
@@ -913,6 +925,10 @@ def main():
     ap.add_argument("--two-kernel-ode", action="store_true",
                     help="integrate and differentiate with vihds_ode_fwd + vihds_ode_bwd (trajectory through HBM) "
                          "instead of the fused vihds_ode_logp_grad")
+    ap.add_argument("--online-summaries", action="store_true",
+                    help="evaluation pass: a second forward launch adds the importance-weighted summaries up on the way instead "
+                         "of writing the trajectory and streaming it back (params.online_summaries: true; 0.1 GB instead of "
+                         "1.33 GB of HBM traffic per pass, but slower: the integration is VALU-bound)")
     ap.add_argument("--no-fused-iwae", action="store_true",
                     help="keep the IWAE loss as its own launch instead of forming it inside the theta-adjoint launch")
     ap.add_argument("--no-step-tail", action="store_true",

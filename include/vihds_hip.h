@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define VIHDS_ABI_VERSION 13
+#define VIHDS_ABI_VERSION 14
 
 /* error codes */
 #define VIHDS_OK 0
@@ -429,6 +429,23 @@ int vihds_iw_summaries_states(int B, int S, int T, int N_total, int n_species, i
                               const float* lse, const float* traj, const float* theta, const int* prec_rows,
                               float* iw_predict_mu, float* iw_predict_std, float* iw_states, float* iw_variance,
                               void* stream);
+
+/* The same summaries WITHOUT the trajectory's round trip through HBM (round 5): the evaluation pass calls vihds_ode_fwd with
+ * traj == NULL and xpred == NULL (log-likelihoods only), forms log_w / lse (vihds_iwae_loss_fwd), and this entry point
+ * integrates a second time -- the same kernel arithmetic, so the trajectory it sums is bit for bit the one the weights came
+ * from -- adding up  w y,  w x_predict,  w (x_predict^2 + 1 / precision)  and  w / precision  per time point on the way
+ * (w = exp(log_w - lse)): 26 MB of per-wavefront partial rows instead of 644 MB written and read back at B = 234, S = 1 000.
+ * Models: all but dr_blackbox; fixed-grid solvers (VIHDS_E_UNSUPPORTED otherwise: vihds_ode_fwd + vihds_iw_summaries_states).
+ *   workspace  vihds_ode_fwd_summaries_workspace_floats(p) floats
+ *   outputs    as vihds_iw_summaries (n_species = the model's states without the four precision states of *_precisions)
+ * vihds_ode_fwd_summaries_supported(p): 1 when the problem's vihds_ode_fwd launch is the thread-per-trajectory kernel this
+ * pass repeats (kernel_variant 1, or an evaluation-sized launch) and the model / solver are served. */
+int vihds_ode_fwd_summaries_supported(const vihds_ode_problem* p);
+long long vihds_ode_fwd_summaries_workspace_floats(const vihds_ode_problem* p);
+int vihds_ode_fwd_summaries(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                            const float* times, const float* weights, const float* log_w, const float* lse,
+                            float* workspace, float* iw_predict_mu, float* iw_predict_std, float* iw_states,
+                            float* iw_variance, void* stream);
 
 /* q(theta | data) encoder (vihds/encoders.py): ConditionalEncoder.forward :49-55 (Conv1d -> AvgPool1d(stride 1) ->
  * Linear -> tanh), the per-parameter Linear(n,1) heads of Q_Local :143-169 and Q_Global_Cond :187-213, Q_Global's free

@@ -904,3 +904,38 @@ def test_epoch_graph_walks_the_same_steps_as_one_graph_per_step():
     out = training.run()
     assert training._steps == 9 and any(k[0] == "epoch" for k in training._graphs if isinstance(k[0], str))
     assert out is not None and np.isfinite(float(out.elbo))
+
+
+@pytest.mark.parametrize("model_name,graph", [("dr_constant_icml", False), ("dr_constant_icml", True),
+                                              ("relay_constant_precisions", False)])
+def test_evaluation_with_online_summaries_gives_the_two_kernel_results(model_name, graph):
+    """params.online_summaries (default: the evaluation's forward launch writes the log-likelihoods only, the summaries come
+    from a second forward launch that adds them up on the way: no trajectory through HBM) against the pass that stores the
+    trajectory and streams it back, at an evaluation-sized launch (24 rows x 1 000 samples), from the same generator
+    states: the same ELBO and theta samples bit for bit, the summaries to rounding (another summation order); eagerly and
+    from the captured evaluation graph; a plugin that asks for the trajectory after all gets it."""
+    from vihds import synthetic
+
+    outs = []
+    for online in (True, False):
+        args, settings, data, parameters, model, training = synthetic.build(
+            model_name, 24, 16, solver="rk4", device="cuda:0", seed=3, u_rng="kernel", conditioner_rng="kernel",
+            hip_graph=graph, nan_check_every=0, learning_rate=0.001, online_summaries=online)
+        model.eval()
+        res = [training.evaluate(training.train_data, 1000) for _ in range(2)]
+        sol = model.decoder.ode_model._last
+        assert (getattr(sol, "online_summaries", None) is not None) == online
+        outs.append(res[-1])
+        if online and not graph:
+            with torch.no_grad():
+                results, theta, q, p = model(training.train_data, 1000)
+                x_states, x_predict, precisions = tuple(results)
+            assert x_states.shape[:2] == (24, 1000) and torch.isfinite(x_states).all()
+    a, b = outs
+    assert float(a.elbo) == float(b.elbo)
+    for k in ("iw_predict_mu", "iw_states", "iw_variance"):
+        x, y = np.asarray(getattr(a, k)), np.asarray(getattr(b, k))
+        assert x.shape == y.shape and np.abs(x - y).max() <= 2e-5 * np.abs(y).max(), k
+    x, y = np.asarray(a.iw_predict_std), np.asarray(b.iw_predict_std)
+    ok = np.isfinite(x) & np.isfinite(y)
+    assert ok.mean() > 0.95 and np.abs(x[ok] - y[ok]).max() <= 2e-3 * np.abs(y[ok]).max()

@@ -2373,3 +2373,72 @@ def test_adaptive_solvers_at_torchdiffeqs_default_tolerances(solver):
               else ode.last_adaptive_stats["accepted"] + 1)
     print("%s at rtol 1e-7 / atol 1e-9: %d accepted grid points" % (solver, n_grid))
     assert torch.isfinite(x_states).all() and n_grid >= 2
+
+
+# ---------------------------------------------------------------------------------------------------
+# evaluation summaries from a second forward pass (vihds_ode_fwd_summaries: no trajectory through HBM)
+# ---------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", CONST_PREC_FIXTURES + NEURAL_PREC_FIXTURES)
+def test_online_summaries_match_oracle_and_the_two_kernel_form(name):
+    """vihds_ode_fwd_summaries on every fixture: against oracle.importance_weighted_summaries fed the reference's own
+    x_predict / x_states / precisions, against the reference's Results.init where the fixture holds it, and against the
+    two-kernel form (vihds_ode_fwd with the trajectory stored + vihds_iw_summaries_states) on the same weights."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture(name)
+    if "dr_blackbox" in name:
+        pytest.skip("dr_blackbox keeps the two-kernel form")
+    th, row_of = H.pack_theta(fx, DEV)
+    spec = H.spec_for(fx, row_of, th.shape[0], None, 1)  # (thread-per-trajectory: the kernel the second pass repeats)
+    weights = _flat_prec_weights(fx)
+    cond, times, obs = fx.t("inputs", DEV), fx.t("times", DEV), fx.t("observations", DEV)
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, weights)
+    loss, log_w, lse = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
+    mu, sd, st, var = ops.ode_fwd_summaries(spec, th, cond, times, None, weights, log_w, lse)
+    neural = name in NEURAL_PREC_FIXTURES
+    n_species = traj.shape[1] - (4 if neural else 0)
+    prow = None if neural else [row_of[n] for n in H.PREC_NAMES]
+    m2, s2, t2, v2 = ops.iw_summaries(log_w, lse, traj, None, n_species, theta=None if neural else th, prec_rows=prow,
+                                      observe_kind="direct" if name.startswith("auto_constant") else "default")
+    assert rel_err(mu, m2, dim=1) < 1e-5 and rel_err(st, t2, dim=1) < 1e-5 and rel_err(var, v2, dim=1) < 1e-5
+    ok = torch.isfinite(s2) & torch.isfinite(sd)
+    assert ok.float().mean() > 0.9 and rel_err(sd[ok], s2[ok]) < 1e-3
+    stride = int(fx.z["sample_stride"]) if "sample_stride" in fx.z else 1
+    if stride == 1:
+        r_mu, r_sd, r_st, r_var = O.importance_weighted_summaries(log_w.cpu(), fx.t("x_predict"), fx.t("x_states"),
+                                                                  fx.t("precisions"))
+        assert rel_err(mu, r_mu, dim=1) < TOL and rel_err(st, r_st, dim=1) < TOL and rel_err(var, r_var, dim=1) < TOL
+        # (the standard deviation is what is left of a cancellation -- with one sample per row exactly 1 / precision out
+        # of x^2 + 1 / precision - x^2 -- so it is the SUMMED quantity, the second moment, that is compared)
+        okr = torch.isfinite(r_sd) & torch.isfinite(sd.cpu())
+        assert rel_err((sd.cpu() ** 2 + mu.cpu() ** 2)[okr], (r_sd ** 2 + r_mu ** 2)[okr]) < TOL
+    if "iw_predict_mu" in fx.z:
+        assert rel_err(mu, fx.t("iw_predict_mu"), dim=1) < TOL and rel_err(st, fx.t("iw_states"), dim=1) < TOL
+        assert rel_err(var, fx.t("iw_variance"), dim=1) < TOL
+
+
+@pytest.mark.parametrize("S,solver", [(1000, "rk4"), (77, "midpoint"), (257, "modeuler"), (1, "euler"), (513, "rk4")])
+def test_online_summaries_at_ragged_sample_counts(S, solver):
+    """Sample counts that are not a multiple of the block (idle lanes shadow the row's last sample at weight 0), a single
+    sample, several blocks per row: vihds_ode_fwd_summaries against the two-kernel form on the same trajectories."""
+    from vihds import hip, ops
+
+    B, T = 5, 23
+    g = torch.Generator().manual_seed(7 + S)
+    slots = hip.model_slots("dr_constant")
+    th = torch.stack([torch.rand(B, S, generator=g) * 0.9 + 0.1 for _ in slots]).to(DEV)
+    row_of = {n: i for i, n in enumerate(slots)}
+    spec = ops.OdeProblemSpec("dr_constant", solver, row_of, len(slots), C=2, kernel_variant=1)
+    cond = torch.log1p(torch.rand(B, 2, generator=g) * 100.0).to(DEV)
+    times = (torch.arange(T, dtype=torch.float32) * 0.25).to(DEV)
+    obs = torch.rand(B, 4, T, generator=g).to(DEV)
+    traj, xpred, logp = ops.OdeSolveObserve.apply(spec, th, cond, times, obs, None, None, None, None, False)
+    log_w = logp.sum(0) * 0.01 + torch.randn(B, S, generator=g).to(DEV)
+    lse = torch.logsumexp(log_w, 1)
+    prow = [row_of[n] for n in ("prec_x", "prec_rfp", "prec_yfp", "prec_cfp")]
+    m2, s2, t2, v2 = ops.iw_summaries(log_w, lse, traj, None, traj.shape[1], theta=th, prec_rows=prow)
+    mu, sd, st, var = ops.ode_fwd_summaries(spec, th, cond, times, None, None, log_w, lse)
+    assert rel_err(mu, m2, dim=1) < 1e-5 and rel_err(st, t2, dim=1) < 1e-5 and rel_err(var, v2, dim=1) < 1e-5
+    ok = torch.isfinite(s2) & torch.isfinite(sd)
+    assert ok.float().mean() > 0.9 and rel_err(sd[ok], s2[ok]) < 1e-3

@@ -25,7 +25,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name), "libvihds_hip.so does not export %s" % name
     assert sorted(hip.exported_symbols()) == declared
-    assert lib.vihds_abi_version() == 13
+    assert lib.vihds_abi_version() == 14
 
 
 def test_model_slot_tables():

@@ -55,6 +55,7 @@ thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;  // this library's own (it d
 // (never set here: the device-resident adaptive solver does not serve models with shared neural weights, but launch_ode
 // looks at it -- without this definition the library did not load: an undefined symbol only libvihds_hip.so has)
 thread_local AdaptiveDevCtl* g_adaptive_dev = nullptr;
+thread_local const SummArgs* g_summ = nullptr;  // (the same: vihds_ode_fwd_summaries does not serve dr_blackbox)
 static int n_weights_sized(int n_const) { return BBV::n_weights(n_const); }
 static long long gram_floats_sized(int n) { return BBV_MFMA ? (long long)KV::gram_floats(n) : -1; }
 static void gram_reduce_sized(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {

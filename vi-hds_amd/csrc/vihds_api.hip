@@ -22,6 +22,7 @@ namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
 thread_local AdaptiveDevCtl* g_adaptive_dev = nullptr;
 thread_local const ThetaStageArgs* g_theta_stage = nullptr;
+thread_local const SummArgs* g_summ = nullptr;
 // per-model translation units (ode_<model>.hip)
 #define VIHDS_DECL(name)                                                        \
   int launch_##name(bool backward, int solver, const OdeArgs& a, hipStream_t st); \
@@ -477,6 +478,97 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
   rc = sized ? sized->launch(false, p->solver, a, (hipStream_t)stream, nullptr) : e->launch(false, p->solver, a, (hipStream_t)stream);
   if (rc) return fail(rc, "unknown solver");
   return check_hip("vihds_ode_fwd launch");
+}
+
+// ---- evaluation summaries by a second forward pass (csrc/vihds_ode_kernels.hpp: ode_fwd_summ_kernel) ---------------------
+namespace vihds {
+// partial [B][nch][T][nvp] -> the four summaries, chunks added in a fixed order; one thread per (data row, time point)
+// (var_at_first: constant precisions -- the sums of w / precision were taken at the first time point only)
+__global__ void __launch_bounds__(256) summ_finish_kernel(int B, int T, int nch, int nvp, int ns, int var_at_first,
+                                                          const float* partial, float* mu, float* sd, float* states,
+                                                          float* var) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= B * T) return;
+  const int b = idx / T, t = idx - b * T;
+  const float* src = partial + ((size_t)b * nch * T + t) * nvp;
+  const float* src0 = partial + ((size_t)b * nch * T) * nvp;
+  for (int v = 0; v < ns + 12; ++v) {
+    float r = 0.f;
+    const float* from = (var_at_first && v >= ns + 8) ? src0 : src;
+    for (int ch = 0; ch < nch; ++ch) r += from[(size_t)ch * T * nvp + v];
+    if (v < ns) states[((size_t)b * ns + v) * T + t] = r;
+    else if (v < ns + 4) mu[((size_t)b * 4 + (v - ns)) * T + t] = r;
+    else if (v < ns + 8) {
+      const size_t o = ((size_t)b * 4 + (v - ns - 4)) * T + t;
+      const float m = mu[o];  // (written by this thread two rounds ago)
+      sd[o] = sqrtf(r - m * m);
+    } else var[((size_t)b * 4 + (v - ns - 8)) * T + t] = r;
+  }
+}
+}  // namespace vihds
+static int summ_species(const vihds_ode_problem* p, const ModelEntry* e) {
+  const int n_states = vihds_problem_n_states(p);
+  return n_states < 0 ? n_states : (e->neural_prec ? n_states - 4 : n_states);
+}
+int vihds_ode_fwd_summaries_supported(const vihds_ode_problem* p) {
+  if (!p) return 0;
+  const ModelEntry* e = entry(p->model);
+  if (!e || p->model == VIHDS_MODEL_DR_BLACKBOX || solver_is_adaptive(p->solver)) return 0;
+  if (e->neural_prec && p->n_hidden_prec > 256) return 0;
+  // ... and the forward launch of this problem is the thread-per-trajectory kernel (whose integration the second pass
+  // repeats bit for bit): asked for, or an evaluation-sized launch
+  static const long long lane_max = [] {
+    const char* ev = std::getenv("VIHDS_LANE_SPLIT_MAX_N");
+    return ev ? std::atoll(ev) : 16384LL;
+  }();
+  const long long n = (long long)p->B * p->S;
+  return p->kernel_variant == 1 || (p->kernel_variant == 0 && n > lane_max);
+}
+long long vihds_ode_fwd_summaries_workspace_floats(const vihds_ode_problem* p) {
+  if (!p) return VIHDS_E_BADARG;
+  const ModelEntry* e = entry(p->model);
+  if (!e) return VIHDS_E_UNSUPPORTED;
+  const int ns = summ_species(p, e);
+  if (ns < 0) return ns;
+  const long long nvp = (ns + 12 + 3) & ~3, nch = ((p->S + 255) / 256) * 4;
+  return (long long)p->B * nch * p->T * nvp;
+}
+int vihds_ode_fwd_summaries(const vihds_ode_problem* p, const float* theta, const float* cond, const float* dev1hot,
+                            const float* times, const float* weights, const float* log_w, const float* lse,
+                            float* workspace, float* iw_predict_mu, float* iw_predict_std, float* iw_states,
+                            float* iw_variance, void* stream) {
+  if (!p || !theta || !times || !log_w || !lse || !workspace || !iw_predict_mu || !iw_predict_std || !iw_states || !iw_variance)
+    return fail(VIHDS_E_BADARG, "null argument");
+  const ModelEntry* e = entry(p->model);
+  if (!e) return fail(VIHDS_E_UNSUPPORTED, "model not supported by this build");
+  if (p->model == VIHDS_MODEL_DR_BLACKBOX || solver_is_adaptive(p->solver))
+    return VIHDS_E_UNSUPPORTED;  // (dr_blackbox and the adaptive pairs keep vihds_ode_fwd + vihds_iw_summaries_states)
+  if (e->neural_prec) {
+    if (!weights) return fail(VIHDS_E_BADARG, "model has neural blocks: weights must not be NULL");
+    if (p->n_hidden_prec > 256) return fail(VIHDS_E_UNSUPPORTED, "neural precisions: at most 256 hidden units");
+  }
+  OdeArgs a;
+  int rc = build_args(p, e, a, nullptr);
+  if (rc) return rc;
+  if (p->C > 0 && !cond) return fail(VIHDS_E_BADARG, "null cond");
+  a.theta = theta; a.cond = cond; a.dev1hot = dev1hot; a.times = times; a.obs = nullptr; a.weights = weights;
+  a.traj = nullptr; a.xpred = nullptr; a.logp = nullptr;
+  a.kernel_variant = 1;  // (every model's launcher sends this to launch_ode: the thread-per-trajectory kernels)
+  const int ns = summ_species(p, e);
+  if (ns < 0) return ns;
+  SummArgs sa;
+  sa.log_w = log_w; sa.lse = lse; sa.partial = workspace;
+  sa.nch = ((p->S + 255) / 256) * 4;
+  sa.nvp = (ns + 12 + 3) & ~3;
+  g_summ = &sa;
+  rc = e->launch(false, p->solver, a, (hipStream_t)stream);
+  g_summ = nullptr;
+  if (rc) return rc == VIHDS_E_UNSUPPORTED ? rc : fail(rc, "vihds_ode_fwd_summaries: launch refused");
+  const int items = p->B * p->T;
+  hipLaunchKernelGGL(vihds::summ_finish_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->B, p->T,
+                     sa.nch, sa.nvp, ns, e->neural_prec ? 0 : 1, workspace, iw_predict_mu, iw_predict_std, iw_states,
+                     iw_variance);
+  return check_hip("vihds_ode_fwd_summaries launch");
 }
 
 long long vihds_ode_adaptive_workspace_floats(const vihds_ode_problem* p) {

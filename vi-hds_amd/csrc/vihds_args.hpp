@@ -67,4 +67,12 @@ struct ThetaStageArgs {
   const float *off_w, *off_b;
 };
 
+// vihds_ode_fwd_summaries: the evaluation's second forward pass (csrc/vihds_ode_kernels.hpp, ode_fwd_summ_kernel)
+struct SummArgs {
+  const float* log_w;  // [B][S] unnormalised log importance weights
+  const float* lse;    // [B] their row-wise logsumexp
+  float* partial;      // [B][nch][T][nvp] per-wavefront sums
+  int nch, nvp;
+};
+
 }  // namespace vihds

@@ -382,6 +382,157 @@ __global__ void __launch_bounds__(256) ode_fwd_kernel(OdeArgs a) {
   }
 }
 
+// ---- evaluation summaries without the trajectory's round trip through HBM (round 5) -------------------------------------
+// Results.init (reference vihds/utils.py:79-99) needs, per data row and time point, sums over the row's samples weighted with
+// the NORMALISED importance weights -- which exist only when every sample's last time point does.  The evaluation pass used
+// to write the trajectory (644 MB at B = 234, S = 1 000) and stream it back through vihds_iw_summaries_states; now a first
+// forward launch writes the log-likelihoods only (traj == NULL), the weights are formed, and THIS kernel integrates again
+// and adds up on the way: per time point NV = n_species + 12 weighted values per lane, summed over the wavefront with
+// gfx950's row swaps (2.5 instructions per value instead of 6 DPP additions), one partial row per wavefront and time point
+// (26 MB at that size), which summ_finish_kernel adds up in a fixed order.  The integration is ode_fwd_kernel's (same
+// ode_step, same operands): the trajectory summed here is bit for bit the one the weights were computed from.
+// grid: (ceil(S / 256), B), 256 threads: every wavefront's 64 samples belong to one data row.
+extern thread_local const SummArgs* g_summ;
+
+// v[0 .. NVP): per-lane values -> u[p] (p < NVP / 4): in the lanes of row r (lanes 16 r .. 16 r + 15) the wavefront's total of
+// value 4 p + {0, 2, 1, 3}[r]
+// (NR <= NVP / 4 output registers: only the first 4 NR values are summed.  A swap costs the issuing wavefront 15 cycles, 23
+// with a nop of its own -- tests/micro/permlane_rate.hip)
+template <int NVP, int NR>
+__device__ __forceinline__ void wave_sum_rows(const float (&v)[NVP], float (&u)[NVP / 4]) {
+  static_assert(NVP % 4 == 0 && NR <= NVP / 4, "pad the values to a multiple of four");
+  float a[2 * NR], b[2 * NR];
+#pragma unroll
+  for (int p = 0; p < 2 * NR; ++p) { a[p] = v[2 * p]; b[p] = v[2 * p + 1]; }
+  // lanes l and l ^ 32: rows 0, 1 keep value 2 p, rows 2, 3 value 2 p + 1
+  // (two swaps per asm block behind ONE s_nop: the compiler may put the copies that feed a swap right in front of its
+  // block, and the swap reads a VALU result two wait states late at the earliest)
+#pragma unroll
+  for (int p = 0; p < 2 * NR; p += 2)
+    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\tv_permlane32_swap_b32 %2, %3"
+                 : "+v"(a[p]), "+v"(b[p]), "+v"(a[p + 1]), "+v"(b[p + 1]));
+  float c[NR], d[NR];
+#pragma unroll
+  for (int p = 0; p < NR; ++p) { c[p] = a[2 * p] + b[2 * p]; d[p] = a[2 * p + 1] + b[2 * p + 1]; }
+  // rows 0 + 1 and 2 + 3 of each: one value per row
+#pragma unroll
+  for (int p = 0; p + 1 < NR; p += 2)
+    asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1\n\tv_permlane16_swap_b32 %2, %3"
+                 : "+v"(c[p]), "+v"(d[p]), "+v"(c[p + 1]), "+v"(d[p + 1]));
+  if (NR & 1) asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(c[NR - 1]), "+v"(d[NR - 1]));
+#pragma unroll
+  for (int p = 0; p < NR; ++p) u[p] = c[p] + d[p];
+  // all 16 lanes of a row: rotations by 8, 4, 2, 1 (every lane ends with the row's total), the registers side by side
+#pragma unroll
+  for (int p = 0; p < NR; ++p) u[p] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u[p]), 0x128, 0xf, 0xf, false));
+#pragma unroll
+  for (int p = 0; p < NR; ++p) u[p] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u[p]), 0x124, 0xf, 0xf, false));
+#pragma unroll
+  for (int p = 0; p < NR; ++p) u[p] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u[p]), 0x122, 0xf, 0xf, false));
+#pragma unroll
+  for (int p = 0; p < NR; ++p) u[p] += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, u[p]), 0x121, 0xf, 0xf, false));
+}
+
+template <class M>
+struct SummLayout {
+  static constexpr int NS = M::NEURAL_PREC ? M::N - 4 : M::N;  // species (the last four states of a neural-precision model are the precisions)
+  static constexpr int NV = NS + 12, NVP = (NV + 3) & ~3;      // states | w x | w (x^2 + 1 / prec) | w / prec
+};
+
+template <class M, int SOLVER>
+__global__ void __launch_bounds__(256) ode_fwd_summ_kernel(OdeArgs a, SummArgs sa) {
+  constexpr int N = M::N;
+  using L = SummLayout<M>;
+  constexpr int NS = L::NS, NVP = L::NVP;
+  __shared__ float wlds[M::NW > 0 ? M::NW : 1];
+  extern __shared__ float in_lds[];  // [T] times
+  const float* wts = stage_weights<M>(a, wlds);
+  for (int q = threadIdx.x; q < a.T; q += blockDim.x) in_lds[q] = a.times[q];
+  __syncthreads();
+  const int b = blockIdx.y;
+  const int s0 = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool live = s0 < a.S;
+  const int i = b * a.S + (live ? s0 : a.S - 1);  // (idle lanes shadow the row's last sample at weight 0)
+  float th[M::NSLOT], prec[4], c[M::NC > 0 ? M::NC : 1], p[M::NP], y[N];
+  load_theta<M>(a, i, b, th, prec, c);
+  M::prepare(th, c, p);
+  if constexpr (M::NEURAL_PREC) p[M::NP - 1] = __int_as_float(a.n_hidden_prec);
+  M::init(th, c, y);
+  const float w = live ? expf(sa.log_w[i] - sa.lse[b]) : 0.f;
+  float ivc[4];  // 1 / precision (constant precisions)
+  VIHDS_UNROLL for (int j = 0; j < 4; ++j) ivc[j] = M::NEURAL_PREC ? 0.f : 1.f / prec[j];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  // the wavefront's partial rows [T][NVP]; lane 16 r writes the values of row r (wave_sum_rows)
+  float* out = sa.partial + ((size_t)b * sa.nch + (size_t)blockIdx.x * (blockDim.x >> 6) + wave) * (size_t)a.T * NVP;
+  const int row = lane >> 4;
+  const int slot = row == 1 ? 2 : (row == 2 ? 1 : row);
+  const bool writer = (lane & 15) == 0;
+  float* p_out = out + slot;
+  const float h0 = a.times[1] - a.times[0];
+  float tA = in_lds[0], tB = in_lds[a.T > 1 ? 1 : 0];
+  __builtin_amdgcn_s_waitcnt(0);  // (nothing loaded before the loop is waited for inside it, behind the loop's stores)
+  for (int k = 0; k < a.T; ++k) {
+    const float tC = (k + 1 < a.T) ? in_lds[k + 1] : tB;
+    if (k > 0) {
+      ode_step<M, SOLVER>(tA, tB, h0, y, p, wts);
+      tA = tB;
+    }
+    tB = tC;
+    float xp[4];
+    observe<M::OBS>(y, xp);
+    float v[NVP];
+    VIHDS_UNROLL for (int j = 0; j < NVP; ++j) v[j] = 0.f;
+    VIHDS_UNROLL for (int j = 0; j < NS; ++j) v[j] = w * y[j];
+    VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
+      const float iv = M::NEURAL_PREC ? 1.f / y[NS + j] : ivc[j];  // (per-sample terms as vihds_iw_summaries forms them)
+      v[NS + j] = w * xp[j];
+      v[NS + 4 + j] = w * (xp[j] * xp[j] + iv);
+      v[NS + 8 + j] = w * iv;
+    }
+    // constant precisions: the four sums of w / precision do not depend on the time point -- they are taken at the first one
+    // only (summ_finish_kernel hands them to every time point)
+    constexpr int NR_ALL = NVP / 4, NR_STEP = M::NEURAL_PREC ? NR_ALL : (NS + 8 + 3) / 4;
+    float u[NVP / 4];
+    if (k == 0) {
+      wave_sum_rows<NVP, NR_ALL>(v, u);
+      if (writer) {
+        VIHDS_UNROLL for (int q = 0; q < NR_ALL; ++q) p_out[4 * q] = u[q];
+      }
+    } else {
+      wave_sum_rows<NVP, NR_STEP>(v, u);
+      if (writer) {
+        VIHDS_UNROLL for (int q = 0; q < NR_STEP; ++q) p_out[4 * q] = u[q];
+      }
+    }
+    p_out += NVP;
+  }
+}
+template <class M, int ONLY>
+inline int launch_fwd_summ(int solver, const OdeArgs& a, const SummArgs& sa, hipStream_t st) {
+  if constexpr (is_blackbox<M>::value) return VIHDS_E_UNSUPPORTED;
+  else {
+    if (sa.nvp != SummLayout<M>::NVP || sa.nch != ((a.S + 255) / 256) * 4) return VIHDS_E_BADARG;
+    const dim3 grid((a.S + 255) / 256, a.B);
+    const size_t lds = (size_t)a.T * sizeof(float);
+#define VIHDS_SUMM_CASE(SV)                                                                                         \
+  case SV:                                                                                                        \
+    if constexpr (ONLY < 0 || SV == ONLY) {                                                                       \
+      hipLaunchKernelGGL((ode_fwd_summ_kernel<M, SV>), grid, dim3(256), lds, st, a, sa);                           \
+      return VIHDS_OK;                                                                                            \
+    }                                                                                                             \
+    break;
+    switch (solver) {
+      VIHDS_SUMM_CASE(VIHDS_SOLVER_MODEULER)
+      VIHDS_SUMM_CASE(VIHDS_SOLVER_MODEULERWHILE)
+      VIHDS_SUMM_CASE(VIHDS_SOLVER_EULER)
+      VIHDS_SUMM_CASE(VIHDS_SOLVER_MIDPOINT)
+      VIHDS_SUMM_CASE(VIHDS_SOLVER_RK4)
+    }
+#undef VIHDS_SUMM_CASE
+    return VIHDS_E_UNSUPPORTED;  // (the adaptive pairs keep the two-kernel form)
+  }
+}
+
 // ---- backward ------------------------------------------------------------------------------------
 template <class M, int SOLVER, bool DUMP = false>
 __global__ void __launch_bounds__(256) ode_bwd_kernel(OdeArgs a) {
@@ -550,6 +701,9 @@ namespace vihds {
 
 template <class M, int ONLY = kOnlySolver>
 inline int launch_ode(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
+  if (const SummArgs* sm = g_summ) {  // vihds_ode_fwd_summaries: the evaluation's second forward pass
+    return backward ? VIHDS_E_BADARG : launch_fwd_summ<M, ONLY>(solver, a, *sm, st);
+  }
   if (AdaptiveDevCtl* dc = g_adaptive_dev) {  // vihds_ode_adaptive_fwd / _bwd: the device-resident controller and its adjoint
     dc->result = adaptive_device<M, ONLY>(solver, a, *dc, st);
     return dc->result;

@@ -182,6 +182,9 @@ _PROTOTYPES = {
     "vihds_ode_adaptive_tape_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem), _I]),
     "vihds_ode_adaptive_fwd": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
     "vihds_ode_adaptive_bwd": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _I, _P, _P, _P, _P]),
+    "vihds_ode_fwd_summaries_supported": (_I, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_fwd_summaries_workspace_floats": (ctypes.c_longlong, [ctypes.POINTER(OdeProblem)]),
+    "vihds_ode_fwd_summaries": (_I, [ctypes.POINTER(OdeProblem)] + [_P] * 13),
     "vihds_ode_adaptive_fwd_w": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _P, ctypes.c_float, ctypes.c_float, _I, _P, _P, _P]),
     "vihds_ode_adaptive_bwd_w": (_I, [ctypes.POINTER(OdeProblem), _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P]),
     "vihds_blackbox_dump_fields": (_I, []),
@@ -239,7 +242,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI is incomplete
             fn.restype = res
             fn.argtypes = args
-        if handle.vihds_abi_version() != 13:
+        if handle.vihds_abi_version() != 14:
             raise RuntimeError("libvihds_hip.so ABI version mismatch")
         _LIB = handle
     return _LIB

@@ -364,6 +364,8 @@ class OdeModel(nn.Module):
         adjoint (ops.OdeLogLikFused); returns a LazySolution, or None when the path does not apply (then use solve)."""
         import vihds.hip as hip
 
+        if observations is not None and not torch.is_grad_enabled():
+            return self._solve_for_evaluation(config, times, theta, conditions, dev_1hot, observations)
         if (observations is None or self.model_key not in self.fused_training_keys or not torch.is_grad_enabled()
                 or not default_get_value(config.params, "fused_ode_training", True)
                 or config.params.solver in hip.ADAPTIVE_SOLVERS):
@@ -385,6 +387,37 @@ class OdeModel(nn.Module):
             self._fused_unsupported[key] = True
             return None
         self._last = LazySolution(logp, lambda: self.solve(config, times, theta, conditions, dev_1hot, observations))
+        return self._last
+
+    def _solve_for_evaluation(self, config, times, theta, conditions, dev_1hot, observations):
+        """Evaluation without the trajectory's round trip (params.online_summaries: true; default OFF): the forward launch
+        writes the log-likelihoods ONLY, and Results' importance-weighted summaries come from a second forward launch that
+        adds them up on the way (ops.ode_fwd_summaries) -- the trajectory (644 MB at 234 rows x 1 000 samples) is neither
+        written nor read back: 1.33 GB -> 0.1 GB of HBM traffic per pass.  Off by default because it is SLOWER on this chip:
+        the integration is VALU-bound, not HBM-bound (second pass 267 us against 181 us for streaming the stored trajectory
+        back; 0.72 against 0.67 ms per pass).
+        Returns a LazySolution carrying `online_summaries(log_w, lse)`; trajectory and x_predict are computed (the ordinary
+        forward launch) only if somebody asks.  None where the path does not apply (dr_blackbox, the adaptive solvers,
+        launches below the evaluation size, which run other kernel families): then use solve."""
+        import vihds.hip as hip
+
+        if (not default_get_value(config.params, "online_summaries", False) or not default_get_value(config.params, "lazy_x_predict", True)
+                or config.params.solver in hip.ADAPTIVE_SOLVERS or getattr(theta, "_row_offset", None)
+                or getattr(self, "_no_online_summaries", False)):  # (Training: samples sharded over ranks)
+            return None
+        packed, row_of = theta.pack(self.kernel_slots())
+        if not packed.is_cuda:
+            return None
+        spec = self._spec(config, row_of, packed.shape[0])
+        if not ops.ode_fwd_summaries_supported(spec, packed.shape[1], packed.shape[2], times.shape[0]):
+            return None
+        dev = packed.device
+        args = (packed, conditions.to(dev), times.to(dev), dev_1hot.to(dev) if dev_1hot is not None else None,
+                self.neural_weights())
+        logp = ops.ode_logp_only(spec, args[0], args[1], args[2], observations.to(dev), args[3], args[4])
+        self._last = LazySolution(logp, lambda: self.solve(config, times, theta, conditions, dev_1hot, observations))
+        self._last.online_summaries = lambda log_w, lse: ops.ode_fwd_summaries(spec, args[0], args[1], args[2], args[3],
+                                                                               args[4], log_w, lse)
         return self._last
 
     # ---- reference entry points ---------------------------------------------------------------------

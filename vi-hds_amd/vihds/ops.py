@@ -1622,6 +1622,57 @@ def iwae_loss(logp, log_p, log_q, n_iwae_total=None, group=None, defer=False):
 OBSERVE_KINDS = {"default": 0, "direct": 1, "inducer": 2}  # VIHDS_OBS_* of include/vihds_hip.h
 
 
+def ode_logp_only(spec, theta, cond, times, obs, dev1hot, weights):
+    """The forward launch with the per-species log-likelihood as its ONLY output ([4,B,S]; no trajectory, no x_predict, no
+    autograd node): the first pass of an evaluation that takes its summaries from ode_fwd_summaries."""
+    _require_cuda(theta, cond, times, obs)
+    theta, cond, times, obs = _c(theta), _c(cond), _c(times), _c(obs)
+    R, B, S = theta.shape
+    if R != spec.n_rows:
+        raise RuntimeError("theta has %d rows, problem expects %d" % (R, spec.n_rows))
+    prob = spec.bind(B, S, times.shape[0])
+    logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
+    rc = _launch("ode_fwd", lambda: hip.lib().vihds_ode_fwd(
+        ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
+        hip.ptr(weights), None, None, hip.ptr(logp), hip.current_stream()))
+    hip.check(rc, "vihds_ode_fwd")
+    return logp
+
+
+def ode_fwd_summaries_supported(spec, B, S, T):
+    """True when the evaluation pass of this problem can take its summaries from a second forward launch
+    (vihds_ode_fwd_summaries) instead of writing the trajectory and streaming it back."""
+    return bool(hip.lib().vihds_ode_fwd_summaries_supported(ctypes.byref(spec.bind(B, S, T))))
+
+
+def ode_fwd_summaries(spec, theta, cond, times, dev1hot, weights, log_w, lse):
+    """Results.init's importance-weighted summaries (vihds/utils.py:79-99) from a SECOND forward integration with the
+    normalised weights known, added up on the way: the trajectory never goes through HBM (include/vihds_hip.h,
+    vihds_ode_fwd_summaries).  theta [R,B,S] packed as for OdeSolveObserve; log_w [B,S], lse [B].
+    Returns (iw_predict_mu [B,4,T], iw_predict_std [B,4,T], iw_states [B,n_species,T], iw_variance [B,4,T])."""
+    _require_cuda(theta, times, log_w, lse)
+    theta, cond, times, log_w, lse = _c(theta), _c(cond), _c(times), _c(log_w), _c(lse)
+    R, B, S = theta.shape
+    T = times.shape[0]
+    prob = spec.bind(B, S, T)
+    n_ws = hip.lib().vihds_ode_fwd_summaries_workspace_floats(ctypes.byref(prob))
+    if n_ws < 0:
+        hip.check(int(n_ws), "vihds_ode_fwd_summaries_workspace_floats")
+    n_species = spec.n_species
+    dev = theta.device
+    ws = torch.empty(int(n_ws), device=dev, dtype=torch.float32)
+    mu = torch.empty((B, 4, T), device=dev)
+    sd = torch.empty((B, 4, T), device=dev)
+    st = torch.empty((B, n_species, T), device=dev)
+    var = torch.empty((B, 4, T), device=dev)
+    rc = _launch("ode_fwd_summaries", lambda: hip.lib().vihds_ode_fwd_summaries(
+        ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(weights),
+        hip.ptr(log_w), hip.ptr(lse), hip.ptr(ws), hip.ptr(mu), hip.ptr(sd), hip.ptr(st), hip.ptr(var),
+        hip.current_stream()))
+    hip.check(rc, "vihds_ode_fwd_summaries")
+    return mu, sd, st, var
+
+
 def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None, observe_kind="default"):
     """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99).  xpred None: the observed signals
     are formed from the trajectory by the model's observation map (observe_kind) inside the kernel."""

@@ -222,7 +222,10 @@ class Training:
                                    log_p_by_species, elbo, log_p_theta, log_q_theta)
         output = Results()
         ode_model = self.model.decoder.ode_model
-        if sol is not None:
+        online = getattr(sol, "online_summaries", None) if self.shard is None else None
+        if online is not None:  # (evaluation without the trajectory's round trip: OdeModel._solve_for_evaluation)
+            summ = online(log_unnormalized_iws.detach(), lse.detach())
+        elif sol is not None:
             traj = sol.traj_buffer.detach()
             # (a solution without a stored x_predict -- params.lazy_x_predict -- has the kernel form it from the states)
             xpred = sol.xpred_buffer.detach() if getattr(sol, "has_x_predict", True) else None
@@ -269,6 +272,7 @@ class Training:
         Results copies to the host into one buffer -- is captured once per (data set, sample count) and replayed: the pass
         is some 25 launches whose host-side cost was a third of its time.  The draws come from the device generators, which
         advance inside the kernels, so every replay is a fresh evaluation, as in the eager pass."""
+        self.model.decoder.ode_model._no_online_summaries = self.shard is not None
         dev_ok = (self.eval_graph and self.use_graph and writer is None and self.shard is None and self.replica is None)
         if not dev_ok:
             with torch.no_grad():
