@@ -242,8 +242,8 @@ WORKLOAD_TABLE = {
     "config2": ("dr_constant_icml", 36, 200, "rk4", "train", "hbm", "configs[1]"),
     "config3_train": ("dr_constant_icml", 36, 1000, "rk4", "train", "hbm", "configs[2], training shape (one batch, n_iwae=1000)"),
     "config3_eval": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm", "configs[2], evaluation shape (all 234 rows, n_iwae=1000)"),
-    "config3_eval_online": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm",
-                            "configs[2], evaluation shape, params.online_summaries: no trajectory through HBM"),
+    "config3_eval_stored": ("dr_constant_icml", 234, 1000, "rk4", "eval", "hbm",
+                            "configs[2], evaluation shape, params.online_summaries: false -- the trajectory through HBM"),
     "config4": ("dr_blackbox_icml", 36, 200, "midpoint", "train", "mfma", "configs[3]"),
     "config5": ("relay_constant_precisions", 36, 200, "midpoint", "train", "hbm", "configs[4]"),
     # the dr_blackbox kernels with the chip FULL (2 250 groups of 16 trajectories on 1 024 SIMDs; configs[3] itself is 450): what
@@ -306,8 +306,8 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
     dev = "cuda:%d" % local_rank
     use_graph = not a.eager
     extra = {}
-    if a.online_summaries or name.endswith("_online"):
-        extra["online_summaries"] = True
+    if a.stored_trajectory_eval or name.endswith("_stored"):
+        extra["online_summaries"] = False
     if wl == "dr_constant_icml":
         extra["fused_ode_training"] = not a.two_kernel_ode
         extra["fused_iwae_backward"] = not a.no_fused_iwae
@@ -456,7 +456,7 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
                                % (wl, cfg_note, B, S, N, T, P, solver,
                                   "full training step (encoder+theta+ODE+IWAE fwd/bwd+Adam)" if mode == "train" else
                                   "evaluation pass (forward without grad writing the log-likelihoods only, the importance-weighted summaries from a second forward launch that adds them up on the way: no trajectory through HBM; the [B,.,T] summaries, q and the ELBO are copied to the host, the theta samples [P,B,S] stay on the device until Results.theta / dump() reads them)"
-                                  if bool(settings.params.get("online_summaries", False)) else
+                                  if bool(settings.params.get("online_summaries", True)) else
                                   "evaluation pass (forward without grad, trajectories through HBM, IW summaries on device; the [B,.,T] summaries, q and the ELBO are copied to the host, the theta samples [P,B,S] stay on the device until Results.theta / dump() reads them)"),
                    "name": name, "solver": solver, "n_iwae_per_gpu": s_local, "n_iwae_global": S,
                    "rows_global": B * (world if replica is not None else 1),
@@ -751,9 +751,9 @@ def distributed_path_leg(a, plain_ms):
            "--no-other-configs", "--no-strong-leg", "--roofline-steps", "0", "--seed", str(a.seed), "--lr", str(a.lr)]
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    if out.returncode != 0 or not line:
+    if not line:
         return {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
-    d = json.loads(line[-1])
+    d = json.loads(line[-1])  # (a child that died in the process group's teardown behind its line has still measured)
     keep = {k: d.get(k) for k in ("value", "ms_per_step", "steps", "launch", "world_size", "dist_backend",
                                   "collectives_in_graph", "steps_per_graph_launch")}
     keep["overhead_us_per_step_vs_plain"] = 1e3 * (d["ms_per_step"] - plain_ms)
@@ -791,6 +791,12 @@ def shard_emulation_child(a):
                 rows[str(N)]["predicted_efficiency"] = t1 / tN / N
         table[name] = rows
     emit(table)
+    try:  # (leaving the group alive made the process abort in RCCL's teardown now and then, after the line was out)
+        torch.cuda.synchronize()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+    except Exception:  # noqa: BLE001
+        pass
 
 
 def shard_emulation(a):
@@ -809,10 +815,12 @@ def shard_emulation(a):
         cmd = [sys.executable, os.path.abspath(__file__), "--emulate-shards", "--seed", str(a.seed), "--lr", str(a.lr)]
         out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        if out.returncode != 0 or not line:
+        if not line:
             table = {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
-        else:
+        else:  # (a child that printed its table and then died in the process group's teardown has still measured)
             table = json.loads(line[-1])
+            if out.returncode != 0:
+                table["child_exit_code"] = out.returncode
     except BaseException as exc:  # noqa: BLE001
         table = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     table["how"] = ("per-rank shapes of the sample-sharded configurations (n_iwae / N samples of ONE batch of 36 rows) timed on one "
@@ -828,11 +836,11 @@ def other_config_legs(a, dev):
     driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
     error; it never takes the headline line with it."""
     legs = {}
-    for name in ("config3_train", "config3_eval", "config3_eval_online", "config4", "config5", "config4_s1000"):
+    for name in ("config3_train", "config3_eval", "config3_eval_stored", "config4", "config5", "config4_s1000"):
         t0 = time.perf_counter()
         try:
             # (no CPU leg: 36 000 trajectories of eager [B,S] tensors would be a minute per step; config3_eval has the pass's)
-            no_cpu = name in ("config4_s1000", "config3_eval_online")
+            no_cpu = name in ("config4_s1000", "config3_eval_stored")
             if no_cpu:
                 keep_cb, a.no_cpu_baseline = a.no_cpu_baseline, True
             out = run_workload(a, name, min_seconds=a.leg_seconds, bounded_cpu=True)
@@ -925,10 +933,10 @@ def main():
     ap.add_argument("--two-kernel-ode", action="store_true",
                     help="integrate and differentiate with vihds_ode_fwd + vihds_ode_bwd (trajectory through HBM) "
                          "instead of the fused vihds_ode_logp_grad")
-    ap.add_argument("--online-summaries", action="store_true",
-                    help="evaluation pass: a second forward launch adds the importance-weighted summaries up on the way instead "
-                         "of writing the trajectory and streaming it back (params.online_summaries: true; 0.1 GB instead of "
-                         "1.33 GB of HBM traffic per pass, but slower: the integration is VALU-bound)")
+    ap.add_argument("--stored-trajectory-eval", action="store_true",
+                    help="evaluation pass: write the trajectory (644 MB at config 3's evaluation shape) and stream it back "
+                         "through vihds_iw_summaries_states instead of the second forward launch that adds the summaries up "
+                         "on the way (params.online_summaries: false)")
     ap.add_argument("--no-fused-iwae", action="store_true",
                     help="keep the IWAE loss as its own launch instead of forming it inside the theta-adjoint launch")
     ap.add_argument("--no-step-tail", action="store_true",
@@ -1320,6 +1328,13 @@ def main():
         if a.shard_emulation:
             out["shard_emulation"] = shard_emulation(a)
     emit(out)
+    if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1:
+        try:  # (the one-rank legs: a group left alive aborted in RCCL's teardown now and then, behind the line)
+            torch.cuda.synchronize()
+            torch.distributed.destroy_process_group()
+        except Exception:  # noqa: BLE001
+            pass
+
 
 
 if __name__ == "__main__":

@@ -5,7 +5,7 @@
 TAG=$1
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for W in config3_train config3_eval config3_eval_online config4 config5; do
+for W in config3_train config3_eval config3_eval_stored config4 config5; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -o $W -- python $R/bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline > $O/stats_$W.log 2>&1
   cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
   rm -rf $O/stats_$W
@@ -53,7 +53,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4s -o c4s -- p
 cp $(find $O/stats_c4s -name "*kernel_stats.csv" | head -1) $O/${TAG}_config4_s1000_kernel_stats.csv
 rm -rf $O/stats_c4s
 cd $R
-for W in config3_train config3_eval config3_eval_online config4 config5 config4_s1000; do
+for W in config3_train config3_eval config3_eval_stored config4 config5 config4_s1000; do
   python bench.py --workload $W > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
   tail -1 $O/${TAG}_${W}_bench.json | cut -c1-160
 done

@@ -482,27 +482,33 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
 
 // ---- evaluation summaries by a second forward pass (csrc/vihds_ode_kernels.hpp: ode_fwd_summ_kernel) ---------------------
 namespace vihds {
-// partial [B][nch][T][nvp] -> the four summaries, chunks added in a fixed order; one thread per (data row, time point)
+// partial [B][nch][T][nvp] -> the four summaries, chunks added in a fixed order; one thread per (data row, time point, value):
+// consecutive threads read consecutive floats of a partial row
 // (var_at_first: constant precisions -- the sums of w / precision were taken at the first time point only)
 __global__ void __launch_bounds__(256) summ_finish_kernel(int B, int T, int nch, int nvp, int ns, int var_at_first,
                                                           const float* partial, float* mu, float* sd, float* states,
                                                           float* var) {
-  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= B * T) return;
-  const int b = idx / T, t = idx - b * T;
-  const float* src = partial + ((size_t)b * nch * T + t) * nvp;
-  const float* src0 = partial + ((size_t)b * nch * T) * nvp;
-  for (int v = 0; v < ns + 12; ++v) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)B * T * nvp) return;
+  const int v = (int)(idx % nvp);
+  const int t = (int)((idx / nvp) % T), b = (int)(idx / ((long long)nvp * T));
+  if (v >= ns + 12) return;
+  const size_t stride = (size_t)T * nvp;
+  auto total = [&](int vv, int tt) {
+    const float* src = partial + ((size_t)b * nch * T + tt) * nvp + vv;
     float r = 0.f;
-    const float* from = (var_at_first && v >= ns + 8) ? src0 : src;
-    for (int ch = 0; ch < nch; ++ch) r += from[(size_t)ch * T * nvp + v];
-    if (v < ns) states[((size_t)b * ns + v) * T + t] = r;
-    else if (v < ns + 4) mu[((size_t)b * 4 + (v - ns)) * T + t] = r;
-    else if (v < ns + 8) {
-      const size_t o = ((size_t)b * 4 + (v - ns - 4)) * T + t;
-      const float m = mu[o];  // (written by this thread two rounds ago)
-      sd[o] = sqrtf(r - m * m);
-    } else var[((size_t)b * 4 + (v - ns - 8)) * T + t] = r;
+    for (int ch = 0; ch < nch; ++ch) r += src[(size_t)ch * stride];
+    return r;
+  };
+  if (v < ns) {
+    states[((size_t)b * ns + v) * T + t] = total(v, t);
+  } else if (v < ns + 4) {
+    mu[((size_t)b * 4 + (v - ns)) * T + t] = total(v, t);
+  } else if (v < ns + 8) {
+    const float m = total(v - 4, t), m2 = total(v, t);  // (the mean again: its own thread's sum, in the same order)
+    sd[((size_t)b * 4 + (v - ns - 4)) * T + t] = sqrtf(m2 - m * m);
+  } else {
+    var[((size_t)b * 4 + (v - ns - 8)) * T + t] = total(v, var_at_first ? 0 : t);
   }
 }
 }  // namespace vihds
@@ -564,8 +570,8 @@ int vihds_ode_fwd_summaries(const vihds_ode_problem* p, const float* theta, cons
   rc = e->launch(false, p->solver, a, (hipStream_t)stream);
   g_summ = nullptr;
   if (rc) return rc == VIHDS_E_UNSUPPORTED ? rc : fail(rc, "vihds_ode_fwd_summaries: launch refused");
-  const int items = p->B * p->T;
-  hipLaunchKernelGGL(vihds::summ_finish_kernel, dim3((items + 255) / 256), dim3(256), 0, (hipStream_t)stream, p->B, p->T,
+  const long long items = (long long)p->B * p->T * sa.nvp;
+  hipLaunchKernelGGL(vihds::summ_finish_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p->B, p->T,
                      sa.nch, sa.nvp, ns, e->neural_prec ? 0 : 1, workspace, iw_predict_mu, iw_predict_std, iw_states,
                      iw_variance);
   return check_hip("vihds_ode_fwd_summaries launch");

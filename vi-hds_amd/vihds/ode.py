@@ -390,18 +390,18 @@ class OdeModel(nn.Module):
         return self._last
 
     def _solve_for_evaluation(self, config, times, theta, conditions, dev_1hot, observations):
-        """Evaluation without the trajectory's round trip (params.online_summaries: true; default OFF): the forward launch
-        writes the log-likelihoods ONLY, and Results' importance-weighted summaries come from a second forward launch that
-        adds them up on the way (ops.ode_fwd_summaries) -- the trajectory (644 MB at 234 rows x 1 000 samples) is neither
-        written nor read back: 1.33 GB -> 0.1 GB of HBM traffic per pass.  Off by default because it is SLOWER on this chip:
-        the integration is VALU-bound, not HBM-bound (second pass 267 us against 181 us for streaming the stored trajectory
-        back; 0.72 against 0.67 ms per pass).
+        """Evaluation without the trajectory's round trip (params.online_summaries, default on): the forward launch writes
+        the log-likelihoods ONLY, and Results' importance-weighted summaries come from a second forward launch that adds
+        them up on the way (ops.ode_fwd_summaries) -- the trajectory (644 MB at 234 rows x 1 000 samples) is neither
+        allocated, written nor read back: 1.33 GB -> 0.12 GB of HBM traffic for the two launches, at the same time per pass
+        (0.68 ms either way: the integration is VALU-bound, the second one costs what streaming the trajectory back did;
+        DESIGN section 4.3).  `online_summaries: false` keeps the stored form.
         Returns a LazySolution carrying `online_summaries(log_w, lse)`; trajectory and x_predict are computed (the ordinary
         forward launch) only if somebody asks.  None where the path does not apply (dr_blackbox, the adaptive solvers,
         launches below the evaluation size, which run other kernel families): then use solve."""
         import vihds.hip as hip
 
-        if (not default_get_value(config.params, "online_summaries", False) or not default_get_value(config.params, "lazy_x_predict", True)
+        if (not default_get_value(config.params, "online_summaries", True) or not default_get_value(config.params, "lazy_x_predict", True)
                 or config.params.solver in hip.ADAPTIVE_SOLVERS or getattr(theta, "_row_offset", None)
                 or getattr(self, "_no_online_summaries", False)):  # (Training: samples sharded over ranks)
             return None
