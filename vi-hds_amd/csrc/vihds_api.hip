@@ -497,7 +497,15 @@ __global__ void __launch_bounds__(256) summ_finish_kernel(int B, int T, int nch,
   auto total = [&](int vv, int tt) {
     const float* src = partial + ((size_t)b * nch * T + tt) * nvp + vv;
     float r = 0.f;
-    for (int ch = 0; ch < nch; ++ch) r += src[(size_t)ch * stride];
+    int ch = 0;
+    for (; ch + 8 <= nch; ch += 8) {  // (eight loads in flight, added in chunk order)
+      float x[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) x[e] = src[(size_t)(ch + e) * stride];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) r += x[e];
+    }
+    for (; ch < nch; ++ch) r += src[(size_t)ch * stride];
     return r;
   };
   if (v < ns) {
