@@ -281,6 +281,26 @@ __device__ __forceinline__ Aff after(const Aff& g, const Aff& f) { return {g.a *
 __device__ __forceinline__ float lane_read(float v, int src_lane) {
   return __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute(src_lane << 2, __builtin_bit_cast(int, v)));
 }
+// The lane moves this kernel needs across the 16-lane rows, WITHOUT the LDS crossbar (round 5: each ds_bpermute was an LDS
+// round trip -- ~100 cycles before its s_waitcnt lets the wavefront go on -- 42 of them per block; tests/micro/dpp_moves.hip
+// checks every form against ds_bpermute).  All of them assume what holds at every call site: all 64 lanes active.
+//   lane - 1 / lane + 1 of the wavefront (the trajectory's first / last lane overrides what crossed from the other half)
+__device__ __forceinline__ float lane_below(float v) { return dpp_mov<0x138>(0.f, v); }  // wave_shr:1
+__device__ __forceinline__ float lane_above(float v) { return dpp_mov<0x130>(0.f, v); }  // wave_shl:1
+//   rows 1 and 3: lane 15 of the row below (row_bcast:15 into rows 1, 3; rows 0, 2 keep `keep`)
+__device__ __forceinline__ float last_of_lower_row(float keep, float v) { return dpp_mov<0x142, 0xa>(keep, v); }
+//   rows 0 and 2: lane 0 of the row above (lanes 16 / 48), by two scalar reads
+__device__ __forceinline__ float first_of_upper_row(float v, int lane) {
+  const float s0 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 16));
+  const float s1 = __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 48));
+  return lane < 32 ? s0 : s1;
+}
+//   v + v[lane ^ 16] on gfx950's row swap (through asm: the builtin's two results came back as one register)
+__device__ __forceinline__ float add_other_row(float v) {
+  float a = v, b = v;
+  asm volatile("s_nop 1\n\tv_permlane16_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
 // inclusive scan in increasing lane order: lane l ends with  m_l o m_{l-1} o ... o m_0  (lower lanes act first)
 __device__ __forceinline__ Aff scan_up32(Aff m, int lane) {
 #define VIHDS_UP(CTRL)                          \
@@ -293,8 +313,8 @@ __device__ __forceinline__ Aff scan_up32(Aff m, int lane) {
   VIHDS_UP(0x111) VIHDS_UP(0x112) VIHDS_UP(0x114) VIHDS_UP(0x118)  // row_shr:1,2,4,8 (lanes without a source keep identity)
 #undef VIHDS_UP
   Aff p;
-  p.a = lane_read(m.a, (lane & 32) + 15);
-  p.b = lane_read(m.b, (lane & 32) + 15);
+  p.a = last_of_lower_row(1.f, m.a);
+  p.b = last_of_lower_row(0.f, m.b);
   if ((lane & 31) >= 16) m = after(m, p);
   return m;
 }
@@ -310,8 +330,8 @@ __device__ __forceinline__ Aff scan_down32(Aff m, int lane) {
   VIHDS_DN(0x101) VIHDS_DN(0x102) VIHDS_DN(0x104) VIHDS_DN(0x108)  // row_shl:1,2,4,8
 #undef VIHDS_DN
   Aff p;
-  p.a = lane_read(m.a, (lane & 32) + 16);
-  p.b = lane_read(m.b, (lane & 32) + 16);
+  p.a = first_of_upper_row(m.a, lane);
+  p.b = first_of_upper_row(m.b, lane);
   if ((lane & 31) < 16) m = after(m, p);
   return m;
 }
@@ -321,8 +341,7 @@ __device__ __forceinline__ float sum32(float v, int lane) {
   v += dpp_all<0x4E>(v);   // quad_perm [2,3,0,1]
   v += dpp_all<0x141>(v);  // row_half_mirror
   v += dpp_all<0x140>(v);  // row_mirror
-  v += lane_read(v, lane ^ 16);
-  return v;
+  return add_other_row(v);
 }
 // no code motion of LDS accesses across this point (the lanes of a wavefront exchange data through LDS; the hardware
 // executes a wavefront's LDS instructions in order, so no s_barrier is needed)
@@ -639,7 +658,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       if (clog >= 2) sm += dpp_all<0x4E>(sm);   // quad_perm [2,3,0,1]
       if (clog >= 3) sm += dpp_all<0x141>(sm);  // row_half_mirror
       if (clog >= 4) sm += dpp_all<0x140>(sm);  // row_mirror
-      if (clog >= 5) sm += lane_read(sm, lane ^ 16);
+      if (clog >= 5) sm = add_other_row(sm);
       cf_val = (cf_dfl ? 1.f : 0.f) + fmaxf(sm, 0.f);
       if (cmine && cd == 0) par[t.cond_row0 + ce] = cf_val;  // (its copy in theta: with the stage's other stores, below)
     }
@@ -782,7 +801,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
       mp.b = fmaf(-da, g, u);
       const Aff inc = scan_up32(mp, lane);               // lane l: this lane's map after those of the lanes below it
       const float end_new = fmaf(inc.a, u0, inc.b);      // the new value at the first step of lane l + 1
-      float gn = lane_read(end_new, (lane & 32) + ((l + 31) & 31));
+      float gn = lane_below(end_new);  // (lane l - 1 of the trajectory; its first lane takes u0 below)
       gn = l == 0 ? u0 : gn;
       // A lane whose values are not finite has NOT settled: a poor guess far above the capacity can overflow a lane's walk
       // while the lanes below it are still converging -- maps only act upwards, so those keep converging, and each
@@ -995,7 +1014,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_UNROLL for (int j = 0; j < 4; ++j) {
       const Aff sc = scan_up32(lm[j], lane);
       const float end = fmaf(sc.a, y0[j], sc.b);
-      const float prev = lane_read(end, lane - 1);
+      const float prev = lane_below(end);
       ys[j] = l == 0 ? y0[j] : prev;
     }
   }
@@ -1041,7 +1060,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
     VIHDS_UNROLL for (int q = 0; q < 2; ++q) {
       const Aff sc = scan_up32(lm[q], lane);
       const float end = fmaf(sc.a, y0[YFP + q], sc.b);
-      const float prev = lane_read(end, lane - 1);
+      const float prev = lane_below(end);
       ys[YFP + q] = l == 0 ? y0[YFP + q] : prev;
       yend[YFP + q] = end;
     }
@@ -1111,7 +1130,7 @@ __device__ __forceinline__ void dr_scan_train_body(const OdeArgs& a, float* lds,
   };
   auto lane_entry = [&](const Aff& lm) {
     const Aff sc = scan_down32(lm, lane);  // applied to 0: Lambda at this lane's first grid point
-    const float nxt = lane_read(sc.b, lane + 1);
+    const float nxt = lane_above(sc.b);
     return l == 31 ? 0.f : nxt;
   };
   float sv[NSP], degb[NSP], lam0[NSP];
