@@ -13,7 +13,7 @@
 //           evaluation between them) from the tiles A and B leave in LDS
 // Hand-overs go through LDS with workgroup barriers (s_barrier behind lgkmcnt(0) only; global prefetches stay in flight):
 //   forward, "in" barrier: A has published the inputs (y_a, y_b | t) of an evaluation (or of a grid point's log-likelihood)
-//         in a ring entry; B reads them (and, from quarter 0's words of the same entry, the column's OD).
+//         in a double-buffered entry; B reads them (and, from quarter 0's words of the same entry, the column's OD).
 //   adjoint, "out" barrier: A and B have left their tiles and B its input adjoint; A adds it, H1 / H2 consume the tiles.
 //         There is no "in" hand-over in the adjoint: B evaluates the state network at the earlier stage points itself
 //         (round 5; B then depends on nobody, and A no longer waits for a B that could only start behind it).
@@ -28,10 +28,10 @@
 //   * the forward's stores: every wait for a load inside the time loop also waited for the step's trajectory stores
 //     (staged inputs, bb_split_fwd_body);
 //   * the forward's address arithmetic, ds_bpermute round trips and serialised sigmoid pairs.
-// Measured and NOT kept (compiled out, VIHDS_BB_FWD_RING / VIHDS_BB_BWD_RING): hand-overs through flag-counted rings that a
-// consumer polls, so that no wavefront waits for a slower phase of another -- forward 70.5 against 64.8 us with barriers,
-// adjoint 194.9 against 182.4: a polling wavefront takes issue slots from the chain wavefront of the CU's other block that
-// shares its SIMD.
+// Measured and NOT kept (round 5, commit 0b5146b has the code; profiles/r05_blackbox.md the numbers): hand-overs through
+// flag-counted LDS rings that a consumer polls, so that no wavefront waits for a slower phase of another -- forward 70.5
+// against 64.8 us with barriers, adjoint 194.9 against 182.4: a polling wavefront takes issue slots from the chain wavefront
+// of the CU's other block that shares its SIMD.
 //
 // Arithmetic: the same MFMAs on the same operands as the one-wavefront kernels; the only regrouping is that the input
 // adjoint is (W1s^T gs) + (W1p^T gp) with the two products accumulated separately instead of in one chain.
@@ -73,18 +73,14 @@ struct BbSplitT {
   using Weights = typename K::Weights;
   using WeightsT = typename K::WeightsT;
   static constexpr int MT = K::MT;
-  // LDS of the adjoint (floats): wave A's tiles [2][NTA] | wave B's tiles [2][NTB] | input adjoints, a ring [DYR][64][2] |
-  // gc [64][4] | flags (ints).  A's entry: dz, inputs, h[m], gs[m]; B's: dzp, inputs (its own copy), g[m], gp[m]
+  // LDS of the adjoint (floats): wave A's tiles [2][NTA] | wave B's tiles [2][NTB] | input adjoints [2][64][2] | gc [64][4].
+  // A's entry: dz, inputs, h[m], gs[m]; B's: dzp, inputs (its own copy), g[m], gp[m]
   static constexpr int TA_DZ = 0, TA_IN = 1, TA_H = 2, TA_GS = 2 + K::MS, NTA = 2 + 2 * K::MS;
   static constexpr int TB_DZ = 0, TB_IN = 1, TB_G = 2, TB_GP = 2 + K::MP, NTB = 2 + 2 * K::MP;
-  static constexpr int TA_WAVE = NTA * K::GT_TILE, TB_WAVE = NTB * K::GT_TILE, DYR = 4;
-  static constexpr int O_TB = 2 * TA_WAVE, O_DY = O_TB + 2 * TB_WAVE, O_GC = O_DY + DYR * 128, O_FLAGS = O_GC + 256,
-                       LDS_BWD = O_FLAGS + 8;
-  // flags of the adjoint: entries produced by A / B, entries consumed by H1 / H2, input adjoints consumed by A
-  static constexpr int FB_A = 0, FB_B = 1, FB_H1 = 2, FB_H2 = 3, FB_AC = 4;
-  // LDS of the forward (floats): a ring of FWD_RING published inputs [64][2] | flags (ints)
-  static constexpr int FWD_RING = 8, LDS_FWD = FWD_RING * 128 + 4;
-  static constexpr int F_PROD = 0, F_CONS = 1;
+  static constexpr int TA_WAVE = NTA * K::GT_TILE, TB_WAVE = NTB * K::GT_TILE;
+  static constexpr int O_TB = 2 * TA_WAVE, O_DY = O_TB + 2 * TB_WAVE, O_GC = O_DY + 2 * 128, LDS_BWD = O_GC + 256;
+  // LDS of the forward (floats): the published inputs [2][64][2], double-buffered by the hand-over's index
+  static constexpr int LDS_FWD = 2 * 128;
 
   __device__ __forceinline__ static void sync() { K::pair_sync(); }
   // sum over lanes l, l ^ 16, l ^ 32, l ^ 48 as (x + x^16) + the same of l ^ 32, on gfx950's row swaps (two VALU instructions
@@ -106,62 +102,7 @@ struct BbSplitT {
 #endif
   }
 
-  // ---- hand-overs without a barrier (round 5) ------------------------------------------------------------------------------
-  // In the forward the state wavefront never needs anything from the precision wavefront, and in the adjoint (with
-  // VIHDS_BB_BWD_DUP) the precision wavefront needs nothing from the state wavefront and the Gram helpers only consume: a
-  // workgroup barrier per hand-over made every wavefront walk at the pace of the slowest one of every PHASE.  A producer
-  // now writes entry e into a ring in LDS and then the count e + 1 into a flag word; the consumer polls the flag, reads the
-  // entry and writes its own count, which the producer looks at before it reuses a slot.  The LDS performs a wavefront's
-  // operations in the order they were issued: an entry's writes are done before the count that announces it is, and a
-  // consumer's reads behind its poll see them (compiler barriers keep the order in the instruction stream).
-  // (explicit ds_ instructions: a volatile access through a generic pointer becomes a system-scope FLAT access with a wait for
-  // every outstanding vector-memory operation behind it -- the global prefetches and stores these kernels keep in flight)
-  __device__ __forceinline__ static unsigned lds_addr(const void* p) {
-    return (unsigned)(unsigned long long)(const __attribute__((address_space(3))) char*)p;
-  }
-  __device__ __forceinline__ static void flag_set(int* f, int v) {
-    asm volatile("ds_write_b32 %0, %1" ::"v"(lds_addr(f)), "v"(v) : "memory");
-  }
-  __device__ __forceinline__ static int flag_get(const int* f) {
-    int v;
-    asm volatile("ds_read_b32 %0, %1\n\ts_waitcnt lgkmcnt(0)" : "=v"(v) : "v"(lds_addr(f)) : "memory");
-    return __builtin_amdgcn_readfirstlane(v);
-  }
-  __device__ __forceinline__ static int flag_get2(const int* f, const int* g, int& gv) {
-    int v, w;
-    asm volatile("ds_read_b32 %0, %2\n\tds_read_b32 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v), "=&v"(w)
-                 : "v"(lds_addr(f)), "v"(lds_addr(g))
-                 : "memory");
-    gv = __builtin_amdgcn_readfirstlane(w);
-    return __builtin_amdgcn_readfirstlane(v);
-  }
-  // the count and, issued behind it, a two-float entry: one LDS round trip (the entry's read is performed after the count's,
-  // so when the count says the entry is there, what was read is the entry)
-  // (`other`: one more word of the same ring entry, another lane's -- the precision wavefront's copy of OD)
-  __device__ __forceinline__ static int flag_get_with(const int* f, const float* entry, const float* other, float& x0, float& x1,
-                                                      float& xo) {
-    int v;
-    double xy;
-    asm volatile("ds_read_b32 %0, %3\n\tds_read_b64 %1, %4\n\tds_read_b32 %2, %5\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(v), "=&v"(xy), "=&v"(xo)
-                 : "v"(lds_addr(f)), "v"(lds_addr(entry)), "v"(lds_addr(other))
-                 : "memory");
-    const unsigned long long bits = __builtin_bit_cast(unsigned long long, xy);
-    x0 = __builtin_bit_cast(float, (unsigned)(bits & 0xffffffffu));
-    x1 = __builtin_bit_cast(float, (unsigned)(bits >> 32));
-    return __builtin_amdgcn_readfirstlane(v);
-  }
-  __device__ __forceinline__ static void flag_wait(const int* f, int v) {  // until *f >= v
-    asm volatile("" ::: "memory");
-    while (flag_get(f) < v) __builtin_amdgcn_s_sleep(1);
-    asm volatile("" ::: "memory");
-  }
-
-  // hand-overs per step: stage points whose inputs A publishes, evaluations with an adjoint
-  __host__ __device__ static constexpr int n_in(int solver) {
-    return solver == VIHDS_SOLVER_EULER ? 0 : (solver == VIHDS_SOLVER_RK4 ? 3 : 1);
-  }
+  // hand-overs per step of the adjoint: evaluations with an adjoint
   __host__ __device__ static constexpr int n_vjp(int solver) {
     return solver == VIHDS_SOLVER_EULER ? 1 : (solver == VIHDS_SOLVER_RK4 ? 4 : 2);
   }
@@ -234,20 +175,15 @@ struct BbSplitT {
   struct FwdA {
     const Weights& W;
     const f32x4 (*hc)[MT];
-    float* pub;  // [FWD_RING][64][2] | flags
+    float* pub;  // [2][64][2]
     int lane, q, e;
-    bool ring = true;  // hand-overs through the ring (every working wavefront has a SIMD to itself) or at a barrier
     bool cyc = false;  // (profiling build: this step is stamped)
     int cyc_i = 0;
-    // entry e of the ring: the inputs of an evaluation (or of a grid point's log-likelihood)
+    // hand-over e: the inputs of an evaluation (or of a grid point's log-likelihood), then the barrier
     __device__ __forceinline__ void publish(float b0, float b1) {
-      int* flags = reinterpret_cast<int*>(pub + FWD_RING * 128);
-      // (every FWD_RING / 2 entries: the consumer is through with the half of the ring the next entries go into)
-      if (ring && (e & (FWD_RING / 2 - 1)) == 0) flag_wait(flags + F_CONS, e - FWD_RING / 2);
-      *reinterpret_cast<float2*>(pub + ((e & (FWD_RING - 1)) * 64 + lane) * 2) = make_float2(b0, b1);
+      *reinterpret_cast<float2*>(pub + ((e & 1) * 64 + lane) * 2) = make_float2(b0, b1);
       ++e;
-      if (ring) flag_set(flags + F_PROD, e);
-      else sync();
+      sync();
     }
     // publish the inputs of the next evaluation, evaluate the state network there
     __device__ __forceinline__ SA eval(float t, const SA& y) {
@@ -255,9 +191,6 @@ struct BbSplitT {
       VIHDS_BB_CYC(cyc, cyc_i++)
       publish(b0, b1);
       VIHDS_BB_CYC(cyc, cyc_i++)
-#if defined(VIHDS_BB_EXP) && VIHDS_BB_EXP == 2
-      return SA{b0 * 1e-3f, b1 * 1e-3f};
-#endif
       f32x4 h[K::MS];
       const f32x4 z = net_eval<0>(b0, b1, W, hc, h);
       VIHDS_BB_CYC(cyc && z[0] != 12345.f, cyc_i++)
@@ -277,32 +210,16 @@ struct BbSplitT {
     const float* pub;
     int lane, e;
     float b0, b1;  // the inputs of the last hand-over
-    bool ring = true;
     float od = 0.f;  // ... and the first state (OD) of this lane's trajectory at that point (quarter 0's b0)
     __device__ __forceinline__ void take() {
-      int* flags = reinterpret_cast<int*>(const_cast<float*>(pub) + FWD_RING * 128);
-      // the entry is read in the shadow of the count's read (issued behind it, so performed behind it: when the count
-      // says the entry is there, what was read is the entry) -- one LDS round trip per hand-over, not two
-      const float* slot = pub + ((e & (FWD_RING - 1)) * 64 + lane) * 2;
-      const float* slot_od = pub + ((e & (FWD_RING - 1)) * 64 + (lane & 15)) * 2;
-      float x0, x1;
-      if (ring) {
-        while (flag_get_with(flags + F_PROD, slot, slot_od, x0, x1, od) <= e) __builtin_amdgcn_s_sleep(1);
-        ++e;
-        flag_set(flags + F_CONS, e);
-      } else {
-        sync();
-        const float2 in = *reinterpret_cast<const float2*>(slot);
-        od = *slot_od;
-        x0 = in.x; x1 = in.y;
-        ++e;
-      }
-      b0 = x0; b1 = x1;
+      sync();
+      const float* slot = pub + ((e & 1) * 64 + lane) * 2;
+      const float2 in = *reinterpret_cast<const float2*>(slot);
+      od = pub[((e & 1) * 64 + (lane & 15)) * 2];  // (read beside the entry: no ds_bpermute round trip in the step)
+      ++e;
+      b0 = in.x; b1 = in.y;
     }
     __device__ __forceinline__ float rate(float v) {  // dv/dt at the inputs last taken
-#if defined(VIHDS_BB_EXP) && VIHDS_BB_EXP == 1
-      return b0 * 1e-3f;
-#endif
       f32x4 g[K::MP];
       const f32x4 zp = net_eval<1>(b0, b1, W, hc, g);
       return bb_sigmoid(zp[0]) - bb_sigmoid(zp[1]) * v;
@@ -376,12 +293,6 @@ struct BbSplitT {
 #ifndef VIHDS_BB_FWD_WAVES
 #define VIHDS_BB_FWD_WAVES 4
 #endif
-#ifndef VIHDS_BB_FWD_RING
-#define VIHDS_BB_FWD_RING 0  // 0 = barriers (default: measured faster), 1 = ring, 2 = ring while the launch has at most 512 groups
-#endif
-#ifndef VIHDS_BB_BWD_RING
-#define VIHDS_BB_BWD_RING 0  // 0 = barriers (default: measured faster, see the kernel), 1 = rings, 2 = rings while the launch has at most 512 groups
-#endif
 #ifndef VIHDS_BB_BWD_ORDER
 #define VIHDS_BB_BWD_ORDER 0x3120  // role of wavefront w = nibble w: A(0), H1(2), B(1), H2(3)
 #endif
@@ -404,7 +315,6 @@ __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaS
   using S = BbSplitT<K>;
   __shared__ __attribute__((aligned(16))) float pub[S::LDS_FWD];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  if (threadIdx.x < 4) reinterpret_cast<int*>(pub + S::FWD_RING * 128)[threadIdx.x] = 0;
   const int row0 = (blockIdx.x * K::TPW) / a.S;  // first data row of the block
   {
     const int nrow = min(stage_rows, a.B - row0);
@@ -415,10 +325,6 @@ __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaS
   __syncthreads();
   if (VIHDS_BB_FWD_WAVES == 4 && (wave & 1)) return;
   const int role = VIHDS_BB_FWD_WAVES == 4 ? wave >> 1 : wave;
-  // ring hand-overs while every working wavefront of the launch has a SIMD to itself (two per group, 1 024 SIMDs); with more
-  // groups than that a polling consumer takes issue slots from the wavefronts it shares its SIMD with: barriers then
-  // (S = 1 000: 249 us with the ring, profiles/r05_bb_forward.log)
-  const bool ring = VIHDS_BB_FWD_RING == 1 || (VIHDS_BB_FWD_RING == 2 && gridDim.x <= 512);
   const int jj = lane & 15, q = lane >> 4;
   const int i0 = blockIdx.x * K::TPW + jj;
   const bool live = i0 < a.n;
@@ -433,7 +339,6 @@ __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaS
   auto time_at = [&](int k) { return bb_dyn[k]; };
   if (role == 0) {
     typename S::FwdA F = {W, hc, pub, lane, q, 0};
-    F.ring = ring;
     typename S::SA y;
     y.a = a.theta[(size_t)a.slot_row[K::NLAT + q] * n + i];  // init_x, init_rfp, init_yfp, init_cfp
     y.b = q < K::L ? a.init_latent : 0.f;
@@ -475,7 +380,6 @@ __device__ __forceinline__ void bb_split_fwd_body(const OdeArgs& a, const ThetaS
     F.publish(y.a, S::in1(y, tA, q));
   } else {
     typename S::FwdB F = {W, hc, pub, lane, 0, 0.f, 0.f};
-    F.ring = ring;
     float v = a.init_prec, lp = 0.f;
     const float* ob = bb_dyn + a.T + ((size_t)(b - row0) * 4 + q) * a.T;
     float ob_cur = a.logp ? ob[0] : 0.f;
@@ -527,16 +431,10 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
   // as wave A) instead of waiting for A to publish the stage inputs (round 5): no "in" hand-over is left in the adjoint, B --
   // whose evaluation at a stage point could only start when A's previous one was done -- no longer arrives last at the
   // step's first hand-over (stamps: A waited 0.6 of a step's 2.8 us there), and B depends on nobody.
-  // What is left is one-directional: B -> A (the precision network's input adjoint), A -> H1 and B -> H2 (tiles).  `ring`:
-  // these go through flag-counted rings (see flag_set) and the time loop holds no barrier at all -- every wavefront
-  // walks at its own pace, A waits for B's two numbers only if B is behind; otherwise (more groups than the chip has room
-  // for at two per CU: a polling helper takes issue slots from the chain wavefront it shares a SIMD with) at barriers.
+  // What is left is one-directional -- B -> A (the precision network's input adjoint), A -> H1 and B -> H2 (tiles) -- and goes
+  // through LDS at ONE workgroup barrier per evaluation with an adjoint.
   constexpr int NVJP = S::n_vjp(SOLVER);
   const int n_steps = a.T - 1;
-  const bool ring = VIHDS_BB_BWD_RING == 1 || (VIHDS_BB_BWD_RING == 2 && gridDim.x <= 512);
-  int* flags = reinterpret_cast<int*>(lds + S::O_FLAGS);
-  if (threadIdx.x < 8) flags[threadIdx.x] = 0;
-  __syncthreads();
 #ifdef VIHDS_BB_STAMPS
   bool stamp_on = false;
   int stamp_i = 0, stamp_c = 0;
@@ -551,8 +449,6 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
 #pragma unroll
     for (int tq = 0; tq < 2 * MH; ++tq) G[tq] = zero;
     int e = 0;
-    const int* f_prod = flags + (st ? S::FB_A : S::FB_B);
-    int* f_cons = flags + (st ? S::FB_H1 : S::FB_H2);
     for (int k = 0; k < n_steps; ++k) {
 #ifdef VIHDS_BB_STAMPS
       stamp_on = k == n_steps / 2;
@@ -562,11 +458,7 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       for (int p = 0; p < NVJP; ++p) {
         VIHDS_BB_STOP
         VIHDS_BB_CYC(stamp_on, 48 + 8 * (role - 2) + stamp_c++)
-        if (ring) {
-          while (S::flag_get(f_prod) <= e) __builtin_amdgcn_s_sleep(2);
-        } else {
-          S::sync();
-        }
+        S::sync();
         VIHDS_BB_STOP
         const float* buf = st ? lds + (e & 1) * S::TA_WAVE : lds + S::O_TB + (e & 1) * S::TB_WAVE;
         ++e;
@@ -583,7 +475,6 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
             Xg[m] = K::get_rows(buf + (t_x + m) * K::GT_TILE, lane);
           }
         }
-        if (ring) S::flag_set(f_cons, e);  // (behind the reads in the LDS's order: the producer may reuse the slot)
 #pragma unroll
         for (int m = 0; m < MH; ++m) {
           if (m < M) {
@@ -653,7 +544,6 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     using SA = typename S::SA;
     float bs[4] = {0.f, 0.f, 0.f, 0.f};
     SA lam = {0.f, 0.f};
-    int h1_seen = 0;  // H1's count as last read (beside B's, at the end of the previous hand-over)
     // One evaluation of the state network: the hidden tiles and the four sigmoids.  An evaluation point that is visited
     // twice in a step (the grid point by every scheme but Euler; rk4's stage points) is evaluated ONCE: the adjoint sweep
     // reuses what the forward pass of the step left (12 registers per point) instead of running the network again.
@@ -685,9 +575,6 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       const f32x4 dy = S::template net_vjp<0>(dz, A.h, WT, gs, delta);
       VIHDS_BB_CYCF(stamp_on && dy[0] != 12345.f, 16 + stamp_c++)
       bs[0] += dz[0]; bs[1] += dz[1]; bs[2] += dz[2]; bs[3] += dz[3];
-      // entry e_vjp goes where entry e_vjp - 2 was: H1 must be through with that one
-      if (ring && h1_seen < e_vjp - 1)
-        while ((h1_seen = S::flag_get(flags + S::FB_H1)) < e_vjp - 1) __builtin_amdgcn_s_sleep(1);
       float* buf = lds + (e_vjp & 1) * S::TA_WAVE;
       const f32x4 xin = {y.a, q < K::L ? y.b : 0.f, q == 0 ? t : 0.f, 0.f};
       K::put_cols(buf + S::TA_DZ * K::GT_TILE, dz * lm, lane);
@@ -699,17 +586,11 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
       }
       VIHDS_BB_STOP
       VIHDS_BB_CYC(stamp_on, 16 + stamp_c++)
-      if (ring) {
-        S::flag_set(flags + S::FB_A, e_vjp + 1);
-        while (S::flag_get2(flags + S::FB_B, flags + S::FB_H1, h1_seen) <= e_vjp) __builtin_amdgcn_s_sleep(1);
-      } else {
-        S::sync();
-      }
+      S::sync();
       VIHDS_BB_CYCF(stamp_on, 16 + stamp_c++)
       VIHDS_BB_STOP
-      const float2 dyp = *reinterpret_cast<const float2*>(pub_dy + ((e_vjp & (S::DYR - 1)) * 64 + lane) * 2);
+      const float2 dyp = *reinterpret_cast<const float2*>(pub_dy + ((e_vjp & 1) * 64 + lane) * 2);
       ++e_vjp;
-      if (ring) S::flag_set(flags + S::FB_AC, e_vjp);  // (behind the read)
       yb.a += dy[0] + dyp.x;
       if (q < K::L) yb.b += dy[1] + dyp.y;
       return yb;
@@ -843,12 +724,6 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
     };
     auto rate = [&](const ActB& A, float v) { return A.pa - A.pd * v; };
     auto eval_vjp = [&](const In& in, float t, float yv, float vv, const ActB& A) {
-      // entry e_vjp goes where H2 read entry e_vjp - 2, its input adjoint where A read number e_vjp - DYR
-      if (ring) {
-        int ac;
-        while (S::flag_get2(flags + S::FB_H2, flags + S::FB_AC, ac) < e_vjp - 1 || ac < e_vjp - (S::DYR - 1))
-          __builtin_amdgcn_s_sleep(1);
-      }
       f32x4 gp[K::MP];
       const float ybv = -vv * A.pd;
       f32x4 dzp = zero;
@@ -866,12 +741,11 @@ __global__ void __launch_bounds__(256) bb_split_bwd_kernel(OdeArgs a) {
         K::put_cols(buf + (S::TB_G + m) * K::GT_TILE, A.g[m], lane);
         K::put_cols(buf + (S::TB_GP + m) * K::GT_TILE, gp[m] * lm, lane);
       }
-      *reinterpret_cast<float2*>(pub_dy + ((e_vjp & (S::DYR - 1)) * 64 + lane) * 2) = make_float2(dy[0], dy[1]);
+      *reinterpret_cast<float2*>(pub_dy + ((e_vjp & 1) * 64 + lane) * 2) = make_float2(dy[0], dy[1]);
       ++e_vjp;
       VIHDS_BB_STOP
       VIHDS_BB_CYC(stamp_on, 32 + stamp_c++)
-      if (ring) S::flag_set(flags + S::FB_B, e_vjp);
-      else S::sync();
+      S::sync();
       VIHDS_BB_STOP
       return ybv;
     };
