@@ -538,8 +538,8 @@ def run_loop_legs(a, plate="synthetic", leg_names=None, epochs=None, telemetry=T
         if leg_names is not None and name not in leg_names:
             continue
         keys = dict(u_rng=a.device_rng, conditioner_rng=a.device_rng, hip_graph=not a.eager, nan_check_every=check,
-                    epoch_graph=epoch_graph, lazy_cache_dump=epoch_graph, fused_ode_training=True, fused_iwae_backward=True,
-                    fused_step_tail=not a.no_step_tail)
+                    epoch_graph=epoch_graph, lazy_cache_dump=epoch_graph, epoch_lookahead=epoch_graph, fused_ode_training=True,
+                    fused_iwae_backward=True, fused_step_tail=not a.no_step_tail)
         hist = torch.zeros(34, dtype=torch.int32, device="cuda:0") if telemetry else None
         hip.lib().vihds_debug_newton_hist(hip.ptr(hist))  # (before the captures: a captured launch keeps its pointer)
         try:
@@ -638,7 +638,7 @@ def loop_legs_for_default_line(a):
                            "the reference's processed ICML plate: 312 wells from data/*.csv through datasets.py:173-224, recorded "
                            "in tests/golden/trace_dr_constant_icml_modeuler.npz; 234 train / 78 validation rows (its own split)")
             leg["workload"] = ("Training.run(): batches of 36 (ragged last 18), n_iwae=200, rk4, evaluation of train + validation "
-                               "rows at n_iwae=1000 every 20 epochs, one hipGraph launch per epoch, fast keys")
+                               "rows at n_iwae=1000 every 20 epochs, one hipGraph launch per epoch queued ahead of the look at the previous epoch's losses, fast keys")
             out[key] = leg
         except BaseException as exc:  # noqa: BLE001
             out[key] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}

@@ -939,3 +939,35 @@ def test_evaluation_with_online_summaries_gives_the_two_kernel_results(model_nam
     x, y = np.asarray(a.iw_predict_std), np.asarray(b.iw_predict_std)
     ok = np.isfinite(x) & np.isfinite(y)
     assert ok.mean() > 0.95 and np.abs(x[ok] - y[ok]).max() <= 2e-3 * np.abs(y[ok]).max()
+
+
+def test_run_with_epoch_lookahead_walks_the_same_steps_and_notices_a_nan():
+    """params.epoch_lookahead (run() queues an epoch's graph launch BEFORE it looks at the previous epoch's losses: the look
+    is one flag per epoch in pinned memory behind an event): the same steps -- parameters and validation ELBOs bit for bit --
+    as the loop that looks first; and a NaN loss still ends the run (one epoch later at most), with every NaN step a no-op."""
+    from vihds import synthetic
+
+    kw = dict(solver="rk4", seed=5, u_rng="kernel", conditioner_rng="kernel", learning_rate=0.01, hip_graph=True, nan_check_every=3,
+              fused_ode_training=True, fused_decoder_step=True, fused_iwae_backward=True, fused_step_tail=True, n_batch=8)
+    runs = {}
+    for look in (False, True):
+        args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                            epoch_lookahead=look, **kw)
+        args.epochs, args.test_epoch, args.test_samples = 6, 3, 32
+        assert training.epoch_graph and training.epoch_lookahead == look
+        out = training.run()
+        assert training._steps == 18
+        runs[look] = ({k: v.detach().clone() for k, v in model.named_parameters()}, [float(e) for e in out.elbo_list])
+    for k, v in runs[False][0].items():
+        assert torch.equal(runs[True][0][k], v), k
+    assert runs[True][1] == runs[False][1]
+    # a NaN in the data: the run stops, the parameters are those of before (every step's update is gated on its own loss)
+    args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                        epoch_lookahead=True, **kw)
+    args.epochs, args.test_epoch, args.test_samples = 6, 3, 32
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    training.train_data.observations[:, 0, 5] = float("nan")
+    training.run()
+    assert training._steps <= 2 * 3  # (noticed after the second epoch was queued at the latest)
+    for k, v in before.items():
+        assert torch.equal(dict(model.named_parameters())[k].detach(), v), k

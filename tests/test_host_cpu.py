@@ -349,3 +349,29 @@ def test_sized_blackbox_libraries_load_on_their_own():
                 "assert h.vihds_bb_variant_v2" % path)
         out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
         assert out.returncode == 0, (path, out.stderr[-400:])
+
+
+def test_index_batches_without_the_loader_are_the_loaders():
+    """Training.run() takes an epoch's row-index batches from _shuffled_index_batches instead of iterating its
+    DataLoader(shuffle=True): the same draws from torch's default generator in the same order (reference training.py:108-113
+    builds exactly that loader), so the same shuffles AND the same generator state afterwards -- checked against the loader
+    itself, full and ragged last batches, a batch larger than the set."""
+    from torch.utils.data import DataLoader
+
+    from vihds.training import _RowIndices, _index_batches_match_loader, _shuffled_index_batches
+
+    for n, b in ((234, 36), (20, 8), (7, 7), (5, 10), (312, 36)):
+        loader = DataLoader(dataset=_RowIndices(n), batch_size=b, shuffle=True,
+                            collate_fn=lambda rows: torch.tensor(rows, dtype=torch.int64))
+        torch.manual_seed(17 + n)
+        want = [list(loader) for _ in range(3)]
+        end = torch.get_rng_state()
+        torch.manual_seed(17 + n)
+        got = [_shuffled_index_batches(n, b) for _ in range(3)]
+        assert torch.equal(end, torch.get_rng_state())
+        for x, y in zip(want, got):
+            assert len(x) == len(y) and all(torch.equal(u, v) and u.dtype == v.dtype for u, v in zip(x, y))
+        torch.manual_seed(5)
+        keep = torch.get_rng_state()
+        assert _index_batches_match_loader(loader, n, b)
+        assert torch.equal(keep, torch.get_rng_state())  # (the check consumes nothing)

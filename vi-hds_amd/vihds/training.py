@@ -55,6 +55,66 @@ def collate_merged(times, device, batch):
     return batch_to_device(times, device, dd)
 
 
+def _shuffled_index_batches(n, batch_size):
+    """One epoch of DataLoader(range(n), batch_size, shuffle=True) WITHOUT the loader: the same two draws from torch's
+    default generator in the same order (the loader iterator's base seed, torch/utils/data/dataloader.py
+    _BaseDataLoaderIter.__init__; RandomSampler's seed for its own generator, sampler.py RandomSampler.__iter__), the same
+    permutation, cut into consecutive batches.  (The loader's per-batch machinery -- a profiler scope, the fetcher, the
+    collate call -- cost 0.24 ms per epoch of seven batches, half of the epoch's GPU time: tests/probe/run_loop_cprofile.py.)
+    Training checks it against the loader itself once (_index_batches_match_loader) and keeps the loader if a torch
+    version draws differently."""
+    torch.empty((), dtype=torch.int64).random_()
+    seed = int(torch.empty((), dtype=torch.int64).random_().item())
+    g = torch.Generator()
+    g.manual_seed(seed)
+    perm = torch.randperm(n, generator=g)
+    return [perm[i:i + batch_size] for i in range(0, n, batch_size)]
+
+
+def _index_batches_match_loader(loader, n, batch_size):
+    """True when two epochs of _shuffled_index_batches equal two passes over `loader` from the same generator state, batches
+    AND the state the default generator is left in (the state is restored afterwards: nothing is consumed)."""
+    keep = torch.get_rng_state()
+    try:
+        a = [list(loader), list(loader)]
+        end_a = torch.get_rng_state()
+        torch.set_rng_state(keep)
+        b = [_shuffled_index_batches(n, batch_size), _shuffled_index_batches(n, batch_size)]
+        end_b = torch.get_rng_state()
+        same = torch.equal(end_a, end_b) and all(
+            len(x) == len(y) and all(isinstance(u, torch.Tensor) and u.dtype == v.dtype and torch.equal(u, v) for u, v in zip(x, y))
+            for x, y in zip(a, b))
+    except Exception:  # noqa: BLE001 (anything unexpected: keep the loader)
+        same = False
+    finally:
+        torch.set_rng_state(keep)
+    return bool(same)
+
+
+class _EpochLook(object):
+    """params.epoch_lookahead: "does this epoch hold a NaN loss" as ONE flag per epoch that travels to pinned host memory
+    behind the epoch's own graph launch (two slots, used in turn), with an event: the loop can queue the NEXT epoch's launch
+    and only then wait for this flag -- reading the losses themselves would wait for whatever has been queued behind them,
+    and the graph's loss buffers are the next replay's as well."""
+
+    def __init__(self):
+        self.host = torch.zeros(2, dtype=torch.bool).pin_memory()
+        self.events = [torch.cuda.Event(), torch.cuda.Event()]
+        self.k = 0
+
+    def post(self, losses):
+        i = self.k
+        self.k ^= 1
+        flag = (~torch.isfinite(torch.stack([l.detach().reshape(()) for l in losses]))).any()
+        self.host[i: i + 1].copy_(flag.reshape(1), non_blocking=True)
+        self.events[i].record()
+        return i
+
+    def take(self, i):
+        self.events[i].synchronize()
+        return bool(self.host[i])
+
+
 class _RowIndices(torch.utils.data.Dataset):
     """range(n) as a dataset: what DataLoader shuffles when the rows themselves already live on the device."""
 
@@ -120,6 +180,9 @@ class Training:
         self._elbo_look = None
         self.nan_check_every = int(default_get_value(p, "nan_check_every", 1))  # 0 = never check
         # run(): with hip_graph, a single process and a NaN check at most once per epoch, an epoch is ONE graph launch
+        # (run(): queue an epoch's graph launch before the look at the previous epoch's losses -- see run())
+        self.epoch_lookahead = bool(default_get_value(p, "epoch_lookahead", False)) and self.use_graph
+        self._epoch_look = _EpochLook() if self.epoch_lookahead else None
         self.epoch_graph = (self.use_graph and bool(default_get_value(p, "epoch_graph", True)) and self.shard is None
                             and self.replica is None)
         # (a captured step that keeps the reference's host-side streams -- u_rng: numpy, conditioner_rng: cpu, the defaults --
@@ -153,6 +216,8 @@ class Training:
         self.train_loader = DataLoader(dataset=_RowIndices(data.n_train if hasattr(data, "n_train") else len(data.train)),
                                        batch_size=self.n_batch, shuffle=True,
                                        collate_fn=lambda rows: torch.tensor(rows, dtype=torch.int64))
+        n_train = len(self.train_loader.dataset)
+        self._fast_index_batches = _index_batches_match_loader(self.train_loader, n_train, self.n_batch)
         self.host_loader = DataLoader(
             dataset=data.train, batch_size=self.n_batch, shuffle=True,
             collate_fn=functools.partial(collate_merged, data.train.dataset.times, settings.device),
@@ -851,7 +916,7 @@ class Training:
                 self._elbo_look = _ElboLook()
             self._pending_elbo = elbo
             prev = self._elbo_look.push(elbo)
-            if prev is not None and math.isnan(self._elbo_look.take(prev)):
+            if prev is not None and not math.isfinite(self._elbo_look.take(prev)):
                 self._pending_elbo = None
                 self._elbo_look.pending = None
                 print("Cannot proceed with ELBO = nan. Exiting.")
@@ -870,8 +935,11 @@ class Training:
         """The reference's per-step check (training.py:331).  Row replicas must all leave the loop together -- a rank that
         stopped alone would leave its peers blocked in the next gradient all-reduce -- so they agree on the flag first."""
         if self.replica is None:
-            return math.isnan(float(elbo))  # (one device->host copy; torch.isnan would be a launch of its own before it)
-        bad = torch.isnan(elbo)
+            # (one device->host copy; torch.isfinite would be a launch of its own before it.  NOT FINITE rather than NaN: where
+            # the reference's eager graph ends in NaN, the kernels' max / sum reductions can end in +-inf -- a NaN observation
+            # gives -ELBO = +inf from vihds_step_tail -- and the step was a no-op on the device either way)
+            return not math.isfinite(float(elbo))
+        bad = ~torch.isfinite(elbo)
         if self.replica is not None:
             import torch.distributed as dist
 
@@ -879,6 +947,13 @@ class Training:
             dist.all_reduce(flag, op=dist.ReduceOp.MAX, group=self.replica.group)
             bad = flag[0] > 0
         return bool(bad)
+
+    def epoch_index_batches(self):
+        """The row-index batches of one epoch, as iterating self.train_loader yields them (same draws from torch's generator,
+        same batches): without the loader's per-batch machinery when the check at construction found the short form equal."""
+        if self._fast_index_batches:
+            return _shuffled_index_batches(len(self.train_loader.dataset), self.n_batch)
+        return list(self.train_loader)
 
     def run(self):
         """reference training.py:342-383"""
@@ -910,11 +985,15 @@ class Training:
             if self._pending_elbo is not None:  # (the per-step check that runs one step late: _run_batch)
                 self._pending_elbo = None
                 last, self._elbo_look.pending = self._elbo_look.pending, None
-                if last is not None and math.isnan(self._elbo_look.take(last)):
+                if last is not None and not math.isfinite(self._elbo_look.take(last)):
                     print("Cannot proceed with ELBO = nan. Exiting.")
                     ok = False
             if pending is not None and self.nan_check_every > 0:
-                if bool(torch.isnan(torch.stack([l.detach().reshape(()) for l in pending])).any()):
+                if isinstance(pending, int):  # (epoch_lookahead: the epoch's flag, _EpochLook)
+                    nan = self._epoch_look.take(pending)
+                else:
+                    nan = bool((~torch.isfinite(torch.stack([l.detach().reshape(()) for l in pending]))).any())
+                if nan:
                     print("Cannot proceed with ELBO = nan. Exiting.")
                     ok = False
             pending = None
@@ -922,27 +1001,50 @@ class Training:
 
         try:
             while iterating is True and (epoch < self.args.epochs + 1):
-                self.model.train()
+                if not self.model.training:  # (walking the module tree every epoch: 50 us)
+                    self.model.train()
                 epoch_start = time.time()
                 batches = None
                 if self.epoch_graph:
                     # the sampler's draws for the epoch (same generator stream as iterating the loader step by step); this host
                     # work runs while the GPU is still in the previous epoch: its losses are looked at only afterwards
-                    batches = list(self.train_loader)
+                    batches = self.epoch_index_batches()
                     if not all(isinstance(b, torch.Tensor) for b in batches):
                         batches = None
-                iterating = settle()
-                if not iterating:
-                    break
-                if batches is not None and (self.nan_check_every == 0 or self.nan_check_every >= len(batches)):
+                whole = batches is not None and (self.nan_check_every == 0 or self.nan_check_every >= len(batches))
+                if whole and self.epoch_lookahead and isinstance(pending, int):
+                    # params.epoch_lookahead: this epoch's graph is queued BEHIND the one whose losses have not been looked at
+                    # yet, and only then is that look taken -- the index upload and the graph launch (0.1 ms, a fifth of an
+                    # epoch of seven steps) no longer find the GPU idle.  Every update is gated on its own loss on the device
+                    # either way; what changes is how late the loop notices a NaN: one more epoch is queued by then.
+                    log_data.batch_feed_time += time.time() - epoch_start
+                    train_start = time.time()
+                    queued = self._epoch_look.post(self.epoch_rows(batches))
+                    self._steps += len(batches)
+                    iterating = settle()
+                    pending = queued
+                    log_data.batch_train_time += time.time() - train_start
+                    if not iterating:
+                        break
+                    whole = False  # (done)
+                    batches = ()
+                else:
+                    iterating = settle()
+                    if not iterating:
+                        break
+                if whole:
                     # the whole epoch in one graph launch
                     log_data.batch_feed_time += time.time() - epoch_start
                     train_start = time.time()
                     pending = self.epoch_rows(batches)
+                    if self.epoch_lookahead and self.nan_check_every > 0 and self.use_graph:
+                        pending = self._epoch_look.post(pending)
                     self._steps += len(batches)
                     log_data.batch_train_time += time.time() - train_start
+                elif batches == ():
+                    pass
                 else:
-                    todo = batches if batches is not None else list(self.train_loader)
+                    todo = batches if batches is not None else self.epoch_index_batches()
                     def n_rows(b):
                         return int(b.shape[0]) if isinstance(b, torch.Tensor) else len(b.observations)
 
