@@ -830,6 +830,11 @@ def test_bench_gpus_2_self_launch_on_one_device():
     assert [ln for ln in r.stdout.splitlines() if ln.strip()] == lines, r.stdout[-3000:]  # the line and nothing else on stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["value"] > 0 and np.isfinite(out["final_loss"])
+    # the strong-scaling legs: ONE batch, its IWAE-sample axis sharded over the two ranks -- config 3 and config 5
+    for leg, per_rank in (("strong_scaling_config3", 500), ("strong_scaling_config5", 100)):
+        assert out[leg]["scaling"] == "strong" and out[leg]["n_iwae_per_gpu"] == per_rank, out[leg]
+        assert out[leg]["value"] > 0 and np.isfinite(out[leg]["final_loss"]), out[leg]
+    assert out["eager_ms_per_step"] > 0  # (the safe measurement that precedes the captured one)
 
 
 @pytest.mark.parametrize("graph", [False, True])
