@@ -45,6 +45,79 @@ def emit(obj):
     out.flush()
 
 
+LINE_LIMIT = 6144  # bytes: the driver keeps only the tail of stdout (r05's 28 KB line was cut mid-object and parsed as nothing)
+EXTRA_FILE = "bench_extra.json"  # everything that is not the headline measurement (written next to bench.py, named in the line)
+
+_LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "value_long", "steps_long", "final_loss", "rows_per_step", "n_ranks_seen",
+              "eager_ms_per_step", "note")
+_CONFIG_KEYS = ("workload", "solver", "launch", "steps_per_graph_launch", "parallelism", "world_size", "dist_backend",
+                "collectives_in_graph", "rows_global", "n_iwae_global")
+_ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
+                  "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "mean_us", "launches_timed")
+_CPU_KEYS = ("value", "unit", "cores", "ms_per_step", "kind", "sample", "rows_steps_per_s", "reference_over_oracle",
+             "value_scaled_to_reference_best")
+
+
+def _short(v, n=200):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def compact_line(full, extra_path=None):
+    """The driver's line: the headline measurement, `roofline` and `cpu_baseline` with their contract keys and nothing nested
+    beyond them (VERDICT r05 #1).  Every other leg / note of `full` stays in the side file `extra_path` names."""
+    line = {k: _short(full[k]) for k in _LINE_KEYS if k in full and (full[k] is not None or k == "vs_baseline")}
+    cfg = full.get("config") or {}
+    line["config"] = {k: _short(cfg[k], 260) for k in _CONFIG_KEYS if cfg.get(k) is not None}
+    rf = full.get("roofline")
+    if rf is not None:
+        r = {k: _short(rf[k], 160) for k in _ROOFLINE_KEYS if k in rf and (rf[k] is not None or k == "traffic")}
+        ib = rf.get("issue_bound")
+        if isinstance(ib, dict):
+            r["issue_bound"] = {k: ib[k] for k in ("frac", "frac_at_residency", "issue_time_us", "valu_insts_per_launch", "source")
+                                if k in ib}
+        line["roofline"] = r
+    else:
+        line["roofline"] = None
+    cb = full.get("cpu_baseline")
+    line["cpu_baseline"] = {k: _short(cb[k], 320) for k in _CPU_KEYS if k in cb} if cb is not None else None
+    for k in ("strong_scaling_config3", "strong_scaling_config5"):
+        leg = full.get(k)
+        if isinstance(leg, dict):
+            line[k] = {j: _short(leg[j], 120) for j in ("value", "unit", "ms_per_step", "steps", "scaling", "workload", "n_iwae_per_gpu", "error",
+                                                        "skipped")
+                       if j in leg}
+    if extra_path is not None:
+        line["extra"] = extra_path
+    text = json.dumps(line, allow_nan=False)
+    if len(text) >= LINE_LIMIT:  # (cannot happen with the keys above; a line that would be cut is worth less than a short one)
+        for k in ("strong_scaling_config3", "strong_scaling_config5", "note"):
+            line.pop(k, None)
+        line["config"] = {k: line["config"][k] for k in ("workload", "solver", "launch") if k in line["config"]}
+    return line
+
+
+def emit_line(full):
+    """Write the full result to EXTRA_FILE (best effort) and print the compact line."""
+    path = os.path.join(ROOT, EXTRA_FILE)
+    try:
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1, default=str)
+        named = EXTRA_FILE
+    except OSError:
+        named = None
+    emit(compact_line(full, named))
+
+
+def load_pmc(path):
+    """A committed PMC reduction (profiles/make_pmc_*.py) and whether it was measured on THIS tree's kernel sources."""
+    sys.path.insert(0, os.path.join(ROOT, "profiles"))
+    from srcsha import csrc_sha16
+
+    d = json.load(open(path))
+    return d["kernels"], d.get("csrc_sha16") == csrc_sha16()
+
+
 def algorithmic_bytes(B, S, T=N_TIMES, N=N_STATES, P=N_PARAMS):
     """SURVEY.md 8d: fwd = read theta + write trajectory + write x_predict; bwd = read trajectory + write d theta."""
     fwd = 4 * (P * B * S + B * S * N * T + B * S * 4 * T)
@@ -225,7 +298,18 @@ def cpu_baseline(solver, observations, seconds_budget=20.0, max_steps=8, n_iwae=
            "rows_steps_per_s": {("%d thread%s" % (k, "" if k == 1 else "s")): round(1.0 / v, 3) for k, v in probe.items()}}
     fid = os.path.join(ROOT, "oracle", "cpu_fidelity.json")
     if os.path.exists(fid) and workload == "dr_constant_icml":
-        out["fidelity"] = json.load(open(fid))
+        fidelity = json.load(open(fid))
+        out["fidelity"] = fidelity
+        # how the timed restatement stands against the imported reference (build container, oracle/time_vs_reference.py):
+        # per thread count, and best thread count of each against the other's best -- the reference's own op program is quickest on
+        # ONE thread, the oracle's on eight, and best against best the reference is the faster (ratio < 1)
+        rows_f = fidelity["rows"]
+        ref_best = min(r["reference_modeuler_s_per_step"] for r in rows_f.values())
+        ora_best = min(r["oracle_modeuler_s_per_step"] for r in rows_f.values())
+        out["reference_over_oracle"] = dict({k: r["reference_over_oracle_modeuler"] for k, r in rows_f.items()},
+                                            best_vs_best=round(ref_best / ora_best, 4), solver="modeuler",
+                                            source="oracle/cpu_fidelity.json")
+        out["value_scaled_to_reference_best"] = out["value"] * ora_best / ref_best
     if workload == "relay_constant_precisions":
         out["note"] = ("no reference timing exists beside this one: the reference's classes for this model raise at "
                        "construction (relay_constant.py:17,201); the oracle restates its equations and is pinned on the "
@@ -396,7 +480,8 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
     import glob
     pmc = {}
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_%s_pmc_hbm_traffic.json" % name)), reverse=True):
-        pmc = {"file": os.path.basename(f), "kernels": json.load(open(f))["kernels"]}
+        ks, fresh = load_pmc(f)
+        pmc = {"file": os.path.basename(f), "kernels": ks if fresh else {}, "stale": not fresh}
         break
 
     def traffic_of(launch):
@@ -895,7 +980,9 @@ def issue_bound(kernel_name, mean_us):
     import glob
 
     for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_valu.json")), reverse=True):
-        ks = json.load(open(f))["kernels"]
+        ks, fresh = load_pmc(f)
+        if kernel_name in ks and not fresh:
+            return None  # (an instruction count of other kernel code)
         if kernel_name in ks:
             insts = ks[kernel_name]["SQ_INSTS_VALU"]
             cyc, cyc2, clk, simds = ISSUE_CYCLES_FULL_SIMD, ISSUE_CYCLES_TWO_WAVES, 2.4e9, 1024
@@ -949,9 +1036,12 @@ def main():
                     help="N > 1: skip the extra strong-scaling measurement (config 3's one batch, n_iwae=1000, sample-sharded) "
                          "that is otherwise added to the line as `strong_scaling_config3`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--all-legs", action="store_true",
+                    help="N = 1: after the headline, also time the other single-GPU BASELINE configurations (config3_train, "
+                         "config3_eval, config4, config5), the unchanged-spec path, Training.run() end to end and the per-rank "
+                         "shard shapes.  They go to bench_extra.json, never into the line (the driver's line stays < 6 KB)")
     ap.add_argument("--no-other-configs", dest="other_configs", action="store_false",
-                    help="N = 1: skip the legs of the other single-GPU BASELINE configurations (config3_train, config3_eval, "
-                         "config4, config5) and of the unchanged-spec path that the default line nests under `other_configs`")
+                    help="--all-legs: skip the legs of the other single-GPU BASELINE configurations and the unchanged-spec path")
     ap.add_argument("--leg-seconds", type=float, default=0.6, help="timed window of each `other_configs` leg")
     ap.add_argument("--roofline-steps", type=int, default=100,
                     help="launches of each ODE kernel timed for the roofline object (0: skip)")
@@ -1087,7 +1177,7 @@ def main():
 
         def fire():
             if rank == 0:
-                emit(fallback)
+                emit_line(fallback)
             os._exit(0)
 
         watchdog = threading.Timer(MULTI_RANK_WATCHDOG_S, fire)
@@ -1205,7 +1295,9 @@ def main():
                 short["graph_replay"] = {"value": short["value"], "ms_per_step": short["ms_per_step"], "launch": launch_mode}
                 short["value"], short["ms_per_step"] = fallback["value"], eager_ms
                 short["launch"] = "eager (faster than the hipGraph replay on this run: see graph_replay)"
-            emit(short)
+            short["config"] = {"workload": "dr_constant_icml: B=36 rows x n_iwae=200 per GPU, T=86, %s" % a.solver,
+                               "solver": a.solver, "launch": short.pop("launch"), "world_size": world}
+            emit_line(short)
         return
     # (training.step needs a live autograd graph; the direct launches below reuse the resident batch and the model)
     kt = ode_kernel_times(model, settings, batch, n_iwae_model, a.roofline_steps)
@@ -1254,11 +1346,14 @@ def main():
 
     # HBM traffic per launch from the PMC passes committed under profiles/ (newest set that has this kernel)
     import glob
-    pmc_kernels, pmc_name = {}, None
+    pmc_kernels, pmc_name, pmc_stale = {}, None, None
     for pmc_file in sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_pmc_hbm_traffic.json")), reverse=True):
-        ks = json.load(open(pmc_file))["kernels"]
+        ks, fresh = load_pmc(pmc_file)
         if kname["ode_step" if "ode_step" in kt else "ode_fused"] in ks:
-            pmc_kernels, pmc_name = ks, os.path.basename(pmc_file)
+            if fresh:
+                pmc_kernels, pmc_name = ks, os.path.basename(pmc_file)
+            else:  # counters of other kernel code are not this kernel's traffic
+                pmc_stale = os.path.basename(pmc_file)
             break
 
     def entry(k):
@@ -1279,8 +1374,10 @@ def main():
     roofline = {
         "bound": "hbm", "kernel": d["kernel"], "achieved": d["achieved"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": d["achieved"] / HBM_PEAK_GBS, "traffic": d["traffic"],
-        "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload)"
-                           % pmc_name) if d["traffic"] is not None else None,
+        "traffic_source": ("profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, same workload, same "
+                           "kernel sources: csrc_sha16 checked)" % pmc_name) if d["traffic"] is not None else
+                          ("none: newest profiles/%s was measured on other kernel sources (csrc_sha16 differs); re-run "
+                           "tests/probe/profile_set.sh" % pmc_stale) if pmc_stale else None,
         "algorithmic_bytes_per_launch": d["algorithmic_bytes_per_launch"], "mean_us": d["mean_us"],
         "launches_timed": kt[dom]["launches"],
         "timing": "back-to-back launches of the kernel between one HIP event pair on the launch stream",
@@ -1301,6 +1398,10 @@ def main():
         "value": world * a.steps / elapsed, "unit": "steps/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
         "ms_per_step": 1e3 * elapsed / a.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
+        # what ONE counted step is at N > 1: row replicas (--shard rows) put 36 rows per rank through one Adam step on the
+        # averaged gradient -- `value` counts that as N steps of the named 36-row configuration (weak scaling), and says so here
+        "rows_per_step": B_ROWS * (world if replica is not None else 1),
+        "n_ranks_seen": torch.distributed.get_world_size() if multi else 1,
         "value_long": long_run["value"] if long_run else None,
         "ms_per_step_long": long_run["ms_per_step"] if long_run else None,
         "steps_long": long_run["steps"] if long_run else None,
@@ -1334,7 +1435,7 @@ def main():
     if world == 1 and not a.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(a.solver, batch.observations.detach().cpu())
         out["speedup_vs_cpu_restatement"] = out["value"] / out["cpu_baseline"]["value"]
-    if world == 1 and a.other_configs and not (a.eager or a.host_rng or a.two_kernel_ode):
+    if world == 1 and a.all_legs and a.other_configs and not (a.eager or a.host_rng or a.two_kernel_ode):
         del model, training, step
         torch.cuda.synchronize()
         torch.cuda.empty_cache()
@@ -1346,7 +1447,7 @@ def main():
             out["newton_iters"] = {k: (loops[k] or {}).get("newton_iters") for k in ("run_loop", "real_plate")}
         if a.shard_emulation:
             out["shard_emulation"] = shard_emulation(a)
-    emit(out)
+    emit_line(out)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1:
         try:  # (the one-rank legs: a group left alive aborted in RCCL's teardown now and then, behind the line)
             torch.cuda.synchronize()

@@ -12,6 +12,8 @@ import statistics
 import sys
 from collections import defaultdict
 
+from srcsha import csrc_sha16
+
 
 def medians(path, counter):
     per = defaultdict(list)
@@ -34,7 +36,7 @@ def main():
                        "alongside). Counter unit: KiB per dispatch; medians over the dispatches. gfx950 correction per "
                        "/opt/skills/guides/MI355X_MICROARCH.md (HBM section): FETCH_SIZE x2 for streaming reads "
                        "(calibrated for 16 B/lane loads; ours are 4 B/lane: upper estimate), WRITE_SIZE as is." % cmd,
-               "kernels": kernels}, open(out, "w"), indent=1)
+               "csrc_sha16": csrc_sha16(), "kernels": kernels}, open(out, "w"), indent=1)
     for k, v in kernels.items():
         print("%-90s %10d B corrected" % (k[:90], v["hbm_bytes_corrected"]))
 

@@ -10,6 +10,8 @@ import statistics
 import sys
 from collections import defaultdict
 
+from srcsha import csrc_sha16
+
 
 def main():
     path, out, cmd = sys.argv[1:4]
@@ -19,7 +21,7 @@ def main():
             per[r["Kernel_Name"]].append(float(r["Counter_Value"]))
     kernels = {k: {"SQ_INSTS_VALU": statistics.median(v), "dispatches": len(v)} for k, v in per.items()}
     json.dump({"note": "rocprofv3 --pmc SQ_INSTS_VALU in a pass of its own of `%s`; wavefront-level VALU instructions per "
-                       "dispatch, summed over the chip, medians over the dispatches" % cmd, "kernels": kernels},
+                       "dispatch, summed over the chip, medians over the dispatches" % cmd, "csrc_sha16": csrc_sha16(), "kernels": kernels},
               open(out, "w"), indent=1)
     for k, v in sorted(kernels.items(), key=lambda kv: -kv[1]["SQ_INSTS_VALU"]):
         print("%-100s %12.0f VALU insts" % (k[:100], v["SQ_INSTS_VALU"]))
