@@ -22,9 +22,19 @@ Pinning status (see tests/test_oracle_golden.py, tests/golden/*.npz, tests/golde
   ``torchdiffeq==0.1`` (requirements.txt:6; call site vihds/ode.py:79-81) which is neither vendored in
   /root/reference nor installed here (no network).  Their tableaux below restate torchdiffeq 0.1's
   fixed-grid solvers as published (grid = the supplied ``t``; ``midpoint``: y_mid = y + f(t,y)*dt/2,
-  dy = dt*f(t+dt/2, y_mid); ``rk4`` = the 3/8-rule "rk4_alt_step_func").  The only reference-anchored
-  check is the reference's own criterion (tests/test_ode_solvers.py:83-89): final state within 5 % CV of
-  the pinned ``modeuler`` result.
+  dy = dt*f(t+dt/2, y_mid); ``rk4`` = the 3/8-rule "rk4_alt_step_func").
+  ANCHORED (tests/test_solver_pin.py, float64, CPU): (a) observed order of convergence 4 / 2 / 2 / 1 (rk4 / midpoint /
+  modeuler / euler) on the dr_constant right-hand side with the reference fixture's parameters; (b) on the plate reader's
+  own non-uniform grid the schemes sit at their truncation error (Richardson) from the dopri5 rtol-1e-10 solution -- i.e.
+  they are consistent integrators of the reference's equations with outputs at the grid points; (c) the eight order
+  conditions of a 4-stage 4th-order method hold on the constants csrc/vihds_dr_scan.hpp is compiled with (printed by a
+  host harness), those constants are the 3/8 rule, and the step functions below are that tableau to 1e-13; (d) the
+  reference's own criterion (tests/test_ode_solvers.py:83-89): final state within 5 % CV of the pinned ``modeuler``
+  result; (e) on the GPU, kernels == these functions at the headline shape on the reference's real plate batch
+  (tests/test_hip_parity.py::test_torchdiffeq_schemes_on_the_reference_plate_batch_at_full_size).
+  NOT ANCHORED (recalled from the dependency's source, no execution possible): that torchdiffeq 0.1's ``rk4`` is the
+  3/8-rule member of the 4th-order family and not the classic 1/6-2/6-2/6-1/6 one (they differ at truncation level,
+  ~1e-4 relative on this grid -- both pass (a)-(d)); that its fixed-grid solvers take the supplied ``t`` as the grid.
 * PINNED AGAINST THE *MODIFIED* REFERENCE (round 4): relay_constant_precisions, degrader_constant_precisions,
   inducer_constant_precisions, prpr_constant_precisions.  The reference raises at construction for them
   (relay_constant.py:17,201; degrader_constant.py:17; inducer_constant.py:85,119): OdeFunc.__init__ takes four

@@ -196,6 +196,49 @@ def test_both_kernel_variants_match_reference(name, variant):
     assert rel_err((th.grad[: len(fx.names)].cpu() + extra)[live], fx.t("theta_grad")[live], dim=0) < GTOL
 
 
+@pytest.mark.parametrize("solver", ["rk4", "midpoint"])
+def test_torchdiffeq_schemes_on_the_reference_plate_batch_at_full_size(solver):
+    """rk4 (BASELINE config 2's solver) and midpoint (every spec's default) at the headline shape on the REAL plate batch: the
+    36 rows, time grid, treatments, observations and the 35 x 36 x 200 clipped theta the imported reference itself produced
+    (tests/golden/dr_constant_icml_full_modeuler.npz).  The reference could only integrate them with its own modified Euler
+    (torchdiffeq is absent); here the HIP kernels -- thread-per-trajectory, lane-split and the time-parallel training kernel --
+    are held against the oracle's restatement of the dependency's schemes on exactly that batch, forward and gradient.  What
+    the oracle's schemes are anchored to is in tests/test_solver_pin.py."""
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture("dr_constant_icml_full_modeuler")
+    assert (fx.B, fx.S, fx.z["times"].shape[0]) == (36, 200, 86)
+    thc = fx.theta_dict(requires_grad=True)
+    xs, xp, prec = O.decode(fx.model, thc, fx.t("inputs"), fx.t("times"), solver)
+    lpo = O.log_prob_observations(xp, fx.t("observations"), prec)
+    loss_c, _ = O.iwae_loss(lpo, fx.t("log_p"), fx.t("log_q"))
+    loss_c.backward()
+    ref = torch.stack([thc[n].grad if thc[n].grad is not None else torch.zeros(fx.B, fx.S) for n in fx.names])
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    for variant in (1, 2):
+        th, row_of = H.pack_theta(fx, DEV)
+        th.requires_grad_(True)
+        _, _, traj, xpred, logp = _hip_forward(fx, solver=solver, theta=th, kernel_variant=variant)
+        loss, _, _ = ops.iwae_loss(logp, fx.t("log_p", DEV), fx.t("log_q", DEV))
+        loss.backward()
+        assert rel_err(H.view_bsnt(traj), xs) < TOL, variant
+        assert rel_err(H.view_bsnt(xpred), xp) < TOL, variant
+        assert rel_err(H.view_bs4(logp), lpo, dim=2) < TOL, variant
+        assert rel_err(loss, loss_c) < TOL, variant
+        assert rel_err(th.grad[: len(fx.names)].cpu()[live], ref[live], dim=0) < GTOL, variant
+    # the bench's own decoder kernel (time-parallel: log-likelihood + adjoint in one launch, no trajectory)
+    th3, row_of = H.pack_theta(fx, DEV)
+    th3.requires_grad_(True)
+    spec3 = H.spec_for(fx, row_of, th3.shape[0], solver, 3)
+    logp3 = ops.OdeLogLikFused.apply(spec3, th3, fx.t("inputs", DEV), fx.t("times", DEV), fx.t("observations", DEV), None)
+    loss3, _, _ = ops.iwae_loss(logp3, fx.t("log_p", DEV), fx.t("log_q", DEV))
+    loss3.backward()
+    assert rel_err(H.view_bs4(logp3), lpo, dim=2) < TOL
+    assert rel_err(loss3, loss_c) < TOL
+    assert rel_err(th3.grad[: len(fx.names)].cpu()[live], ref[live], dim=0) < GTOL
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4"])
 def test_lane_split_solvers_and_generic_gradients(solver, variant):

@@ -28,6 +28,40 @@ def test_library_exports_every_declared_symbol():
     assert lib.vihds_abi_version() == 14
 
 
+def test_problem_descriptor_agrees_in_header_binding_and_integration_doc():
+    """struct vihds_ode_problem three times over: include/vihds_hip.h, the ctypes mirror the package binds with, and the
+    stub INTEGRATION.md section 1 tells a maintainer to paste (round 5's stub lacked the last two fields: a struct 8 bytes
+    short, the library reading kernel_variant past its end)."""
+    import ctypes
+
+    from vihds import hip
+
+    header = open(os.path.join(ROOT, "include", "vihds_hip.h")).read()
+    body = re.search(r"typedef struct vihds_ode_problem \{(.*?)\} vihds_ode_problem;", header, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    h_fields = []
+    for ctype, names in re.findall(r"\b(int|float)\s+([^;]+);", body):
+        for n in names.split(","):
+            m = re.match(r"\s*(\w+)\s*(\[\s*(\w+)\s*\])?\s*$", n)
+            h_fields.append((m.group(1), ctype, m.group(3)))
+    max_slots = int(re.search(r"#define\s+VIHDS_MAX_SLOTS\s+(\d+)", header).group(1))
+    h_size = sum(4 * (max_slots if dim else 1) for _, _, dim in h_fields)
+    py_fields = hip.OdeProblem._fields_
+    assert [f[0] for f in py_fields] == [f[0] for f in h_fields]
+    for (name, ct), (_, ctype, dim) in zip(py_fields, h_fields):
+        base = ct._type_ if dim else ct
+        assert base is (ctypes.c_int if ctype == "int" else ctypes.c_float), name
+        assert (ct._length_ if dim else None) == (max_slots if dim else None), name
+    assert ctypes.sizeof(hip.OdeProblem) == h_size
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    stub = re.search(r"class OdeProblem\(ctypes\.Structure\):.*?_fields_ = \[(.*?)\]\n", doc, re.S).group(1)
+    d_fields = re.findall(r'\("(\w+)",\s*ctypes\.(c_int|c_float)(\s*\*\s*(\d+))?\)', stub)
+    assert [f[0] for f in d_fields] == [f[0] for f in h_fields]
+    for (name, ct, _, dim), (_, ctype, hdim) in zip(d_fields, h_fields):
+        assert ct == "c_" + ctype, name
+        assert (int(dim) if dim else None) == (max_slots if hdim else None), name
+
+
 def test_model_slot_tables():
     from vihds import hip
 

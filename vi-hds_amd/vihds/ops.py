@@ -1269,6 +1269,7 @@ class GeneralTail(StepTail):
         off = getattr(ode_model, "offset_layer", None)
         self.offset = off if (off is not None and getattr(ode_model, "n_y", 0) > 0) else None
         self._bufs = {}
+        self._declined = {}  # shape key -> why launch() declines it (looked at before any kernel is queued)
         self._maps = {}
         self._sides = {}
         self.inkernel_iwae = True  # (False: vihds_iwae_loss_fwd + vihds_ode_bwd -- the same numbers, one launch more)
@@ -1371,8 +1372,33 @@ class GeneralTail(StepTail):
             return None
         L = hip.lib()
         logp = fwd["logp"]
-        # ---- work buffers: allocated once per shape OUTSIDE any capture (the warm-up steps come first) and reused
         key = (B, S, R, str(dev))
+        # ---- everything vihds_step_tail (or the bookkeeping below) would refuse is looked at HERE, before the adjoint is
+        # queued: a refusal is a decline (None: the caller runs cost() + autograd + optimizer.step()), remembered per shape --
+        # never an exception after vihds_ode_bwd_elbo has already run
+        if key in self._declined:
+            return None
+        why = None
+        if off_n > 0 and s.D <= 0:
+            why = "an offset layer without device columns in the encoder's shape"
+        elif off_n * (s.D + 1) > 256:  # (vihds_api.hip: the offset layer's update is one block of the update launch)
+            why = "offset layer of %d x %d weights: more than one block of the update launch" % (off_n, s.D)
+        elif weights is not None:
+            fo = 0
+            for t in self.flat_tensors:
+                if t.data_ptr() != weights.data_ptr() + 4 * fo or not t.is_contiguous():
+                    why = "the decoder's parameters are not views of its flat weight buffer"
+                    break
+                fo += t.numel()
+            if (why is None and not blackbox and len(self._chunks_static()) != 1
+                    and bool(L.vihds_ode_bwd_reduces_weights(ctypes.byref(prob)))):
+                why = "the precision network's tensors are not one run of Adam's flat state"
+        if why is None and any(t is not None and not t.is_contiguous() for t in self.tensors):
+            why = "a non-contiguous encoder parameter"
+        if why is not None:
+            self._declined[key] = why
+            return None
+        # ---- work buffers: allocated once per shape OUTSIDE any capture (the warm-up steps come first) and reused
         capturing = torch.cuda.is_current_stream_capturing()
         if key not in self._bufs:
             n_aux = int(L.vihds_ode_bwd_aux_floats(ctypes.byref(prob)))
