@@ -96,10 +96,11 @@ typedef struct vihds_ode_problem {
   int logp_grad_broadcast; /* backward only: 1 = g_logp is ONE [B][S] array applied to all four species
                               (what the IWAE reduction hands back); 0 = [4][B][S] */
   int kernel_variant;      /* 0 = auto; 1 = one thread per trajectory; 2 = lane-split (8 lanes per trajectory,
-                              dr_constant family only; auto picks it below 16 384 trajectories); 5 = the time axis in
-                              parallel for relay / degrader / prpr / auto_constant and their _precisions forms
-                              (csrc/vihds_relay_scan.hpp; T <= 257, fixed-grid solvers, no hidden precision layer):
-                              trajectory and x_predict are then laid out [B][S][N][T] -- see vihds_ode_traj_layout */
+                              dr_constant family only; auto picks it below 16 384 trajectories); 3 = dr_constant's
+                              time-parallel training kernel (vihds_ode_logp_grad's default where it applies); 4 =
+                              dr_blackbox's single-wavefront MFMA kernels.  (5, the time axis in parallel for relay /
+                              degrader / prpr / auto_constant, was removed in round 6: never faster than the lane
+                              kernels; the value now selects what 0 does) */
 } vihds_ode_problem;
 
 int vihds_abi_version(void);
@@ -161,10 +162,8 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p);
  * second launch of the same call); 0: aux receives the dump described above and the caller contracts it. */
 int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p);
 /* Layout of the traj / xpred buffers of vihds_ode_fwd (and of traj / g_traj / g_xpred of vihds_ode_bwd) for this problem:
- * 0 = [T][N][B][S] and [T][4][B][S] (every kernel family but one); 1 = [B][S][N][T] and [B][S][4][T], time fastest --
- * the reference's own logical layout (OdeModel.simulate returns sol.permute(1,2,3,0), vihds/ode.py:82) -- which the
- * time-parallel kernels of kernel_variant 5 write (a wavefront's lanes are consecutive time points).  logp stays
- * [4][B][S]. */
+ * always 0 = [T][N][B][S] and [T][4][B][S]; logp is [4][B][S].  (1 = time fastest was the layout of the removed
+ * kernel_variant 5; the entry point stays so that ABI 14 is unchanged.) */
 int vihds_ode_traj_layout(const vihds_ode_problem* p);
 
 /* torchdiffeq==0.1's adaptive algorithm ITSELF, resident on the device (round 4; reference call site vihds/ode.py:79-81,

@@ -149,37 +149,6 @@ def test_importance_weights_formed_inside_the_adjoint_launch(name):
         assert rel_err(got[1][k], g) < 1e-5, k
 
 
-@pytest.mark.parametrize("name", ["relay_constant_precisions_tiny_modeuler", "prpr_constant_precisions_tiny_modeuler"])
-@pytest.mark.parametrize("lazy", [False, True])
-def test_evaluation_summaries_with_the_time_parallel_kernels(name, lazy):
-    """with kernel_variant 5 the solution comes back as a permuted view of time-fastest storage ([B][S][N][T]); the
-    summaries kernels read raw [T][N][B][S] pointers and used to take that storage as it was -- iw_predict_mu / std, iw_states
-    and iw_variance of an evaluation pass came out wrong.  cost(full_output=True) (reference utils.py:79-99, training.py:150-172)
-    with variant 5 against the lane kernels' (variant 0), same draws."""
-    import e2e_util as E
-    from vihds.training import Training
-    from vihds.vae import build_model
-
-    fx = Fixture(name)
-    outs = []
-    for variant in (0, 5):
-        args, settings, data, parameters = E.build_from_fixture(fx, gpu=0, kernel_variant=variant, lazy_x_predict=lazy)
-        model = build_model(args, settings, data, parameters)
-        training = Training(args, settings, data, parameters, model)
-        batch = E.batch_from_fixture(fx, settings.device)
-        model.eval()
-        np.random.seed(11)
-        torch.manual_seed(11)
-        with torch.no_grad():
-            results, theta, q, p = model(batch, args.train_samples)
-            outs.append(training.cost(batch, results, theta, q, p, full_output=True))
-    a, b = outs
-    assert abs(float(a.elbo) - float(b.elbo)) <= 1e-5 * abs(float(a.elbo))
-    for k in ("iw_predict_mu", "iw_predict_std", "iw_states", "iw_variance"):
-        x, y = torch.as_tensor(getattr(a, k)), torch.as_tensor(getattr(b, k))
-        assert x.shape == y.shape and rel_err(y, x) < 1e-4, k
-
-
 @pytest.mark.parametrize("rng", ["numpy", "kernel"])
 @pytest.mark.parametrize("name", ["relay_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
                                   "prpr_constant_tiny_modeuler", "degrader_constant_precisions_tiny_modeuler"])

@@ -2,16 +2,11 @@
 // library builds in parallel).  Model definition: vihds_models.hpp.
 #include "vihds_ode_kernels.hpp"
 #include "vihds_relay_lanes.hpp"
-#include "vihds_relay_scan_api.hpp"
 
 namespace vihds {
-int launch_scan_prpr_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st);  // scan_prpr_constant_prec.hip
 int launch_prpr_constant_prec(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
-  // kernel_variant 5: the time axis in parallel (vihds_relay_scan.hpp; trajectory / x_predict in the layout [B][S][N][T])
-  if (g_theta_stage && (g_adaptive_ctl || relay_scan_applicable(a.T, solver, a.kernel_variant, a.n_hidden_prec)))
+  if (g_theta_stage && g_adaptive_ctl)
     return VIHDS_E_UNSUPPORTED;  // (vihds_theta_ode_fwd: the sampling stage exists in the lane-split kernels only)
-  if (!g_adaptive_ctl && relay_scan_applicable(a.T, solver, a.kernel_variant, a.n_hidden_prec))
-    return launch_scan_prpr_constant_prec(backward, solver, a, st);
   // below 16 384 trajectories: one lane per state, sixteen lanes per trajectory (vihds_relay_lanes.hpp, RlPrpr); the adaptive
   // controller, a hidden layer in the precision network and kernel_variant 1 keep one thread per trajectory
   if (!g_adaptive_ctl && relay_lanes_applicable(a.n, solver, a.kernel_variant, a.n_hidden_prec) &&

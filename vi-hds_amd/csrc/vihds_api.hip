@@ -16,7 +16,7 @@
 #include "vihds_bb_variant.hpp"
 
 #include "vihds_relay_lanes.hpp"
-#include "vihds_relay_scan_api.hpp"
+#include "vihds_relay_lanes.hpp"
 
 namespace vihds {
 thread_local AdaptiveCtl* g_adaptive_ctl = nullptr;
@@ -363,20 +363,15 @@ static int lane_model_species(int model) {
   }
   return 0;
 }
-// the models with time-parallel kernels (vihds_relay_scan.hpp): relay / degrader / prpr / auto_constant, both forms
-static bool scan_model(int model) {
-  switch (model) {
-    case VIHDS_MODEL_RELAY_CONSTANT: case VIHDS_MODEL_DEGRADER_CONSTANT: case VIHDS_MODEL_PRPR_CONSTANT:
-    case VIHDS_MODEL_AUTO_CONSTANT: return true;
-  }
-  return lane_model_species(model) > 0;
-}
+// (ABI 14 keeps the entry point: the time-fastest [B][S][N][T] layout belonged to kernel_variant 5 -- the time-parallel
+// kernels for relay / degrader / prpr / auto_constant, built in round 4, never faster than the lane kernels and removed in
+// round 6 -- so every kernel family now writes [T][N][B][S])
 int vihds_ode_traj_layout(const vihds_ode_problem* p) {
-  return (p && scan_model(p->model) && relay_scan_applicable(p->T, p->solver, p->kernel_variant, p->n_hidden_prec)) ? 1 : 0;
+  (void)p;
+  return 0;
 }
 int vihds_ode_bwd_reduces_weights(const vihds_ode_problem* p) {
   if (!p) return 0;
-  if (lane_model_species(p->model) > 0 && vihds_ode_traj_layout(p)) return 1;
   return lane_model_species(p->model) > 0 &&
          relay_lanes_applicable(p->B * p->S, p->solver, p->kernel_variant, p->n_hidden_prec) ? 1 : 0;
 }
@@ -392,7 +387,6 @@ long long vihds_ode_bwd_aux_floats(const vihds_ode_problem* p) {
   const ModelEntry* e = entry(p->model);
   if (!e) return VIHDS_E_UNSUPPORTED;
   if (!e->neural_prec) return 0;
-  if (vihds_ode_traj_layout(p)) return relay_scan_aux_floats(p->B * p->S, p->T, lane_model_species(p->model));
   if (vihds_ode_bwd_reduces_weights(p)) return relay_lanes_aux_floats(p->B * p->S, lane_model_species(p->model));  // one partial row per block
   // white-box + neural precisions: [8 + NIN][E][n], NIN = 1 + core states (optional: see vihds_ode_bwd)
   const long long stages = ode_stages(p->solver);

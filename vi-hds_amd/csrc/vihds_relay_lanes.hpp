@@ -303,11 +303,6 @@ struct RlRelay {  // reference models/relay_constant.py:91-134
   using M = RelayConstant;
   static constexpr int NSP = 12, Q0 = 10, NCOND = 2;
   static constexpr bool HAS_P = true, HAS_Q = true, OBS_SUM = true;
-  // dependency levels of the states (the time-parallel kernels, vihds_relay_scan.hpp): 0 = OD; 1 = diluted species with a
-  // constant production; 2 = promoter-driven (their forcing reads luxR / lasR); 3 = quadratures of x I / (1 + I / K)
-  static constexpr int level(int l) { return l == 0 ? 0 : ((l == 2 || l == 3 || l == 8 || l == 9) ? 2 : (l >= 10 ? 3 : 1)); }
-  static constexpr int prom(int l) { return (l == 2 || l == 8) ? 0 : 1; }  // 0: P81 (constants of lane 2), 1: P76 (lane 3)
-  static constexpr int qsrc(int l) { return l == 10 ? 8 : 9; }
   __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI : (l == 9 ? wI : 0.f); }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
@@ -351,9 +346,6 @@ struct RlDegrader {  // reference models/degrader_constant.py:103-143: aiiA in l
   using M = DegraderConstant;
   static constexpr int NSP = 11, Q0 = 9, NCOND = 3;
   static constexpr bool HAS_P = true, HAS_Q = true, OBS_SUM = true;
-  static constexpr int level(int l) { return l == 0 ? 0 : ((l == 2 || l == 3) ? 2 : (l >= 9 ? 3 : 1)); }
-  static constexpr int prom(int l) { return l == 2 ? 0 : 1; }
-  static constexpr int qsrc(int) { return 8; }
   __device__ static float source_adjoint(int l, float zI, float wI) { return l == 8 ? zI + wI : 0.f; }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc], fR = p[M::P_fR], fS = p[M::P_fS];
@@ -393,9 +385,6 @@ struct RlPrpr {  // reference models/prpr_constant.py:46-69: every species with 
   using M = PrprConstant;
   static constexpr int NSP = 6, Q0 = 14, NCOND = 0;  // (prpr_constant reads no treatment: a.cond may be empty)
   static constexpr bool HAS_P = false, HAS_Q = false, OBS_SUM = true;
-  static constexpr int level(int l) { return l == 0 ? 0 : 1; }
-  static constexpr int prom(int) { return 0; }
-  static constexpr int qsrc(int) { return 0; }
   __device__ static float source_adjoint(int, float, float) { return 0.f; }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc];
@@ -422,9 +411,6 @@ struct RlAuto {  // reference models/auto_constant.py:42-63 (observation: x, x r
   using M = AutoConstant;
   static constexpr int NSP = 4, Q0 = 14, NCOND = 0;
   static constexpr bool HAS_P = false, HAS_Q = false, OBS_SUM = false;
-  static constexpr int level(int l) { return l == 0 ? 0 : 1; }
-  static constexpr int prom(int) { return 0; }
-  static constexpr int qsrc(int) { return 0; }
   __device__ static float source_adjoint(int, float, float) { return 0.f; }
   __device__ static void lane(int l, const float* p, RlLane& c) {
     const float rc = p[M::P_rc];

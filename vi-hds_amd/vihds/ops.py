@@ -245,26 +245,20 @@ class OdeSolveObserve(torch.autograd.Function):
             raise RuntimeError("theta has %d rows, problem expects %d" % (R, spec.n_rows))
         prob = spec.bind(B, S, T)
         N = spec.n_states
-        # kernel_variant 5 (time-parallel kernels): the buffers are [B][S][N][T] / [B][S][4][T], time fastest -- the reference's
-        # own logical layout (ode.py:82); what this function returns keeps the shape [T,N,B,S] / [T,4,B,S] as a permuted view
-        time_fastest = bool(hip.lib().vihds_ode_traj_layout(ctypes.byref(prob)))
-        traj = torch.empty((B, S, N, T) if time_fastest else (T, N, B, S), device=theta.device, dtype=torch.float32)
+        traj = torch.empty((T, N, B, S), device=theta.device, dtype=torch.float32)
         # (want_xpred False: the observed signals are not written -- they are a pointwise map of the trajectory and the
         # evaluation summaries form them in registers, vihds_iw_summaries_states; the second output is then None)
-        xpred = (torch.empty((B, S, 4, T) if time_fastest else (T, 4, B, S), device=theta.device, dtype=torch.float32)
-                 if (want_xpred or time_fastest) else None)
+        xpred = torch.empty((T, 4, B, S), device=theta.device, dtype=torch.float32) if want_xpred else None
         logp = torch.empty((4, B, S), device=theta.device, dtype=torch.float32)
         rc = _launch("ode_fwd", lambda: hip.lib().vihds_ode_fwd(
             ctypes.byref(prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
             hip.ptr(weights), hip.ptr(traj), hip.ptr(xpred), hip.ptr(logp), hip.current_stream()))
         hip.check(rc, "vihds_ode_fwd")
-        ctx.spec, ctx.prob, ctx.time_fastest = spec, prob, time_fastest
+        ctx.spec, ctx.prob = spec, prob
         ctx.row_offset_map = row_offset_map if row_offset is not None else None
         ctx.logp_out = logp.detach()  # (GeneralTail reads the step's forward state off this node)
         ctx.save_for_backward(theta, cond, times, obs, traj, dev1hot, weights)
         ctx.set_materialize_grads(False)
-        if time_fastest:
-            return traj.permute(3, 2, 0, 1), xpred.permute(3, 2, 0, 1), logp
         return traj, xpred, logp
 
     @staticmethod
@@ -289,11 +283,7 @@ class OdeSolveObserve(torch.autograd.Function):
         else:
             prob.logp_grad_broadcast = 0
             g_logp = _c(g_logp)
-        if ctx.time_fastest:  # upstream gradients arrive shaped [T,.,B,S]: the kernels read them as [B][S][.][T]
-            g_traj = None if g_traj is None else g_traj.permute(2, 3, 1, 0).contiguous()
-            g_xpred = None if g_xpred is None else g_xpred.permute(2, 3, 1, 0).contiguous()
-        else:
-            g_traj, g_xpred = _c(g_traj), _c(g_xpred)
+        g_traj, g_xpred = _c(g_traj), _c(g_xpred)
         aux = torch.empty(n_aux, device=theta.device, dtype=torch.float32) if n_aux > 0 else None
         rc = _launch("ode_bwd", lambda: hip.lib().vihds_ode_bwd(
             ctypes.byref(ctx.prob), hip.ptr(theta), hip.ptr(cond), hip.ptr(dev1hot), hip.ptr(times), hip.ptr(obs),
@@ -575,8 +565,6 @@ class ThetaOdeFused(torch.autograd.Function):
         if n_rows != spec.n_rows:
             raise RuntimeError("theta has %d rows, problem expects %d" % (n_rows, spec.n_rows))
         prob = spec.bind(B, S, T)
-        if hip.lib().vihds_ode_traj_layout(ctypes.byref(prob)):
-            raise FusedTrainingUnsupported("time-fastest trajectory layout")
         dev = q_all.device
         theta = torch.empty((n_rows, B, S), device=dev, dtype=torch.float32)
         log_q = torch.empty((B, S), device=dev, dtype=torch.float32)
@@ -596,7 +584,7 @@ class ThetaOdeFused(torch.autograd.Function):
         if rc == hip.E_UNSUPPORTED:
             raise FusedTrainingUnsupported(hip.lib().vihds_last_error().decode())
         hip.check(rc, "vihds_theta_ode_fwd")
-        ctx.spec, ctx.prob, ctx.time_fastest = spec, prob, False
+        ctx.spec, ctx.prob = spec, prob
         ctx.row_offset_map = None if off_rows is None else (off_rows[0], off_rows[1], off_rows[2], "linear")
         ctx.logp_out = logp.detach()
         ctx.rng_state = rng_state  # (its step is advanced by the launch that follows: GeneralTail, or vihds_rng_advance)
@@ -1339,7 +1327,7 @@ class GeneralTail(StepTail):
         return {"q_all": q_all, "kind": kind, "p_mu": p_mu, "p_prec": p_prec, "clip_lo": clip_lo, "clip_hi": clip_hi, "u": u,
                 "q_rows": q_rows, "theta": theta, "cond": cond, "times": times, "obs": obs, "traj": traj, "dev1hot": dev1hot,
                 "weights": weights, "spec": ode_node.spec, "prob": ode_node.prob, "rom": ode_node.row_offset_map,
-                "time_fastest": ode_node.time_fastest, "logp": ode_node.logp_out, "rng_advance": rng}
+                "logp": ode_node.logp_out, "rng_advance": rng}
 
     def launch(self, fwd, enc_node, log_q, log_p, n_total, apply_adam=True):
         """fwd: forward_state(...) of the step; enc_node: EncoderQTables' backward node.  Returns the loss tensor (-ELBO), or
@@ -1351,8 +1339,6 @@ class GeneralTail(StepTail):
                                                                             "weights"))
         delta_obs, inputs, dev_1hot_e, _cw, lin_w, local_w, _lb, _gw, _gf, pooled, hidden = enc_node.saved_tensors
         spec, prob, rom = fwd["spec"], fwd["prob"], fwd["rom"]
-        if fwd["time_fastest"]:
-            return None
         s = enc_node.shape
         P, B, S = q_all.shape[0] // 2, q_all.shape[1], u.shape[1]
         dev = q_all.device
@@ -1703,9 +1689,7 @@ def iw_summaries(log_w, lse, traj, xpred, n_species, theta=None, prec_rows=None,
     """Results.init's importance-weighted summaries on device (vihds/utils.py:79-99).  xpred None: the observed signals
     are formed from the trajectory by the model's observation map (observe_kind) inside the kernel."""
     _require_cuda(log_w, lse, traj)
-    # the kernels read [T][N][B][S] / [T][4][B][S] storage through raw pointers: a solution that came back as a permuted view of
-    # time-fastest storage (kernel_variant 5: [B][S][N][T], ops.OdeSolveObserve) is laid out first (ADVICE r04: it was read as
-    # is, and the summaries of relay / degrader / prpr / auto models evaluated with that variant came out wrong)
+    # (the kernels read [T][N][B][S] / [T][4][B][S] storage through raw pointers)
     traj, xpred = _c(traj), _c(xpred)
     T, N, B, S = traj.shape
     dev = traj.device
