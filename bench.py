@@ -84,8 +84,8 @@ def compact_line(full, extra_path=None):
     for k in ("strong_scaling_config3", "strong_scaling_config5"):
         leg = full.get(k)
         if isinstance(leg, dict):
-            line[k] = {j: _short(leg[j], 120) for j in ("value", "unit", "ms_per_step", "steps", "scaling", "workload", "n_iwae_per_gpu", "error",
-                                                        "skipped")
+            line[k] = {j: _short(leg[j], 120) for j in ("value", "unit", "ms_per_step", "steps", "scaling", "workload", "n_iwae_per_gpu",
+                                                        "final_loss", "error", "skipped")
                        if j in leg}
     if extra_path is not None:
         line["extra"] = extra_path

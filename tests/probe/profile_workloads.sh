@@ -1,11 +1,12 @@
 #!/bin/bash
-# usage: bash tests/probe/profile_workloads.sh <tag>
+# usage: [WORKLOADS="config5 ..."] [MFMA=0] bash tests/probe/profile_workloads.sh <tag>
 # The other BASELINE configurations (bench.py --workload ...): bench line + rocprofv3 kernel stats each, and the MFMA-busy
 # counters of the dr_blackbox step.  Output in gpurun_out/<tag>/ (copy what is to be kept to profiles/).
 TAG=$1
+WL=${WORKLOADS:-config3_train config3_eval config3_eval_stored config4 config5}
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-for W in config3_train config3_eval config3_eval_stored config4 config5; do
+for W in $WL; do
   rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_$W -o $W -- python $R/bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline > $O/stats_$W.log 2>&1
   cp $(find $O/stats_$W -name "*kernel_stats.csv" | head -1) $O/${TAG}_${W}_kernel_stats.csv
   rm -rf $O/stats_$W
@@ -21,6 +22,7 @@ for W in config3_train config3_eval config3_eval_stored config4 config5; do
 done
 # matrix-core busy fraction of the dr_blackbox kernels: BASELINE config 4 itself (450 groups of 16 trajectories: fewer than the
 # chip's SIMDs) and the same kernels with the chip full (config4_s1000: 2 250 groups)
+if [ "${MFMA:-1}" = "1" ]; then
 for W in config4 config4_s1000; do
   cd /tmp
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $O/mfma_$W -o mfma -- python $R/bench.py --workload $W --steps 20 --warmup 5 --no-cpu-baseline --roofline-steps 4 > $O/mfma_$W.log 2>&1
@@ -52,8 +54,10 @@ cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/stats_c4s -o c4s -- python $R/bench.py --workload config4_s1000 --steps 50 --warmup 10 --no-cpu-baseline > $O/stats_c4s.log 2>&1
 cp $(find $O/stats_c4s -name "*kernel_stats.csv" | head -1) $O/${TAG}_config4_s1000_kernel_stats.csv
 rm -rf $O/stats_c4s
+WL="$WL config4_s1000"
+fi
 cd $R
-for W in config3_train config3_eval config3_eval_stored config4 config5 config4_s1000; do
+for W in $WL; do
   python bench.py --workload $W > $O/${TAG}_${W}_bench.json 2> $O/${W}.err
   tail -1 $O/${TAG}_${W}_bench.json | cut -c1-160
 done

@@ -35,6 +35,7 @@
 #include "vihds_models.hpp"
 #include "vihds_iwae_inline.hpp"
 #include "vihds_theta_stage.hpp"
+#include "vihds_wave.hpp"
 
 namespace vihds {
 
@@ -514,12 +515,13 @@ __device__ __forceinline__ void relay_lane_fwd_body(const OdeArgs& a, int sig_ta
   __shared__ __attribute__((aligned(16))) float patch[RL_TR][RL_PATCH];
   extern __shared__ float in_lds[];
   const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
-  const int i0 = blockIdx.x * RL_TR + g;
+  const int blk = xcd_block(blockIdx.x, gridDim.x);  // (neighbouring blocks share 128-byte lines: same XCD, same L2)
+  const int i0 = blk * RL_TR + g;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;
   const int b = i / a.S;
   // time grid and the observation rows of the block's data rows -> LDS (no vector loads inside the time loop)
-  const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
+  const int first = blk * RL_TR, last = min(first + RL_TR, a.n) - 1;
   const int b0 = first / a.S, nb = last / a.S - b0 + 1;
   const int n_sg = sig_tab ? (a.T - 1) * Tab::S : 0, o_obs = a.T + RL_TR * n_sg;  // (sig_tab 0: a grid too long for the table)
   for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
@@ -621,11 +623,12 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig
   __shared__ float wred[PREC ? RL_TR : 1][PREC ? NWG : 1];
   extern __shared__ float in_lds[];
   const int tid = threadIdx.x, l = tid & 15, g = tid >> 4;
-  const int i0 = blockIdx.x * RL_TR + g;
+  const int blk = xcd_block(blockIdx.x, gridDim.x);  // (neighbouring blocks share 128-byte lines: same XCD, same L2)
+  const int i0 = blk * RL_TR + g;
   const bool live = i0 < a.n;
   const int i = live ? i0 : a.n - 1;  // tail trajectories shadow the last one (they take part in the exchanges)
   const int b = i / a.S;
-  const int first = blockIdx.x * RL_TR, last = min(first + RL_TR, a.n) - 1;
+  const int first = blk * RL_TR, last = min(first + RL_TR, a.n) - 1;
   const int b0 = first / a.S, nb = last / a.S - b0 + 1;
   const int n_sg = sig_tab ? (a.T - 1) * Tab::S : 0, o_obs = a.T + RL_TR * n_sg;  // (sig_tab 0: a grid too long for the table)
   for (int q = tid; q < a.T; q += RL_T) in_lds[q] = a.times[q];
@@ -807,7 +810,7 @@ __global__ void __launch_bounds__(RL_T) relay_lane_bwd_kernel(OdeArgs a, int sig
       float acc = 0.f;
 #pragma unroll
       for (int q = 0; q < RL_TR; ++q) acc += wred[q][tid];
-      a.aux[(size_t)blockIdx.x * NWG + tid] = acc;
+      a.aux[(size_t)blk * NWG + tid] = acc;
     }
   }
 }

@@ -36,4 +36,16 @@ __device__ __forceinline__ float wave_max_total(float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
 }
 
+// Which run of trajectories a workgroup takes, XCD-aware.  The dispatcher hands consecutive workgroup ids to the chip's eight XCDs
+// in turn (id % 8), and every XCD has its own L2.  A kernel whose neighbouring workgroups touch the two halves of the same
+// 128-byte lines (sixteen trajectories x 4 bytes per row: the lane kernels of vihds_relay_lanes.hpp) then fetches every line
+// into two L2s -- measured as twice the algorithmic bytes from HBM (round 5, PMC).  With this map the workgroups of ONE XCD
+// take a contiguous range of logical blocks, so the two halves of a line meet in one L2.  A bijection on [0, nblk).
+__device__ __forceinline__ int xcd_block(int wg, int nblk) {
+  constexpr int NXCD = 8;
+  const int x = wg % NXCD, local = wg / NXCD;
+  const int q = nblk / NXCD, r = nblk % NXCD;
+  return x * q + (x < r ? x : r) + local;
+}
+
 }  // namespace vihds
