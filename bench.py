@@ -335,8 +335,8 @@ WORKLOAD_TABLE = {
     "config4_s1000": ("dr_blackbox_icml", 36, 1000, "midpoint", "train", "mfma", "configs[3] at n_iwae=1000"),
 }
 LAUNCH_KERNELS = {  # launch name (ops._launch) -> substrings of the kernels it can run, for the PMC lookup
-    "decoder_step": ["dr_scan_train_theta_kernel", "dr_lane_train_theta_kernel"],
-    "ode_logp_grad": ["dr_scan_train_kernel", "dr_lane_train_kernel"],
+    "decoder_step": ["dr_scan_train_theta_kernel"],
+    "ode_logp_grad": ["dr_scan_train_kernel"],
     "ode_fwd": ["bb_split_fwd_kernel", "bb_mfma_fwd_kernel", "relay_lane_fwd_kernel", "dr_lane_fwd_kernel", "ode_fwd_kernel"],
     "ode_bwd": ["bb_split_bwd_kernel", "bb_mfma_bwd_kernel", "relay_lane_bwd_kernel", "dr_lane_bwd_kernel", "ode_bwd_kernel"],
     "ode_fwd_summaries": ["ode_fwd_summ_kernel"],
@@ -357,7 +357,7 @@ def time_launch(fn, n):
     return e0.elapsed_time(e1) * 1e3 / n
 
 
-def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, light=False):
+def run_workload(a, name, min_seconds=None, bounded_cpu=False):
     """Returns the JSON object of one of BASELINE.json's other configurations (None on ranks other than 0).  min_seconds:
     the timed window is sized from a short trial instead of --steps (the legs of the default line: >= that many seconds
     each).  bounded_cpu: the cpu_baseline leg runs at 8 threads without the thread probe, two samples.
@@ -368,8 +368,6 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
     from vihds import hip, ops, parallel, synthetic
 
     wl, B, S, solver, mode, bound, cfg_note = WORKLOAD_TABLE[name]
-    if s_override is not None:  # (--emulate-shards: the per-rank share of the configuration's IWAE-sample axis)
-        S = int(s_override)
     if a.solver_given:
         solver = a.solver
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -445,11 +443,6 @@ def run_workload(a, name, min_seconds=None, bounded_cpu=False, s_override=None, 
         raise SystemExit("degenerate objective %r after the timed steps (training ran away): not a valid bench run" % final)
     if not np.isfinite(final):
         raise SystemExit("non-finite objective %r after the timed passes: not a valid bench run" % final)
-
-    if light:  # (--emulate-shards: the timing only)
-        return {"value": n_steps / elapsed, "ms_per_step": 1e3 * elapsed / n_steps, "steps": n_steps, "final_objective": final,
-                "n_iwae": S, "launch": "hipGraph replay" if use_graph else "eager",
-                "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None}
 
     # ---- roofline: the step's own ODE launches, re-issued back to back ---------------------------------------------
     rec = ops.LaunchRecorder()
@@ -846,76 +839,6 @@ def distributed_path_leg(a, plain_ms):
     return keep
 
 
-def shard_emulation_child(a):
-    """`python bench.py --emulate-shards` (started by shard_emulation below with VIHDS_FORCE_DIST=1: a ONE-rank RCCL job): for
-    the configurations BASELINE.json shards over the IWAE-sample axis, the step time of the PER-RANK shape at N = 1, 2, 4, 8 --
-    n_iwae / N samples of the one batch -- through the whole distributed path (communicator, the all-gather of row statistics,
-    the gradient all-reduce; captured in the step's hipGraph when RCCL allows), on the one GPU there is.  What it measures:
-    whether the per-rank launch shrinks with its share of the samples, i.e. the speed-up sharding CAN give before any wire
-    latency: predicted_speedup(N) = t(N = 1) / t(per-rank shape at N).  What it cannot: the xGMI latency of the two
-    collectives at N > 1 (one-rank collectives are local copies)."""
-    a.shard, a.solver_given, a.no_cpu_baseline = "samples", False, True
-    table = {}
-    for name in ("config3_train", "config5", "config4"):
-        S_full = WORKLOAD_TABLE[name][2]
-        rows = {}
-        for N in (1, 2, 4, 8):
-            try:
-                out = run_workload(a, name, min_seconds=0.25, s_override=S_full // N, light=True)
-                rows[str(N)] = {"n_iwae_per_rank": S_full // N, "ms_per_step": out["ms_per_step"], "launch": out["launch"],
-                                "collectives_in_graph": out["collectives_in_graph"]}
-            except BaseException as exc:  # noqa: BLE001
-                rows[str(N)] = {"n_iwae_per_rank": S_full // N, "error": "%s: %s" % (type(exc).__name__, str(exc)[:200])}
-            torch.cuda.synchronize()
-            torch.cuda.empty_cache()
-        t1 = rows["1"].get("ms_per_step")
-        for N in (2, 4, 8):
-            tN = rows[str(N)].get("ms_per_step")
-            if t1 and tN:
-                rows[str(N)]["predicted_speedup"] = t1 / tN
-                rows[str(N)]["predicted_efficiency"] = t1 / tN / N
-        table[name] = rows
-    emit(table)
-    try:  # (leaving the group alive made the process abort in RCCL's teardown now and then, after the line was out)
-        torch.cuda.synchronize()
-        if torch.distributed.is_initialized():
-            torch.distributed.destroy_process_group()
-    except Exception:  # noqa: BLE001
-        pass
-
-
-def shard_emulation(a):
-    """The table of shard_emulation_child, from a child process with a one-rank communicator of its own."""
-    import socket
-    import subprocess
-
-    t0 = time.perf_counter()
-    try:
-        with socket.socket() as sock:
-            sock.bind(("127.0.0.1", 0))
-            port = sock.getsockname()[1]
-        env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   VIHDS_FORCE_DIST="1")
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        cmd = [sys.executable, os.path.abspath(__file__), "--emulate-shards", "--seed", str(a.seed), "--lr", str(a.lr)]
-        out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900)
-        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-        if not line:
-            table = {"error": "rc %d: %s" % (out.returncode, (out.stderr or out.stdout)[-300:])}
-        else:  # (a child that printed its table and then died in the process group's teardown has still measured)
-            table = json.loads(line[-1])
-            if out.returncode != 0:
-                table["child_exit_code"] = out.returncode
-    except BaseException as exc:  # noqa: BLE001
-        table = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
-    table["how"] = ("per-rank shapes of the sample-sharded configurations (n_iwae / N samples of ONE batch of 36 rows) timed on one "
-                    "GPU through a one-rank RCCL job: predicted_speedup = t(N=1) / t(per-rank shape); the collectives' xGMI latency "
-                    "at N > 1 is NOT in it.  The weak-scaling headline's per-rank shape is the headline itself: see "
-                    "other_configs.distributed_path_world1")
-    table["leg_wall_s"] = time.perf_counter() - t0
-    return table
-
-
 def other_config_legs(a, dev):
     """The other single-GPU BASELINE configurations and the unchanged-spec path, each timed for >= --leg-seconds inside the
     driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
@@ -946,17 +869,6 @@ def other_config_legs(a, dev):
         legs["unchanged_spec"] = {"error": "%s: %s" % (type(exc).__name__, str(exc)[:300])}
     legs["unchanged_spec"]["leg_wall_s"] = time.perf_counter() - t0
     return legs
-
-
-def run_plain_ms(a):
-    """ms per step of the plain one-process headline run, from a child process with the distributed leg's own arguments."""
-    import subprocess
-
-    cmd = [sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "2000", "--warmup", "200", "--no-cpu-baseline",
-           "--no-other-configs", "--no-strong-leg", "--roofline-steps", "0", "--seed", str(a.seed), "--lr", str(a.lr)]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
-    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    return json.loads(line[-1])["ms_per_step"]
 
 
 def distributed_leg_guarded(a, plain_ms):
@@ -1051,30 +963,9 @@ def main():
                          "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
                          "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
-    ap.add_argument("--emulate-shards", action="store_true",
-                    help="print the per-rank-shape table of the sample-sharded configurations (see shard_emulation_child); run "
-                         "as a one-rank distributed job, which the default line does for itself in a child process")
-    ap.add_argument("--no-shard-emulation", dest="shard_emulation", action="store_false",
-                    help="N = 1: skip the `shard_emulation` object of the default line")
     ap.add_argument("--no-loop-legs", dest="loop_legs", action="store_false",
                     help="N = 1: skip the `run_loop` / `real_plate` legs (Training.run() end to end) of the default line")
-    ap.add_argument("--legs-only", action="store_true",
-                    help="development aid: time only the two host-bound legs (unchanged spec; one rank through the "
-                         "distributed path) and print them; not the driver's line")
     a = ap.parse_args()
-    if a.emulate_shards:
-        if not torch.cuda.is_available():
-            raise SystemExit("bench.py needs an MI355X: the HIP path has no CPU fallback")
-        return shard_emulation_child(a)
-    if a.legs_only:
-        a.solver = a.solver or "rk4"
-        torch.cuda.set_device(0)
-        legs = {"unchanged_spec": unchanged_spec_leg(a, "cuda:0", a.leg_seconds)}
-        plain = run_plain_ms(a)
-        legs["plain_ms_per_step"] = plain
-        legs["distributed_path_world1"] = distributed_leg_guarded(a, plain)
-        emit(legs)
-        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
         # hand the same arguments on; rank 0 of that job prints the line
@@ -1215,7 +1106,7 @@ def main():
                         # (twice: the launch after the capture's own is still a first one for the runtime -- a 20-step
                         # window, the driver's, measured 1.5 % shorter with the graph launched once more here; setup, like
                         # the capture itself: not among the W warm-up or the K timed steps)
-                        for _ in range(2):
+                        for _ in range(int(os.environ.get("VIHDS_BENCH_SETUP_LAUNCHES", "2"))):
                             training.graph_step(batch, repeat=k)
         except Exception as exc:  # noqa: BLE001 -- (reported in the line; the run goes on with eager launches)
             if not multi:
@@ -1325,17 +1216,11 @@ def main():
     kname = {k: ("void vihds::dr_lane_%s_kernel<1, %d, true>(vihds::OdeArgs)" % (k[4:], solver_id)) if lanes else
                 ("void vihds::%s_kernel<vihds::DrConstant<1>, %d>(vihds::OdeArgs)" % (k, solver_id))
              for k in ("ode_fwd", "ode_bwd")}
-    kname["ode_fused"] = "void vihds::dr_lane_train_kernel<1, %d>(vihds::OdeArgs, int)" % solver_id
-    # the library's choice for the decoder launch (csrc/ode_dr_constant_v1.hip): the time-parallel kernel whenever the
-    # grid has at most 32 x 4 steps, else the lane-split one
+    # the decoder launch: the time-parallel kernel (csrc/vihds_dr_scan.hpp), ITEMS = steps per lane
     scan_items = (N_TIMES - 1 + 31) // 32
-    if scan_items <= 4 and os.environ.get("VIHDS_TRAIN_KERNEL") != "lanes":
-        kname["ode_fused"] = "void vihds::dr_scan_train_kernel<1, %d, %d>(vihds::OdeArgs)" % (solver_id, scan_items)
-        kname["ode_step"] = ("void vihds::dr_scan_train_theta_kernel<1, %d, %d>(vihds::OdeArgs, int, "
-                             "vihds::ThetaStageArgs)" % (solver_id, scan_items))
-    else:
-        kname["ode_step"] = ("void vihds::dr_lane_train_theta_kernel<1, %d>(vihds::OdeArgs, int, "
-                             "vihds::ThetaStageArgs)" % solver_id)
+    kname["ode_fused"] = "void vihds::dr_scan_train_kernel<1, %d, %d>(vihds::OdeArgs)" % (solver_id, scan_items)
+    kname["ode_step"] = ("void vihds::dr_scan_train_theta_kernel<1, %d, %d>(vihds::OdeArgs, int, "
+                         "vihds::ThetaStageArgs)" % (solver_id, scan_items))
     theta_b = 4 * (2 * N_PARAMS * B_ROWS * N_IWAE + 2 * B_ROWS * N_IWAE)  # the sampling stage's u, theta, log q, log p
     # SURVEY 8d's fixed numerator for every form of the decoder launch: 30 729 600 + 20 822 400 = 51 552 000 B; the
     # sampling stage's bytes (theta_b) are reported next to it, never added to it
@@ -1445,8 +1330,6 @@ def main():
             loops = loop_legs_for_default_line(a)
             out["run_loop"], out["real_plate"] = loops["run_loop"], loops["real_plate"]
             out["newton_iters"] = {k: (loops[k] or {}).get("newton_iters") for k in ("run_loop", "real_plate")}
-        if a.shard_emulation:
-            out["shard_emulation"] = shard_emulation(a)
     emit_line(out)
     if torch.distributed.is_available() and torch.distributed.is_initialized() and torch.distributed.get_world_size() == 1:
         try:  # (the one-rank legs: a group left alive aborted in RCCL's teardown now and then, behind the line)

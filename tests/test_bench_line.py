@@ -40,7 +40,7 @@ def test_default_line_is_short_strict_json_with_contract_keys():
     for k in ("value", "unit", "cores", "kind", "sample", "ms_per_step"):
         assert k in back["cpu_baseline"], k
     # nothing nested beyond the contract's objects: no other legs, no fidelity blobs, no histograms
-    for k in ("other_configs", "run_loop", "real_plate", "newton_iters", "shard_emulation"):
+    for k in ("other_configs", "run_loop", "real_plate", "newton_iters"):
         assert k not in back
     assert "fidelity" not in back["cpu_baseline"] and "other_kernels" not in back["roofline"]
 

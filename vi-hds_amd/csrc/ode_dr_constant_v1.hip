@@ -21,22 +21,10 @@ int launch_dr_constant_v1(bool backward, int solver, const OdeArgs& a, hipStream
   if (lanes && !solver_is_adaptive(solver) && !g_adaptive_ctl) return launch_dr_lanes<1>(backward, solver, a, st);
   return launch_ode<DrConstant<1>>(backward, solver, a, st);
 }
-// fused log-likelihood + unit-weight adjoint (lane-split regime only)
+// fused log-likelihood + unit-weight adjoint: the time-parallel kernel (vihds_dr_scan.hpp; any batch size, time grids up to
+// 129 points).  VIHDS_E_UNSUPPORTED beyond that: the caller takes vihds_ode_fwd + vihds_ode_bwd.
 int launch_dr_constant_train_v1(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts) {
-  // time-parallel form (vihds_dr_scan.hpp): the default wherever it applies (any batch size, time grids up to 129
-  // points); kernel_variant 2 / VIHDS_TRAIN_KERNEL=lanes keep the lane-split training kernel
-  const int kv = a.kernel_variant & 0xff;
-  static const bool scan_default = [] {
-    const char* e = std::getenv("VIHDS_TRAIN_KERNEL");
-    return !(e && std::string(e) == "lanes");
-  }();
-  if (kv == 3 || (kv == 0 && scan_default)) {
-    const int rc = launch_dr_scan_train<1>(solver, a, st, ts);
-    if (rc != VIHDS_E_UNSUPPORTED || kv == 3) return rc;
-  }
-  const bool lanes = a.kernel_variant == 2 || (a.kernel_variant == 0 && a.n <= lane_split_max_n_v1());
-  if (!lanes) return VIHDS_E_UNSUPPORTED;
-  return launch_dr_lane_train<1>(solver, a, st, ts);
+  return launch_dr_scan_train<1>(solver, a, st, ts);
 }
 int n_slots_dr_constant_v1() { return DrConstant<1>::NSLOT; }
 int n_states_dr_constant_v1() { return DrConstant<1>::N; }

@@ -578,356 +578,19 @@ __global__ void __launch_bounds__(256) dr_lane_bwd_kernel(OdeArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Training step in ONE launch: log-likelihood AND the adjoint for a unit upstream gradient.
-//
-// In the ELBO, d loss / d logp[j][b][s] is the same number w[b][s] for the four observed signals (the IWAE softmax
-// weight), and the adjoint is linear in it.  So the adjoint for w = 1 can be computed right behind the forward sweep,
-// before the weights exist; the caller scales the resulting theta gradient by w[b][s] afterwards (one elementwise
-// pass).  The forward sweep then has nobody to write the trajectory for: the states of the block's 32 trajectories
-// stay in LDS ([T][256] floats = 86 KB at T = 86) and the reverse sweep reads them from there.  Compared with
-// dr_lane_fwd_kernel + dr_lane_bwd_kernel: one launch and one prologue instead of two, no trajectory / x_predict
-// stores (29.7 MB) and no trajectory reads (19.8 MB).  Outputs: logp [4][n] and the unit-weight gradient g_theta.
-// time grid and the observation rows of the batch rows this block spans -> LDS (no barrier: the caller's next one covers it)
-__device__ __forceinline__ void dr_lane_stage_inputs(const OdeArgs& a, int tpb, float* lds) {
-  const int first = blockIdx.x * tpb, last = min(first + tpb, a.n) - 1;
-  const int b0 = first / a.S, nb = last / a.S - b0 + 1;
-  for (int q = threadIdx.x; q < a.T; q += 256) lds[q] = a.times[q];
-  const float* src = a.obs + (size_t)b0 * 4 * a.T;
-  for (int q = threadIdx.x; q < nb * 4 * a.T; q += 256) lds[a.T + q] = src[q];
-}
-template <int VERSION, int SOLVER, bool INPUTS_STAGED = false>
-__device__ __forceinline__ void dr_lane_train_body(const OdeArgs& a, int nb_max, float* lds) {
-  using D = DrLanes<VERSION>;
-  // lds: [T] times | [nb_max][4][T] observations | [T][256] states
-  const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
-  const int i0 = blockIdx.x * D::TPB + tl;
-  const bool live = i0 < a.n;
-  const int i = live ? i0 : a.n - 1;
-  const int b = i / a.S;
-  const int b0 = (blockIdx.x * D::TPB) / a.S;
-  if (!INPUTS_STAGED) {
-    dr_lane_stage_inputs(a, D::TPB, lds);
-    __syncthreads();
-  }
-  const float* tm = lds;
-  const float* ob = lds + a.T + ((b - b0) * 4 + (j & 3)) * a.T;
-  float* ys = lds + a.T + (size_t)nb_max * 4 * a.T + threadIdx.x;  // this lane's column, stride 256
-  DrLane L;
-  float c[2], y;
-  typename D::HillTerm H;
-  D::template prepare<SOLVER>(a, i, b, j, L, c, y, H);
-  const size_t n = a.n;
-  const float h0 = tm[1] - tm[0];
-  // ---- forward sweep: states to LDS, log-likelihood accumulated
-  {
-    const float lc = LOG2PI_F - logf(L.prec);
-    float lp = 0.f;
-    float tA = tm[0], tB = tm[1];
-    float ob_cur = j < 4 ? ob[0] : 0.f;
-    for (int k = 0; k < a.T; ++k) {
-      const float tC = (k + 1 < a.T) ? tm[k + 1] : tB;
-      const float ob_next = (j < 4 && k + 1 < a.T) ? ob[k + 1] : 0.f;
-      if (k > 0) {
-        y = D::template step<SOLVER>(tA, tB, h0, y, L);
-        tA = tB;
-      }
-      tB = tC;
-      ys[(size_t)k * 256] = y;
-      float inner;
-      const float xp = D::observe(y, bcast8<0>(y), L, inner);
-      if (j < 4) {
-        const float e = xp - ob_cur;
-        lp += -0.5f * (lc + L.prec * e * e);
-      }
-      ob_cur = ob_next;
-    }
-    if (a.logp && live && j < 4) a.logp[(size_t)j * n + i] = lp;
-  }
-  // ---- reverse sweep with unit weight on the four log-likelihoods
-  typename D::Adj A = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-  float lam = 0.f, precb = 0.f;
-  const float glp = j < 4 ? 1.f : 0.f;
-  float y_next = y;  // = state at T-1
-  float ob_next = j < 4 ? ob[a.T - 1] : 0.f;
-  float tHi = tm[a.T - 1], tLo = tHi;
-  for (int k = a.T - 1; k >= 0; --k) {
-    const float yk = y_next, obk = ob_next;
-    const float tK = tLo;
-    if (k > 0) {
-      y_next = ys[(size_t)(k - 1) * 256];
-      ob_next = j < 4 ? ob[k - 1] : 0.f;
-      tLo = tm[k - 1];
-    }
-    if (k < a.T - 1) lam = D::template step_vjp<SOLVER>(tK, tHi, h0, yk, L, lam, A);
-    tHi = tK;
-    const float x = bcast8<0>(yk);
-    float inner;
-    const float xp = D::observe(yk, x, L, inner);
-    float xpb = 0.f;
-    if (j < 4) {
-      const float e = xp - obk;
-      xpb = -glp * L.prec * e;
-      precb += glp * (0.5f / L.prec - 0.5f * e * e);
-    }
-    const float q = xpb * x;
-    lam += L.mo1 * q + dpp_mov<0x112>(0.f, L.mo2 * q);
-    const float xsum = sum4(xpb * inner);
-    lam += L.m0 * xsum;
-  }
-  dr_lane_write_adjoints<VERSION>(a, i, j, live, L, c, H, A, lam, precb);
-}
-
-
-// The sampling stage of the decoder step, run by the same block before its sweeps (vihds_theta_ode_logp_grad):
-// theta = clip(sample(q, u)) with log q / log p for the block's 32 trajectories (the arithmetic of theta_fwd_lds_kernel;
-// here the 8 lanes of a trajectory own parameter blocks j, j+8, ...), then the device-conditioner rows (the
-// arithmetic of device_condition_kernel).  Writes theta / u / log_q / log_p to global memory; the sweeps read theta
-// back after the barrier.  `scratch` (dr_lane_theta_stage_floats floats of LDS) holds the per-(row, parameter)
-// constants and the conditioner's tables.  (Routing theta / u through LDS tiles -- coalesced stores, sweeps reading
-// theta from LDS -- was measured slower: 100.7 vs 96.0 us.)
-// LDS floats the stage needs behind the time grid / observation rows
-__host__ __device__ inline size_t dr_lane_theta_stage_floats(int nb_max, int P, int E, int D, int B) {
-  return (size_t)10 * nb_max * P + (size_t)2 * E * D + (size_t)B * D;
-}
+// (The lane-split TRAINING kernel -- forward sweep with the states in LDS, unit-weight adjoint behind it, the sampling stage in
+// front: rounds 1-2's decoder launch -- was removed in round 6: the time-parallel kernel of vihds_dr_scan.hpp serves every
+// shape it served except time grids of 130-150 points, which take vihds_ode_fwd + vihds_ode_bwd.)
+// What the decoder launch's generator bookkeeping needs:
 struct RngTickets {
-  unsigned int u, c;  // this block's tickets of the two generators (valid in threads 0 and 64)
+  unsigned int u, c;  // this block's tickets of the two generators
 };
-__device__ __forceinline__ RngTickets dr_lane_theta_stage(const OdeArgs& a, const ThetaStageArgs& t, int nb_max,
-                                                          float* scratch) {
-  constexpr int TPB = 32;
-  constexpr float LOG2PI = 1.8378770664093453f;
-  const int n = a.n, P = t.P, B = a.B, S = a.S;
-  const int first = blockIdx.x * TPB, last = min(first + TPB, n) - 1;
-  const int b0 = first / S, nb = last / S - b0 + 1;
-  const int stride = nb_max * P;
-  float* t_kind = scratch;
-  float* t_mu = scratch + stride;
-  float* t_sigma = scratch + 2 * stride;
-  float* t_prec = scratch + 3 * stride;
-  float* t_cq = scratch + 4 * stride;
-  float* t_lo = scratch + 5 * stride;
-  float* t_hi = scratch + 6 * stride;
-  float* t_pmu = scratch + 7 * stride;
-  float* t_cp = scratch + 8 * stride;
-  float* t_pprec = scratch + 9 * stride;
-  float* t_cw = scratch + 10 * stride;      // [E*D] conditioner weights of this call
-  float* t_rel = t_cw + t.E * a.D;          // [E*D] relevance masks
-  float* t_dev = t_rel + t.E * a.D;         // [B*D] device one-hot rows (the conditioner's tiling reads any row)
-  const int tl = threadIdx.x >> 3, j = threadIdx.x & 7;
-  const int i0 = first + tl;
-  const bool live = i0 < n;
-  const int i = live ? i0 : n - 1;
-  const int b = i / S;
-  const int row = (b - b0) * P;
-  // -- table loads are issued first; the draws below need none of them and run while they are in flight
-  const int e1 = threadIdx.x;
-  const bool filler = e1 < nb * P;
-  int f_kd = 0, f_p = 0;
-  float f_pr = 1.f, f_mu = 0.f, f_lo = 0.f, f_hi = 0.f, f_pmu = 0.f, f_pp = 1.f;
-  if (filler) {
-    const int bb = e1 / P;
-    f_p = e1 - bb * P;
-    const int rm = t.q_rows ? t.q_rows[f_p] : f_p, rp = t.q_rows ? t.q_rows[P + f_p] : f_p;
-    f_kd = t.kind[f_p];
-    f_pr = t.q_prec[rp * B + b0 + bb];
-    f_mu = t.q_mu[rm * B + b0 + bb];
-    f_lo = t.clip_lo[f_p];
-    f_hi = t.clip_hi[f_p];
-    f_pmu = t.p_mu[f_p];
-    f_pp = t.p_prec[f_p];
-  }
-  if (t.E > 0) {  // conditioner tables: waves 2, 3 (the fillers sit in waves 0, 1)
-    const int ed = t.E * a.D;
-    for (int e = threadIdx.x - 128; e >= 0 && e < ed; e += 128) {
-      float zz;
-      if (t.crng) zz = philox_normal((unsigned int)e, 0xC04Du, t.crng[2], 0u, t.crng[0], t.crng[1], 0);
-      else zz = t.z[e];
-      t_cw[e] = t.w_mean + t.w_std * zz;
-      t_rel[e] = t.rel[e];
-    }
-    for (int e = threadIdx.x; e < B * a.D; e += 256) t_dev[e] = a.dev1hot[e];
-  }
-
-  unsigned int k0 = 0, k1 = 0, step = 0, gidx = 0;
-  if (t.rng) {
-    k0 = t.rng[0]; k1 = t.rng[1]; step = t.rng[2];
-    gidx = (unsigned int)(b * t.S_total + t.s_off + (i - b * S));
-  }
-  // this lane's parameter blocks are j, j + 8, (j + 16, ...): the first two are drawn ahead of the barrier
-  float za[4] = {0.f, 0.f, 0.f, 0.f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
-  if (t.rng) {
-    if (4 * j < P) philox_normal4(gidx, (unsigned int)j, step, 0u, k0, k1, za);
-    if (4 * (j + 8) < P) philox_normal4(gidx, (unsigned int)(j + 8), step, 0u, k0, k1, zb);
-  }
-  for (int e = e1; e < nb * P; e += 256) {
-    if (e != e1) {  // (more than 256 table entries: the remaining ones the plain way)
-      const int bb = e / P;
-      f_p = e - bb * P;
-      const int rm = t.q_rows ? t.q_rows[f_p] : f_p, rp = t.q_rows ? t.q_rows[P + f_p] : f_p;
-      f_kd = t.kind[f_p];
-      f_pr = t.q_prec[rp * B + b0 + bb];
-      f_mu = t.q_mu[rm * B + b0 + bb];
-      f_lo = t.clip_lo[f_p]; f_hi = t.clip_hi[f_p]; f_pmu = t.p_mu[f_p]; f_pp = t.p_prec[f_p];
-    }
-    const float prec = (f_kd == KIND_CONSTANT) ? 1.f : (t.prec_is_log ? expf(f_pr) : f_pr);
-    t_kind[e] = (float)f_kd;
-    t_mu[e] = f_mu;
-    t_sigma[e] = 1.f / sqrtf(prec);
-    t_prec[e] = prec;
-    t_cq[e] = -LOG2PI + 0.5f * logf(prec + 1e-12f);
-    t_lo[e] = f_lo;
-    t_hi[e] = f_hi;
-    t_pmu[e] = f_pmu;
-    t_cp[e] = -LOG2PI + 0.5f * logf(f_pp + 1e-12f);
-    t_pprec[e] = f_pp;
-  }
-  __syncthreads();
-  // Every thread of this block has read the generators' step counters by now (the loads were complete at the barrier),
-  // so the block takes its tickets here and the atomics' round trips hide behind the sweeps; the last ticket holder
-  // advances the step at the very end of the kernel (rng_advance), when every other block is past this point too.
-  RngTickets tk = {0u, 0u};
-  if (t.rng && threadIdx.x == 0) tk.u = atomicAdd(&t.rng[3], 1u);
-  if (t.crng && threadIdx.x == 64) tk.c = atomicAdd(&t.crng[3], 1u);
-  float lq = 0.f, lp = 0.f;
-  int it = 0;
-  for (int kb = j; 4 * kb < P; kb += 8, ++it) {
-    float z4[4];
-    if (t.rng) {
-      if (it == 0) { z4[0] = za[0]; z4[1] = za[1]; z4[2] = za[2]; z4[3] = za[3]; }
-      else if (it == 1) { z4[0] = zb[0]; z4[1] = zb[1]; z4[2] = zb[2]; z4[3] = zb[3]; }
-      else philox_normal4(gidx, (unsigned int)kb, step, 0u, k0, k1, z4);
-    }
-#pragma unroll
-    for (int jj = 0; jj < 4; ++jj) {
-      const int p = 4 * kb + jj;
-      if (p >= P) break;
-      float uu;
-      if (t.rng) {
-        uu = z4[jj];
-        if (live) t.u[(size_t)i * P + p] = uu;
-      } else {
-        uu = t.u[(size_t)i * P + p];
-      }
-      // straight-line: the 8 lanes of a trajectory hold parameters of different kinds, so a branch per kind would
-      // run every side anyway (measured: this loop was 3.5 us of the launch with branches)
-      const int e = row + p;
-      const float kdf = t_kind[e], mu = t_mu[e];
-      const bool cst = kdf == (float)KIND_CONSTANT, ln = kdf == (float)KIND_LOGNORMAL;
-      const float zz = mu + t_sigma[e] * uu;
-      float x = ln ? expf(zz) : zz;
-      const float lo = t_lo[e], hi = t_hi[e];
-      x = x < lo ? lo : (x > hi ? hi : x);
-      const float v = ln ? logf(x + 1e-12f) : x;
-      const float jac = ln ? v : 0.f;
-      const float dq = mu - v, dp = t_pmu[e] - v;
-      const float tq = t_cq[e] - 0.5f * t_prec[e] * dq * dq - jac;
-      const float tp = t_cp[e] - 0.5f * t_pprec[e] * dp * dp - jac;
-      lq += cst ? 0.f : tq;
-      lp += cst ? 0.f : tp;
-      x = cst ? 0.f * uu + mu : x;
-      if (live) t.theta[(size_t)p * n + i] = x;
-    }
-  }
-  lq = sum8(lq);
-  lp = sum8(lp);
-  if (live && j == 0) {
-    if (t.log_q) t.log_q[i] = lq;
-    if (t.log_p) t.log_p[i] = lp;
-  }
-  // device conditioner: lane e of the trajectory's group produces row cond_row0 + e.  Weights, masks and one-hot rows
-  // come from LDS (as global loads inside this data-dependent loop they were serialised: ~6 us of the launch)
-  if (t.E > 0) {
-    const int r = (int)(((long long)b * t.S_total + t.s_off + (i - b * S)) % B);
-    for (int e = j; e < t.E; e += 8) {
-      float c = 0.f;
-      for (int d = 0; d < a.D; ++d) {
-        const float hot = t_dev[r * a.D + d] * t_rel[e * a.D + d];
-        c += t_cw[e * a.D + d] * hot;  // (hot == 0 contributes exactly 0, as when the weight is not drawn for it)
-      }
-      c = fmaxf(c, 0.f);
-      if (live) t.theta[(size_t)(t.cond_row0 + e) * n + i] = (t.is_default[e] ? 1.f : 0.f) + c;
-    }
-  }
-  __syncthreads();  // theta of this block's trajectories is in memory; the scratch region is free again
-  return tk;
-}
-// the holder of the last ticket advances a generator's step: every block has read it before taking its ticket
+// the holder of a launch's last ticket advances the generator's step (at the very end of the kernel)
 __device__ __forceinline__ void rng_advance(unsigned int* rng, unsigned int ticket, int thread) {
   if (rng && threadIdx.x == thread && ticket == gridDim.x - 1) {
     rng[2] = rng[2] + 1u;
     rng[3] = 0u;
   }
-}
-
-template <int VERSION, int SOLVER>
-__global__ void __launch_bounds__(256) dr_lane_train_kernel(OdeArgs a, int nb_max) {
-  extern __shared__ float lds[];
-  dr_lane_train_body<VERSION, SOLVER>(a, nb_max, lds);
-}
-// sampling stage + conditioner + sweeps: the whole decoder side of a training step
-template <int VERSION, int SOLVER>
-__global__ void __launch_bounds__(256) dr_lane_train_theta_kernel(OdeArgs a, int nb_max, ThetaStageArgs t) {
-  extern __shared__ float lds[];
-  dr_lane_stage_inputs(a, DrLanes<VERSION>::TPB, lds);  // in flight during the sampling stage, whose barriers cover it
-  // scratch = the (still unused) states region
-  const RngTickets tk = dr_lane_theta_stage(a, t, nb_max, lds + a.T + (size_t)nb_max * 4 * a.T);
-  dr_lane_train_body<VERSION, SOLVER, true>(a, nb_max, lds);
-  rng_advance(t.rng, tk.u, 0);
-  rng_advance(t.crng, tk.c, 64);
-}
-
-inline size_t dr_lane_train_lds_bytes(const OdeArgs& a, int tpb, int* nb_max_out) {
-  const int nb = min(a.B, (tpb - 1) / a.S + 2);
-  if (nb_max_out) *nb_max_out = nb;
-  return ((size_t)a.T + (size_t)nb * 4 * a.T + (size_t)a.T * 256) * sizeof(float);
-}
-constexpr size_t DR_LANE_TRAIN_MAX_LDS = 160 * 1024;
-
-// returns VIHDS_E_UNSUPPORTED when the states of a block do not fit in LDS (long time grids)
-template <int VERSION>
-inline int launch_dr_lane_train(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts = nullptr) {
-  int nb_max = 0;
-  const size_t lds = dr_lane_train_lds_bytes(a, DrLanes<VERSION>::TPB, &nb_max);
-  if (lds > DR_LANE_TRAIN_MAX_LDS) return VIHDS_E_UNSUPPORTED;
-  // The states in LDS allow one block per CU: beyond one block per CU the launch runs in rounds and the forward +
-  // adjoint pair (several waves per SIMD, trajectory through HBM) is faster (measured: 163 vs 145 us at 14 400
-  // trajectories, 84 vs 99 us at 7 200).
-  static const int n_cu = [] {
-    int dev = 0, v = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-      v = 256;
-    return v;
-  }();
-  if ((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB > n_cu) return VIHDS_E_UNSUPPORTED;
-  if (ts && dr_lane_theta_stage_floats(nb_max, ts->P, ts->E, a.D, a.B) > (size_t)a.T * 256)
-    return VIHDS_E_UNSUPPORTED;  // stage scratch must fit
-  const dim3 grid((a.n + DrLanes<VERSION>::TPB - 1) / DrLanes<VERSION>::TPB), block(256);
-#define VIHDS_TCASE(SV)                                                                                         \
-  case SV: {                                                                                                    \
-    auto kern = dr_lane_train_kernel<VERSION, SV>;                                                              \
-    auto kern_t = dr_lane_train_theta_kernel<VERSION, SV>;                                                      \
-    static size_t allowed = 64 * 1024, allowed_t = 64 * 1024; /* dynamic LDS opted in to so far, per kernel */  \
-    size_t& have = ts ? allowed_t : allowed;                                                                    \
-    if (lds > have) {                                                                                           \
-      const void* f = ts ? reinterpret_cast<const void*>(kern_t) : reinterpret_cast<const void*>(kern);         \
-      if (hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)DR_LANE_TRAIN_MAX_LDS) !=     \
-          hipSuccess)                                                                                           \
-        return VIHDS_E_HIP;                                                                                     \
-      have = DR_LANE_TRAIN_MAX_LDS;                                                                             \
-    }                                                                                                           \
-    if (ts) hipLaunchKernelGGL(kern_t, grid, block, lds, st, a, nb_max, *ts);                                   \
-    else hipLaunchKernelGGL(kern, grid, block, lds, st, a, nb_max);                                             \
-    return VIHDS_OK;                                                                                            \
-  }
-  switch (solver) {
-    VIHDS_TCASE(VIHDS_SOLVER_MODEULER)
-    VIHDS_TCASE(VIHDS_SOLVER_MODEULERWHILE)
-    VIHDS_TCASE(VIHDS_SOLVER_EULER)
-    VIHDS_TCASE(VIHDS_SOLVER_MIDPOINT)
-    VIHDS_TCASE(VIHDS_SOLVER_RK4)
-  }
-#undef VIHDS_TCASE
-  return VIHDS_E_BADARG;
 }
 
 // LDS floats the forward kernel stages per block: the time grid + the observation rows of the batch rows one block spans
