@@ -31,6 +31,7 @@ import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 B_ROWS, N_IWAE, N_TIMES, N_STATES, N_PARAMS = 36, 200, 86, 8, 35
+SETUP_SECONDS = float(os.environ.get("VIHDS_BENCH_SETUP_SECONDS", "0.3"))  # untimed graph launches ahead of the W warm-up steps
 MULTI_RANK_WATCHDOG_S = 300  # a multi-rank graph path that has not finished by then gives way to the eager line taken before it
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 
@@ -51,7 +52,7 @@ EXTRA_FILE = "bench_extra.json"  # everything that is not the headline measureme
 _LINE_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "value_long", "steps_long", "final_loss", "rows_per_step", "n_ranks_seen",
               "eager_ms_per_step", "note")
-_CONFIG_KEYS = ("workload", "solver", "launch", "steps_per_graph_launch", "parallelism", "world_size", "dist_backend",
+_CONFIG_KEYS = ("workload", "solver", "launch", "steps_per_graph_launch", "setup_seconds", "parallelism", "world_size", "dist_backend",
                 "collectives_in_graph", "rows_global", "n_iwae_global")
 _ROOFLINE_KEYS = ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "traffic_source",
                   "algorithmic_bytes_per_launch", "algorithmic_flops_per_launch", "mean_us", "launches_timed")
@@ -1103,11 +1104,17 @@ def main():
                 training.graph_step(batch, repeat=G)  # (same for the G-step graph: G untimed steps)
                 for k in sorted({a.warmup % G, a.steps % G}):  # (and for the graphs that hold the remainders)
                     if k > 1:
-                        # (twice: the launch after the capture's own is still a first one for the runtime -- a 20-step
-                        # window, the driver's, measured 1.5 % shorter with the graph launched once more here; setup, like
-                        # the capture itself: not among the W warm-up or the K timed steps)
-                        for _ in range(int(os.environ.get("VIHDS_BENCH_SETUP_LAUNCHES", "2"))):
-                            training.graph_step(batch, repeat=k)
+                        # (setup, like the capture itself -- not among the W warm-up or the K timed steps: the graph that holds the
+                        # remainder is launched until the device has been busy for SETUP_SECONDS.  A launch after an idle stretch
+                        # runs below the steady rate: the driver's 20-step window measured 13.5-14.1k steps/s behind two such
+                        # launches, 14.4-14.6k behind 32 (gpurun_out/r06d), 14.9k in a long run.  Reported as config.setup_seconds)
+                        t_setup = time.perf_counter()
+                        while True:
+                            for _ in range(8):
+                                training.graph_step(batch, repeat=k)
+                            torch.cuda.synchronize()
+                            if time.perf_counter() - t_setup >= SETUP_SECONDS:
+                                break
         except Exception as exc:  # noqa: BLE001 -- (reported in the line; the run goes on with eager launches)
             if not multi:
                 raise
@@ -1295,6 +1302,7 @@ def main():
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
                    "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "steps_per_graph_launch": G, "learning_rate": a.lr,
+                   "setup_seconds": SETUP_SECONDS if use_graph else 0.0,
                    "world_size": torch.distributed.get_world_size() if multi else 1, "rank_devices": rank_devices,
                    "dist_backend": torch.distributed.get_backend() if multi else None,
                    "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None,

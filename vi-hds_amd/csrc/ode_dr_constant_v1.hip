@@ -24,6 +24,7 @@ int launch_dr_constant_v1(bool backward, int solver, const OdeArgs& a, hipStream
 // fused log-likelihood + unit-weight adjoint: the time-parallel kernel (vihds_dr_scan.hpp; any batch size, time grids up to
 // 129 points).  VIHDS_E_UNSUPPORTED beyond that: the caller takes vihds_ode_fwd + vihds_ode_bwd.
 int launch_dr_constant_train_v1(int solver, const OdeArgs& a, hipStream_t st, const ThetaStageArgs* ts) {
+  if ((a.kernel_variant & 0xff) == 1) return VIHDS_E_UNSUPPORTED;  // (one thread per trajectory asked for: no fused form)
   return launch_dr_scan_train<1>(solver, a, st, ts);
 }
 int n_slots_dr_constant_v1() { return DrConstant<1>::NSLOT; }
