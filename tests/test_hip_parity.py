@@ -1609,9 +1609,9 @@ def test_time_parallel_training_kernel_at_the_config3_sizes(B, S):
 ADAPTIVE = ["dopri5", "bosh3", "adaptive_heun", "dopri8"]  # ("dopri8": the DOP853 coefficients, vihds_dop853_tableau.hpp)
 
 
-@pytest.mark.parametrize("solver", ADAPTIVE)
-@pytest.mark.parametrize("name", ["dr_constant_icml_tiny_modeuler", "auto_constant_tiny_modeuler",
-                                  "dr_constant_precisions_tiny_modeuler"])
+@pytest.mark.parametrize("name,solver", [("dr_constant_icml_tiny_modeuler", sv) for sv in ADAPTIVE] +
+                         [("auto_constant_tiny_modeuler", "dopri5"), ("dr_constant_precisions_tiny_modeuler", "dopri5"),
+                          ("dr_constant_precisions_tiny_modeuler", "bosh3")])
 def test_adaptive_pair_on_a_given_grid_matches_oracle_forward_and_gradient(name, solver):
     """The fixed-grid kernels with an adaptive pair's higher-order tableau (what runs on the accepted grid) against the
     oracle's generic explicit-RK restatement on the SAME non-uniform grid: trajectories, x_predict, log-likelihood and
@@ -1778,7 +1778,7 @@ def test_adaptive_solver_on_the_blackbox_and_hidden_precision_models():
     assert torch.isfinite(th2.grad).all() and torch.isfinite(w2.grad).all()
 
 
-@pytest.mark.parametrize("solver", ["euler", "midpoint", "rk4", "dopri5"])
+@pytest.mark.parametrize("solver", ["midpoint", "rk4", "dopri5"])
 def test_sized_blackbox_every_solver_against_the_restatement(solver):
     """dr_blackbox at network sizes other than the ICML spec's (side library libvihds_bb_3_12_6_8.so; the reference
     fixture pins modeuler in test_blackbox_forward_and_gradients_match_reference): the other schemes against the CPU
@@ -1843,8 +1843,7 @@ def test_sized_blackbox_every_solver_against_the_restatement(solver):
     assert rel_err(theta.grad[live.to(DEV)], th_ref[live], dim=0) < GTOL
 
 
-@pytest.mark.parametrize("variant", [0, 1])
-@pytest.mark.parametrize("solver", ["rk4", "euler", "midpoint", "modeuler"])
+@pytest.mark.parametrize("solver,variant", [("rk4", 0), ("euler", 0), ("midpoint", 0), ("modeuler", 0), ("midpoint", 1)])
 def test_wide_blackbox_default_hidden_size_against_the_restatement(solver, variant):
     """dr_blackbox with the reference's DEFAULT n_hidden_decoder = 50 (vihds/config.py:71 -- what a YAML that omits the
     key gets): libvihds_bb_2_50_20_12.so on the ICML fixture's inputs with seeded random weights, forward and every
@@ -2283,9 +2282,10 @@ def test_adaptive_device_solver_is_the_dependencys_algorithm(solver):
     assert e_sol < 1e-4 and e_grad < 1e-4
 
 
-@pytest.mark.parametrize("name", ["dr_constant_precisions_tiny_modeuler", "auto_constant_precisions_tiny_modeuler",
-                                  "relay_constant_precisions_tiny_modeuler"])
-@pytest.mark.parametrize("solver", ["dopri5", "bosh3"])
+@pytest.mark.parametrize("name,solver", [("dr_constant_precisions_tiny_modeuler", "dopri5"),
+                                         ("auto_constant_precisions_tiny_modeuler", "dopri5"),
+                                         ("relay_constant_precisions_tiny_modeuler", "dopri5"),
+                                         ("relay_constant_precisions_tiny_modeuler", "bosh3")])
 def test_adaptive_device_solver_with_neural_precisions(name, solver):
     """Round 5: the dependency's adaptive algorithm on the device for the white-box models WITH neural
     precisions (*_precisions, no hidden layer: vihds_ode_adaptive_fwd_w / _bwd_w) -- they used to take the clipped-grid,

@@ -401,7 +401,11 @@ class OdeModel(nn.Module):
         launches below the evaluation size, which run other kernel families): then use solve."""
         import vihds.hip as hip
 
-        if (not default_get_value(config.params, "online_summaries", True) or not default_get_value(config.params, "lazy_x_predict", True)
+        # (opt-in per call: Training.evaluate sets `_evaluating` around its passes.  Any other forward under no_grad -- plots, xval
+        # scripts, plugin code that reads x_states / x_predict -- keeps the stored trajectory: for it the lazy solution's full
+        # solve would be a THIRD integration; ADVICE r05)
+        if (not getattr(self, "_evaluating", False)
+                or not default_get_value(config.params, "online_summaries", True) or not default_get_value(config.params, "lazy_x_predict", True)
                 or config.params.solver in hip.ADAPTIVE_SOLVERS or getattr(theta, "_row_offset", None)
                 or getattr(self, "_no_online_summaries", False)):  # (Training: samples sharded over ranks)
             return None

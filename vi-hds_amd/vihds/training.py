@@ -239,6 +239,7 @@ class Training:
         self.fused_tail = bool(default_get_value(p, "fused_step_tail", True)) and on_gpu
         self._tail, self._tail_ok, self._tail_shapes = None, False, {}
         self._gtail, self._gtail_ok = None, None  # ops.GeneralTail (any model); None: not decided yet
+        self._gtail_declined = set()  # (batch shape, n_iwae) pairs GeneralTail.launch has declined
         if on_gpu:
             self.optimizer.gate = None
         self._graphs = {}
@@ -337,7 +338,15 @@ class Training:
         Results copies to the host into one buffer -- is captured once per (data set, sample count) and replayed: the pass
         is some 25 launches whose host-side cost was a third of its time.  The draws come from the device generators, which
         advance inside the kernels, so every replay is a fresh evaluation, as in the eager pass."""
-        self.model.decoder.ode_model._no_online_summaries = self.shard is not None
+        ode_model = self.model.decoder.ode_model
+        ode_model._no_online_summaries = self.shard is not None
+        ode_model._evaluating = True  # (the summaries-on-the-way form of the pass is this method's: OdeModel._solve_for_evaluation)
+        try:
+            return self._evaluate(data, n_samples, writer, epoch)
+        finally:
+            ode_model._evaluating = False
+
+    def _evaluate(self, data, n_samples, writer, epoch):
         dev_ok = (self.eval_graph and self.use_graph and writer is None and self.shard is None and self.replica is None)
         if not dev_ok:
             with torch.no_grad():
@@ -385,9 +394,14 @@ class Training:
         return out
 
     def _evaluation_device_side(self, data, n_samples):
-        with torch.no_grad():
-            results, theta, q, p = self.model(data, n_samples)
-            elbo, summ = self.cost(data, results, theta, q, p, full_output="device")
+        ode_model = self.model.decoder.ode_model
+        was, ode_model._evaluating = getattr(ode_model, "_evaluating", False), True
+        try:
+            with torch.no_grad():
+                results, theta, q, p = self.model(data, n_samples)
+                elbo, summ = self.cost(data, results, theta, q, p, full_output="device")
+        finally:
+            ode_model._evaluating = was
         q_tensors = [t.detach() for t in q.get_tensors()]
         parts = q_tensors + [elbo.detach().reshape(1)] + [x.detach() for x in summ]
         flat = torch.cat([t.reshape(-1).float() for t in parts])  # ONE device->host transfer per pass
@@ -462,15 +476,22 @@ class Training:
         Returns the loss tensor (-ELBO) without synchronising."""
         ode = self.model.decoder.ode_model
         # (a step whose backward is ops.GeneralTail reads neither trajectory views nor x_predict: the forward skips the latter)
-        ode._train_without_x_predict = bool(self._gtail_ok)
+        # (a batch shape the tail has declined once -- LDS budget, offset layer, row layout -- keeps the ordinary forward: the fused
+        # one would integrate twice and spend a vihds_rng_advance launch per step for nothing; ADVICE r05)
+        obs = getattr(batch, "observations", None)
+        shape_key = (tuple(obs.shape) if obs is not None else None, int(self.args.train_samples))
+        gtail_on = bool(self._gtail_ok) and shape_key not in self._gtail_declined
+        ode._train_without_x_predict = gtail_on
         # (... and the sampling stage can run inside the forward launch: params.fused_theta_ode, vihds_theta_ode_fwd)
-        self.model._fuse_theta_ode = bool(self._gtail_ok) and bool(default_get_value(self.settings.params, "fused_theta_ode", True))
+        self.model._fuse_theta_ode = gtail_on and bool(default_get_value(self.settings.params, "fused_theta_ode", True))
         try:
             batch_results, theta, q, p = self.model(batch, self.args.train_samples)
         finally:
             ode._train_without_x_predict = False
             self.model._fuse_theta_ode = False
         loss = self._general_tail(batch_results, theta, q, p)
+        if loss is None and gtail_on:
+            self._gtail_declined.add(shape_key)
         if loss is not None:
             # params.fused_step_tail, any model: IWAE loss, ODE adjoint, weight gradients, theta / encoder adjoints and Adam
             # ran as GeneralTail's launches; autograd's backward and optimizer.step() do not run for this step
