@@ -699,17 +699,22 @@ def loop_legs_for_default_line(a):
                 # The spec's learning rate (0.01) on this objective is not stable for every random stream: the reference's own
                 # clip-after-sample log q lets q collapse onto a clipped sample (-ELBO -> -1e19) for some draws -- with the
                 # reference's own keys (numpy stream, modeuler) as with these; tests/probe/runaway_seeds.py, DESIGN.md.  Four
-                # streams are run, every final validation ELBO is reported; `value` is the median throughput.
+                # streams are run and every final validation ELBO is reported.
                 runs = [run_loop_legs(a, plate, leg_names=(name,), epochs=epochs, stream_seed=k)[name] for k in range(4)]
-                runs_sorted = sorted(runs, key=lambda r: r["value"])
-                leg = dict(runs_sorted[len(runs) // 2])
+
+                def ran_away(r):
+                    v = r["final_validation_elbo"]
+                    return v is None or not np.isfinite(v) or abs(v) > 1e6
+
+                # (a stream whose objective ran away measures nothing: `value` is the median throughput of the streams that
+                # stayed finite, the others are counted and listed -- VERDICT r05 weak #10)
+                finite = [r for r in runs if not ran_away(r)]
+                pool = sorted(finite or runs, key=lambda r: r["value"])
+                leg = dict(pool[len(pool) // 2])
                 leg["final_validation_elbo_by_stream"] = [r["final_validation_elbo"] for r in runs]
                 leg["value_by_stream"] = [r["value"] for r in runs]
-                leg["runaway_streams"] = sum(1 for r in runs if r["final_validation_elbo"] is None
-                                             or not np.isfinite(r["final_validation_elbo"]) or abs(r["final_validation_elbo"]) > 1e6)
-                finite = [r for r in runs if r["final_validation_elbo"] is not None and abs(r["final_validation_elbo"]) <= 1e6]
-                if finite:  # (the telemetry and the ELBO quoted at top level come from a run that stayed finite)
-                    leg["final_validation_elbo"], leg["newton_iters"] = finite[0]["final_validation_elbo"], finite[0]["newton_iters"]
+                leg["runaway_streams"] = len(runs) - len(finite)
+                leg["value_is_median_of"] = "%d finite streams" % len(finite) if finite else "all streams (every one ran away)"
             else:
                 leg = run_loop_legs(a, plate, leg_names=(name,), epochs=epochs)[name]
             leg["unit"] = "steps/s"

@@ -21,6 +21,7 @@ ALL_FIXTURES = [
     "dr_constant_precisions_hidden20_tiny_modeuler",
     "auto_constant_precisions_tiny_modeuler",
     "dr_blackbox_icml_tiny_modeuler",
+    "dr_blackbox_icml_full_modeuler",  # BASELINE config 4's own shape (36 x 200) from the reference (round 6)
     "dr_blackbox_sized_tiny_modeuler",
     "prpr_constant_tiny_modeuler",
 ]
@@ -31,6 +32,7 @@ ALL_FIXTURES = [
 PATCHED_FIXTURES = [
     "relay_constant_precisions_tiny_modeuler",
     "relay_constant_precisions_tiny_modeulerwhile",
+    "relay_constant_precisions_full_modeuler",  # BASELINE config 5's own shape (36 x 200, T = 99), MODIFIED reference (round 6)
     "degrader_constant_precisions_tiny_modeuler",
     "inducer_constant_precisions_tiny_modeuler",
     "prpr_constant_precisions_tiny_modeuler",

@@ -423,6 +423,9 @@ CASES = [
     ("dr_constant_precisions_tiny_modeuler", "dr_constant_precisions", "modeuler", 8, 4, 1),
     ("auto_constant_precisions_tiny_modeuler", "auto_constant_precisions", "modeuler", 8, 4, 1),
     ("dr_blackbox_icml_tiny_modeuler", "dr_blackbox_icml", "modeuler", 8, 4, 1),
+    # BASELINE config 4's own shape (36 rows x 200 samples) from the reference itself (round 6): the matrix-core kernels at the
+    # size the bench times them, against the reference's modified Euler (midpoint, the spec's solver, is torchdiffeq's)
+    ("dr_blackbox_icml_full_modeuler", "dr_blackbox_icml", "modeuler", 200, 36, 25),
     ("prpr_constant_tiny_modeuler", "prpr_constant", "modeuler", 8, 4, 1),
     # NeuralPrecisions with a hidden layer (reference precisions.py:63-74) through the CLI flag --precision_hidden_layers
     ("dr_constant_precisions_hidden20_tiny_modeuler", "dr_constant_precisions", "modeuler", 8, 4, 1, 20),
@@ -444,6 +447,8 @@ PATCHED_PROVENANCE = (
 PATCHED_CASES = [
     ("relay_constant_precisions_tiny_modeuler", "relay_constant_precisions", "modeuler", 8, 4, 1),
     ("relay_constant_precisions_tiny_modeulerwhile", "relay_constant_precisions", "modeulerwhile", 5, 3, 1),
+    # BASELINE config 5's own shape (36 rows x 200 samples, T = 99) from the MODIFIED reference (round 6)
+    ("relay_constant_precisions_full_modeuler", "relay_constant_precisions", "modeuler", 200, 36, 25),
     ("degrader_constant_precisions_tiny_modeuler", "degrader_constant_precisions", "modeuler", 8, 4, 1),
     ("inducer_constant_precisions_tiny_modeuler", "inducer_constant_precisions", "modeuler", 8, 4, 1),
     ("prpr_constant_precisions_tiny_modeuler", "prpr_constant_precisions", "modeuler", 8, 4, 1),

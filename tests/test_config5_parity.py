@@ -91,9 +91,10 @@ def test_precisions_models_match_the_modified_reference(name, variant):
     out = _hip_run(fx.model, fx.names, theta, fx.t("inputs"), fx.t("times"), fx.t("observations"), fx.solver,
                    _flat(prec_w), fx.t("log_p"), fx.t("log_q"), variant)
     assert out["traj"].shape[2] == n_core + 4
-    assert rel_err(out["traj"][:, :, :n_core], fx.t("x_states")) < TOL
-    assert rel_err(out["traj"][:, :, n_core:], fx.t("precisions")) < TOL
-    assert rel_err(out["xp"], fx.t("x_predict")) < TOL
+    st = int(fx.z["sample_stride"])  # (the full-size fixture -- config 5's own 36 x 200 -- keeps every 25th sample's trajectory)
+    assert rel_err(out["traj"][:, ::st, :n_core], fx.t("x_states")) < TOL
+    assert rel_err(out["traj"][:, ::st, n_core:], fx.t("precisions")) < TOL
+    assert rel_err(out["xp"][:, ::st], fx.t("x_predict")) < TOL
     assert rel_err(out["lpo"], fx.t("log_p_by_species"), dim=2) < TOL
     assert rel_err(out["loss"], fx.t("loss")) < TOL
     # the reference's d loss / d theta_i also holds the log p - log q terms: added analytically (oracle functions), so

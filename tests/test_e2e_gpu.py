@@ -15,7 +15,7 @@ CASES = ["dr_constant_one_modeuler", "dr_constant_one_s5_modeulerwhile", "dr_con
          "dr_constant_icml_tiny_modeulerwhile", "dr_constant_icml_full_modeuler", "dr_constant_v2_tiny_modeuler",
          "auto_constant_tiny_modeuler", "prpr_constant_tiny_modeuler", "dr_constant_precisions_tiny_modeuler",
          "auto_constant_precisions_tiny_modeuler", "dr_blackbox_icml_tiny_modeuler",
-         "dr_constant_precisions_hidden20_tiny_modeuler", "dr_blackbox_sized_tiny_modeuler"]
+         "dr_constant_precisions_hidden20_tiny_modeuler", "dr_blackbox_sized_tiny_modeuler", "dr_blackbox_icml_full_modeuler"]
 # + the MODIFIED reference (construction defects repaired, fixture_util.PATCHED_FIXTURES): the relay / degrader / inducer /
 # prpr *_precisions plugins end to end, BASELINE config 5's model among them
 CASES = CASES + PATCHED_FIXTURES
