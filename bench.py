@@ -1113,12 +1113,14 @@ def main():
                         # remainder is launched until the device has been busy for SETUP_SECONDS.  A launch after an idle stretch
                         # runs below the steady rate: the driver's 20-step window measured 13.5-14.1k steps/s behind two such
                         # launches, 14.4-14.6k behind 32 (gpurun_out/r06d), 14.9k in a long run.  Reported as config.setup_seconds)
+                        # (several ranks: a FIXED number of launches -- every launch holds collectives, and ranks that looked at
+                        # their own clocks would disagree about how many there are)
                         t_setup = time.perf_counter()
-                        while True:
+                        for _round in range(4 if multi else 1 << 30):
                             for _ in range(8):
                                 training.graph_step(batch, repeat=k)
                             torch.cuda.synchronize()
-                            if time.perf_counter() - t_setup >= SETUP_SECONDS:
+                            if not multi and time.perf_counter() - t_setup >= SETUP_SECONDS:
                                 break
         except Exception as exc:  # noqa: BLE001 -- (reported in the line; the run goes on with eager launches)
             if not multi:
@@ -1307,7 +1309,7 @@ def main():
                    "solver": a.solver, "n_iwae_per_gpu": N_IWAE, "n_iwae_global": n_iwae_model,
                    "rows_global": B_ROWS * (world if replica is not None else 1),
                    "launch": launch_mode, "steps_per_graph_launch": G, "learning_rate": a.lr,
-                   "setup_seconds": SETUP_SECONDS if use_graph else 0.0,
+                   "setup_seconds": (SETUP_SECONDS if not multi else "32 launches per remainder graph") if use_graph else 0.0,
                    "world_size": torch.distributed.get_world_size() if multi else 1, "rank_devices": rank_devices,
                    "dist_backend": torch.distributed.get_backend() if multi else None,
                    "collectives_in_graph": bool(getattr(training, "collectives_captured", False)) if multi else None,
