@@ -967,7 +967,7 @@ def main():
     ap.add_argument("--lr", type=float, default=0.001,
                     help="Adam learning rate.  The reference spec's 0.01 makes the objective run away on the synthetic "
                          "plate within a few hundred steps on some seeds (q collapses onto a clipped sample: -ELBO "
-                         "-> -1e20 / nan, DESIGN.md measurement log); the arithmetic per step does not depend on it.  On the "
+                         "-> -1e20 / nan, DESIGN.md section 2, profiles/LOG.md); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
     ap.add_argument("--no-loop-legs", dest="loop_legs", action="store_false",
                     help="N = 1: skip the `run_loop` / `real_plate` legs (Training.run() end to end) of the default line")

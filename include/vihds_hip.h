@@ -86,7 +86,7 @@ typedef struct vihds_ode_problem {
   int C, D;     /* #conditions (cond row length), device_depth (dev1hot row length) */
   int n_rows;   /* rows of the theta / g_theta buffers */
   int slot_row[VIHDS_MAX_SLOTS]; /* kernel slot -> theta row; must be set for every slot of the model */
-  /* sizes of the neural blocks (0 when the model has none); weights buffer layout in DESIGN.md */
+  /* sizes of the neural blocks (0 when the model has none); weights buffer layout: hidden W, b; production W, b; degradation W, b (row-major), states network first */
   int n_hidden_prec;   /* params.n_hidden_decoder_precisions (vihds/precisions.py:55) */
   int n_hidden_states; /* params.n_hidden_decoder (dr_blackbox only) */
   int n_latent_states; /* params.n_latent_species (dr_blackbox only) */
@@ -127,7 +127,7 @@ int vihds_ode_fwd(const vihds_ode_problem* p, const float* theta, const float* c
  *   - dr_blackbox: the contraction over (trajectory x RHS evaluation) is left to the caller as batched GEMMs:
  *     the kernel fills `aux` (vihds_ode_bwd_aux_floats floats) with the field-major dump
  *     [F = vihds_blackbox_dump_fields()][E evaluations][B*S] (layer inputs and pre-activation gradients; field
- *     order in DESIGN.md 4.4) followed by Delta [HS+HP][B*S] and the output-bias adjoint sums [2*NX+8][B*S];
+ *     order in profiles/LOG.md, appendix section 4.4) followed by Delta [HS+HP][B*S] and the output-bias adjoint sums [2*NX+8][B*S];
  *     g_weights is not touched.
  *   - white-box models with neural precisions, aux != NULL (optional, vihds_ode_bwd_aux_floats floats): the same
  *     scheme -- aux receives [8 + NIN][E][B*S] (fields 0..3 production and 4..7 degradation pre-activation adjoints,

@@ -2204,7 +2204,7 @@ def test_adaptive_product_vs_the_dependencys_algorithm(solver):
     step's quartic interpolant there.  Against `oracle.odeint_adaptive` -- the restatement of the DEPENDENCY's algorithm,
     not of the kernels -- on a reference fixture's theta: trajectories at the output times and the gradient of a
     log-likelihood-like scalar w.r.t. every theta row.  Both are solutions of the same ODE to the same tolerance, so they
-    must agree to a small multiple of it; the measured figures are printed (and recorded in DESIGN.md section 4.6)."""
+    must agree to a small multiple of it; the measured figures are printed (and recorded in profiles/LOG.md, appendix section 4.6)."""
     from vihds import ops
     import hip_util as H
 

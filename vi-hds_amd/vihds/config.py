@@ -21,7 +21,7 @@ PARAM_DEFAULTS = {
     "precision_beta": 1.0, "init_prec": 0.00001, "init_latent_species": 0.001, "transfer_func": "tanh",
     "n_hidden_decoder_precisions": 20, "n_growth_layers": 4, "tb_gradients": False, "plot_histograms": False,
     "learning_boundaries": [250, 500], "learning_rate": 0.01, "learning_gamma": 0.2,
-    # additions of this implementation (documented in DESIGN.md); every one defaults to reference behaviour
+    # additions of this implementation (documented in INTEGRATION.md section 6); every one defaults to reference behaviour
     "u_rng": "numpy",          # "numpy": host RNG as vae.py:22-24 | "device": torch Philox on the GPU |
                                # "kernel": drawn inside the theta kernel (vihds_theta_opts.rng)
     "conditioner_rng": "cpu",  # where DeviceConditioner's per-call random weights are drawn (ode.py:48):

@@ -395,7 +395,7 @@ class OdeModel(nn.Module):
         them up on the way (ops.ode_fwd_summaries) -- the trajectory (644 MB at 234 rows x 1 000 samples) is neither
         allocated, written nor read back: 1.33 GB -> 0.12 GB of HBM traffic for the two launches, at the same time per pass
         (0.68 ms either way: the integration is VALU-bound, the second one costs what streaming the trajectory back did;
-        DESIGN section 4.3).  `online_summaries: false` keeps the stored form.
+        DESIGN.md section 1; profiles/LOG.md, round 5).  `online_summaries: false` keeps the stored form.
         Returns a LazySolution carrying `online_summaries(log_w, lse)`; trajectory and x_predict are computed (the ordinary
         forward launch) only if somebody asks.  None where the path does not apply (dr_blackbox, the adaptive solvers,
         launches below the evaluation size, which run other kernel families): then use solve."""

@@ -60,7 +60,7 @@ def _shuffled_index_batches(n, batch_size):
     default generator in the same order (the loader iterator's base seed, torch/utils/data/dataloader.py
     _BaseDataLoaderIter.__init__; RandomSampler's seed for its own generator, sampler.py RandomSampler.__iter__), the same
     permutation, cut into consecutive batches.  (The loader's per-batch machinery -- a profiler scope, the fetcher, the
-    collate call -- cost 0.24 ms per epoch of seven batches, half of the epoch's GPU time: tests/probe/run_loop_cprofile.py.)
+    collate call -- cost 0.24 ms per epoch of seven batches, half of the epoch's GPU time: measured with cProfile in round 5, profiles/LOG.md.)
     Training checks it against the loader itself once (_index_batches_match_loader) and keeps the loader if a torch
     version draws differently."""
     torch.empty((), dtype=torch.int64).random_()
