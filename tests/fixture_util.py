@@ -29,6 +29,10 @@ ALL_FIXTURES = [
 # Produced by `make_fixtures.py --patched`: the reference with its two CONSTRUCTION defects repaired in memory
 # (OdeFunc.__init__'s arity, the non-existent init_with_params) -- "MODIFIED REFERENCE" in their provenance.
 # The equations are the reference's own forward(); the only relay / degrader / inducer specs it ships are these.
+# BASELINE config 3's training shape (36 rows x 1 000 samples) from the reference, LIGHT: u by seed, no theta arrays (see
+# make_fixtures.py); used by dedicated tests, not by the parametrised fixture lists
+LIGHT_FIXTURE_S1000 = "dr_constant_icml_s1000_light_modeuler"
+
 PATCHED_FIXTURES = [
     "relay_constant_precisions_tiny_modeuler",
     "relay_constant_precisions_tiny_modeulerwhile",
@@ -51,15 +55,23 @@ class Fixture:
         self.kinds = [int(k) for k in self.z["kind"]]
 
     def t(self, key, device="cpu", dtype=torch.float32):
+        if key == "u" and "u" not in self.z.files:
+            # LIGHT fixtures (make_fixtures.py, CASES): u is numpy's legacy normal stream from the recorded seed -- the
+            # reference's own draw, vae.py:22-24 -- checked against the recorded u when the fixture was made
+            state = np.random.get_state()
+            np.random.seed(int(self.z["u_seed"]))
+            u = np.random.randn(*[int(v) for v in self.z["u_shape"]]).astype(np.float32)
+            np.random.set_state(state)
+            return torch.tensor(u, dtype=dtype, device=device)
         return torch.tensor(np.asarray(self.z[key]), dtype=dtype, device=device)
 
     @property
     def B(self):
-        return self.z["theta"].shape[1]
+        return int(self.z["u_shape"][0]) if "theta" not in self.z.files else self.z["theta"].shape[1]
 
     @property
     def S(self):
-        return self.z["theta"].shape[2]
+        return int(self.z["u_shape"][1]) if "theta" not in self.z.files else self.z["theta"].shape[2]
 
     def theta_dict(self, requires_grad=False, device="cpu"):
         """Clipped theta as the decoder saw it (+ aR/aS from condition_theta), as leaf tensors."""

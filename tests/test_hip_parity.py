@@ -164,6 +164,52 @@ def test_full_chain_q_gradients_match_reference(name):
     assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL
 
 
+def test_config3_training_shape_against_the_reference():
+    """BASELINE config 3's training shape, 36 rows x 1 000 importance samples, against the reference's own run at that shape
+    (tests/golden/dr_constant_icml_s1000_light_modeuler.npz; u regenerated from the recorded seed): (q_mu, q_log_prec, u) ->
+    theta kernel -> ODE kernels -> IWAE kernel -> loss and back to q -- once through vihds_ode_fwd + vihds_ode_bwd (the trajectory
+    compared on every 125th sample) and once through the time-parallel training kernel that config 3 actually runs
+    (vihds_ode_logp_grad: one launch of 4 500 blocks, no trajectory)."""
+    from fixture_util import LIGHT_FIXTURE_S1000
+    from vihds import ops
+    import hip_util as H
+
+    fx = Fixture(LIGHT_FIXTURE_S1000)
+    assert (fx.B, fx.S) == (36, 1000)
+    kind, q_mu0, q_prec0, p_mu, p_prec, lo, hi = H.theta_inputs(fx, DEV)
+    P = len(fx.names)
+    n_rows = P + len(fx.extra_names)
+    row_of = {n: i for i, n in enumerate(fx.names + fx.extra_names)}
+    glob = fx.t("q_is_global").bool()
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    u = fx.t("u", DEV)
+    st = int(fx.z["sample_stride"])
+    for fused in (False, True):
+        q_mu = q_mu0.clone().requires_grad_(True)
+        q_lp = q_prec0.log().clone().requires_grad_(True)
+        theta, log_q, log_p = ops.ThetaSampleLogProb.apply(q_mu, q_lp.exp(), kind, p_mu, p_prec, lo, hi, u, n_rows)
+        theta = torch.cat([theta[:P], fx.t("extra_theta", DEV)], 0)
+        assert rel_err(log_q.cpu(), fx.t("log_q")) < TOL and rel_err(log_p.cpu(), fx.t("log_p")) < TOL
+        if fused:
+            spec = H.spec_for(fx, row_of, n_rows, None, 3)
+            logp = ops.OdeLogLikFused.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV), fx.t("observations", DEV), None)
+        else:
+            spec = H.spec_for(fx, row_of, n_rows)
+            traj, xpred, logp = ops.OdeSolveObserve.apply(spec, theta, fx.t("inputs", DEV), fx.t("times", DEV),
+                                                          fx.t("observations", DEV), None, None)
+            assert rel_err(H.view_bsnt(traj)[:, ::st], fx.t("x_states")) < TOL
+            assert rel_err(H.view_bsnt(xpred)[:, ::st], fx.t("x_predict")) < TOL
+        assert rel_err(H.view_bs4(logp), fx.t("log_p_by_species"), dim=2) < TOL
+        loss, _, _ = ops.iwae_loss(logp, log_p, log_q)
+        assert rel_err(loss, fx.t("loss")) < TOL
+        loss.backward()
+        gm, gl = q_mu.grad.cpu().clone(), q_lp.grad.cpu().clone()
+        gm[glob] = gm[glob].sum(1, keepdim=True).expand(-1, fx.B)
+        gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, fx.B)
+        assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < GTOL, fused
+        assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < GTOL, fused
+
+
 @pytest.mark.parametrize("variant", [1, 2])
 @pytest.mark.parametrize("name", ["dr_constant_one_modeuler", "dr_constant_one_s5_modeulerwhile",
                                   "dr_constant_icml_tiny_modeuler", "dr_constant_icml_full_modeuler",

@@ -146,6 +146,48 @@ def test_q_parameter_gradients_match_reference(name):
     assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < 2e-4
 
 
+def test_config3_training_shape_against_the_reference():
+    """BASELINE config 3's training shape -- 36 rows x 1 000 importance samples -- recorded from the reference itself
+    (tests/golden/dr_constant_icml_s1000_light_modeuler.npz: the four sample-sized input arrays are left out; u is the
+    reference's own draw regenerated from the recorded seed).  u -> sample / clip -> decode -> cost: log q, log p, the
+    log-likelihoods, every 125th sample's trajectory, the loss and d loss / d (mu, log_prec) of q."""
+    from fixture_util import LIGHT_FIXTURE_S1000
+
+    fx = Fixture(LIGHT_FIXTURE_S1000)
+    assert (fx.B, fx.S) == (36, 1000)
+    qm_leaf = fx.t("q_mu").clone().requires_grad_(True)
+    qlp_leaf = fx.t("q_prec").log().clone().requires_grad_(True)
+    P = len(fx.names)
+    qm = [qm_leaf[i][:, None] for i in range(P)]
+    qp = [qlp_leaf[i][:, None].exp() for i in range(P)]
+    pm, pp = fx.p_params()
+    th = O.sample_clip_theta(fx.names, fx.kinds, qm, qp, pm, pp, fx.t("u"))
+    ex = fx.t("extra_theta")
+    for i, n in enumerate(fx.extra_names):
+        th[n] = ex[i]
+    xs, xp, prec = O.decode(fx.model, th, fx.t("inputs"), fx.t("times"), fx.solver)
+    lpo = O.log_prob_observations(xp, fx.t("observations"), prec)
+    vals = [th[n] for n in fx.names]
+    log_p, log_q = O.chained_log_prob(fx.kinds, pm, pp, vals), O.chained_log_prob(fx.kinds, qm, qp, vals)
+    loss, _ = O.iwae_loss(lpo, log_p, log_q)
+    st = int(fx.z["sample_stride"])
+    assert rel_err(xs.detach()[:, ::st], fx.t("x_states")) < 1e-5
+    assert rel_err(xp.detach()[:, ::st], fx.t("x_predict")) < 1e-5
+    assert rel_err(xs.detach().double().sum(1), fx.t("x_states_sum_over_samples", dtype=torch.float64), dim=1) < 1e-5
+    assert rel_err(lpo.detach(), fx.t("log_p_by_species"), dim=2) < 1e-5
+    assert rel_err(log_q.detach(), fx.t("log_q")) < 1e-5
+    assert rel_err(log_p.detach(), fx.t("log_p")) < 1e-5
+    assert rel_err(loss.detach(), fx.t("loss")) < 1e-5
+    loss.backward()
+    glob = fx.t("q_is_global").bool()
+    gm, gl = qm_leaf.grad.clone(), qlp_leaf.grad.clone()
+    gm[glob] = gm[glob].sum(1, keepdim=True).expand(-1, fx.B)
+    gl[glob] = gl[glob].sum(1, keepdim=True).expand(-1, fx.B)
+    live = torch.tensor([k != O.CONSTANT for k in fx.kinds])
+    assert rel_err(gm[live], fx.t("q_mu_grad")[live], dim=0) < 2e-4
+    assert rel_err(gl[live], fx.t("q_logprec_grad")[live], dim=0) < 2e-4
+
+
 def test_unpinned_solvers_meet_reference_cv_criterion():
     """tests/test_ode_solvers.py:83-89 of the reference: final state across solvers within 5 % CV.
     midpoint/rk4/euler are restated from torchdiffeq==0.1 (absent) -- this is the only reference-anchored
