@@ -940,9 +940,14 @@ def test_evaluation_with_online_summaries_gives_the_two_kernel_results(model_nam
     for k in ("iw_predict_mu", "iw_states", "iw_variance"):
         x, y = np.asarray(getattr(a, k)), np.asarray(getattr(b, k))
         assert x.shape == y.shape and np.abs(x - y).max() <= 2e-5 * np.abs(y).max(), k
+    # iw_predict_std = sqrt(sum_s w (x^2 + 1 / prec) - mu^2) as the reference forms it (utils.py:92-96): where ONE sample holds
+    # nearly all the weight and x^2 >> 1 / prec the difference of the two float32 terms can round below zero and the root is
+    # NaN -- in the reference's expression as in both kernel forms, at the same (row, signal, time) entries up to rounding.
+    # The two forms must agree wherever both are finite, and on (almost) the same set of entries.
     x, y = np.asarray(a.iw_predict_std), np.asarray(b.iw_predict_std)
     ok = np.isfinite(x) & np.isfinite(y)
-    assert ok.mean() > 0.95 and np.abs(x[ok] - y[ok]).max() <= 2e-3 * np.abs(y[ok]).max()
+    assert ok.mean() > 0.95 and (np.isfinite(x) != np.isfinite(y)).mean() < 0.01
+    assert np.abs(x[ok] - y[ok]).max() <= 2e-3 * np.abs(y[ok]).max()
 
 
 def test_run_with_epoch_lookahead_walks_the_same_steps_and_notices_a_nan():
