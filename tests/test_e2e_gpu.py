@@ -980,3 +980,16 @@ def test_run_with_epoch_lookahead_walks_the_same_steps_and_notices_a_nan():
     assert training._steps <= 2 * 3  # (noticed after the second epoch was queued at the latest)
     for k, v in before.items():
         assert torch.equal(dict(model.named_parameters())[k].detach(), v), k
+    # a NaN in ONE row: exactly one batch of every epoch has a non-finite loss.  Documented semantics
+    # (INTEGRATION.md section 7): that batch's step is a no-op on the device, the finite batches of the epoch(s) already queued
+    # still apply their updates (the reference would have stopped before them), and the run ends within two epochs.
+    args, settings, data, parameters, model, training = synthetic.build("dr_constant_icml", 20, 16, device="cuda:0",
+                                                                        epoch_lookahead=True, **kw)
+    args.epochs, args.test_epoch, args.test_samples = 6, 3, 32
+    before = {k: v.detach().clone() for k, v in model.named_parameters()}
+    training.train_data.observations[7, 0, 5] = float("nan")
+    training.run()
+    assert training._steps <= 2 * 3
+    after = {k: v.detach() for k, v in model.named_parameters()}
+    assert all(torch.isfinite(v).all() for v in after.values())  # the NaN step touched nothing
+    assert any(not torch.equal(after[k], before[k]) for k in before)  # ... and the finite steps beside it did train
