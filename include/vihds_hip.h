@@ -97,10 +97,10 @@ typedef struct vihds_ode_problem {
                               (what the IWAE reduction hands back); 0 = [4][B][S] */
   int kernel_variant;      /* 0 = auto; 1 = one thread per trajectory; 2 = lane-split (8 lanes per trajectory,
                               dr_constant family only; auto picks it below 16 384 trajectories); 3 = dr_constant's
-                              time-parallel training kernel (vihds_ode_logp_grad's default where it applies); 4 =
-                              dr_blackbox's single-wavefront MFMA kernels.  (5, the time axis in parallel for relay /
-                              degrader / prpr / auto_constant, was removed in round 6: never faster than the lane
-                              kernels; the value now selects what 0 does) */
+                              time-parallel training kernel (vihds_ode_logp_grad's default where it applies).  (4,
+                              dr_blackbox's single-wavefront MFMA kernels, and 5, the time axis in parallel for relay /
+                              degrader / prpr / auto_constant, were removed in round 6: superseded / never faster;
+                              the values now select what 0 does) */
 } vihds_ode_problem;
 
 int vihds_abi_version(void);
@@ -501,7 +501,8 @@ int vihds_gram_blocks(int n_fields, long long n_columns, int n_rects, const vihd
  * evaluation over tiles transposed through LDS) and leaves 8 KB of partial sums at the head of aux instead of the
  * [117][E][B*S] dump; vihds_blackbox_gram_reduce adds them in wavefront order and scatters them into g_weights (flat
  * weight layout).  The tail (Delta, bias sums) follows at vihds_blackbox_tail_offset_floats(p) floats into aux and is
- * consumed by vihds_blackbox_tail_grads as before.  kernel_variant 4 keeps the dump + vihds_gram_blocks pair. */
+ * consumed by vihds_blackbox_tail_grads as before.  (kernel_variant 1, the adaptive solvers and the *_precisions models keep the dump + vihds_gram_blocks pair; the
+ * one-wavefront MFMA kernels of kernel_variant 4 were removed in round 6: the value now selects what 0 does.) */
 int vihds_blackbox_gram_on_chip(const vihds_ode_problem* p);           /* 1 / 0 */
 long long vihds_blackbox_tail_offset_floats(const vihds_ode_problem* p);
 int vihds_blackbox_gram_reduce(const vihds_ode_problem* p, const float* aux, float* g_weights, void* stream);

@@ -23,16 +23,14 @@ int launch_dr_blackbox_split_fwd(int solver, const OdeArgs& a, hipStream_t st);
 int launch_dr_blackbox(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
   // kernel_variant 1 = VALU, one thread per trajectory (vihds_blackbox.hpp); otherwise the MFMA formulation
   // (vihds_theta_ode_fwd: the sampling stage exists in the cooperating-wavefront forward only)
-  if (g_theta_stage && (backward || a.kernel_variant == 1 || a.kernel_variant == 4 || solver_is_adaptive(solver) || g_adaptive_ctl))
+  if (g_theta_stage && (backward || a.kernel_variant == 1 || solver_is_adaptive(solver) || g_adaptive_ctl))
     return VIHDS_E_UNSUPPORTED;
   if (a.kernel_variant == 1 || solver_is_adaptive(solver) || g_adaptive_ctl) return launch_ode<BB>(backward, solver, a, st);
-  // kernel_variant 4: one wavefront per 16 trajectories, the adjoint dumping every evaluation (vihds_blackbox_mfma.hpp);
   // otherwise the two networks on two wavefronts and the Gram tiles on two more (vihds_blackbox_split.hpp)
-  if (a.kernel_variant == 4) return launch_bb_mfma(backward, solver, a, st);
   if (!backward) {
     const int rc = launch_dr_blackbox_split_fwd(solver, a, st);
-    // (a time grid too long for the cooperating-wavefront forward's staged inputs: the one-wavefront forward, same arithmetic)
-    return (rc == VIHDS_E_UNSUPPORTED && !g_theta_stage) ? launch_bb_mfma(false, solver, a, st) : rc;
+    // (a time grid too long for the cooperating-wavefront forward's staged inputs: the thread-per-trajectory forward)
+    return (rc == VIHDS_E_UNSUPPORTED && !g_theta_stage) ? launch_ode<BB>(false, solver, a, st) : rc;
   }
   return launch_bb_split_dir<BbMfma, true>(solver, a, st);
 }
@@ -41,9 +39,9 @@ int n_states_dr_blackbox() { return BB::N; }
 int n_cond_dr_blackbox() { return BB::NC; }
 const char* slot_name_dr_blackbox(int s) { return BB::slot_name(s); }
 int bb_n_weights(int n_const) { return BB::n_weights(n_const); }
-// kernel_variant 0 (and anything but 1 / 4) with a fixed-grid solver: the matrix-core adjoint with the Gram tiles on chip
+// kernel_variant 0 (anything but 1) with a fixed-grid solver: the matrix-core adjoint with the Gram tiles on chip
 static bool bb_gram_mode(int solver, int kernel_variant) {
-  return kernel_variant != 1 && kernel_variant != 4 && !solver_is_adaptive(solver);
+  return kernel_variant != 1 && !solver_is_adaptive(solver);
 }
 long long bb_aux_floats(int n, int T, int solver, int kernel_variant) {
   return (long long)bb_mfma_head_floats(n, T, solver, bb_gram_mode(solver, kernel_variant)) + (long long)BB::NTAIL * n;

@@ -20,8 +20,8 @@
 // Per RHS evaluation: 20 MFMAs forward (8 first-layer, 12 second-layer); the adjoint adds 24 transposed ones.  The
 // 21 time-invariant inputs are folded into the first layers' accumulator initial values by 24 MFMAs in the prologue.
 // Weight gradients: accumulated on chip as Gram tiles by the cooperating-wavefront kernels (vihds_blackbox_split.hpp,
-// the default); the one-wavefront adjoint below (kernel_variant 4) writes the same per-evaluation dump as the VALU
-// kernels (vihds_blackbox.hpp) for vihds_gram_blocks.
+// the default); the VALU kernels (vihds_blackbox.hpp: kernel_variant 1, the adaptive solvers) write a per-evaluation dump for
+// vihds_gram_blocks instead.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -239,358 +239,16 @@ struct BbMfmaT {
 };
 
 // ---- the ICML sizes (specs/dr_blackbox_icml.yaml:17-31) with the one-wavefront-per-group formulation on top -------------
-struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {
-  struct State {  // one lane's share of a trajectory: state q, latent state 4+q (q < 2), precision q
-    float a, b, v;
-  };
-  struct Act {  // what the adjoint and the dump need from one evaluation
-    f32x4 h[2], g[2];  // post-ReLU hidden tiles (states, precisions): h[m], g[m]
-    float pa, pd, sa, sd, sa2, sd2;  // sigmoids: precision prod/degr, state prod/degr, latent prod/degr
-  };
-  __device__ __forceinline__ static State eval(float t, const State& y, int q, const Weights& W, const f32x4 hc[2][2],
-                                               Act& A) {
-    const float b0 = y.a;
-    const float b1 = q < 2 ? y.b : (q == 2 ? t : 0.f);
-    f32x4 h0 = mfma(W.w1s[0][1], b1, mfma(W.w1s[0][0], b0, hc[0][0]));
-    f32x4 h1 = mfma(W.w1s[1][1], b1, mfma(W.w1s[1][0], b0, hc[0][1]));
-    f32x4 g0 = mfma(W.w1p[0][1], b1, mfma(W.w1p[0][0], b0, hc[1][0]));
-    f32x4 g1 = mfma(W.w1p[1][1], b1, mfma(W.w1p[1][0], b0, hc[1][1]));
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      h0[r] = fmaxf(h0[r], 0.f); h1[r] = fmaxf(h1[r], 0.f);
-      g0[r] = fmaxf(g0[r], 0.f); g1[r] = fmaxf(g1[r], 0.f);
-    }
-    f32x4 z = W.b2s, zp = W.b2p;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) z = mfma(W.w2s[s], step_m(s) ? h1[step_r(s)] : h0[step_r(s)], z);
-#pragma unroll
-    for (int s = 0; s < KP; ++s) zp = mfma(W.w2p[s], step_m(s) ? g1[step_r(s)] : g0[step_r(s)], zp);
-    A.h[0] = h0; A.h[1] = h1; A.g[0] = g0; A.g[1] = g1;
-    A.sa = bb_sigmoid(z[0]); A.sd = bb_sigmoid(z[1]); A.sa2 = bb_sigmoid(z[2]); A.sd2 = bb_sigmoid(z[3]);
-    A.pa = bb_sigmoid(zp[0]); A.pd = bb_sigmoid(zp[1]);
-    State d;
-    d.a = A.sa - A.sd * y.a;
-    d.b = q < 2 ? A.sa2 - A.sd2 * y.b : 0.f;
-    d.v = A.pa - A.pd * y.v;
-    return d;
-  }
-
-  __device__ __forceinline__ static State axpy(const State& y, float h, const State& k) {
-    return {y.a + h * k.a, y.b + h * k.b, y.v + h * k.v};
-  }
-  template <int SOLVER>
-  __device__ __forceinline__ static State step(float t0, float t1, float h0, const State& y, int q, const Weights& W,
-                                               const f32x4 hc[2][2]) {
-    Act A;
-    if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
-      const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
-      const State k1 = eval(t0, y, q, W, hc, A);
-      const State k2 = eval(t1, axpy(y, h, k1), q, W, hc, A);
-      const float hh = 0.5f * h;
-      return {y.a + hh * (k1.a + k2.a), y.b + hh * (k1.b + k2.b), y.v + hh * (k1.v + k2.v)};
-    } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      return axpy(y, t1 - t0, eval(t0, y, q, W, hc, A));
-    } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
-      const float dt = t1 - t0;
-      const State k1 = eval(t0, y, q, W, hc, A);
-      return axpy(y, dt, eval(t0 + dt * 0.5f, axpy(y, dt * 0.5f, k1), q, W, hc, A));
-    } else {
-      const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
-      const State k1 = eval(t0, y, q, W, hc, A);
-      const State k2 = eval(t0 + d3, axpy(y, d3, k1), q, W, hc, A);
-      const State y3 = {y.a + (dt * k2.a - d3 * k1.a), y.b + (dt * k2.b - d3 * k1.b), y.v + (dt * k2.v - d3 * k1.v)};
-      const State k3 = eval(t0 + 2.f * d3, y3, q, W, hc, A);
-      const State y4 = {y.a + dt * (k1.a - k2.a + k3.a), y.b + dt * (k1.b - k2.b + k3.b), y.v + dt * (k1.v - k2.v + k3.v)};
-      const State k4 = eval(t0 + dt, y4, q, W, hc, A);
-      return {y.a + (k1.a + 3.f * k2.a + 3.f * k3.a + k4.a) * d8, y.b + (k1.b + 3.f * k2.b + 3.f * k3.b + k4.b) * d8,
-              y.v + (k1.v + 3.f * k2.v + 3.f * k3.v + k4.v) * d8};
-    }
-  }
-
-  struct Dump {
-    float* base;     // &aux[i]
-    size_t n;        // trajectories
-    size_t fstride;  // floats between fields = E * n (dump layout [F][E][n])
-    int e;
-    float bs[6];     // running sums of dz[0..3], dzp[0..1] (-> output-bias gradients)
-  };
-  // (d eval / d y)^T v, accumulating Delta (hidden pre-activation adjoint sums) and dumping the evaluation's fields
-  __device__ __forceinline__ static State eval_vjp(float t, const State& y, const State& v, int q, bool live,
-                                                   const Weights& W, const WeightsT& WT, const f32x4 hc[2][2],
-                                                   f32x4 delta[2][2], Dump& D, int lane) {
-    Act A;
-    eval(t, y, q, W, hc, A);
-    State yb;
-    yb.a = -v.a * A.sd;
-    yb.b = q < 2 ? -v.b * A.sd2 : 0.f;
-    yb.v = -v.v * A.pd;
-    f32x4 dz, dzp;
-    dz[0] = v.a * A.sa * (1.f - A.sa);
-    dz[1] = -v.a * y.a * A.sd * (1.f - A.sd);
-    dz[2] = q < 2 ? v.b * A.sa2 * (1.f - A.sa2) : 0.f;
-    dz[3] = q < 2 ? -v.b * y.b * A.sd2 * (1.f - A.sd2) : 0.f;
-    dzp[0] = v.v * A.pa * (1.f - A.pa);
-    dzp[1] = -v.v * y.v * A.pd * (1.f - A.pd);
-    f32x4 gs[2], gp[2];
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-      f32x4 acc = zero, accp = zero;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = mfma(WT.w2sT[m][r], dz[r], acc);
-#pragma unroll
-      for (int r = 0; r < 2; ++r) accp = mfma(WT.w2pT[m][r], dzp[r], accp);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        gs[m][r] = A.h[m][r] > 0.f ? acc[r] : 0.f;
-        gp[m][r] = A.g[m][r] > 0.f ? accp[r] : 0.f;
-        delta[0][m][r] += gs[m][r];
-        delta[1][m][r] += gp[m][r];
-      }
-    }
-    f32x4 dy = zero;
-#pragma unroll
-    for (int s = 0; s < KS; ++s) dy = mfma(WT.w1sT[s], gs[step_m(s)][step_r(s)], dy);
-#pragma unroll
-    for (int s = 0; s < KP; ++s) dy = mfma(WT.w1pT[s], gp[step_m(s)][step_r(s)], dy);
-    yb.a += dy[0];
-    if (q < 2) yb.b += dy[1];
-    // ---- dump (same field layout as vihds_blackbox.hpp: the host contraction is shared)
-    D.bs[0] += dz[0]; D.bs[1] += dz[1]; D.bs[2] += dz[2]; D.bs[3] += dz[3]; D.bs[4] += dzp[0]; D.bs[5] += dzp[1];
-    if (live) {
-      float* Dp = D.base + (size_t)D.e * D.n;
-      const size_t n = D.fstride;
-#pragma unroll
-      for (int m = 0; m < 2; ++m)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int us = unit_of(16 * m + 4 * q + r, HS), up = unit_of(16 * m + 4 * q + r, HP);
-          if (us >= 0) { Dp[(size_t)(BB::F_HS + us) * n] = A.h[m][r]; Dp[(size_t)(BB::F_GS + us) * n] = gs[m][r]; }
-          if (up >= 0) { Dp[(size_t)(BB::F_HP + up) * n] = A.g[m][r]; Dp[(size_t)(BB::F_GP + up) * n] = gp[m][r]; }
-        }
-      Dp[(size_t)(BB::F_ZA + q) * n] = dz[0];
-      Dp[(size_t)(BB::F_ZD + q) * n] = dz[1];
-      Dp[(size_t)(BB::F_Y + q) * n] = y.a;
-      Dp[(size_t)(BB::F_ZAP + q) * n] = dzp[0];
-      Dp[(size_t)(BB::F_ZDP + q) * n] = dzp[1];
-      if (q < 2) {
-        Dp[(size_t)(BB::F_ZA + 4 + q) * n] = dz[2];
-        Dp[(size_t)(BB::F_ZD + 4 + q) * n] = dz[3];
-        Dp[(size_t)(BB::F_Y + 4 + q) * n] = y.b;
-      }
-      if (q == 0) Dp[(size_t)BB::F_T * n] = t;
-    }
-    D.e += 1;
-    return yb;
-  }
-
-  template <int SOLVER>
-  __device__ __forceinline__ static State step_vjp(float t0, float t1, float h0, const State& y, const State& lam_in,
-                                                   int q, bool live, const Weights& W, const WeightsT& WT,
-                                                   const f32x4 hc[2][2], f32x4 delta[2][2], Dump& D, int lane) {
-    Act A;
-    State lam = lam_in;
-    auto add = [](State& x, const State& w, float s) { x.a += s * w.a; x.b += s * w.b; x.v += s * w.v; };
-    auto scaled = [](const State& x, float s) { return State{s * x.a, s * x.b, s * x.v}; };
-    if (SOLVER == VIHDS_SOLVER_MODEULER || SOLVER == VIHDS_SOLVER_MODEULERWHILE) {
-      const float h = (SOLVER == VIHDS_SOLVER_MODEULER) ? h0 : (t1 - t0);
-      const State k1 = eval(t0, y, q, W, hc, A);
-      const State ya = axpy(y, h, k1);
-      State vv = scaled(lam, 0.5f * h);
-      const State w = eval_vjp(t1, ya, vv, q, live, W, WT, hc, delta, D, lane);
-      add(lam, w, 1.f);
-      add(vv, w, h);
-      add(lam, eval_vjp(t0, y, vv, q, live, W, WT, hc, delta, D, lane), 1.f);
-      return lam;
-    } else if (SOLVER == VIHDS_SOLVER_EULER) {
-      add(lam, eval_vjp(t0, y, scaled(lam, t1 - t0), q, live, W, WT, hc, delta, D, lane), 1.f);
-      return lam;
-    } else if (SOLVER == VIHDS_SOLVER_MIDPOINT) {
-      const float dt = t1 - t0;
-      const State k1 = eval(t0, y, q, W, hc, A);
-      const State ym = axpy(y, dt * 0.5f, k1);
-      const State w = eval_vjp(t0 + dt * 0.5f, ym, scaled(lam, dt), q, live, W, WT, hc, delta, D, lane);
-      add(lam, w, 1.f);
-      add(lam, eval_vjp(t0, y, scaled(w, 0.5f * dt), q, live, W, WT, hc, delta, D, lane), 1.f);
-      return lam;
-    } else {
-      const float dt = t1 - t0, d3 = dt * (1.f / 3.f), d8 = dt * 0.125f;
-      const State k1 = eval(t0, y, q, W, hc, A);
-      const State y2 = axpy(y, d3, k1);
-      const State k2 = eval(t0 + d3, y2, q, W, hc, A);
-      const State y3 = {y.a + (dt * k2.a - d3 * k1.a), y.b + (dt * k2.b - d3 * k1.b), y.v + (dt * k2.v - d3 * k1.v)};
-      const State k3 = eval(t0 + 2.f * d3, y3, q, W, hc, A);
-      const State y4 = {y.a + dt * (k1.a - k2.a + k3.a), y.b + dt * (k1.b - k2.b + k3.b), y.v + dt * (k1.v - k2.v + k3.v)};
-      const State k4b = scaled(lam, d8);
-      State k1b = k4b, k2b = scaled(k4b, 3.f), k3b = scaled(k4b, 3.f);
-      State w = eval_vjp(t0 + dt, y4, k4b, q, live, W, WT, hc, delta, D, lane);
-      add(lam, w, 1.f); add(k1b, w, dt); add(k2b, w, -dt); add(k3b, w, dt);
-      w = eval_vjp(t0 + 2.f * d3, y3, k3b, q, live, W, WT, hc, delta, D, lane);
-      add(lam, w, 1.f); add(k1b, w, -d3); add(k2b, w, dt);
-      w = eval_vjp(t0 + d3, y2, k2b, q, live, W, WT, hc, delta, D, lane);
-      add(lam, w, 1.f); add(k1b, w, d3);
-      add(lam, eval_vjp(t0, y, k1b, q, live, W, WT, hc, delta, D, lane), 1.f);
-      return lam;
-    }
-  }
-};
-
-template <int SOLVER>
-__global__ void __launch_bounds__(256) bb_mfma_fwd_kernel(OdeArgs a) {
-  using K = BbMfma;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jj = lane & 15, q = lane >> 4;
-  const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
-  const bool live = i0 < a.n;
-  const int i = live ? i0 : a.n - 1;
-  const int b = i / a.S;
-  K::Weights W;
-  K::gather(a, lane, W);
-  f32x4 hc[2][2];
-  K::hoist(a, lane, i, b, hc);
-  K::State y;
-  y.a = a.theta[(size_t)a.slot_row[K::NLAT + q] * a.n + i];  // init_x, init_rfp, init_yfp, init_cfp
-  y.b = q < 2 ? a.init_latent : 0.f;
-  y.v = a.init_prec;
-  const size_t n = a.n;
-  const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
-  const float h0 = a.times[1] - a.times[0];
-  float lp = 0.f;
-  float tA = a.times[0], tB = a.times[1];
-  float ob_cur = a.logp ? ob[0] : 0.f;
-  for (int k = 0; k < a.T; ++k) {
-    const float tC = (k + 1 < a.T) ? a.times[k + 1] : tB;
-    const float ob_next = (a.logp && k + 1 < a.T) ? ob[k + 1] : 0.f;
-    if (k > 0) {
-      y = K::template step<SOLVER>(tA, tB, h0, y, q, W, hc);
-      tA = tB;
-    }
-    tB = tC;
-    if (a.traj && live) {
-      a.traj[((size_t)k * 10 + q) * n + i] = y.a;
-      if (q < 2) a.traj[((size_t)k * 10 + 4 + q) * n + i] = y.b;
-      a.traj[((size_t)k * 10 + 6 + q) * n + i] = y.v;
-    }
-    const float x0 = __shfl(y.a, jj, 64);  // OD lives in quarter 0 of the column
-    const float xp = q == 0 ? x0 : x0 * y.a;
-    if (a.xpred && live) a.xpred[((size_t)k * 4 + q) * n + i] = xp;
-    const float e = xp - ob_cur;
-    lp += -0.5f * (LOG2PI_F - logf(y.v) + y.v * e * e);
-    ob_cur = ob_next;
-  }
-  if (a.logp && live) a.logp[(size_t)q * n + i] = lp;
-}
+struct BbMfma : BbMfmaT<Blackbox<2, 25, 20, 5, 5, 2>, 2, 25, 20, 12> {};
+// (Round 1-5 also kept the ONE-wavefront-per-group kernels here -- forward, and an adjoint dumping every evaluation for
+// vihds_gram_blocks: `kernel_variant 4`.  The cooperating-wavefront kernels of vihds_blackbox_split.hpp superseded them at every
+// size; removed in round 6.)
 
 // floats of aux ahead of the tail (Delta, bias sums): the per-evaluation dump, or the wavefronts' Gram partial sums
 __host__ __device__ inline size_t bb_mfma_head_floats(int n, int T, int solver, bool gram) {
   using BB = BbMfma::BB;
   if (gram) return BbMfma::gram_floats(n);
   return (size_t)(T - 1) * BB::stages(solver) * BB::NF * n;
-}
-
-template <int SOLVER>
-__global__ void __launch_bounds__(256) bb_mfma_bwd_kernel(OdeArgs a) {
-  using K = BbMfma;
-  using BB = K::BB;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int jj = lane & 15, q = lane >> 4;
-  const int i0 = (blockIdx.x * 4 + wave) * K::TPW + jj;
-  const bool live = i0 < a.n;
-  const int i = live ? i0 : a.n - 1;
-  const int b = i / a.S;
-  K::Weights W;
-  K::WeightsT WT;
-  K::gather(a, lane, W);
-  K::gather_t(a, lane, WT);
-  f32x4 hc[2][2], delta[2][2];
-  K::hoist(a, lane, i, b, hc);
-  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-  delta[0][0] = delta[0][1] = delta[1][0] = delta[1][1] = zero;
-  K::Dump D = {a.aux + i, (size_t)a.n, (size_t)(a.T - 1) * BB::stages(a.solver) * a.n, 0, {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
-  K::State lam = {0.f, 0.f, 0.f};
-  const size_t n = a.n;
-  const float w_iw = a.iw_logp ? iw_wave_weight(a, i, b) : 0.f;
-  const float glp = ode_logp_grad(a, w_iw, i, q);
-  const float* ob = a.obs + ((size_t)b * 4 + q) * a.T;
-  const float h0 = a.times[1] - a.times[0];
-  auto load_state = [&](int k) {
-    K::State s;
-    s.a = a.traj_in[((size_t)k * 10 + q) * n + i];
-    s.b = q < 2 ? a.traj_in[((size_t)k * 10 + 4 + q) * n + i] : 0.f;
-    s.v = a.traj_in[((size_t)k * 10 + 6 + q) * n + i];
-    return s;
-  };
-  K::State ynext = load_state(a.T - 1);
-  float ob_next = ob[a.T - 1];
-  float tHi = a.times[a.T - 1], tLo = tHi;
-  for (int k = a.T - 1; k >= 0; --k) {
-    const K::State y = ynext;
-    const float obk = ob_next, tK = tLo;
-    if (k > 0) {
-      ynext = load_state(k - 1);
-      ob_next = ob[k - 1];
-      tLo = a.times[k - 1];
-    }
-    if (k < a.T - 1) lam = K::template step_vjp<SOLVER>(tK, tHi, h0, y, lam, q, live, W, WT, hc, delta, D, lane);
-    tHi = tK;
-    // injection at time k: signal q = OD (q = 0) or OD * state q; precision q is an ODE state
-    const float x0 = __shfl(y.a, jj, 64);
-    const float xp = q == 0 ? x0 : x0 * y.a;
-    const float e = xp - obk;
-    float xpb = -glp * y.v * e;
-    lam.v += glp * (0.5f / y.v - 0.5f * e * e);
-    if (a.g_xpred) xpb += a.g_xpred[((size_t)k * 4 + q) * n + i];
-    // d xp / d y_q (q >= 1) = OD ; d xp_q / d OD = (q == 0 ? 1 : y_q): summed over the four quarters of the column
-    float to_od = q == 0 ? xpb : xpb * y.a;
-    to_od += __shfl_xor(to_od, 16, 64);
-    to_od += __shfl_xor(to_od, 32, 64);
-    if (q == 0) lam.a += to_od;
-    else lam.a += xpb * x0;
-    if (a.g_traj) {
-      lam.a += a.g_traj[((size_t)k * 10 + q) * n + i];
-      if (q < 2) lam.b += a.g_traj[((size_t)k * 10 + 4 + q) * n + i];
-      lam.v += a.g_traj[((size_t)k * 10 + 6 + q) * n + i];
-    }
-  }
-  // ---- d loss / d latent theta through the hoisted inputs: (Wc^T)[const x slot] . Delta[slot x traj]
-  {
-    const BB::Off o = BB::offsets(a.n_const);
-    const float* w = a.weights;
-    const int ii = lane & 15, kq = lane >> 4;
-    f32x4 gc = zero;  // rows = constants 0..15 (only the 12 latents are theta)
-    _Pragma("unroll") for (int s = 0; s < K::KS; ++s) {
-      const int u = K::unit_of(16 * K::step_m(s) + 4 * kq + K::step_r(s), K::HS);
-      const float av = (u >= 0 && ii < K::NLAT) ? w[o.wh + u * o.nin_s + K::NX + ii] : 0.f;
-      gc = K::mfma(av, delta[0][K::step_m(s)][K::step_r(s)], gc);
-    }
-    _Pragma("unroll") for (int s = 0; s < K::KP; ++s) {
-      const int u = K::unit_of(16 * K::step_m(s) + 4 * kq + K::step_r(s), K::HP);
-      const float av = (u >= 0 && ii < K::NLAT) ? w[o.vh + u * o.nin_p + 1 + K::NX + ii] : 0.f;
-      gc = K::mfma(av, delta[1][K::step_m(s)][K::step_r(s)], gc);
-    }
-    if (live) {
-      _Pragma("unroll") for (int r = 0; r < 4; ++r) {
-        const int c = 4 * q + r;
-        if (c < K::NLAT) a.g_theta[(size_t)a.slot_row[c] * n + i] = gc[r];
-      }
-      a.g_theta[(size_t)a.slot_row[K::NLAT + q] * n + i] = lam.a;  // init_x .. init_cfp
-      // Delta [HS+HP][n] behind the evaluation dump (or behind the Gram partial sums)
-      float* dd = a.aux + bb_mfma_head_floats(a.n, a.T, a.solver, false);
-      _Pragma("unroll") for (int m = 0; m < 2; ++m)
-        _Pragma("unroll") for (int r = 0; r < 4; ++r) {
-          const int us = K::unit_of(16 * m + 4 * q + r, K::HS), up = K::unit_of(16 * m + 4 * q + r, K::HP);
-          if (us >= 0) dd[(size_t)us * n + i] = delta[0][m][r];
-          if (up >= 0) dd[(size_t)(K::HS + up) * n + i] = delta[1][m][r];
-        }
-      // output-bias adjoint sums, VALU-kernel order: prod states (6), degr states (6), prod prec (4), degr prec (4)
-      float* bb = dd + (size_t)BB::NP * n;
-      bb[(size_t)q * n + i] = D.bs[0];
-      bb[(size_t)(K::NX + q) * n + i] = D.bs[1];
-      if (q < 2) { bb[(size_t)(4 + q) * n + i] = D.bs[2]; bb[(size_t)(K::NX + 4 + q) * n + i] = D.bs[3]; }
-      bb[(size_t)(2 * K::NX + q) * n + i] = D.bs[4];
-      bb[(size_t)(2 * K::NX + 4 + q) * n + i] = D.bs[5];
-    }
-  }
 }
 
 // sums the wavefronts' partial tiles in a fixed order (deterministic) and scatters them into the flat weight gradient.
@@ -628,27 +286,6 @@ template <class K>
 inline void launch_bb_gram_reduce(const OdeArgs& a, const float* aux, float* g_weights, hipStream_t st) {
   const int n_waves = K::gram_groups(a.n);
   hipLaunchKernelGGL((bb_gram_reduce_kernel<K>), dim3(K::NG * 4), dim3(1024), 0, st, n_waves, a.n_const, aux, g_weights);
-}
-
-// the one-wavefront-per-group kernels: forward, and the adjoint that dumps every evaluation for vihds_gram_blocks
-// (kernel_variant 4, round 1's weight-gradient path).  The default path is vihds_blackbox_split.hpp.
-template <class KDUMMY = BbMfma>  // (a template so that a side library that only wants BbMfmaT does not compile these kernels)
-inline int launch_bb_mfma(bool backward, int solver, const OdeArgs& a, hipStream_t st) {
-  const dim3 grid((a.n + BbMfma::TPB - 1) / BbMfma::TPB), block(256);
-#define VIHDS_BCASE(SV)                                                                                  \
-  case SV:                                                                                               \
-    if (backward) hipLaunchKernelGGL((bb_mfma_bwd_kernel<SV>), grid, block, 0, st, a);            \
-    else hipLaunchKernelGGL((bb_mfma_fwd_kernel<SV>), grid, block, 0, st, a);                            \
-    return VIHDS_OK;
-  switch (solver) {
-    VIHDS_BCASE(VIHDS_SOLVER_MODEULER)
-    VIHDS_BCASE(VIHDS_SOLVER_MODEULERWHILE)
-    VIHDS_BCASE(VIHDS_SOLVER_EULER)
-    VIHDS_BCASE(VIHDS_SOLVER_MIDPOINT)
-    VIHDS_BCASE(VIHDS_SOLVER_RK4)
-  }
-#undef VIHDS_BCASE
-  return VIHDS_E_BADARG;
 }
 
 }  // namespace vihds
