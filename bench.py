@@ -13,8 +13,9 @@ parameter gradients are averaged with ONE all-reduce per step (global batch 36*N
 --shard samples = every rank holds the same 36 rows and 200 of the 200*N samples per row, the row (max, sum-exp)
 pairs are all-gathered and one all-reduce sums the gradients.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` for the dominant kernel
-(ODE adjoint) and `cpu_baseline` (the oracle's op-by-op CPU restatement of the same step, timed here)."""
+Prints ONE JSON line (< 6 KB: compact_line) on rank 0 with `roofline` for the dominant kernel (the decoder launch) and
+`cpu_baseline` (the oracle's op-by-op CPU restatement of the same step, timed here).  `--all-legs` also runs the other
+BASELINE configurations and the Training.run() / unchanged-spec legs and writes everything to bench_extra.json."""
 import argparse
 import json
 import math
@@ -360,7 +361,7 @@ def time_launch(fn, n):
 
 def run_workload(a, name, min_seconds=None, bounded_cpu=False):
     """Returns the JSON object of one of BASELINE.json's other configurations (None on ranks other than 0).  min_seconds:
-    the timed window is sized from a short trial instead of --steps (the legs of the default line: >= that many seconds
+    the timed window is sized from a short trial instead of --steps (the `--all-legs` legs: >= that many seconds
     each).  bounded_cpu: the cpu_baseline leg runs at 8 threads without the thread probe, two samples.
     One of BASELINE.json's other configurations through the same host path: timed loop (barrier + synchronize on
     both sides, max over ranks), then the step's own ODE launches re-issued back to back between one HIP event pair for
@@ -688,7 +689,7 @@ def run_loop_workload(a):
 
 def loop_legs_for_default_line(a):
     """`run_loop` (synthetic plate, --lr) and `real_plate` (the reference's processed plate at the spec's own learning rate and
-    schedule) for the default line: Training.run() end to end, one graph launch per epoch, with the decoder kernel's Newton
+    schedule) for `--all-legs` (bench_extra.json): Training.run() end to end, one graph launch per epoch, with the decoder kernel's Newton
     telemetry.  A failure is reported in the object, never raised."""
     out = {}
     for key, plate, epochs in (("run_loop", "synthetic", 200), ("real_plate", "real", 300)):
@@ -847,7 +848,7 @@ def distributed_path_leg(a, plain_ms):
 
 def other_config_legs(a, dev):
     """The other single-GPU BASELINE configurations and the unchanged-spec path, each timed for >= --leg-seconds inside the
-    driver's ONE command, nested under `other_configs` of the headline line.  A leg that fails reports its
+    `--all-legs` command, written to bench_extra.json under `other_configs` (never into the driver's line).  A leg that fails reports its
     error; it never takes the headline line with it."""
     legs = {}
     for name in ("config3_train", "config3_eval", "config3_eval_stored", "config4", "config5", "config4_s1000"):
@@ -970,7 +971,7 @@ def main():
                          "-> -1e20 / nan, DESIGN.md section 2, profiles/LOG.md); the arithmetic per step does not depend on it.  On the "
                          "real plate data 0.01 trains for 3 000 steps without incident (tests/probe/real_data_long_run.py)")
     ap.add_argument("--no-loop-legs", dest="loop_legs", action="store_false",
-                    help="N = 1: skip the `run_loop` / `real_plate` legs (Training.run() end to end) of the default line")
+                    help="--all-legs: skip the `run_loop` / `real_plate` legs (Training.run() end to end)")
     a = ap.parse_args()
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         # `python bench.py --gpus N` as typed: start the N ranks ourselves (one process per GPU, rendezvous on 127.0.0.1) and
